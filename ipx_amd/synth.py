@@ -1,0 +1,154 @@
+"""Seeded synthetic LPs, IPM states and planted-LU bases for tests and bench.py.
+
+Shapes follow SURVEY.md section 8(d): every structural column has k distinct
+uniformly drawn rows, values +-U[0.5,4) (the reference's power-of-2 equilibration
+is then a no-op, reference src/presolver.cc:913-924, so solver matrix == input
+matrix), all constraints '<' (slack in [0,inf)), lb=0, ub=inf.  Pure numpy; no
+reference or oracle code is involved.
+"""
+import numpy as np
+
+i64 = np.int64
+f64 = np.float64
+
+
+class CscMatrix:
+    """m x n CSC matrix, int64 indices, sorted row indices within columns."""
+
+    def __init__(self, nrow, ncol, colptr, rowidx, values):
+        self.nrow, self.ncol = int(nrow), int(ncol)
+        self.p = np.ascontiguousarray(colptr, dtype=i64)
+        self.i = np.ascontiguousarray(rowidx, dtype=i64)
+        self.x = np.ascontiguousarray(values, dtype=f64)
+
+    @property
+    def nnz(self):
+        return int(self.p[-1])
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csc_matrix((self.x, self.i, self.p), shape=(self.nrow, self.ncol))
+
+    def with_identity(self):
+        """[A I] as the reference's Model::AI() (src/model.h:61)."""
+        m, n = self.nrow, self.ncol
+        p = np.concatenate([self.p, self.nnz + 1 + np.arange(m, dtype=i64)])
+        i = np.concatenate([self.i, np.arange(m, dtype=i64)])
+        x = np.concatenate([self.x, np.ones(m, dtype=f64)])
+        return CscMatrix(m, n + m, p, i, x)
+
+
+def _distinct_rows(rng, m, n, k):
+    rows = np.sort(rng.integers(0, m, size=(n, k), dtype=i64), axis=1)
+    while True:
+        bad = np.nonzero((rows[:, 1:] == rows[:, :-1]).any(axis=1))[0]
+        if bad.size == 0:
+            return rows
+        rows[bad] = np.sort(rng.integers(0, m, size=(bad.size, k), dtype=i64), axis=1)
+
+
+def synthetic_lp(m, n, k=8, seed=12345, num_dense=0):
+    """Returns the structural matrix A (m x n CSC).  With num_dense > 0 the first
+    num_dense columns hold ~m/2 random rows each (drawn with replacement, then
+    de-duplicated) -- the dense-column stress case C5."""
+    rng = np.random.default_rng(seed)
+    k = min(k, m)
+    rows = _distinct_rows(rng, m, n, k)
+    vals = rng.uniform(0.5, 4.0, size=(n, k)) * rng.choice([-1.0, 1.0], size=(n, k))
+    if num_dense == 0:
+        colptr = np.arange(n + 1, dtype=i64) * k
+        return CscMatrix(m, n, colptr, rows.reshape(-1), vals.reshape(-1))
+    cols_i, cols_x = [], []
+    for j in range(num_dense):
+        r = np.unique(rng.integers(0, m, size=max(m // 2, 1), dtype=i64))
+        cols_i.append(r)
+        cols_x.append(rng.uniform(0.5, 4.0, size=r.size) * rng.choice([-1.0, 1.0], size=r.size))
+    counts = np.concatenate([[c.size for c in cols_i], np.full(n - num_dense, k)]).astype(i64)
+    colptr = np.concatenate([[0], np.cumsum(counts)]).astype(i64)
+    rowidx = np.concatenate(cols_i + [rows[num_dense:].reshape(-1)])
+    values = np.concatenate(cols_x + [vals[num_dense:].reshape(-1)])
+    return CscMatrix(m, n, colptr, rowidx, values)
+
+
+def synthetic_ipm_state(m, n, spread=1.0, seed=12345):
+    """xl, zl = 10^(spread*U[-1,1]) independently, xu=inf, zu=0 (W_j = xl_j/zl_j spans
+    4*spread decades); a, b ~ U[-0.5,0.5).  Returns dict with xl,xu,zl,zu,mu,a,b."""
+    rng = np.random.default_rng(seed + 1)
+    N = n + m
+    xl = 10.0 ** (spread * rng.uniform(-1.0, 1.0, N))
+    zl = 10.0 ** (spread * rng.uniform(-1.0, 1.0, N))
+    xu = np.full(N, np.inf)
+    zu = np.zeros(N)
+    mu = float(np.dot(xl, zl) / N)  # complementarity measure, all N barrier terms
+    a = rng.uniform(-0.5, 0.5, N)
+    b = rng.uniform(-0.5, 0.5, m)
+    return dict(xl=xl, xu=xu, zl=zl, zu=zu, mu=mu, a=a, b=b)
+
+
+def lp_vectors(m, n):
+    """obj=1, lb=0, ub=inf, rhs=1, constr_type='<' (SURVEY 8d)."""
+    return dict(obj=np.ones(n), lb=np.zeros(n), ub=np.full(n, np.inf), rhs=np.ones(m),
+                constr_type="<" * m)
+
+
+def planted_lu_basis(A, offdiag=3, seed=12345, band=None, num_free=0, num_fixed=0):
+    """Plants a basis with known LU factors into [A I] (BASICLU is not available
+    offline).  Generates sparse unit-lower L0 (strictly lower part
+    returned) and upper U0 with `offdiag` off-diagonal entries per column (uniform
+    rows, or confined to a `band`), forms B = (L0+I) U0 and REPLACES the first m
+    structural columns of A by B's columns (scrambled by random row/column
+    permutations) so that variables basis[p] = p are basic.
+
+    Returns dict(A=new structural matrix, L, U (CscMatrix, diagonal of U last in each
+    column), rowperm, colperm, basis, status) with the reference's factor contract
+    B[rowperm,colperm] = (L+I)U (reference src/lu_update.h:43-60).
+    """
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed + 2)
+    m, n = A.nrow, A.ncol
+    assert n >= m
+
+    def strict_tri(lower):
+        cols = np.repeat(np.arange(m, dtype=i64), offdiag)
+        if lower:   # rows > col
+            span = (m - 1 - cols) if band is None else np.minimum(m - 1 - cols, band)
+            rows = cols + 1 + (rng.random(cols.size) * span).astype(i64)
+            ok = span > 0
+        else:       # rows < col
+            span = cols if band is None else np.minimum(cols, band)
+            rows = cols - 1 - (rng.random(cols.size) * span).astype(i64)
+            ok = span > 0
+        rows, cols = rows[ok], cols[ok]
+        vals = rng.uniform(0.1, 0.6, rows.size) * rng.choice([-1.0, 1.0], rows.size)
+        T = sp.coo_matrix((vals, (rows, cols)), shape=(m, m)).tocsc()
+        T.sum_duplicates()
+        T.sort_indices()
+        return T
+
+    L0 = strict_tri(True)
+    Us = strict_tri(False)
+    udiag = rng.uniform(0.5, 2.0, m) * rng.choice([-1.0, 1.0], m)
+    U0 = (Us + sp.diags(udiag)).tocsc()
+    U0.sort_indices()  # diagonal is the largest row index in an upper column -> last
+    Bp = ((L0 + sp.identity(m, format="csc")) @ U0).tocsc()
+    rowperm = rng.permutation(m).astype(i64)
+    colperm = rng.permutation(m).astype(i64)
+    # B[rowperm[i], colperm[k]] = Bp[i, k]
+    Bcoo = Bp.tocoo()
+    B = sp.coo_matrix((Bcoo.data, (rowperm[Bcoo.row], colperm[Bcoo.col])), shape=(m, m)).tocsc()
+    B.sum_duplicates()
+    B.sort_indices()
+    # scale B's columns into the value range of A so that the equilibration stays a no-op
+    rest = A.to_scipy()[:, m:]
+    Anew = sp.hstack([B, rest]).tocsc()
+    Anew.sort_indices()
+    status = np.full(n + m, -1, dtype=i64)          # NONBASIC
+    status[:m] = 0                                   # BASIC
+    basis = np.arange(m, dtype=i64)
+    if num_free:
+        status[rng.choice(m, num_free, replace=False)] = 1     # BASIC_FREE
+    if num_fixed:
+        status[m + rng.choice(n, num_fixed, replace=False)] = -2  # NONBASIC_FIXED
+    mk = lambda M: CscMatrix(M.shape[0], M.shape[1], M.indptr, M.indices, M.data)
+    return dict(A=mk(Anew), L=mk(L0), U=mk(U0), rowperm=rowperm, colperm=colperm,
+                basis=basis, status=status)

@@ -1,0 +1,178 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of the reference's
+ * KKT normal-equations hot path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library; the product (ipx_amd/) never does.
+ *
+ * Conventions: ipxint = int64_t indices, fp64 values, CSC matrices given as
+ * (colptr[ncol+1], rowidx[nnz], values[nnz]).  Every function cites the
+ * reference file:line whose arithmetic (including loop/summation order) it
+ * restates; paths are relative to the reference root.
+ */
+#ifndef IPX_ORACLE_H_
+#define IPX_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int64_t orc_int;
+
+/* error flags, values of include/ipx_status.h:31-47 */
+#define ORC_ERROR_cr_iter_limit 201
+#define ORC_ERROR_cr_matrix_not_posdef 202
+#define ORC_ERROR_cr_precond_not_posdef 203
+#define ORC_ERROR_cr_no_progress 204
+#define ORC_ERROR_cr_inf_or_nan 205
+#define ORC_ERROR_lapack_chol 401
+
+/* variable statuses used by the basis path (src/basis.h BasicStatus) */
+#define ORC_NONBASIC_FIXED -2
+#define ORC_NONBASIC -1
+#define ORC_BASIC 0
+#define ORC_BASIC_FREE 1
+
+/* lhs = F(rhs); *dot = rhs'lhs if dot != NULL (src/linear_operator.h:10-24) */
+typedef void (*orc_apply_fn)(void* ctx, const double* rhs, double* lhs,
+                             double* dot);
+
+/* ---- vector kernels (src/utils.cc:32-45) -------------------------------- */
+double orc_dot(orc_int m, const double* x, const double* y);
+double orc_infnorm(orc_int m, const double* x);
+
+/* ---- index / permutation arithmetic, bit-exact (row a15, a16) ----------- */
+/* src/sparse_matrix.cc:120-151 */
+void orc_transpose(orc_int nrow, orc_int ncol, const orc_int* Ap,
+                   const orc_int* Ai, const double* Ax, orc_int* ATp,
+                   orc_int* ATi, double* ATx);
+/* src/utils.cc:73-80 */
+void orc_inverse_perm(orc_int m, const orc_int* perm, orc_int* invperm);
+/* CopyColumns + PermuteRows + ScaleColumn, src/sparse_matrix.cc:153-166,
+ * src/splitted_normal_matrix.cc:42-55.  perm / scale may be NULL. */
+void orc_copy_permute_scale(orc_int nrow, const orc_int* Ap, const orc_int* Ai,
+                            const double* Ax, orc_int nsel, const orc_int* cols,
+                            const orc_int* perm, const double* scale,
+                            orc_int* Np, orc_int* Ni, double* Nx);
+/* src/model.cc:34-56: returns num_dense_cols, *nz_dense = threshold
+ * (nrow+1 if none).  colptr covers the ncol structural columns. */
+orc_int orc_find_dense_columns(orc_int nrow, orc_int ncol, const orc_int* Ap,
+                               orc_int* nz_dense);
+
+/* ---- NormalMatrix (src/normal_matrix.cc:45-126, one-pass variant) ------- */
+/* Ap/Ai/Ax: first n columns of AI (the slack identity is never read).
+ * W has n+m entries or is NULL (W=1 on structurals, 0 on slacks). */
+void orc_normal_apply(orc_int m, orc_int n, const orc_int* Ap,
+                      const orc_int* Ai, const double* Ax, const double* W,
+                      const double* rhs, double* lhs, double* dot);
+
+/* ---- DiagonalPrecond (src/diagonal_precond.cc) --------------------------- */
+typedef struct orc_diag_precond orc_diag_precond;
+/* Factorize, :17-111.  Columns j<n with Ap[j+1]-Ap[j] >= nz_dense are "dense"
+ * (src/model.h:52-55).  Returns NULL and *errflag = 401 if Cholesky fails. */
+orc_diag_precond* orc_diag_factorize(orc_int m, orc_int n, const orc_int* Ap,
+                                     const orc_int* Ai, const double* Ax,
+                                     const double* W, orc_int nz_dense,
+                                     orc_int precond_dense_cols,
+                                     orc_int* errflag);
+/* _Apply, :121-159 */
+void orc_diag_apply(orc_diag_precond* P, const double* rhs, double* lhs,
+                    double* dot);
+orc_int orc_diag_num_dense(const orc_diag_precond* P);
+/* copies diagonal_[m] and (if num_dense>0) chol_factor_[k*k]; NULL skips */
+void orc_diag_get(const orc_diag_precond* P, double* diagonal, double* chol);
+void orc_diag_free(orc_diag_precond* P);
+/* dense Cholesky used in place of LAPACK dpotrf('L')/dpotrs('L'); column
+ * major, lower triangle (src/lapack.cc:25-52).  Returns LAPACK-style info. */
+orc_int orc_dpotrf_lower(orc_int k, double* a, orc_int lda);
+void orc_dpotrs_lower(orc_int k, const double* a, orc_int lda, double* b);
+
+/* ---- ConjugateResiduals (src/conjugate_residuals.cc) --------------------- */
+/* Preconditioned CR, :90-213.  lhs holds the initial iterate on entry.
+ * resnorm_hist (may be NULL) receives the termination-test residual norm of
+ * every pass through the loop head (at most hist_cap entries).
+ * Returns errflag; *iter = # iterations. */
+orc_int orc_pcr_solve(orc_int m, orc_apply_fn C, void* Cctx, orc_apply_fn P,
+                      void* Pctx, const double* rhs, double tol,
+                      const double* resscale, orc_int maxiter, double* lhs,
+                      orc_int* iter, double* resnorm_hist, orc_int hist_cap);
+/* Plain CR, :14-88 */
+orc_int orc_cr_solve(orc_int m, orc_apply_fn C, void* Cctx, const double* rhs,
+                     double tol, const double* resscale, orc_int maxiter,
+                     double* lhs, orc_int* iter, double* resnorm_hist,
+                     orc_int hist_cap);
+
+/* ---- KKTSolverDiag (src/kkt_solver_diag.cc) ------------------------------- */
+typedef struct orc_kkt_diag orc_kkt_diag;
+/* The matrix arrays must outlive the object (no copy, like the reference). */
+orc_kkt_diag* orc_kkt_diag_new(orc_int m, orc_int n, const orc_int* Ap,
+                               const orc_int* Ai, const double* Ax,
+                               orc_int nz_dense, orc_int precond_dense_cols,
+                               orc_int maxiter);
+/* _Factorize, :18-65.  xl == NULL means Factorize(nullptr): W = 1. */
+orc_int orc_kkt_diag_factorize(orc_kkt_diag* K, const double* xl,
+                               const double* xu, const double* zl,
+                               const double* zu, double mu);
+/* _Solve, :82-118.  Returns errflag. */
+orc_int orc_kkt_diag_solve(orc_kkt_diag* K, const double* a, const double* b,
+                           double tol, double* x, double* y, orc_int* iter,
+                           double* resnorm_hist, orc_int hist_cap);
+void orc_kkt_diag_get(const orc_kkt_diag* K, double* W, double* resscale);
+void orc_kkt_diag_free(orc_kkt_diag* K);
+
+/* ---- sparse triangular solves (src/sparse_matrix.cc:224-311) ------------- */
+orc_int orc_trisolve(orc_int dim, const orc_int* Ap, const orc_int* Ai,
+                     const double* Ax, double* x, char trans, char uplo,
+                     orc_int unitdiag);
+void orc_forward_solve(orc_int dim, const orc_int* Lp, const orc_int* Li,
+                       const double* Lx, const orc_int* Up, const orc_int* Ui,
+                       const double* Ux, double* x);
+void orc_backward_solve(orc_int dim, const orc_int* Lp, const orc_int* Li,
+                        const double* Lx, const orc_int* Up, const orc_int* Ui,
+                        const double* Ux, double* x);
+/* src/sparse_matrix.cc:211-222; D may be NULL */
+void orc_add_normal_product(orc_int nrow, orc_int ncol, const orc_int* Ap,
+                            const orc_int* Ai, const double* Ax,
+                            const double* D, const double* rhs, double* lhs);
+
+/* ---- SplittedNormalMatrix + KKTSolverBasis::_Solve ------------------------ */
+/* The LU factors are INPUTS (BASICLU is not part of the reference tree):
+ * B[rowperm,colperm] = (L+I)*U, L strictly lower without diagonal, U upper with
+ * the diagonal entry last in each column (src/lu_update.h:43-60).
+ * basis[p] = variable at basis position p; status[j] for j<n+m is one of ORC_*.
+ */
+typedef struct orc_split orc_split;
+/* Prepare, src/splitted_normal_matrix.cc:18-66 (copies everything) */
+orc_split* orc_split_prepare(orc_int m, orc_int n, const orc_int* AIp,
+                             const orc_int* AIi, const double* AIx,
+                             const orc_int* Lp, const orc_int* Li,
+                             const double* Lx, const orc_int* Up,
+                             const orc_int* Ui, const double* Ux,
+                             const orc_int* rowperm, const orc_int* colperm,
+                             const orc_int* basis, const orc_int* status,
+                             const double* colscale);
+/* _Apply, :90-117 */
+void orc_split_apply(orc_split* S, const double* rhs, double* lhs, double* dot);
+/* exports of the prepared state for index-parity checks; NULL skips */
+orc_int orc_split_get_sizes(const orc_split* S, orc_int* nnzN, orc_int* ncolN,
+                            orc_int* nfree);
+void orc_split_get(const orc_split* S, orc_int* Np, orc_int* Ni, double* Nx,
+                   double* Ux_scaled, orc_int* rowperm_inv,
+                   orc_int* free_positions);
+/* Basis::SolveDense on the fresh factors (src/basis.cc:168-170 contract,
+ * src/lu_update.h:62-65): trans 'N': B*lhs = rhs; 'T': B'*lhs = rhs. */
+void orc_split_solve_dense(const orc_split* S, const double* rhs, double* lhs,
+                           char trans);
+/* KKTSolverBasis::_Solve, src/kkt_solver_basis.cc:75-194.  AI arrays are the
+ * full m x (n+m) matrix [A I].  Returns errflag. */
+orc_int orc_kkt_basis_solve(orc_split* S, const double* a, const double* b,
+                            double tol, orc_int maxiter, double* x, double* y,
+                            orc_int* iter, double* resnorm_hist,
+                            orc_int hist_cap);
+void orc_split_free(orc_split* S);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPX_ORACLE_H_ */
