@@ -1,0 +1,209 @@
+/* ipx_kkt_hip.h -- C ABI of the MI355X (gfx950) implementation of IPX's
+ * per-IPM-iteration KKT normal-equations solve.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.
+ * Each entry point names the reference interface (file:line under the reference
+ * root) it replaces; ipx_amd/host/ holds KKTSolver / LinearOperator subclasses
+ * written against the reference's own headers that call nothing but this file
+ * (see INTEGRATION.md for the three lines of lp_solver.cc that select them).
+ *
+ * Conventions
+ *  - ipxint = int64_t (include/ipx_config.h:5); values are IEEE fp64.
+ *  - Sparse matrices are CSC triples (colptr[ncol+1], rowidx[nnz], values[nnz])
+ *    exactly as ipx::SparseMatrix stores them (src/sparse_matrix.h:59-65).
+ *  - Vector arguments are host pointers by default (the reference's Vector is a
+ *    std::valarray in host memory).  ipxk_set_pointer_mode(IPXK_POINTER_DEVICE)
+ *    switches all *vector* arguments of the solve/apply calls to device
+ *    pointers (resident inputs, what bench.py times); matrix/factor/permutation
+ *    arguments are always host pointers (they are uploaded once per
+ *    model / per Factorize).
+ *  - Every function returns 0 on success or a negative IPXK_E_* code; the text
+ *    of the last failure is available from ipxk_last_error().  Numerical
+ *    outcomes use the reference's own channel: an `errflag` output holding 0 or
+ *    an IPX_ERROR_* value of include/ipx_status.h:31-47.
+ *  - A context is not thread safe; calls block until results are in the output
+ *    arrays (the reference interface is blocking and single-threaded).
+ */
+#ifndef IPX_KKT_HIP_H_
+#define IPX_KKT_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int64_t ipxint;
+typedef struct ipxk_context ipxk_context;
+
+#define IPXK_OK 0
+#define IPXK_E_HIP (-1)        /* HIP runtime / RCCL failure  -> std::runtime_error */
+#define IPXK_E_ALLOC (-2)      /* device or host allocation   -> std::bad_alloc     */
+#define IPXK_E_ARGUMENT (-3)   /* invalid argument / state    -> std::logic_error   */
+#define IPXK_E_UNSUPPORTED (-4)
+
+#define IPXK_POINTER_HOST 0
+#define IPXK_POINTER_DEVICE 1
+
+/* basis statuses, values of ipx::Basis::BasicStatus (src/basis.h:64) */
+#define IPXK_NONBASIC_FIXED (-2)
+#define IPXK_NONBASIC (-1)
+#define IPXK_BASIC 0
+#define IPXK_BASIC_FREE 1
+
+/* Wall-clock seconds accumulated by the last solve, measured with HIP events on
+ * the context's stream; they feed ipx_info::time_cr1* / time_cr2*
+ * (include/ipx_info.h:66-75, src/kkt_solver_diag.cc:100-105,
+ * src/kkt_solver_basis.cc:151-156). */
+typedef struct ipxk_times {
+    double cr;        /* whole CR loop            -> time_cr1 / time_cr2      */
+    double op;        /* operator C applications  -> time_cr1_AAt / _NNt      */
+    double precond;   /* preconditioner P         -> time_cr1_pre             */
+    double solve_B;   /* forward solves           -> time_cr2_B               */
+    double solve_Bt;  /* backward solves          -> time_cr2_Bt              */
+} ipxk_times;
+
+const char* ipxk_last_error(void);
+int ipxk_device_count(void);
+
+/* ---- context: the model's matrix, resident on one GPU -------------------- */
+/* Replaces the role of ipx::Model::AI()/AIt() for the path (src/model.h:61):
+ * uploads the n structural columns of AI = [A I] (the slack identity is never
+ * stored) as a 32-bit-index CSC and builds the row-wise copy on the device
+ * side's own index arithmetic (Transpose, src/sparse_matrix.cc:120-151 --
+ * ascending source-column order within each row).  Also classifies dense
+ * columns as Model::FindDenseColumns does (src/model.cc:34-56). */
+int ipxk_create(ipxint m, ipxint n, const ipxint* Ap, const ipxint* Ai,
+                const double* Ax, int device, ipxk_context** out);
+void ipxk_destroy(ipxk_context* ctx);
+int ipxk_set_pointer_mode(ipxk_context* ctx, int mode);
+/* Use a caller-owned hipStream_t (e.g. torch's current stream); NULL restores
+ * the context's own stream. */
+int ipxk_set_stream(ipxk_context* ctx, void* hip_stream);
+int ipxk_synchronize(ipxk_context* ctx);
+ipxint ipxk_num_dense_cols(const ipxk_context* ctx);
+/* Copies out the device-side row-wise matrix (for bit-exact index parity
+ * tests against Transpose): ATp[m+1], ATi[nnz], ATx[nnz]; NULL skips. */
+int ipxk_get_rowwise(const ipxk_context* ctx, ipxint* ATp, ipxint* ATi,
+                     double* ATx);
+
+/* ---- NormalMatrix (src/normal_matrix.h:18-43) ---------------------------- */
+/* Prepare(W): W has n+m entries or is NULL (1 on structurals, 0 on slacks).
+ * Unlike the reference (raw pointer kept, normal_matrix.h:24-28) W is copied
+ * to the device here; in device pointer mode it is used in place. */
+int ipxk_normal_prepare(ipxk_context* ctx, const double* W);
+/* _Apply (src/normal_matrix.cc:45-126): lhs = AI*W*AI'*rhs, optional dot. */
+int ipxk_normal_apply(ipxk_context* ctx, const double* rhs, double* lhs,
+                      double* rhs_dot_lhs);
+
+/* ---- DiagonalPrecond (src/diagonal_precond.h:25-57) ---------------------- */
+/* Factorize (src/diagonal_precond.cc:17-111); *errflag = 0 or
+ * IPX_ERROR_lapack_chol (401). */
+int ipxk_diag_factorize(ipxk_context* ctx, const double* W,
+                        int precond_dense_cols, ipxint* errflag);
+/* _Apply (src/diagonal_precond.cc:121-159) */
+int ipxk_diag_apply(ipxk_context* ctx, const double* rhs, double* lhs,
+                    double* rhs_dot_lhs);
+/* copies diagonal_[m] and the k x k column-major Cholesky factor; NULL skips */
+int ipxk_diag_get(const ipxk_context* ctx, double* diagonal, double* chol);
+
+/* ---- ConjugateResiduals (src/conjugate_residuals.h:20-70) ---------------- */
+/* Preconditioned CR (src/conjugate_residuals.cc:90-213) with C = the prepared
+ * NormalMatrix and P = the factorized DiagonalPrecond.  lhs: initial iterate in,
+ * solution out.  resscale may be NULL.  maxiter < 0 means m+100.
+ * interrupt (may be NULL) is polled between batches of iterations and plays
+ * Control::InterruptCheck() (src/control.cc:17-22): a nonzero return value
+ * stops the solve and becomes *errflag.
+ * resnorm_hist (may be NULL): termination-test residual norm of each pass
+ * through the loop head, at most hist_cap entries (always a host pointer). */
+typedef ipxint (*ipxk_interrupt_fn)(void* user);
+int ipxk_pcr_solve(ipxk_context* ctx, const double* rhs, double tol,
+                   const double* resscale, ipxint maxiter, double* lhs,
+                   ipxint* iter, ipxint* errflag, ipxk_interrupt_fn interrupt,
+                   void* interrupt_user, double* resnorm_hist, ipxint hist_cap,
+                   ipxk_times* times);
+
+/* ---- KKTSolverDiag (src/kkt_solver_diag.h:23-49) ------------------------- */
+/* _Factorize (src/kkt_solver_diag.cc:18-65).  xl == NULL is Factorize(nullptr)
+ * (W = 1).  mu = iterate->mu().  Builds W, resscale, prepares the normal matrix
+ * and factorizes the preconditioner. */
+int ipxk_kkt_diag_factorize(ipxk_context* ctx, const double* xl,
+                            const double* xu, const double* zl,
+                            const double* zu, double mu,
+                            int precond_dense_cols, ipxint* errflag);
+/* _Solve (src/kkt_solver_diag.cc:82-118): a[n+m], b[m] -> x[n+m], y[m]. */
+int ipxk_kkt_diag_solve(ipxk_context* ctx, const double* a, const double* b,
+                        double tol, ipxint maxiter, double* x, double* y,
+                        ipxint* iter, ipxint* errflag,
+                        ipxk_interrupt_fn interrupt, void* interrupt_user,
+                        ipxk_times* times);
+/* copies W_[n+m] and resscale_[m] (host pointers; NULL skips) */
+int ipxk_kkt_diag_get(const ipxk_context* ctx, double* W, double* resscale);
+
+/* ---- SplittedNormalMatrix (src/splitted_normal_matrix.h:25-67) ----------- */
+/* Prepare (src/splitted_normal_matrix.cc:18-66).  The hand-off from
+ * Basis::GetLuFactors (src/basis.cc:162-166) is explicit: L (strictly lower,
+ * no diagonal), U (upper, diagonal last in each column), rowperm, colperm with
+ * B[rowperm,colperm] = (L+I)*U (src/lu_update.h:43-60); basis[p] = variable at
+ * position p; status[n+m] in IPXK_*; colscale[n+m]. */
+int ipxk_split_prepare(ipxk_context* ctx, const ipxint* Lp, const ipxint* Li,
+                       const double* Lx, const ipxint* Up, const ipxint* Ui,
+                       const double* Ux, const ipxint* rowperm,
+                       const ipxint* colperm, const ipxint* basis,
+                       const ipxint* status, const double* colscale);
+/* _Apply (src/splitted_normal_matrix.cc:90-117) */
+int ipxk_split_apply(ipxk_context* ctx, const double* rhs, double* lhs,
+                     double* rhs_dot_lhs);
+/* ForwardSolve / BackwardSolve with the prepared (scaled) factors, in place
+ * (src/sparse_matrix.cc:303-311). */
+int ipxk_forward_solve(ipxk_context* ctx, double* x);
+int ipxk_backward_solve(ipxk_context* ctx, double* x);
+/* Basis::SolveDense on the fresh unscaled factors (src/basis.cc:168-170) */
+int ipxk_solve_dense(ipxk_context* ctx, const double* rhs, double* lhs,
+                     char trans);
+/* number of level sets of the four triangular sweeps (U', L', L, U) */
+int ipxk_split_levels(const ipxk_context* ctx, ipxint levels[4]);
+/* Plain CR (src/conjugate_residuals.cc:14-88) on the prepared split operator */
+int ipxk_cr_solve(ipxk_context* ctx, const double* rhs, double tol,
+                  const double* resscale, ipxint maxiter, double* lhs,
+                  ipxint* iter, ipxint* errflag, ipxk_interrupt_fn interrupt,
+                  void* interrupt_user, double* resnorm_hist, ipxint hist_cap,
+                  ipxk_times* times);
+
+/* ---- KKTSolverBasis::_Solve (src/kkt_solver_basis.cc:75-194) ------------- */
+int ipxk_kkt_basis_solve(ipxk_context* ctx, const double* a, const double* b,
+                         double tol, ipxint maxiter, double* x, double* y,
+                         ipxint* iter, ipxint* errflag,
+                         ipxk_interrupt_fn interrupt, void* interrupt_user,
+                         ipxk_times* times);
+
+/* ---- multi-GPU: rows of AI partitioned over ranks, one RCCL all-reduce per
+ *      NormalMatrix apply ---------------------------- */
+/* 128-byte RCCL unique id, created on rank 0 and broadcast by the launcher. */
+int ipxk_comm_unique_id(void* id128);
+/* The context must have been created from this rank's row slab (m = local
+ * rows, all n columns, row indices local).  After this call dot products and
+ * norms of the CR loop are global and ipxk_normal_apply all-reduces A_g' y_g. */
+int ipxk_comm_init(ipxk_context* ctx, const void* id128, int rank, int nranks);
+
+/* ---- measurement helpers (bench.py, section 8d) --------------------------- */
+/* Runs `reps` NormalMatrix applies on resident device vectors and returns the
+ * total elapsed milliseconds between HIP events on the context's stream. */
+int ipxk_time_normal_apply(ipxk_context* ctx, const double* rhs_dev,
+                           double* lhs_dev, int reps, double* ms_total);
+/* algorithmic bytes of one NormalMatrix apply: 2*nnz*(4+8) + (n+m+2)*4 +
+ * 8*(3n+4m) */
+ipxint ipxk_normal_apply_bytes(const ipxk_context* ctx);
+/* plain device allocation helpers so that callers without torch can hold
+ * resident vectors */
+int ipxk_dev_alloc(ipxk_context* ctx, ipxint bytes, void** ptr);
+int ipxk_dev_free(ipxk_context* ctx, void* ptr);
+int ipxk_dev_upload(ipxk_context* ctx, void* dst_dev, const void* src_host,
+                    ipxint bytes);
+int ipxk_dev_download(ipxk_context* ctx, void* dst_host, const void* src_dev,
+                      ipxint bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPX_KKT_HIP_H_ */

@@ -1,0 +1,537 @@
+// extern "C" entry points of libipx_kkt_hip.so (see include/ipx_kkt_hip.h).
+// Thin glue: argument checks, host<->device staging according to the pointer mode,
+// exception -> return-code mapping.  No arithmetic lives here.
+#include <mutex>
+
+#include "context.hpp"
+
+namespace ipxk {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+
+Context::~Context() {
+    if (split) destroy_split(split);
+    comm_destroy(this);
+    if (h_state) (void)hipHostFree(h_state);
+    if (h_done) (void)hipHostFree(h_done);
+    if (ev_a) (void)hipEventDestroy(ev_a);
+    if (ev_b) (void)hipEventDestroy(ev_b);
+    for (hipEvent_t e : ev_window) (void)hipEventDestroy(e);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+const double* stage_in(Context* c, const double* p, size_t len, DevBuf<double>& buf) {
+    if (!p) return nullptr;
+    if (c->pointer_mode == IPXK_POINTER_DEVICE) return p;
+    if (buf.size() < len) buf.resize(len > 0 ? len : 1);
+    buf.upload(p, len, c->stream);
+    return buf.get();
+}
+
+double* stage_out(Context* c, double* p, size_t len, DevBuf<double>& buf) {
+    if (!p) return nullptr;
+    if (c->pointer_mode == IPXK_POINTER_DEVICE) return p;
+    if (buf.size() < len) buf.resize(len > 0 ? len : 1);
+    return buf.get();
+}
+
+void finish_out(Context* c, double* user, const double* dev, size_t len) {
+    if (!user || c->pointer_mode == IPXK_POINTER_DEVICE) return;
+    IPXK_HIP(hipMemcpyAsync(user, dev, len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    IPXK_HIP(hipStreamSynchronize(c->stream));
+}
+
+template <class F>
+static int guarded(F&& f) {
+    try {
+        f();
+        return IPXK_OK;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_last_error("host allocation failed");
+        return IPXK_E_ALLOC;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return IPXK_E_HIP;
+    }
+}
+
+static void bind_device(Context* c) { IPXK_HIP(hipSetDevice(c->device)); }
+
+}  // namespace ipxk
+
+using namespace ipxk;
+
+extern "C" {
+
+const char* ipxk_last_error(void) { return g_last_error.c_str(); }
+
+int ipxk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ipxk_create(ipxint m, ipxint n, const ipxint* Ap, const ipxint* Ai, const double* Ax, int device,
+                ipxk_context** out) {
+    if (out) *out = nullptr;
+    return guarded([&] {
+        IPXK_REQUIRE(out != nullptr, "out is NULL");
+        IPXK_REQUIRE(m >= 0 && n >= 0, "negative dimension");
+        IPXK_REQUIRE(Ap != nullptr && (Ap[n] == 0 || (Ai && Ax)), "matrix argument is NULL");
+        int ndev = 0;
+        IPXK_HIP(hipGetDeviceCount(&ndev));
+        if (ndev <= 0) throw Error(IPXK_E_HIP, "no HIP device available (the GPU path has no CPU fallback)");
+        IPXK_REQUIRE(device >= 0 && device < ndev, "device ordinal out of range");
+        std::unique_ptr<ipxk_context> c(new ipxk_context);
+        c->device = device;
+        IPXK_HIP(hipSetDevice(device));
+        IPXK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        c->stream = c->own_stream;
+        c->m = m;
+        c->n = n;
+        build_model(c.get(), Ap, Ai, Ax);
+        *out = c.release();
+    });
+}
+
+void ipxk_destroy(ipxk_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    delete ctx;
+}
+
+int ipxk_set_pointer_mode(ipxk_context* c, int mode) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && (mode == IPXK_POINTER_HOST || mode == IPXK_POINTER_DEVICE), "bad argument");
+        c->pointer_mode = mode;
+    });
+}
+
+int ipxk_set_stream(ipxk_context* c, void* hip_stream) {
+    return guarded([&] {
+        IPXK_REQUIRE(c != nullptr, "ctx is NULL");
+        bind_device(c);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+        c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    });
+}
+
+int ipxk_synchronize(ipxk_context* c) {
+    return guarded([&] {
+        IPXK_REQUIRE(c != nullptr, "ctx is NULL");
+        bind_device(c);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+ipxint ipxk_num_dense_cols(const ipxk_context* c) { return c ? c->num_dense : 0; }
+
+int ipxk_get_rowwise(const ipxk_context* c, ipxint* ATp, ipxint* ATi, double* ATx) {
+    return guarded([&] {
+        IPXK_REQUIRE(c != nullptr, "ctx is NULL");
+        IPXK_HIP(hipSetDevice(c->device));
+        // the row-wise copy is produced by the library's own Transpose arithmetic (spmv.hip)
+        const size_t m = (size_t)c->m, nz = (size_t)c->nnz;
+        if (ATp) for (size_t r = 0; r <= m; r++) ATp[r] = c->h_ATp[r];
+        if (ATi) for (size_t q = 0; q < nz; q++) ATi[q] = c->h_ATi[q];
+        if (ATx) for (size_t q = 0; q < nz; q++) ATx[q] = c->h_ATx[q];
+    });
+}
+
+// ---- NormalMatrix ------------------------------------------------------------
+int ipxk_normal_prepare(ipxk_context* c, const double* W) {
+    return guarded([&] {
+        IPXK_REQUIRE(c != nullptr, "ctx is NULL");
+        bind_device(c);
+        const size_t N = (size_t)(c->n + c->m);
+        if (!W) {
+            std::vector<double> w(N, 0.0);
+            std::fill(w.begin(), w.begin() + c->n, 1.0);
+            c->W_own.resize(N);
+            c->W_own.upload(w, c->stream);
+            IPXK_HIP(hipStreamSynchronize(c->stream));
+            c->W = c->W_own.get();
+        } else if (c->pointer_mode == IPXK_POINTER_DEVICE) {
+            c->W = W;
+        } else {
+            c->W_own.resize(N);
+            c->W_own.upload(W, N, c->stream);
+            IPXK_HIP(hipStreamSynchronize(c->stream));
+            c->W = c->W_own.get();
+        }
+        c->normal_prepared = true;
+    });
+}
+
+int ipxk_normal_apply(ipxk_context* c, const double* rhs, double* lhs, double* rhs_dot_lhs) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && rhs && lhs, "NULL argument");
+        IPXK_REQUIRE(c->normal_prepared, "NormalMatrix not prepared");
+        bind_device(c);
+        if (c->partials.size() == 0) c->partials.resize((size_t)kNumPartialSlots * kPartialStride);
+        const size_t m = (size_t)c->m;
+        const double* drhs = stage_in(c, rhs, m, c->v_rhs);
+        double* dlhs = stage_out(c, lhs, m, c->v_lhs);
+        int np = 0;
+        normal_apply_dev(c, c->W, drhs, dlhs, rhs_dot_lhs ? &np : nullptr, nullptr);
+        IPXK_HIP(hipGetLastError());
+        if (rhs_dot_lhs) *rhs_dot_lhs = reduce_partials_host(c, kPartCdot, np, false);
+        finish_out(c, lhs, dlhs, m);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+// ---- DiagonalPrecond -----------------------------------------------------------
+int ipxk_diag_factorize(ipxk_context* c, const double* W, int precond_dense_cols, ipxint* errflag) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && errflag, "NULL argument");
+        bind_device(c);
+        if (c->partials.size() == 0) c->partials.resize((size_t)kNumPartialSlots * kPartialStride);
+        const size_t N = (size_t)(c->n + c->m);
+        const double* dW;
+        DevBuf<double> tmp;
+        if (!W) {
+            std::vector<double> w(N, 0.0);
+            std::fill(w.begin(), w.begin() + c->n, 1.0);
+            tmp.upload(w, c->stream);
+            IPXK_HIP(hipStreamSynchronize(c->stream));
+            dW = tmp.get();
+        } else if (c->pointer_mode == IPXK_POINTER_DEVICE) {
+            dW = W;
+        } else {
+            tmp.upload(W, N, c->stream);
+            dW = tmp.get();
+        }
+        diag_factorize_dev(c, dW, precond_dense_cols != 0, errflag);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int ipxk_diag_apply(ipxk_context* c, const double* rhs, double* lhs, double* rhs_dot_lhs) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && rhs && lhs, "NULL argument");
+        IPXK_REQUIRE(c->diag_factorized, "DiagonalPrecond not factorized");
+        bind_device(c);
+        const size_t m = (size_t)c->m;
+        const double* drhs = stage_in(c, rhs, m, c->v_rhs);
+        double* dlhs = stage_out(c, lhs, m, c->v_lhs);
+        const int np = diag_apply_dev(c, drhs, dlhs, kPartScratch, nullptr);
+        IPXK_HIP(hipGetLastError());
+        if (rhs_dot_lhs) *rhs_dot_lhs = reduce_partials_host(c, kPartScratch, np, false);
+        finish_out(c, lhs, dlhs, m);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int ipxk_diag_get(const ipxk_context* c, double* diagonal, double* chol) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && c->diag_factorized, "DiagonalPrecond not factorized");
+        IPXK_HIP(hipSetDevice(c->device));
+        if (diagonal) c->diagonal.download(diagonal, (size_t)c->m, c->stream);
+        if (chol && c->kdense > 0) c->chol.download(chol, (size_t)(c->kdense * c->kdense), c->stream);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+// ---- ConjugateResiduals -----------------------------------------------------------
+static bool host_is_zero(const double* x, size_t len) {
+    for (size_t i = 0; i < len; i++)
+        if (x[i] != 0.0) return false;
+    return true;
+}
+
+int ipxk_pcr_solve(ipxk_context* c, const double* rhs, double tol, const double* resscale,
+                   ipxint maxiter, double* lhs, ipxint* iter, ipxint* errflag,
+                   ipxk_interrupt_fn interrupt, void* interrupt_user, double* resnorm_hist,
+                   ipxint hist_cap, ipxk_times* times) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && rhs && lhs && iter && errflag, "NULL argument");
+        bind_device(c);
+        const size_t m = (size_t)c->m;
+        const bool host = c->pointer_mode == IPXK_POINTER_HOST;
+        // Infnorm(lhs) == 0 saves one operator application (conjugate_residuals.cc:118-123);
+        // with device pointers the general branch is taken (same result: C*0 == 0).
+        const bool zero = host && host_is_zero(lhs, m);
+        const double* drhs = stage_in(c, rhs, m, c->v_rhs);
+        const double* dscale = stage_in(c, resscale, m, c->v_resscale_in);
+        double* dlhs = stage_out(c, lhs, m, c->v_lhs);
+        if (host) {
+            IPXK_HIP(hipMemcpyAsync(dlhs, lhs, m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        if (times) *times = ipxk_times{};
+        CrResult r = pcr_solve_dev(c, drhs, tol, dscale, maxiter, dlhs, zero, interrupt, interrupt_user,
+                                   resnorm_hist, hist_cap, times);
+        *iter = r.iter;
+        *errflag = r.errflag;
+        finish_out(c, lhs, dlhs, m);
+    });
+}
+
+int ipxk_cr_solve(ipxk_context* c, const double* rhs, double tol, const double* resscale,
+                  ipxint maxiter, double* lhs, ipxint* iter, ipxint* errflag,
+                  ipxk_interrupt_fn interrupt, void* interrupt_user, double* resnorm_hist,
+                  ipxint hist_cap, ipxk_times* times) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && rhs && lhs && iter && errflag, "NULL argument");
+        bind_device(c);
+        const size_t m = (size_t)c->m;
+        const bool host = c->pointer_mode == IPXK_POINTER_HOST;
+        const bool zero = host && host_is_zero(lhs, m);
+        const double* drhs = stage_in(c, rhs, m, c->v_rhs);
+        const double* dscale = stage_in(c, resscale, m, c->v_resscale_in);
+        double* dlhs = stage_out(c, lhs, m, c->v_lhs);
+        if (host) {
+            IPXK_HIP(hipMemcpyAsync(dlhs, lhs, m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        if (times) *times = ipxk_times{};
+        CrResult r = cr_solve_dev(c, drhs, tol, dscale, maxiter, dlhs, zero, interrupt, interrupt_user,
+                                  resnorm_hist, hist_cap, times);
+        *iter = r.iter;
+        *errflag = r.errflag;
+        finish_out(c, lhs, dlhs, m);
+    });
+}
+
+// ---- KKTSolverDiag ------------------------------------------------------------------
+int ipxk_kkt_diag_factorize(ipxk_context* c, const double* xl, const double* xu, const double* zl,
+                            const double* zu, double mu, int precond_dense_cols, ipxint* errflag) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && errflag, "NULL argument");
+        IPXK_REQUIRE(!xl || (xu && zl && zu), "iterate vectors must be all NULL or all given");
+        bind_device(c);
+        const size_t N = (size_t)(c->n + c->m);
+        DevBuf<double> t0, t1, t2, t3;
+        const double* dxl = stage_in(c, xl, N, t0);
+        const double* dxu = stage_in(c, xu, N, t1);
+        const double* dzl = stage_in(c, zl, N, t2);
+        const double* dzu = stage_in(c, zu, N, t3);
+        kkt_diag_factorize_dev(c, dxl, dxu, dzl, dzu, mu, precond_dense_cols != 0, errflag);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int ipxk_kkt_diag_solve(ipxk_context* c, const double* a, const double* b, double tol, ipxint maxiter,
+                        double* x, double* y, ipxint* iter, ipxint* errflag,
+                        ipxk_interrupt_fn interrupt, void* interrupt_user, ipxk_times* times) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && a && b && x && y && iter && errflag, "NULL argument");
+        bind_device(c);
+        const size_t m = (size_t)c->m, N = (size_t)(c->n + c->m);
+        const double* da = stage_in(c, a, N, c->k_a);
+        const double* db = stage_in(c, b, m, c->k_b);
+        double* dx = stage_out(c, x, N, c->k_x);
+        double* dy = stage_out(c, y, m, c->k_y);
+        if (times) *times = ipxk_times{};
+        CrResult r = kkt_diag_solve_dev(c, da, db, tol, maxiter, dx, dy, interrupt, interrupt_user, times);
+        *iter = r.iter;
+        *errflag = r.errflag;
+        finish_out(c, x, dx, N);
+        finish_out(c, y, dy, m);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int ipxk_kkt_diag_get(const ipxk_context* c, double* W, double* resscale) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && c->kkt_diag_factorized, "KKTSolverDiag not factorized");
+        IPXK_HIP(hipSetDevice(c->device));
+        if (W) c->W_own.download(W, (size_t)(c->n + c->m), c->stream);
+        if (resscale) c->resscale.download(resscale, (size_t)c->m, c->stream);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+// ---- SplittedNormalMatrix / basis path -------------------------------------------------
+int ipxk_split_prepare(ipxk_context* c, const ipxint* Lp, const ipxint* Li, const double* Lx,
+                       const ipxint* Up, const ipxint* Ui, const double* Ux, const ipxint* rowperm,
+                       const ipxint* colperm, const ipxint* basis, const ipxint* status,
+                       const double* colscale) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && Lp && Up && rowperm && colperm && basis && status && colscale, "NULL argument");
+        bind_device(c);
+        split_prepare_host(c, Lp, Li, Lx, Up, Ui, Ux, rowperm, colperm, basis, status, colscale);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int ipxk_split_apply(ipxk_context* c, const double* rhs, double* lhs, double* rhs_dot_lhs) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && rhs && lhs, "NULL argument");
+        IPXK_REQUIRE(c->split != nullptr, "SplittedNormalMatrix not prepared");
+        bind_device(c);
+        if (c->partials.size() == 0) c->partials.resize((size_t)kNumPartialSlots * kPartialStride);
+        const size_t m = (size_t)c->m;
+        const double* drhs = stage_in(c, rhs, m, c->v_rhs);
+        double* dlhs = stage_out(c, lhs, m, c->v_lhs);
+        const int np = split_apply_dev(c, drhs, dlhs, nullptr);
+        IPXK_HIP(hipGetLastError());
+        if (rhs_dot_lhs) *rhs_dot_lhs = reduce_partials_host(c, kPartCdot, np, false);
+        finish_out(c, lhs, dlhs, m);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+static int inplace_solve(ipxk_context* c, double* x, bool forward) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && x, "NULL argument");
+        IPXK_REQUIRE(c->split != nullptr, "SplittedNormalMatrix not prepared");
+        bind_device(c);
+        const size_t m = (size_t)c->m;
+        double* dx = stage_out(c, x, m, c->v_lhs);
+        if (c->pointer_mode == IPXK_POINTER_HOST)
+            IPXK_HIP(hipMemcpyAsync(dx, x, m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (forward) forward_solve_dev(c, dx, true, nullptr);
+        else backward_solve_dev(c, dx, true, nullptr);
+        IPXK_HIP(hipGetLastError());
+        finish_out(c, x, dx, m);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int ipxk_forward_solve(ipxk_context* c, double* x) { return inplace_solve(c, x, true); }
+int ipxk_backward_solve(ipxk_context* c, double* x) { return inplace_solve(c, x, false); }
+
+int ipxk_solve_dense(ipxk_context* c, const double* rhs, double* lhs, char trans) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && rhs && lhs, "NULL argument");
+        IPXK_REQUIRE(c->split != nullptr, "SplittedNormalMatrix not prepared");
+        bind_device(c);
+        const size_t m = (size_t)c->m;
+        const double* drhs = stage_in(c, rhs, m, c->v_rhs);
+        double* dlhs = stage_out(c, lhs, m, c->v_lhs);
+        solve_dense_dev(c, drhs, dlhs, trans);
+        IPXK_HIP(hipGetLastError());
+        finish_out(c, lhs, dlhs, m);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int ipxk_split_levels(const ipxk_context* c, ipxint levels[4]) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && c->split && levels, "SplittedNormalMatrix not prepared");
+        split_levels(c, levels);
+    });
+}
+
+int ipxk_kkt_basis_solve(ipxk_context* c, const double* a, const double* b, double tol, ipxint maxiter,
+                         double* x, double* y, ipxint* iter, ipxint* errflag,
+                         ipxk_interrupt_fn interrupt, void* interrupt_user, ipxk_times* times) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && a && b && x && y && iter && errflag, "NULL argument");
+        IPXK_REQUIRE(c->split != nullptr, "KKTSolverBasis not factorized (split operator missing)");
+        bind_device(c);
+        const size_t m = (size_t)c->m, N = (size_t)(c->n + c->m);
+        const double* da = stage_in(c, a, N, c->k_a);
+        const double* db = stage_in(c, b, m, c->k_b);
+        double* dx = stage_out(c, x, N, c->k_x);
+        double* dy = stage_out(c, y, m, c->k_y);
+        if (times) *times = ipxk_times{};
+        CrResult r = kkt_basis_solve_dev(c, da, db, tol, maxiter, dx, dy, interrupt, interrupt_user, times);
+        *iter = r.iter;
+        *errflag = r.errflag;
+        finish_out(c, x, dx, N);
+        finish_out(c, y, dy, m);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+// ---- measurement ---------------------------------------------------------------------
+int ipxk_time_normal_apply(ipxk_context* c, const double* rhs_dev, double* lhs_dev, int reps,
+                           double* ms_total) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && rhs_dev && lhs_dev && ms_total && reps > 0, "bad argument");
+        IPXK_REQUIRE(c->normal_prepared, "NormalMatrix not prepared");
+        bind_device(c);
+        if (c->partials.size() == 0) c->partials.resize((size_t)kNumPartialSlots * kPartialStride);
+        hipEvent_t e0, e1;
+        IPXK_HIP(hipEventCreate(&e0));
+        IPXK_HIP(hipEventCreate(&e1));
+        int np = 0;
+        IPXK_HIP(hipEventRecord(e0, c->stream));
+        for (int r = 0; r < reps; r++) normal_apply_dev(c, c->W, rhs_dev, lhs_dev, &np, nullptr);
+        IPXK_HIP(hipEventRecord(e1, c->stream));
+        IPXK_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        IPXK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *ms_total = ms;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        IPXK_HIP(hipGetLastError());
+    });
+}
+
+// tuning aid (not part of the reference-facing surface): times one pass of the product
+int ipxk_debug_time_pass(ipxk_context* c, int which, const double* x_dev, double* out_dev, int reps,
+                         double* ms_total) {
+    return guarded([&] {
+        bind_device(c);
+        hipEvent_t e0, e1;
+        IPXK_HIP(hipEventCreate(&e0));
+        IPXK_HIP(hipEventCreate(&e1));
+        IPXK_HIP(hipEventRecord(e0, c->stream));
+        for (int r = 0; r < reps; r++) debug_single_pass(c, which, x_dev, out_dev);
+        IPXK_HIP(hipEventRecord(e1, c->stream));
+        IPXK_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        IPXK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *ms_total = ms;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    });
+}
+
+int ipxk_debug_get_stamps(ipxk_context* c, int which, unsigned long long* out, ipxint cap, int* geom) {
+    return guarded([&] {
+        bind_device(c);
+        const GatherMatrix& M = which == 1 ? c->Acols : c->Arows;
+        geom[0] = M.P; geom[1] = M.G; geom[2] = M.RT; geom[3] = M.Q;
+        const size_t n = std::min<size_t>((size_t)cap, M.stamps.size());
+        M.stamps.download(out, n, c->stream);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+ipxint ipxk_normal_apply_bytes(const ipxk_context* c) {
+    if (!c) return 0;
+    const ipxint wi = 4;
+    return 2 * c->nnz * (wi + 8) + (c->n + c->m + 2) * wi + 8 * (3 * c->n + 4 * c->m);
+}
+
+int ipxk_dev_alloc(ipxk_context* c, ipxint bytes, void** ptr) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && ptr && bytes >= 0, "bad argument");
+        bind_device(c);
+        *ptr = nullptr;
+        IPXK_HIP(hipMalloc(ptr, bytes > 0 ? (size_t)bytes : 8));
+    });
+}
+int ipxk_dev_free(ipxk_context* c, void* ptr) {
+    return guarded([&] {
+        IPXK_REQUIRE(c != nullptr, "ctx is NULL");
+        bind_device(c);
+        if (ptr) IPXK_HIP(hipFree(ptr));
+    });
+}
+int ipxk_dev_upload(ipxk_context* c, void* dst_dev, const void* src_host, ipxint bytes) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && dst_dev && src_host && bytes >= 0, "bad argument");
+        bind_device(c);
+        IPXK_HIP(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+int ipxk_dev_download(ipxk_context* c, void* dst_host, const void* src_dev, ipxint bytes) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && dst_host && src_dev && bytes >= 0, "bad argument");
+        bind_device(c);
+        IPXK_HIP(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// The object behind ipxk_context: one model's matrix resident on one GPU plus
+// every workspace of the KKT path (allocated once, reused by every solve).
+#pragma once
+
+#include "internal.hpp"
+
+struct ncclComm;
+
+namespace ipxk {
+
+constexpr int kPartialStride = kMaxPartials + 8;   // doubles per partial array
+
+// indices of the per-workgroup partial arrays inside Context::partials
+enum PartialSlot {
+    kPartRes0 = 0,   // scaled residual norm (max), parity 0
+    kPartRes1,       //                          , parity 1
+    kPartPdot,       // Cstep' * P * Cstep  (or Cstep'*Cstep for plain CR)
+    kPartCdot,       // dot from C.Apply
+    kPartRsdot,      // residual' * P * residual (every 5th iteration)
+    kPartScratch,
+    kNumPartialSlots
+};
+
+struct SplitOperator;   // trisolve.hip
+
+struct Context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int pointer_mode = IPXK_POINTER_HOST;
+    bool profile_ops = false;
+
+    // ---- model ----
+    int64_t m = 0, n = 0, nnz = 0;
+    std::vector<ipxint> h_Ap, h_Ai;     // host copy of the structural CSC
+    std::vector<double> h_Ax;
+    std::vector<ipxint> h_ATp, h_ATi;   // row-wise copy (host)
+    std::vector<double> h_ATx;
+    GatherMatrix Acols;                 // rows = columns of A  (computes A'y)
+    GatherMatrix Arows;                 // rows = rows of A     (computes A t)
+    int64_t num_dense = 0, nz_dense = 0;
+    std::vector<ipxint> dense_cols;
+
+    // ---- NormalMatrix ----
+    DevBuf<double> W_own;               // n+m
+    const double* W = nullptr;          // device pointer in use (W_own or caller's)
+    bool normal_prepared = false;
+    DevBuf<double> tcols;               // n workspace: t = Ws .* (A'y)
+
+    // ---- DiagonalPrecond ----
+    DevBuf<double> diagonal;            // m
+    bool diag_factorized = false;
+    int64_t kdense = 0;                 // # dense columns treated by SMW (0: plain diagonal)
+    GatherMatrix AdCols;                // k rows x m: computes Ad' u
+    GatherMatrix AdRows;                // m rows x k: computes Ad w
+    DevBuf<double> chol, smw_work, smw_u, Wnodense;
+    DevBuf<int> chol_info;
+    DevBuf<unsigned char> dense_mask;   // n, 1 for dense columns
+
+    // ---- CR workspaces (m-vectors) ----
+    DevBuf<double> v_rhs, v_lhs, v_residual, v_sresidual, v_step, v_Cstep, v_Cres, v_pCstep;
+    DevBuf<double> v_resscale_in;       // staging for a host resscale
+    DevBuf<double> partials;            // kNumPartialSlots * kPartialStride
+    DevBuf<CrState> state;
+    CrState* h_state = nullptr;         // pinned
+    int* h_done = nullptr;              // mapped pinned termination flag (host view)
+    int* d_done = nullptr;              //                                (device view)
+    DevBuf<double> hist;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    std::vector<hipEvent_t> ev_window;
+
+    // ---- KKTSolverDiag ----
+    DevBuf<double> resscale;            // m
+    DevBuf<double> k_a, k_b, k_x, k_y;  // staging for host vectors (n+m, m, n+m, m)
+    DevBuf<double> k_tmp;               // n+m scratch
+    bool kkt_diag_factorized = false;
+
+    // ---- basis path ----
+    SplitOperator* split = nullptr;
+
+    // ---- multi-GPU ----
+    ncclComm* comm = nullptr;
+    int rank = 0, nranks = 1;
+    DevBuf<double> comm_scalars;        // nranks * 8 gathered scalars
+
+    Context() = default;
+    ~Context();
+    double* part(int slot) const { return partials.get() + (size_t)slot * kPartialStride; }
+};
+
+// staging of vector arguments according to the pointer mode
+const double* stage_in(Context* c, const double* p, size_t len, DevBuf<double>& buf);
+double* stage_out(Context* c, double* p, size_t len, DevBuf<double>& buf);
+void finish_out(Context* c, double* user, const double* dev, size_t len);
+
+// ---- spmv.hip ----
+void normal_apply_dev(Context* c, const double* W, const double* rhs, double* lhs, int* ndot,
+                      const int* done);
+void build_model(Context* c, const ipxint* Ap, const ipxint* Ai, const double* Ax);
+void debug_single_pass(Context* c, int which, const double* x, double* out);
+
+// ---- precond.hip ----
+void diag_factorize_dev(Context* c, const double* W, bool precond_dense_cols, ipxint* errflag);
+// lhs = P rhs; partial dot rhs'lhs -> part(slot); returns # partials
+int diag_apply_dev(Context* c, const double* rhs, double* lhs, int slot, const int* done);
+
+// ---- cr.hip ----
+struct CrResult { ipxint iter; ipxint errflag; };
+CrResult pcr_solve_dev(Context* c, const double* rhs, double tol, const double* resscale,
+                       ipxint maxiter, double* lhs, bool lhs_is_zero, ipxk_interrupt_fn interrupt,
+                       void* user, double* hist_host, ipxint hist_cap, ipxk_times* times);
+CrResult cr_solve_dev(Context* c, const double* rhs, double tol, const double* resscale,
+                      ipxint maxiter, double* lhs, bool lhs_is_zero, ipxk_interrupt_fn interrupt,
+                      void* user, double* hist_host, ipxint hist_cap, ipxk_times* times);
+double reduce_partials_host(Context* c, int slot, int count, bool is_max);
+
+// ---- kkt_diag.hip ----
+void kkt_diag_factorize_dev(Context* c, const double* xl, const double* xu, const double* zl,
+                            const double* zu, double mu, bool precond_dense_cols, ipxint* errflag);
+CrResult kkt_diag_solve_dev(Context* c, const double* a, const double* b, double tol,
+                            ipxint maxiter, double* x, double* y, ipxk_interrupt_fn interrupt,
+                            void* user, ipxk_times* times);
+
+// ---- trisolve.hip / kkt_basis.hip ----
+void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const double* Lx,
+                        const ipxint* Up, const ipxint* Ui, const double* Ux, const ipxint* rowperm,
+                        const ipxint* colperm, const ipxint* basis, const ipxint* status,
+                        const double* colscale);
+// lhs = C rhs (device vectors), dot partials -> part(kPartCdot); returns # partials
+int split_apply_dev(Context* c, const double* rhs, double* lhs, const int* done);
+void forward_solve_dev(Context* c, double* x, bool scaled, const int* done);
+void backward_solve_dev(Context* c, double* x, bool scaled, const int* done);
+void solve_dense_dev(Context* c, const double* rhs, double* lhs, char trans);
+CrResult kkt_basis_solve_dev(Context* c, const double* a, const double* b, double tol,
+                             ipxint maxiter, double* x, double* y, ipxk_interrupt_fn interrupt,
+                             void* user, ipxk_times* times);
+void split_levels(const Context* c, ipxint levels[4]);
+void destroy_split(SplitOperator*);
+
+// ---- comm.hip ----
+void comm_allreduce_sum(Context* c, double* buf, size_t count);
+void comm_destroy(Context* c);
+
+}  // namespace ipxk
+
+struct ipxk_context : ipxk::Context {};

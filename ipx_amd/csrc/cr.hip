@@ -1,0 +1,388 @@
+// Conjugate Residuals on the device             reference src/conjugate_residuals.cc
+//   preconditioned CR (:90-213) for the diag path, plain CR (:14-88) for the basis path.
+//
+// The whole loop runs on the GPU without a host round trip per iteration:
+//  * vectors and the loop scalars (cdot, alpha, beta, iteration count, errflag) live in HBM;
+//  * every dot product / norm is produced as per-workgroup partials by the kernel that
+//    touches the data anyway and is finished redundantly (bitwise identically) by every
+//    workgroup of the consuming kernel -- no atomics, no extra "finalize" launches;
+//  * the termination test, the error checks (:139-171) and the every-5th-iteration
+//    refresh with its monotonicity check (:186-207) are evaluated by the control kernel,
+//    which turns all later kernels into no-ops once `done` is set;
+//  * the host enqueues cycles of 5 iterations, stays at most kWindow cycles ahead of the
+//    GPU and learns about termination from a flag in mapped host memory.
+// Steady state per PCR iteration: 4 launches (control+update, SpMV pass 1, SpMV pass 2,
+// direction) touching 12 m-vectors instead of the ~22 of the unfused formulation.
+#include <cmath>
+
+#include "context.hpp"
+#include "spmv_kernels.hpp"
+
+namespace ipxk {
+
+constexpr int kWindow = 2;  // cycles (of 5 iterations) the host may run ahead
+
+enum CrMode { kModePcrDiag = 0, kModePcrSmw = 1, kModePlain = 2 };
+
+struct CrVecs {
+    int m;
+    double* lhs;
+    double* residual;
+    double* sresidual;   // PCR only
+    double* step;
+    double* Cstep;
+    double* Cres;        // C*sresidual (PCR) or C*residual (plain)
+    double* pCstep;      // P*Cstep, SMW mode only
+    const double* resscale;
+    const double* diag;
+};
+
+static int vec_grid(int64_t len) {
+    int64_t g = (len + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    return (int)(g < 1024 ? g : 1024);
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+// out = rhs - sub (sub == nullptr: out = rhs); partial max |resscale .* out|
+__global__ __launch_bounds__(kBlock) void residual_init_kernel(int m, const double* __restrict__ rhs,
+                                                               const double* __restrict__ sub,
+                                                               const double* __restrict__ resscale,
+                                                               double* __restrict__ out,
+                                                               double* partial) {
+    __shared__ double red[kBlock / 64 + 1];
+    double mx = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock) {
+        const double r = sub ? rhs[i] - sub[i] : rhs[i];
+        out[i] = r;
+        mx = MaxOp::apply(mx, fabs(resscale ? resscale[i] * r : r));
+    }
+    mx = block_reduce<MaxOp>(mx, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = mx;
+}
+
+__global__ __launch_bounds__(kBlock) void cr_init_state_kernel(CrState* st, double tol, long long maxiter,
+                                                               long long hist_cap, PartRef rsdot) {
+    __shared__ double red[kBlock / 64 + 1];
+    const double r = rsdot.p ? reduce_partials<SumOp>(rsdot, red) : 0.0;
+    if (threadIdx.x == 0) {
+        st->tol = tol;
+        st->maxiter = maxiter;
+        st->k_started = 0;
+        st->k_finished = 0;
+        st->cdot[0] = st->cdot[1] = 0.0;
+        st->rps[0] = r;
+        st->rps[1] = 0.0;
+        st->resnorm = 0.0;
+        st->iter = 0;
+        st->errflag = 0;
+        st->done = 0;
+        st->hist_cap = hist_cap;
+    }
+}
+
+// Loop head + solution update of iteration k = st->k_finished.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void cr_control_update_kernel(
+    CrState* st, CrVecs v, PartRef res0, PartRef res1, PartRef pdot_ref, PartRef rsdot_ref,
+    double* res_next0, double* res_next1, double* hist, int* host_done) {
+    if (st->done) return;
+    __shared__ double red[kBlock / 64 + 1];
+    const long long k = st->k_finished;
+    const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+    int errflag = -1;  // -1: continue
+    double resnorm = st->resnorm;
+
+    if (MODE != kModePlain && k > 0 && k % 5 == 0) {
+        // :195-206 monotonicity of residual'*P*residual over the last 5 iterations
+        const double rsdot = reduce_partials<SumOp>(rsdot_ref, red);
+        const long long c5 = k / 5;
+        if (rsdot >= st->rps[(c5 - 1) & 1]) errflag = 204;   // IPX_ERROR_cr_no_progress
+        else if (writer) st->rps[c5 & 1] = rsdot;
+    }
+    double alpha = 0.0;
+    if (errflag < 0) {
+        resnorm = reduce_partials<MaxOp>((k & 1) ? res1 : res0, red);
+        if (writer && k < st->hist_cap) hist[k] = resnorm;
+        const double cdot = st->cdot[k & 1];
+        if (resnorm <= st->tol) errflag = 0;
+        else if (k == st->maxiter) errflag = 201;             // IPX_ERROR_cr_iter_limit
+        else if (cdot <= 0.0) errflag = 202;                  // IPX_ERROR_cr_matrix_not_posdef
+        else {
+            const double pdot = reduce_partials<SumOp>(pdot_ref, red);
+            if (MODE != kModePlain && pdot <= 0.0) errflag = 203;  // IPX_ERROR_cr_precond_not_posdef
+            else {
+                alpha = cdot / pdot;
+                if (!isfinite(alpha)) errflag = 205;          // IPX_ERROR_cr_inf_or_nan
+            }
+        }
+    }
+    if (errflag >= 0) {
+        if (writer) {
+            st->errflag = errflag;
+            st->iter = k;
+            st->resnorm = resnorm;
+            st->done = 1;
+            __hip_atomic_store(host_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+
+    // :173-175 / :72-73
+    double mx = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < v.m; i += gridDim.x * kBlock) {
+        const double q = v.Cstep[i];
+        v.lhs[i] += alpha * v.step[i];
+        const double r = v.residual[i] - alpha * q;
+        v.residual[i] = r;
+        if (MODE == kModePcrDiag) v.sresidual[i] -= alpha * (q / v.diag[i]);
+        if (MODE == kModePcrSmw) v.sresidual[i] -= alpha * v.pCstep[i];
+        mx = MaxOp::apply(mx, fabs(v.resscale ? v.resscale[i] * r : r));
+    }
+    mx = block_reduce<MaxOp>(mx, red);
+    if (threadIdx.x == 0) ((k & 1) ? res_next0 : res_next1)[blockIdx.x] = mx;
+    if (writer) {
+        st->k_started = k + 1;
+        st->resnorm = resnorm;
+    }
+}
+
+// :180-184 / :78-81  new search direction; INIT: step = (s)residual, Cstep = C*(s)residual
+template <int MODE, bool INIT>
+__global__ __launch_bounds__(kBlock) void cr_direction_kernel(CrState* st, CrVecs v, PartRef cdot_ref,
+                                                              double* pdot_partial) {
+    if (st->done) return;
+    __shared__ double red[kBlock / 64 + 1];
+    const long long k = INIT ? -1 : st->k_started - 1;
+    const double cdotnew = reduce_partials<SumOp>(cdot_ref, red);
+    const double beta = INIT ? 0.0 : cdotnew / st->cdot[k & 1];
+    const double* src = MODE == kModePlain ? v.residual : v.sresidual;
+    double acc = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < v.m; i += gridDim.x * kBlock) {
+        double p, q;
+        if (INIT) {
+            p = src[i];
+            q = v.Cres[i];
+        } else {
+            p = src[i] + beta * v.step[i];
+            q = v.Cres[i] + beta * v.Cstep[i];
+        }
+        v.step[i] = p;
+        v.Cstep[i] = q;
+        if (MODE == kModePcrDiag) acc += (q / v.diag[i]) * q;   // pdot of diagonal_precond.cc:152-154
+        if (MODE == kModePlain) acc += q * q;                   // Dot(Cstep,Cstep), :66
+    }
+    if (MODE != kModePcrSmw) {
+        acc = block_reduce<SumOp>(acc, red);
+        if (threadIdx.x == 0) pdot_partial[blockIdx.x] = acc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->cdot[(k + 1) & 1] = cdotnew;
+        st->k_finished = k + 1;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void finalize_scalar_kernel(PartRef ref, int is_max, double* out) {
+    __shared__ double red[kBlock / 64 + 1];
+    const double v = is_max ? reduce_partials<MaxOp>(ref, red) : reduce_partials<SumOp>(ref, red);
+    if (threadIdx.x == 0) *out = v;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct CrHostFlag {
+    int* host;   // mapped pinned memory, written by the control kernel at termination
+    int* dev;
+};
+
+static CrHostFlag host_flag(Context* c) {
+    if (!c->h_done) {
+        IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_done), 64, hipHostMallocMapped));
+        IPXK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_done), c->h_done, 0));
+    }
+    return CrHostFlag{c->h_done, c->d_done};
+}
+
+double reduce_partials_host(Context* c, int slot, int count, bool is_max) {
+    DevBuf<double>& scratch = c->comm_scalars;
+    if (scratch.size() < 64) scratch.resize(64);
+    PartRef ref{c->part(slot), count, 1};
+    hipLaunchKernelGGL(finalize_scalar_kernel, dim3(1), dim3(kBlock), 0, c->stream, ref,
+                       is_max ? 1 : 0, scratch.get() + 63);
+    double v = 0.0;
+    IPXK_HIP(hipMemcpyAsync(&v, scratch.get() + 63, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    IPXK_HIP(hipStreamSynchronize(c->stream));
+    return v;
+}
+
+static void ensure_workspaces(Context* c) {
+    const size_t m = (size_t)(c->m > 0 ? c->m : 1);
+    if (c->v_residual.size() != m) {
+        c->v_residual.resize(m); c->v_sresidual.resize(m); c->v_step.resize(m);
+        c->v_Cstep.resize(m); c->v_Cres.resize(m); c->v_pCstep.resize(m);
+    }
+    if (c->partials.size() == 0) c->partials.resize((size_t)kNumPartialSlots * kPartialStride);
+    if (c->state.size() == 0) c->state.resize(1);
+    if (!c->h_state) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_state), sizeof(CrState)));
+    if (!c->ev_a) { IPXK_HIP(hipEventCreate(&c->ev_a)); IPXK_HIP(hipEventCreate(&c->ev_b)); }
+    while ((int)c->ev_window.size() < kWindow + 1) {
+        hipEvent_t e;
+        IPXK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->ev_window.push_back(e);
+    }
+}
+
+// Operator / preconditioner hooks of one solve.
+struct CrOps {
+    int mode;
+    // lhs = C rhs, dot partials into part(kPartCdot); returns their count
+    int (*applyC)(Context*, const double* rhs, double* lhs, const int* done);
+};
+
+static int applyC_normal(Context* c, const double* rhs, double* lhs, const int* done) {
+    int np = 0;
+    normal_apply_dev(c, c->W, rhs, lhs, &np, done);
+    return np;
+}
+static int applyC_split(Context* c, const double* rhs, double* lhs, const int* done) {
+    return split_apply_dev(c, rhs, lhs, done);
+}
+
+template <int MODE>
+static CrResult run_cr(Context* c, const CrOps& ops, const double* rhs, double tol,
+                       const double* resscale, ipxint maxiter, double* lhs, bool lhs_is_zero,
+                       ipxk_interrupt_fn interrupt, void* user, double* hist_host, ipxint hist_cap,
+                       ipxk_times* times) {
+    ensure_workspaces(c);
+    hipStream_t s = c->stream;
+    const int m = (int)c->m;
+    if (maxiter < 0) maxiter = c->m + 100;            // :114-115
+    if (hist_cap < 0) hist_cap = 0;
+    if (!hist_host) hist_cap = 0;
+    if (c->hist.size() < (size_t)hist_cap + 1) c->hist.resize((size_t)hist_cap + 1);
+    CrHostFlag flag = host_flag(c);
+    *(volatile int*)flag.host = 0;   // the previous solve has been synchronized
+    CrState* st = c->state.get();
+    int* done = &st->done;
+    const int g = vec_grid(m);
+
+    CrVecs v;
+    v.m = m; v.lhs = lhs; v.residual = c->v_residual.get(); v.sresidual = c->v_sresidual.get();
+    v.step = c->v_step.get(); v.Cstep = c->v_Cstep.get(); v.Cres = c->v_Cres.get();
+    v.pCstep = c->v_pCstep.get(); v.resscale = resscale; v.diag = c->diagonal.get();
+
+    IPXK_HIP(hipEventRecord(c->ev_a, s));
+
+    // ---- initialisation, :117-126 / :33-41 ----
+    PartRef none{nullptr, 0, 1};
+    if (lhs_is_zero) {
+        hipLaunchKernelGGL(residual_init_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs,
+                           (const double*)nullptr, resscale, v.residual, c->part(kPartRes0));
+    } else {
+        ops.applyC(c, lhs, v.Cres, nullptr);
+        hipLaunchKernelGGL(residual_init_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs,
+                           (const double*)v.Cres, resscale, v.residual, c->part(kPartRes0));
+    }
+    PartRef res0{c->part(kPartRes0), g, 1}, res1{c->part(kPartRes1), g, 1};
+    PartRef rsdot = none;
+    if (MODE != kModePlain) {
+        const int np = diag_apply_dev(c, v.residual, v.sresidual, kPartRsdot, nullptr);
+        rsdot = PartRef{c->part(kPartRsdot), np, 1};
+    }
+    hipLaunchKernelGGL(cr_init_state_kernel, dim3(1), dim3(kBlock), 0, s, st, tol, (long long)maxiter,
+                       (long long)hist_cap, rsdot);
+    const double* csrc = MODE == kModePlain ? v.residual : v.sresidual;
+    int ncdot = ops.applyC(c, csrc, v.Cres, nullptr);
+    PartRef cdot_ref{c->part(kPartCdot), ncdot, 1};
+    PartRef pdot_ref{c->part(kPartPdot), g, 1};
+    hipLaunchKernelGGL((cr_direction_kernel<MODE, true>), dim3(g), dim3(kBlock), 0, s, st, v, cdot_ref,
+                       c->part(kPartPdot));
+    if (MODE == kModePcrSmw) {
+        const int np = diag_apply_dev(c, v.Cstep, v.pCstep, kPartPdot, nullptr);
+        pdot_ref = PartRef{c->part(kPartPdot), np, 1};
+    }
+
+    // ---- main loop: cycles of 5 iterations ----
+    ipxint interrupt_flag = 0;
+    long long cycle = 0;
+    for (;; cycle++) {
+        const long long k0 = cycle * 5;
+        if (k0 > maxiter) break;
+        if (*(volatile int*)flag.host) break;
+        if (cycle >= kWindow) {
+            IPXK_HIP(hipEventSynchronize(c->ev_window[(cycle - kWindow) % (kWindow + 1)]));
+            if (*(volatile int*)flag.host) break;
+        }
+        if (interrupt && (interrupt_flag = interrupt(user)) != 0) break;   // :209 / :84
+        for (long long k = k0; k < k0 + 5 && k <= maxiter; k++) {
+            hipLaunchKernelGGL((cr_control_update_kernel<MODE>), dim3(g), dim3(kBlock), 0, s, st, v,
+                               res0, res1, pdot_ref, rsdot, c->part(kPartRes0), c->part(kPartRes1),
+                               c->hist.get(), flag.dev);
+            ncdot = ops.applyC(c, csrc, v.Cres, done);
+            cdot_ref.count = ncdot;
+            hipLaunchKernelGGL((cr_direction_kernel<MODE, false>), dim3(g), dim3(kBlock), 0, s, st, v,
+                               cdot_ref, c->part(kPartPdot));
+            if (MODE == kModePcrSmw) diag_apply_dev(c, v.Cstep, v.pCstep, kPartPdot, done);
+            if (MODE != kModePlain && (k + 1) % 5 == 0)
+                diag_apply_dev(c, v.residual, v.sresidual, kPartRsdot, done);   // :187-194
+        }
+        IPXK_HIP(hipEventRecord(c->ev_window[cycle % (kWindow + 1)], s));
+    }
+    IPXK_HIP(hipEventRecord(c->ev_b, s));
+    IPXK_HIP(hipMemcpyAsync(c->h_state, st, sizeof(CrState), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    IPXK_HIP(hipGetLastError());
+
+    CrResult res;
+    if (c->h_state->done) {
+        res.iter = c->h_state->iter;
+        res.errflag = c->h_state->errflag;
+    } else {
+        // interrupted: the iterate of the last finished iteration is in lhs
+        res.iter = c->h_state->k_finished;
+        res.errflag = interrupt_flag;
+    }
+    if (hist_cap > 0) {
+        long long nh = c->h_state->done && c->h_state->errflag != 204 ? res.iter + 1 : res.iter;
+        if (!c->h_state->done) nh = c->h_state->k_started;
+        if (nh > hist_cap) nh = hist_cap;
+        for (long long i = nh; i < hist_cap; i++) hist_host[i] = std::nan("");
+        if (nh > 0) {
+            c->hist.download(hist_host, (size_t)nh, s);
+            IPXK_HIP(hipStreamSynchronize(s));
+        }
+    }
+    if (times) {
+        float ms = 0.f;
+        IPXK_HIP(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
+        times->cr = ms * 1e-3;
+    }
+    return res;
+}
+
+CrResult pcr_solve_dev(Context* c, const double* rhs, double tol, const double* resscale,
+                       ipxint maxiter, double* lhs, bool lhs_is_zero, ipxk_interrupt_fn interrupt,
+                       void* user, double* hist_host, ipxint hist_cap, ipxk_times* times) {
+    IPXK_REQUIRE(c->normal_prepared, "NormalMatrix not prepared");
+    IPXK_REQUIRE(c->diag_factorized, "DiagonalPrecond not factorized");
+    CrOps ops{c->kdense > 0 ? kModePcrSmw : kModePcrDiag, applyC_normal};
+    if (c->kdense > 0)
+        return run_cr<kModePcrSmw>(c, ops, rhs, tol, resscale, maxiter, lhs, lhs_is_zero, interrupt,
+                                   user, hist_host, hist_cap, times);
+    return run_cr<kModePcrDiag>(c, ops, rhs, tol, resscale, maxiter, lhs, lhs_is_zero, interrupt, user,
+                                hist_host, hist_cap, times);
+}
+
+CrResult cr_solve_dev(Context* c, const double* rhs, double tol, const double* resscale,
+                      ipxint maxiter, double* lhs, bool lhs_is_zero, ipxk_interrupt_fn interrupt,
+                      void* user, double* hist_host, ipxint hist_cap, ipxk_times* times) {
+    IPXK_REQUIRE(c->split != nullptr, "SplittedNormalMatrix not prepared");
+    CrOps ops{kModePlain, applyC_split};
+    return run_cr<kModePlain>(c, ops, rhs, tol, resscale, maxiter, lhs, lhs_is_zero, interrupt, user,
+                              hist_host, hist_cap, times);
+}
+
+}  // namespace ipxk

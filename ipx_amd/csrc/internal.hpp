@@ -1,0 +1,219 @@
+// Internal declarations shared by the translation units of libipx_kkt_hip.so.
+// Nothing here is part of the ABI (see include/ipx_kkt_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ipx_kkt_hip.h"
+
+namespace ipxk {
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+void set_last_error(const std::string& msg);
+
+#define IPXK_HIP(expr)                                                         \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess) {                                                \
+            char buf_[512];                                                    \
+            snprintf(buf_, sizeof buf_, "%s:%d: %s failed: %s", __FILE__,      \
+                     __LINE__, #expr, hipGetErrorString(e_));                  \
+            throw ::ipxk::Error(e_ == hipErrorOutOfMemory ? IPXK_E_ALLOC       \
+                                                          : IPXK_E_HIP, buf_); \
+        }                                                                      \
+    } while (0)
+
+#define IPXK_REQUIRE(cond, msg)                                                \
+    do {                                                                       \
+        if (!(cond))                                                           \
+            throw ::ipxk::Error(IPXK_E_ARGUMENT, std::string(__func__) + ": " + (msg)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// device memory
+// ---------------------------------------------------------------------------
+template <class T>
+class DevBuf {
+public:
+    DevBuf() = default;
+    explicit DevBuf(size_t n) { resize(n); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void resize(size_t n) {
+        if (n == n_) return;
+        release();
+        if (n > 0) IPXK_HIP(hipMalloc(reinterpret_cast<void**>(&p_), n * sizeof(T)));
+        n_ = n;
+    }
+    void release() {
+        if (p_) (void)hipFree(p_);
+        p_ = nullptr;
+        n_ = 0;
+    }
+    T* get() const { return p_; }
+    size_t size() const { return n_; }
+    void upload(const T* host, size_t n, hipStream_t s) {
+        if (n > n_) resize(n);
+        if (n) IPXK_HIP(hipMemcpyAsync(p_, host, n * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void upload(const std::vector<T>& v, hipStream_t s) { upload(v.data(), v.size(), s); }
+    void download(T* host, size_t n, hipStream_t s) const {
+        if (n) IPXK_HIP(hipMemcpyAsync(host, p_, n * sizeof(T), hipMemcpyDeviceToHost, s));
+    }
+private:
+    T* p_ = nullptr;
+    size_t n_ = 0;
+};
+
+// ---------------------------------------------------------------------------
+// "gather matrix": a sparse matrix stored by output row, out[r] = f(sum_p
+// x[idx[p]] * val[p]).  The CSC of A is the gather matrix of A' (pass 1 of
+// A W A'), the row-wise copy of A is the gather matrix of A (pass 2).
+// 32-bit indices on the device (4 B per index in the roofline model).
+//
+// Layout ("time-tiled, LDS-staged partial rows").  Measured on MI355X
+// (profiles/r01_gather_microbench.txt): random 8-byte gathers run at ~190 G/s
+// when the gathered vector slice is L2-resident (<= 2 MB) but only 70-98 G/s from
+// a 16 / 8 MB vector, while the (idx,val) stream alone runs at 6.6 TB/s.  So the
+// entries are re-ordered such that, at any time, every workgroup gathers from the
+// same slice of x:
+//   * the gathered index space is cut into P "phases" of kSliceElems entries;
+//   * G co-resident workgroups each own kBlock*RT consecutive output rows per
+//     round (thread t owns RT consecutive rows, accumulators live in registers);
+//   * storage is ordered (round, phase, workgroup): in step (q,p,w) workgroup w
+//     streams -- with fully coalesced loads -- the entries of its rows whose index
+//     falls into phase p, stages the products in LDS and each thread adds its
+//     rows' products in storage order.  Per (row, phase) only an 8-bit count is
+//     stored (no row pointers).
+// Because phases ascend with the index, a row is still summed in ascending index
+// order, i.e. in the reference's order (bit-exact row sums).
+// Rows with more than kMaxRowLen entries ("long rows": dense columns) are cut into
+// segments of kLongSeg entries that separate workgroups sum into `long_partials`,
+// combined in segment order by a fix-up kernel (deterministic, atomic-free).
+// ---------------------------------------------------------------------------
+constexpr int kBlock = 256;        // threads per workgroup (4 waves)
+constexpr int kChunkNnz = 1024;    // products staged in LDS at a time (4 per thread)
+constexpr int kMaxRowLen = 255;    // longer rows take the long-row path
+constexpr int kLongSeg = 8192;     // nonzeros per segment of a long row
+constexpr int kMaxWorkgroups = 1280; // 5 per CU: all co-resident (20 waves/CU)
+constexpr int kMaxPartials = 2048; // upper bound on grid size of reducing kernels
+constexpr int kMaxRT = 8;          // rows per thread per round
+
+struct GatherView {                // passed to kernels by value
+    int nrows, ncols;
+    int P, G, RT, Q;               // phases, workgroups, rows/thread, rounds
+    int RWrows;                    // rows owned by a workgroup per round (<= kBlock*RT)
+    const int* step_ptr;           // [Q*P*G+1] first entry of each step
+    // per-workgroup chunk table: the non-empty steps of (round q, workgroup w) cut into
+    // chunks of at most kChunkNnz entries, in phase order
+    const int* wg_chunk_ptr;       // [Q*G+1]
+    const int* chunk_start;        // first entry of the chunk
+    const int* chunk_info;         // # entries | (first chunk of its step) << 30
+    const int* chunk_step;         // step index (addresses the counts)
+    const unsigned char* counts;   // [Q*P*G*kBlock*RT] entries per (row, phase)
+    const int* idx;                // [nnz_short] gathered index
+    const double* val;             // [nnz_short]
+    const unsigned char* row_long; // [nrows] 1 for long rows, nullptr if there are none
+    // long rows
+    int nseg;                      // # segments (= workgroups of the long kernel)
+    const int* seg_p0;             // [nseg] first entry in lidx/lval
+    const int* seg_p1;
+    const int* lidx;
+    const double* lval;
+    int nlong;                     // # long rows
+    const int* long_row;           // [nlong] row index
+    const int* long_slot;          // [nlong+1] segment range of each long row
+    double* long_partials;         // [nseg]
+    unsigned long long* stamps;    // tuning aid: wall clock at the start of each step (or nullptr)
+};
+
+struct GatherMatrix {
+    int nrows = 0, ncols = 0;
+    int64_t nnz = 0;
+    int P = 1, G = 1, RT = 1, Q = 1, RWrows = kBlock;
+    DevBuf<int> step_ptr, idx, wg_chunk_ptr, chunk_start, chunk_info, chunk_step;
+    DevBuf<unsigned char> counts, row_long;
+    DevBuf<double> val;
+    int nseg = 0, nlong = 0;
+    DevBuf<int> seg_p0, seg_p1, lidx, long_row, long_slot;
+    DevBuf<double> lval, long_partials;
+    DevBuf<unsigned long long> stamps;   // allocated only when IPXK_STAMPS=1
+    // optional copy in plain row order (ptr/idx/val) for callers that address single rows
+    bool keep_plain = false;
+    std::vector<int> h_plain_ptr;
+    DevBuf<int> plain_idx;
+    DevBuf<double> plain_val;
+
+    // Builds from host arrays with 64-bit indices (ptr has nrows+1 entries).
+    void build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, const ipxint* hidx,
+               const double* hval, hipStream_t s);
+    GatherView view() const;
+    int grid() const { return G; }
+    // # dot partials a launch produces
+    int num_partials() const { return G + (nlong > 0 ? 1 : 0); }
+};
+
+// elements of the gathered vector per phase (IPXK_SLICE_KB overrides, default 1 MiB)
+int slice_elems();
+
+// ---------------------------------------------------------------------------
+// CR loop state kept on the device (see cr.hip)
+// ---------------------------------------------------------------------------
+struct CrState {
+    double tol;
+    long long maxiter;
+    long long k_started;     // written by the control kernel, read by the others
+    long long k_finished;    // written by the direction-update kernel
+    double cdot[2];          // indexed by iteration parity
+    double rps[2];           // resnorm_precond_system, indexed by (iter/5) parity
+    double resnorm;          // residual norm at the last loop head
+    long long iter;          // result: # iterations
+    int errflag;             // result
+    int done;
+    long long hist_cap;
+};
+
+// ---------------------------------------------------------------------------
+// level-scheduled triangular factor (see trisolve.hip)
+// ---------------------------------------------------------------------------
+struct LevelSweep {
+    // Rows renumbered by level: position k in [0,dim) is row order[k].
+    int dim = 0, nlevels = 0;
+    int64_t nnz = 0;
+    DevBuf<int> order, ptr, idx;   // ptr[dim+1] over level-ordered rows; idx = original unknown index
+    DevBuf<double> val, diag;      // off-diagonal values; diag[k] (1.0 when unit)
+    DevBuf<int> valsrc;            // source position of each val in the factor's value array
+    DevBuf<int> diagsrc;           // source position of diag, -1 when unit
+    std::vector<int> level_ptr;    // host: [nlevels+1] positions
+    // launch plan: one entry per kernel launch
+    struct Launch { int k0, k1, l0, l1; bool tail; };
+    std::vector<Launch> plan;
+    DevBuf<int> level_ptr_dev;
+    bool unitdiag = false;
+};
+
+struct Context;
+void cr_set_error_from_exception(Context*);
+
+}  // namespace ipxk

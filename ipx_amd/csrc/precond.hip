@@ -1,0 +1,280 @@
+// DiagonalPrecond on the device                reference src/diagonal_precond.cc
+//   Factorize (:17-111): diagonal = W_I + sum_j W_j a_ij^2 over non-dense columns as a
+//     row-gather SpMV; with dense columns the k x k Schur complement
+//     S = inv(Wd) + Ad' inv(E) Ad is assembled column by column with the same SpMV
+//     kernel and factorized by an in-library dense Cholesky (the GPU box has no LAPACK).
+//   _Apply (:121-159): lhs = rhs ./ diagonal, or the Sherman-Morrison-Woodbury form.
+#include "context.hpp"
+#include "spmv_kernels.hpp"
+
+namespace ipxk {
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+// lhs = rhs ./ diag, partial[block] = sum lhs*rhs            (:151-155)
+__global__ __launch_bounds__(kBlock) void diag_apply_kernel(int m, const double* __restrict__ rhs,
+                                                            const double* __restrict__ diag,
+                                                            double* __restrict__ lhs,
+                                                            double* partial, const int* done) {
+    if (done && *done) return;
+    __shared__ double red[kBlock / 64 + 1];
+    double acc = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock) {
+        const double r = rhs[i];
+        const double l = r / diag[i];
+        lhs[i] = l;
+        acc += l * r;
+    }
+    acc = block_reduce<SumOp>(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// u = rhs ./ diag                                            (:136)
+__global__ void divide_kernel(int m, const double* __restrict__ rhs, const double* __restrict__ diag,
+                              double* __restrict__ u, const int* done) {
+    if (done && *done) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
+        u[i] = rhs[i] / diag[i];
+}
+
+__global__ void copy_mask_kernel(int n, const double* __restrict__ W,
+                                 const unsigned char* __restrict__ is_dense, double* __restrict__ out) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        out[j] = is_dense[j] ? 0.0 : W[j];
+}
+
+// u[Ai[p]] = set ? Ax[p]/diag[Ai[p]] : 0 over one column         (:76-78)
+__global__ void column_scatter_kernel(int p0, int p1, const int* __restrict__ idx,
+                                      const double* __restrict__ val,
+                                      const double* __restrict__ diag, double* __restrict__ u,
+                                      int set) {
+    for (int p = p0 + blockIdx.x * blockDim.x + threadIdx.x; p < p1; p += gridDim.x * blockDim.x) {
+        const int i = idx[p];
+        u[i] = set ? val[p] / diag[i] : 0.0;
+    }
+}
+
+// S[c,c] += 1/W[dense_col[c]]                                     (:82-83)
+__global__ void schur_add_diag_kernel(int k, const int* __restrict__ dense_col,
+                                      const double* __restrict__ W, double* __restrict__ S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < k) S[c + (size_t)c * k] += 1.0 / W[dense_col[c]];
+}
+
+// Dense Cholesky A = L L' of the lower triangle, column major, one workgroup,
+// left-looking by columns (the arithmetic of LAPACK's unblocked dpotf2):
+// info = 0 or the 1-based index of the first non-positive pivot.
+__global__ __launch_bounds__(1024) void cholesky_lower_kernel(int k, double* __restrict__ a,
+                                                              int* info) {
+    __shared__ int fail;
+    __shared__ double pivot;
+    if (threadIdx.x == 0) fail = 0;
+    __syncthreads();
+    for (int j = 0; j < k; j++) {
+        // a[i,j] -= sum_{l<j} a[i,l]*a[j,l] for i >= j
+        for (int i = j + threadIdx.x; i < k; i += blockDim.x) {
+            double s = a[i + (size_t)j * k];
+            for (int l = 0; l < j; l++) s -= a[i + (size_t)l * k] * a[j + (size_t)l * k];
+            a[i + (size_t)j * k] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double d = a[j + (size_t)j * k];
+            if (!(d > 0.0)) fail = j + 1;
+            else { pivot = sqrt(d); a[j + (size_t)j * k] = pivot; }
+        }
+        __syncthreads();
+        if (fail) break;
+        const double d = pivot;
+        for (int i = j + 1 + threadIdx.x; i < k; i += blockDim.x) a[i + (size_t)j * k] /= d;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *info = fail;
+}
+
+// Solves L L' x = b in place for k <= 64 inside one wavefront: lane i owns b[i];
+// each elimination step broadcasts the newly fixed unknown with a shuffle.
+__global__ __launch_bounds__(64) void potrs_wave_kernel(int k, const double* __restrict__ a,
+                                                        double* __restrict__ b, const int* done) {
+    if (done && *done) return;
+    const int i = threadIdx.x;
+    double bi = i < k ? b[i] : 0.0;
+    for (int l = 0; l < k; l++) {                  // L z = b
+        const double dl = a[l + (size_t)l * k];
+        const double zl = __shfl(bi, l, 64) / dl;
+        if (i == l) bi = zl;
+        else if (i > l && i < k) bi -= a[i + (size_t)l * k] * zl;
+    }
+    for (int l = k - 1; l >= 0; l--) {             // L' x = z
+        const double dl = a[l + (size_t)l * k];
+        const double xl = __shfl(bi, l, 64) / dl;
+        if (i == l) bi = xl;
+        else if (i < l) bi -= a[l + (size_t)i * k] * xl;
+    }
+    if (i < k) b[i] = bi;
+}
+
+// Same for 64 < k <= 1000, one workgroup, column-oriented substitution.
+__global__ __launch_bounds__(1024) void potrs_block_kernel(int k, const double* __restrict__ a,
+                                                           double* __restrict__ b, const int* done) {
+    if (done && *done) return;
+    extern __shared__ double x[];
+    for (int i = threadIdx.x; i < k; i += blockDim.x) x[i] = b[i];
+    __syncthreads();
+    for (int l = 0; l < k; l++) {
+        if (threadIdx.x == 0) x[l] /= a[l + (size_t)l * k];
+        __syncthreads();
+        const double xl = x[l];
+        for (int i = l + 1 + threadIdx.x; i < k; i += blockDim.x) x[i] -= a[i + (size_t)l * k] * xl;
+        __syncthreads();
+    }
+    for (int l = k - 1; l >= 0; l--) {
+        if (threadIdx.x == 0) x[l] /= a[l + (size_t)l * k];
+        __syncthreads();
+        const double xl = x[l];
+        for (int i = threadIdx.x; i < l; i += blockDim.x) x[i] -= a[l + (size_t)i * k] * xl;
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < k; i += blockDim.x) b[i] = x[i];
+}
+
+static int vec_grid(int64_t len) {
+    int64_t g = (len + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    return (int)(g < 1024 ? g : 1024);
+}
+
+// ---------------------------------------------------------------------------
+// Factorize
+// ---------------------------------------------------------------------------
+static void build_dense_structures(Context* c) {
+    // Ad as "rows = dense columns" (CopyColumns) and its transpose Atdense
+    // (src/diagonal_precond.cc:59-65), both host-built once per model.
+    const int64_t k = (int64_t)c->dense_cols.size(), m = c->m;
+    if (c->AdCols.nrows == k && c->AdRows.nrows == m && k > 0) return;
+    std::vector<ipxint> Cp(k + 1, 0), Ci;
+    std::vector<double> Cx;
+    for (int64_t kk = 0; kk < k; kk++) {
+        const ipxint j = c->dense_cols[kk];
+        for (ipxint p = c->h_Ap[j]; p < c->h_Ap[j + 1]; p++) {
+            Ci.push_back(c->h_Ai[p]);
+            Cx.push_back(c->h_Ax[p]);
+        }
+        Cp[kk + 1] = (ipxint)Ci.size();
+    }
+    // transpose (counting sort, ascending dense-column position within a row)
+    std::vector<ipxint> Tp(m + 1, 0), Ti(Ci.size());
+    std::vector<double> Tx(Ci.size());
+    for (ipxint i : Ci) Tp[i + 1]++;
+    for (int64_t i = 0; i < m; i++) Tp[i + 1] += Tp[i];
+    std::vector<ipxint> next(Tp.begin(), Tp.end() - 1);
+    for (int64_t kk = 0; kk < k; kk++)
+        for (ipxint p = Cp[kk]; p < Cp[kk + 1]; p++) {
+            const ipxint put = next[Ci[p]]++;
+            Ti[put] = kk;
+            Tx[put] = Cx[p];
+        }
+    c->AdCols.keep_plain = true;
+    c->AdCols.build(k, m, Cp.data(), Ci.data(), Cx.data(), c->stream);
+    c->AdRows.build(m, k, Tp.data(), Ti.data(), Tx.data(), c->stream);
+    c->chol.resize((size_t)k * k);
+    c->smw_work.resize(k);
+    c->smw_u.resize(m);
+    c->chol_info.resize(1);
+}
+
+void diag_factorize_dev(Context* c, const double* W, bool precond_dense_cols, ipxint* errflag) {
+    const int64_t m = c->m, n = c->n;
+    hipStream_t s = c->stream;
+    *errflag = 0;
+    c->diag_factorized = false;
+    c->diagonal.resize(m);
+    const bool smw = precond_dense_cols && c->num_dense > 0;
+    const double* Wcols = W;
+    if (smw) {
+        c->Wnodense.resize(n);
+        if (c->dense_mask.size() != (size_t)n) {
+            std::vector<unsigned char> mask(n, 0);
+            for (ipxint j : c->dense_cols) mask[j] = 1;
+            c->dense_mask.upload(mask, s);
+            IPXK_HIP(hipStreamSynchronize(s));
+        }
+        hipLaunchKernelGGL(copy_mask_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, s, (int)n, W,
+                           c->dense_mask.get(), c->Wnodense.get());
+        Wcols = c->Wnodense.get();
+    }
+    // :28-46
+    EpiDiagonal ed{{}, W + n, c->diagonal.get()};
+    launch_spmv(c->Arows, Wcols, ed, nullptr, nullptr, s);
+    c->kdense = 0;
+    if (smw) {
+        build_dense_structures(c);
+        const int k = (int)c->dense_cols.size();
+        // :68-85 Schur complement, one column per dense column
+        IPXK_HIP(hipMemsetAsync(c->smw_u.get(), 0, sizeof(double) * m, s));
+        std::vector<int> dc(k);
+        for (int kk = 0; kk < k; kk++) dc[kk] = (int)c->dense_cols[kk];
+        DevBuf<int> dcols;
+        dcols.upload(dc, s);
+        for (int kk = 0; kk < k; kk++) {
+            const int p0 = c->AdCols.h_plain_ptr[kk], p1 = c->AdCols.h_plain_ptr[kk + 1];
+            const int g = vec_grid(p1 - p0);
+            hipLaunchKernelGGL(column_scatter_kernel, dim3(g), dim3(kBlock), 0, s, p0, p1,
+                               c->AdCols.plain_idx.get(), c->AdCols.plain_val.get(), c->diagonal.get(),
+                               c->smw_u.get(), 1);
+            EpiScale es{{}, nullptr, c->chol.get() + (size_t)kk * k};
+            launch_spmv(c->AdCols, c->smw_u.get(), es, nullptr, nullptr, s);
+            hipLaunchKernelGGL(column_scatter_kernel, dim3(g), dim3(kBlock), 0, s, p0, p1,
+                               c->AdCols.plain_idx.get(), c->AdCols.plain_val.get(), c->diagonal.get(),
+                               c->smw_u.get(), 0);
+        }
+        hipLaunchKernelGGL(schur_add_diag_kernel, dim3((k + 63) / 64), dim3(64), 0, s, k, dcols.get(),
+                           W, c->chol.get());
+        // :88-92
+        hipLaunchKernelGGL(cholesky_lower_kernel, dim3(1), dim3(k <= 64 ? 64 : 1024), 0, s, k,
+                           c->chol.get(), c->chol_info.get());
+        int info = 0;
+        c->chol_info.download(&info, 1, s);
+        IPXK_HIP(hipStreamSynchronize(s));
+        if (info != 0) {
+            *errflag = 401;  // IPX_ERROR_lapack_chol
+            return;
+        }
+        c->kdense = k;
+    }
+    IPXK_HIP(hipGetLastError());
+    c->diag_factorized = true;
+}
+
+// ---------------------------------------------------------------------------
+// Apply
+// ---------------------------------------------------------------------------
+int diag_apply_dev(Context* c, const double* rhs, double* lhs, int slot, const int* done) {
+    const int m = (int)c->m;
+    hipStream_t s = c->stream;
+    if (c->kdense == 0) {
+        const int g = vec_grid(m);
+        hipLaunchKernelGGL(diag_apply_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs,
+                           c->diagonal.get(), lhs, c->part(slot), done);
+        return g;
+    }
+    const int k = (int)c->kdense;
+    // :135-137 work = Ad' * (rhs ./ diagonal)
+    hipLaunchKernelGGL(divide_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, m, rhs,
+                       c->diagonal.get(), c->smw_u.get(), done);
+    EpiScale es{{}, nullptr, c->smw_work.get()};
+    launch_spmv(c->AdCols, c->smw_u.get(), es, nullptr, done, s);
+    // :140-141
+    if (k <= 64)
+        hipLaunchKernelGGL(potrs_wave_kernel, dim3(1), dim3(64), 0, s, k, c->chol.get(),
+                           c->smw_work.get(), done);
+    else
+        hipLaunchKernelGGL(potrs_block_kernel, dim3(1), dim3(1024), sizeof(double) * k, s, k,
+                           c->chol.get(), c->smw_work.get(), done);
+    // :145-149
+    EpiSmwRows er{{}, rhs, c->diagonal.get(), lhs};
+    return launch_spmv(c->AdRows, c->smw_work.get(), er, c->part(slot), done, s);
+}
+
+}  // namespace ipxk

@@ -1,0 +1,270 @@
+// Gather-matrix construction (host) and the NormalMatrix product
+//   lhs = AI * W * AI' * rhs                 reference src/normal_matrix.cc:45-126
+// as two row-gather SpMVs:  t = Ws .* (A' rhs);  lhs = W_I .* rhs + A t  with the
+// dot product rhs'lhs fused into the second pass (src/normal_matrix.cc:123-124).
+#include <algorithm>
+#include <cstdlib>
+
+#include "context.hpp"
+#include "spmv_kernels.hpp"
+
+namespace ipxk {
+
+// ---------------------------------------------------------------------------
+// GatherMatrix
+// ---------------------------------------------------------------------------
+int slice_elems() {
+    static int cached = 0;
+    if (!cached) {
+        int kb = 1024;
+        if (const char* e = getenv("IPXK_SLICE_KB")) kb = atoi(e) > 0 ? atoi(e) : kb;
+        cached = kb * 128;   // doubles
+    }
+    return cached;
+}
+
+void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, const ipxint* hidx,
+                         const double* hval, hipStream_t s) {
+    IPXK_REQUIRE(nrows_ >= 0 && ncols_ >= 0, "negative dimension");
+    IPXK_REQUIRE(nrows_ < (int64_t(1) << 31) - 1 && ncols_ < (int64_t(1) << 31) - 1,
+                 "dimension exceeds 32-bit device indices");
+    const int64_t nz = hptr[nrows_];
+    IPXK_REQUIRE(nz < (int64_t(1) << 31) - kLongSeg, "nnz exceeds 32-bit device indices");
+    nrows = (int)nrows_;
+    ncols = (int)ncols_;
+    nnz = nz;
+
+    // geometry
+    const int slice = slice_elems();
+    P = (int)std::max<int64_t>(1, (ncols_ + slice - 1) / slice);
+    int maxwg = kMaxWorkgroups;
+    if (const char* e = getenv("IPXK_MAX_WG")) maxwg = atoi(e) > 0 ? atoi(e) : maxwg;
+    G = (int)std::min<int64_t>(maxwg, std::max<int64_t>(1, (nrows_ + kBlock - 1) / kBlock));
+    RT = 1;
+    while (RT < kMaxRT && (int64_t)G * kBlock * RT < nrows_) RT *= 2;
+    const int64_t RW = (int64_t)kBlock * RT;     // count slots per step
+    // rows a workgroup owns per round: all RW slots, or -- for matrices too small to give
+    // every CU several workgroups that way -- fewer (threads without a row still stream)
+    RWrows = (int)RW;
+    if (RT == 1 && nrows_ < (int64_t)kBlock * maxwg) {
+        const int64_t want = (nrows_ + maxwg - 1) / maxwg;
+        RWrows = (int)std::min<int64_t>(kBlock, std::max<int64_t>(32, (want + 31) / 32 * 32));
+    }
+    G = (int)std::max<int64_t>(1, std::min<int64_t>(maxwg, (nrows_ + RWrows - 1) / RWrows));
+    Q = (int)std::max<int64_t>(1, (nrows_ + (int64_t)G * RWrows - 1) / ((int64_t)G * RWrows));
+    const int64_t nsteps = (int64_t)Q * P * G;
+    IPXK_REQUIRE(nsteps * RW < (int64_t(1) << 40), "matrix too large for the phased layout");
+
+    // long rows
+    std::vector<unsigned char> rlong;
+    std::vector<int> sp0, sp1, lrow, lslot, li;
+    std::vector<double> lv;
+    for (int r = 0; r < nrows; r++) {
+        const int64_t len = hptr[r + 1] - hptr[r];
+        if (len <= kMaxRowLen) continue;
+        if (rlong.empty()) rlong.assign(nrows, 0);
+        rlong[r] = 1;
+        lrow.push_back(r);
+        lslot.push_back((int)sp0.size());
+        for (int64_t q0 = hptr[r]; q0 < hptr[r + 1]; q0 += kLongSeg) {
+            const int64_t q1 = std::min<int64_t>(q0 + kLongSeg, hptr[r + 1]);
+            sp0.push_back((int)li.size());
+            for (int64_t p = q0; p < q1; p++) { li.push_back((int)hidx[p]); lv.push_back(hval[p]); }
+            sp1.push_back((int)li.size());
+        }
+    }
+    lslot.push_back((int)sp0.size());
+    nlong = (int)lrow.size();
+    nseg = (int)sp0.size();
+
+    // counts per (row, phase) and step sizes
+    std::vector<unsigned char> cnt((size_t)nsteps * RW, 0);
+    std::vector<int> sptr(nsteps + 1, 0);
+    auto step_of = [&](int r, int p, int64_t& lr) {
+        const int64_t per = (int64_t)G * RWrows;
+        const int64_t q = r / per, rem = r % per;
+        const int64_t w = rem / RWrows;
+        lr = rem % RWrows;
+        return (q * P + p) * G + w;
+    };
+    for (int r = 0; r < nrows; r++) {
+        if (!rlong.empty() && rlong[r]) continue;
+        for (int64_t p = hptr[r]; p < hptr[r + 1]; p++) {
+            int64_t lr;
+            const int64_t st = step_of(r, (int)(hidx[p] / slice), lr);
+            cnt[(size_t)st * RW + lr]++;
+            sptr[st + 1]++;
+        }
+    }
+    for (int64_t st = 0; st < nsteps; st++) sptr[st + 1] += sptr[st];
+    const int64_t nshort = sptr[nsteps];
+    std::vector<int> i32((size_t)std::max<int64_t>(nshort, 1));
+    std::vector<double> v64((size_t)std::max<int64_t>(nshort, 1));
+    {
+        std::vector<int> cursor(sptr.begin(), sptr.end() - 1);
+        for (int r = 0; r < nrows; r++) {
+            if (!rlong.empty() && rlong[r]) continue;
+            for (int64_t p = hptr[r]; p < hptr[r + 1]; p++) {
+                int64_t lr;
+                const int64_t st = step_of(r, (int)(hidx[p] / slice), lr);
+                const int put = cursor[st]++;
+                i32[put] = (int)hidx[p];
+                v64[put] = hval[p];
+            }
+        }
+    }
+
+    // chunk table
+    std::vector<int> wcp((size_t)Q * G + 1, 0), cst, cinf, cstep;
+    for (int q = 0; q < Q; q++)
+        for (int w = 0; w < G; w++) {
+            for (int p = 0; p < P; p++) {
+                const int64_t st = ((int64_t)q * P + p) * G + w;
+                for (int c0 = sptr[st]; c0 < sptr[st + 1]; c0 += kChunkNnz) {
+                    cst.push_back(c0);
+                    cinf.push_back(std::min(kChunkNnz, sptr[st + 1] - c0) | (c0 == sptr[st] ? (1 << 30) : 0));
+                    cstep.push_back((int)st);
+                }
+            }
+            wcp[(size_t)q * G + w + 1] = (int)cst.size();
+        }
+    for (int pad = 0; pad < 4; pad++) { cst.push_back(0); cinf.push_back(0); cstep.push_back(0); }
+    wg_chunk_ptr.upload(wcp, s);
+    chunk_start.upload(cst, s);
+    chunk_info.upload(cinf, s);
+    chunk_step.upload(cstep, s);
+    step_ptr.upload(sptr, s);
+    counts.upload(cnt, s);
+    idx.upload(i32, s);
+    val.upload(v64, s);
+    if (nlong > 0) {
+        row_long.upload(rlong, s);
+        seg_p0.upload(sp0, s);
+        seg_p1.upload(sp1, s);
+        lidx.upload(li, s);
+        lval.upload(lv, s);
+        long_row.upload(lrow, s);
+        long_slot.upload(lslot, s);
+    }
+    long_partials.resize(nseg > 0 ? nseg : 1);
+    if (getenv("IPXK_STAMPS")) stamps.resize((size_t)nsteps + G);
+    if (keep_plain) {
+        h_plain_ptr.resize(nrows + 1);
+        std::vector<int> pi((size_t)std::max<int64_t>(nz, 1));
+        for (int r = 0; r <= nrows; r++) h_plain_ptr[r] = (int)hptr[r];
+        for (int64_t p = 0; p < nz; p++) pi[p] = (int)hidx[p];
+        plain_idx.upload(pi, s);
+        plain_val.upload(hval, (size_t)nz, s);
+    }
+    IPXK_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
+}
+
+GatherView GatherMatrix::view() const {
+    GatherView V;
+    V.nrows = nrows; V.ncols = ncols;
+    V.P = P; V.G = G; V.RT = RT; V.Q = Q; V.RWrows = RWrows;
+    V.step_ptr = step_ptr.get(); V.counts = counts.get();
+    V.wg_chunk_ptr = wg_chunk_ptr.get(); V.chunk_start = chunk_start.get();
+    V.chunk_info = chunk_info.get(); V.chunk_step = chunk_step.get();
+    V.idx = idx.get(); V.val = val.get();
+    V.row_long = nlong > 0 ? row_long.get() : nullptr;
+    V.nseg = nseg; V.seg_p0 = seg_p0.get(); V.seg_p1 = seg_p1.get();
+    V.lidx = lidx.get(); V.lval = lval.get();
+    V.nlong = nlong; V.long_row = long_row.get(); V.long_slot = long_slot.get();
+    V.long_partials = long_partials.get();
+    V.stamps = stamps.size() ? stamps.get() : nullptr;
+    return V;
+}
+
+// ---------------------------------------------------------------------------
+// model upload
+// ---------------------------------------------------------------------------
+// Row-wise copy by counting sort, entries of a row in ascending source-column
+// order -- the index arithmetic of Transpose (src/sparse_matrix.cc:120-151).
+static void transpose_host(int64_t nrow, int64_t ncol, const ipxint* Ap, const ipxint* Ai,
+                           const double* Ax, std::vector<ipxint>& Tp, std::vector<ipxint>& Ti,
+                           std::vector<double>& Tx) {
+    const int64_t nz = Ap[ncol];
+    Tp.assign(nrow + 1, 0);
+    Ti.resize(nz);
+    Tx.resize(nz);
+    for (int64_t p = 0; p < nz; p++) Tp[Ai[p] + 1]++;
+    for (int64_t i = 0; i < nrow; i++) Tp[i + 1] += Tp[i];
+    std::vector<ipxint> next(Tp.begin(), Tp.end() - 1);
+    for (int64_t j = 0; j < ncol; j++)
+        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+            const int64_t put = next[Ai[p]]++;
+            Ti[put] = j;
+            Tx[put] = Ax[p];
+        }
+}
+
+// Dense-column classification of Model::FindDenseColumns (src/model.cc:34-56).
+static void find_dense_columns(Context* c) {
+    const int64_t n = c->n, m = c->m;
+    c->num_dense = 0;
+    c->nz_dense = m + 1;
+    std::vector<ipxint> cnt(n);
+    for (int64_t j = 0; j < n; j++) cnt[j] = c->h_Ap[j + 1] - c->h_Ap[j];
+    std::sort(cnt.begin(), cnt.end());
+    for (int64_t j = 1; j < n; j++) {
+        if (cnt[j] > std::max<ipxint>(40, 10 * cnt[j - 1])) {
+            c->num_dense = n - j;
+            c->nz_dense = cnt[j];
+            break;
+        }
+    }
+    if (c->num_dense > 1000) {
+        c->num_dense = 0;
+        c->nz_dense = m + 1;
+    }
+    c->dense_cols.clear();
+    for (int64_t j = 0; j < n; j++)
+        if (c->h_Ap[j + 1] - c->h_Ap[j] >= c->nz_dense) c->dense_cols.push_back(j);
+}
+
+void build_model(Context* c, const ipxint* Ap, const ipxint* Ai, const double* Ax) {
+    const int64_t m = c->m, n = c->n;
+    IPXK_REQUIRE(Ap[0] == 0, "colptr[0] must be 0");
+    const int64_t nz = Ap[n];
+    for (int64_t j = 0; j < n; j++) IPXK_REQUIRE(Ap[j] <= Ap[j + 1], "colptr not monotone");
+    for (int64_t p = 0; p < nz; p++) IPXK_REQUIRE(Ai[p] >= 0 && Ai[p] < m, "row index out of range");
+    c->nnz = nz;
+    c->h_Ap.assign(Ap, Ap + n + 1);
+    c->h_Ai.assign(Ai, Ai + nz);
+    c->h_Ax.assign(Ax, Ax + nz);
+    transpose_host(m, n, Ap, Ai, Ax, c->h_ATp, c->h_ATi, c->h_ATx);
+    c->Acols.build(n, m, c->h_Ap.data(), c->h_Ai.data(), c->h_Ax.data(), c->stream);
+    c->Arows.build(m, n, c->h_ATp.data(), c->h_ATi.data(), c->h_ATx.data(), c->stream);
+    find_dense_columns(c);
+    c->tcols.resize(n > 0 ? n : 1);
+}
+
+// ---------------------------------------------------------------------------
+// NormalMatrix::_Apply on device vectors
+// ---------------------------------------------------------------------------
+// W: device pointer to n+m weights.  Dot partials go to part(kPartCdot); *ndot
+// receives their count (nullptr: no dot product wanted).
+void normal_apply_dev(Context* c, const double* W, const double* rhs, double* lhs, int* ndot,
+                      const int* done) {
+    const int64_t n = c->n;
+    EpiScale e1{{}, W, c->tcols.get()};
+    launch_spmv(c->Acols, rhs, e1, nullptr, done, c->stream);
+    if (c->nranks > 1) comm_allreduce_sum(c, c->tcols.get(), (size_t)n);
+    EpiNormalRows e2{{}, W + n, rhs, lhs};
+    const int np = launch_spmv(c->Arows, c->tcols.get(), e2, ndot ? c->part(kPartCdot) : nullptr,
+                               done, c->stream);
+    if (ndot) *ndot = np;
+}
+
+void debug_single_pass(Context* c, int which, const double* x, double* out) {
+    if (which == 1) {
+        EpiScale e1{{}, c->W, out};
+        launch_spmv(c->Acols, x, e1, nullptr, nullptr, c->stream);
+    } else {
+        EpiNormalRows e2{{}, c->W + c->n, out, out};   // y := out (only timing matters)
+        launch_spmv(c->Arows, x, e2, nullptr, nullptr, c->stream);
+    }
+}
+
+}  // namespace ipxk

@@ -1,0 +1,333 @@
+// Row-gather SpMV for gfx950: out[r] = finish(init(r) (+|-) sum_p prod(x[idx[p]], val[p])).
+//
+// One kernel serves every sparse product on the path (A'y, A t, diag(A W A'),
+// right-hand-side assembly, solution recovery, the dense-column SMW terms and
+// N N') through small epilogue functors.  HBM-bound: per nonzero it moves a
+// 4-byte index and an 8-byte value exactly once with coalesced loads (lane i
+// reads element base+i), the x gather is served by L2 / Infinity Cache.
+//
+// Summation order inside a row is the storage order (one thread adds the row's
+// LDS-staged products sequentially), which is the reference's order:
+//   * pass 1 of NormalMatrix::_Apply, d += rhs[Ai[p]]*Ax[p] (normal_matrix.cc:69-70)
+//   * pass 2 equals the reference's one-pass scatter because row i of the
+//     row-wise copy lists columns in ascending order (normal_matrix.cc:65-74).
+// Products are rounded before they are added (they pass through LDS and the
+// library is built with -ffp-contract=off), like the reference's x86 -O2 build.
+#pragma once
+
+#include "device_utils.hpp"
+#include "internal.hpp"
+
+namespace ipxk {
+
+constexpr int kLdsDoubles = kChunkNnz + kChunkNnz / 32;
+
+// +1 double of padding per 32: rows of equal length 8 (stride 64 B) would
+// otherwise hit 4 of the 64 LDS banks 8 ways in the per-row read phase.
+__device__ __forceinline__ int lds_slot(int q) { return q + (q >> 5); }
+
+// ---- epilogues ---------------------------------------------------------------
+struct ProdMul {
+    static __device__ __forceinline__ double prod(double xg, double v) { return xg * v; }
+};
+// (v * w) * v, the evaluation order of diagonal_precond.cc:37
+struct ProdSquareWeighted {
+    static __device__ __forceinline__ double prod(double xg, double v) { return (v * xg) * v; }
+};
+
+// out[r] = acc * w[r]  (w == nullptr: out[r] = acc)
+struct EpiScale : ProdMul {
+    const double* w; double* out;
+    static constexpr bool kNeg = false;
+    __device__ __forceinline__ double init(int) const { return 0.0; }
+    __device__ __forceinline__ void finish(int r, double acc, double&) const {
+        out[r] = w ? acc * w[r] : acc;
+    }
+};
+// out[r] = y[r]*wI[r] + acc, dot += y[r]*out[r]   (wI == nullptr: no slack term)
+struct EpiNormalRows : ProdMul {
+    const double* wI; const double* y; double* out;
+    static constexpr bool kNeg = false;
+    __device__ __forceinline__ double init(int r) const { return wI ? y[r] * wI[r] : 0.0; }
+    __device__ __forceinline__ void finish(int r, double acc, double& dot) const {
+        out[r] = acc;
+        dot += y[r] * acc;
+    }
+};
+// out[r] = wI[r] + sum (v*w)*v
+struct EpiDiagonal : ProdSquareWeighted {
+    const double* wI; double* out;
+    static constexpr bool kNeg = false;
+    __device__ __forceinline__ double init(int r) const { return wI ? wI[r] : 0.0; }
+    __device__ __forceinline__ void finish(int r, double acc, double&) const { out[r] = acc; }
+};
+// out[r] = (-b[r] + acc) + wI[r]*aI[r]          (kkt_solver_diag.cc:90-92)
+struct EpiKktRhs : ProdMul {
+    const double* b; const double* wI; const double* aI; double* out;
+    static constexpr bool kNeg = false;
+    __device__ __forceinline__ double init(int r) const { return -b[r]; }
+    __device__ __forceinline__ void finish(int r, double acc, double&) const {
+        out[r] = acc + wI[r] * aI[r];
+    }
+};
+// out[j] = w[j]*(a[j] - acc)                     (kkt_solver_diag.cc:111-112)
+struct EpiRecoverX : ProdMul {
+    const double* w; const double* a; double* out;
+    static constexpr bool kNeg = false;
+    __device__ __forceinline__ double init(int) const { return 0.0; }
+    __device__ __forceinline__ void finish(int j, double acc, double&) const {
+        out[j] = w[j] * (a[j] - acc);
+    }
+};
+// out[i] = b[i] - sum                            (kkt_solver_diag.cc:108-116)
+struct EpiResidualRows : ProdMul {
+    const double* b; double* out;
+    static constexpr bool kNeg = true;
+    __device__ __forceinline__ double init(int r) const { return b[r]; }
+    __device__ __forceinline__ void finish(int r, double acc, double&) const { out[r] = acc; }
+};
+// out[r] = (rhs[r] - acc)/diag[r], dot += out[r]*rhs[r]   (diagonal_precond.cc:145-149)
+struct EpiSmwRows : ProdMul {
+    const double* rhs; const double* diag; double* out;
+    static constexpr bool kNeg = false;
+    __device__ __forceinline__ double init(int) const { return 0.0; }
+    __device__ __forceinline__ void finish(int r, double acc, double& dot) const {
+        const double d = rhs[r] - acc;
+        const double l = d / diag[r];
+        out[r] = l;
+        dot += l * rhs[r];
+    }
+};
+// out[j] = mask[j] * scale2[j] * (a[j] - acc)    (kkt_solver_basis.cc:101-120,178-188)
+struct EpiBasisColumns : ProdMul {
+    const double* scale2;   // colscale^2 on nonbasic columns, 0 elsewhere
+    const double* a; double* out;
+    static constexpr bool kNeg = false;
+    __device__ __forceinline__ double init(int) const { return 0.0; }
+    __device__ __forceinline__ void finish(int j, double acc, double&) const {
+        const double s = scale2[j];
+        out[j] = s != 0.0 ? (a[j] - acc) * s : 0.0;
+    }
+};
+// out[i] = base[i] + sign*(acc + tI[i])
+struct EpiBasisRows : ProdMul {
+    const double* base; const double* tI; double sign; double* out;
+    static constexpr bool kNeg = false;
+    __device__ __forceinline__ double init(int) const { return 0.0; }
+    __device__ __forceinline__ void finish(int i, double acc, double&) const {
+        const double v = acc + tI[i];
+        out[i] = (base ? base[i] : 0.0) + sign * v;
+    }
+};
+
+// ---- the kernels ---------------------------------------------------------------
+template <int RT> struct CountWord;
+template <> struct CountWord<1> { typedef unsigned char type; };
+template <> struct CountWord<2> { typedef unsigned short type; };
+template <> struct CountWord<4> { typedef unsigned int type; };
+template <> struct CountWord<8> { typedef unsigned long long type; };
+
+// Time-tiled row-gather SpMV (layout: internal.hpp, GatherMatrix).  Workgroup w of G
+// co-resident workgroups walks the phases of its rows; all workgroups are in the same
+// phase at (roughly) the same time, so the slice of x being gathered stays in L2.
+//
+// Three-stage software pipeline over chunks of kChunkNnz entries: while chunk k's
+// products are staged in LDS and added to the row accumulators, the x gathers of chunk
+// k+1 and the coalesced (idx,val,count) stream loads of chunk k+2 are in flight, so
+// neither the HBM nor the L2 gather latency sits on the per-chunk critical path.
+// LDS is double-buffered: one barrier per chunk.
+constexpr int kPerThread = kChunkNnz / kBlock;
+
+template <class CW>
+struct ChunkLoad {          // stream loads of one chunk held in registers
+    int c[kPerThread];
+    double v[kPerThread];
+    CW cw;                  // row counts of the step (valid when the chunk opens a step)
+    int start, nn, first, step;
+};
+
+template <class CW, int RT>
+__device__ __forceinline__ void issue_stream(const GatherView& M, int k, int kend, int w, int tid,
+                                             ChunkLoad<CW>& L) {
+    L.nn = 0; L.first = 0; L.step = 0; L.start = 0; L.cw = 0;
+    if (k >= kend) {
+        // past the end: harmless indices so that the (unused) gathers stay in bounds
+#pragma unroll
+        for (int e = 0; e < kPerThread; e++) { L.c[e] = 0; L.v[e] = 0.0; }
+        return;
+    }
+    L.start = M.chunk_start[k];
+    const int info = M.chunk_info[k];
+    L.nn = info & 0xffffff;
+    L.first = info >> 30;
+    L.step = M.chunk_step[k];
+#pragma unroll
+    for (int e = 0; e < kPerThread; e++) {
+        const int qq = e * kBlock + tid;
+        const int pp = L.start + (qq < L.nn ? qq : 0);
+        L.c[e] = __builtin_nontemporal_load(M.idx + pp);
+        L.v[e] = __builtin_nontemporal_load(M.val + pp);
+    }
+    if (L.first)
+        L.cw = *reinterpret_cast<const CW*>(M.counts + (size_t)L.step * (kBlock * RT) + tid * RT);
+}
+
+template <class Epi, int RT>
+__global__ __launch_bounds__(kBlock, 5) void spmv_phased_kernel(GatherView M, const double* __restrict__ x,
+                                                             Epi epi, double* dot_partials,
+                                                             const int* done) {
+    if (done && *done) return;
+    typedef typename CountWord<RT>::type CW;
+    __shared__ double lds[2][kLdsDoubles];
+    __shared__ double red[kBlock / 64 + 1];
+    __shared__ int wave_total[2][kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = blockIdx.x;
+    double dotpart = 0.0;
+    if (M.stamps && tid == 0) {
+        // tuning aid: where this workgroup runs (XCC_ID = hwreg 20, HW_ID = hwreg 4)
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+        M.stamps[(size_t)M.Q * M.P * M.G + w] = ((unsigned long long)xcc << 32) | hw;
+    }
+
+    for (int q = 0; q < M.Q; q++) {
+        const int row0 = (q * M.G + w) * M.RWrows + tid * RT;
+        const int row_end = min(M.nrows, (q * M.G + w + 1) * M.RWrows);   // rows of this workgroup
+        double acc[RT];
+#pragma unroll
+        for (int u = 0; u < RT; u++) acc[u] = (row0 + u < row_end) ? epi.init(row0 + u) : 0.0;
+
+        const int kbeg = M.wg_chunk_ptr[q * M.G + w], kend = M.wg_chunk_ptr[q * M.G + w + 1];
+        ChunkLoad<CW> cur, nxt;
+        double xg[kPerThread];
+        issue_stream<CW, RT>(M, kbeg, kend, w, tid, cur);
+        issue_stream<CW, RT>(M, kbeg + 1, kend, w, tid, nxt);
+#pragma unroll
+        for (int e = 0; e < kPerThread; e++) xg[e] = x[cur.c[e]];   // gathers of chunk 0
+
+        int buf = 0, my_off = 0, step_n0 = 0;
+        CW cw_cur = 0;
+        __syncthreads();   // LDS buffers free (previous round)
+        for (int k = kbeg; k < kend; k++) {
+            if (M.stamps && tid == 0 && cur.first) M.stamps[cur.step] = wall_clock64();
+            // stage the products of chunk k (waits for its gathers only)
+#pragma unroll
+            for (int e = 0; e < kPerThread; e++) {
+                const int qq = e * kBlock + tid;
+                if (qq < cur.nn) lds[buf][lds_slot(qq)] = Epi::prod(xg[e], cur.v[e]);
+            }
+            // gathers of chunk k+1, stream loads of chunk k+2
+            const int cstart = cur.start, cnn = cur.nn, cfirst = cur.first;
+            const CW cwk = cur.cw;
+#pragma unroll
+            for (int e = 0; e < kPerThread; e++) xg[e] = x[nxt.c[e]];
+            cur = nxt;
+            issue_stream<CW, RT>(M, k + 2, kend, w, tid, nxt);
+
+            int incl = 0, tot = 0;
+            if (cfirst) {
+                // entries of my RT rows in this phase; my segment follows those of lower threads
+                cw_cur = cwk;
+                step_n0 = cstart;
+#pragma unroll
+                for (int u = 0; u < RT; u++) tot += (int)((cw_cur >> (8 * u)) & 0xff);
+                incl = tot;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int t = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += t;
+                }
+                if (lane == 63) wave_total[buf][wave] = incl;
+            }
+            __syncthreads();
+            if (cfirst) {
+                my_off = incl - tot;
+#pragma unroll
+                for (int ww = 0; ww < kBlock / 64; ww++) if (ww < wave) my_off += wave_total[buf][ww];
+            }
+            // add my rows' products that lie in this chunk, in storage order
+            int pos = my_off - (cstart - step_n0);
+#pragma unroll
+            for (int u = 0; u < RT; u++) {
+                const int cu = (int)((cw_cur >> (8 * u)) & 0xff);
+                for (int e = 0; e < cu; e++, pos++) {
+                    if (pos >= 0 && pos < cnn) {
+                        const double t = lds[buf][lds_slot(pos)];
+                        acc[u] = Epi::kNeg ? acc[u] - t : acc[u] + t;
+                    }
+                }
+            }
+            buf ^= 1;
+        }
+#pragma unroll
+        for (int u = 0; u < RT; u++) {
+            const int r = row0 + u;
+            if (r < row_end && !(M.row_long && M.row_long[r])) epi.finish(r, acc[u], dotpart);
+        }
+    }
+    if (dot_partials) {
+        const double d = block_reduce<SumOp>(dotpart, red);
+        if (tid == 0) dot_partials[blockIdx.x] = d;
+    }
+}
+
+// One segment of a long row per workgroup: strided per-thread sums, fixed block tree.
+template <class Epi>
+__global__ __launch_bounds__(kBlock) void spmv_long_kernel(GatherView M, const double* __restrict__ x,
+                                                           const int* done) {
+    if (done && *done) return;
+    __shared__ double red[kBlock / 64 + 1];
+    const int sgm = blockIdx.x;
+    double acc = 0.0;
+    for (int p = M.seg_p0[sgm] + threadIdx.x; p < M.seg_p1[sgm]; p += kBlock)
+        acc += Epi::prod(x[M.lidx[p]], __builtin_nontemporal_load(M.lval + p));
+    acc = block_reduce<SumOp>(acc, red);
+    if (threadIdx.x == 0) M.long_partials[sgm] = acc;
+}
+
+// Combines the segment sums of long rows in segment order and runs the epilogue;
+// its dot contribution goes to dot_partials[dot_slot].
+template <class Epi>
+__global__ __launch_bounds__(kBlock) void spmv_long_fixup_kernel(GatherView M, Epi epi,
+                                                                 double* dot_partials, int dot_slot,
+                                                                 const int* done) {
+    if (done && *done) return;
+    __shared__ double red[kBlock / 64 + 1];
+    double dotpart = 0.0;
+    for (int l = threadIdx.x; l < M.nlong; l += kBlock) {
+        const int r = M.long_row[l];
+        double acc = epi.init(r);
+        for (int s = M.long_slot[l]; s < M.long_slot[l + 1]; s++) {
+            const double t = M.long_partials[s];
+            acc = Epi::kNeg ? acc - t : acc + t;
+        }
+        epi.finish(r, acc, dotpart);
+    }
+    if (dot_partials) {
+        const double d = block_reduce<SumOp>(dotpart, red);
+        if (threadIdx.x == 0) dot_partials[dot_slot] = d;
+    }
+}
+
+// Launches the SpMV (+ long-row kernels when the matrix has long rows).  Returns
+// the number of dot partials written (0 when dot_partials == nullptr).
+template <class Epi>
+inline int launch_spmv(const GatherMatrix& M, const double* x, const Epi& epi, double* dot_partials,
+                       const int* done, hipStream_t s) {
+    const GatherView V = M.view();
+    const dim3 grid(M.G), block(kBlock);
+    switch (M.RT) {
+        case 1: hipLaunchKernelGGL((spmv_phased_kernel<Epi, 1>), grid, block, 0, s, V, x, epi, dot_partials, done); break;
+        case 2: hipLaunchKernelGGL((spmv_phased_kernel<Epi, 2>), grid, block, 0, s, V, x, epi, dot_partials, done); break;
+        case 4: hipLaunchKernelGGL((spmv_phased_kernel<Epi, 4>), grid, block, 0, s, V, x, epi, dot_partials, done); break;
+        default: hipLaunchKernelGGL((spmv_phased_kernel<Epi, 8>), grid, block, 0, s, V, x, epi, dot_partials, done); break;
+    }
+    if (M.nlong > 0) {
+        hipLaunchKernelGGL(spmv_long_kernel<Epi>, dim3(M.nseg), block, 0, s, V, x, done);
+        hipLaunchKernelGGL(spmv_long_fixup_kernel<Epi>, dim3(1), block, 0, s, V, epi, dot_partials, M.G, done);
+    }
+    return dot_partials ? M.num_partials() : 0;
+}
+
+}  // namespace ipxk

@@ -1,0 +1,335 @@
+"""ctypes binding of the C ABI in include/ipx_kkt_hip.h (libipx_kkt_hip.so).
+
+This is plumbing for tests and bench.py; the product is the shared library.  There
+is no CPU fallback: if the library is missing or no GPU is present, construction
+raises.  Names mirror the reference's classes on the path (NormalMatrix,
+DiagonalPrecond, ConjugateResiduals, KKTSolverDiag, SplittedNormalMatrix,
+KKTSolverBasis) -- see the file:line citations in the header.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libipx_kkt_hip.so")
+
+i64, f64 = np.int64, np.float64
+c_i64, c_f64 = C.c_int64, C.c_double
+P_i64, P_f64 = C.POINTER(C.c_int64), C.POINTER(C.c_double)
+INTERRUPT_FN = C.CFUNCTYPE(c_i64, C.c_void_p)
+
+POINTER_HOST, POINTER_DEVICE = 0, 1
+NONBASIC_FIXED, NONBASIC, BASIC, BASIC_FREE = -2, -1, 0, 1
+
+EXPORTS = [
+    "ipxk_last_error", "ipxk_device_count", "ipxk_create", "ipxk_destroy", "ipxk_set_pointer_mode",
+    "ipxk_set_stream", "ipxk_synchronize", "ipxk_num_dense_cols", "ipxk_get_rowwise",
+    "ipxk_normal_prepare", "ipxk_normal_apply", "ipxk_diag_factorize", "ipxk_diag_apply",
+    "ipxk_diag_get", "ipxk_pcr_solve", "ipxk_kkt_diag_factorize", "ipxk_kkt_diag_solve",
+    "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_apply", "ipxk_forward_solve",
+    "ipxk_backward_solve", "ipxk_solve_dense", "ipxk_split_levels", "ipxk_cr_solve",
+    "ipxk_kkt_basis_solve", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_time_normal_apply",
+    "ipxk_normal_apply_bytes", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
+    "ipxk_dev_download",
+]
+
+
+class Times(C.Structure):
+    _fields_ = [("cr", c_f64), ("op", c_f64), ("precond", c_f64), ("solve_B", c_f64),
+                ("solve_Bt", c_f64)]
+
+
+class KktError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ipxk error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build_library():
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(HERE, "csrc")])
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libipx_kkt_hip.so (raises if it has not been built: no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                "%s is missing: build it with `make -C ipx_amd/csrc` (hipcc, gfx950)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.ipxk_last_error.restype = C.c_char_p
+        L.ipxk_num_dense_cols.restype = c_i64
+        L.ipxk_normal_apply_bytes.restype = c_i64
+        _lib = L
+    return _lib
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(P_i64)
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(P_f64)
+
+
+def _I(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=i64)
+
+
+def _F(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=f64)
+
+
+class DeviceVector:
+    """fp64 vector resident in HBM (hipMalloc through the C ABI)."""
+
+    def __init__(self, ctx, n, host=None):
+        self.ctx, self.n = ctx, int(n)
+        p = C.c_void_p()
+        ctx._check(ctx.lib.ipxk_dev_alloc(ctx.h, c_i64(8 * self.n), C.byref(p)))
+        self.ptr = p
+        if host is not None:
+            self.upload(host)
+
+    def upload(self, host):
+        host = _F(host)
+        assert host.size == self.n
+        self.ctx._check(self.ctx.lib.ipxk_dev_upload(self.ctx.h, self.ptr, _fp(host),
+                                                     c_i64(8 * self.n)))
+
+    def download(self):
+        out = np.empty(self.n, f64)
+        self.ctx._check(self.ctx.lib.ipxk_dev_download(self.ctx.h, _fp(out), self.ptr,
+                                                       c_i64(8 * self.n)))
+        return out
+
+    def as_arg(self):
+        return C.cast(self.ptr, P_f64)
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.ipxk_dev_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class KktContext:
+    """One model's constraint matrix resident on one MI355X.
+
+    A: object with .nrow, .ncol, .p, .i, .x (int64 CSC of the n structural columns).
+    """
+
+    def __init__(self, A, device=0):
+        self.lib = load_library()
+        self.m, self.n = int(A.nrow), int(A.ncol)
+        self._keep = (_I(A.p), _I(A.i), _F(A.x))
+        h = C.c_void_p()
+        rc = self.lib.ipxk_create(c_i64(self.m), c_i64(self.n), _ip(self._keep[0]),
+                                  _ip(self._keep[1]), _fp(self._keep[2]), C.c_int(device),
+                                  C.byref(h))
+        if rc != 0:
+            raise KktError(rc, self.lib.ipxk_last_error().decode())
+        self.h = h
+        self.device_mode = False
+
+    def _check(self, rc):
+        if rc != 0:
+            raise KktError(rc, self.lib.ipxk_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ipxk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    # -- plumbing ---------------------------------------------------------------
+    def set_pointer_mode(self, device):
+        self._check(self.lib.ipxk_set_pointer_mode(self.h, C.c_int(1 if device else 0)))
+        self.device_mode = bool(device)
+
+    def set_stream(self, stream_handle):
+        self._check(self.lib.ipxk_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        self._check(self.lib.ipxk_synchronize(self.h))
+
+    def vector(self, n, host=None):
+        return DeviceVector(self, n, host)
+
+    @property
+    def num_dense_cols(self):
+        return int(self.lib.ipxk_num_dense_cols(self.h))
+
+    @property
+    def normal_apply_bytes(self):
+        return int(self.lib.ipxk_normal_apply_bytes(self.h))
+
+    def get_rowwise(self):
+        nnz = int(self._keep[0][-1])
+        p, i, x = np.zeros(self.m + 1, i64), np.zeros(nnz, i64), np.zeros(nnz, f64)
+        self._check(self.lib.ipxk_get_rowwise(self.h, _ip(p), _ip(i), _fp(x)))
+        return p, i, x
+
+    # -- NormalMatrix -------------------------------------------------------------
+    def normal_prepare(self, W):
+        self._W = _F(W)
+        self._check(self.lib.ipxk_normal_prepare(self.h, _fp(self._W)))
+
+    def normal_apply(self, rhs, want_dot=True):
+        rhs = _F(rhs)
+        lhs = np.zeros(self.m, f64)
+        dot = c_f64(0.0)
+        self._check(self.lib.ipxk_normal_apply(self.h, _fp(rhs), _fp(lhs),
+                                               C.byref(dot) if want_dot else None))
+        return lhs, dot.value
+
+    def time_normal_apply(self, rhs_dev, lhs_dev, reps):
+        ms = c_f64(0.0)
+        self._check(self.lib.ipxk_time_normal_apply(self.h, rhs_dev.as_arg(), lhs_dev.as_arg(),
+                                                    C.c_int(reps), C.byref(ms)))
+        return ms.value
+
+    # -- DiagonalPrecond ------------------------------------------------------------
+    def diag_factorize(self, W, precond_dense_cols=True):
+        err = c_i64(0)
+        self._check(self.lib.ipxk_diag_factorize(self.h, _fp(_F(W)),
+                                                 C.c_int(1 if precond_dense_cols else 0),
+                                                 C.byref(err)))
+        return int(err.value)
+
+    def diag_apply(self, rhs):
+        rhs = _F(rhs)
+        lhs = np.zeros(self.m, f64)
+        dot = c_f64(0.0)
+        self._check(self.lib.ipxk_diag_apply(self.h, _fp(rhs), _fp(lhs), C.byref(dot)))
+        return lhs, dot.value
+
+    def diag_get(self, k=0):
+        d = np.zeros(self.m, f64)
+        ch = np.zeros(k * k, f64)
+        self._check(self.lib.ipxk_diag_get(self.h, _fp(d), _fp(ch) if k else None))
+        return d, ch.reshape(k, k).T
+
+    # -- ConjugateResiduals -----------------------------------------------------------
+    def _cr(self, fn, rhs, tol, resscale, maxiter, lhs0, hist_cap, interrupt):
+        rhs = _F(rhs)
+        lhs = np.zeros(self.m, f64) if lhs0 is None else _F(lhs0).copy()
+        it, err = c_i64(0), c_i64(0)
+        hist = np.full(max(hist_cap, 1), np.nan, f64)
+        times = Times()
+        cb = INTERRUPT_FN(lambda _u: int(interrupt())) if interrupt else C.cast(None, INTERRUPT_FN)
+        self._check(fn(self.h, _fp(rhs), c_f64(tol), _fp(_F(resscale)), c_i64(maxiter), _fp(lhs),
+                       C.byref(it), C.byref(err), cb, None, _fp(hist) if hist_cap else None,
+                       c_i64(hist_cap), C.byref(times)))
+        hist = hist[:hist_cap]
+        return lhs, int(it.value), int(err.value), hist[~np.isnan(hist)], times
+
+    def pcr_solve(self, rhs, tol, resscale, maxiter, lhs0=None, hist_cap=0, interrupt=None):
+        return self._cr(self.lib.ipxk_pcr_solve, rhs, tol, resscale, maxiter, lhs0, hist_cap, interrupt)
+
+    def cr_solve(self, rhs, tol, resscale, maxiter, lhs0=None, hist_cap=0, interrupt=None):
+        return self._cr(self.lib.ipxk_cr_solve, rhs, tol, resscale, maxiter, lhs0, hist_cap, interrupt)
+
+    # -- KKTSolverDiag ------------------------------------------------------------------
+    def kkt_diag_factorize(self, xl=None, xu=None, zl=None, zu=None, mu=0.0,
+                           precond_dense_cols=True):
+        err = c_i64(0)
+        self._check(self.lib.ipxk_kkt_diag_factorize(
+            self.h, _fp(_F(xl)), _fp(_F(xu)), _fp(_F(zl)), _fp(_F(zu)), c_f64(mu),
+            C.c_int(1 if precond_dense_cols else 0), C.byref(err)))
+        return int(err.value)
+
+    def kkt_diag_solve(self, a, b, tol, maxiter=-1, interrupt=None):
+        """Host vectors in/out (the reference's Vector boundary)."""
+        a, b = _F(a), _F(b)
+        x, y = np.zeros(self.n + self.m, f64), np.zeros(self.m, f64)
+        it, err, times = c_i64(0), c_i64(0), Times()
+        cb = INTERRUPT_FN(lambda _u: int(interrupt())) if interrupt else C.cast(None, INTERRUPT_FN)
+        self._check(self.lib.ipxk_kkt_diag_solve(self.h, _fp(a), _fp(b), c_f64(tol), c_i64(maxiter),
+                                                 _fp(x), _fp(y), C.byref(it), C.byref(err), cb, None,
+                                                 C.byref(times)))
+        return x, y, int(it.value), int(err.value), times
+
+    def kkt_diag_solve_resident(self, a_dev, b_dev, x_dev, y_dev, tol, maxiter=-1):
+        """Device-resident vectors (pointer mode must be device): what bench.py times."""
+        it, err, times = c_i64(0), c_i64(0), Times()
+        self._check(self.lib.ipxk_kkt_diag_solve(self.h, a_dev.as_arg(), b_dev.as_arg(), c_f64(tol),
+                                                 c_i64(maxiter), x_dev.as_arg(), y_dev.as_arg(),
+                                                 C.byref(it), C.byref(err),
+                                                 C.cast(None, INTERRUPT_FN), None, C.byref(times)))
+        return int(it.value), int(err.value), times
+
+    def kkt_diag_get(self):
+        W, rs = np.zeros(self.n + self.m, f64), np.zeros(self.m, f64)
+        self._check(self.lib.ipxk_kkt_diag_get(self.h, _fp(W), _fp(rs)))
+        return W, rs
+
+    # -- SplittedNormalMatrix / KKTSolverBasis -------------------------------------------
+    def split_prepare(self, L, U, rowperm, colperm, basis, status, colscale):
+        args = [_I(L.p), _I(L.i), _F(L.x), _I(U.p), _I(U.i), _F(U.x), _I(rowperm), _I(colperm),
+                _I(basis), _I(status), _F(colscale)]
+        self._check(self.lib.ipxk_split_prepare(
+            self.h, _ip(args[0]), _ip(args[1]), _fp(args[2]), _ip(args[3]), _ip(args[4]),
+            _fp(args[5]), _ip(args[6]), _ip(args[7]), _ip(args[8]), _ip(args[9]), _fp(args[10])))
+
+    def split_apply(self, rhs, want_dot=True):
+        rhs = _F(rhs)
+        lhs = np.zeros(self.m, f64)
+        dot = c_f64(0.0)
+        self._check(self.lib.ipxk_split_apply(self.h, _fp(rhs), _fp(lhs),
+                                              C.byref(dot) if want_dot else None))
+        return lhs, dot.value
+
+    def forward_solve(self, x):
+        x = _F(x).copy()
+        self._check(self.lib.ipxk_forward_solve(self.h, _fp(x)))
+        return x
+
+    def backward_solve(self, x):
+        x = _F(x).copy()
+        self._check(self.lib.ipxk_backward_solve(self.h, _fp(x)))
+        return x
+
+    def solve_dense(self, rhs, trans):
+        rhs = _F(rhs)
+        lhs = np.zeros(self.m, f64)
+        self._check(self.lib.ipxk_solve_dense(self.h, _fp(rhs), _fp(lhs), C.c_char(trans.encode())))
+        return lhs
+
+    def split_levels(self):
+        lv = np.zeros(4, i64)
+        self._check(self.lib.ipxk_split_levels(self.h, _ip(lv)))
+        return [int(v) for v in lv]
+
+    def kkt_basis_solve(self, a, b, tol, maxiter=-1):
+        a, b = _F(a), _F(b)
+        x, y = np.zeros(self.n + self.m, f64), np.zeros(self.m, f64)
+        it, err, times = c_i64(0), c_i64(0), Times()
+        self._check(self.lib.ipxk_kkt_basis_solve(self.h, _fp(a), _fp(b), c_f64(tol), c_i64(maxiter),
+                                                  _fp(x), _fp(y), C.byref(it), C.byref(err),
+                                                  C.cast(None, INTERRUPT_FN), None, C.byref(times)))
+        return x, y, int(it.value), int(err.value), times
+
+    def kkt_basis_solve_resident(self, a_dev, b_dev, x_dev, y_dev, tol, maxiter=-1):
+        it, err, times = c_i64(0), c_i64(0), Times()
+        self._check(self.lib.ipxk_kkt_basis_solve(self.h, a_dev.as_arg(), b_dev.as_arg(), c_f64(tol),
+                                                  c_i64(maxiter), x_dev.as_arg(), y_dev.as_arg(),
+                                                  C.byref(it), C.byref(err),
+                                                  C.cast(None, INTERRUPT_FN), None, C.byref(times)))
+        return int(it.value), int(err.value), times
+
+    # -- multi-GPU -------------------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = (C.c_char * 128)()
+        self._check(self.lib.ipxk_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, nranks):
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        self._check(self.lib.ipxk_comm_init(self.h, buf, C.c_int(rank), C.c_int(nranks)))
