@@ -1,16 +1,574 @@
-// placeholder until the basis path lands (filled in below in this round)
+// Basis-preconditioned operator on the device.
+//   SplittedNormalMatrix::Prepare / _Apply      reference src/splitted_normal_matrix.cc:18-117
+//   TriangularSolve / ForwardSolve / BackwardSolve   src/sparse_matrix.cc:224-311
+//   Basis::SolveDense on fresh factors               src/basis.cc:168-170, src/forrest_tomlin.cc:67-78
+//
+// Triangular solves are level-scheduled gather sweeps.  For each of the four sweeps
+// (U', L', L, U) the host computes the dependency level of every unknown once per
+// Prepare (the factors change every IPM iteration) and stores the rows level by level, so
+// that one launch processes one level with one thread per unknown; runs of narrow levels
+// (<= kTailWidth unknowns) are handled by a single workgroup in ONE launch with a
+// workgroup barrier between levels.  Each unknown is computed by one thread that walks its
+// entries in the reference's order:
+//   transposed sweeps ('t'):  d = sum x[i]*a (ascending storage order); x = (x - d)/diag
+//   forward sweeps   ('n'):   x -= a*x_j one at a time in the reference's column order
+// so a sweep reproduces the reference's arithmetic (bit-exact given identical factors).
+//
+// N N' is applied through the resident model matrix: N = AI[:,nonbasic] scaled by D and with
+// rows in pivot order, hence N N' w = P A (M D^2) A' P' w with M the nonbasic mask -- the
+// NormalMatrix kernels with weights W = M.*D^2 between two permutation kernels.  Prepare
+// therefore uploads O(m + n) numbers plus the factors and never copies the matrix
+// (the reference copies all of N every time, splitted_normal_matrix.cc:42-55).
+#include <algorithm>
+
 #include "context.hpp"
+#include "spmv_kernels.hpp"
+
 namespace ipxk {
-struct SplitOperator {};
+
+constexpr int kTailWidth = 1024;
+
+struct SweepView {
+    const int* order;      // [dim] unknown index of level-ordered position k
+    const int* ptr;        // [dim+1]
+    const int* idx;        // dependency unknown index
+    const double* val;
+    const double* diag;    // [dim] diagonal (1.0 for unit triangular)
+};
+
+struct Sweep {
+    int dim = 0, nlevels = 0;
+    bool running = false;          // forward ('n') sweeps subtract one product at a time
+    DevBuf<int> order, ptr, idx;
+    DevBuf<double> val, diag;      // as given
+    DevBuf<double> valS, diagS;    // column-scaled copy (U sweeps only)
+    bool has_scaled = false;
+    std::vector<int> level_ptr;    // host, [nlevels+1]
+    DevBuf<int> level_ptr_dev;
+    struct Launch { int l0, l1; bool tail; };
+    std::vector<Launch> plan;
+    SweepView view(bool scaled) const {
+        SweepView V;
+        V.order = order.get(); V.ptr = ptr.get(); V.idx = idx.get();
+        V.val = (scaled && has_scaled) ? valS.get() : val.get();
+        V.diag = (scaled && has_scaled) ? diagS.get() : diag.get();
+        return V;
+    }
+};
+
+struct SplitOperator {
+    int m = 0;
+    Sweep Ut, Lt, Lf, Uf;
+    DevBuf<double> Wsplit;                 // n+m: colscale^2 on NONBASIC columns, else 0
+    DevBuf<int> rowperm, rowperm_inv, colperm, basis, status;
+    DevBuf<double> colscale;
+    DevBuf<unsigned char> free_mask;       // m, pivot order
+    int num_free = 0;
+    DevBuf<double> w0, w1, w2, w3;         // m workspaces
+    DevBuf<double> tI;                     // m
+};
+
 void destroy_split(SplitOperator* s) { delete s; }
-void split_prepare_host(Context*, const ipxint*, const ipxint*, const double*, const ipxint*, const ipxint*,
-                        const double*, const ipxint*, const ipxint*, const ipxint*, const ipxint*,
-                        const double*) { throw Error(IPXK_E_UNSUPPORTED, "basis path not built yet"); }
-int split_apply_dev(Context*, const double*, double*, const int*) { throw Error(IPXK_E_UNSUPPORTED, "basis path"); }
-void forward_solve_dev(Context*, double*, bool, const int*) { throw Error(IPXK_E_UNSUPPORTED, "basis path"); }
-void backward_solve_dev(Context*, double*, bool, const int*) { throw Error(IPXK_E_UNSUPPORTED, "basis path"); }
-void solve_dense_dev(Context*, const double*, double*, char) { throw Error(IPXK_E_UNSUPPORTED, "basis path"); }
-CrResult kkt_basis_solve_dev(Context*, const double*, const double*, double, ipxint, double*, double*,
-                             ipxk_interrupt_fn, void*, ipxk_times*) { throw Error(IPXK_E_UNSUPPORTED, "basis path"); }
-void split_levels(const Context*, ipxint*) { throw Error(IPXK_E_UNSUPPORTED, "basis path"); }
+
+static int vec_grid(int64_t len) {
+    int64_t g = (len + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    return (int)(g < 1024 ? g : 1024);
 }
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+template <bool RUNNING>
+__device__ __forceinline__ void solve_unknown(const SweepView& S, int k, double* x) {
+    const int r = S.order[k];
+    const int p0 = S.ptr[k], p1 = S.ptr[k + 1];
+    double xr = x[r];
+    if (RUNNING) {
+        for (int p = p0; p < p1; p++) xr -= S.val[p] * x[S.idx[p]];
+    } else {
+        double d = 0.0;
+        for (int p = p0; p < p1; p++) d += x[S.idx[p]] * S.val[p];
+        xr -= d;
+    }
+    x[r] = xr / S.diag[k];
+}
+
+// one level per launch
+template <bool RUNNING>
+__global__ __launch_bounds__(kBlock) void level_kernel(SweepView S, int k0, int k1, double* x,
+                                                       const int* done) {
+    if (done && *done) return;
+    const int k = k0 + blockIdx.x * kBlock + threadIdx.x;
+    if (k < k1) solve_unknown<RUNNING>(S, k, x);
+}
+
+// a run of narrow levels in one workgroup
+template <bool RUNNING>
+__global__ __launch_bounds__(kTailWidth) void tail_kernel(SweepView S, const int* level_ptr, int l0,
+                                                          int l1, double* x, const int* done) {
+    if (done && *done) return;
+    for (int l = l0; l < l1; l++) {
+        const int k = level_ptr[l] + threadIdx.x;
+        if (k < level_ptr[l + 1]) solve_unknown<RUNNING>(S, k, x);
+        __syncthreads();   // workgroup-scope ordering of the global writes of this level
+    }
+}
+
+// out[i] = in[perm[i]]
+__global__ void gather_perm_kernel(int m, const double* __restrict__ in, const int* __restrict__ perm,
+                                   double* __restrict__ out, const int* done) {
+    if (done && *done) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
+        out[i] = in[perm[i]];
+}
+// out[perm[i]] = in[i]
+__global__ void scatter_perm_kernel(int m, const double* __restrict__ in, const int* __restrict__ perm,
+                                    double* __restrict__ out, const int* done) {
+    if (done && *done) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
+        out[perm[i]] = in[i];
+}
+
+// lhs = free ? 0 : lhs + rhs;  partial dot rhs'lhs       (splitted_normal_matrix.cc:112-116)
+__global__ __launch_bounds__(kBlock) void split_finish_kernel(int m, const double* __restrict__ rhs,
+                                                              const unsigned char* __restrict__ free_mask,
+                                                              double* __restrict__ lhs, double* partial,
+                                                              const int* done) {
+    if (done && *done) return;
+    __shared__ double red[kBlock / 64 + 1];
+    double acc = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock) {
+        const double r = rhs[i];
+        const double l = free_mask[i] ? 0.0 : lhs[i] + r;
+        lhs[i] = l;
+        acc += r * l;
+    }
+    acc = block_reduce<SumOp>(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// host: level analysis
+// ---------------------------------------------------------------------------
+// Generic builder.  Unknown i has the dependency list dep(i) = entries [rp[i], rp[i+1]) of
+// (ri, rx) in the order in which they must be visited; `diag[i]` is its divisor.  Unknowns are
+// processed in `ascending` or descending index order by the reference, which is a valid
+// topological order of the dependencies.
+static void build_sweep(Sweep& S, int dim, bool ascending, bool running, const std::vector<int>& rp,
+                        const std::vector<int>& ri, const std::vector<double>& rx,
+                        const std::vector<double>& diag, const std::vector<double>* rxS,
+                        const std::vector<double>* diagS, hipStream_t s) {
+    S.dim = dim;
+    S.running = running;
+    std::vector<int> level(dim, 0);
+    int nlev = dim > 0 ? 1 : 0;
+    for (int t = 0; t < dim; t++) {
+        const int i = ascending ? t : dim - 1 - t;
+        int lv = 0;
+        for (int p = rp[i]; p < rp[i + 1]; p++) lv = std::max(lv, level[ri[p]] + 1);
+        level[i] = lv;
+        nlev = std::max(nlev, lv + 1);
+    }
+    S.nlevels = nlev;
+    // counting sort of unknowns by level (stable in processing order)
+    std::vector<int> lptr(nlev + 1, 0);
+    for (int i = 0; i < dim; i++) lptr[level[i] + 1]++;
+    for (int l = 0; l < nlev; l++) lptr[l + 1] += lptr[l];
+    std::vector<int> order(dim), next(lptr.begin(), lptr.end() - 1);
+    for (int t = 0; t < dim; t++) {
+        const int i = ascending ? t : dim - 1 - t;
+        order[next[level[i]]++] = i;
+    }
+    const size_t nz = ri.size();
+    std::vector<int> ptr(dim + 1, 0), idx(std::max<size_t>(nz, 1));
+    std::vector<double> val(std::max<size_t>(nz, 1)), valS, dg(std::max(dim, 1)), dgS;
+    if (rxS) { valS.resize(std::max<size_t>(nz, 1)); dgS.resize(std::max(dim, 1)); }
+    int put = 0;
+    for (int k = 0; k < dim; k++) {
+        const int i = order[k];
+        ptr[k] = put;
+        for (int p = rp[i]; p < rp[i + 1]; p++, put++) {
+            idx[put] = ri[p];
+            val[put] = rx[p];
+            if (rxS) valS[put] = (*rxS)[p];
+        }
+        dg[k] = diag[i];
+        if (rxS) dgS[k] = (*diagS)[i];
+    }
+    ptr[dim] = put;
+    S.level_ptr = lptr;
+    S.order.upload(order, s);
+    S.ptr.upload(ptr, s);
+    S.idx.upload(idx, s);
+    S.val.upload(val, s);
+    S.diag.upload(dg, s);
+    S.has_scaled = rxS != nullptr;
+    if (rxS) { S.valS.upload(valS, s); S.diagS.upload(dgS, s); }
+    S.level_ptr_dev.upload(lptr, s);
+    // launch plan
+    S.plan.clear();
+    int l = 0;
+    while (l < nlev) {
+        if (lptr[l + 1] - lptr[l] > kTailWidth) {
+            S.plan.push_back({l, l + 1, false});
+            l++;
+        } else {
+            int l1 = l;
+            while (l1 < nlev && lptr[l1 + 1] - lptr[l1] <= kTailWidth) l1++;
+            S.plan.push_back({l, l1, true});
+            l = l1;
+        }
+    }
+    IPXK_HIP(hipStreamSynchronize(s));
+}
+
+static void run_sweep(Context* c, const Sweep& S, bool scaled, double* x, const int* done) {
+    const SweepView V = S.view(scaled);
+    for (const Sweep::Launch& L : S.plan) {
+        if (L.tail) {
+            if (S.running)
+                hipLaunchKernelGGL(tail_kernel<true>, dim3(1), dim3(kTailWidth), 0, c->stream, V,
+                                   S.level_ptr_dev.get(), L.l0, L.l1, x, done);
+            else
+                hipLaunchKernelGGL(tail_kernel<false>, dim3(1), dim3(kTailWidth), 0, c->stream, V,
+                                   S.level_ptr_dev.get(), L.l0, L.l1, x, done);
+        } else {
+            const int k0 = S.level_ptr[L.l0], k1 = S.level_ptr[L.l1];
+            const int g = (k1 - k0 + kBlock - 1) / kBlock;
+            if (S.running)
+                hipLaunchKernelGGL(level_kernel<true>, dim3(g), dim3(kBlock), 0, c->stream, V, k0, k1, x, done);
+            else
+                hipLaunchKernelGGL(level_kernel<false>, dim3(g), dim3(kBlock), 0, c->stream, V, k0, k1, x, done);
+        }
+    }
+}
+
+// ForwardSolve: L then U (sparse_matrix.cc:303-306)
+void forward_solve_dev(Context* c, double* x, bool scaled, const int* done) {
+    run_sweep(c, c->split->Lf, scaled, x, done);
+    run_sweep(c, c->split->Uf, scaled, x, done);
+}
+// BackwardSolve: U' then L' (sparse_matrix.cc:308-311)
+void backward_solve_dev(Context* c, double* x, bool scaled, const int* done) {
+    run_sweep(c, c->split->Ut, scaled, x, done);
+    run_sweep(c, c->split->Lt, scaled, x, done);
+}
+
+void split_levels(const Context* c, ipxint levels[4]) {
+    levels[0] = c->split->Ut.nlevels;
+    levels[1] = c->split->Lt.nlevels;
+    levels[2] = c->split->Lf.nlevels;
+    levels[3] = c->split->Uf.nlevels;
+}
+
+// ---------------------------------------------------------------------------
+// Prepare
+// ---------------------------------------------------------------------------
+void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const double* Lx,
+                        const ipxint* Up, const ipxint* Ui, const double* Ux, const ipxint* rowperm,
+                        const ipxint* colperm, const ipxint* basis, const ipxint* status,
+                        const double* colscale) {
+    const int m = (int)c->m, n = (int)c->n;
+    hipStream_t s = c->stream;
+    IPXK_REQUIRE(c->nranks == 1, "the basis path does not shard: run it as independent replicas");
+    IPXK_REQUIRE(Lp[m] < (int64_t(1) << 31) && Up[m] < (int64_t(1) << 31), "factor nnz exceeds 32 bits");
+    for (int k = 0; k < m; k++) {
+        IPXK_REQUIRE(Up[k + 1] > Up[k] && Ui[Up[k + 1] - 1] == k, "U must hold its diagonal last in each column");
+        IPXK_REQUIRE(basis[k] >= 0 && basis[k] < n + m, "basis entry out of range");
+        IPXK_REQUIRE(rowperm[k] >= 0 && rowperm[k] < m && colperm[k] >= 0 && colperm[k] < m, "permutation entry out of range");
+    }
+    if (c->split) { destroy_split(c->split); c->split = nullptr; }
+    std::unique_ptr<SplitOperator> S(new SplitOperator);
+    S->m = m;
+
+    // column scaling of U (splitted_normal_matrix.cc:30-39): nothing for BASIC_FREE
+    std::vector<double> uscale(m, 1.0);
+    std::vector<unsigned char> fmask(m, 0);
+    S->num_free = 0;
+    for (int k = 0; k < m; k++) {
+        const ipxint j = basis[colperm[k]];
+        if (status[j] == IPXK_BASIC) uscale[k] = colscale[j];
+        else if (status[j] == IPXK_BASIC_FREE) { fmask[k] = 1; S->num_free++; }   // :58-64
+    }
+
+    // --- U' sweep: unknown k gathers the rows above the diagonal of column k, ascending
+    {
+        std::vector<int> rp(m + 1), ri(Up[m] - m);
+        std::vector<double> rx(ri.size()), rxS(ri.size()), dg(m), dgS(m);
+        int put = 0;
+        for (int k = 0; k < m; k++) {
+            rp[k] = put;
+            for (ipxint p = Up[k]; p < Up[k + 1] - 1; p++, put++) {
+                ri[put] = (int)Ui[p];
+                rx[put] = Ux[p];
+                rxS[put] = Ux[p] * uscale[k];
+            }
+            dg[k] = Ux[Up[k + 1] - 1];
+            dgS[k] = dg[k] * uscale[k];
+        }
+        rp[m] = put;
+        build_sweep(S->Ut, m, true, false, rp, ri, rx, dg, &rxS, &dgS, s);
+    }
+    // --- L' sweep: unknown k gathers column k of L (rows > k), descending, unit diagonal
+    {
+        std::vector<int> rp(m + 1), ri(Lp[m]);
+        std::vector<double> rx(Lp[m]), dg(m, 1.0);
+        for (int k = 0; k <= m; k++) rp[k] = (int)Lp[k];
+        for (ipxint p = 0; p < Lp[m]; p++) { ri[p] = (int)Li[p]; rx[p] = Lx[p]; }
+        build_sweep(S->Lt, m, false, false, rp, ri, rx, dg, nullptr, nullptr, s);
+    }
+    // --- L sweep: unknown i subtracts L[i,j]*x_j for the columns j < i of row i, ascending j
+    //     (the order in which the reference's column loop updates x[i], sparse_matrix.cc:283-297)
+    {
+        std::vector<int> rp(m + 1, 0), ri(Lp[m]);
+        std::vector<double> rx(Lp[m]), dg(m, 1.0);
+        for (ipxint p = 0; p < Lp[m]; p++) rp[Li[p] + 1]++;
+        for (int i = 0; i < m; i++) rp[i + 1] += rp[i];
+        std::vector<int> next(rp.begin(), rp.end() - 1);
+        for (int j = 0; j < m; j++)
+            for (ipxint p = Lp[j]; p < Lp[j + 1]; p++) {
+                const int put = next[Li[p]]++;
+                ri[put] = j;
+                rx[put] = Lx[p];
+            }
+        build_sweep(S->Lf, m, true, true, rp, ri, rx, dg, nullptr, nullptr, s);
+    }
+    // --- U sweep: unknown i subtracts U[i,j]*x_j for the columns j > i of row i, DESCENDING j
+    //     (sparse_matrix.cc:267-281), then divides by U[i,i]
+    {
+        std::vector<int> cnt(m + 1, 0);
+        for (int k = 0; k < m; k++)
+            for (ipxint p = Up[k]; p < Up[k + 1] - 1; p++) cnt[Ui[p] + 1]++;
+        std::vector<int> rp(cnt);
+        for (int i = 0; i < m; i++) rp[i + 1] += rp[i];
+        std::vector<int> ri(rp[m]);
+        std::vector<double> rx(rp[m]), rxS(rp[m]), dg(m), dgS(m);
+        std::vector<int> next(rp.begin(), rp.end() - 1);
+        for (int k = m - 1; k >= 0; k--) {   // descending column order within each row
+            for (ipxint p = Up[k]; p < Up[k + 1] - 1; p++) {
+                const int put = next[Ui[p]]++;
+                ri[put] = k;
+                rx[put] = Ux[p];
+                rxS[put] = Ux[p] * uscale[k];
+            }
+            dg[k] = Ux[Up[k + 1] - 1];
+            dgS[k] = dg[k] * uscale[k];
+        }
+        build_sweep(S->Uf, m, false, true, rp, ri, rx, dg, &rxS, &dgS, s);
+    }
+
+    // --- N N' weights: colscale^2 on NONBASIC columns (splitted_normal_matrix.cc:42-55)
+    {
+        std::vector<double> W((size_t)n + m, 0.0);
+        for (int j = 0; j < n + m; j++)
+            if (status[j] == IPXK_NONBASIC) W[j] = colscale[j] * colscale[j];
+        S->Wsplit.upload(W, s);
+    }
+    // --- permutations (InversePerm, utils.cc:73-80) and bookkeeping for KKTSolverBasis::_Solve
+    {
+        std::vector<int> rpm(m), rpi(m), cpm(m), bs(m), stt((size_t)n + m);
+        for (int i = 0; i < m; i++) { rpm[i] = (int)rowperm[i]; cpm[i] = (int)colperm[i]; bs[i] = (int)basis[i]; }
+        for (int i = 0; i < m; i++) rpi[rpm[i]] = i;
+        for (int j = 0; j < n + m; j++) stt[j] = (int)status[j];
+        S->rowperm.upload(rpm, s);
+        S->rowperm_inv.upload(rpi, s);
+        S->colperm.upload(cpm, s);
+        S->basis.upload(bs, s);
+        S->status.upload(stt, s);
+        S->colscale.upload(colscale, (size_t)n + m, s);
+        S->free_mask.upload(fmask, s);
+    }
+    const size_t mm = (size_t)std::max(m, 1);
+    S->w0.resize(mm); S->w1.resize(mm); S->w2.resize(mm); S->w3.resize(mm); S->tI.resize(mm);
+    if (c->partials.size() == 0) c->partials.resize((size_t)kNumPartialSlots * kPartialStride);
+    IPXK_HIP(hipStreamSynchronize(s));
+    c->split = S.release();
+}
+
+// ---------------------------------------------------------------------------
+// _Apply                                    (splitted_normal_matrix.cc:90-117)
+// ---------------------------------------------------------------------------
+int split_apply_dev(Context* c, const double* rhs, double* lhs, const int* done) {
+    SplitOperator* S = c->split;
+    const int m = S->m, n = (int)c->n;
+    hipStream_t s = c->stream;
+    const int g = vec_grid(m);
+    double* work = S->w0.get();
+    double* u = S->w1.get();
+    // work = inverse(B') * rhs
+    IPXK_HIP(hipMemcpyAsync(work, rhs, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+    backward_solve_dev(c, work, true, done);
+    // lhs = N N' work : un-permute, A (M D^2) A', permute
+    hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, work, S->rowperm_inv.get(), u, done);
+    EpiScale e1{{}, S->Wsplit.get(), c->tcols.get()};
+    launch_spmv(c->Acols, u, e1, nullptr, done, s);
+    EpiNormalRows e2{{}, S->Wsplit.get() + n, u, work};
+    launch_spmv(c->Arows, c->tcols.get(), e2, nullptr, done, s);
+    hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, work, S->rowperm.get(), lhs, done);
+    // lhs = inverse(B) * lhs
+    forward_solve_dev(c, lhs, true, done);
+    // lhs += rhs; zero free positions; dot
+    hipLaunchKernelGGL(split_finish_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs, S->free_mask.get(), lhs,
+                       c->part(kPartCdot), done);
+    return g;
+}
+
+// Basis::SolveDense on the fresh, unscaled factors (forrest_tomlin.cc:67-78)
+void solve_dense_dev(Context* c, const double* rhs, double* lhs, char trans) {
+    SplitOperator* S = c->split;
+    const int m = S->m;
+    hipStream_t s = c->stream;
+    const int g = vec_grid(m);
+    double* work = S->w3.get();
+    if (trans == 't' || trans == 'T') {
+        hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs, S->colperm.get(), work,
+                           (const int*)nullptr);
+        backward_solve_dev(c, work, false, nullptr);
+        hipLaunchKernelGGL(scatter_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, work, S->rowperm.get(), lhs,
+                           (const int*)nullptr);
+    } else {
+        hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs, S->rowperm.get(), work,
+                           (const int*)nullptr);
+        forward_solve_dev(c, work, false, nullptr);
+        hipLaunchKernelGGL(scatter_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, work, S->colperm.get(), lhs,
+                           (const int*)nullptr);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// KKTSolverBasis::_Solve                        (kkt_solver_basis.cc:75-194)
+// ---------------------------------------------------------------------------
+// work[p] = a[basis[p]] for BASIC_FREE positions, 0 otherwise            (:87-97)
+__global__ void basis_free_rhs_kernel(int m, const int* __restrict__ basis, const int* __restrict__ status,
+                                      const double* __restrict__ a, double* __restrict__ work) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < m; p += gridDim.x * blockDim.x) {
+        const int j = basis[p];
+        work[p] = status[j] == IPXK_BASIC_FREE ? a[j] : 0.0;
+    }
+}
+// slack columns: tI[i] = W[n+i]*(a[n+i] - work[i])  (work == nullptr: W*a)   (:102-120, :178-188)
+__global__ void basis_slack_kernel(int m, const double* __restrict__ WI, const double* __restrict__ aI,
+                                   const double* __restrict__ work, double* __restrict__ tI) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const double s = WI[i];
+        tI[i] = s != 0.0 ? (aI[i] - (work ? work[i] : 0.0)) * s : 0.0;
+    }
+}
+// rhs[p] = (rhs[p]-work[p])/d + a[j]*d for BASIC, 0 for BASIC_FREE          (:128-138)
+__global__ void basis_reduce_rhs_kernel(int m, const int* __restrict__ basis, const int* __restrict__ status,
+                                        const double* __restrict__ colscale, const double* __restrict__ a,
+                                        const double* __restrict__ work, double* __restrict__ rhs) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < m; p += gridDim.x * blockDim.x) {
+        const int j = basis[p];
+        if (status[j] == IPXK_BASIC) {
+            const double d = colscale[j];
+            rhs[p] = (rhs[p] - work[p]) / d + a[j] * d;
+        } else {
+            rhs[p] = 0.0;
+        }
+    }
+}
+// y[p] = y[p]/d for BASIC, a[j] for BASIC_FREE                               (:164-174)
+__global__ void basis_unscale_y_kernel(int m, const int* __restrict__ basis, const int* __restrict__ status,
+                                       const double* __restrict__ colscale, const double* __restrict__ a,
+                                       double* __restrict__ y) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < m; p += gridDim.x * blockDim.x) {
+        const int j = basis[p];
+        y[p] = status[j] == IPXK_BASIC ? y[p] / colscale[j] : a[j];
+    }
+}
+// x[basis[p]] = work[p]                                                      (:192-193)
+__global__ void basis_scatter_x_kernel(int m, const int* __restrict__ basis, const double* __restrict__ work,
+                                       double* __restrict__ x) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < m; p += gridDim.x * blockDim.x)
+        x[basis[p]] = work[p];
+}
+
+// out[i] = acc + tI[i]  (acc = sum_j a_ij t_j starting from 0)
+struct EpiBasisRhs : ProdMul {
+    const double* tI; double* out;
+    static constexpr bool kNeg = false;
+    __device__ __forceinline__ double init(int) const { return 0.0; }
+    __device__ __forceinline__ void finish(int i, double acc, double&) const { out[i] = acc + tI[i]; }
+};
+// out[i] = (b[i] - sum_j a_ij x_j) - tI[i]
+struct EpiBasisResidual : ProdMul {
+    const double* b; const double* tI; double* out;
+    static constexpr bool kNeg = true;
+    __device__ __forceinline__ double init(int i) const { return b[i]; }
+    __device__ __forceinline__ void finish(int i, double acc, double&) const { out[i] = acc - tI[i]; }
+};
+
+CrResult kkt_basis_solve_dev(Context* c, const double* a, const double* b, double tol, ipxint maxiter,
+                             double* x, double* y, ipxk_interrupt_fn interrupt, void* user,
+                             ipxk_times* times) {
+    SplitOperator* S = c->split;
+    const int m = S->m, n = (int)c->n;
+    hipStream_t s = c->stream;
+    const int g = vec_grid(m);
+    const double* W = S->Wsplit.get();
+    double* rhs = S->w2.get();
+    double* work = S->w1.get();     // note: split_apply_dev uses w0/w1 only inside the CR loop
+    if (c->v_lhs.size() < (size_t)std::max(m, 1)) c->v_lhs.resize(std::max(m, 1));
+    if (c->v_rhs.size() < (size_t)std::max(m, 1)) c->v_rhs.resize(std::max(m, 1));
+    double* lhs = c->v_lhs.get();
+    double* crrhs = c->v_rhs.get();
+
+    // :87-99
+    if (S->num_free > 0) {
+        hipLaunchKernelGGL(basis_free_rhs_kernel, dim3(g), dim3(kBlock), 0, s, m, S->basis.get(),
+                           S->status.get(), a, S->tI.get());
+        solve_dense_dev(c, S->tI.get(), work, 'T');
+    }
+    const double* wk = S->num_free > 0 ? work : nullptr;
+    // :101-121  rhs = sum over nonbasic j of AI[:,j] * d2_j*(a_j - AI[:,j]'work)
+    if (wk) {
+        EpiBasisColumns ec{{}, W, a, c->tcols.get()};
+        launch_spmv(c->Acols, wk, ec, nullptr, nullptr, s);
+    } else {
+        // no free variables: alpha_j = d2_j * a_j
+        hipLaunchKernelGGL(basis_slack_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, s, n, W, a,
+                           (const double*)nullptr, c->tcols.get());
+    }
+    hipLaunchKernelGGL(basis_slack_kernel, dim3(g), dim3(kBlock), 0, s, m, W + n, a + n, wk, S->tI.get());
+    {
+        EpiBasisRhs er{{}, S->tI.get(), rhs};
+        launch_spmv(c->Arows, c->tcols.get(), er, nullptr, nullptr, s);
+    }
+    solve_dense_dev(c, rhs, rhs, 'N');
+    // :124
+    solve_dense_dev(c, b, work, 'N');
+    // :128-138
+    hipLaunchKernelGGL(basis_reduce_rhs_kernel, dim3(g), dim3(kBlock), 0, s, m, S->basis.get(),
+                       S->status.get(), S->colscale.get(), a, work, rhs);
+    // :141-143
+    hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs, S->colperm.get(), crrhs,
+                       (const int*)nullptr);
+    // :146-157
+    IPXK_HIP(hipMemsetAsync(lhs, 0, sizeof(double) * m, s));
+    CrResult res = cr_solve_dev(c, crrhs, tol, nullptr, maxiter, lhs, true, interrupt, user, nullptr, 0, times);
+    // :160-161
+    hipLaunchKernelGGL(scatter_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, lhs, S->colperm.get(), y,
+                       (const int*)nullptr);
+    // :164-175
+    hipLaunchKernelGGL(basis_unscale_y_kernel, dim3(g), dim3(kBlock), 0, s, m, S->basis.get(),
+                       S->status.get(), S->colscale.get(), a, y);
+    solve_dense_dev(c, y, y, 'T');
+    // :178-188  x[nonbasic] and work = b - N*x[nonbasic]
+    {
+        EpiBasisColumns ec{{}, W, a, x};
+        launch_spmv(c->Acols, y, ec, nullptr, nullptr, s);
+        hipLaunchKernelGGL(basis_slack_kernel, dim3(g), dim3(kBlock), 0, s, m, W + n, a + n, (const double*)y,
+                           x + n);
+        EpiBasisResidual er{{}, b, x + n, work};
+        launch_spmv(c->Arows, x, er, nullptr, nullptr, s);
+    }
+    // :191-193
+    solve_dense_dev(c, work, work, 'N');
+    hipLaunchKernelGGL(basis_scatter_x_kernel, dim3(g), dim3(kBlock), 0, s, m, S->basis.get(), work, x);
+    IPXK_HIP(hipGetLastError());
+    return res;
+}
+
+}  // namespace ipxk

@@ -85,6 +85,20 @@ def synthetic_ipm_state(m, n, spread=1.0, seed=12345):
     return dict(xl=xl, xu=xu, zl=zl, zu=zu, mu=mu, a=a, b=b)
 
 
+def synthetic_basis_state(status, spread=1.0, seed=12345):
+    """Column scaling factors (Iterate::ScalingFactor, reference src/iterate.cc:183-198) for the
+    basis path in the regime the basis preconditioner is built for: basic variables are the
+    ones with large scaling factors (what maxvolume arranges), nonbasic ones small.
+    BASIC_FREE -> inf, NONBASIC_FIXED -> 0 as in the reference."""
+    rng = np.random.default_rng(seed + 3)
+    N = status.size
+    u = rng.uniform(0.0, 1.0, N)
+    d = np.where(status >= 0, 10.0 ** (spread * u), 0.3 * 10.0 ** (-spread * u))
+    d[status == 1] = np.inf
+    d[status == -2] = 0.0
+    return d
+
+
 def lp_vectors(m, n):
     """obj=1, lb=0, ub=inf, rhs=1, constr_type='<' (SURVEY 8d)."""
     return dict(obj=np.ones(n), lb=np.zeros(n), ub=np.full(n, np.inf), rhs=np.ones(m),

@@ -1,0 +1,308 @@
+"""GPU parity tests: the HIP path (through the C ABI of libipx_kkt_hip.so) against the CPU oracle
+on seeded inputs and against the committed golden vectors of the reference.
+
+Tolerances ("Parity gate"):
+  * index / permutation arrays: bit-exact;
+  * operator applications: relative inf-norm error <= 1e-12 (most rows are in fact bit-exact because
+    the kernels add a row's products in the reference's order);
+  * CR runs: identical errflag, |iter_gpu - iter_cpu| <= max(2, 2%), first 10 residual norms within
+    1e-9 relative, final solution within 1e-6 relative for runs <= ~150 iterations, and the KKT
+    residual of the returned point recomputed on the CPU within the requested tolerance.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import basis_problem, diag_problem, kkt_residual_diag, relerr
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def kkt():
+    from ipx_amd import kkt as k
+    k.load_library()          # raises if the HIP library was not built: no fallback
+    assert k.load_library().ipxk_device_count() > 0, "no GPU visible"
+    return k
+
+
+@pytest.fixture(scope="module")
+def po():
+    from oracle import pyoracle
+    return pyoracle
+
+
+def ocsc(po, A):
+    return po.Csc(A.nrow, A.ncol, A.p, A.i, A.x)
+
+
+def iters_close(a, b):
+    return abs(a - b) <= max(2, int(0.02 * max(a, b)))
+
+
+# --------------------------------------------------------------------------------------
+# golden vectors of the reference
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["diag_200", "dense_300"])
+def test_golden_diag(kkt, po, name):
+    from ipx_amd.synth import CscMatrix
+    d = np.load(os.path.join(GOLD, name + ".npz"))
+    m, n = int(d["m"]), int(d["n"])
+    A = CscMatrix(m, n, d["Ap"], d["Ai"], d["Ax"])
+    ctx = kkt.KktContext(A)
+    assert ctx.num_dense_cols == int(d["num_dense"])
+    p, i, x = ctx.get_rowwise()
+    keep = d["AIti"] < n
+    assert np.array_equal(i, d["AIti"][keep]) and np.array_equal(x, d["AItx"][keep])
+    W, rhs = d["W"], d["rhs"]
+    ctx.normal_prepare(W)
+    lhs, dot = ctx.normal_apply(rhs)
+    assert relerr(lhs, d["normal_lhs"]) <= 1e-12 and abs(dot - float(d["normal_dot"])) <= 1e-12 * abs(dot)
+    ctx.normal_prepare(None)
+    lhs, dot = ctx.normal_apply(rhs)
+    assert relerr(lhs, d["normal0_lhs"]) <= 1e-12
+    assert ctx.diag_factorize(W, True) == int(d["prec_err"])
+    pl, pd = ctx.diag_apply(rhs)
+    assert relerr(pl, d["prec_lhs"]) <= 1e-12 and abs(pd - float(d["prec_dot"])) <= 1e-12 * abs(pd)
+    ctx.normal_prepare(W)
+    y, it, e, hist, _ = ctx.pcr_solve(rhs, float(d["pcr_tol"]), d["resscale"], 500, hist_cap=600)
+    assert e == int(d["pcr_err"]) and iters_close(it, int(d["pcr_iter"]))
+    assert relerr(y, d["pcr_y"]) < 1e-6 and hist[-1] <= float(d["pcr_tol"])
+    _, it, e, _, _ = ctx.pcr_solve(rhs, 1e-30, d["resscale"], 7)
+    assert (it, e) == (7, 201)
+    ctx.normal_prepare(d["Wneg"])
+    assert ctx.diag_factorize(d["Wneg"], False) == 0
+    _, it, e, _, _ = ctx.pcr_solve(rhs, 1e-12, None, 200)
+    assert (it, e) == (int(d["neg_iter"]), int(d["neg_err"]))
+    assert ctx.kkt_diag_factorize(d["xl"], d["xu"], d["zl"], d["zu"], float(d["mu"])) == 0
+    x, yk, it, e, _ = ctx.kkt_diag_solve(d["a"], d["b"], float(d["kkt_tol"]), 500)
+    assert e == int(d["kkt_err"]) and iters_close(it, int(d["kkt_iter"]))
+    assert relerr(x, d["kkt_x"]) < 1e-6 and relerr(yk, d["kkt_y"]) < 1e-6
+    ctx.close()
+
+
+def test_golden_afiro(kkt):
+    from ipx_amd.synth import CscMatrix
+    d = np.load(os.path.join(GOLD, "afiro.npz"))
+    m, n = int(d["m"]), int(d["n"])
+    AIp, AIi, AIx = d["AIp"], d["AIi"], d["AIx"]
+    A = CscMatrix(m, n, AIp[: n + 1], AIi[: AIp[n]], AIx[: AIp[n]])
+    ctx = kkt.KktContext(A)
+    assert ctx.kkt_diag_factorize() == 0          # Factorize(nullptr)
+    x, y, it, e, _ = ctx.kkt_diag_solve(d["a"], d["b"], float(d["tol"]))
+    assert (it, e) == (int(d["iter"]), int(d["errflag"]))
+    assert relerr(x, d["x"]) < 1e-9 and relerr(y, d["y"]) < 1e-9
+    assert ctx.kkt_diag_factorize(d["xl"], d["xu"], d["zl"], d["zu"], float(d["mu"])) == 0
+    x, y, it, e, _ = ctx.kkt_diag_solve(d["a"], d["b"], float(d["tol2"]))
+    assert (it, e) == (int(d["iter2"]), int(d["errflag2"]))
+    assert relerr(x, d["x2"]) < 1e-9 and relerr(y, d["y2"]) < 1e-9
+    ctx.close()
+
+
+def test_golden_basis(kkt):
+    from ipx_amd.synth import CscMatrix
+    d = np.load(os.path.join(GOLD, "basis_200.npz"))
+    m, n = int(d["m"]), int(d["n"])
+    A = CscMatrix(m, n, d["Ap"], d["Ai"], d["Ax"])
+    L = CscMatrix(m, m, d["Lp"], d["Li"], d["Lx"])
+    U = CscMatrix(m, m, d["Up"], d["Ui"], d["Ux"])
+    ctx = kkt.KktContext(A)
+    ctx.split_prepare(L, U, d["rowperm"], d["colperm"], d["basis"], d["status"], d["colscale"])
+    lhs, dot = ctx.split_apply(d["x0"])
+    assert relerr(lhs, d["split_lhs"]) <= 1e-12 and abs(dot - float(d["split_dot"])) <= 1e-12 * abs(dot)
+    y, it, e, hist, _ = ctx.cr_solve(d["cr_rhs"], float(d["cr_tol"]), None, -1, hist_cap=300)
+    assert (it, e) == (int(d["cr_iter"]), int(d["cr_err"])) and relerr(y, d["cr_y"]) < 1e-9
+    _, it, e, _, _ = ctx.cr_solve(d["cr_rhs"], 1e-30, None, 5)
+    assert (it, e) == (5, 201)
+    # SolveDense on the unscaled factors == the reference's ForwardSolve/BackwardSolve between the
+    # permutations of src/forrest_tomlin.cc:67-78 (fwd/bwd of the fixture were computed on x0)
+    rp, cp = d["rowperm"], d["colperm"]
+    rp_inv, cp_inv = np.argsort(rp), np.argsort(cp)
+    xN = ctx.solve_dense(d["x0"][rp_inv], "N")        # work = rhs[rowperm] == x0
+    assert np.array_equal(xN[cp], d["fwd"])
+    xT = ctx.solve_dense(d["x0"][cp_inv], "T")        # work = rhs[colperm] == x0
+    assert np.array_equal(xT[rp], d["bwd"])
+    ctx.close()
+
+
+# --------------------------------------------------------------------------------------
+# HIP vs oracle on seeded inputs
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,num_dense,spread", [(64, 100, 0, 1.0), (2000, 4100, 0, 1.0),
+                                                  (3000, 6000, 5, 1.0), (5000, 9000, 0, 0.0)])
+def test_diag_path_vs_oracle(kkt, po, oracle, m, n, num_dense, spread):
+    A, st = diag_problem(m, n, seed=21, spread=spread, num_dense=num_dense)
+    Ao = ocsc(po, A)
+    ctx = kkt.KktContext(A)
+    nd, nzd = oracle.find_dense_columns(Ao)
+    assert ctx.num_dense_cols == nd
+    AT = oracle.transpose(Ao)
+    p, i, x = ctx.get_rowwise()
+    assert np.array_equal(p, AT.p) and np.array_equal(i, AT.i) and np.array_equal(x, AT.x)
+    rng = np.random.default_rng(1)
+    rhs = rng.standard_normal(m)
+    mu = st["mu"]
+    assert ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], mu) == 0
+    ko = oracle.kkt_diag(Ao, nzd, True, 500)
+    assert ko.factorize(st["xl"], st["xu"], st["zl"], st["zu"], mu) == 0
+    W1, r1 = ctx.kkt_diag_get()
+    W2, r2 = ko.get()
+    assert np.array_equal(W1, W2) and np.array_equal(r1, r2)
+    lhs, dot = ctx.normal_apply(rhs)
+    lhs2, dot2 = oracle.normal_apply(Ao, W2, rhs)
+    assert relerr(lhs, lhs2) <= 1e-12 and abs(dot - dot2) <= 1e-12 * abs(dot2)
+    if num_dense == 0:
+        assert np.array_equal(lhs, lhs2)          # rows are added in the reference's order
+    pl, pd = ctx.diag_apply(rhs)
+    pl2, pd2 = ko_precond_apply(oracle, Ao, W2, nzd, rhs)
+    assert relerr(pl, pl2) <= 1e-12 and abs(pd - pd2) <= 1e-12 * abs(pd2)
+    tol = 0.3 * np.sqrt(mu)
+    x1, y1, it1, e1, _ = ctx.kkt_diag_solve(st["a"], st["b"], tol, 500)
+    x2, y2, it2, e2, _ = ko.solve(st["a"], st["b"], tol)
+    assert e1 == e2 == 0 and iters_close(it1, it2)
+    assert relerr(y1, y2) < 1e-6 and relerr(x1, x2) < 1e-5
+    # the returned point satisfies the contract of src/kkt_solver.h:21-27
+    res1, res2 = kkt_residual_diag(A, W2, st["a"], st["b"], x1, y1)
+    assert np.abs(res2).max() < 1e-9 * max(1.0, np.abs(st["b"]).max() + np.abs(x1).max())
+    assert np.abs(res1[:n]).max() < 1e-9 * max(1.0, np.abs(x1 / W2).max())
+    assert np.abs(np.sqrt(W2[n:]) * res1[n:]).max() <= tol * (1 + 1e-9)
+    ctx.close()
+
+
+def ko_precond_apply(oracle, Ao, W, nzd, rhs):
+    P, err = oracle.diag_factorize(Ao, W, nzd, True)
+    assert err == 0
+    return P.apply(rhs)
+
+
+def test_pcr_trajectory_vs_oracle(kkt, po, oracle):
+    m, n = 1500, 3200
+    A, st = diag_problem(m, n, seed=33, spread=1.0)
+    Ao = ocsc(po, A)
+    W = st["xl"] / st["zl"]
+    resscale = 1.0 / np.sqrt(W[n:])
+    rhs = np.random.default_rng(2).standard_normal(m)
+    ctx = kkt.KktContext(A)
+    ctx.normal_prepare(W)
+    assert ctx.diag_factorize(W, True) == 0
+    y1, it1, e1, h1, _ = ctx.pcr_solve(rhs, 1e-8, resscale, 1000, hist_cap=1200)
+    P, _ = oracle.diag_factorize(Ao, W, m + 1, True)
+    y2, it2, e2, h2 = oracle.pcr_solve(lambda v: oracle.normal_apply(Ao, W, v), P.apply, rhs, 1e-8,
+                                       resscale, 1000, hist_cap=1200)
+    assert e1 == e2 == 0 and iters_close(it1, it2)
+    assert np.abs(h1[:10] - h2[:10]).max() <= 1e-9 * h2[:10].max()
+    assert len(h1) == it1 + 1 and h1[-1] <= 1e-8
+    assert relerr(y1, y2) < 1e-5
+    # nonzero starting iterate takes the general initialisation branch (conjugate_residuals.cc:118-123)
+    y0 = 0.1 * np.random.default_rng(3).standard_normal(m)
+    y3, it3, e3, _, _ = ctx.pcr_solve(rhs, 1e-8, resscale, 1000, lhs0=y0)
+    y4, it4, e4, _ = oracle.pcr_solve(lambda v: oracle.normal_apply(Ao, W, v), P.apply, rhs, 1e-8,
+                                      resscale, 1000, lhs0=y0)
+    assert e3 == e4 == 0 and iters_close(it3, it4) and relerr(y3, y4) < 1e-5
+    # interrupt callback plays Control::InterruptCheck (errflag 999 = IPX_ERROR_interrupt_time)
+    _, it5, e5, _, _ = ctx.pcr_solve(rhs, 1e-300, resscale, 100000, interrupt=lambda: 999)
+    assert e5 == 999
+    ctx.close()
+
+
+@pytest.mark.parametrize("m,n,num_free,num_fixed", [(150, 320, 0, 0), (2500, 5200, 6, 9)])
+def test_basis_path_vs_oracle(kkt, po, oracle, m, n, num_free, num_fixed):
+    B, st, colscale = basis_problem(m, n, seed=41, num_free=num_free, num_fixed=num_fixed)
+    A, L, U = B["A"], B["L"], B["U"]
+    AI = A.with_identity()
+    ctx = kkt.KktContext(A)
+    ctx.split_prepare(L, U, B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
+    S = oracle.split_prepare(ocsc(po, AI), n, ocsc(po, L), ocsc(po, U), B["rowperm"], B["colperm"],
+                             B["basis"], B["status"], colscale)
+    pre = S.get()
+    Us = po.Csc(m, m, U.p, U.i, pre["Ux"])
+    rhs = np.random.default_rng(4).standard_normal(m)
+    # level-scheduled sweeps reproduce the sequential reference arithmetic exactly
+    assert np.array_equal(ctx.forward_solve(rhs), oracle.forward_solve(ocsc(po, L), Us, rhs))
+    assert np.array_equal(ctx.backward_solve(rhs), oracle.backward_solve(ocsc(po, L), Us, rhs))
+    for tr in "NT":
+        assert np.array_equal(ctx.solve_dense(rhs, tr), S.solve_dense(rhs, tr))
+    lv = ctx.split_levels()
+    assert all(1 <= v <= m for v in lv)
+    l1, d1 = ctx.split_apply(rhs)
+    l2, d2 = S.apply(rhs)
+    assert relerr(l1, l2) <= 1e-12 and abs(d1 - d2) <= 1e-12 * abs(d2)
+    free = pre["free_positions"]
+    assert np.all(l1[free] == 0.0)
+    rhs_cr = rhs.copy()
+    rhs_cr[free] = 0.0
+    y1, it1, e1, h1, _ = ctx.cr_solve(rhs_cr, 1e-9, None, -1, hist_cap=2000)
+    y2, it2, e2, h2 = oracle.cr_solve(S.apply, rhs_cr, 1e-9, None, -1, hist_cap=2000)
+    assert e1 == e2 == 0 and iters_close(it1, it2) and relerr(y1, y2) < 1e-6
+    assert np.abs(h1[:10] - h2[:10]).max() <= 1e-9 * h2[:10].max()
+    x1, yy1, it1, e1, _ = ctx.kkt_basis_solve(st["a"], st["b"], 1e-8)
+    x2, yy2, it2, e2, _ = S.kkt_solve(st["a"], st["b"], 1e-8)
+    assert e1 == e2 == 0 and iters_close(it1, it2)
+    assert relerr(x1, x2) < 1e-6 and relerr(yy1, yy2) < 1e-6
+    AIs = AI.to_scipy()
+    assert relerr(AIs @ x1, st["b"]) < 1e-9
+    ctx.close()
+
+
+# --------------------------------------------------------------------------------------
+# edge cases: empty rows / columns, tiny and ragged shapes, iteration caps
+# --------------------------------------------------------------------------------------
+def test_edge_cases(kkt, po, oracle):
+    import scipy.sparse as sp
+    from ipx_amd.synth import CscMatrix
+    rng = np.random.default_rng(9)
+    for (m, n, dens) in [(1, 1, 1.0), (7, 3, 0.5), (40, 90, 0.05), (300, 17, 0.02), (33, 700, 0.01)]:
+        M = sp.random(m, n, density=dens, random_state=int(rng.integers(1 << 30)), format="csc")
+        M.sort_indices()
+        A = CscMatrix(m, n, M.indptr, M.indices, M.data)       # has empty rows and columns
+        ctx = kkt.KktContext(A)
+        W = 10.0 ** rng.uniform(-1, 1, n + m)
+        rhs = rng.standard_normal(m)
+        ctx.normal_prepare(W)
+        l1, d1 = ctx.normal_apply(rhs)
+        l2, d2 = oracle.normal_apply(ocsc(po, A), W, rhs)
+        assert relerr(l1, l2) <= 1e-12 and abs(d1 - d2) <= 1e-12 * max(abs(d2), 1e-300)
+        assert ctx.diag_factorize(W, True) == 0
+        y, it, e, hist, _ = ctx.pcr_solve(rhs, 1e-10, None, -1, hist_cap=m + 200)
+        assert e == 0 and relerr(ctx.normal_apply(y)[0], rhs) < 1e-8
+        _, it, e, _, _ = ctx.pcr_solve(rhs, 1e-300, None, 0)     # maxiter = 0
+        assert (it, e) == (0, 201)
+        _, it, e, _, _ = ctx.pcr_solve(np.zeros(m), 1e-10, None, 50)   # zero rhs converges at once
+        assert (it, e) == (0, 0)
+        ctx.close()
+    with pytest.raises(kkt.KktError):
+        bad = CscMatrix(3, 2, [0, 1, 2], [0, 5], [1.0, 1.0])   # row index out of range
+        kkt.KktContext(bad)
+
+
+# --------------------------------------------------------------------------------------
+# BASELINE sizes: size-independent properties (the oracle would take minutes here)
+# --------------------------------------------------------------------------------------
+def test_full_size_properties(kkt):
+    m, n = 1000000, 2000000
+    A, st = diag_problem(m, n, seed=12345, spread=1.0)
+    ctx = kkt.KktContext(A)
+    W = st["xl"] / st["zl"]
+    ctx.normal_prepare(W)
+    rng = np.random.default_rng(0)
+    u, v = rng.standard_normal(m), rng.standard_normal(m)
+    Cu, uCu = ctx.normal_apply(u)
+    Cv, vCv = ctx.normal_apply(v)
+    Cuv, _ = ctx.normal_apply(u + 2.0 * v)
+    assert relerr(Cuv, Cu + 2.0 * Cv) < 1e-12            # linearity
+    assert abs(np.dot(v, Cu) - np.dot(u, Cv)) <= 1e-11 * abs(np.dot(v, Cu))   # symmetry
+    assert uCu > 0 and vCv > 0 and abs(uCu - np.dot(u, Cu)) <= 1e-12 * uCu    # SPD, fused dot
+    S = A.to_scipy()                                      # independent check with scipy
+    ref = S @ (W[:n] * (S.T @ u)) + W[n:] * u
+    assert relerr(Cu, ref) < 1e-12
+    assert ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"]) == 0
+    tol = 0.3 * np.sqrt(st["mu"])
+    x, y, it, e, _ = ctx.kkt_diag_solve(st["a"], st["b"], tol, 500)
+    assert e == 0 and 20 <= it <= 200
+    res1, res2 = kkt_residual_diag(A, W, st["a"], st["b"], x, y)
+    assert np.abs(res2).max() < 1e-8 * (1 + np.abs(x).max())
+    assert np.abs(np.sqrt(W[n:]) * res1[n:]).max() <= tol * (1 + 1e-9)
+    assert np.abs(res1[:n]).max() < 1e-8 * np.abs(x[:n] / W[:n]).max()
+    ctx.close()
