@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): KKT solves/sec + A*D*A' SpMV HBM GB/s on the 1M-row
+synthetic LP, 1/2/4/8 GPUs.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one KKTSolver::Solve (reference src/kkt_solver_diag.cc:82-118: right-hand-side
+assembly, preconditioned CR to tol = 0.3*sqrt(mu), solution recovery) on the C3 workload of
+SURVEY.md section 8(d): m = 1M, n = 2M, 8 nnz/col, IPM scaling spread s = 1, inputs resident in
+HBM.  N > 1: the SAME system with the rows of AI partitioned over the N ranks and one RCCL
+all-reduce per NormalMatrix apply (strong scaling; value = solves/s of the joint solve).
+
+One JSON line on rank 0:  metric/value/unit/...,
+  "roofline":     the NormalMatrix apply (two launches of spmv_phased_kernel) against the HBM roof:
+                  algorithmic bytes 2*nnz*12 + (n+m+2)*4 + 8*(3n+4m) per apply / HIP-event time;
+  "cpu_baseline": the same solve on ONE host core, timed in this run, by the reference's own
+                  objects (oracle/_ref, kind "reference") when that build is present, else by
+                  this repo's restatement (oracle/, kind "port").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1000000)
+    ap.add_argument("--cols", type=int, default=2000000)
+    ap.add_argument("--spread", type=float, default=1.0)
+    ap.add_argument("--maxiter", type=int, default=500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--basis", action="store_true", help="also time the basis-preconditioned solve (extra field)")
+    return ap.parse_args()
+
+
+def cpu_baseline(A, st, tol, maxiter):
+    """One solve of the same system on one host core (bounded: ~15-25 s at the default size)."""
+    from oracle import pyoracle as po
+    m, n = A.nrow, A.ncol
+    Ao = po.Csc(m, n, A.p, A.i, A.x)
+    cpu = os.cpu_count()
+    if po.ref_available():
+        try:
+            from ipx_amd import synth
+            ref = po.Ref()
+            v = synth.lp_vectors(m, n)
+            rm = ref.model(Ao, v["rhs"], v["constr_type"], v["obj"], v["lb"], v["ub"])
+            if rm.m == m and rm.n == n and not rm.dualized:
+                k = rm.kkt_diag(maxiter=maxiter)
+                k.factorize(np.ones(n + m), st["xl"], st["xu"], np.zeros(m), st["zl"], st["zu"])
+                t0 = time.perf_counter()
+                x, y, it, err = k.solve(st["a"], st["b"], tol)
+                dt = time.perf_counter() - t0
+                return dict(value=1.0 / dt, unit="solves/s", cores=1, kind="reference",
+                            sample="1 KKTSolverDiag::Solve of the same system by the reference's objects "
+                                   "(%d CR iterations, errflag %d, %.2f s; host has %d cores)" % (it, err, dt, cpu)), (x, y, it)
+        except Exception as exc:   # reference build unusable on this box: use the port
+            sys.stderr.write("reference baseline unavailable (%s); using the port\n" % exc)
+    orc = po.Oracle()
+    k = orc.kkt_diag(Ao, maxiter=maxiter)
+    k.factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"])
+    t0 = time.perf_counter()
+    x, y, it, err, _ = k.solve(st["a"], st["b"], tol)
+    dt = time.perf_counter() - t0
+    return dict(value=1.0 / dt, unit="solves/s", cores=1, kind="port",
+                sample="1 solve of the same system by oracle/ipx_oracle.cc (%d CR iterations, errflag %d, "
+                       "%.2f s; host has %d cores)" % (it, err, dt, cpu)), (x, y, it)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from ipx_amd import kkt, synth
+    from ipx_amd.partition import row_slab
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    m, n = args.rows, args.cols
+    A = synth.synthetic_lp(m, n, 8, 12345)
+    st = synth.synthetic_ipm_state(m, n, args.spread, 12345)
+    tol = 0.3 * np.sqrt(st["mu"])                 # kkt_tol*sqrt(mu), reference src/ipm.cc:572
+
+    # ---- this rank's slab of rows (the whole matrix when N = 1) ----
+    slab = row_slab(A, st, rank, world)
+    ctx = kkt.KktContext(slab.A, device=local_rank)
+    if world > 1:
+        ids = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(ids[0], rank, world)
+    err = ctx.kkt_diag_factorize(slab.xl, slab.xu, slab.zl, slab.zu, st["mu"])
+    assert err == 0
+    ctx.set_pointer_mode(True)
+    mg = slab.A.nrow
+    a = ctx.vector(n + mg, slab.a)
+    b = ctx.vector(mg, slab.b)
+    x = ctx.vector(n + mg)
+    y = ctx.vector(mg)
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        it, errflag, tm = ctx.kkt_diag_solve_resident(a, b, x, y, tol, args.maxiter)
+    sync()
+    t0 = time.perf_counter()
+    cr_time = 0.0
+    for _ in range(args.steps):
+        it, errflag, tm = ctx.kkt_diag_solve_resident(a, b, x, y, tol, args.maxiter)
+        cr_time += tm.cr
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- roofline of the dominant kernel pair, measured live with HIP events on the ctx stream ----
+    rng = np.random.default_rng(0)
+    rhs_d = ctx.vector(mg, rng.standard_normal(mg))
+    lhs_d = ctx.vector(mg)
+    ctx.time_normal_apply(rhs_d, lhs_d, 5)
+    reps = 50
+    apply_ms = ctx.time_normal_apply(rhs_d, lhs_d, reps) / reps
+    nnz = A.nnz
+    bytes_apply = 2 * nnz * 12 + (n + m + 2) * 4 + 8 * (3 * n + 4 * m)   # whole system (all ranks)
+    achieved = bytes_apply / (apply_ms * 1e-3) / 1e9
+    peak = HBM_PEAK_GBS * world
+
+    out = {
+        "metric": "kkt_solves_per_sec",
+        "value": args.steps / dt,
+        "unit": "solves/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "C3 synthetic LP m=%d n=%d 8 nnz/col (nnz=%d), KKTSolverDiag::Solve = diag-precond CR "
+                               "to tol=0.3*sqrt(mu), scaling spread s=%g; rows of AI partitioned over %d GPU(s)"
+                               % (m, n, nnz, args.spread, world),
+                   "cr_iterations_per_solve": it, "errflag": errflag,
+                   "cr_iterations_per_sec": it * args.steps / dt,
+                   "cr_loop_ms_per_solve": cr_time / args.steps * 1e3},
+        "roofline": {"bound": "hbm", "kernel": "spmv_phased_kernel (NormalMatrix apply = pass 1 + pass 2)",
+                     "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                     "traffic": None, "us_per_apply": apply_ms * 1e3, "algorithmic_bytes": bytes_apply},
+    }
+
+    if rank == 0 and world == 1 and args.basis:
+        out["config"]["basis_path"] = bench_basis(kkt, synth, m, n, args)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        ctx.set_pointer_mode(False)
+        xg, yg = x.download(), y.download()
+        base, (xc, yc, itc) = cpu_baseline(A, st, tol, args.maxiter)
+        out["cpu_baseline"] = base
+        out["config"]["gpu_over_cpu"] = out["value"] / base["value"]
+        out["config"]["parity_vs_cpu"] = {"iter_gpu": it, "iter_cpu": itc,
+                                          "y_relerr": float(np.abs(yg - yc).max() / np.abs(yc).max())}
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_basis(kkt, synth, m, n, args):
+    """KKTSolverBasis::_Solve on the planted-LU basis (synthetic factors)."""
+    A0 = synth.synthetic_lp(m, n, 8, 12345)
+    B = synth.planted_lu_basis(A0, offdiag=3, seed=12345)
+    st = synth.synthetic_ipm_state(m, n, 1.0, 12345)
+    colscale = synth.synthetic_basis_state(B["status"], 1.0, 12345)
+    ctx = kkt.KktContext(B["A"])
+    t0 = time.perf_counter()
+    ctx.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
+    prep = time.perf_counter() - t0
+    ctx.set_pointer_mode(True)
+    a, b = ctx.vector(n + m, st["a"]), ctx.vector(m, st["b"])
+    x, y = ctx.vector(n + m), ctx.vector(m)
+    tol = 0.3 * np.sqrt(st["mu"])
+    it, err, tm = ctx.kkt_basis_solve_resident(a, b, x, y, tol, args.maxiter)
+    t0 = time.perf_counter()
+    K = 3
+    for _ in range(K):
+        it, err, tm = ctx.kkt_basis_solve_resident(a, b, x, y, tol, args.maxiter)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    lv = ctx.split_levels()
+    ctx.close()
+    return {"solves_per_sec": 1.0 / dt, "cr_iterations": it, "errflag": err, "levels_Ut_Lt_L_U": lv,
+            "prepare_s": prep, "us_per_cr_iteration": tm.cr / max(it, 1) * 1e6,
+            "note": "planted (synthetic) LU factors, ~3 off-diagonals per column"}
+
+
+if __name__ == "__main__":
+    main()

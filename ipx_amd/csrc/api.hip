@@ -14,7 +14,7 @@ Context::~Context() {
     if (split) destroy_split(split);
     comm_destroy(this);
     if (h_state) (void)hipHostFree(h_state);
-    if (h_done) (void)hipHostFree(h_done);
+    if (h_cycle_done) (void)hipHostFree(h_cycle_done);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
     for (hipEvent_t e : ev_window) (void)hipEventDestroy(e);

@@ -4,6 +4,8 @@
 // that a single-GPU process never pays for (or depends on) librccl.
 #include <dlfcn.h>
 
+#include <cstdlib>
+
 #include "context.hpp"
 
 namespace ipxk {
@@ -57,18 +59,22 @@ void check(int rc, const char* what) {
 }
 }  // namespace
 
+// IPXK_FORCE_COMM=1 sends a single rank through the collective code path (used by the
+// GPU tests: the one-GPU test box cannot host a second rank).
+bool comm_active(const Context* c) { return c->comm != nullptr && (c->nranks > 1 || c->force_comm); }
+
 void comm_allreduce_sum(Context* c, double* buf, size_t count) {
-    if (c->nranks <= 1 || count == 0) return;
+    if (!comm_active(c) || count == 0) return;
     check(rccl().all_reduce(buf, buf, count, kNcclFloat64, kNcclSum, c->comm, c->stream), "ncclAllReduce");
 }
 
 void comm_allreduce_max(Context* c, double* buf, size_t count) {
-    if (c->nranks <= 1 || count == 0) return;
+    if (!comm_active(c) || count == 0) return;
     check(rccl().all_reduce(buf, buf, count, kNcclFloat64, kNcclMax, c->comm, c->stream), "ncclAllReduce");
 }
 
 void comm_allgather(Context* c, const double* send, double* recv, size_t count_per_rank) {
-    if (c->nranks <= 1) {
+    if (!comm_active(c)) {
         if (send != recv)
             IPXK_HIP(hipMemcpyAsync(recv, send, count_per_rank * sizeof(double), hipMemcpyDeviceToDevice,
                                     c->stream));
@@ -112,6 +118,16 @@ extern "C" int ipxk_comm_init(ipxk_context* c, const void* id128, int rank, int 
         check(rccl().comm_init_rank(&c->comm, nranks, id, rank), "ncclCommInitRank");
         c->rank = rank;
         c->nranks = nranks;
+        c->force_comm = getenv("IPXK_FORCE_COMM") != nullptr;
+        // global row count (defines the default iteration cap m+100 identically on every rank)
+        DevBuf<double> cnt(1);
+        const double mine = (double)c->m;
+        IPXK_HIP(hipMemcpyAsync(cnt.get(), &mine, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        check(rccl().all_reduce(cnt.get(), cnt.get(), 1, kNcclFloat64, kNcclSum, c->comm, c->stream), "ncclAllReduce");
+        double total = 0.0;
+        IPXK_HIP(hipMemcpyAsync(&total, cnt.get(), sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+        c->m_global = (int64_t)(total + 0.5);
         return IPXK_OK;
     } catch (const Error& e) {
         set_last_error(e.what());

@@ -3,6 +3,7 @@
 #pragma once
 
 #include "internal.hpp"
+#include "device_utils.hpp"
 
 struct ncclComm;
 
@@ -63,8 +64,6 @@ struct Context {
     DevBuf<double> partials;            // kNumPartialSlots * kPartialStride
     DevBuf<CrState> state;
     CrState* h_state = nullptr;         // pinned
-    int* h_done = nullptr;              // mapped pinned termination flag (host view)
-    int* d_done = nullptr;              //                                (device view)
     DevBuf<double> hist;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     std::vector<hipEvent_t> ev_window;
@@ -81,7 +80,13 @@ struct Context {
     // ---- multi-GPU ----
     ncclComm* comm = nullptr;
     int rank = 0, nranks = 1;
-    DevBuf<double> comm_scalars;        // nranks * 8 gathered scalars
+    int64_t m_global = 0;               // rows of the whole system (sum over ranks)
+    bool force_comm = false;
+    DevBuf<double> comm_scalars;        // scratch scalars (single-value reductions)
+    DevBuf<double> comm_send;           // kNumPartialSlots scalars of this rank
+    DevBuf<double> comm_gather;         // nranks * kNumPartialSlots, rank-major
+    int* h_cycle_done = nullptr;        // mapped pinned ring: `done` at the end of each cycle
+    int* d_cycle_done = nullptr;
 
     Context() = default;
     ~Context();
@@ -113,6 +118,8 @@ CrResult cr_solve_dev(Context* c, const double* rhs, double tol, const double* r
                       ipxint maxiter, double* lhs, bool lhs_is_zero, ipxk_interrupt_fn interrupt,
                       void* user, double* hist_host, ipxint hist_cap, ipxk_times* times);
 double reduce_partials_host(Context* c, int slot, int count, bool is_max);
+// partitioned runs: finalize this rank's partials of `slot`, all-gather, return the per-rank view
+struct PartRef publish_scalar(Context* c, int slot, int count, int op);
 
 // ---- kkt_diag.hip ----
 void kkt_diag_factorize_dev(Context* c, const double* xl, const double* xu, const double* zl,
@@ -139,6 +146,9 @@ void destroy_split(SplitOperator*);
 
 // ---- comm.hip ----
 void comm_allreduce_sum(Context* c, double* buf, size_t count);
+void comm_allreduce_max(Context* c, double* buf, size_t count);
+void comm_allgather(Context* c, const double* send, double* recv, size_t count_per_rank);
+bool comm_active(const Context* c);      // more than one rank (or forced for testing)
 void comm_destroy(Context* c);
 
 }  // namespace ipxk

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void cr_init_state_kernel(CrState* st, doub
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void cr_control_update_kernel(
     CrState* st, CrVecs v, PartRef res0, PartRef res1, PartRef pdot_ref, PartRef rsdot_ref,
-    double* res_next0, double* res_next1, double* hist, int* host_done) {
+    double* res_next0, double* res_next1, double* hist) {
     if (st->done) return;
     __shared__ double red[kBlock / 64 + 1];
     const long long k = st->k_finished;
@@ -125,7 +125,6 @@ __global__ __launch_bounds__(kBlock) void cr_control_update_kernel(
             st->iter = k;
             st->resnorm = resnorm;
             st->done = 1;
-            __hip_atomic_store(host_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }
@@ -184,36 +183,75 @@ __global__ __launch_bounds__(kBlock) void cr_direction_kernel(CrState* st, CrVec
     }
 }
 
-__global__ __launch_bounds__(kBlock) void finalize_scalar_kernel(PartRef ref, int is_max, double* out) {
+__global__ __launch_bounds__(kBlock) void finalize_scalar_kernel(PartRef ref, int op, double* out) {
     __shared__ double red[kBlock / 64 + 1];
-    const double v = is_max ? reduce_partials<MaxOp>(ref, red) : reduce_partials<SumOp>(ref, red);
+    const double v = op == 1 ? reduce_partials<MaxOp>(ref, red)
+                   : op == 2 ? reduce_partials<MinOp>(ref, red) : reduce_partials<SumOp>(ref, red);
     if (threadIdx.x == 0) *out = v;
+}
+
+// `done` at the end of a cycle, for the host (mapped pinned memory).  Every rank of a
+// partitioned solve reads the SAME snapshot, so all ranks enqueue the same number of cycles
+// (and hence of collectives).
+__global__ void snapshot_done_kernel(const CrState* st, int* host_slot) {
+    __hip_atomic_store(host_slot, st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-struct CrHostFlag {
-    int* host;   // mapped pinned memory, written by the control kernel at termination
-    int* dev;
+constexpr int kDoneRing = kWindow + 2;
+
+static void ensure_comm_buffers(Context* c) {
+    if (c->comm_scalars.size() < 64) c->comm_scalars.resize(64);
+    if (c->comm_send.size() < (size_t)kNumPartialSlots) {
+        c->comm_send.resize(kNumPartialSlots);
+        IPXK_HIP(hipMemsetAsync(c->comm_send.get(), 0, sizeof(double) * kNumPartialSlots, c->stream));
+    }
+    const size_t need = (size_t)c->nranks * kNumPartialSlots;
+    if (c->comm_gather.size() < need) c->comm_gather.resize(need);
+}
+
+// Scalars of the CR loop across ranks.  Single rank: a consumer kernel reduces the producer's
+// per-workgroup partials itself.  Partitioned: one finalize launch turns this rank's partials into
+// scalars, one all-gather of the (tiny) scalar table makes every rank's values visible, and the
+// consumer reduces over ranks in rank order -- every rank obtains bitwise identical scalars and
+// therefore takes identical decisions.
+struct Pub {
+    Context* c;
+    bool multi;
+    explicit Pub(Context* ctx) : c(ctx), multi(comm_active(ctx)) { if (multi) ensure_comm_buffers(ctx); }
+    PartRef ref(int slot, int nparts) const {
+        if (!multi) return PartRef{c->part(slot), nparts, 1};
+        return PartRef{c->comm_gather.get() + slot, c->nranks, kNumPartialSlots};
+    }
+    // op: 0 sum, 1 max, 2 min
+    void publish(int slot0, int n0, int op0, int slot1 = -1, int n1 = 0, int op1 = 0) const {
+        if (!multi) return;
+        hipLaunchKernelGGL(finalize_scalar_kernel, dim3(1), dim3(kBlock), 0, c->stream,
+                           PartRef{c->part(slot0), n0, 1}, op0, c->comm_send.get() + slot0);
+        if (slot1 >= 0)
+            hipLaunchKernelGGL(finalize_scalar_kernel, dim3(1), dim3(kBlock), 0, c->stream,
+                               PartRef{c->part(slot1), n1, 1}, op1, c->comm_send.get() + slot1);
+        comm_allgather(c, c->comm_send.get(), c->comm_gather.get(), kNumPartialSlots);
+    }
 };
 
-static CrHostFlag host_flag(Context* c) {
-    if (!c->h_done) {
-        IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_done), 64, hipHostMallocMapped));
-        IPXK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_done), c->h_done, 0));
-    }
-    return CrHostFlag{c->h_done, c->d_done};
+PartRef publish_scalar(Context* c, int slot, int count, int op) {
+    const Pub pub(c);
+    pub.publish(slot, count, op);
+    return pub.ref(slot, count);
 }
 
 double reduce_partials_host(Context* c, int slot, int count, bool is_max) {
-    DevBuf<double>& scratch = c->comm_scalars;
-    if (scratch.size() < 64) scratch.resize(64);
-    PartRef ref{c->part(slot), count, 1};
-    hipLaunchKernelGGL(finalize_scalar_kernel, dim3(1), dim3(kBlock), 0, c->stream, ref,
-                       is_max ? 1 : 0, scratch.get() + 63);
+    ensure_comm_buffers(c);
+    double* out = c->comm_scalars.get() + 63;
+    hipLaunchKernelGGL(finalize_scalar_kernel, dim3(1), dim3(kBlock), 0, c->stream,
+                       PartRef{c->part(slot), count, 1}, is_max ? 1 : 0, out);
+    if (is_max) comm_allreduce_max(c, out, 1);
+    else comm_allreduce_sum(c, out, 1);
     double v = 0.0;
-    IPXK_HIP(hipMemcpyAsync(&v, scratch.get() + 63, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    IPXK_HIP(hipMemcpyAsync(&v, out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     IPXK_HIP(hipStreamSynchronize(c->stream));
     return v;
 }
@@ -228,6 +266,10 @@ static void ensure_workspaces(Context* c) {
     if (c->state.size() == 0) c->state.resize(1);
     if (!c->h_state) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_state), sizeof(CrState)));
     if (!c->ev_a) { IPXK_HIP(hipEventCreate(&c->ev_a)); IPXK_HIP(hipEventCreate(&c->ev_b)); }
+    if (!c->h_cycle_done) {
+        IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_cycle_done), 64 * sizeof(int), hipHostMallocMapped));
+        IPXK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_cycle_done), c->h_cycle_done, 0));
+    }
     while ((int)c->ev_window.size() < kWindow + 1) {
         hipEvent_t e;
         IPXK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -259,15 +301,15 @@ static CrResult run_cr(Context* c, const CrOps& ops, const double* rhs, double t
     ensure_workspaces(c);
     hipStream_t s = c->stream;
     const int m = (int)c->m;
-    if (maxiter < 0) maxiter = c->m + 100;            // :114-115
+    if (maxiter < 0) maxiter = (comm_active(c) ? c->m_global : c->m) + 100;   // :114-115
     if (hist_cap < 0) hist_cap = 0;
     if (!hist_host) hist_cap = 0;
     if (c->hist.size() < (size_t)hist_cap + 1) c->hist.resize((size_t)hist_cap + 1);
-    CrHostFlag flag = host_flag(c);
-    *(volatile int*)flag.host = 0;   // the previous solve has been synchronized
     CrState* st = c->state.get();
     int* done = &st->done;
     const int g = vec_grid(m);
+    const Pub pub(c);
+    for (int i = 0; i < kDoneRing; i++) c->h_cycle_done[i] = 0;   // previous solve is synchronized
 
     CrVecs v;
     v.m = m; v.lhs = lhs; v.residual = c->v_residual.get(); v.sresidual = c->v_sresidual.get();
@@ -277,7 +319,6 @@ static CrResult run_cr(Context* c, const CrOps& ops, const double* rhs, double t
     IPXK_HIP(hipEventRecord(c->ev_a, s));
 
     // ---- initialisation, :117-126 / :33-41 ----
-    PartRef none{nullptr, 0, 1};
     if (lhs_is_zero) {
         hipLaunchKernelGGL(residual_init_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs,
                            (const double*)nullptr, resscale, v.residual, c->part(kPartRes0));
@@ -286,49 +327,53 @@ static CrResult run_cr(Context* c, const CrOps& ops, const double* rhs, double t
         hipLaunchKernelGGL(residual_init_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs,
                            (const double*)v.Cres, resscale, v.residual, c->part(kPartRes0));
     }
-    PartRef res0{c->part(kPartRes0), g, 1}, res1{c->part(kPartRes1), g, 1};
-    PartRef rsdot = none;
-    if (MODE != kModePlain) {
-        const int np = diag_apply_dev(c, v.residual, v.sresidual, kPartRsdot, nullptr);
-        rsdot = PartRef{c->part(kPartRsdot), np, 1};
-    }
+    int nrsdot = 0;
+    if (MODE != kModePlain) nrsdot = diag_apply_dev(c, v.residual, v.sresidual, kPartRsdot, nullptr);
+    if (MODE != kModePlain) pub.publish(kPartRes0, g, 1, kPartRsdot, nrsdot, 0);
+    else pub.publish(kPartRes0, g, 1);
+    const PartRef res0 = pub.ref(kPartRes0, g), res1 = pub.ref(kPartRes1, g);
+    const PartRef rsdot = MODE != kModePlain ? pub.ref(kPartRsdot, nrsdot) : PartRef{nullptr, 0, 1};
     hipLaunchKernelGGL(cr_init_state_kernel, dim3(1), dim3(kBlock), 0, s, st, tol, (long long)maxiter,
                        (long long)hist_cap, rsdot);
     const double* csrc = MODE == kModePlain ? v.residual : v.sresidual;
     int ncdot = ops.applyC(c, csrc, v.Cres, nullptr);
-    PartRef cdot_ref{c->part(kPartCdot), ncdot, 1};
-    PartRef pdot_ref{c->part(kPartPdot), g, 1};
-    hipLaunchKernelGGL((cr_direction_kernel<MODE, true>), dim3(g), dim3(kBlock), 0, s, st, v, cdot_ref,
-                       c->part(kPartPdot));
-    if (MODE == kModePcrSmw) {
-        const int np = diag_apply_dev(c, v.Cstep, v.pCstep, kPartPdot, nullptr);
-        pdot_ref = PartRef{c->part(kPartPdot), np, 1};
-    }
+    pub.publish(kPartCdot, ncdot, 0);
+    hipLaunchKernelGGL((cr_direction_kernel<MODE, true>), dim3(g), dim3(kBlock), 0, s, st, v,
+                       pub.ref(kPartCdot, ncdot), c->part(kPartPdot));
+    int npdot = g;
+    if (MODE == kModePcrSmw) npdot = diag_apply_dev(c, v.Cstep, v.pCstep, kPartPdot, nullptr);
+    pub.publish(kPartPdot, npdot, 0);
+    const PartRef pdot_ref = pub.ref(kPartPdot, npdot);
 
     // ---- main loop: cycles of 5 iterations ----
     ipxint interrupt_flag = 0;
-    long long cycle = 0;
-    for (;; cycle++) {
+    for (long long cycle = 0;; cycle++) {
         const long long k0 = cycle * 5;
         if (k0 > maxiter) break;
-        if (*(volatile int*)flag.host) break;
         if (cycle >= kWindow) {
-            IPXK_HIP(hipEventSynchronize(c->ev_window[(cycle - kWindow) % (kWindow + 1)]));
-            if (*(volatile int*)flag.host) break;
+            const long long cw = cycle - kWindow;
+            IPXK_HIP(hipEventSynchronize(c->ev_window[cw % (kWindow + 1)]));
+            if (*(volatile int*)(c->h_cycle_done + cw % kDoneRing)) break;
         }
         if (interrupt && (interrupt_flag = interrupt(user)) != 0) break;   // :209 / :84
         for (long long k = k0; k < k0 + 5 && k <= maxiter; k++) {
             hipLaunchKernelGGL((cr_control_update_kernel<MODE>), dim3(g), dim3(kBlock), 0, s, st, v,
                                res0, res1, pdot_ref, rsdot, c->part(kPartRes0), c->part(kPartRes1),
-                               c->hist.get(), flag.dev);
+                               c->hist.get());
             ncdot = ops.applyC(c, csrc, v.Cres, done);
-            cdot_ref.count = ncdot;
+            // the control kernel of iteration k wrote the residual-norm partials of parity (k+1)&1
+            pub.publish(kPartCdot, ncdot, 0, ((k + 1) & 1) ? kPartRes1 : kPartRes0, g, 1);
             hipLaunchKernelGGL((cr_direction_kernel<MODE, false>), dim3(g), dim3(kBlock), 0, s, st, v,
-                               cdot_ref, c->part(kPartPdot));
+                               pub.ref(kPartCdot, ncdot), c->part(kPartPdot));
             if (MODE == kModePcrSmw) diag_apply_dev(c, v.Cstep, v.pCstep, kPartPdot, done);
-            if (MODE != kModePlain && (k + 1) % 5 == 0)
+            if (MODE != kModePlain && (k + 1) % 5 == 0) {
                 diag_apply_dev(c, v.residual, v.sresidual, kPartRsdot, done);   // :187-194
+                pub.publish(kPartPdot, npdot, 0, kPartRsdot, nrsdot, 0);
+            } else {
+                pub.publish(kPartPdot, npdot, 0);
+            }
         }
+        hipLaunchKernelGGL(snapshot_done_kernel, dim3(1), dim3(1), 0, s, st, c->d_cycle_done + cycle % kDoneRing);
         IPXK_HIP(hipEventRecord(c->ev_window[cycle % (kWindow + 1)], s));
     }
     IPXK_HIP(hipEventRecord(c->ev_b, s));

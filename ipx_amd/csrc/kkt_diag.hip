@@ -51,6 +51,13 @@ __global__ __launch_bounds__(kBlock) void kkt_regularize_kernel(int n, int m, do
     }
 }
 
+// x[j] = w[j]*(a[j] - aty[j])   (kkt_solver_diag.cc:111-112, after the cross-rank sum of A'y)
+__global__ void recover_x_kernel(int n, const double* __restrict__ w, const double* __restrict__ a,
+                                 const double* __restrict__ aty, double* __restrict__ x) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        x[j] = w[j] * (a[j] - aty[j]);
+}
+
 __global__ void fill_kernel(int len, double value, double* __restrict__ out) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x)
         out[i] = value;
@@ -75,8 +82,13 @@ void kkt_diag_factorize_dev(Context* c, const double* xl, const double* xu, cons
     if (xl) {
         hipLaunchKernelGGL(kkt_weights_kernel, dim3(g), dim3(kBlock), 0, s, n + m, xl, xu, zl, zu,
                            c->W_own.get(), c->part(kPartScratch));
-        hipLaunchKernelGGL(kkt_regularize_kernel, dim3(g), dim3(kBlock), 0, s, n, m, mu,
-                           PartRef{c->part(kPartScratch), g, 1}, c->W_own.get(), c->resscale.get());
+        PartRef gmin{c->part(kPartScratch), g, 1};
+        if (comm_active(c)) {
+            // smallest nonzero g over all ranks (the slack part of G is partitioned)
+            gmin = publish_scalar(c, kPartScratch, g, 2);
+        }
+        hipLaunchKernelGGL(kkt_regularize_kernel, dim3(g), dim3(kBlock), 0, s, n, m, mu, gmin,
+                           c->W_own.get(), c->resscale.get());
     } else {
         // :50-52 Factorize(nullptr): G = identity
         hipLaunchKernelGGL(fill_kernel, dim3(g), dim3(kBlock), 0, s, n + m, 1.0, c->W_own.get());
@@ -104,8 +116,7 @@ CrResult kkt_diag_solve_dev(Context* c, const double* a, const double* b, double
     // :90-92  rhs = -b + A*(Ws.*as) + W_I.*a_I
     hipLaunchKernelGGL(multiply_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, s, n, W, a, c->k_tmp.get());
     EpiKktRhs er{{}, b, W + n, a + n, c->v_rhs.get()};
-    launch_spmv(c->Arows, c->k_tmp.get(), er, nullptr, nullptr, s);
-    if (c->nranks > 1) throw Error(IPXK_E_UNSUPPORTED, "kkt_diag_solve: use the partitioned driver");
+    launch_spmv(c->Arows, c->k_tmp.get(), er, nullptr, nullptr, s);   // rows are local: no exchange
 
     // :95-105
     IPXK_HIP(hipMemsetAsync(y, 0, sizeof(double) * m, s));
@@ -113,8 +124,16 @@ CrResult kkt_diag_solve_dev(Context* c, const double* a, const double* b, double
                                  user, nullptr, 0, times);
 
     // :108-117
-    EpiRecoverX ex{{}, W, a, x};
-    launch_spmv(c->Acols, y, ex, nullptr, nullptr, s);
+    if (comm_active(c)) {
+        // A'y = sum over ranks of A_g' y_g
+        EpiScale ea{{}, nullptr, c->tcols.get()};
+        launch_spmv(c->Acols, y, ea, nullptr, nullptr, s);
+        comm_allreduce_sum(c, c->tcols.get(), (size_t)n);
+        hipLaunchKernelGGL(recover_x_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, s, n, W, a, c->tcols.get(), x);
+    } else {
+        EpiRecoverX ex{{}, W, a, x};
+        launch_spmv(c->Acols, y, ex, nullptr, nullptr, s);
+    }
     EpiResidualRows es{{}, b, x + n};
     launch_spmv(c->Arows, x, es, nullptr, nullptr, s);
     IPXK_HIP(hipGetLastError());

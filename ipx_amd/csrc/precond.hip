@@ -191,6 +191,9 @@ void diag_factorize_dev(Context* c, const double* W, bool precond_dense_cols, ip
     c->diag_factorized = false;
     c->diagonal.resize(m);
     const bool smw = precond_dense_cols && c->num_dense > 0;
+    if (smw && comm_active(c))
+        throw Error(IPXK_E_UNSUPPORTED, "dense-column (SMW) preconditioning is not available on a row-partitioned "
+                                        "system: pass precond_dense_cols = 0");
     const double* Wcols = W;
     if (smw) {
         c->Wnodense.resize(n);

@@ -250,7 +250,7 @@ void normal_apply_dev(Context* c, const double* W, const double* rhs, double* lh
     const int64_t n = c->n;
     EpiScale e1{{}, W, c->tcols.get()};
     launch_spmv(c->Acols, rhs, e1, nullptr, done, c->stream);
-    if (c->nranks > 1) comm_allreduce_sum(c, c->tcols.get(), (size_t)n);
+    if (comm_active(c)) comm_allreduce_sum(c, c->tcols.get(), (size_t)n);
     EpiNormalRows e2{{}, W + n, rhs, lhs};
     const int np = launch_spmv(c->Arows, c->tcols.get(), e2, ndot ? c->part(kPartCdot) : nullptr,
                                done, c->stream);

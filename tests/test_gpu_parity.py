@@ -306,3 +306,30 @@ def test_full_size_properties(kkt):
     assert np.abs(np.sqrt(W[n:]) * res1[n:]).max() <= tol * (1 + 1e-9)
     assert np.abs(res1[:n]).max() < 1e-8 * np.abs(x[:n] / W[:n]).max()
     ctx.close()
+
+
+# --------------------------------------------------------------------------------------
+# the collective code path (RCCL), exercised with a one-rank communicator: IPXK_FORCE_COMM
+# routes a single rank through finalize + all-gather + all-reduce exactly as N ranks would run
+# --------------------------------------------------------------------------------------
+def test_partitioned_code_path_single_rank(kkt, po, oracle, monkeypatch):
+    from ipx_amd import partition
+    monkeypatch.setenv("IPXK_FORCE_COMM", "1")
+    m, n = 2000, 4300
+    A, st = diag_problem(m, n, seed=55)
+    slab = partition.row_slab(A, st, 0, 1)
+    ctx = kkt.KktContext(slab.A)
+    ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    assert ctx.kkt_diag_factorize(slab.xl, slab.xu, slab.zl, slab.zu, st["mu"], precond_dense_cols=False) == 0
+    tol = 0.3 * np.sqrt(st["mu"])
+    x1, y1, it1, e1, _ = ctx.kkt_diag_solve(slab.a, slab.b, tol, 500)
+    ko = oracle.kkt_diag(ocsc(po, A), maxiter=500)
+    ko.factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"])
+    x2, y2, it2, e2, _ = ko.solve(st["a"], st["b"], tol)
+    assert e1 == e2 == 0 and iters_close(it1, it2)
+    assert relerr(y1, y2) < 1e-6 and relerr(x1, x2) < 1e-5
+    rhs = np.random.default_rng(6).standard_normal(m)
+    l1, d1 = ctx.normal_apply(rhs)
+    l2, d2 = oracle.normal_apply(ocsc(po, A), ko.get()[0], rhs)
+    assert relerr(l1, l2) <= 1e-12 and abs(d1 - d2) <= 1e-12 * abs(d2)
+    ctx.close()

@@ -1,0 +1,83 @@
+"""CPU: the oracle against the reference's OWN objects (oracle/_ref), live, on fresh seeds.
+Skipped where the reference build is absent (the GPU box only has the prebuilt files, which is
+enough to run; a checkout without /root/reference and without oracle/_ref skips)."""
+import numpy as np
+import pytest
+
+from helpers import basis_problem, diag_problem, relerr
+
+
+@pytest.fixture(scope="module")
+def po():
+    from oracle import pyoracle
+    return pyoracle
+
+
+@pytest.mark.parametrize("seed,m,n,num_dense", [(101, 120, 260, 0), (102, 333, 700, 0), (103, 400, 900, 3)])
+def test_diag_path_bitwise(oracle, ref, po, seed, m, n, num_dense):
+    from ipx_amd import synth
+    A, st = diag_problem(m, n, seed=seed, num_dense=num_dense)
+    v = synth.lp_vectors(m, n)
+    Ao = po.Csc(m, n, A.p, A.i, A.x)
+    rm = ref.model(Ao, v["rhs"], v["constr_type"], v["obj"], v["lb"], v["ub"])
+    assert (rm.m, rm.n, rm.dualized) == (m, n, 0)
+    AI = rm.AI()
+    assert np.array_equal(AI.p[: n + 1], A.p) and np.array_equal(AI.x[: A.nnz], A.x)   # no rescaling
+    nd, nzd = oracle.find_dense_columns(Ao)
+    assert nd == rm.num_dense
+    assert [rm.is_dense(j) for j in range(n)] == list(np.diff(A.p) >= nzd)
+    AT, RT = oracle.transpose(po.Csc(m, n + m, AI.p, AI.i, AI.x)), rm.AIt()
+    assert np.array_equal(AT.p, RT.p) and np.array_equal(AT.i, RT.i) and np.array_equal(AT.x, RT.x)
+    W = st["xl"] / st["zl"]
+    rhs = np.random.default_rng(seed).standard_normal(m)
+    for Wv in (W, None):
+        l1, d1 = rm.normal_apply(Wv, rhs)
+        l2, d2 = oracle.normal_apply(Ao, Wv, rhs)
+        assert np.array_equal(l1, l2) and d1 == d2
+    k = rm.kkt_diag(maxiter=400)
+    err, mu = k.factorize(np.ones(n + m), st["xl"], st["xu"], np.zeros(m), st["zl"], st["zu"])
+    ko = oracle.kkt_diag(Ao, nzd, True, 400)
+    assert ko.factorize(st["xl"], st["xu"], st["zl"], st["zu"], mu) == err == 0
+    for tol in (0.3 * np.sqrt(mu), 1e-9):
+        x1, y1, it1, e1 = k.solve(st["a"], st["b"], tol)
+        x2, y2, it2, e2, _ = ko.solve(st["a"], st["b"], tol)
+        assert e1 == e2
+        if num_dense == 0:      # no LAPACK involved: bit for bit
+            assert it1 == it2 and np.array_equal(x1, x2) and np.array_equal(y1, y2)
+        else:                   # Cholesky rounding differs (in-repo dpotrf vs OpenBLAS)
+            assert abs(it1 - it2) <= 2 and relerr(y1, y2) < 1e-6
+
+
+def test_sparse_kernels_bitwise(oracle, ref, po):
+    B, st, colscale = basis_problem(180, 400, seed=77, num_free=2, num_fixed=3)
+    cs = lambda M: po.Csc(M.nrow, M.ncol, M.p, M.i, M.x)
+    L, U, AI = cs(B["L"]), cs(B["U"]), cs(B["A"].with_identity())
+    x0 = np.random.default_rng(1).standard_normal(180)
+    for trans, uplo, unit, T in (("t", "u", 0, U), ("t", "l", 1, L), ("n", "l", 1, L), ("n", "u", 0, U)):
+        a, na = ref.trisolve(T, x0, trans, uplo, unit)
+        b, nb = oracle.trisolve(T, x0, trans, uplo, unit)
+        assert np.array_equal(a, b) and na == nb
+    assert np.array_equal(ref.forward_solve(L, U, x0), oracle.forward_solve(L, U, x0))
+    assert np.array_equal(ref.backward_solve(L, U, x0), oracle.backward_solve(L, U, x0))
+    assert np.array_equal(ref.inverse_perm(B["rowperm"]), oracle.inverse_perm(B["rowperm"]))
+    nb_cols = np.nonzero(B["status"] == -1)[0]
+    rpi = oracle.inverse_perm(B["rowperm"])
+    N1 = ref.copy_permute_scale(AI, nb_cols, rpi, colscale[nb_cols])
+    N2 = oracle.copy_permute_scale(AI, nb_cols, rpi, colscale[nb_cols])
+    assert np.array_equal(N1.p, N2.p) and np.array_equal(N1.i, N2.i) and np.array_equal(N1.x, N2.x)
+    z = np.zeros(180)
+    assert np.array_equal(ref.add_normal_product(N1, None, x0, z), oracle.add_normal_product(N2, None, x0, z))
+    assert ref.dot(x0, x0[::-1].copy()) == oracle.dot(x0, x0[::-1].copy())
+    # the split operator + plain CR from explicit factors
+    S = oracle.split_prepare(AI, 400, L, U, B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
+    pre = S.get()
+    Us = po.Csc(180, 180, U.p, U.i, pre["Ux"])
+    R = ref.split(L, Us, pre["N"], pre["free_positions"])
+    l1, d1 = R.apply(x0)
+    l2, d2 = S.apply(x0)
+    assert np.array_equal(l1, l2) and d1 == d2
+    rhs = x0.copy()
+    rhs[pre["free_positions"]] = 0.0
+    y1, it1, e1, _ = R.cr_solve(rhs, 1e-9, -1)
+    y2, it2, e2, _ = oracle.cr_solve(S.apply, rhs, 1e-9, None, -1)
+    assert (it1, e1) == (it2, e2) and np.array_equal(y1, y2)
