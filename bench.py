@@ -150,6 +150,15 @@ def main():
     bytes_apply = 2 * nnz * 12 + (n + m + 2) * 4 + 8 * (3 * n + 4 * m)   # whole system (all ranks)
     achieved = bytes_apply / (apply_ms * 1e-3) / 1e9
     peak = HBM_PEAK_GBS * world
+    # L2<->fabric bytes per apply from the PMC passes of the same command (profiles/, separate
+    # rocprofv3 --pmc runs; bench.py cannot collect counters on itself)
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if world == 1 and pm["workload"] == "C3 m=%d n=%d nnz=%d" % (m, n, nnz):
+            traffic = pm["traffic_bytes_per_apply"]
+    except (OSError, KeyError, ValueError):
+        pass
 
     out = {
         "metric": "kkt_solves_per_sec",
@@ -172,7 +181,7 @@ def main():
                    "cr_loop_ms_per_solve": cr_time / args.steps * 1e3},
         "roofline": {"bound": "hbm", "kernel": "spmv_phased_kernel (NormalMatrix apply = pass 1 + pass 2)",
                      "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                     "traffic": None, "us_per_apply": apply_ms * 1e3, "algorithmic_bytes": bytes_apply},
+                     "traffic": traffic, "us_per_apply": apply_ms * 1e3, "algorithmic_bytes": bytes_apply},
     }
 
     if rank == 0 and world == 1 and args.basis:
