@@ -1,0 +1,57 @@
+#include "kkt_solver_diag_hip.h"
+
+#include <cassert>
+
+namespace ipx {
+
+namespace {
+ipxint PollInterrupt(void* control) {
+    return static_cast<const Control*>(control)->InterruptCheck();
+}
+}  // namespace
+
+KKTSolverDiagHip::KKTSolverDiagHip(const Control& control, const Model& model)
+    : control_(control), model_(model), device_(model) {}
+
+// Builds W, resscale, the normal matrix and the (dense-column aware) diagonal
+// preconditioner on the device; see reference src/kkt_solver_diag.cc:18-65.
+void KKTSolverDiagHip::_Factorize(Iterate* pt, Info* info) {
+    iter_ = 0;
+    factorized_ = false;
+    ipxint errflag = 0;
+    const int dense = control_.precond_dense_cols() ? 1 : 0;
+    if (pt) {
+        const Vector& xl = pt->xl();
+        const Vector& xu = pt->xu();
+        const Vector& zl = pt->zl();
+        const Vector& zu = pt->zu();
+        HipCheck(ipxk_kkt_diag_factorize(device_.get(), &xl[0], &xu[0], &zl[0], &zu[0],
+                                         pt->mu(), dense, &errflag));
+    } else {
+        HipCheck(ipxk_kkt_diag_factorize(device_.get(), nullptr, nullptr, nullptr, nullptr,
+                                         0.0, dense, &errflag));
+    }
+    info->errflag = errflag;          // 0 or IPX_ERROR_lapack_chol
+    if (errflag)
+        return;
+    factorized_ = true;
+}
+
+// Reference src/kkt_solver_diag.cc:82-118.
+void KKTSolverDiagHip::_Solve(const Vector& a, const Vector& b, double tol,
+                               Vector& x, Vector& y, Info* info) {
+    assert(factorized_);
+    ipxint iter = 0, errflag = 0;
+    ipxk_times times;
+    HipCheck(ipxk_kkt_diag_solve(device_.get(), &a[0], &b[0], tol, maxiter_, &x[0], &y[0],
+                                 &iter, &errflag, PollInterrupt,
+                                 const_cast<Control*>(&control_), &times));
+    info->errflag = errflag;
+    info->kktiter1 += iter;
+    info->time_cr1 += times.cr;
+    info->time_cr1_AAt += times.op;
+    info->time_cr1_pre += times.precond;
+    iter_ += iter;
+}
+
+}  // namespace ipx

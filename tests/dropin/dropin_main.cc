@@ -1,0 +1,114 @@
+// TEST INFRASTRUCTURE.  Drop-in check at the reference's own boundary: the reference's
+// Model / Iterate / Control objects (from oracle/_ref, built from the reference's sources) drive
+// BOTH ipx::KKTSolverDiag (reference, CPU) and ipx::KKTSolverDiagHip (this repo, MI355X) through
+// the abstract ipx::KKTSolver interface (Factorize / Solve / iter), and the results are compared.
+// Built by `make -C oracle dropin` into oracle/_ref/test_dropin; run by tests/test_gpu_dropin.py.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "control.h"
+#include "iterate.h"
+#include "kkt_solver_diag.h"
+#include "kkt_solver_diag_hip.h"
+#include "model.h"
+#include "presolver.h"
+#include "user_model.h"
+
+using ipx::Int;
+using ipx::Vector;
+
+static double RelErr(const Vector& a, const Vector& b) {
+    double num = 0.0, den = 0.0;
+    for (size_t i = 0; i < a.size(); i++) {
+        num = std::max(num, std::abs(a[i] - b[i]));
+        den = std::max(den, std::abs(b[i]));
+    }
+    return den > 0.0 ? num / den : num;
+}
+
+struct Result { Vector x, y; Int iter; Int errflag; double time_cr1; Int kktiter1; };
+
+static Result Run(ipx::KKTSolver& kkt, ipx::Iterate* iterate, const Vector& a, const Vector& b,
+                  double tol, Int n, Int m) {
+    ipx::Info info;
+    Result r;
+    r.x.resize(n + m);
+    r.y.resize(m);
+    kkt.Factorize(iterate, &info);
+    if (info.errflag) { r.errflag = info.errflag; r.iter = -1; return r; }
+    kkt.Solve(a, b, tol, r.x, r.y, &info);
+    r.iter = kkt.iter();
+    r.errflag = info.errflag;
+    r.time_cr1 = info.time_cr1;
+    r.kktiter1 = info.kktiter1;
+    return r;
+}
+
+int main(int argc, char** argv) {
+    const Int m = argc > 1 ? atol(argv[1]) : 3000;
+    const Int n = argc > 2 ? atol(argv[2]) : 7000;
+    const Int k = 8;
+    std::mt19937_64 rng(12345);
+    std::uniform_real_distribution<double> uval(0.5, 4.0), u01(-1.0, 1.0), uab(-0.5, 0.5);
+    std::vector<Int> Ap(n + 1), Ai;
+    std::vector<double> Ax;
+    for (Int j = 0; j < n; j++) {
+        Ap[j] = (Int)Ai.size();
+        std::vector<Int> rows;
+        while ((Int)rows.size() < std::min(k, m)) {
+            Int r = (Int)(rng() % (uint64_t)m);
+            bool dup = false;
+            for (Int q : rows) dup |= q == r;
+            if (!dup) rows.push_back(r);
+        }
+        std::sort(rows.begin(), rows.end());
+        for (Int r : rows) { Ai.push_back(r); Ax.push_back((rng() & 1 ? 1.0 : -1.0) * uval(rng)); }
+    }
+    Ap[n] = (Int)Ai.size();
+    std::vector<double> obj(n, 1.0), lb(n, 0.0), ub(n, INFINITY), rhs(m, 1.0);
+    std::vector<char> ct(m, '<');
+
+    ipx::Control control;
+    ipx::Parameters params;
+    params.display = 0;
+    control.parameters(params);
+    ipx::UserModel user_model;
+    ipx::Model model;
+    if (user_model.Load(control, m, n, Ap.data(), Ai.data(), Ax.data(), rhs.data(), ct.data(),
+                        obj.data(), lb.data(), ub.data()) != 0) return 2;
+    ipx::Presolver presolver(user_model, model);
+    if (presolver.PresolveModel(control) != 0 || model.rows() != m || model.cols() != n) return 2;
+
+    Vector x0(1.0, n + m), y0(0.0, m), xl(n + m), xu(INFINITY, n + m), zl(n + m), zu(0.0, n + m);
+    for (Int j = 0; j < n + m; j++) { xl[j] = std::pow(10.0, u01(rng)); zl[j] = std::pow(10.0, u01(rng)); }
+    ipx::Iterate iterate(model);
+    iterate.Initialize(x0, xl, xu, y0, zl, zu);
+    Vector a(n + m), b(m);
+    for (auto& v : a) v = uab(rng);
+    for (auto& v : b) v = uab(rng);
+    const double tol = 0.3 * std::sqrt(iterate.mu());
+
+    int failures = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        ipx::Iterate* it = pass == 0 ? &iterate : nullptr;      // pass 1: Factorize(nullptr)
+        const double t = pass == 0 ? tol : 1e-6;
+        ipx::KKTSolverDiag cpu(control, model);
+        ipx::KKTSolverDiagHip gpu(control, model);
+        cpu.maxiter(500);
+        gpu.maxiter(500);
+        Result rc = Run(cpu, it, a, b, t, n, m);
+        Result rg = Run(gpu, it, a, b, t, n, m);
+        const double ey = RelErr(rg.y, rc.y), ex = RelErr(rg.x, rc.x);
+        const bool ok = rc.errflag == rg.errflag && std::labs((long)(rc.iter - rg.iter)) <= 2 &&
+                        ey < 1e-6 && ex < 1e-5 && rg.kktiter1 == rg.iter && gpu.maxiter() == 500;
+        printf("%s: cpu iter %ld errflag %ld | hip iter %ld errflag %ld | y relerr %.2e x relerr %.2e | "
+               "time_cr1 cpu %.4fs hip %.4fs -> %s\n",
+               pass == 0 ? "Factorize(iterate)" : "Factorize(nullptr)", (long)rc.iter, (long)rc.errflag,
+               (long)rg.iter, (long)rg.errflag, ey, ex, rc.time_cr1, rg.time_cr1, ok ? "PASS" : "FAIL");
+        failures += !ok;
+    }
+    return failures ? 1 : 0;
+}
