@@ -294,6 +294,7 @@ int ipxk_cr_solve(ipxk_context* c, const double* rhs, double tol, const double* 
         *iter = r.iter;
         *errflag = r.errflag;
         finish_out(c, lhs, dlhs, m);
+        check_sweep_abort(c);
     });
 }
 
@@ -373,6 +374,7 @@ int ipxk_split_apply(ipxk_context* c, const double* rhs, double* lhs, double* rh
         if (rhs_dot_lhs) *rhs_dot_lhs = reduce_partials_host(c, kPartCdot, np, false);
         finish_out(c, lhs, dlhs, m);
         IPXK_HIP(hipStreamSynchronize(c->stream));
+        check_sweep_abort(c);
     });
 }
 
@@ -390,6 +392,7 @@ static int inplace_solve(ipxk_context* c, double* x, bool forward) {
         IPXK_HIP(hipGetLastError());
         finish_out(c, x, dx, m);
         IPXK_HIP(hipStreamSynchronize(c->stream));
+        check_sweep_abort(c);
     });
 }
 
@@ -408,6 +411,7 @@ int ipxk_solve_dense(ipxk_context* c, const double* rhs, double* lhs, char trans
         IPXK_HIP(hipGetLastError());
         finish_out(c, lhs, dlhs, m);
         IPXK_HIP(hipStreamSynchronize(c->stream));
+        check_sweep_abort(c);
     });
 }
 
@@ -437,6 +441,7 @@ int ipxk_kkt_basis_solve(ipxk_context* c, const double* a, const double* b, doub
         finish_out(c, x, dx, N);
         finish_out(c, y, dy, m);
         IPXK_HIP(hipStreamSynchronize(c->stream));
+        check_sweep_abort(c);
     });
 }
 

@@ -142,6 +142,7 @@ CrResult kkt_basis_solve_dev(Context* c, const double* a, const double* b, doubl
                              ipxint maxiter, double* x, double* y, ipxk_interrupt_fn interrupt,
                              void* user, ipxk_times* times);
 void split_levels(const Context* c, ipxint levels[4]);
+void check_sweep_abort(Context* c);
 void destroy_split(SplitOperator*);
 
 // ---- comm.hip ----

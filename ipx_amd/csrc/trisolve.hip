@@ -20,6 +20,8 @@
 // therefore uploads O(m + n) numbers plus the factors and never copies the matrix
 // (the reference copies all of N every time, splitted_normal_matrix.cc:42-55).
 #include <algorithm>
+#include <cstdlib>
+#include <string>
 
 #include "context.hpp"
 #include "spmv_kernels.hpp"
@@ -37,7 +39,7 @@ struct SweepView {
 };
 
 struct Sweep {
-    int dim = 0, nlevels = 0;
+    int dim = 0, nlevels = 0, npos = 0;   // npos: level-ordered positions incl. padding
     bool running = false;          // forward ('n') sweeps subtract one product at a time
     DevBuf<int> order, ptr, idx;
     DevBuf<double> val, diag;      // as given
@@ -65,6 +67,9 @@ struct SplitOperator {
     DevBuf<unsigned char> free_mask;       // m, pivot order
     int num_free = 0;
     DevBuf<double> w0, w1, w2, w3;         // m workspaces
+    DevBuf<double> wsf;                    // intermediate vector of a sync-free solve pair
+    DevBuf<int> ticket, abort_flag;
+    bool syncfree = false;                 // IPXK_TRISOLVE=syncfree selects the single-launch sweeps
     DevBuf<double> tI;                     // m
 };
 
@@ -79,39 +84,136 @@ static int vec_grid(int64_t len) {
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-template <bool RUNNING>
+// One unknown per group of GL lanes.  The group's lanes load the row's entries side by side
+// (coalesced, all memory latency overlapped); the products are then combined ONE AT A TIME in
+// storage order through shuffles, so the arithmetic is the reference's sequential arithmetic
+// even for the long rows near the end of a forward sweep.
+template <bool RUNNING, int GL>
 __device__ __forceinline__ void solve_unknown(const SweepView& S, int k, double* x) {
+    const int lane = threadIdx.x & 63, gl = lane & (GL - 1), gbase = lane & ~(GL - 1);
     const int r = S.order[k];
+    if (r < 0) return;   // padding slot (whole groups are padding or real together)
     const int p0 = S.ptr[k], p1 = S.ptr[k + 1];
-    double xr = x[r];
-    if (RUNNING) {
-        for (int p = p0; p < p1; p++) xr -= S.val[p] * x[S.idx[p]];
-    } else {
-        double d = 0.0;
-        for (int p = p0; p < p1; p++) d += x[S.idx[p]] * S.val[p];
-        xr -= d;
+    const double xr = x[r];
+    double acc = RUNNING ? xr : 0.0;
+    for (int base = p0; base < p1; base += GL) {
+        const int p = base + gl;
+        double prod = 0.0;
+        if (p < p1) prod = RUNNING ? S.val[p] * x[S.idx[p]] : x[S.idx[p]] * S.val[p];
+        const int cnt = min(GL, p1 - base);
+        if (GL == 1) {
+            acc = RUNNING ? acc - prod : acc + prod;
+        } else {
+            for (int l = 0; l < cnt; l++) {
+                const double t = __shfl(prod, gbase + l, 64);
+                acc = RUNNING ? acc - t : acc + t;
+            }
+        }
     }
-    x[r] = xr / S.diag[k];
+    const double res = (RUNNING ? acc : xr - acc) / S.diag[k];
+    if (gl == 0) x[r] = res;
 }
 
 // one level per launch
-template <bool RUNNING>
+template <bool RUNNING, int GL>
 __global__ __launch_bounds__(kBlock) void level_kernel(SweepView S, int k0, int k1, double* x,
                                                        const int* done) {
     if (done && *done) return;
-    const int k = k0 + blockIdx.x * kBlock + threadIdx.x;
-    if (k < k1) solve_unknown<RUNNING>(S, k, x);
+    const int k = k0 + (blockIdx.x * kBlock + threadIdx.x) / GL;
+    if (k < k1) solve_unknown<RUNNING, GL>(S, k, x);
 }
 
 // a run of narrow levels in one workgroup
-template <bool RUNNING>
+template <bool RUNNING, int GL>
 __global__ __launch_bounds__(kTailWidth) void tail_kernel(SweepView S, const int* level_ptr, int l0,
                                                           int l1, double* x, const int* done) {
     if (done && *done) return;
     for (int l = l0; l < l1; l++) {
-        const int k = level_ptr[l] + threadIdx.x;
-        if (k < level_ptr[l + 1]) solve_unknown<RUNNING>(S, k, x);
+        const int kb = level_ptr[l], ke = level_ptr[l + 1];
+        for (int k = kb + threadIdx.x / GL; k < ke; k += kTailWidth / GL) solve_unknown<RUNNING, GL>(S, k, x);
         __syncthreads();   // workgroup-scope ordering of the global writes of this level
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Synchronisation-free sweep: ONE launch per sweep instead of one per level.  Opt-in
+// (IPXK_TRISOLVE=syncfree): on MI355X it measured SLOWER than one launch per level on the C3
+// planted factors (4.2 vs 2.7 ms per basis CR iteration, round 1) -- a level hand-off through
+// memory-side polling costs more than a kernel boundary here.  Kept because it is the single-
+// launch form a hipGraph-free persistent variant would build on, and it is parity-tested.
+// The result vector is single-assignment: it is pre-filled with a sentinel NaN and every unknown
+// is written once with an agent-scope 8-byte store, so the value IS the ready flag (no separate
+// flags, no fences; the hand-off form R2 of the CDNA guide).  Workgroups take chunks of the
+// level-ordered positions from a ticket counter, hence every dependency of a position held by a
+// running wave belongs to a lower ticket that some resident wave already owns: progress does not
+// depend on dispatch order or placement.  Levels are padded to whole lane groups, so the lanes of
+// one wavefront never wait for each other.  Every spin is bounded; a timeout raises `abort`.
+// ---------------------------------------------------------------------------
+constexpr unsigned long long kSentinel = 0x7FF8DEAD5EEDBEEFull;   // a quiet NaN nobody computes
+constexpr int kChunkRows = 256;      // positions per ticket
+constexpr int kSpinLimit = 1 << 20;
+
+__global__ void fill_sentinel_kernel(int m, unsigned long long* __restrict__ x, int* ticket) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) x[i] = kSentinel;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0;
+}
+
+template <bool RUNNING, int GL>
+__global__ __launch_bounds__(kBlock) void syncfree_sweep_kernel(SweepView S, int npos,
+                                                                const double* __restrict__ xin,
+                                                                double* xout, int* ticket, int* abort,
+                                                                const int* done) {
+    if (done && *done) return;
+    __shared__ int chunk_id;
+    const int lane = threadIdx.x & 63, gl = lane & (GL - 1), gbase = lane & ~(GL - 1);
+    const int nchunks = (npos + kChunkRows - 1) / kChunkRows;
+    const unsigned long long* xo = reinterpret_cast<const unsigned long long*>(xout);
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) chunk_id = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int chunk = chunk_id;
+        if (chunk >= nchunks) break;
+        for (int k = chunk * kChunkRows + threadIdx.x / GL; k < min(npos, (chunk + 1) * kChunkRows); k += kBlock / GL) {
+            const int r = S.order[k];
+            if (r < 0) continue;                    // padding (whole lane groups)
+            const int p0 = S.ptr[k], p1 = S.ptr[k + 1];
+            const double xr = xin[r];
+            double acc = RUNNING ? xr : 0.0;
+            for (int base = p0; base < p1; base += GL) {
+                const int p = base + gl;
+                double prod = 0.0;
+                if (p < p1) {
+                    const int j = S.idx[p];
+                    unsigned long long bits;
+                    int spins = 0;
+                    while ((bits = __hip_atomic_load(xo + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kSentinel) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > kSpinLimit || ((spins & 1023) == 0 &&
+                            __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                            __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                    const double xj = __longlong_as_double((long long)bits);
+                    prod = RUNNING ? S.val[p] * xj : xj * S.val[p];
+                }
+                const int cnt = min(GL, p1 - base);
+                if (GL == 1) {
+                    acc = RUNNING ? acc - prod : acc + prod;
+                } else {
+                    for (int l = 0; l < cnt; l++) {
+                        const double t = __shfl(prod, gbase + l, 64);
+                        acc = RUNNING ? acc - t : acc + t;
+                    }
+                }
+            }
+            const double res = (RUNNING ? acc : xr - acc) / S.diag[k];
+            if (gl == 0)
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(xout) + r,
+                                   (unsigned long long)__double_as_longlong(res), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -155,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void split_finish_kernel(int m, const doubl
 // (ri, rx) in the order in which they must be visited; `diag[i]` is its divisor.  Unknowns are
 // processed in `ascending` or descending index order by the reference, which is a valid
 // topological order of the dependencies.
-static void build_sweep(Sweep& S, int dim, bool ascending, bool running, const std::vector<int>& rp,
+static void build_sweep(Sweep& S, int dim, bool ascending, bool running, int align, const std::vector<int>& rp,
                         const std::vector<int>& ri, const std::vector<double>& rx,
                         const std::vector<double>& diag, const std::vector<double>* rxS,
                         const std::vector<double>* diagS, hipStream_t s) {
@@ -171,23 +273,28 @@ static void build_sweep(Sweep& S, int dim, bool ascending, bool running, const s
         nlev = std::max(nlev, lv + 1);
     }
     S.nlevels = nlev;
-    // counting sort of unknowns by level (stable in processing order)
+    // counting sort of unknowns by level (stable in processing order); every level starts at a
+    // multiple of `align` positions (pad slots have order -1) so that the lanes of one wavefront
+    // never hold unknowns of two different levels (needed by the sync-free sweep)
+    std::vector<int> lcount(nlev, 0);
+    for (int i = 0; i < dim; i++) lcount[level[i]]++;
     std::vector<int> lptr(nlev + 1, 0);
-    for (int i = 0; i < dim; i++) lptr[level[i] + 1]++;
-    for (int l = 0; l < nlev; l++) lptr[l + 1] += lptr[l];
-    std::vector<int> order(dim), next(lptr.begin(), lptr.end() - 1);
+    for (int l = 0; l < nlev; l++) lptr[l + 1] = lptr[l] + (lcount[l] + align - 1) / align * align;
+    const int npos = lptr[nlev];
+    std::vector<int> order(std::max(npos, 1), -1), next(lptr.begin(), lptr.end() - 1);
     for (int t = 0; t < dim; t++) {
         const int i = ascending ? t : dim - 1 - t;
         order[next[level[i]]++] = i;
     }
     const size_t nz = ri.size();
-    std::vector<int> ptr(dim + 1, 0), idx(std::max<size_t>(nz, 1));
-    std::vector<double> val(std::max<size_t>(nz, 1)), valS, dg(std::max(dim, 1)), dgS;
-    if (rxS) { valS.resize(std::max<size_t>(nz, 1)); dgS.resize(std::max(dim, 1)); }
+    std::vector<int> ptr(npos + 1, 0), idx(std::max<size_t>(nz, 1));
+    std::vector<double> val(std::max<size_t>(nz, 1)), valS, dg(std::max(npos, 1), 1.0), dgS;
+    if (rxS) { valS.resize(std::max<size_t>(nz, 1)); dgS.assign(std::max(npos, 1), 1.0); }
     int put = 0;
-    for (int k = 0; k < dim; k++) {
+    for (int k = 0; k < npos; k++) {
         const int i = order[k];
         ptr[k] = put;
+        if (i < 0) continue;
         for (int p = rp[i]; p < rp[i + 1]; p++, put++) {
             idx[put] = ri[p];
             val[put] = rx[p];
@@ -196,7 +303,8 @@ static void build_sweep(Sweep& S, int dim, bool ascending, bool running, const s
         dg[k] = diag[i];
         if (rxS) dgS[k] = (*diagS)[i];
     }
-    ptr[dim] = put;
+    ptr[npos] = put;
+    S.npos = npos;
     S.level_ptr = lptr;
     S.order.upload(order, s);
     S.ptr.upload(ptr, s);
@@ -223,36 +331,85 @@ static void build_sweep(Sweep& S, int dim, bool ascending, bool running, const s
     IPXK_HIP(hipStreamSynchronize(s));
 }
 
-static void run_sweep(Context* c, const Sweep& S, bool scaled, double* x, const int* done) {
-    const SweepView V = S.view(scaled);
+template <bool RUNNING, int GL>
+static void run_sweep_t(Context* c, const Sweep& S, const SweepView& V, double* x, const int* done) {
     for (const Sweep::Launch& L : S.plan) {
         if (L.tail) {
-            if (S.running)
-                hipLaunchKernelGGL(tail_kernel<true>, dim3(1), dim3(kTailWidth), 0, c->stream, V,
-                                   S.level_ptr_dev.get(), L.l0, L.l1, x, done);
-            else
-                hipLaunchKernelGGL(tail_kernel<false>, dim3(1), dim3(kTailWidth), 0, c->stream, V,
-                                   S.level_ptr_dev.get(), L.l0, L.l1, x, done);
+            hipLaunchKernelGGL((tail_kernel<RUNNING, GL>), dim3(1), dim3(kTailWidth), 0, c->stream, V,
+                               S.level_ptr_dev.get(), L.l0, L.l1, x, done);
         } else {
             const int k0 = S.level_ptr[L.l0], k1 = S.level_ptr[L.l1];
-            const int g = (k1 - k0 + kBlock - 1) / kBlock;
-            if (S.running)
-                hipLaunchKernelGGL(level_kernel<true>, dim3(g), dim3(kBlock), 0, c->stream, V, k0, k1, x, done);
-            else
-                hipLaunchKernelGGL(level_kernel<false>, dim3(g), dim3(kBlock), 0, c->stream, V, k0, k1, x, done);
+            const int g = (int)(((int64_t)(k1 - k0) * GL + kBlock - 1) / kBlock);
+            hipLaunchKernelGGL((level_kernel<RUNNING, GL>), dim3(g), dim3(kBlock), 0, c->stream, V, k0, k1, x, done);
         }
     }
 }
 
+// Transposed sweeps gather columns of the factors (a few entries each): one lane per unknown.
+// Forward sweeps gather rows, whose lengths grow towards the end of the sweep: 8 lanes each.
+static void run_sweep(Context* c, const Sweep& S, bool scaled, double* x, const int* done) {
+    const SweepView V = S.view(scaled);
+    if (S.running) run_sweep_t<true, 8>(c, S, V, x, done);
+    else run_sweep_t<false, 1>(c, S, V, x, done);
+}
+
+template <bool RUNNING, int GL>
+static void run_syncfree_t(Context* c, const Sweep& S, const SweepView& V, const double* xin, double* xout,
+                           const int* done) {
+    SplitOperator* sp = c->split;
+    const int m = S.dim;
+    hipLaunchKernelGGL(fill_sentinel_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, c->stream, m,
+                       reinterpret_cast<unsigned long long*>(xout), sp->ticket.get());
+    const int nchunks = (S.npos + kChunkRows - 1) / kChunkRows;
+    // few positions in flight beyond the active levels: waiting lanes poll memory
+    int maxgrid = 512;
+    if (const char* e = getenv("IPXK_SYNCFREE_GRID")) maxgrid = atoi(e) > 0 ? atoi(e) : maxgrid;
+    const int grid = std::max(1, std::min(nchunks, maxgrid));
+    hipLaunchKernelGGL((syncfree_sweep_kernel<RUNNING, GL>), dim3(grid), dim3(kBlock), 0, c->stream, V, S.npos,
+                       xin, xout, sp->ticket.get(), sp->abort_flag.get(), done);
+}
+
+static void run_syncfree(Context* c, const Sweep& S, bool scaled, const double* xin, double* xout,
+                         const int* done) {
+    const SweepView V = S.view(scaled);
+    if (S.running) run_syncfree_t<true, 8>(c, S, V, xin, xout, done);
+    else run_syncfree_t<false, 1>(c, S, V, xin, xout, done);
+}
+
 // ForwardSolve: L then U (sparse_matrix.cc:303-306)
 void forward_solve_dev(Context* c, double* x, bool scaled, const int* done) {
-    run_sweep(c, c->split->Lf, scaled, x, done);
-    run_sweep(c, c->split->Uf, scaled, x, done);
+    SplitOperator* S = c->split;
+    if (S->syncfree) {
+        run_syncfree(c, S->Lf, scaled, x, S->wsf.get(), done);
+        run_syncfree(c, S->Uf, scaled, S->wsf.get(), x, done);
+        return;
+    }
+    run_sweep(c, S->Lf, scaled, x, done);
+    run_sweep(c, S->Uf, scaled, x, done);
 }
 // BackwardSolve: U' then L' (sparse_matrix.cc:308-311)
 void backward_solve_dev(Context* c, double* x, bool scaled, const int* done) {
-    run_sweep(c, c->split->Ut, scaled, x, done);
-    run_sweep(c, c->split->Lt, scaled, x, done);
+    SplitOperator* S = c->split;
+    if (S->syncfree) {
+        run_syncfree(c, S->Ut, scaled, x, S->wsf.get(), done);
+        run_syncfree(c, S->Lt, scaled, S->wsf.get(), x, done);
+        return;
+    }
+    run_sweep(c, S->Ut, scaled, x, done);
+    run_sweep(c, S->Lt, scaled, x, done);
+}
+
+// raises if a sync-free sweep timed out (host side, after the stream has been synchronized)
+void check_sweep_abort(Context* c) {
+    SplitOperator* S = c->split;
+    if (!S || !S->syncfree) return;
+    int flag = 0;
+    S->abort_flag.download(&flag, 1, c->stream);
+    IPXK_HIP(hipStreamSynchronize(c->stream));
+    if (flag) {
+        IPXK_HIP(hipMemsetAsync(S->abort_flag.get(), 0, sizeof(int), c->stream));
+        throw Error(IPXK_E_HIP, "sync-free triangular sweep timed out waiting for a dependency");
+    }
 }
 
 void split_levels(const Context* c, ipxint levels[4]) {
@@ -308,7 +465,7 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
             dgS[k] = dg[k] * uscale[k];
         }
         rp[m] = put;
-        build_sweep(S->Ut, m, true, false, rp, ri, rx, dg, &rxS, &dgS, s);
+        build_sweep(S->Ut, m, true, false, 64, rp, ri, rx, dg, &rxS, &dgS, s);
     }
     // --- L' sweep: unknown k gathers column k of L (rows > k), descending, unit diagonal
     {
@@ -316,7 +473,7 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
         std::vector<double> rx(Lp[m]), dg(m, 1.0);
         for (int k = 0; k <= m; k++) rp[k] = (int)Lp[k];
         for (ipxint p = 0; p < Lp[m]; p++) { ri[p] = (int)Li[p]; rx[p] = Lx[p]; }
-        build_sweep(S->Lt, m, false, false, rp, ri, rx, dg, nullptr, nullptr, s);
+        build_sweep(S->Lt, m, false, false, 64, rp, ri, rx, dg, nullptr, nullptr, s);
     }
     // --- L sweep: unknown i subtracts L[i,j]*x_j for the columns j < i of row i, ascending j
     //     (the order in which the reference's column loop updates x[i], sparse_matrix.cc:283-297)
@@ -332,7 +489,7 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
                 ri[put] = j;
                 rx[put] = Lx[p];
             }
-        build_sweep(S->Lf, m, true, true, rp, ri, rx, dg, nullptr, nullptr, s);
+        build_sweep(S->Lf, m, true, true, 8, rp, ri, rx, dg, nullptr, nullptr, s);
     }
     // --- U sweep: unknown i subtracts U[i,j]*x_j for the columns j > i of row i, DESCENDING j
     //     (sparse_matrix.cc:267-281), then divides by U[i,i]
@@ -355,7 +512,7 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
             dg[k] = Ux[Up[k + 1] - 1];
             dgS[k] = dg[k] * uscale[k];
         }
-        build_sweep(S->Uf, m, false, true, rp, ri, rx, dg, &rxS, &dgS, s);
+        build_sweep(S->Uf, m, false, true, 8, rp, ri, rx, dg, &rxS, &dgS, s);
     }
 
     // --- N N' weights: colscale^2 on NONBASIC columns (splitted_normal_matrix.cc:42-55)
@@ -381,6 +538,11 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
     }
     const size_t mm = (size_t)std::max(m, 1);
     S->w0.resize(mm); S->w1.resize(mm); S->w2.resize(mm); S->w3.resize(mm); S->tI.resize(mm);
+    S->wsf.resize(mm);
+    S->ticket.resize(1);
+    S->abort_flag.resize(1);
+    IPXK_HIP(hipMemsetAsync(S->abort_flag.get(), 0, sizeof(int), s));
+    if (const char* e = getenv("IPXK_TRISOLVE")) S->syncfree = std::string(e) == "syncfree";
     if (c->partials.size() == 0) c->partials.resize((size_t)kNumPartialSlots * kPartialStride);
     IPXK_HIP(hipStreamSynchronize(s));
     c->split = S.release();

@@ -33,6 +33,31 @@ __global__ __launch_bounds__(256) void k(const int* __restrict__ idx, const doub
     out[(long)blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+
+// persistent workgroups walking phases (the access pattern of spmv_phased_kernel without its
+// LDS staging / barriers): entries are laid out [phase][workgroup][entries]
+template <int PER>
+__global__ __launch_bounds__(256) void kp(const int* __restrict__ idx, const double* __restrict__ val,
+                                          const double* __restrict__ x, double* out, int P, long per_step) {
+    double acc = 0;
+    const int G = gridDim.x, w = blockIdx.x;
+    for (int p = 0; p < P; p++) {
+        const long base = ((long)p * G + w) * per_step;
+        for (long c = 0; c < per_step; c += 256 * PER) {
+            int ci[PER]; double v[PER];
+#pragma unroll
+            for (int e = 0; e < PER; e++) {
+                long q = base + c + e * 256 + threadIdx.x;
+                ci[e] = __builtin_nontemporal_load(idx + q);
+                v[e] = __builtin_nontemporal_load(val + q);
+            }
+#pragma unroll
+            for (int e = 0; e < PER; e++) acc += x[ci[e]] * v[e];
+        }
+    }
+    out[(long)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 int main() {
     const long nnz = 16L << 20;
     std::vector<int> hidx(nnz);
@@ -66,6 +91,26 @@ int main() {
             printf("x=%6ld KB mode=%d: %7.1f us  stream %.2f TB/s  %.1f Ggather/s\n", S >> 10, mode, us,
                    nnz * 12.0 / us / 1e6, nnz / us / 1e3);
         }
+    }
+    // persistent-workgroup phase walk
+    for (long total : {8L<<20, 16L<<20}) for (long slice : {1L<<20}) for (int G : {1024, 1280, 2048}) for (int PER : {4, 8}) {
+        const int P = (int)(total / slice);
+        long per_step = nnz / ((long)P * G);
+        per_step = per_step / (256 * PER) * (256 * PER);
+        const long ne = slice / 8;
+        const long used = per_step * P * G;
+        for (long q = 0; q < used; q++) { long p = q / (per_step * G); hidx[q] = (int)(p * ne + rng() % ne); }
+        CHECK(hipMemcpy(idx, hidx.data(), nnz * 4, hipMemcpyHostToDevice));
+        auto launch = [&]() {
+            if (PER == 4) hipLaunchKernelGGL(kp<4>, dim3(G), dim3(256), 0, 0, idx, val, x, out, P, per_step);
+            else hipLaunchKernelGGL(kp<8>, dim3(G), dim3(256), 0, 0, idx, val, x, out, P, per_step);
+        };
+        for (int w = 0; w < 3; w++) launch();
+        CHECK(hipEventRecord(e0));
+        for (int r = 0; r < 20; r++) launch();
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("phasewalk x=%ld MB P=%d G=%d PER=%d nnz=%ld: %.1f us  (%.1f Ggather/s)\n", total >> 20, P, G, PER, used, ms / 20 * 1e3, used / (ms / 20 * 1e3) / 1e3);
     }
     // time-tiled: nnz region r gathers only from slice r of a 16 MB / 8 MB vector
     for (long total : {8L<<20, 16L<<20}) for (long slice : {512L<<10, 1L<<20, 2L<<20, 4L<<20}) {

@@ -207,8 +207,10 @@ def test_pcr_trajectory_vs_oracle(kkt, po, oracle):
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", ["levels", "syncfree"])
 @pytest.mark.parametrize("m,n,num_free,num_fixed", [(150, 320, 0, 0), (2500, 5200, 6, 9)])
-def test_basis_path_vs_oracle(kkt, po, oracle, m, n, num_free, num_fixed):
+def test_basis_path_vs_oracle(kkt, po, oracle, monkeypatch, mode, m, n, num_free, num_fixed):
+    monkeypatch.setenv("IPXK_TRISOLVE", mode)     # one launch per level / single-launch sync-free sweeps
     B, st, colscale = basis_problem(m, n, seed=41, num_free=num_free, num_fixed=num_fixed)
     A, L, U = B["A"], B["L"], B["U"]
     AI = A.with_identity()
