@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--maxiter", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--basis", action="store_true", help="also time the basis-preconditioned solve (extra field)")
+    ap.add_argument("--banded", action="store_true", help="also time the apply on a banded matrix of the same size (extra field)")
     return ap.parse_args()
 
 
@@ -184,6 +185,8 @@ def main():
                      "traffic": traffic, "us_per_apply": apply_ms * 1e3, "algorithmic_bytes": bytes_apply},
     }
 
+    if rank == 0 and world == 1 and args.banded:
+        out["roofline"]["banded_matrix_probe"] = bench_banded(kkt, synth, m, n)
     if rank == 0 and world == 1 and args.basis:
         out["config"]["basis_path"] = bench_basis(kkt, synth, m, n, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -201,6 +204,22 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_banded(kkt, synth, m, n):
+    """Same kernel, same size, but gathers with locality (rows of a column within a 4096-row band):
+    shows what the SpMV reaches when the x gathers hit in cache."""
+    A = synth.banded_lp(m, n, 8, 4096, 12345)
+    ctx = kkt.KktContext(A)
+    rng = np.random.default_rng(0)
+    ctx.normal_prepare(10.0 ** rng.uniform(-2, 2, n + m))
+    rhs, lhs = ctx.vector(m, rng.standard_normal(m)), ctx.vector(m)
+    ctx.time_normal_apply(rhs, lhs, 5)
+    ms = ctx.time_normal_apply(rhs, lhs, 50) / 50
+    nbytes = ctx.normal_apply_bytes
+    ctx.close()
+    return {"us_per_apply": ms * 1e3, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9,
+            "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "matrix": "8 rows per column within a 4096-row band"}
 
 
 def bench_basis(kkt, synth, m, n, args):

@@ -138,18 +138,20 @@ template <> struct CountWord<8> { typedef unsigned long long type; };
 // LDS is double-buffered: one barrier per chunk.
 constexpr int kPerThread = kChunkNnz / kBlock;
 
-template <class CW>
+template <int RT>
 struct ChunkLoad {          // stream loads of one chunk held in registers
     int c[kPerThread];
     double v[kPerThread];
-    CW cw;                  // row counts of the step (valid when the chunk opens a step)
+    unsigned char cb[RT];   // entry counts of my RT rows in the step (valid when the chunk opens a step)
     int start, nn, first, step;
 };
 
-template <class CW, int RT>
+template <int RT>
 __device__ __forceinline__ void issue_stream(const GatherView& M, int k, int kend, int w, int tid,
-                                             ChunkLoad<CW>& L) {
-    L.nn = 0; L.first = 0; L.step = 0; L.start = 0; L.cw = 0;
+                                             ChunkLoad<RT>& L) {
+    L.nn = 0; L.first = 0; L.step = 0; L.start = 0;
+#pragma unroll
+    for (int u = 0; u < RT; u++) L.cb[u] = 0;
     if (k >= kend) {
         // past the end: harmless indices so that the (unused) gathers stay in bounds
 #pragma unroll
@@ -168,19 +170,23 @@ __device__ __forceinline__ void issue_stream(const GatherView& M, int k, int ken
         L.c[e] = __builtin_nontemporal_load(M.idx + pp);
         L.v[e] = __builtin_nontemporal_load(M.val + pp);
     }
-    if (L.first)
-        L.cw = *reinterpret_cast<const CW*>(M.counts + (size_t)L.step * (kBlock * RT) + tid * RT);
+    if (L.first) {
+        // thread t owns the rows t, t + kBlock, t + 2 kBlock, ... of the workgroup (strided ownership:
+        // consecutive rows -> consecutive threads, so every chunk of a step keeps many threads busy
+        // whether a row has its entries spread over all phases or concentrated in one)
+#pragma unroll
+        for (int u = 0; u < RT; u++) L.cb[u] = M.counts[(size_t)L.step * (kBlock * RT) + u * kBlock + tid];
+    }
 }
 
 template <class Epi, int RT>
-__global__ __launch_bounds__(kBlock, 5) void spmv_phased_kernel(GatherView M, const double* __restrict__ x,
+__global__ __launch_bounds__(kBlock, 4) void spmv_phased_kernel(GatherView M, const double* __restrict__ x,
                                                              Epi epi, double* dot_partials,
                                                              const int* done) {
     if (done && *done) return;
-    typedef typename CountWord<RT>::type CW;
     __shared__ double lds[2][kLdsDoubles];
     __shared__ double red[kBlock / 64 + 1];
-    __shared__ int wave_total[2][kBlock / 64];
+    __shared__ int wave_total[2][RT][kBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w = blockIdx.x;
     double dotpart = 0.0;
@@ -192,22 +198,27 @@ __global__ __launch_bounds__(kBlock, 5) void spmv_phased_kernel(GatherView M, co
     }
 
     for (int q = 0; q < M.Q; q++) {
-        const int row0 = (q * M.G + w) * M.RWrows + tid * RT;
-        const int row_end = min(M.nrows, (q * M.G + w + 1) * M.RWrows);   // rows of this workgroup
+        const int wg_row0 = (q * M.G + w) * M.RWrows;
+        const int row_end = min(M.nrows, wg_row0 + M.RWrows);   // rows of this workgroup
         double acc[RT];
 #pragma unroll
-        for (int u = 0; u < RT; u++) acc[u] = (row0 + u < row_end) ? epi.init(row0 + u) : 0.0;
+        for (int u = 0; u < RT; u++) {
+            const int r = wg_row0 + u * kBlock + tid;
+            acc[u] = r < row_end ? epi.init(r) : 0.0;
+        }
 
         const int kbeg = M.wg_chunk_ptr[q * M.G + w], kend = M.wg_chunk_ptr[q * M.G + w + 1];
-        ChunkLoad<CW> cur, nxt;
+        ChunkLoad<RT> cur, nxt;
         double xg[kPerThread];
-        issue_stream<CW, RT>(M, kbeg, kend, w, tid, cur);
-        issue_stream<CW, RT>(M, kbeg + 1, kend, w, tid, nxt);
+        issue_stream<RT>(M, kbeg, kend, w, tid, cur);
+        issue_stream<RT>(M, kbeg + 1, kend, w, tid, nxt);
 #pragma unroll
         for (int e = 0; e < kPerThread; e++) xg[e] = x[cur.c[e]];   // gathers of chunk 0
 
-        int buf = 0, my_off = 0, step_n0 = 0;
-        CW cw_cur = 0;
+        int buf = 0, step_n0 = 0;
+        int cnt[RT], off[RT];      // my rows' entry counts and first positions within the current step
+#pragma unroll
+        for (int u = 0; u < RT; u++) { cnt[u] = 0; off[u] = 0; }
         __syncthreads();   // LDS buffers free (previous round)
         for (int k = kbeg; k < kend; k++) {
             if (M.stamps && tid == 0 && cur.first) M.stamps[cur.step] = wall_clock64();
@@ -219,50 +230,67 @@ __global__ __launch_bounds__(kBlock, 5) void spmv_phased_kernel(GatherView M, co
             }
             // gathers of chunk k+1, stream loads of chunk k+2
             const int cstart = cur.start, cnn = cur.nn, cfirst = cur.first;
-            const CW cwk = cur.cw;
+            int incl[RT];
+            if (cfirst) {
+                // positions of my rows' segments: the step stores rows in order, row u*kBlock + t
+                // belongs to thread t -> one scan over the threads per u
+                step_n0 = cstart;
+#pragma unroll
+                for (int u = 0; u < RT; u++) {
+                    cnt[u] = cur.cb[u];
+                    int v = cnt[u];
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int t = __shfl_up(v, o, 64);
+                        if (lane >= o) v += t;
+                    }
+                    incl[u] = v;
+                    if (lane == 63) wave_total[buf][u][wave] = v;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < kPerThread; e++) xg[e] = x[nxt.c[e]];
             cur = nxt;
-            issue_stream<CW, RT>(M, k + 2, kend, w, tid, nxt);
-
-            int incl = 0, tot = 0;
-            if (cfirst) {
-                // entries of my RT rows in this phase; my segment follows those of lower threads
-                cw_cur = cwk;
-                step_n0 = cstart;
-#pragma unroll
-                for (int u = 0; u < RT; u++) tot += (int)((cw_cur >> (8 * u)) & 0xff);
-                incl = tot;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int t = __shfl_up(incl, off, 64);
-                    if (lane >= off) incl += t;
-                }
-                if (lane == 63) wave_total[buf][wave] = incl;
-            }
+            issue_stream<RT>(M, k + 2, kend, w, tid, nxt);
             __syncthreads();
             if (cfirst) {
-                my_off = incl - tot;
+                int base = 0;
 #pragma unroll
-                for (int ww = 0; ww < kBlock / 64; ww++) if (ww < wave) my_off += wave_total[buf][ww];
+                for (int u = 0; u < RT; u++) {
+                    int before = 0, total = 0;
+#pragma unroll
+                    for (int ww = 0; ww < kBlock / 64; ww++) {
+                        const int t = wave_total[buf][u][ww];
+                        if (ww < wave) before += t;
+                        total += t;
+                    }
+                    off[u] = base + before + incl[u] - cnt[u];
+                    base += total;
+                }
             }
             // add my rows' products that lie in this chunk, in storage order
-            int pos = my_off - (cstart - step_n0);
+            const int shift = cstart - step_n0;
 #pragma unroll
             for (int u = 0; u < RT; u++) {
-                const int cu = (int)((cw_cur >> (8 * u)) & 0xff);
-                for (int e = 0; e < cu; e++, pos++) {
-                    if (pos >= 0 && pos < cnn) {
-                        const double t = lds[buf][lds_slot(pos)];
-                        acc[u] = Epi::kNeg ? acc[u] - t : acc[u] + t;
-                    }
+                const int pos0 = off[u] - shift;
+                if (pos0 >= cnn || pos0 + cnt[u] <= 0) continue;
+                // the part of the row's segment inside this chunk, four LDS reads in flight at a time,
+                // added strictly in storage order
+                const int lo = max(pos0, 0), hi = min(pos0 + cnt[u], cnn);
+                for (int pos = lo; pos < hi; pos += 4) {
+                    double t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) t[j] = lds[buf][lds_slot(min(pos + j, hi - 1))];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (pos + j < hi) acc[u] = Epi::kNeg ? acc[u] - t[j] : acc[u] + t[j];
                 }
             }
             buf ^= 1;
         }
 #pragma unroll
         for (int u = 0; u < RT; u++) {
-            const int r = row0 + u;
+            const int r = wg_row0 + u * kBlock + tid;
             if (r < row_end && !(M.row_long && M.row_long[r])) epi.finish(r, acc[u], dotpart);
         }
     }

@@ -70,6 +70,24 @@ def synthetic_lp(m, n, k=8, seed=12345, num_dense=0):
     return CscMatrix(m, n, colptr, rowidx, values)
 
 
+def banded_lp(m, n, k=8, bandwidth=4096, seed=12345):
+    """Structured counterpart of synthetic_lp: the k rows of column j are drawn from a band of
+    `bandwidth` rows around j*m/n, so both gathers of A*D*A' have locality (what row/column
+    orderings of real LPs provide).  Same value distribution."""
+    rng = np.random.default_rng(seed)
+    centre = (np.arange(n, dtype=i64) * m) // n
+    lo = np.clip(centre - bandwidth // 2, 0, max(m - bandwidth, 0))
+    bw = min(bandwidth, m)
+    rows = np.sort(lo[:, None] + rng.integers(0, bw, size=(n, k), dtype=i64), axis=1)
+    while True:
+        bad = np.nonzero((rows[:, 1:] == rows[:, :-1]).any(axis=1))[0]
+        if bad.size == 0:
+            break
+        rows[bad] = np.sort(lo[bad, None] + rng.integers(0, bw, size=(bad.size, k), dtype=i64), axis=1)
+    vals = rng.uniform(0.5, 4.0, size=(n, k)) * rng.choice([-1.0, 1.0], size=(n, k))
+    return CscMatrix(m, n, np.arange(n + 1, dtype=i64) * k, rows.reshape(-1), vals.reshape(-1))
+
+
 def synthetic_ipm_state(m, n, spread=1.0, seed=12345):
     """xl, zl = 10^(spread*U[-1,1]) independently, xu=inf, zu=0 (W_j = xl_j/zl_j spans
     4*spread decades); a, b ~ U[-0.5,0.5).  Returns dict with xl,xu,zl,zu,mu,a,b."""
