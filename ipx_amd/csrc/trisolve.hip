@@ -123,15 +123,72 @@ __global__ __launch_bounds__(kBlock) void level_kernel(SweepView S, int k0, int 
     if (k < k1) solve_unknown<RUNNING, GL>(S, k, x);
 }
 
-// a run of narrow levels in one workgroup
+// A run of narrow levels in one workgroup.  Between two levels only the x values are new, so the
+// metadata of a group's first unknown of the NEXT level (order, row extent, first GL entries,
+// diagonal) is loaded before the barrier that ends the current level: after the barrier just the x
+// gathers (one round trip) and the ordered combine remain on the critical path.
+constexpr int kTailLevelsCached = 512;
+
 template <bool RUNNING, int GL>
 __global__ __launch_bounds__(kTailWidth) void tail_kernel(SweepView S, const int* level_ptr, int l0,
                                                           int l1, double* x, const int* done) {
     if (done && *done) return;
-    for (int l = l0; l < l1; l++) {
-        const int kb = level_ptr[l], ke = level_ptr[l + 1];
-        for (int k = kb + threadIdx.x / GL; k < ke; k += kTailWidth / GL) solve_unknown<RUNNING, GL>(S, k, x);
-        __syncthreads();   // workgroup-scope ordering of the global writes of this level
+    __shared__ int lp[kTailLevelsCached + 1];
+    const int lane = threadIdx.x & 63, gl = lane & (GL - 1), gbase = lane & ~(GL - 1);
+    const int grp = threadIdx.x / GL, ngrp = kTailWidth / GL;
+    for (int lb = l0; lb < l1; lb += kTailLevelsCached) {
+        const int nl = min(kTailLevelsCached, l1 - lb);
+        __syncthreads();
+        for (int i = threadIdx.x; i <= nl; i += kTailWidth) lp[i] = level_ptr[lb + i];
+        __syncthreads();
+        // prefetched head of my first unknown of the next level
+        int pk = lp[0] + grp, pr = -1, pp0 = 0, pp1 = 0, pidx = 0;
+        double pval = 0.0, pdiag = 1.0;
+        auto prefetch = [&](int k, int kend) {
+            pk = k; pr = -1; pp0 = pp1 = 0;
+            if (k < kend) {
+                pr = S.order[k];
+                if (pr >= 0) {
+                    pp0 = S.ptr[k]; pp1 = S.ptr[k + 1];
+                    pdiag = S.diag[k];
+                    if (pp0 + gl < pp1) { pidx = S.idx[pp0 + gl]; pval = S.val[pp0 + gl]; }
+                }
+            }
+        };
+        prefetch(lp[0] + grp, lp[1]);
+        for (int l = 0; l < nl; l++) {
+            const int ke = lp[l + 1];
+            // first unknown of this level for my group: metadata already in registers
+            if (pr >= 0) {
+                const int r = pr, p0 = pp0, p1 = pp1;
+                const double xr = x[r];
+                double acc = RUNNING ? xr : 0.0;
+                for (int base = p0; base < p1; base += GL) {
+                    const int p = base + gl;
+                    double prod = 0.0;
+                    if (p < p1) {
+                        const int j = base == p0 ? pidx : S.idx[p];
+                        const double a = base == p0 ? pval : S.val[p];
+                        prod = RUNNING ? a * x[j] : x[j] * a;
+                    }
+                    const int cnt = min(GL, p1 - base);
+                    if (GL == 1) {
+                        acc = RUNNING ? acc - prod : acc + prod;
+                    } else {
+                        for (int q = 0; q < cnt; q++) {
+                            const double t = __shfl(prod, gbase + q, 64);
+                            acc = RUNNING ? acc - t : acc + t;
+                        }
+                    }
+                }
+                const double res = (RUNNING ? acc : xr - acc) / pdiag;
+                if (gl == 0) x[r] = res;
+            }
+            // further unknowns of a level wider than the workgroup's groups
+            for (int k = pk + ngrp; k < ke; k += ngrp) solve_unknown<RUNNING, GL>(S, k, x);
+            if (l + 1 < nl) prefetch(lp[l + 1] + grp, lp[l + 2]);
+            __syncthreads();   // workgroup-scope ordering of the global writes of this level
+        }
     }
 }
 
@@ -314,16 +371,18 @@ static void build_sweep(Sweep& S, int dim, bool ascending, bool running, int ali
     S.has_scaled = rxS != nullptr;
     if (rxS) { S.valS.upload(valS, s); S.diagS.upload(dgS, s); }
     S.level_ptr_dev.upload(lptr, s);
-    // launch plan
+    // launch plan: a level goes into a single-workgroup "tail" launch only if every lane group of
+    // that workgroup gets at most one unknown of it (align == lanes per unknown's wavefront share)
+    const int tail_positions = kTailWidth / (64 / align);
     S.plan.clear();
     int l = 0;
     while (l < nlev) {
-        if (lptr[l + 1] - lptr[l] > kTailWidth) {
+        if (lptr[l + 1] - lptr[l] > tail_positions) {
             S.plan.push_back({l, l + 1, false});
             l++;
         } else {
             int l1 = l;
-            while (l1 < nlev && lptr[l1 + 1] - lptr[l1] <= kTailWidth) l1++;
+            while (l1 < nlev && lptr[l1 + 1] - lptr[l1] <= tail_positions) l1++;
             S.plan.push_back({l, l1, true});
             l = l1;
         }
