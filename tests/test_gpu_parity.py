@@ -335,3 +335,35 @@ def test_partitioned_code_path_single_rank(kkt, po, oracle, monkeypatch):
     l2, d2 = oracle.normal_apply(ocsc(po, A), ko.get()[0], rhs)
     assert relerr(l1, l2) <= 1e-12 and abs(d1 - d2) <= 1e-12 * abs(d2)
     ctx.close()
+
+
+def test_dense_column_stress_full_size(kkt):
+    """BASELINE config 5: m=200k, n=400k, 32 dense columns (~79k entries each) -- the
+    Sherman-Morrison-Woodbury preconditioner path (src/diagonal_precond.cc:48-101,133-149)."""
+    m, n = 200000, 400000
+    A, st = diag_problem(m, n, seed=12345, num_dense=32)
+    ctx = kkt.KktContext(A)
+    assert ctx.num_dense_cols == 32
+    assert ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"]) == 0
+    W, _ = ctx.kkt_diag_get()
+    # P is the inverse of E + Ad Wd Ad' (form (2) of src/diagonal_precond.h:12-23): check P*(M v) == v
+    S = A.to_scipy()
+    dense = np.arange(32)
+    sparse_part = S[:, 32:]
+    E = W[n:] + (sparse_part.multiply(sparse_part)) @ W[32:n]
+    Ad = S[:, :32]
+    v = np.random.default_rng(0).standard_normal(m)
+    Mv = E * v + Ad @ (W[dense] * (Ad.T @ v))
+    Pv, dot = ctx.diag_apply(Mv)
+    assert relerr(Pv, v) < 1e-9 and abs(dot - Mv @ v) <= 1e-9 * abs(dot)
+    tol = 0.3 * np.sqrt(st["mu"])
+    x, y, it, e, _ = ctx.kkt_diag_solve(st["a"], st["b"], tol, 500)
+    assert e == 0 and it < 150
+    res1, res2 = kkt_residual_diag(A, W, st["a"], st["b"], x, y)
+    assert np.abs(res2).max() < 1e-9 * (1 + np.abs(x).max())
+    assert np.abs(np.sqrt(W[n:]) * res1[n:]).max() <= tol * (1 + 1e-9)
+    # without the dense-column treatment the diag-PCR hits its cap: the case the SMW form exists for
+    assert ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"], precond_dense_cols=False) == 0
+    _, _, it2, e2, _ = ctx.kkt_diag_solve(st["a"], st["b"], tol, 300)
+    assert (it2, e2) == (300, 201)
+    ctx.close()
