@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--maxiter", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--basis", action="store_true", help="also time the basis-preconditioned solve (extra field)")
-    ap.add_argument("--banded", action="store_true", help="also time the apply on a banded matrix of the same size (extra field)")
+    ap.add_argument("--no-banded", action="store_true", help="skip the banded-matrix probe of the SpMV (extra field of roofline)")
     return ap.parse_args()
 
 
@@ -185,7 +185,7 @@ def main():
                      "traffic": traffic, "us_per_apply": apply_ms * 1e3, "algorithmic_bytes": bytes_apply},
     }
 
-    if rank == 0 and world == 1 and args.banded:
+    if rank == 0 and world == 1 and not args.no_banded:
         out["roofline"]["banded_matrix_probe"] = bench_banded(kkt, synth, m, n)
     if rank == 0 and world == 1 and args.basis:
         out["config"]["basis_path"] = bench_basis(kkt, synth, m, n, args)
