@@ -110,6 +110,9 @@ def main():
         ids = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(ids[0], rank, world)
+    elif os.environ.get("IPXK_FORCE_COMM"):
+        # rehearsal of the collective code path on one GPU (1-rank RCCL communicator)
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)
     err = ctx.kkt_diag_factorize(slab.xl, slab.xu, slab.zl, slab.zu, st["mu"])
     assert err == 0
     ctx.set_pointer_mode(True)
