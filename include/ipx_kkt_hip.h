@@ -81,6 +81,11 @@ int ipxk_set_pointer_mode(ipxk_context* ctx, int mode);
  * the context's own stream. */
 int ipxk_set_stream(ipxk_context* ctx, void* hip_stream);
 int ipxk_synchronize(ipxk_context* ctx);
+/* on != 0: HIP events around every operator / preconditioner / triangular-solve application fill
+ * ipxk_times::op, precond, solve_B, solve_Bt (the reference's per-object timers,
+ * src/normal_matrix.cc:57,125, src/diagonal_precond.cc:126,158,
+ * src/splitted_normal_matrix.cc:93-110).  Off by default: ~2 extra stream markers per call. */
+int ipxk_set_profiling(ipxk_context* ctx, int on);
 ipxint ipxk_num_dense_cols(const ipxk_context* ctx);
 /* Copies out the device-side row-wise matrix (for bit-exact index parity
  * tests against Transpose): ATp[m+1], ATi[nnz], ATx[nnz]; NULL skips. */

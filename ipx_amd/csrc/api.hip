@@ -18,7 +18,43 @@ Context::~Context() {
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
     for (hipEvent_t e : ev_window) (void)hipEventDestroy(e);
+    for (hipEvent_t e : time_events) (void)hipEventDestroy(e);
     if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+void time_start(Context* c, ipxk_times* times) {
+    c->timing_active = times != nullptr && c->profile_ops;
+    c->time_used = 0;
+    c->time_kinds.clear();
+}
+
+void time_mark(Context* c, int kind, bool begin) {
+    if (!c->timing_active) return;
+    if (c->time_used == c->time_events.size()) {
+        hipEvent_t e;
+        IPXK_HIP(hipEventCreate(&e));
+        c->time_events.push_back(e);
+    }
+    IPXK_HIP(hipEventRecord(c->time_events[c->time_used++], c->stream));
+    c->time_kinds.push_back(begin ? kind : -1 - kind);
+}
+
+void time_collect(Context* c, ipxk_times* times) {
+    if (!c->timing_active || !times) return;
+    c->timing_active = false;
+    double sum[kNumTimeKinds] = {0, 0, 0, 0};
+    size_t open_at[kNumTimeKinds] = {0, 0, 0, 0};
+    for (size_t i = 0; i < c->time_used; i++) {
+        const int k = c->time_kinds[i];
+        if (k >= 0) { open_at[k] = i; continue; }
+        float ms = 0.f;
+        IPXK_HIP(hipEventElapsedTime(&ms, c->time_events[open_at[-1 - k]], c->time_events[i]));
+        sum[-1 - k] += ms * 1e-3;
+    }
+    times->op = sum[kTimeOp];
+    times->precond = sum[kTimePrecond];
+    times->solve_B = sum[kTimeB];
+    times->solve_Bt = sum[kTimeBt];
 }
 
 const double* stage_in(Context* c, const double* p, size_t len, DevBuf<double>& buf) {
@@ -118,6 +154,13 @@ int ipxk_set_stream(ipxk_context* c, void* hip_stream) {
         bind_device(c);
         IPXK_HIP(hipStreamSynchronize(c->stream));
         c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    });
+}
+
+int ipxk_set_profiling(ipxk_context* c, int on) {
+    return guarded([&] {
+        IPXK_REQUIRE(c != nullptr, "ctx is NULL");
+        c->profile_ops = on != 0;
     });
 }
 

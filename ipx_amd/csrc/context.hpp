@@ -29,7 +29,13 @@ struct Context {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int pointer_mode = IPXK_POINTER_HOST;
+    // optional per-operator timing (ipxk_set_profiling): HIP events around every operator /
+    // preconditioner / triangular-solve application of a solve, summed into ipxk_times afterwards
     bool profile_ops = false;
+    bool timing_active = false;
+    std::vector<hipEvent_t> time_events;
+    std::vector<int> time_kinds;        // per recorded event: kind (begin) or -1-kind (end)
+    size_t time_used = 0;
 
     // ---- model ----
     int64_t m = 0, n = 0, nnz = 0;
@@ -92,6 +98,11 @@ struct Context {
     ~Context();
     double* part(int slot) const { return partials.get() + (size_t)slot * kPartialStride; }
 };
+
+enum TimeKind { kTimeOp = 0, kTimePrecond = 1, kTimeB = 2, kTimeBt = 3, kNumTimeKinds = 4 };
+void time_mark(Context* c, int kind, bool begin);      // no-op unless timing is active
+void time_start(Context* c, ipxk_times* times);        // called by a solve before it enqueues work
+void time_collect(Context* c, ipxk_times* times);      // after the solve's stream sync
 
 // staging of vector arguments according to the pointer mode
 const double* stage_in(Context* c, const double* p, size_t len, DevBuf<double>& buf);

@@ -286,7 +286,9 @@ struct CrOps {
 
 static int applyC_normal(Context* c, const double* rhs, double* lhs, const int* done) {
     int np = 0;
+    time_mark(c, kTimeOp, true);
     normal_apply_dev(c, c->W, rhs, lhs, &np, done);
+    time_mark(c, kTimeOp, false);
     return np;
 }
 static int applyC_split(Context* c, const double* rhs, double* lhs, const int* done) {
@@ -299,6 +301,7 @@ static CrResult run_cr(Context* c, const CrOps& ops, const double* rhs, double t
                        ipxk_interrupt_fn interrupt, void* user, double* hist_host, ipxint hist_cap,
                        ipxk_times* times) {
     ensure_workspaces(c);
+    time_start(c, times);
     hipStream_t s = c->stream;
     const int m = (int)c->m;
     if (maxiter < 0) maxiter = (comm_active(c) ? c->m_global : c->m) + 100;   // :114-115
@@ -404,6 +407,7 @@ static CrResult run_cr(Context* c, const CrOps& ops, const double* rhs, double t
         float ms = 0.f;
         IPXK_HIP(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
         times->cr = ms * 1e-3;
+        time_collect(c, times);
     }
     return res;
 }

@@ -194,26 +194,6 @@ struct CrState {
     long long hist_cap;
 };
 
-// ---------------------------------------------------------------------------
-// level-scheduled triangular factor (see trisolve.hip)
-// ---------------------------------------------------------------------------
-struct LevelSweep {
-    // Rows renumbered by level: position k in [0,dim) is row order[k].
-    int dim = 0, nlevels = 0;
-    int64_t nnz = 0;
-    DevBuf<int> order, ptr, idx;   // ptr[dim+1] over level-ordered rows; idx = original unknown index
-    DevBuf<double> val, diag;      // off-diagonal values; diag[k] (1.0 when unit)
-    DevBuf<int> valsrc;            // source position of each val in the factor's value array
-    DevBuf<int> diagsrc;           // source position of diag, -1 when unit
-    std::vector<int> level_ptr;    // host: [nlevels+1] positions
-    // launch plan: one entry per kernel launch
-    struct Launch { int k0, k1, l0, l1; bool tail; };
-    std::vector<Launch> plan;
-    DevBuf<int> level_ptr_dev;
-    bool unitdiag = false;
-};
-
 struct Context;
-void cr_set_error_from_exception(Context*);
 
 }  // namespace ipxk

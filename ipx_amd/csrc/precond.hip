@@ -256,6 +256,8 @@ void diag_factorize_dev(Context* c, const double* W, bool precond_dense_cols, ip
 int diag_apply_dev(Context* c, const double* rhs, double* lhs, int slot, const int* done) {
     const int m = (int)c->m;
     hipStream_t s = c->stream;
+    time_mark(c, kTimePrecond, true);
+    struct EndMark { Context* c; ~EndMark() { time_mark(c, kTimePrecond, false); } } end_mark{c};
     if (c->kdense == 0) {
         const int g = vec_grid(m);
         hipLaunchKernelGGL(diag_apply_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs,

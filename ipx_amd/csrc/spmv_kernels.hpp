@@ -6,8 +6,8 @@
 // 4-byte index and an 8-byte value exactly once with coalesced loads (lane i
 // reads element base+i), the x gather is served by L2 / Infinity Cache.
 //
-// Summation order inside a row is the storage order (one thread adds the row's
-// LDS-staged products sequentially), which is the reference's order:
+// Summation order inside a row is the storage order (the owning thread adds the
+// row's LDS-staged products sequentially), which is the reference's order:
 //   * pass 1 of NormalMatrix::_Apply, d += rhs[Ai[p]]*Ax[p] (normal_matrix.cc:69-70)
 //   * pass 2 equals the reference's one-pass scatter because row i of the
 //     row-wise copy lists columns in ascending order (normal_matrix.cc:65-74).
@@ -109,24 +109,7 @@ struct EpiBasisColumns : ProdMul {
         out[j] = s != 0.0 ? (a[j] - acc) * s : 0.0;
     }
 };
-// out[i] = base[i] + sign*(acc + tI[i])
-struct EpiBasisRows : ProdMul {
-    const double* base; const double* tI; double sign; double* out;
-    static constexpr bool kNeg = false;
-    __device__ __forceinline__ double init(int) const { return 0.0; }
-    __device__ __forceinline__ void finish(int i, double acc, double&) const {
-        const double v = acc + tI[i];
-        out[i] = (base ? base[i] : 0.0) + sign * v;
-    }
-};
-
 // ---- the kernels ---------------------------------------------------------------
-template <int RT> struct CountWord;
-template <> struct CountWord<1> { typedef unsigned char type; };
-template <> struct CountWord<2> { typedef unsigned short type; };
-template <> struct CountWord<4> { typedef unsigned int type; };
-template <> struct CountWord<8> { typedef unsigned long long type; };
-
 // Time-tiled row-gather SpMV (layout: internal.hpp, GatherMatrix).  Workgroup w of G
 // co-resident workgroups walks the phases of its rows; all workgroups are in the same
 // phase at (roughly) the same time, so the slice of x being gathered stays in L2.

@@ -619,7 +619,10 @@ int split_apply_dev(Context* c, const double* rhs, double* lhs, const int* done)
     double* u = S->w1.get();
     // work = inverse(B') * rhs
     IPXK_HIP(hipMemcpyAsync(work, rhs, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+    time_mark(c, kTimeBt, true);
     backward_solve_dev(c, work, true, done);
+    time_mark(c, kTimeBt, false);
+    time_mark(c, kTimeOp, true);
     // lhs = N N' work : un-permute, A (M D^2) A', permute
     hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, work, S->rowperm_inv.get(), u, done);
     EpiScale e1{{}, S->Wsplit.get(), c->tcols.get()};
@@ -627,8 +630,11 @@ int split_apply_dev(Context* c, const double* rhs, double* lhs, const int* done)
     EpiNormalRows e2{{}, S->Wsplit.get() + n, u, work};
     launch_spmv(c->Arows, c->tcols.get(), e2, nullptr, done, s);
     hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, work, S->rowperm.get(), lhs, done);
+    time_mark(c, kTimeOp, false);
     // lhs = inverse(B) * lhs
+    time_mark(c, kTimeB, true);
     forward_solve_dev(c, lhs, true, done);
+    time_mark(c, kTimeB, false);
     // lhs += rhs; zero free positions; dot
     hipLaunchKernelGGL(split_finish_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs, S->free_mask.get(), lhs,
                        c->part(kPartCdot), done);

@@ -25,7 +25,7 @@ NONBASIC_FIXED, NONBASIC, BASIC, BASIC_FREE = -2, -1, 0, 1
 
 EXPORTS = [
     "ipxk_last_error", "ipxk_device_count", "ipxk_create", "ipxk_destroy", "ipxk_set_pointer_mode",
-    "ipxk_set_stream", "ipxk_synchronize", "ipxk_num_dense_cols", "ipxk_get_rowwise",
+    "ipxk_set_stream", "ipxk_synchronize", "ipxk_set_profiling", "ipxk_num_dense_cols", "ipxk_get_rowwise",
     "ipxk_normal_prepare", "ipxk_normal_apply", "ipxk_diag_factorize", "ipxk_diag_apply",
     "ipxk_diag_get", "ipxk_pcr_solve", "ipxk_kkt_diag_factorize", "ipxk_kkt_diag_solve",
     "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_apply", "ipxk_forward_solve",
@@ -155,6 +155,9 @@ class KktContext:
 
     def set_stream(self, stream_handle):
         self._check(self.lib.ipxk_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def set_profiling(self, on):
+        self._check(self.lib.ipxk_set_profiling(self.h, C.c_int(1 if on else 0)))
 
     def synchronize(self):
         self._check(self.lib.ipxk_synchronize(self.h))

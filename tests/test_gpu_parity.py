@@ -248,6 +248,29 @@ def test_basis_path_vs_oracle(kkt, po, oracle, monkeypatch, mode, m, n, num_free
     ctx.close()
 
 
+def test_operator_timers(kkt):
+    """ipx_info::time_cr1_AAt / time_cr1_pre / time_cr2_NNt / _B / _Bt equivalents (ipxk_times)."""
+    A, st = diag_problem(20000, 42000, seed=77)
+    ctx = kkt.KktContext(A)
+    ctx.set_profiling(True)
+    assert ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"]) == 0
+    x, y, it, e, tm = ctx.kkt_diag_solve(st["a"], st["b"], 1e-3, 500)
+    assert e == 0 and tm.cr > 0 and tm.op > 0 and tm.precond > 0
+    assert tm.op + tm.precond <= tm.cr * 1.05 and tm.op > tm.precond
+    ctx.set_profiling(False)
+    _, _, _, _, tm2 = ctx.kkt_diag_solve(st["a"], st["b"], 1e-3, 500)
+    assert tm2.cr > 0 and tm2.op == 0.0
+    ctx.close()
+    B, st, colscale = basis_problem(3000, 6500, seed=78)
+    ctx = kkt.KktContext(B["A"])
+    ctx.set_profiling(True)
+    ctx.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
+    _, _, it, e, tm = ctx.kkt_basis_solve(st["a"], st["b"], 1e-8)
+    assert e == 0 and min(tm.op, tm.solve_B, tm.solve_Bt) > 0
+    assert tm.op + tm.solve_B + tm.solve_Bt <= tm.cr * 1.05
+    ctx.close()
+
+
 # --------------------------------------------------------------------------------------
 # edge cases: empty rows / columns, tiny and ragged shapes, iteration caps
 # --------------------------------------------------------------------------------------
