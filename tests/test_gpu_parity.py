@@ -390,3 +390,35 @@ def test_dense_column_stress_full_size(kkt):
     _, _, it2, e2, _ = ctx.kkt_diag_solve(st["a"], st["b"], tol, 300)
     assert (it2, e2) == (300, 201)
     ctx.close()
+
+
+def test_basis_path_full_size_properties(kkt):
+    """BASELINE config 3: m=1M, n=2M, basis-preconditioned CR on planted LU factors.  The oracle
+    would need minutes here: check the KKT system the result must satisfy
+    (src/kkt_solver_basis.cc:69-74, src/kkt_solver.h:21-27) and the triangular solves by residual."""
+    m, n = 1000000, 2000000
+    B, st, colscale = basis_problem(m, n, seed=12345)
+    A = B["A"]
+    ctx = kkt.KktContext(A)
+    ctx.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
+    assert all(10 <= v <= 500 for v in ctx.split_levels())
+    AI = A.with_identity().to_scipy()
+    Bm = AI[:, B["basis"]]
+    r = np.random.default_rng(1).standard_normal(m)
+    assert relerr(Bm @ ctx.solve_dense(r, "N"), r) < 1e-9            # B x = r
+    assert relerr(Bm.T @ ctx.solve_dense(r, "T"), r) < 1e-9          # B'x = r
+    # C = I + inv(B~) N~ N~' inv(B~') is symmetric positive definite
+    u, v = r, np.random.default_rng(2).standard_normal(m)
+    Cu, uCu = ctx.split_apply(u)
+    Cv, _ = ctx.split_apply(v)
+    assert abs(v @ Cu - u @ Cv) <= 1e-10 * abs(v @ Cu) and uCu > u @ u * (1 - 1e-12)
+    tol = 0.3 * np.sqrt(st["mu"])
+    x, y, it, e, _ = ctx.kkt_basis_solve(st["a"], st["b"], tol, 500)
+    assert e == 0 and it < 200
+    assert relerr(AI @ x, st["b"]) < 1e-9                             # primal equation
+    g = AI.T @ y
+    res = x / colscale ** 2 + g - st["a"]                            # dual equation, barrier variables
+    nb = B["status"] == -1
+    assert np.abs(res[nb]).max() < 1e-9 * (1 + np.abs(st["a"]).max() + np.abs(g).max())   # exact on nonbasic
+    assert np.abs(res[~nb] * colscale[~nb]).max() <= tol * (1 + 1e-6)                      # tol on basic
+    ctx.close()
