@@ -92,6 +92,19 @@ int main() {
                    nnz * 12.0 / us / 1e6, nnz / us / 1e3);
         }
     }
+    // XCD-sliced gather: block b (XCD b % 8 under round-robin dispatch) gathers only from slice b % nsl
+    for (long total : {8L<<20, 16L<<20}) for (int nsl : {4, 8}) {
+        const long ne = total / 8 / nsl;
+        const int grid = 2048;
+        for (long p = 0; p < nnz; p++) { long chunk = p / 2048; int b = (int)(chunk % grid); hidx[p] = (int)((b % nsl) * ne + rng() % ne); }
+        CHECK(hipMemcpy(idx, hidx.data(), nnz * 4, hipMemcpyHostToDevice));
+        for (int w = 0; w < 3; w++) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, idx, val, x, out, nnz);
+        CHECK(hipEventRecord(e0));
+        for (int r = 0; r < 20; r++) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, idx, val, x, out, nnz);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("xcdsliced x=%ld MB slices=%d (%ld KB each): %.1f us  (%.1f Ggather/s)\n", total >> 20, nsl, total / nsl >> 10, ms / 20 * 1e3, nnz / (ms / 20 * 1e3) / 1e3);
+    }
     // persistent-workgroup phase walk
     for (long total : {8L<<20, 16L<<20}) for (long slice : {1L<<20}) for (int G : {1024, 1280, 2048}) for (int PER : {4, 8}) {
         const int P = (int)(total / slice);
