@@ -21,7 +21,9 @@
 // (the reference copies all of N every time, splitted_normal_matrix.cc:42-55).
 #include <algorithm>
 #include <cstdlib>
+#include <exception>
 #include <string>
+#include <thread>
 
 #include "context.hpp"
 #include "spmv_kernels.hpp"
@@ -314,10 +316,18 @@ __global__ __launch_bounds__(kBlock) void split_finish_kernel(int m, const doubl
 // (ri, rx) in the order in which they must be visited; `diag[i]` is its divisor.  Unknowns are
 // processed in `ascending` or descending index order by the reference, which is a valid
 // topological order of the dependencies.
-static void build_sweep(Sweep& S, int dim, bool ascending, bool running, int align, const std::vector<int>& rp,
+// Host-side result of the level analysis of one sweep (pure CPU work: the four sweeps of a
+// Prepare are analysed on four host threads, then uploaded one after the other).
+struct SweepHost {
+    std::vector<int> order, ptr, idx, lptr;
+    std::vector<double> val, valS, dg, dgS;
+    bool has_scaled = false;
+};
+
+static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool running, int align, const std::vector<int>& rp,
                         const std::vector<int>& ri, const std::vector<double>& rx,
                         const std::vector<double>& diag, const std::vector<double>* rxS,
-                        const std::vector<double>* diagS, hipStream_t s) {
+                        const std::vector<double>* diagS) {
     S.dim = dim;
     S.running = running;
     std::vector<int> level(dim, 0);
@@ -363,14 +373,10 @@ static void build_sweep(Sweep& S, int dim, bool ascending, bool running, int ali
     ptr[npos] = put;
     S.npos = npos;
     S.level_ptr = lptr;
-    S.order.upload(order, s);
-    S.ptr.upload(ptr, s);
-    S.idx.upload(idx, s);
-    S.val.upload(val, s);
-    S.diag.upload(dg, s);
     S.has_scaled = rxS != nullptr;
-    if (rxS) { S.valS.upload(valS, s); S.diagS.upload(dgS, s); }
-    S.level_ptr_dev.upload(lptr, s);
+    H.has_scaled = rxS != nullptr;
+    H.order.swap(order); H.ptr.swap(ptr); H.idx.swap(idx); H.val.swap(val); H.valS.swap(valS);
+    H.dg.swap(dg); H.dgS.swap(dgS); H.lptr = lptr;
     // launch plan: a level goes into a single-workgroup "tail" launch only if every lane group of
     // that workgroup gets at most one unknown of it (align == lanes per unknown's wavefront share)
     const int tail_positions = kTailWidth / (64 / align);
@@ -387,6 +393,16 @@ static void build_sweep(Sweep& S, int dim, bool ascending, bool running, int ali
             l = l1;
         }
     }
+}
+
+static void upload_sweep(Sweep& S, const SweepHost& H, hipStream_t s) {
+    S.order.upload(H.order, s);
+    S.ptr.upload(H.ptr, s);
+    S.idx.upload(H.idx, s);
+    S.val.upload(H.val, s);
+    S.diag.upload(H.dg, s);
+    if (H.has_scaled) { S.valS.upload(H.valS, s); S.diagS.upload(H.dgS, s); }
+    S.level_ptr_dev.upload(H.lptr, s);
     IPXK_HIP(hipStreamSynchronize(s));
 }
 
@@ -508,8 +524,9 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
         else if (status[j] == IPXK_BASIC_FREE) { fmask[k] = 1; S->num_free++; }   // :58-64
     }
 
+    SweepHost hUt, hLt, hLf, hUf;
     // --- U' sweep: unknown k gathers the rows above the diagonal of column k, ascending
-    {
+    auto job_Ut = [&] {
         std::vector<int> rp(m + 1), ri(Up[m] - m);
         std::vector<double> rx(ri.size()), rxS(ri.size()), dg(m), dgS(m);
         int put = 0;
@@ -524,19 +541,19 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
             dgS[k] = dg[k] * uscale[k];
         }
         rp[m] = put;
-        build_sweep(S->Ut, m, true, false, 64, rp, ri, rx, dg, &rxS, &dgS, s);
-    }
+        analyse_sweep(S->Ut, hUt, m, true, false, 64, rp, ri, rx, dg, &rxS, &dgS);
+    };
     // --- L' sweep: unknown k gathers column k of L (rows > k), descending, unit diagonal
-    {
+    auto job_Lt = [&] {
         std::vector<int> rp(m + 1), ri(Lp[m]);
         std::vector<double> rx(Lp[m]), dg(m, 1.0);
         for (int k = 0; k <= m; k++) rp[k] = (int)Lp[k];
         for (ipxint p = 0; p < Lp[m]; p++) { ri[p] = (int)Li[p]; rx[p] = Lx[p]; }
-        build_sweep(S->Lt, m, false, false, 64, rp, ri, rx, dg, nullptr, nullptr, s);
-    }
+        analyse_sweep(S->Lt, hLt, m, false, false, 64, rp, ri, rx, dg, nullptr, nullptr);
+    };
     // --- L sweep: unknown i subtracts L[i,j]*x_j for the columns j < i of row i, ascending j
     //     (the order in which the reference's column loop updates x[i], sparse_matrix.cc:283-297)
-    {
+    auto job_Lf = [&] {
         std::vector<int> rp(m + 1, 0), ri(Lp[m]);
         std::vector<double> rx(Lp[m]), dg(m, 1.0);
         for (ipxint p = 0; p < Lp[m]; p++) rp[Li[p] + 1]++;
@@ -548,11 +565,11 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
                 ri[put] = j;
                 rx[put] = Lx[p];
             }
-        build_sweep(S->Lf, m, true, true, 8, rp, ri, rx, dg, nullptr, nullptr, s);
-    }
+        analyse_sweep(S->Lf, hLf, m, true, true, 8, rp, ri, rx, dg, nullptr, nullptr);
+    };
     // --- U sweep: unknown i subtracts U[i,j]*x_j for the columns j > i of row i, DESCENDING j
     //     (sparse_matrix.cc:267-281), then divides by U[i,i]
-    {
+    auto job_Uf = [&] {
         std::vector<int> cnt(m + 1, 0);
         for (int k = 0; k < m; k++)
             for (ipxint p = Up[k]; p < Up[k + 1] - 1; p++) cnt[Ui[p] + 1]++;
@@ -571,8 +588,21 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
             dg[k] = Ux[Up[k + 1] - 1];
             dgS[k] = dg[k] * uscale[k];
         }
-        build_sweep(S->Uf, m, false, true, 8, rp, ri, rx, dg, &rxS, &dgS, s);
+        analyse_sweep(S->Uf, hUf, m, false, true, 8, rp, ri, rx, dg, &rxS, &dgS);
+    };
+    {
+        // the analyses are independent and sequential each: one host thread per sweep
+        std::exception_ptr err[3];
+        auto guard = [&](int i, auto job) { return std::thread([&, i, job] { try { job(); } catch (...) { err[i] = std::current_exception(); } }); };
+        std::thread t1 = guard(0, job_Lt), t2 = guard(1, job_Lf), t3 = guard(2, job_Uf);
+        job_Ut();
+        t1.join(); t2.join(); t3.join();
+        for (auto& e : err) if (e) std::rethrow_exception(e);
     }
+    upload_sweep(S->Ut, hUt, s);
+    upload_sweep(S->Lt, hLt, s);
+    upload_sweep(S->Lf, hLf, s);
+    upload_sweep(S->Uf, hUf, s);
 
     // --- N N' weights: colscale^2 on NONBASIC columns (splitted_normal_matrix.cc:42-55)
     {
