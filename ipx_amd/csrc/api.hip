@@ -1,7 +1,6 @@
 // extern "C" entry points of libipx_kkt_hip.so (see include/ipx_kkt_hip.h).
 // Thin glue: argument checks, host<->device staging according to the pointer mode,
 // exception -> return-code mapping.  No arithmetic lives here.
-#include <mutex>
 
 #include "context.hpp"
 

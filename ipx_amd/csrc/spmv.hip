@@ -35,7 +35,11 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
     nnz = nz;
 
     // geometry
-    const int slice = slice_elems();
+    // phases of ~1 MiB of x; at most kMaxPhases of them (the per-(row,phase) count table grows
+    // with P), so very long vectors get proportionally larger slices
+    constexpr int kMaxPhases = 64;
+    int64_t slice = slice_elems();
+    if ((ncols_ + slice - 1) / slice > kMaxPhases) slice = (ncols_ + kMaxPhases - 1) / kMaxPhases;
     P = (int)std::max<int64_t>(1, (ncols_ + slice - 1) / slice);
     int maxwg = kMaxWorkgroups;
     if (const char* e = getenv("IPXK_MAX_WG")) maxwg = atoi(e) > 0 ? atoi(e) : maxwg;

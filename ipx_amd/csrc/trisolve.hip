@@ -31,6 +31,7 @@
 namespace ipxk {
 
 constexpr int kTailWidth = 1024;
+constexpr int kShortRow = 8;     // rows up to this many entries are solved by one lane
 
 struct SweepView {
     const int* order;      // [dim] unknown index of level-ordered position k
@@ -49,7 +50,8 @@ struct Sweep {
     bool has_scaled = false;
     std::vector<int> level_ptr;    // host, [nlevels+1]
     DevBuf<int> level_ptr_dev;
-    struct Launch { int l0, l1; bool tail; };
+    struct Launch { int l0, l1; bool tail; int gl; };   // gl: lanes per unknown (1, or 8 for long rows)
+    DevBuf<unsigned char> chunk_long;   // sync-free sweep: chunk holds rows longer than kShortRow
     std::vector<Launch> plan;
     SweepView view(bool scaled) const {
         SweepView V;
@@ -217,61 +219,98 @@ __global__ void fill_sentinel_kernel(int m, unsigned long long* __restrict__ x, 
     if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0;
 }
 
+// polls one dependency until it holds a value (bounded; raises `abort` on timeout)
+__device__ __forceinline__ double wait_value(const unsigned long long* xo, int j, int* abort) {
+    unsigned long long bits;
+    int spins = 0;
+    while ((bits = __hip_atomic_load(xo + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kSentinel) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kSpinLimit || ((spins & 1023) == 0 &&
+            __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    return __longlong_as_double((long long)bits);
+}
+
+// one position with GL lanes; GL == 1: the lane first issues the loads of ALL its (<= kShortRow)
+// dependencies, then waits only for those still missing
 template <bool RUNNING, int GL>
+__device__ __forceinline__ void syncfree_unknown(const SweepView& S, int k, const double* __restrict__ xin,
+                                                 double* xout, int* abort) {
+    const int lane = threadIdx.x & 63, gl = lane & (GL - 1), gbase = lane & ~(GL - 1);
+    const unsigned long long* xo = reinterpret_cast<const unsigned long long*>(xout);
+    const int r = S.order[k];
+    if (r < 0) return;                          // padding (whole wavefronts)
+    const int p0 = S.ptr[k], p1 = S.ptr[k + 1];
+    const double xr = xin[r];
+    double acc = RUNNING ? xr : 0.0;
+    if (GL == 1) {
+        int j[kShortRow];
+        double a[kShortRow];
+        unsigned long long bits[kShortRow];
+        const int len = p1 - p0;               // <= kShortRow in a "short" chunk
+#pragma unroll
+        for (int e = 0; e < kShortRow; e++) {
+            j[e] = e < len ? S.idx[p0 + e] : 0;
+            a[e] = e < len ? S.val[p0 + e] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < kShortRow; e++)
+            bits[e] = e < len ? __hip_atomic_load(xo + j[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+        for (int e = 0; e < kShortRow; e++) {
+            if (e < len) {
+                const double xj = bits[e] == kSentinel ? wait_value(xo, j[e], abort)
+                                                       : __longlong_as_double((long long)bits[e]);
+                const double prod = RUNNING ? a[e] * xj : xj * a[e];
+                acc = RUNNING ? acc - prod : acc + prod;
+            }
+        }
+    } else {
+        for (int base = p0; base < p1; base += GL) {
+            const int p = base + gl;
+            double prod = 0.0;
+            if (p < p1) {
+                const double xj = wait_value(xo, S.idx[p], abort);
+                prod = RUNNING ? S.val[p] * xj : xj * S.val[p];
+            }
+            const int cnt = min(GL, p1 - base);
+            for (int l = 0; l < cnt; l++) {
+                const double t = __shfl(prod, gbase + l, 64);
+                acc = RUNNING ? acc - t : acc + t;
+            }
+        }
+    }
+    const double res = (RUNNING ? acc : xr - acc) / S.diag[k];
+    if (gl == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(xout) + r,
+                           (unsigned long long)__double_as_longlong(res), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool RUNNING>
 __global__ __launch_bounds__(kBlock) void syncfree_sweep_kernel(SweepView S, int npos,
+                                                                const unsigned char* __restrict__ chunk_long,
                                                                 const double* __restrict__ xin,
                                                                 double* xout, int* ticket, int* abort,
                                                                 const int* done) {
     if (done && *done) return;
     __shared__ int chunk_id;
-    const int lane = threadIdx.x & 63, gl = lane & (GL - 1), gbase = lane & ~(GL - 1);
     const int nchunks = (npos + kChunkRows - 1) / kChunkRows;
-    const unsigned long long* xo = reinterpret_cast<const unsigned long long*>(xout);
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) chunk_id = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const int chunk = chunk_id;
         if (chunk >= nchunks) break;
-        for (int k = chunk * kChunkRows + threadIdx.x / GL; k < min(npos, (chunk + 1) * kChunkRows); k += kBlock / GL) {
-            const int r = S.order[k];
-            if (r < 0) continue;                    // padding (whole lane groups)
-            const int p0 = S.ptr[k], p1 = S.ptr[k + 1];
-            const double xr = xin[r];
-            double acc = RUNNING ? xr : 0.0;
-            for (int base = p0; base < p1; base += GL) {
-                const int p = base + gl;
-                double prod = 0.0;
-                if (p < p1) {
-                    const int j = S.idx[p];
-                    unsigned long long bits;
-                    int spins = 0;
-                    while ((bits = __hip_atomic_load(xo + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kSentinel) {
-                        __builtin_amdgcn_s_sleep(8);
-                        if (++spins > kSpinLimit || ((spins & 1023) == 0 &&
-                            __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                            __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                    }
-                    const double xj = __longlong_as_double((long long)bits);
-                    prod = RUNNING ? S.val[p] * xj : xj * S.val[p];
-                }
-                const int cnt = min(GL, p1 - base);
-                if (GL == 1) {
-                    acc = RUNNING ? acc - prod : acc + prod;
-                } else {
-                    for (int l = 0; l < cnt; l++) {
-                        const double t = __shfl(prod, gbase + l, 64);
-                        acc = RUNNING ? acc - t : acc + t;
-                    }
-                }
-            }
-            const double res = (RUNNING ? acc : xr - acc) / S.diag[k];
-            if (gl == 0)
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(xout) + r,
-                                   (unsigned long long)__double_as_longlong(res), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+        const int kb = chunk * kChunkRows, ke = min(npos, kb + kChunkRows);
+        if (chunk_long[chunk]) {
+            for (int k = kb + threadIdx.x / 8; k < ke; k += kBlock / 8) syncfree_unknown<RUNNING, 8>(S, k, xin, xout, abort);
+        } else {
+            const int k = kb + threadIdx.x;
+            if (k < ke) syncfree_unknown<RUNNING, 1>(S, k, xin, xout, abort);
         }
     }
 }
@@ -320,11 +359,12 @@ __global__ __launch_bounds__(kBlock) void split_finish_kernel(int m, const doubl
 // Prepare are analysed on four host threads, then uploaded one after the other).
 struct SweepHost {
     std::vector<int> order, ptr, idx, lptr;
+    std::vector<unsigned char> chunk_long;
     std::vector<double> val, valS, dg, dgS;
     bool has_scaled = false;
 };
 
-static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool running, int align, const std::vector<int>& rp,
+static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool running, const std::vector<int>& rp,
                         const std::vector<int>& ri, const std::vector<double>& rx,
                         const std::vector<double>& diag, const std::vector<double>* rxS,
                         const std::vector<double>* diagS) {
@@ -343,8 +383,13 @@ static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool 
     // counting sort of unknowns by level (stable in processing order); every level starts at a
     // multiple of `align` positions (pad slots have order -1) so that the lanes of one wavefront
     // never hold unknowns of two different levels (needed by the sync-free sweep)
+    const int align = 64;
     std::vector<int> lcount(nlev, 0);
-    for (int i = 0; i < dim; i++) lcount[level[i]]++;
+    std::vector<unsigned char> level_long(nlev, 0);
+    for (int i = 0; i < dim; i++) {
+        lcount[level[i]]++;
+        if (rp[i + 1] - rp[i] > kShortRow) level_long[level[i]] = 1;
+    }
     std::vector<int> lptr(nlev + 1, 0);
     for (int l = 0; l < nlev; l++) lptr[l + 1] = lptr[l] + (lcount[l] + align - 1) / align * align;
     const int npos = lptr[nlev];
@@ -377,22 +422,30 @@ static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool 
     H.has_scaled = rxS != nullptr;
     H.order.swap(order); H.ptr.swap(ptr); H.idx.swap(idx); H.val.swap(val); H.valS.swap(valS);
     H.dg.swap(dg); H.dgS.swap(dgS); H.lptr = lptr;
-    // launch plan: a level goes into a single-workgroup "tail" launch only if every lane group of
-    // that workgroup gets at most one unknown of it (align == lanes per unknown's wavefront share)
-    const int tail_positions = kTailWidth / (64 / align);
+    // launch plan.  Levels whose rows all have <= kShortRow entries use one lane per unknown, the
+    // others (the long rows towards the end of a forward sweep) 8 lanes per unknown.  A level goes
+    // into a single-workgroup "tail" launch only if every lane group of that workgroup gets at most
+    // one unknown of it; consecutive tail levels of the same kind share one launch.
     S.plan.clear();
     int l = 0;
     while (l < nlev) {
+        const int gl = level_long[l] ? 8 : 1;
+        const int tail_positions = kTailWidth / gl;
         if (lptr[l + 1] - lptr[l] > tail_positions) {
-            S.plan.push_back({l, l + 1, false});
+            S.plan.push_back({l, l + 1, false, gl});
             l++;
         } else {
             int l1 = l;
-            while (l1 < nlev && lptr[l1 + 1] - lptr[l1] <= tail_positions) l1++;
-            S.plan.push_back({l, l1, true});
+            while (l1 < nlev && (level_long[l1] ? 8 : 1) == gl && lptr[l1 + 1] - lptr[l1] <= tail_positions) l1++;
+            S.plan.push_back({l, l1, true, gl});
             l = l1;
         }
     }
+    // sync-free sweep: per chunk of kChunkRows positions, does it hold a long row?
+    H.chunk_long.assign((npos + 255) / 256 + 1, 0);
+    for (int lv = 0; lv < nlev; lv++)
+        if (level_long[lv])
+            for (int c = lptr[lv] / 256; c <= (lptr[lv + 1] - 1) / 256; c++) H.chunk_long[c] = 1;
 }
 
 static void upload_sweep(Sweep& S, const SweepHost& H, hipStream_t s) {
@@ -403,35 +456,40 @@ static void upload_sweep(Sweep& S, const SweepHost& H, hipStream_t s) {
     S.diag.upload(H.dg, s);
     if (H.has_scaled) { S.valS.upload(H.valS, s); S.diagS.upload(H.dgS, s); }
     S.level_ptr_dev.upload(H.lptr, s);
+    S.chunk_long.upload(H.chunk_long, s);
     IPXK_HIP(hipStreamSynchronize(s));
 }
 
 template <bool RUNNING, int GL>
-static void run_sweep_t(Context* c, const Sweep& S, const SweepView& V, double* x, const int* done) {
+static void launch_plan_entry(Context* c, const Sweep& S, const SweepView& V, const Sweep::Launch& L, double* x,
+                              const int* done) {
+    if (L.tail) {
+        hipLaunchKernelGGL((tail_kernel<RUNNING, GL>), dim3(1), dim3(kTailWidth), 0, c->stream, V,
+                           S.level_ptr_dev.get(), L.l0, L.l1, x, done);
+    } else {
+        const int k0 = S.level_ptr[L.l0], k1 = S.level_ptr[L.l1];
+        const int g = (int)(((int64_t)(k1 - k0) * GL + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL((level_kernel<RUNNING, GL>), dim3(g), dim3(kBlock), 0, c->stream, V, k0, k1, x, done);
+    }
+}
+
+static void run_sweep(Context* c, const Sweep& S, bool scaled, double* x, const int* done) {
+    const SweepView V = S.view(scaled);
     for (const Sweep::Launch& L : S.plan) {
-        if (L.tail) {
-            hipLaunchKernelGGL((tail_kernel<RUNNING, GL>), dim3(1), dim3(kTailWidth), 0, c->stream, V,
-                               S.level_ptr_dev.get(), L.l0, L.l1, x, done);
+        if (S.running) {
+            if (L.gl == 8) launch_plan_entry<true, 8>(c, S, V, L, x, done);
+            else launch_plan_entry<true, 1>(c, S, V, L, x, done);
         } else {
-            const int k0 = S.level_ptr[L.l0], k1 = S.level_ptr[L.l1];
-            const int g = (int)(((int64_t)(k1 - k0) * GL + kBlock - 1) / kBlock);
-            hipLaunchKernelGGL((level_kernel<RUNNING, GL>), dim3(g), dim3(kBlock), 0, c->stream, V, k0, k1, x, done);
+            if (L.gl == 8) launch_plan_entry<false, 8>(c, S, V, L, x, done);
+            else launch_plan_entry<false, 1>(c, S, V, L, x, done);
         }
     }
 }
 
-// Transposed sweeps gather columns of the factors (a few entries each): one lane per unknown.
-// Forward sweeps gather rows, whose lengths grow towards the end of the sweep: 8 lanes each.
-static void run_sweep(Context* c, const Sweep& S, bool scaled, double* x, const int* done) {
-    const SweepView V = S.view(scaled);
-    if (S.running) run_sweep_t<true, 8>(c, S, V, x, done);
-    else run_sweep_t<false, 1>(c, S, V, x, done);
-}
-
-template <bool RUNNING, int GL>
-static void run_syncfree_t(Context* c, const Sweep& S, const SweepView& V, const double* xin, double* xout,
-                           const int* done) {
+static void run_syncfree(Context* c, const Sweep& S, bool scaled, const double* xin, double* xout,
+                         const int* done) {
     SplitOperator* sp = c->split;
+    const SweepView V = S.view(scaled);
     const int m = S.dim;
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, c->stream, m,
                        reinterpret_cast<unsigned long long*>(xout), sp->ticket.get());
@@ -440,15 +498,12 @@ static void run_syncfree_t(Context* c, const Sweep& S, const SweepView& V, const
     int maxgrid = 512;
     if (const char* e = getenv("IPXK_SYNCFREE_GRID")) maxgrid = atoi(e) > 0 ? atoi(e) : maxgrid;
     const int grid = std::max(1, std::min(nchunks, maxgrid));
-    hipLaunchKernelGGL((syncfree_sweep_kernel<RUNNING, GL>), dim3(grid), dim3(kBlock), 0, c->stream, V, S.npos,
-                       xin, xout, sp->ticket.get(), sp->abort_flag.get(), done);
-}
-
-static void run_syncfree(Context* c, const Sweep& S, bool scaled, const double* xin, double* xout,
-                         const int* done) {
-    const SweepView V = S.view(scaled);
-    if (S.running) run_syncfree_t<true, 8>(c, S, V, xin, xout, done);
-    else run_syncfree_t<false, 1>(c, S, V, xin, xout, done);
+    if (S.running)
+        hipLaunchKernelGGL(syncfree_sweep_kernel<true>, dim3(grid), dim3(kBlock), 0, c->stream, V, S.npos,
+                           S.chunk_long.get(), xin, xout, sp->ticket.get(), sp->abort_flag.get(), done);
+    else
+        hipLaunchKernelGGL(syncfree_sweep_kernel<false>, dim3(grid), dim3(kBlock), 0, c->stream, V, S.npos,
+                           S.chunk_long.get(), xin, xout, sp->ticket.get(), sp->abort_flag.get(), done);
 }
 
 // ForwardSolve: L then U (sparse_matrix.cc:303-306)
@@ -541,7 +596,7 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
             dgS[k] = dg[k] * uscale[k];
         }
         rp[m] = put;
-        analyse_sweep(S->Ut, hUt, m, true, false, 64, rp, ri, rx, dg, &rxS, &dgS);
+        analyse_sweep(S->Ut, hUt, m, true, false, rp, ri, rx, dg, &rxS, &dgS);
     };
     // --- L' sweep: unknown k gathers column k of L (rows > k), descending, unit diagonal
     auto job_Lt = [&] {
@@ -549,7 +604,7 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
         std::vector<double> rx(Lp[m]), dg(m, 1.0);
         for (int k = 0; k <= m; k++) rp[k] = (int)Lp[k];
         for (ipxint p = 0; p < Lp[m]; p++) { ri[p] = (int)Li[p]; rx[p] = Lx[p]; }
-        analyse_sweep(S->Lt, hLt, m, false, false, 64, rp, ri, rx, dg, nullptr, nullptr);
+        analyse_sweep(S->Lt, hLt, m, false, false, rp, ri, rx, dg, nullptr, nullptr);
     };
     // --- L sweep: unknown i subtracts L[i,j]*x_j for the columns j < i of row i, ascending j
     //     (the order in which the reference's column loop updates x[i], sparse_matrix.cc:283-297)
@@ -565,7 +620,7 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
                 ri[put] = j;
                 rx[put] = Lx[p];
             }
-        analyse_sweep(S->Lf, hLf, m, true, true, 8, rp, ri, rx, dg, nullptr, nullptr);
+        analyse_sweep(S->Lf, hLf, m, true, true, rp, ri, rx, dg, nullptr, nullptr);
     };
     // --- U sweep: unknown i subtracts U[i,j]*x_j for the columns j > i of row i, DESCENDING j
     //     (sparse_matrix.cc:267-281), then divides by U[i,i]
@@ -588,7 +643,7 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
             dg[k] = Ux[Up[k + 1] - 1];
             dgS[k] = dg[k] * uscale[k];
         }
-        analyse_sweep(S->Uf, hUf, m, false, true, 8, rp, ri, rx, dg, &rxS, &dgS);
+        analyse_sweep(S->Uf, hUf, m, false, true, rp, ri, rx, dg, &rxS, &dgS);
     };
     {
         // the analyses are independent and sequential each: one host thread per sweep
