@@ -14,7 +14,10 @@ ipxint PollInterrupt(void* control) {
 
 KKTSolverBasisHip::KKTSolverBasisHip(const Control& control, Basis& basis)
     : control_(control), model_(basis.model()), basis_(basis), cpu_(control, basis),
-      device_(basis.model()) {}
+      device_(basis.model()) {
+    // time_cr2_NNt / _B / _Bt are only printed at debug level >= 2 (src/lp_solver.cc:107)
+    HipCheck(ipxk_set_profiling(device_.get(), control_.Debug(2) ? 1 : 0));
+}
 
 void KKTSolverBasisHip::_Factorize(Iterate* iterate, Info* info) {
     const Int m = model_.rows();

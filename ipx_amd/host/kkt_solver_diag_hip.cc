@@ -11,7 +11,11 @@ ipxint PollInterrupt(void* control) {
 }  // namespace
 
 KKTSolverDiagHip::KKTSolverDiagHip(const Control& control, const Model& model)
-    : control_(control), model_(model), device_(model) {}
+    : control_(control), model_(model), device_(model) {
+    // The per-operator timers (time_cr1_AAt, time_cr1_pre) are only printed at debug level >= 2
+    // (reference src/lp_solver.cc:107, src/info.cc:20-105); collecting them costs stream markers.
+    HipCheck(ipxk_set_profiling(device_.get(), control_.Debug(2) ? 1 : 0));
+}
 
 // Builds W, resscale, the normal matrix and the (dense-column aware) diagonal
 // preconditioner on the device; see reference src/kkt_solver_diag.cc:18-65.
