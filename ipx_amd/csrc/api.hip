@@ -2,6 +2,8 @@
 // Thin glue: argument checks, host<->device staging according to the pointer mode,
 // exception -> return-code mapping.  No arithmetic lives here.
 
+#include <algorithm>
+
 #include "context.hpp"
 
 namespace ipxk {
@@ -19,6 +21,62 @@ Context::~Context() {
     for (hipEvent_t e : ev_window) (void)hipEventDestroy(e);
     for (hipEvent_t e : time_events) (void)hipEventDestroy(e);
     if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+namespace {
+struct Staging {
+    static constexpr size_t kChunk = size_t(8) << 20;
+    void* pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    void ensure() {
+        if (pin[0]) return;
+        for (int i = 0; i < 2; i++) {
+            IPXK_HIP(hipHostMalloc(&pin[i], kChunk, hipHostMallocDefault));
+            IPXK_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+    }
+};
+thread_local Staging g_staging;
+}  // namespace
+
+void staged_h2d(void* dst_dev, const void* src_host, size_t bytes, hipStream_t s) {
+    Staging& st = g_staging;
+    st.ensure();
+    const char* src = static_cast<const char*>(src_host);
+    char* dst = static_cast<char*>(dst_dev);
+    int i = 0;
+    for (size_t off = 0; off < bytes; off += Staging::kChunk, i ^= 1) {
+        const size_t n = std::min(Staging::kChunk, bytes - off);
+        IPXK_HIP(hipEventSynchronize(st.ev[i]));          // buffer i free again (no-op the first time)
+        memcpy(st.pin[i], src + off, n);
+        IPXK_HIP(hipMemcpyAsync(dst + off, st.pin[i], n, hipMemcpyHostToDevice, s));
+        IPXK_HIP(hipEventRecord(st.ev[i], s));
+    }
+}
+
+void staged_d2h(void* dst_host, const void* src_dev, size_t bytes, hipStream_t s) {
+    Staging& st = g_staging;
+    st.ensure();
+    char* dst = static_cast<char*>(dst_host);
+    const char* src = static_cast<const char*>(src_dev);
+    // chunk c is copied out of pinned buffer c&1 while chunk c+1 is in flight into the other one
+    size_t off_prev = 0, n_prev = 0;
+    int i = 0;
+    for (size_t off = 0; off < bytes; off += Staging::kChunk, i ^= 1) {
+        const size_t n = std::min(Staging::kChunk, bytes - off);
+        IPXK_HIP(hipEventSynchronize(st.ev[i]));
+        IPXK_HIP(hipMemcpyAsync(st.pin[i], src + off, n, hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipEventRecord(st.ev[i], s));
+        if (n_prev) {
+            IPXK_HIP(hipEventSynchronize(st.ev[i ^ 1]));
+            memcpy(dst + off_prev, st.pin[i ^ 1], n_prev);
+        }
+        off_prev = off; n_prev = n;
+    }
+    if (n_prev) {
+        IPXK_HIP(hipEventSynchronize(st.ev[i ^ 1]));
+        memcpy(dst + off_prev, st.pin[i ^ 1], n_prev);
+    }
 }
 
 void time_start(Context* c, ipxk_times* times) {
@@ -73,8 +131,7 @@ double* stage_out(Context* c, double* p, size_t len, DevBuf<double>& buf) {
 
 void finish_out(Context* c, double* user, const double* dev, size_t len) {
     if (!user || c->pointer_mode == IPXK_POINTER_DEVICE) return;
-    IPXK_HIP(hipMemcpyAsync(user, dev, len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    IPXK_HIP(hipStreamSynchronize(c->stream));
+    staged_d2h(user, dev, len * sizeof(double), c->stream);
 }
 
 template <class F>
@@ -302,9 +359,7 @@ int ipxk_pcr_solve(ipxk_context* c, const double* rhs, double tol, const double*
         const double* drhs = stage_in(c, rhs, m, c->v_rhs);
         const double* dscale = stage_in(c, resscale, m, c->v_resscale_in);
         double* dlhs = stage_out(c, lhs, m, c->v_lhs);
-        if (host) {
-            IPXK_HIP(hipMemcpyAsync(dlhs, lhs, m * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        }
+        if (host) staged_h2d(dlhs, lhs, m * sizeof(double), c->stream);
         if (times) *times = ipxk_times{};
         CrResult r = pcr_solve_dev(c, drhs, tol, dscale, maxiter, dlhs, zero, interrupt, interrupt_user,
                                    resnorm_hist, hist_cap, times);
@@ -327,9 +382,7 @@ int ipxk_cr_solve(ipxk_context* c, const double* rhs, double tol, const double* 
         const double* drhs = stage_in(c, rhs, m, c->v_rhs);
         const double* dscale = stage_in(c, resscale, m, c->v_resscale_in);
         double* dlhs = stage_out(c, lhs, m, c->v_lhs);
-        if (host) {
-            IPXK_HIP(hipMemcpyAsync(dlhs, lhs, m * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        }
+        if (host) staged_h2d(dlhs, lhs, m * sizeof(double), c->stream);
         if (times) *times = ipxk_times{};
         CrResult r = cr_solve_dev(c, drhs, tol, dscale, maxiter, dlhs, zero, interrupt, interrupt_user,
                                   resnorm_hist, hist_cap, times);
@@ -427,8 +480,7 @@ static int inplace_solve(ipxk_context* c, double* x, bool forward) {
         bind_device(c);
         const size_t m = (size_t)c->m;
         double* dx = stage_out(c, x, m, c->v_lhs);
-        if (c->pointer_mode == IPXK_POINTER_HOST)
-            IPXK_HIP(hipMemcpyAsync(dx, x, m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (c->pointer_mode == IPXK_POINTER_HOST) staged_h2d(dx, x, m * sizeof(double), c->stream);
         if (forward) forward_solve_dev(c, dx, true, nullptr);
         else backward_solve_dev(c, dx, true, nullptr);
         IPXK_HIP(hipGetLastError());
@@ -568,7 +620,7 @@ int ipxk_dev_upload(ipxk_context* c, void* dst_dev, const void* src_host, ipxint
     return guarded([&] {
         IPXK_REQUIRE(c && dst_dev && src_host && bytes >= 0, "bad argument");
         bind_device(c);
-        IPXK_HIP(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+        staged_h2d(dst_dev, src_host, (size_t)bytes, c->stream);
         IPXK_HIP(hipStreamSynchronize(c->stream));
     });
 }
@@ -576,8 +628,7 @@ int ipxk_dev_download(ipxk_context* c, void* dst_host, const void* src_dev, ipxi
     return guarded([&] {
         IPXK_REQUIRE(c && dst_host && src_dev && bytes >= 0, "bad argument");
         bind_device(c);
-        IPXK_HIP(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
-        IPXK_HIP(hipStreamSynchronize(c->stream));
+        staged_d2h(dst_host, src_dev, (size_t)bytes, c->stream);
     });
 }
 

@@ -45,6 +45,17 @@ void set_last_error(const std::string& msg);
     } while (0)
 
 // ---------------------------------------------------------------------------
+// host <-> device copies of pageable memory
+// ---------------------------------------------------------------------------
+// hipMemcpyAsync on pageable memory pins the pages on demand: measured 8-36 ms per call on the
+// MI355X box even for a few MB (profiles/, HIP API trace of the host-pointer path).  All copies of
+// caller-owned memory therefore go through two pinned staging buffers owned by the library
+// (memcpy into pinned memory, DMA from there, double-buffered in 8 MiB chunks).
+// On return the host data has been fully consumed (h2d) / is complete (d2h).
+void staged_h2d(void* dst_dev, const void* src_host, size_t bytes, hipStream_t s);
+void staged_d2h(void* dst_host, const void* src_dev, size_t bytes, hipStream_t s);
+
+// ---------------------------------------------------------------------------
 // device memory
 // ---------------------------------------------------------------------------
 template <class T>
@@ -75,11 +86,11 @@ public:
     size_t size() const { return n_; }
     void upload(const T* host, size_t n, hipStream_t s) {
         if (n > n_) resize(n);
-        if (n) IPXK_HIP(hipMemcpyAsync(p_, host, n * sizeof(T), hipMemcpyHostToDevice, s));
+        if (n) staged_h2d(p_, host, n * sizeof(T), s);
     }
     void upload(const std::vector<T>& v, hipStream_t s) { upload(v.data(), v.size(), s); }
     void download(T* host, size_t n, hipStream_t s) const {
-        if (n) IPXK_HIP(hipMemcpyAsync(host, p_, n * sizeof(T), hipMemcpyDeviceToHost, s));
+        if (n) staged_d2h(host, p_, n * sizeof(T), s);
     }
 private:
     T* p_ = nullptr;

@@ -93,24 +93,27 @@ __global__ __launch_bounds__(1024) void cholesky_lower_kernel(int k, double* __r
     if (threadIdx.x == 0) *info = fail;
 }
 
-// Solves L L' x = b in place for k <= 64 inside one wavefront: lane i owns b[i];
-// each elimination step broadcasts the newly fixed unknown with a shuffle.
+// Solves L L' x = b in place for k <= 64 inside one wavefront: the factor is staged in LDS once
+// (coalesced), lane i owns b[i] and each elimination step broadcasts the newly fixed unknown with
+// a shuffle -- no global-memory access on the 2k-step dependency chain.
 __global__ __launch_bounds__(64) void potrs_wave_kernel(int k, const double* __restrict__ a,
                                                         double* __restrict__ b, const int* done) {
     if (done && *done) return;
+    __shared__ double L[64 * 65];                  // column l at L[l*65 ...] (padded)
     const int i = threadIdx.x;
+    for (int l = 0; l < k; l++)
+        if (i < k) L[l * 65 + i] = a[i + (size_t)l * k];
+    __syncthreads();
     double bi = i < k ? b[i] : 0.0;
     for (int l = 0; l < k; l++) {                  // L z = b
-        const double dl = a[l + (size_t)l * k];
-        const double zl = __shfl(bi, l, 64) / dl;
+        const double zl = __shfl(bi, l, 64) / L[l * 65 + l];
         if (i == l) bi = zl;
-        else if (i > l && i < k) bi -= a[i + (size_t)l * k] * zl;
+        else if (i > l && i < k) bi -= L[l * 65 + i] * zl;
     }
     for (int l = k - 1; l >= 0; l--) {             // L' x = z
-        const double dl = a[l + (size_t)l * k];
-        const double xl = __shfl(bi, l, 64) / dl;
+        const double xl = __shfl(bi, l, 64) / L[l * 65 + l];
         if (i == l) bi = xl;
-        else if (i < l) bi -= a[l + (size_t)i * k] * xl;
+        else if (i < l) bi -= L[i * 65 + l] * xl;
     }
     if (i < k) b[i] = bi;
 }
