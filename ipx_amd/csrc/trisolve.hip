@@ -5,11 +5,11 @@
 //
 // Triangular solves are level-scheduled gather sweeps.  For each of the four sweeps
 // (U', L', L, U) the host computes the dependency level of every unknown once per
-// Prepare (the factors change every IPM iteration) and stores the rows level by level, so
-// that one launch processes one level with one thread per unknown; runs of narrow levels
-// (<= kTailWidth unknowns) are handled by a single workgroup in ONE launch with a
-// workgroup barrier between levels.  Each unknown is computed by one thread that walks its
-// entries in the reference's order:
+// Prepare (the factors change every IPM iteration) and stores the rows level by level.  A wide
+// level is one launch with one thread (or, for long rows, 8 lanes) per unknown; a run of narrow
+// levels is ONE single-workgroup launch that keeps the run's entries, unknowns and metadata in
+// LDS and separates levels by workgroup barriers (tail_lds_kernel).  Every row is summed in the
+// reference's order:
 //   transposed sweeps ('t'):  d = sum x[i]*a (ascending storage order); x = (x - d)/diag
 //   forward sweeps   ('n'):   x -= a*x_j one at a time in the reference's column order
 // so a sweep reproduces the reference's arithmetic (bit-exact given identical factors).
@@ -20,6 +20,7 @@
 // therefore uploads O(m + n) numbers plus the factors and never copies the matrix
 // (the reference copies all of N every time, splitted_normal_matrix.cc:42-55).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <exception>
 #include <string>
@@ -50,7 +51,11 @@ struct Sweep {
     bool has_scaled = false;
     std::vector<int> level_ptr;    // host, [nlevels+1]
     DevBuf<int> level_ptr_dev;
-    struct Launch { int l0, l1; bool tail; int gl; };   // gl: lanes per unknown (1, or 8 for long rows)
+    // tail: a run of narrow levels in one LDS-resident single-workgroup launch (tslot_off: offset of
+    // its dependency-slot table in `tslot`; e0/ne: its entries); otherwise one level with gl lanes
+    // per unknown (1, or 8 for long rows)
+    struct Launch { int l0, l1; bool tail; int gl; int tslot_off, e0, ne; };
+    DevBuf<short> tslot;
     DevBuf<unsigned char> chunk_long;   // sync-free sweep: chunk holds rows longer than kShortRow
     std::vector<Launch> plan;
     SweepView view(bool scaled) const {
@@ -92,29 +97,38 @@ static int vec_grid(int64_t len) {
 // (coalesced, all memory latency overlapped); the products are then combined ONE AT A TIME in
 // storage order through shuffles, so the arithmetic is the reference's sequential arithmetic
 // even for the long rows near the end of a forward sweep.
+// acc -= / += the products held by the first `cnt` lanes of the group, one at a time in lane
+// order.  All GL shuffles are issued before the first add, so their latencies overlap and only
+// the adds are serial.
+template <bool RUNNING, int GL>
+__device__ __forceinline__ double ordered_combine(double acc, double prod, int cnt, int gbase) {
+    if (GL == 1) return RUNNING ? acc - prod : acc + prod;
+    double v[GL];
+#pragma unroll
+    for (int t = 0; t < GL; t++) v[t] = __shfl(prod, gbase + t, 64);
+#pragma unroll
+    for (int t = 0; t < GL; t++)
+        if (t < cnt) acc = RUNNING ? acc - v[t] : acc + v[t];
+    return acc;
+}
+
 template <bool RUNNING, int GL>
 __device__ __forceinline__ void solve_unknown(const SweepView& S, int k, double* x) {
     const int lane = threadIdx.x & 63, gl = lane & (GL - 1), gbase = lane & ~(GL - 1);
+    // one round trip for the whole record (none of these loads depends on another)
     const int r = S.order[k];
-    if (r < 0) return;   // padding slot (whole groups are padding or real together)
     const int p0 = S.ptr[k], p1 = S.ptr[k + 1];
+    const double dg = S.diag[k];
+    if (r < 0) return;   // padding slot (whole groups are padding or real together)
     const double xr = x[r];
     double acc = RUNNING ? xr : 0.0;
     for (int base = p0; base < p1; base += GL) {
         const int p = base + gl;
         double prod = 0.0;
         if (p < p1) prod = RUNNING ? S.val[p] * x[S.idx[p]] : x[S.idx[p]] * S.val[p];
-        const int cnt = min(GL, p1 - base);
-        if (GL == 1) {
-            acc = RUNNING ? acc - prod : acc + prod;
-        } else {
-            for (int l = 0; l < cnt; l++) {
-                const double t = __shfl(prod, gbase + l, 64);
-                acc = RUNNING ? acc - t : acc + t;
-            }
-        }
+        acc = ordered_combine<RUNNING, GL>(acc, prod, min(GL, p1 - base), gbase);
     }
-    const double res = (RUNNING ? acc : xr - acc) / S.diag[k];
+    const double res = (RUNNING ? acc : xr - acc) / dg;
     if (gl == 0) x[r] = res;
 }
 
@@ -127,72 +141,126 @@ __global__ __launch_bounds__(kBlock) void level_kernel(SweepView S, int k0, int 
     if (k < k1) solve_unknown<RUNNING, GL>(S, k, x);
 }
 
-// A run of narrow levels in one workgroup.  Between two levels only the x values are new, so the
-// metadata of a group's first unknown of the NEXT level (order, row extent, first GL entries,
-// diagonal) is loaded before the barrier that ends the current level: after the barrier just the x
-// gathers (one round trip) and the ordered combine remain on the critical path.
-constexpr int kTailLevelsCached = 512;
+// A run of narrow levels with EVERYTHING in LDS.  Before the first level the workgroup loads, in
+// parallel, every entry of every unknown of the run: the product with an x value that is already
+// final (computed by an earlier launch), or the bare coefficient plus the run-local slot of the
+// dependency when that unknown belongs to the run itself; and per unknown its right-hand side,
+// row extent and diagonal.  The level loop then touches only LDS -- no global load or store is
+// outstanding at its barriers -- so a level costs a barrier plus a few LDS round trips instead of
+// two or three L2 round trips.  The run's x values go back to global memory once, at the end.
+// Sums are formed in the same storage order as in solve_unknown.  Levels of long and short rows
+// mix freely in one run.
+constexpr int kTailSlots = 4096;      // unknowns (level-ordered positions) per LDS tail launch
+constexpr int kTailEntries = 7168;    // entries per LDS tail launch
+constexpr int kTailLevelsLds = 512;   // levels per LDS tail launch
+constexpr int kTailMinLevels = 4;     // shorter runs are cheaper as one launch per level
+constexpr int kTailLevelWidth = 2048; // widest level (positions) that may join a run
+struct TailLds {                      // carve-up of the dynamic LDS block (150.0 KiB)
+    static constexpr size_t pv = 0;                                   // double[kTailEntries]
+    static constexpr size_t xt = pv + (size_t)kTailEntries * 8;       // double[kTailSlots]
+    static constexpr size_t dg = xt + (size_t)kTailSlots * 8;         // double[kTailSlots]
+    static constexpr size_t rp = dg + (size_t)kTailSlots * 8;         // int[kTailSlots + 1]
+    static constexpr size_t lp = rp + (size_t)(kTailSlots + 1) * 4;   // int[kTailLevelsLds + 1]
+    static constexpr size_t sl = lp + (size_t)(kTailLevelsLds + 1) * 4;   // short[kTailEntries]
+    static constexpr size_t bytes = sl + (size_t)kTailEntries * 2;
+};
+static_assert(TailLds::bytes <= 160 * 1024, "LDS tail does not fit one CU");
 
-template <bool RUNNING, int GL>
-__global__ __launch_bounds__(kTailWidth) void tail_kernel(SweepView S, const int* level_ptr, int l0,
-                                                          int l1, double* x, const int* done) {
+template <bool RUNNING>
+__global__ __launch_bounds__(kTailWidth) void tail_lds_kernel(SweepView S, const int* level_ptr,
+                                                              const short* __restrict__ tslot, int l0, int l1,
+                                                              int k0, int k1, int e0, int ne, double* x,
+                                                              const int* done) {
     if (done && *done) return;
-    __shared__ int lp[kTailLevelsCached + 1];
-    const int lane = threadIdx.x & 63, gl = lane & (GL - 1), gbase = lane & ~(GL - 1);
-    const int grp = threadIdx.x / GL, ngrp = kTailWidth / GL;
-    for (int lb = l0; lb < l1; lb += kTailLevelsCached) {
-        const int nl = min(kTailLevelsCached, l1 - lb);
-        __syncthreads();
-        for (int i = threadIdx.x; i <= nl; i += kTailWidth) lp[i] = level_ptr[lb + i];
-        __syncthreads();
-        // prefetched head of my first unknown of the next level
-        int pk = lp[0] + grp, pr = -1, pp0 = 0, pp1 = 0, pidx = 0;
-        double pval = 0.0, pdiag = 1.0;
-        auto prefetch = [&](int k, int kend) {
-            pk = k; pr = -1; pp0 = pp1 = 0;
-            if (k < kend) {
-                pr = S.order[k];
-                if (pr >= 0) {
-                    pp0 = S.ptr[k]; pp1 = S.ptr[k + 1];
-                    pdiag = S.diag[k];
-                    if (pp0 + gl < pp1) { pidx = S.idx[pp0 + gl]; pval = S.val[pp0 + gl]; }
-                }
-            }
-        };
-        prefetch(lp[0] + grp, lp[1]);
-        for (int l = 0; l < nl; l++) {
-            const int ke = lp[l + 1];
-            // first unknown of this level for my group: metadata already in registers
-            if (pr >= 0) {
-                const int r = pr, p0 = pp0, p1 = pp1;
-                const double xr = x[r];
-                double acc = RUNNING ? xr : 0.0;
-                for (int base = p0; base < p1; base += GL) {
-                    const int p = base + gl;
-                    double prod = 0.0;
-                    if (p < p1) {
-                        const int j = base == p0 ? pidx : S.idx[p];
-                        const double a = base == p0 ? pval : S.val[p];
-                        prod = RUNNING ? a * x[j] : x[j] * a;
-                    }
-                    const int cnt = min(GL, p1 - base);
-                    if (GL == 1) {
-                        acc = RUNNING ? acc - prod : acc + prod;
-                    } else {
-                        for (int q = 0; q < cnt; q++) {
-                            const double t = __shfl(prod, gbase + q, 64);
-                            acc = RUNNING ? acc - t : acc + t;
-                        }
-                    }
-                }
-                const double res = (RUNNING ? acc : xr - acc) / pdiag;
-                if (gl == 0) x[r] = res;
-            }
-            // further unknowns of a level wider than the workgroup's groups
-            for (int k = pk + ngrp; k < ke; k += ngrp) solve_unknown<RUNNING, GL>(S, k, x);
-            if (l + 1 < nl) prefetch(lp[l + 1] + grp, lp[l + 2]);
-            __syncthreads();   // workgroup-scope ordering of the global writes of this level
+    extern __shared__ __align__(16) unsigned char tail_lds[];
+    double* pv = reinterpret_cast<double*>(tail_lds + TailLds::pv);   // product (final dependency) or coefficient
+    double* xt = reinterpret_cast<double*>(tail_lds + TailLds::xt);   // x of the run's unknowns, by run-local position
+    double* dg = reinterpret_cast<double*>(tail_lds + TailLds::dg);
+    int* rp = reinterpret_cast<int*>(tail_lds + TailLds::rp);         // run-local row extents
+    int* lp = reinterpret_cast<int*>(tail_lds + TailLds::lp);         // run-local level extents
+    short* sl = reinterpret_cast<short*>(tail_lds + TailLds::sl);
+    const int nl = l1 - l0, nk = k1 - k0;
+    for (int i = threadIdx.x; i <= nl; i += kTailWidth) lp[i] = level_ptr[l0 + i] - k0;
+    // fill: every thread issues ALL its loads before it uses any of them (the fill is two round
+    // trips -- coefficients/slots/indices, then the gathers of final x values -- not two per entry)
+    {
+        constexpr int EU = kTailEntries / kTailWidth, SU = kTailSlots / kTailWidth;
+        static_assert(kTailEntries % kTailWidth == 0 && kTailSlots % kTailWidth == 0, "fill unroll");
+        int sj[EU], jj[EU], rr[SU];
+        double a[EU], xj[EU], xr[SU], dd[SU];
+#pragma unroll
+        for (int u = 0; u < EU; u++) {
+            const int i = threadIdx.x + u * kTailWidth;
+            const bool ok = i < ne;
+            sj[u] = ok ? tslot[i] : 0;
+            a[u] = ok ? S.val[e0 + i] : 0.0;
+            jj[u] = ok ? S.idx[e0 + i] : 0;
         }
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const int q = threadIdx.x + u * kTailWidth;
+            rr[u] = q < nk ? S.order[k0 + q] : -1;
+            dd[u] = q < nk ? S.diag[k0 + q] : 1.0;
+        }
+        for (int q = threadIdx.x; q <= nk; q += kTailWidth) rp[q] = S.ptr[k0 + q] - e0;
+#pragma unroll
+        for (int u = 0; u < EU; u++) xj[u] = (threadIdx.x + u * kTailWidth < ne && sj[u] < 0) ? x[jj[u]] : 1.0;
+#pragma unroll
+        for (int u = 0; u < SU; u++) xr[u] = rr[u] >= 0 ? x[rr[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < EU; u++) {
+            const int i = threadIdx.x + u * kTailWidth;
+            if (i < ne) {
+                sl[i] = (short)sj[u];
+                pv[i] = sj[u] < 0 ? (RUNNING ? a[u] * xj[u] : xj[u] * a[u]) : a[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const int q = threadIdx.x + u * kTailWidth;
+            if (q < nk) {
+                xt[q] = xr[u];                          // padding slots solve 0/1 and are never referenced
+                dg[q] = rr[u] >= 0 ? dd[u] : 1.0;
+            }
+        }
+    }
+    __syncthreads();
+    // Per level: (A) all threads turn the level's remaining coefficients into products, flat over
+    // its entries; (B) one thread per unknown adds the row's products one at a time in storage
+    // order straight from LDS -- those adds are the only serial work.
+    for (int l = 0; l < nl; l++) {
+        const int qb = lp[l], qe = lp[l + 1];
+        for (int p = rp[qb] + threadIdx.x, pe = rp[qe]; p < pe; p += kTailWidth) {
+            const int sj = sl[p];
+            if (sj >= 0) pv[p] = RUNNING ? pv[p] * xt[sj] : xt[sj] * pv[p];
+        }
+        __syncthreads();
+        for (int q = qb + threadIdx.x; q < qe; q += kTailWidth) {
+            const int p1 = rp[q + 1];
+            const double xr = xt[q];
+            double acc = RUNNING ? xr : 0.0;
+            int p = rp[q];
+            for (; p + 4 <= p1; p += 4) {
+                const double a0 = pv[p], a1 = pv[p + 1], a2 = pv[p + 2], a3 = pv[p + 3];
+                if (RUNNING) { acc -= a0; acc -= a1; acc -= a2; acc -= a3; }
+                else { acc += a0; acc += a1; acc += a2; acc += a3; }
+            }
+            for (; p < p1; p++) acc = RUNNING ? acc - pv[p] : acc + pv[p];
+            xt[q] = (RUNNING ? acc : xr - acc) / dg[q];
+        }
+        __syncthreads();
+    }
+    {
+        constexpr int SU = kTailSlots / kTailWidth;
+        int rr[SU];
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const int q = threadIdx.x + u * kTailWidth;
+            rr[u] = q < nk ? S.order[k0 + q] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < SU; u++)
+            if (rr[u] >= 0) x[rr[u]] = xt[threadIdx.x + u * kTailWidth];
     }
 }
 
@@ -359,6 +427,7 @@ __global__ __launch_bounds__(kBlock) void split_finish_kernel(int m, const doubl
 // Prepare are analysed on four host threads, then uploaded one after the other).
 struct SweepHost {
     std::vector<int> order, ptr, idx, lptr;
+    std::vector<short> tslot;
     std::vector<unsigned char> chunk_long;
     std::vector<double> val, valS, dg, dgS;
     bool has_scaled = false;
@@ -393,9 +462,10 @@ static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool 
     std::vector<int> lptr(nlev + 1, 0);
     for (int l = 0; l < nlev; l++) lptr[l + 1] = lptr[l] + (lcount[l] + align - 1) / align * align;
     const int npos = lptr[nlev];
-    std::vector<int> order(std::max(npos, 1), -1), next(lptr.begin(), lptr.end() - 1);
+    std::vector<int> order(std::max(npos, 1), -1), next(lptr.begin(), lptr.end() - 1), posof(dim, 0);
     for (int t = 0; t < dim; t++) {
         const int i = ascending ? t : dim - 1 - t;
+        posof[i] = next[level[i]];
         order[next[level[i]]++] = i;
     }
     const size_t nz = ri.size();
@@ -422,23 +492,47 @@ static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool 
     H.has_scaled = rxS != nullptr;
     H.order.swap(order); H.ptr.swap(ptr); H.idx.swap(idx); H.val.swap(val); H.valS.swap(valS);
     H.dg.swap(dg); H.dgS.swap(dgS); H.lptr = lptr;
-    // launch plan.  Levels whose rows all have <= kShortRow entries use one lane per unknown, the
-    // others (the long rows towards the end of a forward sweep) 8 lanes per unknown.  A level goes
-    // into a single-workgroup "tail" launch only if every lane group of that workgroup gets at most
-    // one unknown of it; consecutive tail levels of the same kind share one launch.
+    // launch plan.  Runs of >= kTailMinLevels narrow levels whose unknowns and entries fit the LDS of
+    // one CU go to ONE single-workgroup launch (tail_lds_kernel); every other level is a launch of
+    // its own, with one lane per unknown if all its rows have <= kShortRow entries and 8 lanes per
+    // unknown otherwise (the long rows towards the end of a forward sweep).
     S.plan.clear();
+    H.tslot.clear();
+    auto fits = [&](int a, int b) {
+        return b - a <= kTailLevelsLds && lptr[b] - lptr[a] <= kTailSlots &&
+               H.ptr[lptr[b]] - H.ptr[lptr[a]] <= kTailEntries;
+    };
+    auto narrow = [&](int lv) { return lptr[lv + 1] - lptr[lv] <= kTailLevelWidth; };
     int l = 0;
     while (l < nlev) {
-        const int gl = level_long[l] ? 8 : 1;
-        const int tail_positions = kTailWidth / gl;
-        if (lptr[l + 1] - lptr[l] > tail_positions) {
-            S.plan.push_back({l, l + 1, false, gl});
-            l++;
-        } else {
-            int l1 = l;
-            while (l1 < nlev && (level_long[l1] ? 8 : 1) == gl && lptr[l1 + 1] - lptr[l1] <= tail_positions) l1++;
-            S.plan.push_back({l, l1, true, gl});
-            l = l1;
+        if (narrow(l) && fits(l, l + 1)) {
+            int b = l + 1;
+            while (b < nlev && narrow(b) && fits(l, b + 1)) b++;
+            if (b - l >= kTailMinLevels) {
+                const int k0 = lptr[l], k1 = lptr[b];
+                const int off = (int)H.tslot.size();
+                for (int e = H.ptr[k0]; e < H.ptr[k1]; e++) {
+                    const int pj = posof[H.idx[e]];
+                    H.tslot.push_back(pj >= k0 && pj < k1 ? (short)(pj - k0) : (short)-1);
+                }
+                S.plan.push_back({l, b, true, 1, off, H.ptr[k0], H.ptr[k1] - H.ptr[k0]});
+                l = b;
+                continue;
+            }
+        }
+        S.plan.push_back({l, l + 1, false, level_long[l] ? 8 : 1, 0, 0, 0});
+        l++;
+    }
+    if (getenv("IPXK_SWEEP_STATS")) {
+        for (const Sweep::Launch& L : S.plan) {
+            if (!L.tail && getenv("IPXK_SWEEP_STATS")[0] != '2') continue;   // "2": every launch
+            int maxlen = 0; long ent = 0, unk = 0;
+            for (int k = lptr[L.l0]; k < lptr[L.l1]; k++) {
+                if (H.order[k] < 0) continue;
+                unk++; ent += H.ptr[k + 1] - H.ptr[k]; maxlen = std::max(maxlen, H.ptr[k + 1] - H.ptr[k]);
+            }
+            fprintf(stderr, "sweep(%s,%s) %s levels %d..%d gl %d unknowns %ld entries %ld maxrow %d\n",
+                    running ? "fwd" : "trans", ascending ? "asc" : "desc", L.tail ? "TAIL-LDS" : "level", L.l0, L.l1, L.gl, unk, ent, maxlen);
         }
     }
     // sync-free sweep: per chunk of kChunkRows positions, does it hold a long row?
@@ -457,31 +551,43 @@ static void upload_sweep(Sweep& S, const SweepHost& H, hipStream_t s) {
     if (H.has_scaled) { S.valS.upload(H.valS, s); S.diagS.upload(H.dgS, s); }
     S.level_ptr_dev.upload(H.lptr, s);
     S.chunk_long.upload(H.chunk_long, s);
+    if (H.tslot.empty()) S.tslot.resize(1); else S.tslot.upload(H.tslot, s);
     IPXK_HIP(hipStreamSynchronize(s));
 }
 
+template <bool RUNNING>
+static void launch_tail(Context* c, const Sweep& S, const SweepView& V, const Sweep::Launch& L, double* x,
+                        const int* done) {
+    static const bool configured = [] {
+        IPXK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_lds_kernel<RUNNING>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)TailLds::bytes));
+        return true;
+    }();
+    (void)configured;
+    hipLaunchKernelGGL((tail_lds_kernel<RUNNING>), dim3(1), dim3(kTailWidth), TailLds::bytes, c->stream, V,
+                       S.level_ptr_dev.get(), S.tslot.get() + L.tslot_off, L.l0, L.l1, S.level_ptr[L.l0],
+                       S.level_ptr[L.l1], L.e0, L.ne, x, done);
+}
+
 template <bool RUNNING, int GL>
-static void launch_plan_entry(Context* c, const Sweep& S, const SweepView& V, const Sweep::Launch& L, double* x,
-                              const int* done) {
-    if (L.tail) {
-        hipLaunchKernelGGL((tail_kernel<RUNNING, GL>), dim3(1), dim3(kTailWidth), 0, c->stream, V,
-                           S.level_ptr_dev.get(), L.l0, L.l1, x, done);
-    } else {
-        const int k0 = S.level_ptr[L.l0], k1 = S.level_ptr[L.l1];
-        const int g = (int)(((int64_t)(k1 - k0) * GL + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL((level_kernel<RUNNING, GL>), dim3(g), dim3(kBlock), 0, c->stream, V, k0, k1, x, done);
-    }
+static void launch_level(Context* c, const Sweep& S, const SweepView& V, const Sweep::Launch& L, double* x,
+                         const int* done) {
+    const int k0 = S.level_ptr[L.l0], k1 = S.level_ptr[L.l1];
+    const int g = (int)(((int64_t)(k1 - k0) * GL + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((level_kernel<RUNNING, GL>), dim3(g), dim3(kBlock), 0, c->stream, V, k0, k1, x, done);
 }
 
 static void run_sweep(Context* c, const Sweep& S, bool scaled, double* x, const int* done) {
     const SweepView V = S.view(scaled);
     for (const Sweep::Launch& L : S.plan) {
         if (S.running) {
-            if (L.gl == 8) launch_plan_entry<true, 8>(c, S, V, L, x, done);
-            else launch_plan_entry<true, 1>(c, S, V, L, x, done);
+            if (L.tail) launch_tail<true>(c, S, V, L, x, done);
+            else if (L.gl == 8) launch_level<true, 8>(c, S, V, L, x, done);
+            else launch_level<true, 1>(c, S, V, L, x, done);
         } else {
-            if (L.gl == 8) launch_plan_entry<false, 8>(c, S, V, L, x, done);
-            else launch_plan_entry<false, 1>(c, S, V, L, x, done);
+            if (L.tail) launch_tail<false>(c, S, V, L, x, done);
+            else if (L.gl == 8) launch_level<false, 8>(c, S, V, L, x, done);
+            else launch_level<false, 1>(c, S, V, L, x, done);
         }
     }
 }
