@@ -159,10 +159,13 @@ def main():
     peak = HBM_PEAK_GBS * world
     # L2<->fabric bytes per apply from the PMC passes of the same command (profiles/, separate
     # rocprofv3 --pmc runs; bench.py cannot collect counters on itself)
+    layouts, tuned_us = ctx.spmv_layout()
+    kernel_names = {"phased": "spmv_phased_kernel", "sliced": "spmv_sliced_tile_kernel+spmv_sliced_combine_kernel"}
     traffic = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if world == 1 and pm["workload"] == "C3 m=%d n=%d nnz=%d" % (m, n, nnz):
+        if (world == 1 and pm["workload"] == "C3 m=%d n=%d nnz=%d" % (m, n, nnz)
+                and pm.get("layouts", ["phased", "phased"]) == list(layouts)):
             traffic = pm["traffic_bytes_per_apply"]
     except (OSError, KeyError, ValueError):
         pass
@@ -186,9 +189,12 @@ def main():
                    "cr_iterations_per_solve": it, "errflag": errflag,
                    "cr_iterations_per_sec": it * args.steps / dt,
                    "cr_loop_ms_per_solve": cr_time / args.steps * 1e3},
-        "roofline": {"bound": "hbm", "kernel": "spmv_phased_kernel (NormalMatrix apply = pass 1 + pass 2)",
+        "roofline": {"bound": "hbm",
+                     "kernel": "NormalMatrix apply = pass 1 t=W.*(A'y) [%s] + pass 2 lhs=A t [%s]"
+                               % (kernel_names[layouts[0]], kernel_names[layouts[1]]),
                      "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                     "traffic": traffic, "us_per_apply": apply_ms * 1e3, "algorithmic_bytes": bytes_apply},
+                     "traffic": traffic, "us_per_apply": apply_ms * 1e3, "algorithmic_bytes": bytes_apply,
+                     "layouts": list(layouts), "layout_tuning_us": tuned_us},
     }
 
     if rank == 0 and world == 1 and not args.no_banded:

@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -159,6 +160,38 @@ struct GatherView {                // passed to kernels by value
     unsigned long long* stamps;    // tuning aid: wall clock at the start of each step (or nullptr)
 };
 
+// XCD-sliced tile layout (alternative to the phased layout for large gathered vectors).  The
+// columns are cut into `nslices` contiguous slices of at most ~2 MiB of x, the rows into blocks of
+// kSlicedRows.  Tile (rb, s) holds the entries of row block rb whose column lies in slice s, row by
+// row in storage order; it is processed by workgroup rb*nslices + s, which under the round-robin
+// workgroup -> XCD dispatch of gfx950 runs on XCD (rb*nslices + s) % 8: an XCD only ever gathers
+// from the slice(s) congruent to its index, which therefore stay resident in its 4 MiB L2 no
+// matter how far workgroups drift apart -- x is fetched from HBM about once instead of once per
+// XCD.  (Placement affects speed only; the result does not depend on it.)  A tile writes one
+// partial sum per row; a second streaming kernel adds the slices' partials in slice order and
+// applies the epilogue.  Within a slice a row is summed in storage order, so results differ from
+// the phased layout only by the association across slices (~1 ulp).
+constexpr int kSlicedRows = 1024;      // rows per tile (4 per thread)
+constexpr int kSlicedMaxTile = 6144;   // entries per tile that fit the LDS staging buffer
+
+struct SlicedView {
+    int nrows, nrows_pad, nslices, nrb;
+    const unsigned* tile_ptr;          // [nrb*nslices + 1] first entry of each tile
+    const unsigned char* cnt;          // [nrb*nslices][kSlicedRows] entries per row of the tile
+    const int* idx;
+    const double* val;
+    double* partial;                   // [nslices][nrows_pad]
+};
+
+struct SlicedMatrix {
+    bool built = false;
+    int nslices = 0, nrb = 0, nrows_pad = 0, max_tile = 0;
+    DevBuf<unsigned> tile_ptr;
+    DevBuf<unsigned char> cnt;
+    DevBuf<int> idx;
+    DevBuf<double> val, partial;
+};
+
 struct GatherMatrix {
     int nrows = 0, ncols = 0;
     int64_t nnz = 0;
@@ -179,10 +212,19 @@ struct GatherMatrix {
     // Builds from host arrays with 64-bit indices (ptr has nrows+1 entries).
     void build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, const ipxint* hidx,
                const double* hval, hipStream_t s);
+    // optional second layout and the choice between the two (IPXK_SPMV_LAYOUT=phased|sliced|auto;
+    // auto times both once at build time on this matrix and keeps the faster one)
+    SlicedMatrix sliced;
+    bool use_sliced = false;
+    float tuned_us_phased = 0.f, tuned_us_sliced = 0.f;
+    void build_sliced(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s);
+    SlicedView sliced_view() const;
+    int combine_grid() const { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, ((int64_t)nrows + kBlock - 1) / kBlock)); }
+
     GatherView view() const;
     int grid() const { return G; }
     // # dot partials a launch produces
-    int num_partials() const { return G + (nlong > 0 ? 1 : 0); }
+    int num_partials() const { return use_sliced ? combine_grid() : G + (nlong > 0 ? 1 : 0); }
 };
 
 // elements of the gathered vector per phase (IPXK_SLICE_KB overrides, default 1 MiB)

@@ -5,6 +5,9 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <cstdio>
+#include <string>
+
 #include "context.hpp"
 #include "spmv_kernels.hpp"
 
@@ -161,6 +164,111 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
         plain_val.upload(hval, (size_t)nz, s);
     }
     IPXK_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
+
+    // second layout + choice
+    use_sliced = false;
+    sliced = SlicedMatrix();
+    std::string layout = "auto";
+    if (const char* e = getenv("IPXK_SPMV_LAYOUT")) layout = e;
+    if (layout != "phased") build_sliced(hptr, hidx, hval, s);
+    if (sliced.built) {
+        if (layout == "sliced") {
+            use_sliced = true;
+        } else {
+            // time both on this matrix (the gathered values do not matter for the memory system)
+            DevBuf<double> tx((size_t)std::max(ncols, 1)), tout((size_t)std::max(nrows, 1));
+            IPXK_HIP(hipMemsetAsync(tx.get(), 0, tx.size() * sizeof(double), s));
+            hipEvent_t e0, e1;
+            IPXK_HIP(hipEventCreate(&e0));
+            IPXK_HIP(hipEventCreate(&e1));
+            EpiScale epi{{}, nullptr, tout.get()};
+            float best[2] = {0.f, 0.f};
+            for (int which = 0; which < 2; which++) {
+                use_sliced = which == 1;
+                const int reps = 5;
+                for (int w = 0; w < 2; w++) launch_spmv(*this, tx.get(), epi, nullptr, nullptr, s);
+                IPXK_HIP(hipEventRecord(e0, s));
+                for (int r = 0; r < reps; r++) launch_spmv(*this, tx.get(), epi, nullptr, nullptr, s);
+                IPXK_HIP(hipEventRecord(e1, s));
+                IPXK_HIP(hipEventSynchronize(e1));
+                float ms = 0.f;
+                IPXK_HIP(hipEventElapsedTime(&ms, e0, e1));
+                best[which] = ms * 1e3f / reps;
+            }
+            IPXK_HIP(hipEventDestroy(e0));
+            IPXK_HIP(hipEventDestroy(e1));
+            tuned_us_phased = best[0];
+            tuned_us_sliced = best[1];
+            use_sliced = best[1] < 0.95f * best[0];
+            if (!use_sliced) sliced = SlicedMatrix();   // release the unused copy
+            if (getenv("IPXK_VERBOSE"))
+                fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld: phased %.1f us, sliced %.1f us -> %s\n", nrows,
+                        ncols, (long long)nnz, best[0], best[1], use_sliced ? "sliced" : "phased");
+        }
+    }
+}
+
+// Sliced layout (internal.hpp).  Eligible when x does not fit an XCD's L2, no row is "long" and
+// every tile fits the LDS staging buffer.
+void GatherMatrix::build_sliced(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s) {
+    const int64_t x_bytes = (int64_t)ncols * 8;
+    if (nlong > 0 || nrows == 0 || nnz == 0 || x_bytes <= (int64_t(4) << 20)) return;
+    int ns = 2;
+    while (ns < 8 && x_bytes > (int64_t)ns * (int64_t(2) << 20)) ns *= 2;
+    const int64_t slice = ((ncols + ns - 1) / ns + 15) / 16 * 16;
+    const int nrb = (nrows + kSlicedRows - 1) / kSlicedRows;
+    const int64_t ntiles = (int64_t)nrb * ns;
+    std::vector<unsigned> tptr((size_t)ntiles + 1, 0);
+    std::vector<unsigned char> cnt((size_t)ntiles * kSlicedRows, 0);
+    std::vector<int> ti((size_t)nnz);
+    std::vector<double> tv((size_t)nnz);
+    std::vector<ipxint> cur(hptr, hptr + nrows);
+    unsigned put = 0;
+    int max_tile = 0;
+    for (int rb = 0; rb < nrb; rb++) {
+        const int r0 = rb * kSlicedRows, r1 = std::min(nrows, r0 + kSlicedRows);
+        for (int sl = 0; sl < ns; sl++) {
+            const int64_t tile = (int64_t)rb * ns + sl;
+            const ipxint col_end = (ipxint)std::min<int64_t>(ncols, (sl + 1) * slice);
+            tptr[tile] = put;
+            for (int r = r0; r < r1; r++) {
+                ipxint p = cur[r];
+                const ipxint pe = hptr[r + 1];
+                const unsigned first = put;
+                while (p < pe && hidx[p] < col_end) {
+                    ti[put] = (int)hidx[p];
+                    tv[put] = hval[p];
+                    put++; p++;
+                }
+                if (put - first > 255) return;              // count does not fit a byte
+                if (sl == ns - 1 && p != pe) return;        // columns not ascending within the row
+                cnt[(size_t)tile * kSlicedRows + (r - r0)] = (unsigned char)(put - first);
+                cur[r] = p;
+            }
+            max_tile = std::max(max_tile, (int)(put - tptr[tile]));
+        }
+    }
+    tptr[ntiles] = put;
+    if ((int64_t)put != nnz || max_tile > kSlicedMaxTile) return;
+    sliced.nslices = ns;
+    sliced.nrb = nrb;
+    sliced.nrows_pad = nrb * kSlicedRows;
+    sliced.max_tile = max_tile;
+    sliced.tile_ptr.upload(tptr, s);
+    sliced.cnt.upload(cnt, s);
+    sliced.idx.upload(ti, s);
+    sliced.val.upload(tv, s);
+    sliced.partial.resize((size_t)ns * sliced.nrows_pad);
+    IPXK_HIP(hipStreamSynchronize(s));
+    sliced.built = true;
+}
+
+SlicedView GatherMatrix::sliced_view() const {
+    SlicedView V;
+    V.nrows = nrows; V.nrows_pad = sliced.nrows_pad; V.nslices = sliced.nslices; V.nrb = sliced.nrb;
+    V.tile_ptr = sliced.tile_ptr.get(); V.cnt = sliced.cnt.get();
+    V.idx = sliced.idx.get(); V.val = sliced.val.get(); V.partial = sliced.partial.get();
+    return V;
 }
 
 GatherView GatherMatrix::view() const {

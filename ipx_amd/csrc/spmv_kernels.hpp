@@ -321,11 +321,110 @@ __global__ __launch_bounds__(kBlock) void spmv_long_fixup_kernel(GatherView M, E
     }
 }
 
+// ---- XCD-sliced tile layout (internal.hpp, SlicedMatrix) -------------------------
+// One tile per workgroup: the tile's entries are streamed with coalesced loads (8 in flight per
+// thread, gathers issued together), their products are staged in LDS, then every thread adds up
+// the products of its 4 consecutive rows in storage order and writes the 4 partial sums (32 B).
+template <class Epi>
+__global__ __launch_bounds__(kBlock) void spmv_sliced_tile_kernel(SlicedView M, const double* __restrict__ x,
+                                                                  const int* done) {
+    if (done && *done) return;
+    extern __shared__ double sl_prod[];
+    __shared__ int wave_sum[kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int s = tile % M.nslices, rb = tile / M.nslices;
+    const unsigned e0 = M.tile_ptr[tile];
+    const int ne = (int)(M.tile_ptr[tile + 1] - e0);
+    constexpr int RPT = kSlicedRows / kBlock;   // 4
+    static_assert(RPT == 4, "one 32-bit load holds a thread's row counts");
+    const unsigned c4 = reinterpret_cast<const unsigned*>(M.cnt + (size_t)tile * kSlicedRows)[tid];
+    constexpr int U = 8;
+    for (int base = 0; base < ne; base += kBlock * U) {
+        int ci[U];
+        double v[U], xg[U];
+        // unpredicated loads (lanes past the end re-read the tile's last entry), so that all 2*U
+        // stream loads and then all U gathers of a thread are in flight together
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = min(base + u * kBlock + tid, ne - 1);
+            ci[u] = __builtin_nontemporal_load(M.idx + e0 + i);
+            v[u] = __builtin_nontemporal_load(M.val + e0 + i);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) xg[u] = x[ci[u]];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = base + u * kBlock + tid;
+            if (i < ne) sl_prod[lds_slot(i)] = Epi::prod(xg[u], v[u]);
+        }
+    }
+    // exclusive scan of the per-thread entry counts -> first staged product of my rows
+    const int mine = (int)((c4 & 255u) + ((c4 >> 8) & 255u) + ((c4 >> 16) & 255u) + (c4 >> 24));
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int nb = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += nb;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    int p = incl - mine;
+    for (int w = 0; w < wave; w++) p += wave_sum[w];
+    double out[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; q++) {
+        const int cq = (int)((c4 >> (8 * q)) & 255u);
+        double acc = 0.0;
+        for (int kk = 0; kk < cq; kk++) acc += sl_prod[lds_slot(p + kk)];
+        p += cq;
+        out[q] = acc;
+    }
+    double* dst = M.partial + (size_t)s * M.nrows_pad + (size_t)rb * kSlicedRows + (size_t)tid * RPT;
+    reinterpret_cast<double2*>(dst)[0] = make_double2(out[0], out[1]);
+    reinterpret_cast<double2*>(dst)[1] = make_double2(out[2], out[3]);
+}
+
+// out[r] = finish(init(r) (+|-) partial[0][r] (+|-) partial[1][r] ...), slices in ascending order
+template <class Epi>
+__global__ __launch_bounds__(kBlock) void spmv_sliced_combine_kernel(SlicedView M, Epi epi, double* dot_partials,
+                                                                     const int* done) {
+    if (done && *done) return;
+    __shared__ double red[kBlock / 64 + 1];
+    double dotpart = 0.0;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < M.nrows; r += gridDim.x * kBlock) {
+        double acc = epi.init(r);
+        for (int s = 0; s < M.nslices; s++) {
+            const double t = __builtin_nontemporal_load(M.partial + (size_t)s * M.nrows_pad + r);
+            acc = Epi::kNeg ? acc - t : acc + t;
+        }
+        epi.finish(r, acc, dotpart);
+    }
+    if (dot_partials) {
+        const double d = block_reduce<SumOp>(dotpart, red);
+        if (threadIdx.x == 0) dot_partials[blockIdx.x] = d;
+    }
+}
+
+template <class Epi>
+inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi& epi, double* dot_partials,
+                               const int* done, hipStream_t s) {
+    const SlicedView V = M.sliced_view();
+    const size_t lds = (size_t)(M.sliced.max_tile + M.sliced.max_tile / 32 + 1) * sizeof(double);
+    hipLaunchKernelGGL(spmv_sliced_tile_kernel<Epi>, dim3(V.nrb * V.nslices), dim3(kBlock), lds, s, V, x, done);
+    hipLaunchKernelGGL(spmv_sliced_combine_kernel<Epi>, dim3(M.combine_grid()), dim3(kBlock), 0, s, V, epi,
+                       dot_partials, done);
+}
+
 // Launches the SpMV (+ long-row kernels when the matrix has long rows).  Returns
 // the number of dot partials written (0 when dot_partials == nullptr).
 template <class Epi>
 inline int launch_spmv(const GatherMatrix& M, const double* x, const Epi& epi, double* dot_partials,
                        const int* done, hipStream_t s) {
+    if (M.use_sliced) {
+        launch_spmv_sliced(M, x, epi, dot_partials, done, s);
+        return dot_partials ? M.num_partials() : 0;
+    }
     const GatherView V = M.view();
     const dim3 grid(M.G), block(kBlock);
     switch (M.RT) {

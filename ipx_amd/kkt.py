@@ -31,7 +31,7 @@ EXPORTS = [
     "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_apply", "ipxk_forward_solve",
     "ipxk_backward_solve", "ipxk_solve_dense", "ipxk_split_levels", "ipxk_cr_solve",
     "ipxk_kkt_basis_solve", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_time_normal_apply",
-    "ipxk_normal_apply_bytes", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
+    "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
     "ipxk_dev_download",
 ]
 
@@ -172,6 +172,14 @@ class KktContext:
     @property
     def normal_apply_bytes(self):
         return int(self.lib.ipxk_normal_apply_bytes(self.h))
+
+    def spmv_layout(self):
+        """(layout of A'y, layout of A t) as 'phased'/'sliced', and the build-time timings in us."""
+        lay = (C.c_int * 2)()
+        us = (C.c_double * 4)()
+        self._check(self.lib.ipxk_spmv_layout(self.h, lay, us))
+        names = ("phased", "sliced")
+        return (names[lay[0]], names[lay[1]]), [float(v) for v in us]
 
     def get_rowwise(self):
         nnz = int(self._keep[0][-1])

@@ -334,6 +334,33 @@ def test_full_size_properties(kkt):
 
 
 # --------------------------------------------------------------------------------------
+# the two SpMV layouts (phased / XCD-sliced tiles) on a matrix large enough for the sliced one
+# --------------------------------------------------------------------------------------
+def test_spmv_layouts_agree(kkt, po, oracle, monkeypatch):
+    m, n = 300000, 700000                      # A t gathers from 5.6 MB: sliced layout eligible
+    A, st = diag_problem(m, n, seed=77)
+    W = st["xl"] / st["zl"]
+    rng = np.random.default_rng(5)
+    u = rng.standard_normal(m)
+    ref, ref_dot = oracle.normal_apply(ocsc(po, A), W, u)
+    out = {}
+    for layout in ("phased", "sliced"):
+        monkeypatch.setenv("IPXK_SPMV_LAYOUT", layout)
+        ctx = kkt.KktContext(A)
+        ctx.normal_prepare(W)
+        lhs, dot = ctx.normal_apply(u)
+        assert relerr(lhs, ref) < 1e-12 and abs(dot - ref_dot) <= 1e-12 * abs(ref_dot), layout
+        assert ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"]) == 0
+        x, y, it, e, _ = ctx.kkt_diag_solve(st["a"], st["b"], 0.3 * np.sqrt(st["mu"]), 500)
+        out[layout] = (lhs, x, y, it, e)
+        ctx.close()
+    assert np.array_equal(out["phased"][0], ref)        # phased layout: the reference's summation order
+    assert relerr(out["sliced"][0], out["phased"][0]) < 1e-14
+    assert out["sliced"][4] == out["phased"][4] == 0 and abs(out["sliced"][3] - out["phased"][3]) <= 2
+    assert relerr(out["sliced"][2], out["phased"][2]) < 1e-8
+
+
+# --------------------------------------------------------------------------------------
 # the collective code path (RCCL), exercised with a one-rank communicator: IPXK_FORCE_COMM
 # routes a single rank through finalize + all-gather + all-reduce exactly as N ranks would run
 # --------------------------------------------------------------------------------------
