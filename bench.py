@@ -9,10 +9,12 @@ A "step" is one KKTSolver::Solve (reference src/kkt_solver_diag.cc:82-118: right
 assembly, preconditioned CR to tol = 0.3*sqrt(mu), solution recovery) on the C3 workload of
 SURVEY.md section 8(d): m = 1M, n = 2M, 8 nnz/col, IPM scaling spread s = 1, inputs resident in
 HBM.  N > 1: the SAME system with the rows of AI partitioned over the N ranks and one RCCL
-all-reduce per NormalMatrix apply (strong scaling; value = solves/s of the joint solve).
+all-reduce per NormalMatrix apply (strong scaling; value = solves/s of the joint solve); the
+alternative column partition of SURVEY.md section 8(e) is measured in the same run and reported
+in config.column_partition.
 
 One JSON line on rank 0:  metric/value/unit/...,
-  "roofline":     the NormalMatrix apply (two launches of spmv_phased_kernel) against the HBM roof:
+  "roofline":     the NormalMatrix apply (its two sparse products, kernels named in the line) against the HBM roof:
                   algorithmic bytes 2*nnz*12 + (n+m+2)*4 + 8*(3n+4m) per apply / HIP-event time;
   "cpu_baseline": the same solve on ONE host core, timed in this run, by the reference's own
                   objects (oracle/_ref, kind "reference") when that build is present, else by
@@ -43,6 +45,8 @@ def parse():
     ap.add_argument("--maxiter", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--basis", action="store_true", help="also time the basis-preconditioned solve (extra field)")
+    ap.add_argument("--no-column-partition", action="store_true",
+                    help="N > 1: skip the extra measurement of the column partition (config.column_partition)")
     ap.add_argument("--no-banded", action="store_true", help="skip the banded-matrix probe of the SpMV (extra field of roofline)")
     return ap.parse_args()
 
@@ -197,6 +201,10 @@ def main():
                      "layouts": list(layouts), "layout_tuning_us": tuned_us},
     }
 
+    if (world > 1 or os.environ.get("IPXK_FORCE_COMM")) and not args.no_column_partition:
+        # every rank takes part; reported next to the north-star row partition, never as `value`
+        out["config"]["column_partition"] = bench_column_partition(kkt, dist, torch, A, st, tol, args, rank, world,
+                                                                   local_rank)
     if rank == 0 and world == 1 and not args.no_banded:
         out["roofline"]["banded_matrix_probe"] = bench_banded(kkt, synth, m, n)
     if rank == 0 and world == 1 and args.basis:
@@ -216,6 +224,52 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_column_partition(kkt, dist, torch, A, st, tol, args, rank, world, local_rank):
+    """The SAME solve with the structural COLUMNS of A partitioned over the ranks (alternative):
+    every m-vector and every CR scalar is replicated, the one exchange per NormalMatrix apply is an
+    all-reduce of m doubles (half the bytes of the row partition's n doubles, and no scalar exchange)."""
+    from ipx_amd.partition import col_slab
+    slab = col_slab(A, st, rank, world)
+    ctx = kkt.KktContext(slab.A, device=local_rank)
+    if world > 1:
+        ids = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(ids[0], rank, world, columns=True)
+    else:
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1, columns=True)
+    assert ctx.kkt_diag_factorize(slab.xl, slab.xu, slab.zl, slab.zu, st["mu"]) == 0
+    ctx.set_pointer_mode(True)
+    m, ng = A.nrow, slab.A.ncol
+    a, b = ctx.vector(ng + m, slab.a), ctx.vector(m, slab.b)
+    x, y = ctx.vector(ng + m), ctx.vector(m)
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        it, errflag, tm = ctx.kkt_diag_solve_resident(a, b, x, y, tol, args.maxiter)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        it, errflag, tm = ctx.kkt_diag_solve_resident(a, b, x, y, tol, args.maxiter)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    rhs_d, lhs_d = ctx.vector(m, np.random.default_rng(0).standard_normal(m)), ctx.vector(m)
+    ctx.time_normal_apply(rhs_d, lhs_d, 5)
+    apply_ms = ctx.time_normal_apply(rhs_d, lhs_d, 50) / 50
+    ctx.close()
+    return {"solves_per_sec": args.steps / dt, "ms_per_solve": dt / args.steps * 1e3, "cr_iterations": it,
+            "errflag": errflag, "us_per_apply": apply_ms * 1e3,
+            "exchange": "one all-reduce of m = %d doubles per NormalMatrix apply, no scalar exchange" % m}
 
 
 def bench_banded(kkt, synth, m, n):

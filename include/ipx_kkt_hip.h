@@ -190,6 +190,13 @@ int ipxk_comm_unique_id(void* id128);
  * rows, all n columns, row indices local).  After this call dot products and
  * norms of the CR loop are global and ipxk_normal_apply all-reduces A_g' y_g. */
 int ipxk_comm_init(ipxk_context* ctx, const void* id128, int rank, int nranks);
+/* Alternative partition ("column partition"): the context
+ * was created from this rank's slab of structural COLUMNS (all m rows, n =
+ * local columns).  Vector arguments then are [local structural part; all m
+ * slack entries] for (n+m)-vectors and full m-vectors; every m-vector and
+ * every scalar of the CR loop is replicated, the one exchange step per
+ * NormalMatrix::_Apply is the all-reduce of the m partial sums A_g t_g. */
+int ipxk_comm_init_columns(ipxk_context* ctx, const void* id128, int rank, int nranks);
 
 /* ---- measurement helpers (bench.py, section 8d) --------------------------- */
 /* Runs `reps` NormalMatrix applies on resident device vectors and returns the

@@ -14,7 +14,7 @@ namespace {
 // the few RCCL declarations used (ABI of rccl.h, ROCm 7.2)
 typedef struct { char internal[128]; } RcclUniqueId;
 enum { kNcclFloat64 = 8 };   // ncclDouble
-enum { kNcclSum = 0, kNcclMax = 2 };
+enum { kNcclSum = 0, kNcclMax = 2, kNcclMin = 3 };
 typedef int (*GetUniqueIdFn)(RcclUniqueId*);
 typedef int (*CommInitRankFn)(ncclComm**, int, RcclUniqueId, int);
 typedef int (*CommDestroyFn)(ncclComm*);
@@ -63,6 +63,14 @@ void check(int rc, const char* what) {
 // GPU tests: the one-GPU test box cannot host a second rank).
 bool comm_active(const Context* c) { return c->comm != nullptr && (c->nranks > 1 || c->force_comm); }
 
+bool comm_rows(const Context* c) { return comm_active(c) && !c->col_partition; }
+bool comm_cols(const Context* c) { return comm_active(c) && c->col_partition; }
+
+void comm_allreduce_min(Context* c, double* buf, size_t count) {
+    if (!comm_active(c) || count == 0) return;
+    check(rccl().all_reduce(buf, buf, count, kNcclFloat64, kNcclMin, c->comm, c->stream), "ncclAllReduce");
+}
+
 void comm_allreduce_sum(Context* c, double* buf, size_t count) {
     if (!comm_active(c) || count == 0) return;
     check(rccl().all_reduce(buf, buf, count, kNcclFloat64, kNcclSum, c->comm, c->stream), "ncclAllReduce");
@@ -107,7 +115,7 @@ extern "C" int ipxk_comm_unique_id(void* id128) {
     }
 }
 
-extern "C" int ipxk_comm_init(ipxk_context* c, const void* id128, int rank, int nranks) {
+static int comm_init_impl(ipxk_context* c, const void* id128, int rank, int nranks, bool columns) {
     try {
         if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks)
             throw Error(IPXK_E_ARGUMENT, "ipxk_comm_init: bad argument");
@@ -119,6 +127,11 @@ extern "C" int ipxk_comm_init(ipxk_context* c, const void* id128, int rank, int 
         c->rank = rank;
         c->nranks = nranks;
         c->force_comm = getenv("IPXK_FORCE_COMM") != nullptr;
+        c->col_partition = columns;
+        if (columns) {          // every rank holds all m rows
+            c->m_global = c->m;
+            return IPXK_OK;
+        }
         // global row count (defines the default iteration cap m+100 identically on every rank)
         DevBuf<double> cnt(1);
         const double mine = (double)c->m;
@@ -133,4 +146,12 @@ extern "C" int ipxk_comm_init(ipxk_context* c, const void* id128, int rank, int 
         set_last_error(e.what());
         return e.code;
     }
+}
+
+extern "C" int ipxk_comm_init(ipxk_context* c, const void* id128, int rank, int nranks) {
+    return comm_init_impl(c, id128, rank, nranks, false);
+}
+
+extern "C" int ipxk_comm_init_columns(ipxk_context* c, const void* id128, int rank, int nranks) {
+    return comm_init_impl(c, id128, rank, nranks, true);
 }

@@ -88,6 +88,10 @@ struct Context {
     int rank = 0, nranks = 1;
     int64_t m_global = 0;               // rows of the whole system (sum over ranks)
     bool force_comm = false;
+    // false: rows of AI partitioned (m local, n global; scalars and A'y need exchange steps);
+    // true: structural COLUMNS partitioned (m global, n local; every m-vector and every scalar of
+    // the CR loop is replicated, the only exchange is the sum of the partial products A_g t_g)
+    bool col_partition = false;
     DevBuf<double> comm_scalars;        // scratch scalars (single-value reductions)
     DevBuf<double> comm_send;           // kNumPartialSlots scalars of this rank
     DevBuf<double> comm_gather;         // nranks * kNumPartialSlots, rank-major
@@ -131,6 +135,8 @@ CrResult cr_solve_dev(Context* c, const double* rhs, double tol, const double* r
 double reduce_partials_host(Context* c, int slot, int count, bool is_max);
 // partitioned runs: finalize this rank's partials of `slot`, all-gather, return the per-rank view
 struct PartRef publish_scalar(Context* c, int slot, int count, int op);
+// finalize this rank's partials of `slot`, all-reduce the scalar; returns a one-element view
+struct PartRef allreduce_scalar(Context* c, int slot, int count, int op);
 
 // ---- kkt_diag.hip ----
 void kkt_diag_factorize_dev(Context* c, const double* xl, const double* xu, const double* zl,
@@ -161,6 +167,9 @@ void comm_allreduce_sum(Context* c, double* buf, size_t count);
 void comm_allreduce_max(Context* c, double* buf, size_t count);
 void comm_allgather(Context* c, const double* send, double* recv, size_t count_per_rank);
 bool comm_active(const Context* c);      // more than one rank (or forced for testing)
+bool comm_rows(const Context* c);        // active communicator, row partition
+bool comm_cols(const Context* c);        // active communicator, column partition
+void comm_allreduce_min(Context* c, double* buf, size_t count);
 void comm_destroy(Context* c);
 
 }  // namespace ipxk

@@ -220,7 +220,8 @@ static void ensure_comm_buffers(Context* c) {
 struct Pub {
     Context* c;
     bool multi;
-    explicit Pub(Context* ctx) : c(ctx), multi(comm_active(ctx)) { if (multi) ensure_comm_buffers(ctx); }
+    // row partition only: with partitioned columns every rank computes the same scalars itself
+    explicit Pub(Context* ctx) : c(ctx), multi(comm_rows(ctx)) { if (multi) ensure_comm_buffers(ctx); }
     PartRef ref(int slot, int nparts) const {
         if (!multi) return PartRef{c->part(slot), nparts, 1};
         return PartRef{c->comm_gather.get() + slot, c->nranks, kNumPartialSlots};
@@ -243,13 +244,27 @@ PartRef publish_scalar(Context* c, int slot, int count, int op) {
     return pub.ref(slot, count);
 }
 
+// finalize this rank's partials of `slot` and reduce the scalar over the ranks (op: 0 sum, 1 max, 2 min)
+PartRef allreduce_scalar(Context* c, int slot, int count, int op) {
+    ensure_comm_buffers(c);
+    double* out = c->comm_scalars.get() + 62;
+    hipLaunchKernelGGL(finalize_scalar_kernel, dim3(1), dim3(kBlock), 0, c->stream,
+                       PartRef{c->part(slot), count, 1}, op, out);
+    if (op == 0) comm_allreduce_sum(c, out, 1);
+    else if (op == 1) comm_allreduce_max(c, out, 1);
+    else comm_allreduce_min(c, out, 1);
+    return PartRef{out, 1, 1};
+}
+
 double reduce_partials_host(Context* c, int slot, int count, bool is_max) {
     ensure_comm_buffers(c);
     double* out = c->comm_scalars.get() + 63;
     hipLaunchKernelGGL(finalize_scalar_kernel, dim3(1), dim3(kBlock), 0, c->stream,
                        PartRef{c->part(slot), count, 1}, is_max ? 1 : 0, out);
-    if (is_max) comm_allreduce_max(c, out, 1);
-    else comm_allreduce_sum(c, out, 1);
+    if (comm_rows(c)) {   // with partitioned columns the vectors, hence the scalar, are replicated
+        if (is_max) comm_allreduce_max(c, out, 1);
+        else comm_allreduce_sum(c, out, 1);
+    }
     double v = 0.0;
     IPXK_HIP(hipMemcpyAsync(&v, out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     IPXK_HIP(hipStreamSynchronize(c->stream));

@@ -69,6 +69,19 @@ __global__ void multiply_kernel(int len, const double* __restrict__ x, const dou
         out[i] = x[i] * y[i];
 }
 
+// rhs[i] = (-b[i] + rhs[i]) + wI[i]*aI[i]     (column partition: rhs holds the summed product)
+__global__ void kkt_rhs_finish_kernel(int m, const double* __restrict__ b, const double* __restrict__ wI,
+                                      const double* __restrict__ aI, double* __restrict__ rhs) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
+        rhs[i] = (-b[i] + rhs[i]) + wI[i] * aI[i];
+}
+
+// out[i] = b[i] - out[i]
+__global__ void subtract_from_kernel(int m, const double* __restrict__ b, double* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
+        out[i] = b[i] - out[i];
+}
+
 void kkt_diag_factorize_dev(Context* c, const double* xl, const double* xu, const double* zl,
                             const double* zu, double mu, bool precond_dense_cols, ipxint* errflag) {
     const int n = (int)c->n, m = (int)c->m;
@@ -83,9 +96,12 @@ void kkt_diag_factorize_dev(Context* c, const double* xl, const double* xu, cons
         hipLaunchKernelGGL(kkt_weights_kernel, dim3(g), dim3(kBlock), 0, s, n + m, xl, xu, zl, zu,
                            c->W_own.get(), c->part(kPartScratch));
         PartRef gmin{c->part(kPartScratch), g, 1};
-        if (comm_active(c)) {
+        if (comm_rows(c)) {
             // smallest nonzero g over all ranks (the slack part of G is partitioned)
             gmin = publish_scalar(c, kPartScratch, g, 2);
+        } else if (comm_cols(c)) {
+            // ... the structural part is partitioned
+            gmin = allreduce_scalar(c, kPartScratch, g, 2);
         }
         hipLaunchKernelGGL(kkt_regularize_kernel, dim3(g), dim3(kBlock), 0, s, n, m, mu, gmin,
                            c->W_own.get(), c->resscale.get());
@@ -115,8 +131,16 @@ CrResult kkt_diag_solve_dev(Context* c, const double* a, const double* b, double
 
     // :90-92  rhs = -b + A*(Ws.*as) + W_I.*a_I
     hipLaunchKernelGGL(multiply_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, s, n, W, a, c->k_tmp.get());
-    EpiKktRhs er{{}, b, W + n, a + n, c->v_rhs.get()};
-    launch_spmv(c->Arows, c->k_tmp.get(), er, nullptr, nullptr, s);   // rows are local: no exchange
+    if (comm_cols(c)) {
+        EpiScale ep{{}, nullptr, c->v_rhs.get()};
+        launch_spmv(c->Arows, c->k_tmp.get(), ep, nullptr, nullptr, s);
+        comm_allreduce_sum(c, c->v_rhs.get(), (size_t)m);
+        hipLaunchKernelGGL(kkt_rhs_finish_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, m, b, W + n, a + n,
+                           c->v_rhs.get());
+    } else {
+        EpiKktRhs er{{}, b, W + n, a + n, c->v_rhs.get()};
+        launch_spmv(c->Arows, c->k_tmp.get(), er, nullptr, nullptr, s);   // rows are local: no exchange
+    }
 
     // :95-105
     IPXK_HIP(hipMemsetAsync(y, 0, sizeof(double) * m, s));
@@ -124,7 +148,7 @@ CrResult kkt_diag_solve_dev(Context* c, const double* a, const double* b, double
                                  user, nullptr, 0, times);
 
     // :108-117
-    if (comm_active(c)) {
+    if (comm_rows(c)) {
         // A'y = sum over ranks of A_g' y_g
         EpiScale ea{{}, nullptr, c->tcols.get()};
         launch_spmv(c->Acols, y, ea, nullptr, nullptr, s);
@@ -134,8 +158,16 @@ CrResult kkt_diag_solve_dev(Context* c, const double* a, const double* b, double
         EpiRecoverX ex{{}, W, a, x};
         launch_spmv(c->Acols, y, ex, nullptr, nullptr, s);
     }
-    EpiResidualRows es{{}, b, x + n};
-    launch_spmv(c->Arows, x, es, nullptr, nullptr, s);
+    if (comm_cols(c)) {
+        // slack part: b - sum over ranks of A_g x_g
+        EpiScale ep{{}, nullptr, x + n};
+        launch_spmv(c->Arows, x, ep, nullptr, nullptr, s);
+        comm_allreduce_sum(c, x + n, (size_t)m);
+        hipLaunchKernelGGL(subtract_from_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, m, b, x + n);
+    } else {
+        EpiResidualRows es{{}, b, x + n};
+        launch_spmv(c->Arows, x, es, nullptr, nullptr, s);
+    }
     IPXK_HIP(hipGetLastError());
     return res;
 }

@@ -187,6 +187,12 @@ static void build_dense_structures(Context* c) {
     c->chol_info.resize(1);
 }
 
+// out[i] = w[i] + out[i]
+__global__ void add_vector_kernel(int len, const double* __restrict__ w, double* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x)
+        out[i] = w[i] + out[i];
+}
+
 void diag_factorize_dev(Context* c, const double* W, bool precond_dense_cols, ipxint* errflag) {
     const int64_t m = c->m, n = c->n;
     hipStream_t s = c->stream;
@@ -195,7 +201,7 @@ void diag_factorize_dev(Context* c, const double* W, bool precond_dense_cols, ip
     c->diagonal.resize(m);
     const bool smw = precond_dense_cols && c->num_dense > 0;
     if (smw && comm_active(c))
-        throw Error(IPXK_E_UNSUPPORTED, "dense-column (SMW) preconditioning is not available on a row-partitioned "
+        throw Error(IPXK_E_UNSUPPORTED, "dense-column (SMW) preconditioning is not available on a partitioned "
                                         "system: pass precond_dense_cols = 0");
     const double* Wcols = W;
     if (smw) {
@@ -211,8 +217,17 @@ void diag_factorize_dev(Context* c, const double* W, bool precond_dense_cols, ip
         Wcols = c->Wnodense.get();
     }
     // :28-46
-    EpiDiagonal ed{{}, W + n, c->diagonal.get()};
-    launch_spmv(c->Arows, Wcols, ed, nullptr, nullptr, s);
+    if (comm_cols(c)) {
+        // sum over ranks of the local columns' contributions, then the slack weights
+        EpiDiagonal ed{{}, nullptr, c->diagonal.get()};
+        launch_spmv(c->Arows, Wcols, ed, nullptr, nullptr, s);
+        comm_allreduce_sum(c, c->diagonal.get(), (size_t)m);
+        hipLaunchKernelGGL(add_vector_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, (int)m, W + n,
+                           c->diagonal.get());
+    } else {
+        EpiDiagonal ed{{}, W + n, c->diagonal.get()};
+        launch_spmv(c->Arows, Wcols, ed, nullptr, nullptr, s);
+    }
     c->kdense = 0;
     if (smw) {
         build_dense_structures(c);

@@ -357,12 +357,44 @@ void build_model(Context* c, const ipxint* Ap, const ipxint* Ai, const double* A
 // ---------------------------------------------------------------------------
 // W: device pointer to n+m weights.  Dot partials go to part(kPartCdot); *ndot
 // receives their count (nullptr: no dot product wanted).
+// column partition: lhs holds the cross-rank sum of A_g t_g; add the slack term, form the dot
+__global__ __launch_bounds__(kBlock) void normal_finish_kernel(int m, const double* __restrict__ wI,
+                                                               const double* __restrict__ y,
+                                                               double* __restrict__ lhs, double* dot_partials,
+                                                               const int* done) {
+    if (done && *done) return;
+    __shared__ double red[kBlock / 64 + 1];
+    double dotpart = 0.0;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < m; r += gridDim.x * kBlock) {
+        const double v = y[r] * wI[r] + lhs[r];
+        lhs[r] = v;
+        dotpart += y[r] * v;
+    }
+    if (dot_partials) {
+        const double d = block_reduce<SumOp>(dotpart, red);
+        if (threadIdx.x == 0) dot_partials[blockIdx.x] = d;
+    }
+}
+
 void normal_apply_dev(Context* c, const double* W, const double* rhs, double* lhs, int* ndot,
                       const int* done) {
     const int64_t n = c->n;
+    if (comm_cols(c)) {
+        // this rank's columns: t_g = W_g .* (A_g' y) is local, lhs = sum over ranks of A_g t_g
+        EpiScale e1{{}, W, c->tcols.get()};
+        launch_spmv(c->Acols, rhs, e1, nullptr, done, c->stream);
+        EpiScale e2{{}, nullptr, lhs};
+        launch_spmv(c->Arows, c->tcols.get(), e2, nullptr, done, c->stream);
+        comm_allreduce_sum(c, lhs, (size_t)c->m);
+        const int g = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (c->m + kBlock - 1) / kBlock));
+        hipLaunchKernelGGL(normal_finish_kernel, dim3(g), dim3(kBlock), 0, c->stream, (int)c->m, W + n, rhs, lhs,
+                           ndot ? c->part(kPartCdot) : nullptr, done);
+        if (ndot) *ndot = g;
+        return;
+    }
     EpiScale e1{{}, W, c->tcols.get()};
     launch_spmv(c->Acols, rhs, e1, nullptr, done, c->stream);
-    if (comm_active(c)) comm_allreduce_sum(c, c->tcols.get(), (size_t)n);
+    if (comm_rows(c)) comm_allreduce_sum(c, c->tcols.get(), (size_t)n);
     EpiNormalRows e2{{}, W + n, rhs, lhs};
     const int np = launch_spmv(c->Arows, c->tcols.get(), e2, ndot ? c->part(kPartCdot) : nullptr,
                                done, c->stream);

@@ -30,7 +30,8 @@ EXPORTS = [
     "ipxk_diag_get", "ipxk_pcr_solve", "ipxk_kkt_diag_factorize", "ipxk_kkt_diag_solve",
     "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_apply", "ipxk_forward_solve",
     "ipxk_backward_solve", "ipxk_solve_dense", "ipxk_split_levels", "ipxk_cr_solve",
-    "ipxk_kkt_basis_solve", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_time_normal_apply",
+    "ipxk_kkt_basis_solve", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns",
+    "ipxk_time_normal_apply",
     "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
     "ipxk_dev_download",
 ]
@@ -341,6 +342,8 @@ class KktContext:
         self._check(self.lib.ipxk_comm_unique_id(buf))
         return bytes(buf)
 
-    def comm_init(self, unique_id, rank, nranks):
+    def comm_init(self, unique_id, rank, nranks, columns=False):
+        """columns=False: the context holds this rank's rows; True: its structural columns."""
         buf = (C.c_char * 128).from_buffer_copy(unique_id)
-        self._check(self.lib.ipxk_comm_init(self.h, buf, C.c_int(rank), C.c_int(nranks)))
+        fn = self.lib.ipxk_comm_init_columns if columns else self.lib.ipxk_comm_init
+        self._check(fn(self.h, buf, C.c_int(rank), C.c_int(nranks)))

@@ -50,6 +50,40 @@ def row_slab(A, st, rank, world):
                 st["b"][r0:r1])
 
 
+# ---- alternative: column partition --------------------------------------------------------
+# Rank g owns the structural columns C_g (contiguous) of A for all m rows; every m-vector
+# (y, b, the slack parts of a, x, W and all CR work vectors) is replicated.  t_g = W_g.*(A_g'y)
+# is local; the one exchange per NormalMatrix apply is the all-reduce of the m partial sums
+# A_g t_g, after which all ranks hold identical vectors and compute identical scalars.
+ColSlab = namedtuple("ColSlab", "A c0 c1 xl xu zl zu a b")
+
+
+def col_slab_matrix(A, c0, c1):
+    """A[:, c0:c1] (columns are contiguous in CSC)."""
+    p0, p1 = int(A.p[c0]), int(A.p[c1])
+    return CscMatrix(A.nrow, c1 - c0, (A.p[c0:c1 + 1] - A.p[c0]).astype(i64), A.i[p0:p1], A.x[p0:p1])
+
+
+def col_local_vector(v, n, c0, c1):
+    """[this rank's structural slice ; all m slack entries] of an (n+m)-vector."""
+    if v is None:
+        return None
+    return np.concatenate([v[c0:c1], v[n:]])
+
+
+def col_slab(A, st, rank, world):
+    n = A.ncol
+    c0, c1 = row_range(n, rank, world)
+    loc = lambda key: col_local_vector(st[key], n, c0, c1)
+    return ColSlab(col_slab_matrix(A, c0, c1), c0, c1, loc("xl"), loc("xu"), loc("zl"), loc("zu"), loc("a"),
+                   st["b"])
+
+
+def assemble_cols(m, parts_x):
+    """x = [structural slices in rank order ; slack part (identical on every rank)]."""
+    return np.concatenate([p[:len(p) - m] for p in parts_x] + [parts_x[0][len(parts_x[0]) - m:]])
+
+
 def assemble(n, parts_x, parts_y):
     """Inverse of the partition for results: x = [x_s ; x_I slices], y = concatenated slices.
     parts_x[g] has length n + m_g (structural part identical on every rank)."""

@@ -364,14 +364,15 @@ def test_spmv_layouts_agree(kkt, po, oracle, monkeypatch):
 # the collective code path (RCCL), exercised with a one-rank communicator: IPXK_FORCE_COMM
 # routes a single rank through finalize + all-gather + all-reduce exactly as N ranks would run
 # --------------------------------------------------------------------------------------
-def test_partitioned_code_path_single_rank(kkt, po, oracle, monkeypatch):
+@pytest.mark.parametrize("columns", [False, True])
+def test_partitioned_code_path_single_rank(kkt, po, oracle, monkeypatch, columns):
     from ipx_amd import partition
     monkeypatch.setenv("IPXK_FORCE_COMM", "1")
     m, n = 2000, 4300
     A, st = diag_problem(m, n, seed=55)
-    slab = partition.row_slab(A, st, 0, 1)
+    slab = partition.col_slab(A, st, 0, 1) if columns else partition.row_slab(A, st, 0, 1)
     ctx = kkt.KktContext(slab.A)
-    ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    ctx.comm_init(ctx.comm_unique_id(), 0, 1, columns=columns)
     assert ctx.kkt_diag_factorize(slab.xl, slab.xu, slab.zl, slab.zu, st["mu"], precond_dense_cols=False) == 0
     tol = 0.3 * np.sqrt(st["mu"])
     x1, y1, it1, e1, _ = ctx.kkt_diag_solve(slab.a, slab.b, tol, 500)
