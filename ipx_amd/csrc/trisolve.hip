@@ -20,6 +20,7 @@
 // therefore uploads O(m + n) numbers plus the factors and never copies the matrix
 // (the reference copies all of N every time, splitted_normal_matrix.cc:42-55).
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
@@ -439,6 +440,8 @@ static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool 
                         const std::vector<double>* diagS) {
     S.dim = dim;
     S.running = running;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double ta0 = now();
     std::vector<int> level(dim, 0);
     int nlev = dim > 0 ? 1 : 0;
     for (int t = 0; t < dim; t++) {
@@ -468,6 +471,7 @@ static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool 
         posof[i] = next[level[i]];
         order[next[level[i]]++] = i;
     }
+    const double ta1 = now();
     const size_t nz = ri.size();
     std::vector<int> ptr(npos + 1, 0), idx(std::max<size_t>(nz, 1));
     std::vector<double> val(std::max<size_t>(nz, 1)), valS, dg(std::max(npos, 1), 1.0), dgS;
@@ -492,6 +496,7 @@ static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool 
     H.has_scaled = rxS != nullptr;
     H.order.swap(order); H.ptr.swap(ptr); H.idx.swap(idx); H.val.swap(val); H.valS.swap(valS);
     H.dg.swap(dg); H.dgS.swap(dgS); H.lptr = lptr;
+    const double ta2 = now();
     // launch plan.  Runs of >= kTailMinLevels narrow levels whose unknowns and entries fit the LDS of
     // one CU go to ONE single-workgroup launch (tail_lds_kernel); every other level is a launch of
     // its own, with one lane per unknown if all its rows have <= kShortRow entries and 8 lanes per
@@ -523,6 +528,9 @@ static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool 
         S.plan.push_back({l, l + 1, false, level_long[l] ? 8 : 1, 0, 0, 0});
         l++;
     }
+    if (getenv("IPXK_VERBOSE"))
+        fprintf(stderr, "ipxk: analyse_sweep(%s,%s): levels+order %.1f ms, entry copy %.1f ms, plan %.1f ms\n",
+                running ? "fwd" : "trans", ascending ? "asc" : "desc", (ta1 - ta0) * 1e3, (ta2 - ta1) * 1e3, (now() - ta2) * 1e3);
     if (getenv("IPXK_SWEEP_STATS")) {
         for (const Sweep::Launch& L : S.plan) {
             if (!L.tail && getenv("IPXK_SWEEP_STATS")[0] != '2') continue;   // "2": every launch
@@ -685,6 +693,9 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
         else if (status[j] == IPXK_BASIC_FREE) { fmask[k] = 1; S->num_free++; }   // :58-64
     }
 
+    const bool verbose = getenv("IPXK_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tp0 = now();
     SweepHost hUt, hLt, hLf, hUf;
     // --- U' sweep: unknown k gathers the rows above the diagonal of column k, ascending
     auto job_Ut = [&] {
@@ -760,11 +771,13 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
         t1.join(); t2.join(); t3.join();
         for (auto& e : err) if (e) std::rethrow_exception(e);
     }
+    const double tp1 = now();
     upload_sweep(S->Ut, hUt, s);
     upload_sweep(S->Lt, hLt, s);
     upload_sweep(S->Lf, hLf, s);
     upload_sweep(S->Uf, hUf, s);
 
+    const double tp2 = now();
     // --- N N' weights: colscale^2 on NONBASIC columns (splitted_normal_matrix.cc:42-55)
     {
         std::vector<double> W((size_t)n + m, 0.0);
@@ -795,6 +808,9 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
     if (const char* e = getenv("IPXK_TRISOLVE")) S->syncfree = std::string(e) == "syncfree";
     if (c->partials.size() == 0) c->partials.resize((size_t)kNumPartialSlots * kPartialStride);
     IPXK_HIP(hipStreamSynchronize(s));
+    if (verbose)
+        fprintf(stderr, "ipxk: split_prepare: level analysis %.1f ms, factor upload %.1f ms, weights/permutations %.1f ms\n",
+                (tp1 - tp0) * 1e3, (tp2 - tp1) * 1e3, (now() - tp2) * 1e3);
     c->split = S.release();
 }
 
