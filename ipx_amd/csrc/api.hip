@@ -14,6 +14,7 @@ void set_last_error(const std::string& msg) { g_last_error = msg; }
 
 Context::~Context() {
     if (split) destroy_split(split);
+    if (prepare_host) destroy_prepare_host(prepare_host);
     comm_destroy(this);
     if (h_state) (void)hipHostFree(h_state);
     if (h_cycle_done) (void)hipHostFree(h_cycle_done);

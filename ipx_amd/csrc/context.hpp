@@ -23,6 +23,7 @@ enum PartialSlot {
 };
 
 struct SplitOperator;   // trisolve.hip
+struct PrepareHost;     // trisolve.hip
 
 struct Context {
     int device = 0;
@@ -82,6 +83,7 @@ struct Context {
 
     // ---- basis path ----
     SplitOperator* split = nullptr;
+    PrepareHost* prepare_host = nullptr;   // host workspaces of split_prepare (trisolve.hip)
 
     // ---- multi-GPU ----
     ncclComm* comm = nullptr;
@@ -161,6 +163,7 @@ CrResult kkt_basis_solve_dev(Context* c, const double* a, const double* b, doubl
 void split_levels(const Context* c, ipxint levels[4]);
 void check_sweep_abort(Context* c);
 void destroy_split(SplitOperator*);
+void destroy_prepare_host(PrepareHost*);
 
 // ---- comm.hip ----
 void comm_allreduce_sum(Context* c, double* buf, size_t count);

@@ -426,13 +426,28 @@ __global__ __launch_bounds__(kBlock) void split_finish_kernel(int m, const doubl
 // topological order of the dependencies.
 // Host-side result of the level analysis of one sweep (pure CPU work: the four sweeps of a
 // Prepare are analysed on four host threads, then uploaded one after the other).
+constexpr int kAnalysisHelpers = 4;   // host threads per sweep for the row permutation
+
 struct SweepHost {
     std::vector<int> order, ptr, idx, lptr;
     std::vector<short> tslot;
     std::vector<unsigned char> chunk_long;
     std::vector<double> val, valS, dg, dgS;
     bool has_scaled = false;
+    // inputs of the analysis (rows in natural order) and its scratch; kept between Prepare calls so
+    // that only the first one pays for allocating and faulting in a few hundred MB of host memory
+    std::vector<int> rp, ri, level, next, posof;
+    std::vector<double> rx, rxS, dgn, dgnS;
 };
+
+// host workspaces of split_prepare_host, owned by the context
+struct PrepareHost {
+    SweepHost Ut, Lt, Lf, Uf;
+    std::vector<double> uscale;
+    std::vector<unsigned char> fmask;
+    std::vector<int> cnt;
+};
+void destroy_prepare_host(PrepareHost* p) { delete p; }
 
 static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool running, const std::vector<int>& rp,
                         const std::vector<int>& ri, const std::vector<double>& rx,
@@ -442,7 +457,8 @@ static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool 
     S.running = running;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double ta0 = now();
-    std::vector<int> level(dim, 0);
+    std::vector<int>& level = H.level;
+    level.assign(dim, 0);
     int nlev = dim > 0 ? 1 : 0;
     for (int t = 0; t < dim; t++) {
         const int i = ascending ? t : dim - 1 - t;
@@ -465,7 +481,10 @@ static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool 
     std::vector<int> lptr(nlev + 1, 0);
     for (int l = 0; l < nlev; l++) lptr[l + 1] = lptr[l] + (lcount[l] + align - 1) / align * align;
     const int npos = lptr[nlev];
-    std::vector<int> order(std::max(npos, 1), -1), next(lptr.begin(), lptr.end() - 1), posof(dim, 0);
+    std::vector<int>&order = H.order, &next = H.next, &posof = H.posof;
+    order.assign(std::max(npos, 1), -1);
+    next.assign(lptr.begin(), lptr.end() - 1);
+    posof.resize(dim);
     for (int t = 0; t < dim; t++) {
         const int i = ascending ? t : dim - 1 - t;
         posof[i] = next[level[i]];
@@ -473,29 +492,52 @@ static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool 
     }
     const double ta1 = now();
     const size_t nz = ri.size();
-    std::vector<int> ptr(npos + 1, 0), idx(std::max<size_t>(nz, 1));
-    std::vector<double> val(std::max<size_t>(nz, 1)), valS, dg(std::max(npos, 1), 1.0), dgS;
+    std::vector<int>&ptr = H.ptr, &idx = H.idx;
+    std::vector<double>&val = H.val, &valS = H.valS, &dg = H.dg, &dgS = H.dgS;
+    ptr.resize(npos + 1);
+    idx.resize(std::max<size_t>(nz, 1));
+    val.resize(std::max<size_t>(nz, 1));
+    dg.assign(std::max(npos, 1), 1.0);
     if (rxS) { valS.resize(std::max<size_t>(nz, 1)); dgS.assign(std::max(npos, 1), 1.0); }
-    int put = 0;
-    for (int k = 0; k < npos; k++) {
-        const int i = order[k];
-        ptr[k] = put;
-        if (i < 0) continue;
-        for (int p = rp[i]; p < rp[i + 1]; p++, put++) {
-            idx[put] = ri[p];
-            val[put] = rx[p];
-            if (rxS) valS[put] = (*rxS)[p];
+    else { valS.clear(); dgS.clear(); }
+    {
+        int put = 0;
+        for (int k = 0; k < npos; k++) {
+            const int i = order[k];
+            ptr[k] = put;
+            if (i >= 0) put += rp[i + 1] - rp[i];
         }
-        dg[k] = diag[i];
-        if (rxS) dgS[k] = (*diagS)[i];
+        ptr[npos] = put;
     }
-    ptr[npos] = put;
+    // rows into level order: independent per position (a random gather of rows, memory-latency bound
+    // on the host), split over a few threads
+    auto copy_rows = [&](int k0, int k1) {
+        for (int k = k0; k < k1; k++) {
+            const int i = order[k];
+            if (i < 0) continue;
+            int put = ptr[k];
+            for (int p = rp[i]; p < rp[i + 1]; p++, put++) {
+                idx[put] = ri[p];
+                val[put] = rx[p];
+                if (rxS) valS[put] = (*rxS)[p];
+            }
+            dg[k] = diag[i];
+            if (rxS) dgS[k] = (*diagS)[i];
+        }
+    };
+    {
+        const int nt = npos >= (1 << 16) ? kAnalysisHelpers : 1;
+        std::vector<std::thread> helpers;
+        for (int t = 1; t < nt; t++)
+            helpers.emplace_back(copy_rows, (int)((int64_t)npos * t / nt), (int)((int64_t)npos * (t + 1) / nt));
+        copy_rows(0, (int)((int64_t)npos / nt));
+        for (auto& h : helpers) h.join();
+    }
     S.npos = npos;
     S.level_ptr = lptr;
     S.has_scaled = rxS != nullptr;
     H.has_scaled = rxS != nullptr;
-    H.order.swap(order); H.ptr.swap(ptr); H.idx.swap(idx); H.val.swap(val); H.valS.swap(valS);
-    H.dg.swap(dg); H.dgS.swap(dgS); H.lptr = lptr;
+    H.lptr = lptr;
     const double ta2 = now();
     // launch plan.  Runs of >= kTailMinLevels narrow levels whose unknowns and entries fit the LDS of
     // one CU go to ONE single-workgroup launch (tail_lds_kernel); every other level is a launch of
@@ -683,9 +725,13 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
     std::unique_ptr<SplitOperator> S(new SplitOperator);
     S->m = m;
 
+    if (!c->prepare_host) c->prepare_host = new PrepareHost;
+    PrepareHost& P = *c->prepare_host;
     // column scaling of U (splitted_normal_matrix.cc:30-39): nothing for BASIC_FREE
-    std::vector<double> uscale(m, 1.0);
-    std::vector<unsigned char> fmask(m, 0);
+    std::vector<double>& uscale = P.uscale;
+    std::vector<unsigned char>& fmask = P.fmask;
+    uscale.assign(m, 1.0);
+    fmask.assign(m, 0);
     S->num_free = 0;
     for (int k = 0; k < m; k++) {
         const ipxint j = basis[colperm[k]];
@@ -696,71 +742,71 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
     const bool verbose = getenv("IPXK_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tp0 = now();
-    SweepHost hUt, hLt, hLf, hUf;
+    SweepHost &hUt = P.Ut, &hLt = P.Lt, &hLf = P.Lf, &hUf = P.Uf;
     // --- U' sweep: unknown k gathers the rows above the diagonal of column k, ascending
     auto job_Ut = [&] {
-        std::vector<int> rp(m + 1), ri(Up[m] - m);
-        std::vector<double> rx(ri.size()), rxS(ri.size()), dg(m), dgS(m);
+        SweepHost& H = hUt;
+        H.rp.resize(m + 1); H.ri.resize(Up[m] - m);
+        H.rx.resize(H.ri.size()); H.rxS.resize(H.ri.size()); H.dgn.resize(m); H.dgnS.resize(m);
         int put = 0;
         for (int k = 0; k < m; k++) {
-            rp[k] = put;
+            H.rp[k] = put;
             for (ipxint p = Up[k]; p < Up[k + 1] - 1; p++, put++) {
-                ri[put] = (int)Ui[p];
-                rx[put] = Ux[p];
-                rxS[put] = Ux[p] * uscale[k];
+                H.ri[put] = (int)Ui[p];
+                H.rx[put] = Ux[p];
+                H.rxS[put] = Ux[p] * uscale[k];
             }
-            dg[k] = Ux[Up[k + 1] - 1];
-            dgS[k] = dg[k] * uscale[k];
+            H.dgn[k] = Ux[Up[k + 1] - 1];
+            H.dgnS[k] = H.dgn[k] * uscale[k];
         }
-        rp[m] = put;
-        analyse_sweep(S->Ut, hUt, m, true, false, rp, ri, rx, dg, &rxS, &dgS);
+        H.rp[m] = put;
+        analyse_sweep(S->Ut, H, m, true, false, H.rp, H.ri, H.rx, H.dgn, &H.rxS, &H.dgnS);
     };
     // --- L' sweep: unknown k gathers column k of L (rows > k), descending, unit diagonal
     auto job_Lt = [&] {
-        std::vector<int> rp(m + 1), ri(Lp[m]);
-        std::vector<double> rx(Lp[m]), dg(m, 1.0);
-        for (int k = 0; k <= m; k++) rp[k] = (int)Lp[k];
-        for (ipxint p = 0; p < Lp[m]; p++) { ri[p] = (int)Li[p]; rx[p] = Lx[p]; }
-        analyse_sweep(S->Lt, hLt, m, false, false, rp, ri, rx, dg, nullptr, nullptr);
+        SweepHost& H = hLt;
+        H.rp.resize(m + 1); H.ri.resize(Lp[m]); H.rx.resize(Lp[m]); H.dgn.assign(m, 1.0);
+        for (int k = 0; k <= m; k++) H.rp[k] = (int)Lp[k];
+        for (ipxint p = 0; p < Lp[m]; p++) { H.ri[p] = (int)Li[p]; H.rx[p] = Lx[p]; }
+        analyse_sweep(S->Lt, H, m, false, false, H.rp, H.ri, H.rx, H.dgn, nullptr, nullptr);
     };
     // --- L sweep: unknown i subtracts L[i,j]*x_j for the columns j < i of row i, ascending j
     //     (the order in which the reference's column loop updates x[i], sparse_matrix.cc:283-297)
     auto job_Lf = [&] {
-        std::vector<int> rp(m + 1, 0), ri(Lp[m]);
-        std::vector<double> rx(Lp[m]), dg(m, 1.0);
-        for (ipxint p = 0; p < Lp[m]; p++) rp[Li[p] + 1]++;
-        for (int i = 0; i < m; i++) rp[i + 1] += rp[i];
-        std::vector<int> next(rp.begin(), rp.end() - 1);
+        SweepHost& H = hLf;
+        H.rp.assign(m + 1, 0); H.ri.resize(Lp[m]); H.rx.resize(Lp[m]); H.dgn.assign(m, 1.0);
+        for (ipxint p = 0; p < Lp[m]; p++) H.rp[Li[p] + 1]++;
+        for (int i = 0; i < m; i++) H.rp[i + 1] += H.rp[i];
+        H.next.assign(H.rp.begin(), H.rp.end() - 1);
         for (int j = 0; j < m; j++)
             for (ipxint p = Lp[j]; p < Lp[j + 1]; p++) {
-                const int put = next[Li[p]]++;
-                ri[put] = j;
-                rx[put] = Lx[p];
+                const int put = H.next[Li[p]]++;
+                H.ri[put] = j;
+                H.rx[put] = Lx[p];
             }
-        analyse_sweep(S->Lf, hLf, m, true, true, rp, ri, rx, dg, nullptr, nullptr);
+        analyse_sweep(S->Lf, H, m, true, true, H.rp, H.ri, H.rx, H.dgn, nullptr, nullptr);
     };
     // --- U sweep: unknown i subtracts U[i,j]*x_j for the columns j > i of row i, DESCENDING j
     //     (sparse_matrix.cc:267-281), then divides by U[i,i]
     auto job_Uf = [&] {
-        std::vector<int> cnt(m + 1, 0);
+        SweepHost& H = hUf;
+        H.rp.assign(m + 1, 0);
         for (int k = 0; k < m; k++)
-            for (ipxint p = Up[k]; p < Up[k + 1] - 1; p++) cnt[Ui[p] + 1]++;
-        std::vector<int> rp(cnt);
-        for (int i = 0; i < m; i++) rp[i + 1] += rp[i];
-        std::vector<int> ri(rp[m]);
-        std::vector<double> rx(rp[m]), rxS(rp[m]), dg(m), dgS(m);
-        std::vector<int> next(rp.begin(), rp.end() - 1);
+            for (ipxint p = Up[k]; p < Up[k + 1] - 1; p++) H.rp[Ui[p] + 1]++;
+        for (int i = 0; i < m; i++) H.rp[i + 1] += H.rp[i];
+        H.ri.resize(H.rp[m]); H.rx.resize(H.rp[m]); H.rxS.resize(H.rp[m]); H.dgn.resize(m); H.dgnS.resize(m);
+        H.next.assign(H.rp.begin(), H.rp.end() - 1);
         for (int k = m - 1; k >= 0; k--) {   // descending column order within each row
             for (ipxint p = Up[k]; p < Up[k + 1] - 1; p++) {
-                const int put = next[Ui[p]]++;
-                ri[put] = k;
-                rx[put] = Ux[p];
-                rxS[put] = Ux[p] * uscale[k];
+                const int put = H.next[Ui[p]]++;
+                H.ri[put] = k;
+                H.rx[put] = Ux[p];
+                H.rxS[put] = Ux[p] * uscale[k];
             }
-            dg[k] = Ux[Up[k + 1] - 1];
-            dgS[k] = dg[k] * uscale[k];
+            H.dgn[k] = Ux[Up[k + 1] - 1];
+            H.dgnS[k] = H.dgn[k] * uscale[k];
         }
-        analyse_sweep(S->Uf, hUf, m, false, true, rp, ri, rx, dg, &rxS, &dgS);
+        analyse_sweep(S->Uf, H, m, false, true, H.rp, H.ri, H.rx, H.dgn, &H.rxS, &H.dgnS);
     };
     {
         // the analyses are independent and sequential each: one host thread per sweep

@@ -11,5 +11,8 @@ st = synth.synthetic_ipm_state(m, n, 1.0, 3)
 colscale = np.sqrt(st['xl'] / st['zl'])
 colscale[B['status'] == 1] = np.inf
 ctx = kkt.KktContext(B['A'])
-ctx.split_prepare(B['L'], B['U'], B['rowperm'], B['colperm'], B['basis'], B['status'], colscale)
+for k in range(3):
+    t0 = time.time()
+    ctx.split_prepare(B['L'], B['U'], B['rowperm'], B['colperm'], B['basis'], B['status'], colscale)
+    print("split_prepare call %d: %.1f ms" % (k, (time.time() - t0) * 1e3), flush=True)
 print("levels", ctx.split_levels())
