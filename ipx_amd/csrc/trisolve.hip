@@ -29,59 +29,9 @@
 
 #include "context.hpp"
 #include "spmv_kernels.hpp"
+#include "trisolve.hpp"
 
 namespace ipxk {
-
-constexpr int kTailWidth = 1024;
-constexpr int kShortRow = 8;     // rows up to this many entries are solved by one lane
-
-struct SweepView {
-    const int* order;      // [dim] unknown index of level-ordered position k
-    const int* ptr;        // [dim+1]
-    const int* idx;        // dependency unknown index
-    const double* val;
-    const double* diag;    // [dim] diagonal (1.0 for unit triangular)
-};
-
-struct Sweep {
-    int dim = 0, nlevels = 0, npos = 0;   // npos: level-ordered positions incl. padding
-    bool running = false;          // forward ('n') sweeps subtract one product at a time
-    DevBuf<int> order, ptr, idx;
-    DevBuf<double> val, diag;      // as given
-    DevBuf<double> valS, diagS;    // column-scaled copy (U sweeps only)
-    bool has_scaled = false;
-    std::vector<int> level_ptr;    // host, [nlevels+1]
-    DevBuf<int> level_ptr_dev;
-    // tail: a run of narrow levels in one LDS-resident single-workgroup launch (tslot_off: offset of
-    // its dependency-slot table in `tslot`; e0/ne: its entries); otherwise one level with gl lanes
-    // per unknown (1, or 8 for long rows)
-    struct Launch { int l0, l1; bool tail; int gl; int tslot_off, e0, ne; };
-    DevBuf<short> tslot;
-    DevBuf<unsigned char> chunk_long;   // sync-free sweep: chunk holds rows longer than kShortRow
-    std::vector<Launch> plan;
-    SweepView view(bool scaled) const {
-        SweepView V;
-        V.order = order.get(); V.ptr = ptr.get(); V.idx = idx.get();
-        V.val = (scaled && has_scaled) ? valS.get() : val.get();
-        V.diag = (scaled && has_scaled) ? diagS.get() : diag.get();
-        return V;
-    }
-};
-
-struct SplitOperator {
-    int m = 0;
-    Sweep Ut, Lt, Lf, Uf;
-    DevBuf<double> Wsplit;                 // n+m: colscale^2 on NONBASIC columns, else 0
-    DevBuf<int> rowperm, rowperm_inv, colperm, basis, status;
-    DevBuf<double> colscale;
-    DevBuf<unsigned char> free_mask;       // m, pivot order
-    int num_free = 0;
-    DevBuf<double> w0, w1, w2, w3;         // m workspaces
-    DevBuf<double> wsf;                    // intermediate vector of a sync-free solve pair
-    DevBuf<int> ticket, abort_flag;
-    bool syncfree = false;                 // IPXK_TRISOLVE=syncfree selects the single-launch sweeps
-    DevBuf<double> tI;                     // m
-};
 
 void destroy_split(SplitOperator* s) { delete s; }
 
@@ -151,11 +101,6 @@ __global__ __launch_bounds__(kBlock) void level_kernel(SweepView S, int k0, int 
 // two or three L2 round trips.  The run's x values go back to global memory once, at the end.
 // Sums are formed in the same storage order as in solve_unknown.  Levels of long and short rows
 // mix freely in one run.
-constexpr int kTailSlots = 4096;      // unknowns (level-ordered positions) per LDS tail launch
-constexpr int kTailEntries = 7168;    // entries per LDS tail launch
-constexpr int kTailLevelsLds = 512;   // levels per LDS tail launch
-constexpr int kTailMinLevels = 4;     // shorter runs are cheaper as one launch per level
-constexpr int kTailLevelWidth = 2048; // widest level (positions) that may join a run
 struct TailLds {                      // carve-up of the dynamic LDS block (150.0 KiB)
     static constexpr size_t pv = 0;                                   // double[kTailEntries]
     static constexpr size_t xt = pv + (size_t)kTailEntries * 8;       // double[kTailSlots]
@@ -280,7 +225,6 @@ __global__ __launch_bounds__(kTailWidth) void tail_lds_kernel(SweepView S, const
 // one wavefront never wait for each other.  Every spin is bounded; a timeout raises `abort`.
 // ---------------------------------------------------------------------------
 constexpr unsigned long long kSentinel = 0x7FF8DEAD5EEDBEEFull;   // a quiet NaN nobody computes
-constexpr int kChunkRows = 256;      // positions per ticket
 constexpr int kSpinLimit = 1 << 20;
 
 __global__ void fill_sentinel_kernel(int m, unsigned long long* __restrict__ x, int* ticket) {
@@ -539,36 +483,18 @@ static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool 
     H.has_scaled = rxS != nullptr;
     H.lptr = lptr;
     const double ta2 = now();
-    // launch plan.  Runs of >= kTailMinLevels narrow levels whose unknowns and entries fit the LDS of
-    // one CU go to ONE single-workgroup launch (tail_lds_kernel); every other level is a launch of
-    // its own, with one lane per unknown if all its rows have <= kShortRow entries and 8 lanes per
-    // unknown otherwise (the long rows towards the end of a forward sweep).
-    S.plan.clear();
-    H.tslot.clear();
-    auto fits = [&](int a, int b) {
-        return b - a <= kTailLevelsLds && lptr[b] - lptr[a] <= kTailSlots &&
-               H.ptr[lptr[b]] - H.ptr[lptr[a]] <= kTailEntries;
-    };
-    auto narrow = [&](int lv) { return lptr[lv + 1] - lptr[lv] <= kTailLevelWidth; };
-    int l = 0;
-    while (l < nlev) {
-        if (narrow(l) && fits(l, l + 1)) {
-            int b = l + 1;
-            while (b < nlev && narrow(b) && fits(l, b + 1)) b++;
-            if (b - l >= kTailMinLevels) {
-                const int k0 = lptr[l], k1 = lptr[b];
-                const int off = (int)H.tslot.size();
-                for (int e = H.ptr[k0]; e < H.ptr[k1]; e++) {
-                    const int pj = posof[H.idx[e]];
-                    H.tslot.push_back(pj >= k0 && pj < k1 ? (short)(pj - k0) : (short)-1);
-                }
-                S.plan.push_back({l, b, true, 1, off, H.ptr[k0], H.ptr[k1] - H.ptr[k0]});
-                l = b;
-                continue;
-            }
+    // launch plan (plan_sweep) and the dependency-slot tables of its tail runs
+    std::vector<int> lev_entry(nlev + 1);
+    for (int lv = 0; lv <= nlev; lv++) lev_entry[lv] = H.ptr[lptr[lv]];
+    const int ntslot = plan_sweep(S, lptr, level_long, lev_entry);
+    H.tslot.assign((size_t)std::max(ntslot, 1), (short)-1);
+    for (const Sweep::Launch& L : S.plan) {
+        if (!L.tail) continue;
+        const int k0 = lptr[L.l0], k1 = lptr[L.l1];
+        for (int e = 0; e < L.ne; e++) {
+            const int pj = posof[H.idx[L.e0 + e]];
+            H.tslot[(size_t)L.tslot_off + e] = pj >= k0 && pj < k1 ? (short)(pj - k0) : (short)-1;
         }
-        S.plan.push_back({l, l + 1, false, level_long[l] ? 8 : 1, 0, 0, 0});
-        l++;
     }
     if (getenv("IPXK_VERBOSE"))
         fprintf(stderr, "ipxk: analyse_sweep(%s,%s): levels+order %.1f ms, entry copy %.1f ms, plan %.1f ms\n",
@@ -585,11 +511,50 @@ static void analyse_sweep(Sweep& S, SweepHost& H, int dim, bool ascending, bool 
                     running ? "fwd" : "trans", ascending ? "asc" : "desc", L.tail ? "TAIL-LDS" : "level", L.l0, L.l1, L.gl, unk, ent, maxlen);
         }
     }
-    // sync-free sweep: per chunk of kChunkRows positions, does it hold a long row?
-    H.chunk_long.assign((npos + 255) / 256 + 1, 0);
+    H.chunk_long = sweep_chunk_flags(lptr, level_long);
+}
+
+// Launch plan.  Runs of >= kTailMinLevels narrow levels whose unknowns and entries fit the LDS of
+// one CU go to ONE single-workgroup launch (tail_lds_kernel); every other level is a launch of
+// its own, with one lane per unknown if all its rows have <= kShortRow entries and 8 lanes per
+// unknown otherwise (the long rows towards the end of a forward sweep).
+int plan_sweep(Sweep& S, const std::vector<int>& lptr, const std::vector<unsigned char>& level_long,
+               const std::vector<int>& lev_entry) {
+    const int nlev = (int)lptr.size() - 1;
+    S.plan.clear();
+    int ntslot = 0;
+    auto fits = [&](int a, int b) {
+        return b - a <= kTailLevelsLds && lptr[b] - lptr[a] <= kTailSlots &&
+               lev_entry[b] - lev_entry[a] <= kTailEntries;
+    };
+    auto narrow = [&](int lv) { return lptr[lv + 1] - lptr[lv] <= kTailLevelWidth; };
+    int l = 0;
+    while (l < nlev) {
+        if (narrow(l) && fits(l, l + 1)) {
+            int b = l + 1;
+            while (b < nlev && narrow(b) && fits(l, b + 1)) b++;
+            if (b - l >= kTailMinLevels) {
+                S.plan.push_back({l, b, true, 1, ntslot, lev_entry[l], lev_entry[b] - lev_entry[l]});
+                ntslot += lev_entry[b] - lev_entry[l];
+                l = b;
+                continue;
+            }
+        }
+        S.plan.push_back({l, l + 1, false, level_long[l] ? 8 : 1, 0, 0, 0});
+        l++;
+    }
+    return ntslot;
+}
+
+// sync-free sweep: per chunk of kChunkRows positions, does it hold a long row?
+std::vector<unsigned char> sweep_chunk_flags(const std::vector<int>& lptr, const std::vector<unsigned char>& level_long) {
+    const int nlev = (int)lptr.size() - 1;
+    const int npos = lptr[nlev];
+    std::vector<unsigned char> flags((npos + kChunkRows - 1) / kChunkRows + 1, 0);
     for (int lv = 0; lv < nlev; lv++)
-        if (level_long[lv])
-            for (int c = lptr[lv] / 256; c <= (lptr[lv + 1] - 1) / 256; c++) H.chunk_long[c] = 1;
+        if (level_long[lv] && lptr[lv + 1] > lptr[lv])
+            for (int c = lptr[lv] / kChunkRows; c <= (lptr[lv + 1] - 1) / kChunkRows; c++) flags[c] = 1;
+    return flags;
 }
 
 static void upload_sweep(Sweep& S, const SweepHost& H, hipStream_t s) {
@@ -808,7 +773,14 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
         }
         analyse_sweep(S->Uf, H, m, false, true, H.rp, H.ri, H.rx, H.dgn, &H.rxS, &H.dgnS);
     };
-    {
+    // IPXK_PREPARE=host keeps the analysis on host threads (the form the device version is checked
+    // against); default: on the device (prepare_device.hip)
+    const bool on_device = !(getenv("IPXK_PREPARE") && std::string(getenv("IPXK_PREPARE")) == "host");
+    double tp1 = tp0;
+    if (on_device) {
+        analyse_sweeps_device(c, S.get(), Lp, Li, Lx, Up, Ui, Ux, uscale);
+        tp1 = now();
+    } else {
         // the analyses are independent and sequential each: one host thread per sweep
         std::exception_ptr err[3];
         auto guard = [&](int i, auto job) { return std::thread([&, i, job] { try { job(); } catch (...) { err[i] = std::current_exception(); } }); };
@@ -816,13 +788,12 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
         job_Ut();
         t1.join(); t2.join(); t3.join();
         for (auto& e : err) if (e) std::rethrow_exception(e);
+        tp1 = now();
+        upload_sweep(S->Ut, hUt, s);
+        upload_sweep(S->Lt, hLt, s);
+        upload_sweep(S->Lf, hLf, s);
+        upload_sweep(S->Uf, hUf, s);
     }
-    const double tp1 = now();
-    upload_sweep(S->Ut, hUt, s);
-    upload_sweep(S->Lt, hLt, s);
-    upload_sweep(S->Lf, hLf, s);
-    upload_sweep(S->Uf, hUf, s);
-
     const double tp2 = now();
     // --- N N' weights: colscale^2 on NONBASIC columns (splitted_normal_matrix.cc:42-55)
     {
@@ -855,7 +826,8 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
     if (c->partials.size() == 0) c->partials.resize((size_t)kNumPartialSlots * kPartialStride);
     IPXK_HIP(hipStreamSynchronize(s));
     if (verbose)
-        fprintf(stderr, "ipxk: split_prepare: level analysis %.1f ms, factor upload %.1f ms, weights/permutations %.1f ms\n",
+        fprintf(stderr, "ipxk: split_prepare [%s]: level analysis %.1f ms, upload of analysed factors %.1f ms, "
+                        "weights/permutations %.1f ms\n", on_device ? "device" : "host",
                 (tp1 - tp0) * 1e3, (tp2 - tp1) * 1e3, (now() - tp2) * 1e3);
     c->split = S.release();
 }

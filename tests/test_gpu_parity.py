@@ -207,10 +207,12 @@ def test_pcr_trajectory_vs_oracle(kkt, po, oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode", ["levels", "syncfree"])
+@pytest.mark.parametrize("mode", ["levels", "syncfree", "levels-hostanalysis"])
 @pytest.mark.parametrize("m,n,num_free,num_fixed", [(150, 320, 0, 0), (2500, 5200, 6, 9)])
 def test_basis_path_vs_oracle(kkt, po, oracle, monkeypatch, mode, m, n, num_free, num_fixed):
-    monkeypatch.setenv("IPXK_TRISOLVE", mode)     # one launch per level / single-launch sync-free sweeps
+    # one launch per level / single-launch sync-free sweeps; level analysis on the device (default) or host
+    monkeypatch.setenv("IPXK_TRISOLVE", mode.split("-")[0])
+    monkeypatch.setenv("IPXK_PREPARE", "host" if mode.endswith("hostanalysis") else "device")
     B, st, colscale = basis_problem(m, n, seed=41, num_free=num_free, num_fixed=num_fixed)
     A, L, U = B["A"], B["L"], B["U"]
     AI = A.with_identity()
@@ -420,7 +422,7 @@ def test_dense_column_stress_full_size(kkt):
     ctx.close()
 
 
-def test_basis_path_full_size_properties(kkt):
+def test_basis_path_full_size_properties(kkt, monkeypatch):
     """BASELINE config 3: m=1M, n=2M, basis-preconditioned CR on planted LU factors.  The oracle
     would need minutes here: check the KKT system the result must satisfy
     (src/kkt_solver_basis.cc:69-74, src/kkt_solver.h:21-27) and the triangular solves by residual."""
@@ -449,4 +451,11 @@ def test_basis_path_full_size_properties(kkt):
     nb = B["status"] == -1
     assert np.abs(res[nb]).max() < 1e-9 * (1 + np.abs(st["a"]).max() + np.abs(g).max())   # exact on nonbasic
     assert np.abs(res[~nb] * colscale[~nb]).max() <= tol * (1 + 1e-6)                      # tol on basic
+    # the device-side level analysis (default) builds exactly what the host-side analysis builds
+    xN, xT = ctx.solve_dense(r, "N"), ctx.solve_dense(r, "T")
+    lv = ctx.split_levels()
+    monkeypatch.setenv("IPXK_PREPARE", "host")
+    ctx.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
+    assert ctx.split_levels() == lv
+    assert np.array_equal(ctx.solve_dense(r, "N"), xN) and np.array_equal(ctx.solve_dense(r, "T"), xT)
     ctx.close()
