@@ -171,13 +171,14 @@ struct GatherView {                // passed to kernels by value
 // partial sum per row; a second streaming kernel adds the slices' partials in slice order and
 // applies the epilogue.  Within a slice a row is summed in storage order, so results differ from
 // the phased layout only by the association across slices (~1 ulp).
-constexpr int kSlicedRows = 1024;      // rows per tile (4 per thread)
-constexpr int kSlicedMaxTile = 6144;   // entries per tile that fit the LDS staging buffer
+constexpr int kSlicedRows = 1024;      // rows per tile: 4 per thread, or 2 / 1 when tiles would not fit
+constexpr int kSlicedMaxTile = 7680;   // entries per tile that fit the LDS staging buffer (62 KB)
 
 struct SlicedView {
     int nrows, nrows_pad, nslices, nrb;
+    int R;                             // rows per tile (kBlock * 1, 2 or 4)
     const unsigned* tile_ptr;          // [nrb*nslices + 1] first entry of each tile
-    const unsigned char* cnt;          // [nrb*nslices][kSlicedRows] entries per row of the tile
+    const unsigned char* cnt;          // [nrb*nslices][R] entries per row of the tile
     const int* idx;
     const double* val;
     double* partial;                   // [nslices][nrows_pad]
@@ -185,7 +186,7 @@ struct SlicedView {
 
 struct SlicedMatrix {
     bool built = false;
-    int nslices = 0, nrb = 0, nrows_pad = 0, max_tile = 0;
+    int nslices = 0, nrb = 0, nrows_pad = 0, max_tile = 0, R = kSlicedRows;
     DevBuf<unsigned> tile_ptr;
     DevBuf<unsigned char> cnt;
     DevBuf<int> idx;

@@ -216,43 +216,62 @@ void GatherMatrix::build_sliced(const ipxint* hptr, const ipxint* hidx, const do
     int ns = 2;
     while (ns < 8 && x_bytes > (int64_t)ns * (int64_t(2) << 20)) ns *= 2;
     const int64_t slice = ((ncols + ns - 1) / ns + 15) / 16 * 16;
-    const int nrb = (nrows + kSlicedRows - 1) / kSlicedRows;
-    const int64_t ntiles = (int64_t)nrb * ns;
-    std::vector<unsigned> tptr((size_t)ntiles + 1, 0);
-    std::vector<unsigned char> cnt((size_t)ntiles * kSlicedRows, 0);
+    // rows per tile: as many as fit the LDS staging buffer (a matrix whose rows concentrate in one
+    // slice, e.g. a banded one, needs smaller tiles than a uniformly random one)
+    int R = kSlicedRows, nrb = 0, max_tile = 0;
+    int64_t ntiles = 0;
+    std::vector<unsigned> tptr;
+    std::vector<unsigned char> cnt;
+    const bool verbose = getenv("IPXK_VERBOSE") != nullptr;
+    for (;; R /= 2) {
+        if (R < kBlock) {
+            if (verbose) fprintf(stderr, "ipxk: sliced layout not used for %d x %d: a tile of %d rows holds %d entries\n", nrows, ncols, 2 * R, max_tile);
+            return;
+        }
+        nrb = (nrows + R - 1) / R;
+        ntiles = (int64_t)nrb * ns;
+        // pass 1: entries per (tile, row)
+        tptr.assign((size_t)ntiles + 1, 0);
+        cnt.assign((size_t)ntiles * R, 0);
+        for (int r = 0; r < nrows; r++) {
+            const int64_t tile0 = (int64_t)(r / R) * ns;
+            const int rr = r % R;
+            for (ipxint p = hptr[r]; p < hptr[r + 1]; p++) {
+                const int64_t tile = tile0 + hidx[p] / slice;
+                unsigned char& cc = cnt[(size_t)tile * R + rr];
+                if (cc == 255) {                                // count does not fit a byte
+                    if (verbose) fprintf(stderr, "ipxk: sliced layout not used for %d x %d: row %d has > 255 entries in one slice\n", nrows, ncols, r);
+                    return;
+                }
+                cc++;
+                tptr[tile + 1]++;
+            }
+        }
+        max_tile = 0;
+        for (int64_t t = 0; t < ntiles; t++) {
+            max_tile = std::max(max_tile, (int)tptr[t + 1]);
+            tptr[t + 1] += tptr[t];
+        }
+        if ((int64_t)tptr[ntiles] != nnz) return;
+        if (max_tile <= kSlicedMaxTile) break;
+    }
+    // pass 2: fill, rows in order, a row's entries in storage order (no assumption that the indices
+    // of a row are sorted)
     std::vector<int> ti((size_t)nnz);
     std::vector<double> tv((size_t)nnz);
-    std::vector<ipxint> cur(hptr, hptr + nrows);
-    unsigned put = 0;
-    int max_tile = 0;
-    for (int rb = 0; rb < nrb; rb++) {
-        const int r0 = rb * kSlicedRows, r1 = std::min(nrows, r0 + kSlicedRows);
-        for (int sl = 0; sl < ns; sl++) {
-            const int64_t tile = (int64_t)rb * ns + sl;
-            const ipxint col_end = (ipxint)std::min<int64_t>(ncols, (sl + 1) * slice);
-            tptr[tile] = put;
-            for (int r = r0; r < r1; r++) {
-                ipxint p = cur[r];
-                const ipxint pe = hptr[r + 1];
-                const unsigned first = put;
-                while (p < pe && hidx[p] < col_end) {
-                    ti[put] = (int)hidx[p];
-                    tv[put] = hval[p];
-                    put++; p++;
-                }
-                if (put - first > 255) return;              // count does not fit a byte
-                if (sl == ns - 1 && p != pe) return;        // columns not ascending within the row
-                cnt[(size_t)tile * kSlicedRows + (r - r0)] = (unsigned char)(put - first);
-                cur[r] = p;
-            }
-            max_tile = std::max(max_tile, (int)(put - tptr[tile]));
+    std::vector<unsigned> cursor(tptr.begin(), tptr.end() - 1);
+    for (int r = 0; r < nrows; r++) {
+        const int64_t tile0 = (int64_t)(r / R) * ns;
+        for (ipxint p = hptr[r]; p < hptr[r + 1]; p++) {
+            const unsigned put = cursor[tile0 + hidx[p] / slice]++;
+            ti[put] = (int)hidx[p];
+            tv[put] = hval[p];
         }
     }
-    tptr[ntiles] = put;
-    if ((int64_t)put != nnz || max_tile > kSlicedMaxTile) return;
+    sliced.R = R;
     sliced.nslices = ns;
     sliced.nrb = nrb;
-    sliced.nrows_pad = nrb * kSlicedRows;
+    sliced.nrows_pad = nrb * R;
     sliced.max_tile = max_tile;
     sliced.tile_ptr.upload(tptr, s);
     sliced.cnt.upload(cnt, s);
@@ -265,7 +284,7 @@ void GatherMatrix::build_sliced(const ipxint* hptr, const ipxint* hidx, const do
 
 SlicedView GatherMatrix::sliced_view() const {
     SlicedView V;
-    V.nrows = nrows; V.nrows_pad = sliced.nrows_pad; V.nslices = sliced.nslices; V.nrb = sliced.nrb;
+    V.nrows = nrows; V.nrows_pad = sliced.nrows_pad; V.nslices = sliced.nslices; V.nrb = sliced.nrb; V.R = sliced.R;
     V.tile_ptr = sliced.tile_ptr.get(); V.cnt = sliced.cnt.get();
     V.idx = sliced.idx.get(); V.val = sliced.val.get(); V.partial = sliced.partial.get();
     return V;

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void spmv_long_fixup_kernel(GatherView M, E
 // One tile per workgroup: the tile's entries are streamed with coalesced loads (8 in flight per
 // thread, gathers issued together), their products are staged in LDS, then every thread adds up
 // the products of its 4 consecutive rows in storage order and writes the 4 partial sums (32 B).
-template <class Epi>
+template <class Epi, int RPT>
 __global__ __launch_bounds__(kBlock) void spmv_sliced_tile_kernel(SlicedView M, const double* __restrict__ x,
                                                                   const int* done) {
     if (done && *done) return;
@@ -336,9 +336,13 @@ __global__ __launch_bounds__(kBlock) void spmv_sliced_tile_kernel(SlicedView M, 
     const int s = tile % M.nslices, rb = tile / M.nslices;
     const unsigned e0 = M.tile_ptr[tile];
     const int ne = (int)(M.tile_ptr[tile + 1] - e0);
-    constexpr int RPT = kSlicedRows / kBlock;   // 4
-    static_assert(RPT == 4, "one 32-bit load holds a thread's row counts");
-    const unsigned c4 = reinterpret_cast<const unsigned*>(M.cnt + (size_t)tile * kSlicedRows)[tid];
+    // rows per thread: a thread's row counts are one 8-, 16- or 32-bit load
+    static_assert(RPT == 1 || RPT == 2 || RPT == 4, "rows per thread");
+    constexpr int R = kBlock * RPT;
+    const unsigned char* cbase = M.cnt + (size_t)tile * R;
+    const unsigned c4 = RPT == 4 ? reinterpret_cast<const unsigned*>(cbase)[tid]
+                      : RPT == 2 ? (unsigned)reinterpret_cast<const unsigned short*>(cbase)[tid]
+                                 : (unsigned)cbase[tid];
     constexpr int U = 8;
     for (int base = 0; base < ne; base += kBlock * U) {
         int ci[U];
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void spmv_sliced_tile_kernel(SlicedView M, 
         }
     }
     // exclusive scan of the per-thread entry counts -> first staged product of my rows
-    const int mine = (int)((c4 & 255u) + ((c4 >> 8) & 255u) + ((c4 >> 16) & 255u) + (c4 >> 24));
+    const int mine = (int)((c4 & 255u) + ((c4 >> 8) & 255u) + ((c4 >> 16) & 255u) + (c4 >> 24));   // unused bytes are 0
     int incl = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -380,9 +384,13 @@ __global__ __launch_bounds__(kBlock) void spmv_sliced_tile_kernel(SlicedView M, 
         p += cq;
         out[q] = acc;
     }
-    double* dst = M.partial + (size_t)s * M.nrows_pad + (size_t)rb * kSlicedRows + (size_t)tid * RPT;
-    reinterpret_cast<double2*>(dst)[0] = make_double2(out[0], out[1]);
-    reinterpret_cast<double2*>(dst)[1] = make_double2(out[2], out[3]);
+    double* dst = M.partial + (size_t)s * M.nrows_pad + (size_t)rb * R + (size_t)tid * RPT;
+    if (RPT == 1) {
+        dst[0] = out[0];
+    } else {
+#pragma unroll
+        for (int q = 0; q < RPT; q += 2) reinterpret_cast<double2*>(dst)[q / 2] = make_double2(out[q], out[q + 1 < RPT ? q + 1 : q]);
+    }
 }
 
 // out[r] = finish(init(r) (+|-) partial[0][r] (+|-) partial[1][r] ...), slices in ascending order
@@ -411,7 +419,10 @@ inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi
                                const int* done, hipStream_t s) {
     const SlicedView V = M.sliced_view();
     const size_t lds = (size_t)(M.sliced.max_tile + M.sliced.max_tile / 32 + 1) * sizeof(double);
-    hipLaunchKernelGGL(spmv_sliced_tile_kernel<Epi>, dim3(V.nrb * V.nslices), dim3(kBlock), lds, s, V, x, done);
+    const dim3 grid(V.nrb * V.nslices), block(kBlock);
+    if (V.R == kBlock * 4) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 4>), grid, block, lds, s, V, x, done);
+    else if (V.R == kBlock * 2) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 2>), grid, block, lds, s, V, x, done);
+    else hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 1>), grid, block, lds, s, V, x, done);
     hipLaunchKernelGGL(spmv_sliced_combine_kernel<Epi>, dim3(M.combine_grid()), dim3(kBlock), 0, s, V, epi,
                        dot_partials, done);
 }
