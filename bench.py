@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--maxiter", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--basis", action="store_true", help="also time the basis-preconditioned solve (extra field)")
+    ap.add_argument("--newton", action="store_true",
+                    help="also time IPM::SolveNewtonSystem around the diag solve, all vectors resident (extra field)")
     ap.add_argument("--no-column-partition", action="store_true",
                     help="N > 1: skip the extra measurement of the column partition (config.column_partition)")
     ap.add_argument("--no-banded", action="store_true", help="skip the banded-matrix probe of the SpMV (extra field of roofline)")
@@ -209,6 +211,8 @@ def main():
         out["roofline"]["banded_matrix_probe"] = bench_banded(kkt, synth, m, n)
     if rank == 0 and world == 1 and args.basis:
         out["config"]["basis_path"] = bench_basis(kkt, synth, m, n, args)
+    if rank == 0 and world == 1 and args.newton:
+        out["config"]["newton_step"] = bench_newton(kkt, synth, ctx, m, n, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ctx.set_pointer_mode(False)
         xg, yg = x.download(), y.download()
@@ -270,6 +274,30 @@ def bench_column_partition(kkt, dist, torch, A, st, tol, args, rank, world, loca
     return {"solves_per_sec": args.steps / dt, "ms_per_solve": dt / args.steps * 1e3, "cr_iterations": it,
             "errflag": errflag, "us_per_apply": apply_ms * 1e3,
             "exchange": "one all-reduce of m = %d doubles per NormalMatrix apply, no scalar exchange" % m}
+
+
+def bench_newton(kkt, synth, ctx, m, n, args):
+    """IPM::SolveNewtonSystem (src/ipm.cc:532-645) on the device around the same KKTSolverDiag: right-hand side
+    from residuals, solve, recovery of the six step components; all 16 vectors resident."""
+    st = synth.synthetic_newton_state(m, n, 12345)
+    ctx.set_pointer_mode(False)
+    assert ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"]) == 0
+    ctx.set_pointer_mode(True)
+    tol = 0.3 * np.sqrt(st["mu"])
+    N = n + m
+    keys = ("rb", "rc", "rl", "ru", "sl", "su", "xl", "xu", "zl", "zu")
+    dev_in = [ctx.vector(m if k == "rb" else N, st[k]) for k in keys]
+    state = ctx.state_vector(st["state"])
+    dev_out = [ctx.vector(m if k == 3 else N) for k in range(6)]
+    it, err, tm = ctx.newton_solve_resident(False, dev_in, state, tol, args.maxiter, dev_out)
+    K = 5
+    t0 = time.perf_counter()
+    for _ in range(K):
+        it, err, tm = ctx.newton_solve_resident(False, dev_in, state, tol, args.maxiter, dev_out)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    return {"steps_per_sec": 1.0 / dt, "ms_per_step": dt * 1e3, "cr_iterations": it, "errflag": err,
+            "ms_outside_cr_loop": dt * 1e3 - tm.cr * 1e3}
 
 
 def bench_banded(kkt, synth, m, n):

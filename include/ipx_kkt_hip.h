@@ -51,6 +51,14 @@ typedef struct ipxk_context ipxk_context;
 #define IPXK_BASIC 0
 #define IPXK_BASIC_FREE 1
 
+/* variable states, one byte per variable: Iterate::StateOf with the barrier state
+ * split by Iterate::has_barrier_lb / has_barrier_ub (src/iterate.h:99-108,295-318) */
+#define IPXK_STATE_FIXED 0
+#define IPXK_STATE_FREE 1          /* FREE and the IMPLIED_* states */
+#define IPXK_STATE_BARRIER_LB 2
+#define IPXK_STATE_BARRIER_UB 3
+#define IPXK_STATE_BARRIER_BOXED 4
+
 /* Wall-clock seconds accumulated by the last solve, measured with HIP events on
  * the context's stream; they feed ipx_info::time_cr1* / time_cr2*
  * (include/ipx_info.h:66-75, src/kkt_solver_diag.cc:100-105,
@@ -181,6 +189,24 @@ int ipxk_kkt_basis_solve(ipxk_context* ctx, const double* a, const double* b,
                          ipxint* iter, ipxint* errflag,
                          ipxk_interrupt_fn interrupt, void* interrupt_user,
                          ipxk_times* times);
+
+/* ---- IPM::SolveNewtonSystem (src/ipm.cc:532-645), SURVEY.md section 8f row 3 ----
+ * Builds the KKT right-hand side from the residuals rb[m], rc/rl/ru[n+m] (any of
+ * these four may be NULL = zero) and the complementarity targets sl/su[n+m],
+ * solves with the factorized diag solver (use_basis = 0) or the prepared basis
+ * solver (use_basis = 1) to tol, and recovers the Newton step dx, dxl, dxu, dzl,
+ * dzu [n+m], dy [m].  xl, xu, zl, zu are the iterate's vectors, state[n+m] the
+ * IPXK_STATE_* codes.  With device pointers nothing crosses PCIe.  On errflag != 0
+ * the step vectors are undefined (ipm.cc:571-573 returns). */
+int ipxk_newton_solve(ipxk_context* ctx, int use_basis, const double* rb,
+                      const double* rc, const double* rl, const double* ru,
+                      const double* sl, const double* su, const double* xl,
+                      const double* xu, const double* zl, const double* zu,
+                      const unsigned char* state, double tol, ipxint maxiter,
+                      double* dx, double* dxl, double* dxu, double* dy,
+                      double* dzl, double* dzu, ipxint* iter, ipxint* errflag,
+                      ipxk_interrupt_fn interrupt, void* interrupt_user,
+                      ipxk_times* times);
 
 /* ---- multi-GPU: rows of AI partitioned over ranks, one RCCL all-reduce per
  *      NormalMatrix apply ---------------------------- */

@@ -460,6 +460,40 @@ int ipxk_kkt_diag_get(const ipxk_context* c, double* W, double* resscale) {
     });
 }
 
+// ---- IPM::SolveNewtonSystem -----------------------------------------------------------------
+int ipxk_newton_solve(ipxk_context* c, int use_basis, const double* rb, const double* rc, const double* rl,
+                      const double* ru, const double* sl, const double* su, const double* xl, const double* xu,
+                      const double* zl, const double* zu, const unsigned char* state, double tol, ipxint maxiter,
+                      double* dx, double* dxl, double* dxu, double* dy, double* dzl, double* dzu, ipxint* iter,
+                      ipxint* errflag, ipxk_interrupt_fn interrupt, void* interrupt_user, ipxk_times* times) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && sl && su && xl && xu && zl && zu && state && dx && dxl && dxu && dy && dzl && dzu &&
+                     iter && errflag, "NULL argument");
+        IPXK_REQUIRE(use_basis ? c->split != nullptr : c->kkt_diag_factorized, "KKT solver not factorized");
+        bind_device(c);
+        const size_t m = (size_t)c->m, N = (size_t)(c->n + c->m);
+        const double* in[10] = {rb, rc, rl, ru, sl, su, xl, xu, zl, zu};
+        const double* din[10];
+        for (int k = 0; k < 10; k++) din[k] = in[k] ? stage_in(c, in[k], k == 0 ? m : N, c->nw_in[k]) : nullptr;
+        const unsigned char* dstate = state;
+        if (c->pointer_mode == IPXK_POINTER_HOST) {
+            c->nw_state.upload(state, N, c->stream);
+            dstate = c->nw_state.get();
+        }
+        double* out[6] = {dx, dxl, dxu, dy, dzl, dzu};
+        double* dout[6];
+        for (int k = 0; k < 6; k++) dout[k] = stage_out(c, out[k], k == 3 ? m : N, c->nw_out[k]);
+        if (times) *times = ipxk_times{};
+        CrResult r = newton_solve_dev(c, use_basis != 0, din[0], din[1], din[2], din[3], din[4], din[5], din[6],
+                                      din[7], din[8], din[9], dstate, tol, maxiter, dout[0], dout[1], dout[2],
+                                      dout[3], dout[4], dout[5], interrupt, interrupt_user, times);
+        *iter = r.iter;
+        *errflag = r.errflag;
+        for (int k = 0; k < 6; k++) finish_out(c, out[k], dout[k], k == 3 ? m : N);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
 // ---- SplittedNormalMatrix / basis path -------------------------------------------------
 int ipxk_split_prepare(ipxk_context* c, const ipxint* Lp, const ipxint* Li, const double* Lx,
                        const ipxint* Up, const ipxint* Ui, const double* Ux, const ipxint* rowperm,

@@ -81,6 +81,11 @@ struct Context {
     DevBuf<double> k_tmp;               // n+m scratch
     bool kkt_diag_factorized = false;
 
+    // ---- IPM::SolveNewtonSystem (newton.hip) ----
+    DevBuf<double> nw_rhs1, nw_rhs2;    // n+m, m
+    DevBuf<double> nw_in[10], nw_out[6];   // staging for host vectors
+    DevBuf<unsigned char> nw_state;
+
     // ---- basis path ----
     SplitOperator* split = nullptr;
     PrepareHost* prepare_host = nullptr;   // host workspaces of split_prepare (trisolve.hip)
@@ -139,6 +144,13 @@ double reduce_partials_host(Context* c, int slot, int count, bool is_max);
 struct PartRef publish_scalar(Context* c, int slot, int count, int op);
 // finalize this rank's partials of `slot`, all-reduce the scalar; returns a one-element view
 struct PartRef allreduce_scalar(Context* c, int slot, int count, int op);
+
+// ---- newton.hip ----
+CrResult newton_solve_dev(Context* c, bool use_basis, const double* rb, const double* rc, const double* rl,
+                          const double* ru, const double* sl, const double* su, const double* xl, const double* xu,
+                          const double* zl, const double* zu, const unsigned char* state, double tol,
+                          ipxint maxiter, double* dx, double* dxl, double* dxu, double* dy, double* dzl,
+                          double* dzu, ipxk_interrupt_fn interrupt, void* user, ipxk_times* times);
 
 // ---- kkt_diag.hip ----
 void kkt_diag_factorize_dev(Context* c, const double* xl, const double* xu, const double* zl,

@@ -30,7 +30,7 @@ EXPORTS = [
     "ipxk_diag_get", "ipxk_pcr_solve", "ipxk_kkt_diag_factorize", "ipxk_kkt_diag_solve",
     "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_apply", "ipxk_forward_solve",
     "ipxk_backward_solve", "ipxk_solve_dense", "ipxk_split_levels", "ipxk_cr_solve",
-    "ipxk_kkt_basis_solve", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns",
+    "ipxk_kkt_basis_solve", "ipxk_newton_solve", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns",
     "ipxk_time_normal_apply",
     "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
     "ipxk_dev_download",
@@ -276,6 +276,44 @@ class KktContext:
                                                  C.byref(it), C.byref(err),
                                                  C.cast(None, INTERRUPT_FN), None, C.byref(times)))
         return int(it.value), int(err.value), times
+
+    # -- IPM::SolveNewtonSystem ------------------------------------------------------------
+    STATE_FIXED, STATE_FREE, STATE_BARRIER_LB, STATE_BARRIER_UB, STATE_BARRIER_BOXED = range(5)
+
+    def newton_solve(self, use_basis, rb, rc, rl, ru, sl, su, xl, xu, zl, zu, state, tol, maxiter=-1):
+        """Host vectors; rb, rc, rl, ru may be None (zero).  Returns a dict with the six step components."""
+        N = self.n + self.m
+        ins = [_F(v) for v in (rb, rc, rl, ru, sl, su, xl, xu, zl, zu)]
+        st = np.ascontiguousarray(state, dtype=np.uint8)
+        assert st.shape == (N,)
+        out = {k: np.zeros(self.m if k == "dy" else N, f64) for k in ("dx", "dxl", "dxu", "dy", "dzl", "dzu")}
+        it, err, times = c_i64(0), c_i64(0), Times()
+        self._check(self.lib.ipxk_newton_solve(
+            self.h, C.c_int(1 if use_basis else 0), *[_fp(v) for v in ins],
+            st.ctypes.data_as(C.POINTER(C.c_ubyte)), c_f64(tol), c_i64(maxiter),
+            _fp(out["dx"]), _fp(out["dxl"]), _fp(out["dxu"]), _fp(out["dy"]), _fp(out["dzl"]), _fp(out["dzu"]),
+            C.byref(it), C.byref(err), C.cast(None, INTERRUPT_FN), None, C.byref(times)))
+        out.update(iter=int(it.value), errflag=int(err.value), times=times)
+        return out
+
+    def newton_solve_resident(self, use_basis, dev_in, state_dev, tol, maxiter, dev_out):
+        """Device-resident call (pointer mode must be device).  dev_in: 10 DeviceVectors or None in the order
+        rb, rc, rl, ru, sl, su, xl, xu, zl, zu; state_dev: DeviceVector holding the state BYTES (see
+        state_vector); dev_out: dx, dxl, dxu, dy, dzl, dzu."""
+        it, err, times = c_i64(0), c_i64(0), Times()
+        self._check(self.lib.ipxk_newton_solve(
+            self.h, C.c_int(1 if use_basis else 0), *[(v.as_arg() if v is not None else None) for v in dev_in],
+            C.cast(state_dev.ptr, C.POINTER(C.c_ubyte)), c_f64(tol), c_i64(maxiter),
+            *[v.as_arg() for v in dev_out], C.byref(it), C.byref(err), C.cast(None, INTERRUPT_FN), None,
+            C.byref(times)))
+        return int(it.value), int(err.value), times
+
+    def state_vector(self, state):
+        """Uploads one state byte per variable into a device buffer (padded to whole doubles)."""
+        st = np.ascontiguousarray(state, dtype=np.uint8)
+        padded = np.zeros((st.size + 7) // 8 * 8, np.uint8)
+        padded[:st.size] = st
+        return DeviceVector(self, padded.size // 8, padded.view(f64))
 
     def kkt_diag_get(self):
         W, rs = np.zeros(self.n + self.m, f64), np.zeros(self.m, f64)

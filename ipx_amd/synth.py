@@ -184,3 +184,37 @@ def planted_lu_basis(A, offdiag=3, seed=12345, band=None, num_free=0, num_fixed=
     mk = lambda M: CscMatrix(M.shape[0], M.shape[1], M.indptr, M.indices, M.data)
     return dict(A=mk(Anew), L=mk(L0), U=mk(U0), rowperm=rowperm, colperm=colperm,
                 basis=basis, status=status)
+
+
+def synthetic_newton_state(m, n, seed, num_free=0, num_fixed=0, num_ub=0, num_boxed=0):
+    """Iterate vectors, variable states and residuals for IPM::SolveNewtonSystem (src/ipm.cc:532-645).
+    States follow Iterate's invariants (src/iterate.h:220-262): barrier-lb xu = inf, zu = 0; barrier-ub
+    xl = inf, zl = 0; boxed all finite; free xl = xu = inf, zl = zu = 0; fixed all zero.
+    Codes: 0 fixed, 1 free, 2 lb, 3 ub, 4 boxed.  Slack variables are barrier-lb."""
+    rng = np.random.default_rng(seed)
+    N = n + m
+    state = np.full(N, 2, dtype=np.uint8)
+    special = rng.permutation(n)[:num_free + num_fixed + num_ub + num_boxed]
+    state[special[:num_free]] = 1
+    state[special[num_free:num_free + num_fixed]] = 0
+    state[special[num_free + num_fixed:num_free + num_fixed + num_ub]] = 3
+    state[special[num_free + num_fixed + num_ub:]] = 4
+    pos = lambda: 10.0 ** rng.uniform(-1, 1, N)
+    xl, xu, zl, zu = pos(), pos(), pos(), pos()
+    lb, ub = (state == 2) | (state == 4), (state == 3) | (state == 4)
+    xl[~lb] = np.inf; zl[~lb] = 0.0
+    xu[~ub] = np.inf; zu[~ub] = 0.0
+    fx = state == 0
+    xl[fx] = xu[fx] = zl[fx] = zu[fx] = 0.0
+    mu = float((xl[lb] * zl[lb]).sum() + (xu[ub] * zu[ub]).sum()) / (lb.sum() + ub.sum())
+    U = lambda k: rng.uniform(-0.5, 0.5, k)
+    rl = np.where(lb, U(N), 0.0)
+    ru = np.where(ub, U(N), 0.0)
+    sl = np.where(lb, mu - xl_safe(xl) * zl, 0.0)
+    su = np.where(ub, mu - xl_safe(xu) * zu, 0.0)
+    return dict(state=state, xl=xl, xu=xu, zl=zl, zu=zu, mu=mu, rb=U(m), rc=U(N), rl=rl, ru=ru, sl=sl, su=su)
+
+
+def xl_safe(v):
+    """inf -> 0 so that products with zero multipliers stay finite"""
+    return np.where(np.isfinite(v), v, 0.0)

@@ -905,3 +905,97 @@ extern "C" Int orc_kkt_basis_solve(orc_split* S, const double* a,
 }
 
 extern "C" void orc_split_free(orc_split* S) { delete S; }
+
+// ---------------------------------------------------------------------------
+// IPM::SolveNewtonSystem, src/ipm.cc:532-645.
+// PARITY UNPINNED against the reference: ipm.cc cannot be linked here (it needs
+// ipx::Basis, hence BASICLU); this is a line-by-line restatement, additionally
+// checked by the Newton equations it must satisfy (tests/).
+// state[j]: 0 fixed, 1 free, 2 barrier lb, 3 barrier ub, 4 barrier boxed
+// (Iterate::StateOf / has_barrier_lb / has_barrier_ub, src/iterate.h:99-108).
+// ---------------------------------------------------------------------------
+namespace {
+template <class Solve>
+Int NewtonSolve(Int m, Int n, const Int* AIp, const Int* AIi, const double* AIx,
+                bool have_identity, Solve&& kkt_solve, const double* rb,
+                const double* rc, const double* rl, const double* ru,
+                const double* sl, const double* su, const double* xl,
+                const double* xu, const double* zl, const double* zu,
+                const unsigned char* state, double* dx, double* dxl,
+                double* dxu, double* dy, double* dzl, double* dzu) {
+    auto has_lb = [&](Int j) { return state[j] == 2 || state[j] == 4; };
+    auto has_ub = [&](Int j) { return state[j] == 3 || state[j] == 4; };
+    auto fixed = [&](Int j) { return state[j] == 0; };
+    auto barrier = [&](Int j) { return state[j] >= 2; };
+    // :551-566
+    Vec rhs1(n + m, 0.0), rhs2(m, 0.0);
+    if (rc) for (Int j = 0; j < n + m; j++) rhs1[j] = -rc[j];
+    for (Int j = 0; j < n + m; j++) {
+        const double rlj = rl ? rl[j] : 0.0, ruj = ru ? ru[j] : 0.0;
+        if (has_lb(j)) rhs1[j] += (sl[j] + zl[j] * rlj) / xl[j];
+        if (has_ub(j)) rhs1[j] -= (su[j] - zu[j] * ruj) / xu[j];
+        if (fixed(j)) rhs1[j] = 0.0;
+    }
+    if (rb) std::copy(rb, rb + m, rhs2.begin());
+    // :569-573
+    const Int errflag = kkt_solve(rhs1.data(), rhs2.data(), dx, dy);
+    if (errflag) return errflag;
+    // :576-611
+    for (Int i = 0; i < m; i++) dy[i] *= -1.0;
+    for (Int j = 0; j < n + m; j++) {
+        if (!barrier(j)) { dxl[j] = 0.0; dzl[j] = 0.0; continue; }
+        const double rlj = rl ? rl[j] : 0.0;
+        dxl[j] = dx[j] - rlj;
+        dzl[j] = (sl[j] - zl[j] * dxl[j]) / xl[j];
+    }
+    for (Int j = 0; j < n + m; j++) {
+        if (!barrier(j)) { dxu[j] = 0.0; dzu[j] = 0.0; continue; }
+        const double ruj = ru ? ru[j] : 0.0;
+        dxu[j] = ruj - dx[j];
+        dzu[j] = (su[j] - zu[j] * dxu[j]) / xu[j];
+    }
+    // :617-633
+    for (Int j = 0; j < n + m; j++) {
+        if (!barrier(j)) continue;
+        double atdy = 0.0;
+        if (j < n || have_identity) {
+            for (Int p = AIp[j]; p < AIp[j + 1]; p++) atdy += dy[AIi[p]] * AIx[p];
+        } else {
+            atdy = dy[j - n] * 1.0;     // slack column of AI
+        }
+        const double rcj = rc ? rc[j] : 0.0;
+        if (std::isfinite(xl[j]) && std::isfinite(xu[j])) {
+            if (zl[j] * xu[j] >= zu[j] * xl[j]) dzl[j] = rcj + dzu[j] - atdy;
+            else dzu[j] = -rcj + dzl[j] + atdy;
+        } else if (std::isfinite(xl[j])) {
+            dzl[j] = rcj + dzu[j] - atdy;
+        } else {
+            dzu[j] = -rcj + dzl[j] + atdy;
+        }
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" Int orc_newton_solve_diag(orc_kkt_diag* K, const double* rb,
+    const double* rc, const double* rl, const double* ru, const double* sl,
+    const double* su, const double* xl, const double* xu, const double* zl,
+    const double* zu, const unsigned char* state, double tol, double* dx,
+    double* dxl, double* dxu, double* dy, double* dzl, double* dzu, Int* iter) {
+    return NewtonSolve(K->m, K->n, K->Ap, K->Ai, K->Ax, false,
+        [&](const double* a, const double* b, double* x, double* y) {
+            return orc_kkt_diag_solve(K, a, b, tol, x, y, iter, nullptr, 0);
+        }, rb, rc, rl, ru, sl, su, xl, xu, zl, zu, state, dx, dxl, dxu, dy, dzl, dzu);
+}
+
+extern "C" Int orc_newton_solve_basis(orc_split* S, const double* rb,
+    const double* rc, const double* rl, const double* ru, const double* sl,
+    const double* su, const double* xl, const double* xu, const double* zl,
+    const double* zu, const unsigned char* state, double tol, Int maxiter,
+    double* dx, double* dxl, double* dxu, double* dy, double* dzl, double* dzu,
+    Int* iter) {
+    return NewtonSolve(S->m, S->n, S->AIp.data(), S->AIi.data(), S->AIx.data(), true,
+        [&](const double* a, const double* b, double* x, double* y) {
+            return orc_kkt_basis_solve(S, a, b, tol, maxiter, x, y, iter, nullptr, 0);
+        }, rb, rc, rl, ru, sl, su, xl, xu, zl, zu, state, dx, dxl, dxu, dy, dzl, dzu);
+}

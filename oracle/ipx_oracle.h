@@ -172,6 +172,18 @@ orc_int orc_kkt_basis_solve(orc_split* S, const double* a, const double* b,
                             orc_int hist_cap);
 void orc_split_free(orc_split* S);
 
+/* ---- IPM::SolveNewtonSystem (src/ipm.cc:532-645); parity unpinned, see .cc ---- */
+orc_int orc_newton_solve_diag(orc_kkt_diag* K, const double* rb, const double* rc,
+    const double* rl, const double* ru, const double* sl, const double* su,
+    const double* xl, const double* xu, const double* zl, const double* zu,
+    const unsigned char* state, double tol, double* dx, double* dxl, double* dxu,
+    double* dy, double* dzl, double* dzu, orc_int* iter);
+orc_int orc_newton_solve_basis(orc_split* S, const double* rb, const double* rc,
+    const double* rl, const double* ru, const double* sl, const double* su,
+    const double* xl, const double* xu, const double* zl, const double* zu,
+    const unsigned char* state, double tol, orc_int maxiter, double* dx,
+    double* dxl, double* dxu, double* dy, double* dzl, double* dzu, orc_int* iter);
+
 #ifdef __cplusplus
 }
 #endif

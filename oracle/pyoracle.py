@@ -88,7 +88,7 @@ class Oracle:
         for name in ("orc_find_dense_columns", "orc_diag_num_dense", "orc_dpotrf_lower",
                      "orc_pcr_solve", "orc_cr_solve", "orc_kkt_diag_factorize",
                      "orc_kkt_diag_solve", "orc_trisolve", "orc_split_get_sizes",
-                     "orc_kkt_basis_solve"):
+                     "orc_kkt_basis_solve", "orc_newton_solve_diag", "orc_newton_solve_basis"):
             getattr(L, name).restype = c_i64
         for name in ("orc_diag_factorize", "orc_kkt_diag_new", "orc_split_prepare"):
             getattr(L, name).restype = C.c_void_p
@@ -277,6 +277,20 @@ class OracleKktDiag:
                                               _fp(y), C.byref(it), _fp(hist), c_i64(hist_cap))
         return x, y, int(it.value), int(err), hist[:min(hist_cap, it.value + 1)]
 
+    def newton_solve(self, rb, rc, rl, ru, sl, su, xl, xu, zl, zu, state, tol):
+        """IPM::SolveNewtonSystem (src/ipm.cc:532-645) around this solver; None = zero vector."""
+        N = self.n + self.m
+        ins = [_F(v) for v in (rb, rc, rl, ru, sl, su, xl, xu, zl, zu)]
+        st = np.ascontiguousarray(state, dtype=np.uint8)
+        out = {k: np.zeros(self.m if k == "dy" else N, f64) for k in ("dx", "dxl", "dxu", "dy", "dzl", "dzu")}
+        it = c_i64(0)
+        err = self.orc.lib.orc_newton_solve_diag(
+            self.h, *[_fp(v) for v in ins], st.ctypes.data_as(C.POINTER(C.c_ubyte)), c_f64(tol),
+            _fp(out["dx"]), _fp(out["dxl"]), _fp(out["dxu"]), _fp(out["dy"]), _fp(out["dzl"]), _fp(out["dzu"]),
+            C.byref(it))
+        out.update(iter=int(it.value), errflag=int(err))
+        return out
+
     def get(self):
         W = np.zeros(self.n + self.m, f64)
         rs = np.zeros(self.m, f64)
@@ -335,6 +349,19 @@ class OracleSplit:
                                                c_i64(maxiter), _fp(x), _fp(y), C.byref(it),
                                                _fp(hist), c_i64(hist_cap))
         return x, y, int(it.value), int(err), hist[:min(hist_cap, it.value + 1)]
+
+    def newton_solve(self, rb, rc, rl, ru, sl, su, xl, xu, zl, zu, state, tol, maxiter=-1):
+        N = self.n + self.m
+        ins = [_F(v) for v in (rb, rc, rl, ru, sl, su, xl, xu, zl, zu)]
+        st = np.ascontiguousarray(state, dtype=np.uint8)
+        out = {k: np.zeros(self.m if k == "dy" else N, f64) for k in ("dx", "dxl", "dxu", "dy", "dzl", "dzu")}
+        it = c_i64(0)
+        err = self.orc.lib.orc_newton_solve_basis(
+            self.h, *[_fp(v) for v in ins], st.ctypes.data_as(C.POINTER(C.c_ubyte)), c_f64(tol), c_i64(maxiter),
+            _fp(out["dx"]), _fp(out["dxl"]), _fp(out["dxu"]), _fp(out["dy"]), _fp(out["dzl"]), _fp(out["dzu"]),
+            C.byref(it))
+        out.update(iter=int(it.value), errflag=int(err))
+        return out
 
     def __del__(self):
         if self.h:

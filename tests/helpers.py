@@ -34,3 +34,39 @@ def kkt_residual_diag(A, W, a, b, x, y):
     res1 = x / W + aty - a
     res2 = S @ x[:n] + x[n:] - b
     return res1, res2
+
+
+def amax(v):
+    return float(np.abs(v).max()) if v.size else 0.0
+
+
+def check_newton_equations(AI, st, step, tol_kkt):
+    """AI = [A I] (scipy).  The six block equations of the Newton system."""
+    state = st["state"]
+    lb, ub = (state == 2) | (state == 4), (state == 3) | (state == 4)
+    bar = state >= 2
+    dx, dxl, dxu, dy, dzl, dzu = (step[k] for k in ("dx", "dxl", "dxu", "dy", "dzl", "dzu"))
+    scale = 1.0 + max(np.abs(dx).max(), np.abs(dy).max())
+    assert np.abs(AI @ dx - st["rb"]).max() <= 1e-9 * scale                       # A dx = rb
+    assert amax(dx[lb] - dxl[lb] - st["rl"][lb]) <= 1e-12 * scale          # dx - dxl = rl
+    assert amax(dx[ub] + dxu[ub] - st["ru"][ub]) <= 1e-12 * scale          # dx + dxu = ru
+    # A'dy + dzl - dzu = rc holds exactly on barrier variables (the residual was shifted away from it)
+    dual = AI.T @ dy + dzl - dzu - st["rc"]
+    assert np.abs(dual[bar]).max() <= 1e-10 * (1.0 + np.abs(dzl).max() + np.abs(dzu).max())
+    # complementarity rows: exact on the side that was not overwritten by the shift, within the KKT
+    # tolerance (scaled) on the other
+    cl = st["zl"][lb] * dxl[lb] + st["xl"][lb] * dzl[lb] - st["sl"][lb]
+    cu = st["zu"][ub] * dxu[ub] + st["xu"][ub] * dzu[ub] - st["su"][ub]
+    G = np.zeros(len(state))
+    G[lb] += st["zl"][lb] / st["xl"][lb]
+    G[ub] += st["zu"][ub] / st["xu"][ub]
+    # residual of the first KKT block row, D = G^{-1/2} scaling (src/kkt_solver.h:21-27)
+    rl0, ru0 = np.where(lb, st["rl"], 0.0), np.where(ub, st["ru"], 0.0)
+    assert np.isfinite(cl).all() and np.isfinite(cu).all()
+    res_l = np.zeros(len(state)); res_l[lb] = cl / st["xl"][lb]
+    res_u = np.zeros(len(state)); res_u[ub] = cu / st["xu"][ub]
+    assert np.abs((res_l - res_u)[bar] / np.sqrt(G[bar])).max() <= tol_kkt * (1 + 1e-6) + 1e-9 * scale
+    # free and fixed variables carry no bound steps
+    nb = ~bar
+    assert not dxl[nb].any() and not dxu[nb].any() and not dzl[nb].any() and not dzu[nb].any()
+    assert not dx[state == 0].any()
