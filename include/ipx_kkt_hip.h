@@ -208,6 +208,41 @@ int ipxk_newton_solve(ipxk_context* ctx, int use_basis, const double* rb,
                       ipxk_interrupt_fn interrupt, void* interrupt_user,
                       ipxk_times* times);
 
+/* ---- the IPM iterate on the device -----------
+ * Iterate::Initialize / accessors (src/iterate.cc:60-92): the six vectors
+ * x, xl, xu, zl, zu [n+m], y [m] and one IPXK_STATE_* byte per variable are
+ * copied into the context. */
+int ipxk_iterate_set(ipxk_context* ctx, const double* x, const double* xl,
+                     const double* xu, const double* y, const double* zl,
+                     const double* zu, const unsigned char* state);
+/* copies out; NULL pointers are skipped */
+int ipxk_iterate_get(ipxk_context* ctx, double* x, double* xl, double* xu,
+                     double* y, double* zl, double* zu);
+/* Iterate::Update (src/iterate.cc:94-139): x += sp*dx on non-fixed variables,
+ * xl/xu += sp*d, zl/zu += sd*d on variables with that barrier term, truncated
+ * at kBarrierMin = 1e-30; y += sd*dy.  NULL step components are skipped. */
+int ipxk_iterate_update(ipxk_context* ctx, double sp, const double* dx,
+                        const double* dxl, const double* dxu, double sd,
+                        const double* dy, const double* dzl, const double* dzu);
+/* Iterate::ComputeResiduals (src/iterate.cc:536-588) for the model vectors
+ * b[m], c, lb, ub [n+m]: rb = b - AI x, rc = c - AI'y - zl + zu (0 on fixed
+ * variables), rl = lb - x + xl, ru = ub - x - xu (0 without that barrier
+ * term); presidual = max(|rb|,|rl|,|ru|)_inf, dresidual = |rc|_inf. */
+int ipxk_iterate_residuals(ipxk_context* ctx, const double* b, const double* c,
+                           const double* lb, const double* ub, double* rb,
+                           double* rc, double* rl, double* ru,
+                           double* presidual, double* dresidual);
+/* Iterate::ComputeComplementarity (src/iterate.cc:642-670):
+ * out4 = {complementarity, mu, mu_min, mu_max} (host memory) */
+int ipxk_iterate_complementarity(ipxk_context* ctx, double out4[4]);
+/* StepToBoundary (src/ipm.cc:320-339): largest alpha <= alpha0 with
+ * x + alpha*dx >= 0, damped by 1 - eps at the blocking index (-1: none).
+ * Parallel minimum over the candidates; equals the reference's sequential
+ * scan except when alpha lands within one ulp factor of another candidate. */
+int ipxk_step_to_boundary(ipxk_context* ctx, const double* x, const double* dx,
+                          ipxint len, double alpha0, double* alpha,
+                          ipxint* blocking_index);
+
 /* ---- multi-GPU: rows of AI partitioned over ranks, one RCCL all-reduce per
  *      NormalMatrix apply ---------------------------- */
 /* 128-byte RCCL unique id, created on rank 0 and broadcast by the launcher. */

@@ -494,6 +494,106 @@ int ipxk_newton_solve(ipxk_context* c, int use_basis, const double* rb, const do
     });
 }
 
+// ---- the IPM iterate -------------------------------------------------------------------------
+static void copy_in(Context* c, void* dst_dev, const void* src, size_t bytes) {
+    if (c->pointer_mode == IPXK_POINTER_HOST) staged_h2d(dst_dev, src, bytes, c->stream);
+    else IPXK_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+}
+static void copy_out(Context* c, void* dst, const void* src_dev, size_t bytes) {
+    if (c->pointer_mode == IPXK_POINTER_HOST) staged_d2h(dst, src_dev, bytes, c->stream);
+    else IPXK_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToDevice, c->stream));
+}
+
+int ipxk_iterate_set(ipxk_context* c, const double* x, const double* xl, const double* xu, const double* y,
+                     const double* zl, const double* zu, const unsigned char* state) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && x && xl && xu && y && zl && zu && state, "NULL argument");
+        bind_device(c);
+        const size_t m = (size_t)c->m, N = (size_t)(c->n + c->m);
+        DevBuf<double>* dst[6] = {&c->it_x, &c->it_xl, &c->it_xu, &c->it_y, &c->it_zl, &c->it_zu};
+        const double* src[6] = {x, xl, xu, y, zl, zu};
+        for (int k = 0; k < 6; k++) {
+            const size_t len = k == 3 ? m : N;
+            dst[k]->resize(std::max<size_t>(len, 1));
+            copy_in(c, dst[k]->get(), src[k], len * sizeof(double));
+        }
+        c->it_state.resize(std::max<size_t>(N, 1));
+        copy_in(c, c->it_state.get(), state, N);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+        c->it_set = true;
+    });
+}
+
+int ipxk_iterate_get(ipxk_context* c, double* x, double* xl, double* xu, double* y, double* zl, double* zu) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && c->it_set, "no iterate on the device (ipxk_iterate_set)");
+        bind_device(c);
+        const size_t m = (size_t)c->m, N = (size_t)(c->n + c->m);
+        const DevBuf<double>* src[6] = {&c->it_x, &c->it_xl, &c->it_xu, &c->it_y, &c->it_zl, &c->it_zu};
+        double* dst[6] = {x, xl, xu, y, zl, zu};
+        for (int k = 0; k < 6; k++)
+            if (dst[k]) copy_out(c, dst[k], src[k]->get(), (k == 3 ? m : N) * sizeof(double));
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int ipxk_iterate_update(ipxk_context* c, double sp, const double* dx, const double* dxl, const double* dxu,
+                        double sd, const double* dy, const double* dzl, const double* dzu) {
+    return guarded([&] {
+        IPXK_REQUIRE(c, "NULL argument");
+        bind_device(c);
+        const size_t m = (size_t)c->m, N = (size_t)(c->n + c->m);
+        const double* in[6] = {dx, dxl, dxu, dy, dzl, dzu};
+        const double* din[6];
+        for (int k = 0; k < 6; k++) din[k] = in[k] ? stage_in(c, in[k], k == 3 ? m : N, c->nw_out[k]) : nullptr;
+        iterate_update_dev(c, sp, din[0], din[1], din[2], sd, din[3], din[4], din[5]);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int ipxk_iterate_residuals(ipxk_context* c, const double* b, const double* cc, const double* lb, const double* ub,
+                           double* rb, double* rc, double* rl, double* ru, double* presidual,
+                           double* dresidual) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && b && cc && lb && ub && rb && rc && rl && ru, "NULL argument");
+        bind_device(c);
+        const size_t m = (size_t)c->m, N = (size_t)(c->n + c->m);
+        const double* db = stage_in(c, b, m, c->nw_in[0]);
+        const double* dc = stage_in(c, cc, N, c->nw_in[1]);
+        const double* dlb = stage_in(c, lb, N, c->nw_in[2]);
+        const double* dub = stage_in(c, ub, N, c->nw_in[3]);
+        double* drb = stage_out(c, rb, m, c->nw_out[0]);
+        double* drc = stage_out(c, rc, N, c->nw_out[1]);
+        double* drl = stage_out(c, rl, N, c->nw_out[2]);
+        double* dru = stage_out(c, ru, N, c->nw_out[4]);
+        iterate_residuals_dev(c, db, dc, dlb, dub, drb, drc, drl, dru, presidual, dresidual);
+        finish_out(c, rb, drb, m);
+        finish_out(c, rc, drc, N);
+        finish_out(c, rl, drl, N);
+        finish_out(c, ru, dru, N);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int ipxk_iterate_complementarity(ipxk_context* c, double out4[4]) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && out4, "NULL argument");
+        bind_device(c);
+        iterate_complementarity_dev(c, out4);
+    });
+}
+
+int ipxk_step_to_boundary(ipxk_context* c, const double* x, const double* dx, ipxint len, double alpha0,
+                          double* alpha, ipxint* blocking_index) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && x && dx && alpha && len >= 0, "bad argument");
+        bind_device(c);
+        const double* dxv = stage_in(c, x, (size_t)len, c->nw_in[0]);
+        const double* ddx = stage_in(c, dx, (size_t)len, c->nw_in[1]);
+        *alpha = step_to_boundary_dev(c, dxv, ddx, len, alpha0, blocking_index);
+    });
+}
+
 // ---- SplittedNormalMatrix / basis path -------------------------------------------------
 int ipxk_split_prepare(ipxk_context* c, const ipxint* Lp, const ipxint* Li, const double* Lx,
                        const ipxint* Up, const ipxint* Ui, const double* Ux, const ipxint* rowperm,

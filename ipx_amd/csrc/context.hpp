@@ -86,6 +86,11 @@ struct Context {
     DevBuf<double> nw_in[10], nw_out[6];   // staging for host vectors
     DevBuf<unsigned char> nw_state;
 
+    // ---- the IPM iterate (iterate.hip) ----
+    DevBuf<double> it_x, it_xl, it_xu, it_y, it_zl, it_zu, it_partials;
+    DevBuf<unsigned char> it_state;
+    bool it_set = false;
+
     // ---- basis path ----
     SplitOperator* split = nullptr;
     PrepareHost* prepare_host = nullptr;   // host workspaces of split_prepare (trisolve.hip)
@@ -151,6 +156,15 @@ CrResult newton_solve_dev(Context* c, bool use_basis, const double* rb, const do
                           const double* zl, const double* zu, const unsigned char* state, double tol,
                           ipxint maxiter, double* dx, double* dxl, double* dxu, double* dy, double* dzl,
                           double* dzu, ipxk_interrupt_fn interrupt, void* user, ipxk_times* times);
+
+// ---- iterate.hip ----
+void iterate_update_dev(Context* c, double sp, const double* dx, const double* dxl, const double* dxu, double sd,
+                        const double* dy, const double* dzl, const double* dzu);
+void iterate_residuals_dev(Context* c, const double* b, const double* cc, const double* lb, const double* ub,
+                           double* rb, double* rc, double* rl, double* ru, double* presidual, double* dresidual);
+void iterate_complementarity_dev(Context* c, double out4[4]);
+double step_to_boundary_dev(Context* c, const double* x, const double* dx, int64_t len, double alpha0,
+                            ipxint* blocking);
 
 // ---- kkt_diag.hip ----
 void kkt_diag_factorize_dev(Context* c, const double* xl, const double* xu, const double* zl,

@@ -30,7 +30,8 @@ EXPORTS = [
     "ipxk_diag_get", "ipxk_pcr_solve", "ipxk_kkt_diag_factorize", "ipxk_kkt_diag_solve",
     "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_apply", "ipxk_forward_solve",
     "ipxk_backward_solve", "ipxk_solve_dense", "ipxk_split_levels", "ipxk_cr_solve",
-    "ipxk_kkt_basis_solve", "ipxk_newton_solve", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns",
+    "ipxk_kkt_basis_solve", "ipxk_newton_solve", "ipxk_iterate_set", "ipxk_iterate_get", "ipxk_iterate_update",
+    "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns",
     "ipxk_time_normal_apply",
     "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
     "ipxk_dev_download",
@@ -314,6 +315,46 @@ class KktContext:
         padded = np.zeros((st.size + 7) // 8 * 8, np.uint8)
         padded[:st.size] = st
         return DeviceVector(self, padded.size // 8, padded.view(f64))
+
+    # -- the IPM iterate (host vectors; pointer mode host) -----------------------------------
+    IT_KEYS = ("x", "xl", "xu", "y", "zl", "zu")
+
+    def iterate_set(self, it, state):
+        st = np.ascontiguousarray(state, dtype=np.uint8)
+        vecs = [_F(it[key]) for key in self.IT_KEYS]
+        self._check(self.lib.ipxk_iterate_set(self.h, *[_fp(v) for v in vecs],
+                                              st.ctypes.data_as(C.POINTER(C.c_ubyte))))
+
+    def iterate_get(self):
+        N = self.n + self.m
+        out = {key: np.zeros(self.m if key == "y" else N, f64) for key in self.IT_KEYS}
+        self._check(self.lib.ipxk_iterate_get(self.h, *[_fp(out[key]) for key in self.IT_KEYS]))
+        return out
+
+    def iterate_update(self, sp, dx, dxl, dxu, sd, dy, dzl, dzu):
+        self._check(self.lib.ipxk_iterate_update(self.h, c_f64(sp), _fp(_F(dx)), _fp(_F(dxl)), _fp(_F(dxu)),
+                                                 c_f64(sd), _fp(_F(dy)), _fp(_F(dzl)), _fp(_F(dzu))))
+
+    def iterate_residuals(self, b, c, lb, ub):
+        N = self.n + self.m
+        rb, rc, rl, ru = np.zeros(self.m, f64), np.zeros(N, f64), np.zeros(N, f64), np.zeros(N, f64)
+        pres, dres = c_f64(0.0), c_f64(0.0)
+        self._check(self.lib.ipxk_iterate_residuals(self.h, _fp(_F(b)), _fp(_F(c)), _fp(_F(lb)), _fp(_F(ub)),
+                                                    _fp(rb), _fp(rc), _fp(rl), _fp(ru), C.byref(pres),
+                                                    C.byref(dres)))
+        return dict(rb=rb, rc=rc, rl=rl, ru=ru, presidual=pres.value, dresidual=dres.value)
+
+    def iterate_complementarity(self):
+        out = (C.c_double * 4)()
+        self._check(self.lib.ipxk_iterate_complementarity(self.h, out))
+        return dict(complementarity=out[0], mu=out[1], mu_min=out[2], mu_max=out[3])
+
+    def step_to_boundary(self, x, dx, alpha0=1.0):
+        x, dx = _F(x), _F(dx)
+        alpha, blk = c_f64(0.0), c_i64(-1)
+        self._check(self.lib.ipxk_step_to_boundary(self.h, _fp(x), _fp(dx), c_i64(x.size), c_f64(alpha0),
+                                                   C.byref(alpha), C.byref(blk)))
+        return alpha.value, int(blk.value)
 
     def kkt_diag_get(self):
         W, rs = np.zeros(self.n + self.m, f64), np.zeros(self.m, f64)

@@ -218,3 +218,34 @@ def synthetic_newton_state(m, n, seed, num_free=0, num_fixed=0, num_ub=0, num_bo
 def xl_safe(v):
     """inf -> 0 so that products with zero multipliers stay finite"""
     return np.where(np.isfinite(v), v, 0.0)
+
+
+def synthetic_iterate(m, n, seed, frac_special=0.15):
+    """An LP with mixed bounds / constraint types plus an interior iterate and a step for it, consistent
+    with Iterate::Initialize and assert_consistency (reference src/iterate.cc:60-92, 450-520).
+    Returns dict(A, rhs, constr_type, obj, lb, ub  [user model];  lbs, ubs [bounds incl. slacks];
+    state [IPXK_STATE_* per variable of AI];  it = dict(x, xl, xu, y, zl, zu);
+    step = dict(dx, dxl, dxu, dy, dzl, dzu))."""
+    rng = np.random.default_rng(seed)
+    A = synthetic_lp(m, n, 8, seed)
+    N = n + m
+    lb, ub = np.zeros(n), np.full(n, np.inf)
+    k = int(frac_special * n)
+    sp = rng.permutation(n)[:3 * k]
+    lb[sp[:k]] = -np.inf; ub[sp[:k]] = rng.uniform(1, 3, k)                 # upper bound only
+    lb[sp[k:2 * k]] = rng.uniform(-2, 0, k); ub[sp[k:2 * k]] = rng.uniform(1, 3, k)   # boxed
+    lb[sp[2 * k:]] = -np.inf                                              # free
+    ct = rng.choice(list("<>="), size=m, p=[0.6, 0.25, 0.15])
+    slb = np.where(ct == ">", -np.inf, 0.0)
+    sub = np.where(ct == "<", np.inf, 0.0)
+    lbs, ubs = np.concatenate([lb, slb]), np.concatenate([ub, sub])
+    fl, fu = np.isfinite(lbs), np.isfinite(ubs)
+    state = np.where(fl & fu, 4, np.where(fl, 2, np.where(fu, 3, 1))).astype(np.uint8)
+    pos = lambda: 10.0 ** rng.uniform(-1, 1, N)
+    it = dict(x=rng.uniform(-1, 1, N), y=rng.uniform(-1, 1, m),
+              xl=np.where(fl, pos(), np.inf), zl=np.where(fl, pos(), 0.0),
+              xu=np.where(fu, pos(), np.inf), zu=np.where(fu, pos(), 0.0))
+    U = lambda q: rng.uniform(-1, 1, q)
+    step = dict(dx=U(N), dxl=U(N), dxu=U(N), dy=U(m), dzl=U(N), dzu=U(N))
+    return dict(A=A, rhs=rng.uniform(-1, 1, m), constr_type="".join(ct), obj=rng.uniform(-1, 1, n), lb=lb, ub=ub,
+                lbs=lbs, ubs=ubs, state=state, it=it, step=step)

@@ -999,3 +999,101 @@ extern "C" Int orc_newton_solve_basis(orc_split* S, const double* rb,
             return orc_kkt_basis_solve(S, a, b, tol, maxiter, x, y, iter, nullptr, 0);
         }, rb, rc, rl, ru, sl, su, xl, xu, zl, zu, state, dx, dxl, dxu, dy, dzl, dzu);
 }
+
+// ---------------------------------------------------------------------------
+// Iterate::Update / ComputeResiduals / ComputeComplementarity
+// (src/iterate.cc:94-139, 536-588, 642-670) and StepToBoundary (src/ipm.cc:320-339).
+// State codes as above.  Pinned against the reference's ipx::Iterate
+// (oracle/_ref) in tests/test_oracle_vs_ref.py.
+// ---------------------------------------------------------------------------
+static const double kOrcBarrierMin = 1e-30;   // Iterate::kBarrierMin, src/iterate.h
+
+extern "C" void orc_iterate_update(Int m, Int n, const unsigned char* state,
+    double* x, double* xl, double* xu, double* y, double* zl, double* zu,
+    double sp, const double* dx, const double* dxl, const double* dxu,
+    double sd, const double* dy, const double* dzl, const double* dzu) {
+    auto has_lb = [&](Int j) { return state[j] == 2 || state[j] == 4; };
+    auto has_ub = [&](Int j) { return state[j] == 3 || state[j] == 4; };
+    if (dx) for (Int j = 0; j < n + m; j++) if (state[j] != 0) x[j] += sp * dx[j];
+    if (dxl) for (Int j = 0; j < n + m; j++) if (has_lb(j)) { xl[j] += sp * dxl[j]; xl[j] = std::max(xl[j], kOrcBarrierMin); }
+    if (dxu) for (Int j = 0; j < n + m; j++) if (has_ub(j)) { xu[j] += sp * dxu[j]; xu[j] = std::max(xu[j], kOrcBarrierMin); }
+    if (dy) for (Int i = 0; i < m; i++) y[i] += sd * dy[i];
+    if (dzl) for (Int j = 0; j < n + m; j++) if (has_lb(j)) { zl[j] += sd * dzl[j]; zl[j] = std::max(zl[j], kOrcBarrierMin); }
+    if (dzu) for (Int j = 0; j < n + m; j++) if (has_ub(j)) { zu[j] += sd * dzu[j]; zu[j] = std::max(zu[j], kOrcBarrierMin); }
+}
+
+// A: the n structural columns; the slack identity of AI is applied implicitly.
+extern "C" void orc_iterate_residuals(Int m, Int n, const Int* Ap, const Int* Ai,
+    const double* Ax, const unsigned char* state, const double* b,
+    const double* c, const double* lb, const double* ub, const double* x,
+    const double* xl, const double* xu, const double* y, const double* zl,
+    const double* zu, double* rb, double* rc, double* rl, double* ru,
+    double* norms) {
+    // :543-545  rb = b - AI*x, columns in order (MultiplyAdd 'N', sparse_matrix.cc:194-209)
+    for (Int i = 0; i < m; i++) rb[i] = b[i];
+    for (Int j = 0; j < n; j++) {
+        const double alpha = -1.0 * x[j];
+        for (Int p = Ap[j]; p < Ap[j + 1]; p++) rb[Ai[p]] += alpha * Ax[p];
+    }
+    for (Int i = 0; i < m; i++) rb[i] += (-1.0 * x[n + i]) * 1.0;
+    // :550-556  rc = c - zl + zu - AI'y, zero on fixed variables
+    for (Int j = 0; j < n + m; j++) rc[j] = c[j] - zl[j] + zu[j];
+    for (Int j = 0; j < n; j++) {
+        double d = 0.0;
+        for (Int p = Ap[j]; p < Ap[j + 1]; p++) d += y[Ai[p]] * Ax[p];
+        rc[j] += -1.0 * d;
+    }
+    for (Int i = 0; i < m; i++) rc[n + i] += -1.0 * (y[i] * 1.0);
+    for (Int j = 0; j < n + m; j++) if (state[j] == 0) rc[j] = 0.0;
+    // :566-577
+    for (Int j = 0; j < n + m; j++)
+        rl[j] = (state[j] == 2 || state[j] == 4) ? lb[j] - x[j] + xl[j] : 0.0;
+    for (Int j = 0; j < n + m; j++)
+        ru[j] = (state[j] == 3 || state[j] == 4) ? ub[j] - x[j] - xu[j] : 0.0;
+    // :584-587
+    double pres = orc_infnorm(m, rb);
+    pres = std::max(pres, orc_infnorm(n + m, rl));
+    pres = std::max(pres, orc_infnorm(n + m, ru));
+    norms[0] = pres;
+    norms[1] = orc_infnorm(n + m, rc);
+}
+
+// out4: complementarity, mu, mu_min, mu_max
+extern "C" void orc_iterate_complementarity(Int N, const unsigned char* state,
+    const double* xl, const double* xu, const double* zl, const double* zu,
+    double* out4) {
+    double comp = 0.0, mu_min = INFINITY, mu_max = 0.0, mu = 0.0;
+    Int num_finite = 0;
+    for (Int j = 0; j < N; j++)
+        if (state[j] == 2 || state[j] == 4) {
+            comp += xl[j] * zl[j];
+            mu_min = std::min(mu_min, xl[j] * zl[j]);
+            mu_max = std::max(mu_max, xl[j] * zl[j]);
+            num_finite++;
+        }
+    for (Int j = 0; j < N; j++)
+        if (state[j] == 3 || state[j] == 4) {
+            comp += xu[j] * zu[j];
+            mu_min = std::min(mu_min, xu[j] * zu[j]);
+            mu_max = std::max(mu_max, xu[j] * zu[j]);
+            num_finite++;
+        }
+    if (num_finite > 0) mu = comp / num_finite;
+    else mu = mu_min = 0.0;
+    out4[0] = comp; out4[1] = mu; out4[2] = mu_min; out4[3] = mu_max;
+}
+
+// src/ipm.cc:320-339
+extern "C" double orc_step_to_boundary(Int len, const double* x, const double* dx,
+                                       double alpha, Int* blocking_index) {
+    const double damp = 1.0 - std::numeric_limits<double>::epsilon();
+    Int iblock = -1;
+    for (Int i = 0; i < len; i++) {
+        if (x[i] + alpha * dx[i] < 0.0) {
+            alpha = -(x[i] * damp) / dx[i];
+            iblock = i;
+        }
+    }
+    if (blocking_index) *blocking_index = iblock;
+    return alpha;
+}

@@ -184,6 +184,21 @@ orc_int orc_newton_solve_basis(orc_split* S, const double* rb, const double* rc,
     const unsigned char* state, double tol, orc_int maxiter, double* dx,
     double* dxl, double* dxu, double* dy, double* dzl, double* dzu, orc_int* iter);
 
+/* ---- Iterate (src/iterate.cc:94-139,536-588,642-670), StepToBoundary (src/ipm.cc:320-339) ---- */
+void orc_iterate_update(orc_int m, orc_int n, const unsigned char* state, double* x,
+    double* xl, double* xu, double* y, double* zl, double* zu, double sp,
+    const double* dx, const double* dxl, const double* dxu, double sd,
+    const double* dy, const double* dzl, const double* dzu);
+void orc_iterate_residuals(orc_int m, orc_int n, const orc_int* Ap, const orc_int* Ai,
+    const double* Ax, const unsigned char* state, const double* b, const double* c,
+    const double* lb, const double* ub, const double* x, const double* xl,
+    const double* xu, const double* y, const double* zl, const double* zu,
+    double* rb, double* rc, double* rl, double* ru, double* norms);
+void orc_iterate_complementarity(orc_int N, const unsigned char* state, const double* xl,
+    const double* xu, const double* zl, const double* zu, double* out4);
+double orc_step_to_boundary(orc_int len, const double* x, const double* dx, double alpha,
+                            orc_int* blocking_index);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,43 @@ class Oracle:
         for name in ("orc_diag_factorize", "orc_kkt_diag_new", "orc_split_prepare"):
             getattr(L, name).restype = C.c_void_p
 
+    # ---- Iterate / StepToBoundary ---------------------------------------------
+    def iterate_update(self, m, n, state, it, sp, dx, dxl, dxu, sd, dy, dzl, dzu):
+        """it: dict with x, xl, xu, y, zl, zu (modified copies are returned); None steps are skipped."""
+        out = {k: _F(it[k]).copy() for k in ("x", "xl", "xu", "y", "zl", "zu")}
+        st = np.ascontiguousarray(state, dtype=np.uint8)
+        self.lib.orc_iterate_update(c_i64(m), c_i64(n), st.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                    *[_fp(out[k]) for k in ("x", "xl", "xu", "y", "zl", "zu")], c_f64(sp),
+                                    _fp(_F(dx)), _fp(_F(dxl)), _fp(_F(dxu)), c_f64(sd), _fp(_F(dy)),
+                                    _fp(_F(dzl)), _fp(_F(dzu)))
+        return out
+
+    def iterate_residuals(self, A, state, b, c, lb, ub, it):
+        m, n = A.nrow, A.ncol
+        st = np.ascontiguousarray(state, dtype=np.uint8)
+        rb, rc, rl, ru = np.zeros(m, f64), np.zeros(n + m, f64), np.zeros(n + m, f64), np.zeros(n + m, f64)
+        norms = np.zeros(2, f64)
+        self.lib.orc_iterate_residuals(c_i64(m), c_i64(n), _ip(A.p), _ip(A.i), _fp(A.x),
+                                       st.ctypes.data_as(C.POINTER(C.c_ubyte)), _fp(_F(b)), _fp(_F(c)),
+                                       _fp(_F(lb)), _fp(_F(ub)),
+                                       *[_fp(_F(it[k])) for k in ("x", "xl", "xu", "y", "zl", "zu")],
+                                       _fp(rb), _fp(rc), _fp(rl), _fp(ru), _fp(norms))
+        return dict(rb=rb, rc=rc, rl=rl, ru=ru, presidual=float(norms[0]), dresidual=float(norms[1]))
+
+    def iterate_complementarity(self, state, it):
+        st = np.ascontiguousarray(state, dtype=np.uint8)
+        out = np.zeros(4, f64)
+        self.lib.orc_iterate_complementarity(c_i64(st.size), st.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                             *[_fp(_F(it[k])) for k in ("xl", "xu", "zl", "zu")], _fp(out))
+        return dict(complementarity=float(out[0]), mu=float(out[1]), mu_min=float(out[2]), mu_max=float(out[3]))
+
+    def step_to_boundary(self, x, dx, alpha=1.0):
+        x, dx = _F(x), _F(dx)
+        blk = c_i64(-1)
+        self.lib.orc_step_to_boundary.restype = c_f64
+        a = self.lib.orc_step_to_boundary(c_i64(x.size), _fp(x), _fp(dx), c_f64(alpha), C.byref(blk))
+        return float(a), int(blk.value)
+
     # ---- vector / index kernels ------------------------------------------
     def dot(self, x, y):
         x, y = _F(x), _F(y)
@@ -449,6 +486,53 @@ class Ref:
         return RefSplit(self, L, U, N, free_positions)
 
 
+class RefIterate:
+    """The reference's ipx::Iterate on a RefModel."""
+
+    KEYS = ("x", "xl", "xu", "y", "zl", "zu")
+
+    def __init__(self, model):
+        self.model, self.lib = model, model.ref.lib
+        self.lib.ref_iterate_new.restype = C.c_void_p
+        self.h = C.c_void_p(self.lib.ref_iterate_new(model.h))
+        self.m, self.n = model.m, model.n
+
+    def initialize(self, it):
+        self.lib.ref_iterate_initialize(self.h, *[_fp(_F(it[k])) for k in self.KEYS])
+
+    def update(self, sp, dx, dxl, dxu, sd, dy, dzl, dzu):
+        self.lib.ref_iterate_update(self.h, c_f64(sp), _fp(_F(dx)), _fp(_F(dxl)), _fp(_F(dxu)), c_f64(sd),
+                                    _fp(_F(dy)), _fp(_F(dzl)), _fp(_F(dzu)))
+
+    def get(self):
+        N = self.n + self.m
+        out = {k: np.zeros(self.m if k == "y" else N, f64) for k in self.KEYS}
+        self.lib.ref_iterate_get(self.h, *[_fp(out[k]) for k in self.KEYS])
+        return out
+
+    def states(self):
+        st = np.zeros(self.n + self.m, np.uint8)
+        self.lib.ref_iterate_states(self.h, st.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        return st
+
+    def residuals(self):
+        N = self.n + self.m
+        rb, rc, rl, ru = np.zeros(self.m, f64), np.zeros(N, f64), np.zeros(N, f64), np.zeros(N, f64)
+        norms = np.zeros(2, f64)
+        self.lib.ref_iterate_residuals(self.h, _fp(rb), _fp(rc), _fp(rl), _fp(ru), _fp(norms))
+        return dict(rb=rb, rc=rc, rl=rl, ru=ru, presidual=float(norms[0]), dresidual=float(norms[1]))
+
+    def complementarity(self):
+        out = np.zeros(4, f64)
+        self.lib.ref_iterate_complementarity(self.h, _fp(out))
+        return dict(complementarity=float(out[0]), mu=float(out[1]), mu_min=float(out[2]), mu_max=float(out[3]))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_iterate_free(self.h)
+            self.h = None
+
+
 class RefModel:
     """Solver-form model built by the reference's UserModel::Load + Presolver."""
 
@@ -489,6 +573,9 @@ class RefModel:
 
     def is_dense(self, j):
         return bool(self.ref.lib.ref_model_is_dense(self.h, c_i64(j)))
+
+    def iterate(self):
+        return RefIterate(self)
 
     def normal_apply(self, W, rhs, want_dot=True):
         lhs = np.zeros(self.m, f64)

@@ -400,4 +400,65 @@ Int ref_split_cr_solve(void* oph, Int m, const double* rhs, double tol,
     return cr.errflag();
 }
 
+// ---- Iterate (src/iterate.cc) --------------------------------------------------
+void* ref_iterate_new(void* model_h) {
+    return new ipx::Iterate(static_cast<RefModel*>(model_h)->model);
+}
+void ref_iterate_free(void* it) { delete static_cast<ipx::Iterate*>(it); }
+
+void ref_iterate_initialize(void* ith, const double* x, const double* xl,
+                            const double* xu, const double* y, const double* zl,
+                            const double* zu) {
+    ipx::Iterate* it = static_cast<ipx::Iterate*>(ith);
+    const Int m = it->model().rows(), n = it->model().cols();
+    it->Initialize(ToVector(x, n + m), ToVector(xl, n + m), ToVector(xu, n + m),
+                   ToVector(y, m), ToVector(zl, n + m), ToVector(zu, n + m));
+}
+
+// Iterate::Update, :94-139.  NULL components are skipped as in the reference.
+void ref_iterate_update(void* ith, double sp, const double* dx, const double* dxl,
+                        const double* dxu, double sd, const double* dy,
+                        const double* dzl, const double* dzu) {
+    static_cast<ipx::Iterate*>(ith)->Update(sp, dx, dxl, dxu, sd, dy, dzl, dzu);
+}
+
+void ref_iterate_get(void* ith, double* x, double* xl, double* xu, double* y,
+                     double* zl, double* zu) {
+    ipx::Iterate* it = static_cast<ipx::Iterate*>(ith);
+    FromVector(it->x(), x); FromVector(it->xl(), xl); FromVector(it->xu(), xu);
+    FromVector(it->y(), y); FromVector(it->zl(), zl); FromVector(it->zu(), zu);
+}
+
+// state codes of include/ipx_kkt_hip.h: 0 fixed, 1 free, 2 barrier lb, 3 barrier ub, 4 boxed
+void ref_iterate_states(void* ith, unsigned char* state) {
+    ipx::Iterate* it = static_cast<ipx::Iterate*>(ith);
+    const Int N = it->model().rows() + it->model().cols();
+    for (Int j = 0; j < N; j++) {
+        const bool l = it->has_barrier_lb(j), u = it->has_barrier_ub(j);
+        if (l && u) state[j] = 4;
+        else if (l) state[j] = 2;
+        else if (u) state[j] = 3;
+        else state[j] = it->StateOf(j) == ipx::Iterate::State::fixed ? 0 : 1;
+    }
+}
+
+// ComputeResiduals, :536-588 (through the evaluating accessors); norms[0] = presidual, [1] = dresidual
+void ref_iterate_residuals(void* ith, double* rb, double* rc, double* rl,
+                           double* ru, double* norms) {
+    ipx::Iterate* it = static_cast<ipx::Iterate*>(ith);
+    FromVector(it->rb(), rb); FromVector(it->rc(), rc);
+    FromVector(it->rl(), rl); FromVector(it->ru(), ru);
+    norms[0] = it->presidual();
+    norms[1] = it->dresidual();
+}
+
+// ComputeComplementarity, :642-670: complementarity, mu, mu_min, mu_max
+void ref_iterate_complementarity(void* ith, double* out4) {
+    ipx::Iterate* it = static_cast<ipx::Iterate*>(ith);
+    out4[0] = it->complementarity();
+    out4[1] = it->mu();
+    out4[2] = it->mu_min();
+    out4[3] = it->mu_max();
+}
+
 }  // extern "C"

@@ -81,3 +81,45 @@ def test_sparse_kernels_bitwise(oracle, ref, po):
     y1, it1, e1, _ = R.cr_solve(rhs, 1e-9, -1)
     y2, it2, e2, _ = oracle.cr_solve(S.apply, rhs, 1e-9, None, -1)
     assert (it1, e1) == (it2, e2) and np.array_equal(y1, y2)
+
+
+@pytest.mark.parametrize("seed,m,n", [(201, 90, 200), (202, 257, 610)])
+def test_iterate_bitwise(oracle, ref, po, seed, m, n):
+    """Iterate::Initialize states, Update, ComputeResiduals, ComputeComplementarity and StepToBoundary:
+    the oracle against the reference's ipx::Iterate (bitwise)."""
+    from ipx_amd import synth
+    P = synth.synthetic_iterate(m, n, seed)
+    A = P["A"]
+    Ao = po.Csc(m, n, A.p, A.i, A.x)
+    rm = ref.model(Ao, P["rhs"], P["constr_type"], P["obj"], P["lb"], P["ub"])
+    assert (rm.m, rm.n, rm.dualized) == (m, n, 0)
+    b, c, lbs, ubs = rm.vectors()
+    assert np.array_equal(lbs, P["lbs"]) and np.array_equal(ubs, P["ubs"]) and np.array_equal(b, P["rhs"])
+    ri = rm.iterate()
+    ri.initialize(P["it"])
+    assert np.array_equal(ri.states(), P["state"])
+    r1 = ri.residuals()
+    r2 = oracle.iterate_residuals(Ao, P["state"], b, c, lbs, ubs, P["it"])
+    for key in ("rb", "rc", "rl", "ru"):
+        assert np.array_equal(r1[key], r2[key]), key
+    assert r1["presidual"] == r2["presidual"] and r1["dresidual"] == r2["dresidual"]
+    assert ri.complementarity() == oracle.iterate_complementarity(P["state"], P["it"])
+    st = P["step"]
+    for sp_, sd_, skip in ((0.7, 0.4, ()), (1.0, 1.0, ("dxu", "dzl")), (3.0, 5.0, ())):   # last: clamps at kBarrierMin
+        args = {k: (None if k in skip else st[k]) for k in ("dx", "dxl", "dxu", "dy", "dzl", "dzu")}
+        ri.initialize(P["it"])
+        ri.update(sp_, args["dx"], args["dxl"], args["dxu"], sd_, args["dy"], args["dzl"], args["dzu"])
+        got = oracle.iterate_update(m, n, P["state"], P["it"], sp_, args["dx"], args["dxl"], args["dxu"], sd_,
+                                    args["dy"], args["dzl"], args["dzu"])
+        want = ri.get()
+        for key in want:
+            assert np.array_equal(want[key], got[key]), key
+    # StepToBoundary has no reference object to call (static in ipm.cc): sequential semantics by hand
+    x, dx = P["it"]["xl"][P["state"] == 2], st["dxl"][P["state"] == 2]
+    alpha, blk = oracle.step_to_boundary(x, dx)
+    a, ib = 1.0, -1
+    damp = 1.0 - np.finfo(float).eps
+    for i in range(x.size):
+        if x[i] + a * dx[i] < 0.0:
+            a, ib = -(x[i] * damp) / dx[i], i
+    assert alpha == a and blk == ib and np.all(x + alpha * dx >= 0.0)
