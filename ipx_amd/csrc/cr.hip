@@ -271,6 +271,18 @@ double reduce_partials_host(Context* c, int slot, int count, bool is_max) {
     return v;
 }
 
+// max over the ranks of a host-side flag (blocking; only used when an interrupt callback is set)
+static ipxint agree_on_flag(Context* c, ipxint flag) {
+    ensure_comm_buffers(c);
+    double* d = c->comm_scalars.get() + 61;
+    const double mine = (double)flag;
+    staged_h2d(d, &mine, sizeof(double), c->stream);
+    comm_allreduce_max(c, d, 1);
+    double all = 0.0;
+    staged_d2h(&all, d, sizeof(double), c->stream);
+    return (ipxint)all;
+}
+
 static void ensure_workspaces(Context* c) {
     const size_t m = (size_t)(c->m > 0 ? c->m : 1);
     if (c->v_residual.size() != m) {
@@ -373,7 +385,13 @@ static CrResult run_cr(Context* c, const CrOps& ops, const double* rhs, double t
             IPXK_HIP(hipEventSynchronize(c->ev_window[cw % (kWindow + 1)]));
             if (*(volatile int*)(c->h_cycle_done + cw % kDoneRing)) break;
         }
-        if (interrupt && (interrupt_flag = interrupt(user)) != 0) break;   // :209 / :84
+        if (interrupt) {                                                   // :209 / :84
+            interrupt_flag = interrupt(user);
+            // ranks of a partitioned solve must leave the loop together (a time limit can expire on
+            // one rank first): agree on the largest flag
+            if (comm_active(c)) interrupt_flag = agree_on_flag(c, interrupt_flag);
+            if (interrupt_flag != 0) break;
+        }
         for (long long k = k0; k < k0 + 5 && k <= maxiter; k++) {
             hipLaunchKernelGGL((cr_control_update_kernel<MODE>), dim3(g), dim3(kBlock), 0, s, st, v,
                                res0, res1, pdot_ref, rsdot, c->part(kPartRes0), c->part(kPartRes1),

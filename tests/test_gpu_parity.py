@@ -387,6 +387,13 @@ def test_partitioned_code_path_single_rank(kkt, po, oracle, monkeypatch, columns
     l1, d1 = ctx.normal_apply(rhs)
     l2, d2 = oracle.normal_apply(ocsc(po, A), ko.get()[0], rhs)
     assert relerr(l1, l2) <= 1e-12 and abs(d1 - d2) <= 1e-12 * abs(d2)
+    # interrupt flags are agreed on across ranks (Control::InterruptCheck, conjugate_residuals.cc:209)
+    calls = []
+    x3, y3, it3, e3, _ = ctx.kkt_diag_solve(slab.a, slab.b, tol, 500, interrupt=lambda: calls.append(0) or 0)
+    assert e3 == 0 and it3 == it1 and len(calls) >= 1
+    x4, y4, it4, e4, _ = ctx.kkt_diag_solve(slab.a, slab.b, tol, 500,
+                                            interrupt=lambda: calls.append(1) or (999 if len(calls) > 3 else 0))
+    assert e4 == 999 and it4 < it1
     ctx.close()
 
 
