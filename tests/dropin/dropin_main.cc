@@ -9,11 +9,15 @@
 #include <random>
 #include <vector>
 
+#include "conjugate_residuals.h"
 #include "control.h"
+#include "diagonal_precond.h"
 #include "iterate.h"
 #include "kkt_solver_diag.h"
 #include "kkt_solver_diag_hip.h"
+#include "linear_operators_hip.h"
 #include "model.h"
+#include "normal_matrix.h"
 #include "presolver.h"
 #include "user_model.h"
 
@@ -109,6 +113,44 @@ int main(int argc, char** argv) {
                pass == 0 ? "Factorize(iterate)" : "Factorize(nullptr)", (long)rc.iter, (long)rc.errflag,
                (long)rg.iter, (long)rg.errflag, ey, ex, rc.time_cr1, rg.time_cr1, ok ? "PASS" : "FAIL");
         failures += !ok;
+    }
+    // ---- operator level (reference src/linear_operator.h:10-24): the reference's OWN
+    //      ConjugateResiduals loop, running on the host, applies the operator and the preconditioner
+    //      through LinearOperator& -- once its own NormalMatrix / DiagonalPrecond, once the HIP ones
+    {
+        Vector W(n + m), resscale(m), rhs(m);
+        for (Int j = 0; j < n + m; j++) W[j] = xl[j] / zl[j];
+        for (Int i = 0; i < m; i++) { resscale[i] = 1.0 / std::sqrt(W[n + i]); rhs[i] = uab(rng); }
+        ipx::Info info;
+        ipx::NormalMatrix C_cpu(model);
+        ipx::DiagonalPrecond P_cpu(model);
+        C_cpu.Prepare(&W[0]);
+        P_cpu.Factorize(&W[0], false, &info);
+        ipx::HipModel device(model);
+        ipx::NormalMatrixHip C_hip(device);
+        ipx::DiagonalPrecondHip P_hip(device);
+        C_hip.Prepare(&W[0]);
+        P_hip.Factorize(&W[0], false, &info);
+        // single applications
+        Vector l1(m), l2(m), p1(m), p2(m);
+        double d1 = 0, d2 = 0, e1 = 0, e2 = 0;
+        ipx::LinearOperator &Cc = C_cpu, &Ch = C_hip, &Pc = P_cpu, &Ph = P_hip;
+        Cc.Apply(rhs, l1, &d1); Ch.Apply(rhs, l2, &d2);
+        Pc.Apply(rhs, p1, &e1); Ph.Apply(rhs, p2, &e2);
+        const bool ok_apply = RelErr(l2, l1) <= 1e-12 && RelErr(p2, p1) <= 1e-12 &&
+                              std::abs(d1 - d2) <= 1e-12 * std::abs(d1) && std::abs(e1 - e2) <= 1e-12 * std::abs(e1);
+        // the reference's CR loop over both operator pairs
+        ipx::ConjugateResiduals cr_cpu(control), cr_hip(control);
+        Vector y1(0.0, m), y2(0.0, m);
+        cr_cpu.Solve(Cc, Pc, rhs, tol, &resscale[0], 500, y1);
+        cr_hip.Solve(Ch, Ph, rhs, tol, &resscale[0], 500, y2);
+        const bool ok_cr = cr_cpu.errflag() == cr_hip.errflag() &&
+                           std::labs((long)(cr_cpu.iter() - cr_hip.iter())) <= 2 && RelErr(y2, y1) < 1e-6;
+        printf("LinearOperator: apply relerr %.2e precond relerr %.2e | reference CR loop over reference operators: "
+               "%ld its errflag %ld, over HIP operators: %ld its errflag %ld, y relerr %.2e -> %s\n",
+               RelErr(l2, l1), RelErr(p2, p1), (long)cr_cpu.iter(), (long)cr_cpu.errflag(), (long)cr_hip.iter(),
+               (long)cr_hip.errflag(), RelErr(y2, y1), ok_apply && ok_cr ? "PASS" : "FAIL");
+        failures += !(ok_apply && ok_cr);
     }
     return failures ? 1 : 0;
 }
