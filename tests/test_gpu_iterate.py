@@ -90,3 +90,24 @@ def test_iterate_vs_reference_object(kkt, po, ref):
     c1, c2 = ctx.iterate_complementarity(), ri.complementarity()
     assert c1["mu_min"] == c2["mu_min"] and c1["mu_max"] == c2["mu_max"] and abs(c1["mu"] - c2["mu"]) <= 1e-13 * c2["mu"]
     ctx.close()
+
+
+def test_iterate_error_paths(kkt, monkeypatch):
+    A = synth.synthetic_lp(60, 150, 8, 9)
+    ctx = kkt.KktContext(A)
+    with pytest.raises(kkt.KktError):
+        ctx.iterate_update(1.0, None, None, None, 1.0, None, None, None)      # no iterate set
+    with pytest.raises(kkt.KktError):
+        ctx.iterate_complementarity()
+    st = synth.synthetic_newton_state(60, 150, 9)
+    with pytest.raises(kkt.KktError):                                         # solver not factorized
+        ctx.newton_solve(False, *[st[k] for k in ("rb", "rc", "rl", "ru", "sl", "su", "xl", "xu", "zl", "zu",
+                                                   "state")], 1e-3)
+    # partitioned systems: the device iterate / Newton step are single-GPU offers
+    monkeypatch.setenv("IPXK_FORCE_COMM", "1")
+    ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    assert ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"], precond_dense_cols=False) == 0
+    with pytest.raises(kkt.KktError):
+        ctx.newton_solve(False, *[st[k] for k in ("rb", "rc", "rl", "ru", "sl", "su", "xl", "xu", "zl", "zu",
+                                                   "state")], 1e-3)
+    ctx.close()
