@@ -127,7 +127,7 @@ private:
 constexpr int kBlock = 256;        // threads per workgroup (4 waves)
 constexpr int kChunkNnz = 1024;    // products staged in LDS at a time (4 per thread)
 constexpr int kMaxRowLen = 255;    // longer rows take the long-row path
-constexpr int kLongSeg = 8192;     // nonzeros per segment of a long row
+constexpr int kLongSeg = 2048;     // nonzeros per segment of a long row
 constexpr int kMaxWorkgroups = 1024; // 4 per CU: all co-resident (16 waves/CU)
 constexpr int kMaxPartials = 2048; // upper bound on grid size of reducing kernels
 constexpr int kMaxRT = 8;          // rows per thread per round
