@@ -155,9 +155,34 @@ def gen_basis(ref, name, m, n, seed, num_free, num_fixed):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
 
 
+def gen_iterate(ref, name, m, n, seed):
+    """The reference's ipx::Iterate: states, residuals, complementarity, and Update with two step sizes."""
+    P = synth.synthetic_iterate(m, n, seed)
+    A = P["A"]
+    rm = ref.model(po.Csc(m, n, A.p, A.i, A.x), P["rhs"], P["constr_type"], P["obj"], P["lb"], P["ub"])
+    b, c, lbs, ubs = rm.vectors()
+    ri = rm.iterate()
+    ri.initialize(P["it"])
+    d = dict(m=m, n=n, Ap=A.p, Ai=A.i, Ax=A.x, b=b, c=c, lbs=lbs, ubs=ubs, state=ri.states())
+    d.update({"it_" + k: v for k, v in P["it"].items()})
+    d.update({"step_" + k: v for k, v in P["step"].items()})
+    r = ri.residuals()
+    d.update(rb=r["rb"], rc=r["rc"], rl=r["rl"], ru=r["ru"], presidual=r["presidual"], dresidual=r["dresidual"])
+    comp = ri.complementarity()
+    d.update(complementarity=comp["complementarity"], mu=comp["mu"], mu_min=comp["mu_min"], mu_max=comp["mu_max"])
+    st = P["step"]
+    for tag, sp_, sd_ in (("a", 0.7, 0.4), ("b", 3.0, 5.0)):       # b: truncation at kBarrierMin
+        ri.initialize(P["it"])
+        ri.update(sp_, st["dx"], st["dxl"], st["dxu"], sd_, st["dy"], st["dzl"], st["dzu"])
+        d.update({"upd_%s_%s" % (tag, k): v for k, v in ri.get().items()})
+        d["upd_%s_sp" % tag], d["upd_%s_sd" % tag] = sp_, sd_
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+
+
 def main():
     po.build(ref=True)
     ref = po.Ref()
+    gen_iterate(ref, "iterate_150", 150, 360, seed=14)
     gen_afiro(ref)
     gen_diag(ref, "diag_200", 200, 400, seed=11, num_dense=0)
     gen_diag(ref, "dense_300", 300, 640, seed=12, num_dense=4)

@@ -111,3 +111,30 @@ def test_iterate_error_paths(kkt, monkeypatch):
         ctx.newton_solve(False, *[st[k] for k in ("rb", "rc", "rl", "ru", "sl", "su", "xl", "xu", "zl", "zu",
                                                    "state")], 1e-3)
     ctx.close()
+
+
+def test_golden_iterate_gpu(kkt):
+    """the committed outputs of the reference's ipx::Iterate (tests/golden/iterate_150.npz)"""
+    import os
+    from ipx_amd.synth import CscMatrix
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "iterate_150.npz"))
+    m, n = int(g["m"]), int(g["n"])
+    ctx = kkt.KktContext(CscMatrix(m, n, g["Ap"], g["Ai"], g["Ax"]))
+    it = {k: g["it_" + k] for k in ("x", "xl", "xu", "y", "zl", "zu")}
+    st = {k: g["step_" + k] for k in ("dx", "dxl", "dxu", "dy", "dzl", "dzu")}
+    ctx.iterate_set(it, g["state"])
+    r = ctx.iterate_residuals(g["b"], g["c"], g["lbs"], g["ubs"])
+    for key in ("rb", "rc", "rl", "ru"):
+        assert np.array_equal(r[key], g[key]), key
+    assert r["presidual"] == float(g["presidual"]) and r["dresidual"] == float(g["dresidual"])
+    c = ctx.iterate_complementarity()
+    assert c["mu_min"] == float(g["mu_min"]) and c["mu_max"] == float(g["mu_max"])
+    assert abs(c["mu"] - float(g["mu"])) <= 1e-13 * float(g["mu"])
+    for tag in "ab":
+        ctx.iterate_set(it, g["state"])
+        ctx.iterate_update(float(g["upd_%s_sp" % tag]), st["dx"], st["dxl"], st["dxu"], float(g["upd_%s_sd" % tag]),
+                           st["dy"], st["dzl"], st["dzu"])
+        got = ctx.iterate_get()
+        for key in got:
+            assert np.array_equal(got[key], g["upd_%s_%s" % (tag, key)]), (tag, key)
+    ctx.close()

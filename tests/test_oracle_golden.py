@@ -168,3 +168,27 @@ def test_kkt_basis_solve_property(oracle, po):
     res = x[bar] / colscale[bar] ** 2 + g[bar] - a[bar]
     assert np.abs(res * colscale[bar]).max() < 1e-8
     assert np.abs(g[free] - a[free]).max() < 1e-9
+
+
+def test_golden_iterate(oracle):
+    """ipx::Iterate of the reference (states, ComputeResiduals, ComputeComplementarity, Update incl. the
+    kBarrierMin truncation) -- the oracle reproduces the committed outputs bit for bit."""
+    from oracle import pyoracle as po
+    g = np.load(os.path.join(GOLD, "iterate_150.npz"))
+    m, n = int(g["m"]), int(g["n"])
+    A = po.Csc(m, n, g["Ap"], g["Ai"], g["Ax"])
+    it = {k: g["it_" + k] for k in ("x", "xl", "xu", "y", "zl", "zu")}
+    st = {k: g["step_" + k] for k in ("dx", "dxl", "dxu", "dy", "dzl", "dzu")}
+    r = oracle.iterate_residuals(A, g["state"], g["b"], g["c"], g["lbs"], g["ubs"], it)
+    for key in ("rb", "rc", "rl", "ru"):
+        assert np.array_equal(r[key], g[key]), key
+    assert r["presidual"] == float(g["presidual"]) and r["dresidual"] == float(g["dresidual"])
+    c = oracle.iterate_complementarity(g["state"], it)
+    assert (c["complementarity"], c["mu"], c["mu_min"], c["mu_max"]) == tuple(
+        float(g[k]) for k in ("complementarity", "mu", "mu_min", "mu_max"))
+    for tag in "ab":
+        got = oracle.iterate_update(m, n, g["state"], it, float(g["upd_%s_sp" % tag]), st["dx"], st["dxl"],
+                                    st["dxu"], float(g["upd_%s_sd" % tag]), st["dy"], st["dzl"], st["dzu"])
+        for key in got:
+            assert np.array_equal(got[key], g["upd_%s_%s" % (tag, key)]), (tag, key)
+    assert (g["upd_b_xl"] == 1e-30).any()          # the fixture does exercise the truncation
