@@ -102,10 +102,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    # rehearsal on a one-GPU box: IPXK_COMM=hostshm carries the library's collectives through host shared
+    # memory, all ranks share GPU 0 and torch.distributed runs over gloo (RCCL refuses duplicate devices)
+    rehearsal = os.environ.get("IPXK_COMM") == "hostshm"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    tdev = "cpu" if rehearsal else "cuda"
 
     m, n = args.rows, args.cols
     A = synth.synthetic_lp(m, n, 8, 12345)
@@ -148,7 +157,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -189,9 +198,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "C3 synthetic LP m=%d n=%d 8 nnz/col (nnz=%d), KKTSolverDiag::Solve = diag-precond CR "
+        "config": {"workload": "%ssynthetic LP m=%d n=%d 8 nnz/col (nnz=%d), KKTSolverDiag::Solve = diag-precond CR "
                                "to tol=0.3*sqrt(mu), scaling spread s=%g; rows of AI partitioned over %d GPU(s)"
-                               % (m, n, nnz, args.spread, world),
+                               % ("C3 " if (m, n) == (1000000, 2000000) else "", m, n, nnz, args.spread, world),
                    "cr_iterations_per_solve": it, "errflag": errflag,
                    "cr_iterations_per_sec": it * args.steps / dt,
                    "cr_loop_ms_per_solve": cr_time / args.steps * 1e3},
@@ -206,7 +215,9 @@ def main():
     if (world > 1 or os.environ.get("IPXK_FORCE_COMM")) and not args.no_column_partition:
         # every rank takes part; reported next to the north-star row partition, never as `value`
         out["config"]["column_partition"] = bench_column_partition(kkt, dist, torch, A, st, tol, args, rank, world,
-                                                                   local_rank)
+                                                                   local_rank, tdev)
+    if rehearsal:
+        out["config"]["transport"] = "REHEARSAL: host shared memory instead of RCCL, all ranks on one GPU"
     if rank == 0 and world == 1 and not args.no_banded:
         out["roofline"]["banded_matrix_probe"] = bench_banded(kkt, synth, m, n)
     if rank == 0 and world == 1 and args.basis:
@@ -230,7 +241,7 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_column_partition(kkt, dist, torch, A, st, tol, args, rank, world, local_rank):
+def bench_column_partition(kkt, dist, torch, A, st, tol, args, rank, world, local_rank, tdev="cuda"):
     """The SAME solve with the structural COLUMNS of A partitioned over the ranks (alternative):
     every m-vector and every CR scalar is replicated, the one exchange per NormalMatrix apply is an
     all-reduce of m doubles (half the bytes of the row partition's n doubles, and no scalar exchange)."""
@@ -264,7 +275,7 @@ def bench_column_partition(kkt, dist, torch, A, st, tol, args, rank, world, loca
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     rhs_d, lhs_d = ctx.vector(m, np.random.default_rng(0).standard_normal(m)), ctx.vector(m)

@@ -97,6 +97,7 @@ struct Context {
 
     // ---- multi-GPU ----
     ncclComm* comm = nullptr;
+    struct ShmComm* shm = nullptr;      // test transport over host shared memory (IPXK_COMM=hostshm)
     int rank = 0, nranks = 1;
     int64_t m_global = 0;               // rows of the whole system (sum over ranks)
     bool force_comm = false;
