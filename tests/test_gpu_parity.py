@@ -280,7 +280,7 @@ def test_edge_cases(kkt, po, oracle):
     import scipy.sparse as sp
     from ipx_amd.synth import CscMatrix
     rng = np.random.default_rng(9)
-    for (m, n, dens) in [(1, 1, 1.0), (7, 3, 0.5), (40, 90, 0.05), (300, 17, 0.02), (33, 700, 0.01)]:
+    for (m, n, dens) in [(1, 1, 1.0), (5, 4, 0.0), (7, 3, 0.5), (40, 90, 0.05), (300, 17, 0.02), (33, 700, 0.01)]:
         M = sp.random(m, n, density=dens, random_state=int(rng.integers(1 << 30)), format="csc")
         M.sort_indices()
         A = CscMatrix(m, n, M.indptr, M.indices, M.data)       # has empty rows and columns
