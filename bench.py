@@ -68,7 +68,7 @@ def cpu_baseline(A, st, tol, maxiter):
             if rm.m == m and rm.n == n and not rm.dualized:
                 k = rm.kkt_diag(maxiter=maxiter)
                 k.factorize(np.ones(n + m), st["xl"], st["xu"], np.zeros(m), st["zl"], st["zu"])
-                reps = 3
+                reps = 4
                 t0 = time.perf_counter()
                 for _ in range(reps):
                     x, y, it, err = k.solve(st["a"], st["b"], tol)
