@@ -307,8 +307,27 @@ def bench_newton(kkt, synth, ctx, m, n, args):
         it, err, tm = ctx.newton_solve_resident(False, dev_in, state, tol, args.maxiter, dev_out)
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / K
-    return {"steps_per_sec": 1.0 / dt, "ms_per_step": dt * 1e3, "cr_iterations": it, "errflag": err,
-            "ms_outside_cr_loop": dt * 1e3 - tm.cr * 1e3}
+    res = {"steps_per_sec": 1.0 / dt, "ms_per_step": dt * 1e3, "cr_iterations": it, "errflag": err,
+           "ms_outside_cr_loop": dt * 1e3 - tm.cr * 1e3}
+    # one whole IPM iteration on the device: KKTSolverDiag::Factorize from the resident iterate, then
+    # IPM::Predictor + AddCorrector + StepSizes + MakeStep (src/ipm.cc:340-530)
+    P = synth.synthetic_iterate(m, n, 12345, frac_special=0.0)
+    ctx.set_pointer_mode(False)
+    ctx.iterate_set(P["it"], P["state"])
+    ctx.set_pointer_mode(True)
+    mb = ctx.vector(m, P["rhs"])
+    mc = ctx.vector(N, np.concatenate([P["obj"], np.zeros(m)]))
+    mlb, mub = ctx.vector(N, P["lbs"]), ctx.vector(N, P["ubs"])
+    t0 = time.perf_counter()
+    assert ctx.iterate_factorize_diag() == 0
+    info = ctx.ipm_step_resident(False, mb, mc, mlb, mub, 0.3, args.maxiter)
+    ctx.synchronize()
+    res["ipm_iteration"] = {"ms": (time.perf_counter() - t0) * 1e3,
+                            "kkt_iterations": [info["kktiter_predictor"], info["kktiter_corrector"]],
+                            "errflag": info["errflag"], "step_primal": info["step_primal"],
+                            "step_dual": info["step_dual"],
+                            "note": "Factorize + predictor + corrector + step sizes + update, nothing crosses PCIe"}
+    return res
 
 
 def bench_banded(kkt, synth, m, n):

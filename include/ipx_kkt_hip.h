@@ -243,6 +243,31 @@ int ipxk_step_to_boundary(ipxk_context* ctx, const double* x, const double* dx,
                           ipxint len, double alpha0, double* alpha,
                           ipxint* blocking_index);
 
+/* One predictor-corrector step on the resident iterate: IPM::Predictor,
+ * AddCorrector, StepSizes and MakeStep (src/ipm.cc:340-530) with the factorized
+ * diag solver (use_basis = 0) or the prepared basis solver (1); KKT tolerance
+ * kkt_tol*sqrt(mu) (src/ipm.cc:572, ipx_parameters::kkt_tol = 0.3).  The caller
+ * factorizes for the current iterate first, as IPM::Driver does
+ * (ipxk_iterate_factorize_diag for the diag solver).  b[m], c, lb, ub [n+m]
+ * are the model's vectors.  On errflag != 0 (from a KKT solve) the iterate is
+ * left unchanged. */
+typedef struct ipxk_ipm_step_info {
+    double step_primal, step_dual;   /* IPM::step_primal_, step_dual_ */
+    double mu_before, mu_after;      /* Iterate::mu() before / after the update */
+    double sigma;                    /* centering parameter of the corrector */
+    double presidual, dresidual;     /* of the iterate the step started from */
+    ipxint kktiter_predictor, kktiter_corrector;
+    ipxint errflag;
+} ipxk_ipm_step_info;
+int ipxk_ipm_step(ipxk_context* ctx, int use_basis, const double* b,
+                  const double* c, const double* lb, const double* ub,
+                  double kkt_tol, ipxint maxiter, ipxk_ipm_step_info* info,
+                  ipxk_interrupt_fn interrupt, void* interrupt_user);
+/* KKTSolverDiag::_Factorize (src/kkt_solver_diag.cc:18-65) for the resident
+ * iterate: nothing crosses PCIe. */
+int ipxk_iterate_factorize_diag(ipxk_context* ctx, int precond_dense_cols,
+                                ipxint* errflag);
+
 /* ---- multi-GPU: rows of AI partitioned over ranks, one RCCL all-reduce per
  *      NormalMatrix apply ---------------------------- */
 /* 128-byte RCCL unique id, created on rank 0 and broadcast by the launcher. */

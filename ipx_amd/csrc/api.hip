@@ -594,6 +594,36 @@ int ipxk_step_to_boundary(ipxk_context* c, const double* x, const double* dx, ip
     });
 }
 
+int ipxk_ipm_step(ipxk_context* c, int use_basis, const double* b, const double* cc, const double* lb,
+                  const double* ub, double kkt_tol, ipxint maxiter, ipxk_ipm_step_info* info,
+                  ipxk_interrupt_fn interrupt, void* interrupt_user) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && b && cc && lb && ub && info, "NULL argument");
+        IPXK_REQUIRE(use_basis ? c->split != nullptr : c->kkt_diag_factorized, "KKT solver not factorized");
+        IPXK_REQUIRE(!comm_active(c), "ipxk_ipm_step is not available on a partitioned system");
+        bind_device(c);
+        const size_t m = (size_t)c->m, N = (size_t)(c->n + c->m);
+        const double* db = stage_in(c, b, m, c->nw_in[0]);
+        const double* dc = stage_in(c, cc, N, c->nw_in[1]);
+        const double* dlb = stage_in(c, lb, N, c->nw_in[2]);
+        const double* dub = stage_in(c, ub, N, c->nw_in[3]);
+        ipm_step_dev(c, use_basis != 0, db, dc, dlb, dub, kkt_tol, maxiter, info, interrupt, interrupt_user);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int ipxk_iterate_factorize_diag(ipxk_context* c, int precond_dense_cols, ipxint* errflag) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && errflag && c->it_set, "no iterate on the device (ipxk_iterate_set)");
+        bind_device(c);
+        double comp[4];
+        iterate_complementarity_dev(c, comp);
+        kkt_diag_factorize_dev(c, c->it_xl.get(), c->it_xu.get(), c->it_zl.get(), c->it_zu.get(), comp[1],
+                               precond_dense_cols != 0, errflag);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
 // ---- SplittedNormalMatrix / basis path -------------------------------------------------
 int ipxk_split_prepare(ipxk_context* c, const ipxint* Lp, const ipxint* Li, const double* Lx,
                        const ipxint* Up, const ipxint* Ui, const double* Ux, const ipxint* rowperm,

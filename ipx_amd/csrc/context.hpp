@@ -90,6 +90,7 @@ struct Context {
     DevBuf<double> it_x, it_xl, it_xu, it_y, it_zl, it_zu, it_partials;
     DevBuf<unsigned char> it_state;
     bool it_set = false;
+    DevBuf<double> ipm[12];            // residuals, complementarity targets and the step of ipxk_ipm_step
 
     // ---- basis path ----
     SplitOperator* split = nullptr;
@@ -163,9 +164,13 @@ void iterate_update_dev(Context* c, double sp, const double* dx, const double* d
                         const double* dy, const double* dzl, const double* dzu);
 void iterate_residuals_dev(Context* c, const double* b, const double* cc, const double* lb, const double* ub,
                            double* rb, double* rc, double* rl, double* ru, double* presidual, double* dresidual);
-void iterate_complementarity_dev(Context* c, double out4[4]);
+void iterate_complementarity_dev(Context* c, double out4[4], double* num_terms = nullptr);
 double step_to_boundary_dev(Context* c, const double* x, const double* dx, int64_t len, double alpha0,
                             ipxint* blocking);
+
+// ---- ipm_step.hip ----
+void ipm_step_dev(Context* c, bool use_basis, const double* b, const double* cc, const double* lb, const double* ub,
+                  double kkt_tol, ipxint maxiter, ipxk_ipm_step_info* info, ipxk_interrupt_fn interrupt, void* user);
 
 // ---- kkt_diag.hip ----
 void kkt_diag_factorize_dev(Context* c, const double* xl, const double* xu, const double* zl,

@@ -1,0 +1,180 @@
+// One predictor-corrector step of the IPM on the device     reference src/ipm.cc:340-530
+//   IPM::Predictor (:340-371), IPM::AddCorrector (:373-435), IPM::StepSizes (:437-516),
+//   IPM::MakeStep (:518-530: Iterate::Update)
+// composed from the pieces already resident: the iterate and its residuals (iterate.hip), two
+// Newton solves (newton.hip) around the factorized KKT solver, step-to-boundary reductions, and the
+// complementarity of the trial point.  Only scalars (step lengths, mu, four numbers at the blocking
+// indices) reach the host.  SURVEY.md section 8f, row 3.
+#include "context.hpp"
+#include "device_utils.hpp"
+
+namespace ipxk {
+
+namespace {
+
+int vec_grid(int64_t len) {
+    int64_t g = (len + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    return (int)(g < 1024 ? g : 1024);
+}
+
+__device__ __forceinline__ bool has_lb(unsigned char st) { return st == IPXK_STATE_BARRIER_LB || st == IPXK_STATE_BARRIER_BOXED; }
+__device__ __forceinline__ bool has_ub(unsigned char st) { return st == IPXK_STATE_BARRIER_UB || st == IPXK_STATE_BARRIER_BOXED; }
+
+// sl = -xl.*zl + shift - dxl.*dzl on variables with a lower barrier term, 0 elsewhere; same for su.
+// Predictor: shift = 0, no step (d* == nullptr), ipm.cc:349-366.  Corrector: shift = sigma*mu, :410-428.
+__global__ void complementarity_rhs_kernel(int N, const unsigned char* __restrict__ state,
+                                           const double* __restrict__ xl, const double* __restrict__ xu,
+                                           const double* __restrict__ zl, const double* __restrict__ zu,
+                                           double shift, const double* dxl, const double* dxu, const double* dzl,
+                                           const double* dzu, double* __restrict__ sl, double* __restrict__ su) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+        const unsigned char st = state[j];
+        double l = 0.0, u = 0.0;
+        if (has_lb(st)) l = dxl ? -xl[j] * zl[j] + shift - dxl[j] * dzl[j] : -xl[j] * zl[j];
+        if (has_ub(st)) u = dxu ? -xu[j] * zu[j] + shift - dxu[j] * dzu[j] : -xu[j] * zu[j];
+        sl[j] = l;
+        su[j] = u;
+    }
+}
+
+// sum over the barrier terms of (x + ap*dx)*(z + ad*dz), ipm.cc:394-407 / :459-473
+__global__ __launch_bounds__(kBlock) void trial_complementarity_kernel(int N, const unsigned char* __restrict__ state,
+                                                                       const double* __restrict__ xl,
+                                                                       const double* __restrict__ xu,
+                                                                       const double* __restrict__ zl,
+                                                                       const double* __restrict__ zu,
+                                                                       const double* __restrict__ dxl,
+                                                                       const double* __restrict__ dxu,
+                                                                       const double* __restrict__ dzl,
+                                                                       const double* __restrict__ dzu, double ap,
+                                                                       double ad, double* out) {
+    __shared__ double red[kBlock / 64 + 1];
+    double sum = 0.0;
+    for (int j = blockIdx.x * kBlock + threadIdx.x; j < N; j += gridDim.x * kBlock) {
+        const unsigned char st = state[j];
+        if (has_lb(st)) sum += (xl[j] + ap * dxl[j]) * (zl[j] + ad * dzl[j]);
+        if (has_ub(st)) sum += (xu[j] + ap * dxu[j]) * (zu[j] + ad * dzu[j]);
+    }
+    sum = block_reduce<SumOp>(sum, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = sum;
+}
+
+double trial_complementarity(Context* c, const double* dxl, const double* dxu, const double* dzl, const double* dzu,
+                             double ap, double ad) {
+    const int N = (int)(c->n + c->m);
+    const int g = vec_grid(N);
+    c->it_partials.resize((size_t)4 * 1024);
+    hipLaunchKernelGGL(trial_complementarity_kernel, dim3(g), dim3(kBlock), 0, c->stream, N, c->it_state.get(),
+                       c->it_xl.get(), c->it_xu.get(), c->it_zl.get(), c->it_zu.get(), dxl, dxu, dzl, dzu, ap, ad,
+                       c->it_partials.get());
+    std::vector<double> h(g);
+    c->it_partials.download(h.data(), h.size(), c->stream);
+    double s = 0.0;
+    for (double v : h) s += v;
+    return s;
+}
+
+double element(Context* c, const double* dev, ipxint j) {
+    double v = 0.0;
+    staged_d2h(&v, dev + j, sizeof(double), c->stream);
+    return v;
+}
+
+}  // namespace
+
+void ipm_step_dev(Context* c, bool use_basis, const double* b, const double* cc, const double* lb, const double* ub,
+                  double kkt_tol, ipxint maxiter, ipxk_ipm_step_info* info, ipxk_interrupt_fn interrupt, void* user) {
+    IPXK_REQUIRE(c->it_set, "no iterate on the device (ipxk_iterate_set)");
+    const int n = (int)c->n, m = (int)c->m, N = n + m;
+    hipStream_t s = c->stream;
+    *info = ipxk_ipm_step_info{};
+    for (int k = 0; k < 12; k++) c->ipm[k].resize((size_t)std::max(k == 0 || k == 9 ? m : N, 1));
+    double *rb = c->ipm[0].get(), *rc = c->ipm[1].get(), *rl = c->ipm[2].get(), *ru = c->ipm[3].get();
+    double *sl = c->ipm[4].get(), *su = c->ipm[5].get();
+    double *dx = c->ipm[6].get(), *dxl = c->ipm[7].get(), *dxu = c->ipm[8].get(), *dy = c->ipm[9].get();
+    double *dzl = c->ipm[10].get(), *dzu = c->ipm[11].get();
+    const double *xl = c->it_xl.get(), *xu = c->it_xu.get(), *zl = c->it_zl.get(), *zu = c->it_zu.get();
+    const unsigned char* state = c->it_state.get();
+
+    iterate_residuals_dev(c, b, cc, lb, ub, rb, rc, rl, ru, &info->presidual, &info->dresidual);
+    double comp[4], num_finite = 0.0;
+    iterate_complementarity_dev(c, comp, &num_finite);
+    const double mu = comp[1];
+    info->mu_before = mu;
+    const double tol = kkt_tol * std::sqrt(mu);           // ipm.cc:572
+    const int g = vec_grid(N);
+
+    // ---- Predictor, :340-371
+    hipLaunchKernelGGL(complementarity_rhs_kernel, dim3(g), dim3(kBlock), 0, s, N, state, xl, xu, zl, zu, 0.0,
+                       (const double*)nullptr, (const double*)nullptr, (const double*)nullptr,
+                       (const double*)nullptr, sl, su);
+    CrResult r = newton_solve_dev(c, use_basis, rb, rc, rl, ru, sl, su, xl, xu, zl, zu, state, tol, maxiter, dx, dxl,
+                                  dxu, dy, dzl, dzu, interrupt, user, nullptr);
+    info->kktiter_predictor = r.iter;
+    info->errflag = r.errflag;
+    if (r.errflag) return;
+
+    // ---- AddCorrector, :373-435
+    ipxint blk;
+    double step_xl = step_to_boundary_dev(c, xl, dxl, N, 1.0, &blk);
+    double step_xu = step_to_boundary_dev(c, xu, dxu, N, 1.0, &blk);
+    double step_zl = step_to_boundary_dev(c, zl, dzl, N, 1.0, &blk);
+    double step_zu = step_to_boundary_dev(c, zu, dzu, N, 1.0, &blk);
+    double maxp = std::min(step_xl, step_xu), maxd = std::min(step_zl, step_zu);
+    IPXK_REQUIRE(num_finite > 0.0, "the iterate has no barrier term");
+    const double muaff = trial_complementarity(c, dxl, dxu, dzl, dzu, maxp, maxd) / num_finite;
+    const double ratio = muaff / mu;
+    const double sigma = ratio * ratio * ratio;
+    info->sigma = sigma;
+    hipLaunchKernelGGL(complementarity_rhs_kernel, dim3(g), dim3(kBlock), 0, s, N, state, xl, xu, zl, zu, sigma * mu,
+                       (const double*)dxl, (const double*)dxu, (const double*)dzl, (const double*)dzu, sl, su);
+    r = newton_solve_dev(c, use_basis, rb, rc, rl, ru, sl, su, xl, xu, zl, zu, state, tol, maxiter, dx, dxl, dxu, dy,
+                         dzl, dzu, interrupt, user, nullptr);
+    info->kktiter_corrector = r.iter;
+    info->errflag = r.errflag;
+    if (r.errflag) return;
+
+    // ---- StepSizes, :437-516
+    const double gammaf = 0.9, gammaa = 1.0 / (1.0 - gammaf);
+    ipxint block_xl, block_xu, block_zl, block_zu;
+    step_xl = step_to_boundary_dev(c, xl, dxl, N, 1.0, &block_xl);
+    step_xu = step_to_boundary_dev(c, xu, dxu, N, 1.0, &block_xu);
+    step_zl = step_to_boundary_dev(c, zl, dzl, N, 1.0, &block_zl);
+    step_zu = step_to_boundary_dev(c, zu, dzu, N, 1.0, &block_zu);
+    maxp = std::fmin(step_xl, step_xu);
+    maxd = std::fmin(step_zl, step_zu);
+    double mufull = trial_complementarity(c, dxl, dxu, dzl, dzu, maxp, maxd) / num_finite;
+    mufull /= gammaa;
+    double alphap = 1.0, alphad = 1.0;
+    if (maxp < 1.0) {
+        const bool lower = step_xl <= step_xu;
+        const ipxint bp = lower ? block_xl : block_xu;
+        const double z = element(c, lower ? zl : zu, bp), dz = element(c, lower ? dzl : dzu, bp);
+        const double x = element(c, lower ? xl : xu, bp), d = element(c, lower ? dxl : dxu, bp);
+        const double buffer = mufull / (z + maxd * dz);
+        alphap = (x - buffer) / (-d);
+        alphap = std::max(alphap, gammaf * maxp);
+        alphap = std::min(alphap, 1.0);
+    }
+    if (maxd < 1.0) {
+        const bool lower = step_zl <= step_zu;
+        const ipxint bd = lower ? block_zl : block_zu;
+        const double x = element(c, lower ? xl : xu, bd), d = element(c, lower ? dxl : dxu, bd);
+        const double z = element(c, lower ? zl : zu, bd), dz = element(c, lower ? dzl : dzu, bd);
+        const double buffer = mufull / (x + maxp * d);
+        alphad = (z - buffer) / (-dz);
+        alphad = std::max(alphad, gammaf * maxd);
+        alphad = std::min(alphad, 1.0);
+    }
+    info->step_primal = std::min(alphap, 1.0 - 1e-6);
+    info->step_dual = std::min(alphad, 1.0 - 1e-6);
+
+    // ---- MakeStep, :518-530
+    iterate_update_dev(c, info->step_primal, dx, dxl, dxu, info->step_dual, dy, dzl, dzu);
+    iterate_complementarity_dev(c, comp);
+    info->mu_after = comp[1];
+    IPXK_HIP(hipGetLastError());
+}
+
+}  // namespace ipxk

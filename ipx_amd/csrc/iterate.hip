@@ -176,7 +176,7 @@ void iterate_residuals_dev(Context* c, const double* b, const double* cc, const 
     if (dresidual) *dresidual = d;
 }
 
-void iterate_complementarity_dev(Context* c, double out4[4]) {
+void iterate_complementarity_dev(Context* c, double out4[4], double* num_terms) {
     IPXK_REQUIRE(c->it_set, "no iterate on the device (ipxk_iterate_set)");
     const int N = (int)(c->n + c->m);
     const int g = vec_grid(N);
@@ -194,6 +194,7 @@ void iterate_complementarity_dev(Context* c, double out4[4]) {
     double mu = 0.0;
     if (cnt > 0) mu = sum / cnt; else mn = 0.0;
     out4[0] = sum; out4[1] = mu; out4[2] = mn; out4[3] = mx;
+    if (num_terms) *num_terms = cnt;
 }
 
 double step_to_boundary_dev(Context* c, const double* x, const double* dx, int64_t len, double alpha0,

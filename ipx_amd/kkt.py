@@ -31,11 +31,17 @@ EXPORTS = [
     "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_apply", "ipxk_forward_solve",
     "ipxk_backward_solve", "ipxk_solve_dense", "ipxk_split_levels", "ipxk_cr_solve",
     "ipxk_kkt_basis_solve", "ipxk_newton_solve", "ipxk_iterate_set", "ipxk_iterate_get", "ipxk_iterate_update",
-    "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns",
+    "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_ipm_step", "ipxk_iterate_factorize_diag", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns",
     "ipxk_time_normal_apply",
     "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
     "ipxk_dev_download",
 ]
+
+
+class IpmStepInfo(C.Structure):
+    _fields_ = [("step_primal", c_f64), ("step_dual", c_f64), ("mu_before", c_f64), ("mu_after", c_f64),
+                ("sigma", c_f64), ("presidual", c_f64), ("dresidual", c_f64), ("kktiter_predictor", c_i64),
+                ("kktiter_corrector", c_i64), ("errflag", c_i64)]
 
 
 class Times(C.Structure):
@@ -355,6 +361,27 @@ class KktContext:
         self._check(self.lib.ipxk_step_to_boundary(self.h, _fp(x), _fp(dx), c_i64(x.size), c_f64(alpha0),
                                                    C.byref(alpha), C.byref(blk)))
         return alpha.value, int(blk.value)
+
+    def iterate_factorize_diag(self, precond_dense_cols=True):
+        err = c_i64(0)
+        self._check(self.lib.ipxk_iterate_factorize_diag(self.h, C.c_int(1 if precond_dense_cols else 0),
+                                                         C.byref(err)))
+        return int(err.value)
+
+    def ipm_step(self, use_basis, b, c, lb, ub, kkt_tol=0.3, maxiter=-1):
+        """One predictor-corrector step on the resident iterate (host model vectors)."""
+        info = IpmStepInfo()
+        self._check(self.lib.ipxk_ipm_step(self.h, C.c_int(1 if use_basis else 0), _fp(_F(b)), _fp(_F(c)),
+                                           _fp(_F(lb)), _fp(_F(ub)), c_f64(kkt_tol), c_i64(maxiter),
+                                           C.byref(info), C.cast(None, INTERRUPT_FN), None))
+        return {name: getattr(info, name) for name, _ in IpmStepInfo._fields_}
+
+    def ipm_step_resident(self, use_basis, b_dev, c_dev, lb_dev, ub_dev, kkt_tol=0.3, maxiter=-1):
+        info = IpmStepInfo()
+        self._check(self.lib.ipxk_ipm_step(self.h, C.c_int(1 if use_basis else 0), b_dev.as_arg(), c_dev.as_arg(),
+                                           lb_dev.as_arg(), ub_dev.as_arg(), c_f64(kkt_tol), c_i64(maxiter),
+                                           C.byref(info), C.cast(None, INTERRUPT_FN), None))
+        return {name: getattr(info, name) for name, _ in IpmStepInfo._fields_}
 
     def kkt_diag_get(self):
         W, rs = np.zeros(self.n + self.m, f64), np.zeros(self.m, f64)

@@ -1097,3 +1097,112 @@ extern "C" double orc_step_to_boundary(Int len, const double* x, const double* d
     if (blocking_index) *blocking_index = iblock;
     return alpha;
 }
+
+// ---------------------------------------------------------------------------
+// One IPM step: IPM::Predictor, AddCorrector, StepSizes, MakeStep
+// (src/ipm.cc:340-530) around KKTSolverDiag.  PARITY UNPINNED (ipm.cc cannot be
+// linked here); a restatement line by line, built from the pinned pieces above.
+// info: step_primal, step_dual, mu_before, mu_after, sigma, kktiter_predictor,
+//       kktiter_corrector  (7 doubles)
+// ---------------------------------------------------------------------------
+extern "C" Int orc_ipm_step_diag(orc_kkt_diag* K, const unsigned char* state,
+    const double* b, const double* c, const double* lb, const double* ub,
+    double* x, double* xl, double* xu, double* y, double* zl, double* zu,
+    double kkt_tol, double* info) {
+    const Int m = K->m, n = K->n, N = n + m;
+    Vec rb(m), rc(N), rl(N), ru(N), sl(N), su(N), dx(N), dxl(N), dxu(N), dy(m), dzl(N), dzu(N);
+    double norms[2], comp[4];
+    orc_iterate_residuals(m, n, K->Ap, K->Ai, K->Ax, state, b, c, lb, ub, x, xl, xu, y, zl, zu,
+                          rb.data(), rc.data(), rl.data(), ru.data(), norms);
+    orc_iterate_complementarity(N, state, xl, xu, zl, zu, comp);
+    const double mu = comp[1];
+    info[2] = mu;
+    const double tol = kkt_tol * std::sqrt(mu);
+    auto has_lb = [&](Int j) { return state[j] == 2 || state[j] == 4; };
+    auto has_ub = [&](Int j) { return state[j] == 3 || state[j] == 4; };
+    // Predictor :340-371
+    for (Int j = 0; j < N; j++) sl[j] = has_lb(j) ? -xl[j] * zl[j] : 0.0;
+    for (Int j = 0; j < N; j++) su[j] = has_ub(j) ? -xu[j] * zu[j] : 0.0;
+    Int iter = 0;
+    Int err = orc_newton_solve_diag(K, rb.data(), rc.data(), rl.data(), ru.data(), sl.data(), su.data(),
+                                    xl, xu, zl, zu, state, tol, dx.data(), dxl.data(), dxu.data(),
+                                    dy.data(), dzl.data(), dzu.data(), &iter);
+    info[5] = (double)iter;
+    if (err) return err;
+    // AddCorrector :373-435
+    double step_xl = orc_step_to_boundary(N, xl, dxl.data(), 1.0, nullptr);
+    double step_xu = orc_step_to_boundary(N, xu, dxu.data(), 1.0, nullptr);
+    double step_zl = orc_step_to_boundary(N, zl, dzl.data(), 1.0, nullptr);
+    double step_zu = orc_step_to_boundary(N, zu, dzu.data(), 1.0, nullptr);
+    double maxp = std::min(step_xl, step_xu), maxd = std::min(step_zl, step_zu);
+    double muaff = 0.0;
+    Int num_finite = 0;
+    for (Int j = 0; j < N; j++) {
+        if (has_lb(j)) { muaff += (xl[j] + maxp * dxl[j]) * (zl[j] + maxd * dzl[j]); num_finite++; }
+        if (has_ub(j)) { muaff += (xu[j] + maxp * dxu[j]) * (zu[j] + maxd * dzu[j]); num_finite++; }
+    }
+    muaff /= num_finite;
+    const double ratio = muaff / mu;
+    const double sigma = ratio * ratio * ratio;
+    info[4] = sigma;
+    for (Int j = 0; j < N; j++) sl[j] = has_lb(j) ? -xl[j] * zl[j] + sigma * mu - dxl[j] * dzl[j] : 0.0;
+    for (Int j = 0; j < N; j++) su[j] = has_ub(j) ? -xu[j] * zu[j] + sigma * mu - dxu[j] * dzu[j] : 0.0;
+    err = orc_newton_solve_diag(K, rb.data(), rc.data(), rl.data(), ru.data(), sl.data(), su.data(),
+                                xl, xu, zl, zu, state, tol, dx.data(), dxl.data(), dxu.data(),
+                                dy.data(), dzl.data(), dzu.data(), &iter);
+    info[6] = (double)iter;
+    if (err) return err;
+    // StepSizes :437-516
+    const double gammaf = 0.9, gammaa = 1.0 / (1.0 - gammaf);
+    Int block_xl, block_xu, block_zl, block_zu;
+    step_xl = orc_step_to_boundary(N, xl, dxl.data(), 1.0, &block_xl);
+    step_xu = orc_step_to_boundary(N, xu, dxu.data(), 1.0, &block_xu);
+    step_zl = orc_step_to_boundary(N, zl, dzl.data(), 1.0, &block_zl);
+    step_zu = orc_step_to_boundary(N, zu, dzu.data(), 1.0, &block_zu);
+    maxp = std::fmin(step_xl, step_xu);
+    maxd = std::fmin(step_zl, step_zu);
+    double mufull = 0.0;
+    for (Int j = 0; j < N; j++) {
+        if (has_lb(j)) mufull += (xl[j] + maxp * dxl[j]) * (zl[j] + maxd * dzl[j]);
+        if (has_ub(j)) mufull += (xu[j] + maxp * dxu[j]) * (zu[j] + maxd * dzu[j]);
+    }
+    mufull /= num_finite;
+    mufull /= gammaa;
+    double alphap = 1.0, alphad = 1.0;
+    if (maxp < 1.0) {
+        double buffer;
+        if (step_xl <= step_xu) {
+            const Int bp = block_xl;
+            buffer = mufull / (zl[bp] + maxd * dzl[bp]);
+            alphap = (xl[bp] - buffer) / (-dxl[bp]);
+        } else {
+            const Int bp = block_xu;
+            buffer = mufull / (zu[bp] + maxd * dzu[bp]);
+            alphap = (xu[bp] - buffer) / (-dxu[bp]);
+        }
+        alphap = std::max(alphap, gammaf * maxp);
+        alphap = std::min(alphap, 1.0);
+    }
+    if (maxd < 1.0) {
+        double buffer;
+        if (step_zl <= step_zu) {
+            const Int bd = block_zl;
+            buffer = mufull / (xl[bd] + maxp * dxl[bd]);
+            alphad = (zl[bd] - buffer) / (-dzl[bd]);
+        } else {
+            const Int bd = block_zu;
+            buffer = mufull / (xu[bd] + maxp * dxu[bd]);
+            alphad = (zu[bd] - buffer) / (-dzu[bd]);
+        }
+        alphad = std::max(alphad, gammaf * maxd);
+        alphad = std::min(alphad, 1.0);
+    }
+    const double sp = std::min(alphap, 1.0 - 1e-6), sd = std::min(alphad, 1.0 - 1e-6);
+    info[0] = sp; info[1] = sd;
+    // MakeStep :518-530
+    orc_iterate_update(m, n, state, x, xl, xu, y, zl, zu, sp, dx.data(), dxl.data(), dxu.data(), sd,
+                       dy.data(), dzl.data(), dzu.data());
+    orc_iterate_complementarity(N, state, xl, xu, zl, zu, comp);
+    info[3] = comp[1];
+    return 0;
+}

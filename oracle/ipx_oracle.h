@@ -199,6 +199,13 @@ void orc_iterate_complementarity(orc_int N, const unsigned char* state, const do
 double orc_step_to_boundary(orc_int len, const double* x, const double* dx, double alpha,
                             orc_int* blocking_index);
 
+/* IPM::Predictor + AddCorrector + StepSizes + MakeStep (src/ipm.cc:340-530); parity unpinned.
+ * The iterate is updated in place; info[7] = step_primal, step_dual, mu_before, mu_after, sigma,
+ * kktiter_predictor, kktiter_corrector.  Returns the errflag of the KKT solves. */
+orc_int orc_ipm_step_diag(orc_kkt_diag* K, const unsigned char* state, const double* b,
+    const double* c, const double* lb, const double* ub, double* x, double* xl, double* xu,
+    double* y, double* zl, double* zu, double kkt_tol, double* info);
+
 #ifdef __cplusplus
 }
 #endif

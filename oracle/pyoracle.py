@@ -88,7 +88,7 @@ class Oracle:
         for name in ("orc_find_dense_columns", "orc_diag_num_dense", "orc_dpotrf_lower",
                      "orc_pcr_solve", "orc_cr_solve", "orc_kkt_diag_factorize",
                      "orc_kkt_diag_solve", "orc_trisolve", "orc_split_get_sizes",
-                     "orc_kkt_basis_solve", "orc_newton_solve_diag", "orc_newton_solve_basis"):
+                     "orc_kkt_basis_solve", "orc_newton_solve_diag", "orc_newton_solve_basis", "orc_ipm_step_diag"):
             getattr(L, name).restype = c_i64
         for name in ("orc_diag_factorize", "orc_kkt_diag_new", "orc_split_prepare"):
             getattr(L, name).restype = C.c_void_p
@@ -327,6 +327,20 @@ class OracleKktDiag:
             C.byref(it))
         out.update(iter=int(it.value), errflag=int(err))
         return out
+
+    def ipm_step(self, state, b, c, lb, ub, it, kkt_tol=0.3):
+        """IPM::Predictor/AddCorrector/StepSizes/MakeStep (src/ipm.cc:340-530); returns (new iterate, info)."""
+        out = {k: _F(it[k]).copy() for k in ("x", "xl", "xu", "y", "zl", "zu")}
+        st = np.ascontiguousarray(state, dtype=np.uint8)
+        info = np.zeros(7, f64)
+        err = self.orc.lib.orc_ipm_step_diag(self.h, st.ctypes.data_as(C.POINTER(C.c_ubyte)), _fp(_F(b)), _fp(_F(c)),
+                                             _fp(_F(lb)), _fp(_F(ub)),
+                                             *[_fp(out[k]) for k in ("x", "xl", "xu", "y", "zl", "zu")],
+                                             c_f64(kkt_tol), _fp(info))
+        keys = ("step_primal", "step_dual", "mu_before", "mu_after", "sigma", "kktiter_predictor", "kktiter_corrector")
+        d = dict(zip(keys, (float(v) for v in info)))
+        d["errflag"] = int(err)
+        return out, d
 
     def get(self):
         W = np.zeros(self.n + self.m, f64)

@@ -23,3 +23,28 @@ def test_oracle_newton_equations(oracle):
     o0 = k.newton_solve(None, None, None, None, *args[4:], tol)
     st0 = dict(st, rb=np.zeros(m), rc=np.zeros(n + m), rl=np.zeros(n + m), ru=np.zeros(n + m))
     check_newton_equations(A.with_identity().to_scipy(), st0, o0, tol)
+
+
+def test_oracle_ipm_step_properties(oracle):
+    """IPM::Predictor/AddCorrector/StepSizes/MakeStep restated (src/ipm.cc:340-530): a few steps from an
+    infeasible interior start keep the barrier variables positive, take steps in (0, 1) and reduce both
+    residual norms."""
+    from oracle import pyoracle as po
+    m, n = 200, 480
+    P = synth.synthetic_iterate(m, n, 45)
+    A, state = P["A"], P["state"]
+    Ao = po.Csc(m, n, A.p, A.i, A.x)
+    b, c = P["rhs"], np.concatenate([P["obj"], np.zeros(m)])
+    it = P["it"]
+    k = oracle.kkt_diag(Ao, maxiter=2000)
+    r0 = oracle.iterate_residuals(Ao, state, b, c, P["lbs"], P["ubs"], it)
+    for _ in range(4):
+        comp = oracle.iterate_complementarity(state, it)
+        assert k.factorize(it["xl"], it["xu"], it["zl"], it["zu"], comp["mu"]) == 0
+        it, info = k.ipm_step(state, b, c, P["lbs"], P["ubs"], it)
+        assert info["errflag"] == 0 and 0.0 < info["step_primal"] < 1.0 and 0.0 < info["step_dual"] < 1.0
+        assert 0.0 < info["sigma"] <= 1.0 + 1e-12
+    lbm, ubm = (state == 2) | (state == 4), (state == 3) | (state == 4)
+    assert (it["xl"][lbm] > 0).all() and (it["zl"][lbm] > 0).all() and (it["xu"][ubm] > 0).all() and (it["zu"][ubm] > 0).all()
+    r1 = oracle.iterate_residuals(Ao, state, b, c, P["lbs"], P["ubs"], it)
+    assert r1["presidual"] < r0["presidual"] and r1["dresidual"] < r0["dresidual"]
