@@ -175,7 +175,8 @@ def main():
     # L2<->fabric bytes per apply from the PMC passes of the same command (profiles/, separate
     # rocprofv3 --pmc runs; bench.py cannot collect counters on itself)
     layouts, tuned_us = ctx.spmv_layout()
-    kernel_names = {"phased": "spmv_phased_kernel", "sliced": "spmv_sliced_tile_kernel+spmv_sliced_combine_kernel"}
+    kernel_names = {"phased": "spmv_phased_kernel", "sliced": "spmv_sliced_tile_kernel+spmv_sliced_combine_kernel",
+                    "fused": "spmv_sliced_tile_kernel<fused>"}
     traffic = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -341,9 +342,11 @@ def bench_banded(kkt, synth, m, n):
     ctx.time_normal_apply(rhs, lhs, 5)
     ms = ctx.time_normal_apply(rhs, lhs, 50) / 50
     nbytes = ctx.normal_apply_bytes
+    layouts = ctx.spmv_layout()[0]
     ctx.close()
     return {"us_per_apply": ms * 1e3, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9,
-            "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "matrix": "8 rows per column within a 4096-row band"}
+            "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "matrix": "8 rows per column within a 4096-row band",
+            "layouts": list(layouts)}
 
 
 def bench_basis(kkt, synth, m, n, args):

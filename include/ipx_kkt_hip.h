@@ -294,11 +294,12 @@ int ipxk_time_normal_apply(ipxk_context* ctx, const double* rhs_dev,
 ipxint ipxk_normal_apply_bytes(const ipxk_context* ctx);
 /* Which device layout the two sparse products of NormalMatrix::_Apply
  * (normal_matrix.cc:45-126) use on this model: layout[0] for t = W.*(A'y),
- * layout[1] for lhs = A t; 0 = phased (time-tiled), 1 = XCD-sliced tiles.  The
- * choice is made once at ipxk_create by timing both (IPXK_SPMV_LAYOUT=phased|
- * sliced overrides); us[4] receives the measured microseconds
- * {pass1 phased, pass1 sliced, pass2 phased, pass2 sliced} (0 = not timed). */
-int ipxk_spmv_layout(const ipxk_context* ctx, int layout[2], double us[4]);
+ * layout[1] for lhs = A t; 0 = phased (time-tiled), 1 = XCD-sliced tiles,
+ * 2 = fused tiles (one slice, epilogue in the tile kernel).  The choice is made
+ * once at ipxk_create by timing the eligible ones (IPXK_SPMV_LAYOUT=phased|
+ * sliced|fused overrides); us[6] receives the measured microseconds
+ * {pass1 phased, sliced, fused, pass2 phased, sliced, fused} (0 = not timed). */
+int ipxk_spmv_layout(const ipxk_context* ctx, int layout[2], double us[6]);
 /* plain device allocation helpers so that callers without torch can hold
  * resident vectors */
 int ipxk_dev_alloc(ipxk_context* ctx, ipxint bytes, void** ptr);

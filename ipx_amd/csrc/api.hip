@@ -783,14 +783,15 @@ ipxint ipxk_normal_apply_bytes(const ipxk_context* c) {
     return 2 * c->nnz * (wi + 8) + (c->n + c->m + 2) * wi + 8 * (3 * c->n + 4 * c->m);
 }
 
-int ipxk_spmv_layout(const ipxk_context* c, int layout[2], double us[4]) {
+int ipxk_spmv_layout(const ipxk_context* c, int layout[2], double us[6]) {
     return guarded([&] {
         IPXK_REQUIRE(c && layout, "bad argument");
-        layout[0] = c->Acols.use_sliced ? 1 : 0;
-        layout[1] = c->Arows.use_sliced ? 1 : 0;
+        auto code = [](const GatherMatrix& M) { return !M.use_sliced ? 0 : M.sliced.nslices == 1 ? 2 : 1; };
+        layout[0] = code(c->Acols);
+        layout[1] = code(c->Arows);
         if (us) {
-            us[0] = c->Acols.tuned_us_phased; us[1] = c->Acols.tuned_us_sliced;
-            us[2] = c->Arows.tuned_us_phased; us[3] = c->Arows.tuned_us_sliced;
+            us[0] = c->Acols.tuned_us_phased; us[1] = c->Acols.tuned_us_sliced; us[2] = c->Acols.tuned_us_fused;
+            us[3] = c->Arows.tuned_us_phased; us[4] = c->Arows.tuned_us_sliced; us[5] = c->Arows.tuned_us_fused;
         }
     });
 }

@@ -217,15 +217,20 @@ struct GatherMatrix {
     // auto times both once at build time on this matrix and keeps the faster one)
     SlicedMatrix sliced;
     bool use_sliced = false;
-    float tuned_us_phased = 0.f, tuned_us_sliced = 0.f;
-    void build_sliced(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s);
+    float tuned_us_phased = 0.f, tuned_us_sliced = 0.f, tuned_us_fused = 0.f;
+    // ns_request: 0 = as many slices as x needs (>= 2), 1 = the fused single-slice variant
+    void build_sliced(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s, int ns_request);
     SlicedView sliced_view() const;
+    int fused_grid() const { return std::min(sliced.nrb, kMaxPartials); }
     int combine_grid() const { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, ((int64_t)nrows + kBlock - 1) / kBlock)); }
 
     GatherView view() const;
     int grid() const { return G; }
     // # dot partials a launch produces
-    int num_partials() const { return use_sliced ? combine_grid() : G + (nlong > 0 ? 1 : 0); }
+    int num_partials() const {
+        if (!use_sliced) return G + (nlong > 0 ? 1 : 0);
+        return sliced.nslices == 1 ? fused_grid() : combine_grid();   // fused: one dot partial per workgroup
+    }
 };
 
 // elements of the gathered vector per phase (IPXK_SLICE_KB overrides, default 1 MiB)

@@ -165,56 +165,74 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
     }
     IPXK_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
 
-    // second layout + choice
+    // alternative layouts + choice
     use_sliced = false;
     sliced = SlicedMatrix();
     std::string layout = "auto";
     if (const char* e = getenv("IPXK_SPMV_LAYOUT")) layout = e;
-    if (layout != "phased") build_sliced(hptr, hidx, hval, s);
-    if (sliced.built) {
-        if (layout == "sliced") {
-            use_sliced = true;
-        } else {
-            // time both on this matrix (the gathered values do not matter for the memory system)
-            DevBuf<double> tx((size_t)std::max(ncols, 1)), tout((size_t)std::max(nrows, 1));
-            IPXK_HIP(hipMemsetAsync(tx.get(), 0, tx.size() * sizeof(double), s));
-            hipEvent_t e0, e1;
-            IPXK_HIP(hipEventCreate(&e0));
-            IPXK_HIP(hipEventCreate(&e1));
-            EpiScale epi{{}, nullptr, tout.get()};
-            float best[2] = {0.f, 0.f};
-            for (int which = 0; which < 2; which++) {
-                use_sliced = which == 1;
-                const int reps = 5;
-                for (int w = 0; w < 2; w++) launch_spmv(*this, tx.get(), epi, nullptr, nullptr, s);
-                IPXK_HIP(hipEventRecord(e0, s));
-                for (int r = 0; r < reps; r++) launch_spmv(*this, tx.get(), epi, nullptr, nullptr, s);
-                IPXK_HIP(hipEventRecord(e1, s));
-                IPXK_HIP(hipEventSynchronize(e1));
-                float ms = 0.f;
-                IPXK_HIP(hipEventElapsedTime(&ms, e0, e1));
-                best[which] = ms * 1e3f / reps;
-            }
-            IPXK_HIP(hipEventDestroy(e0));
-            IPXK_HIP(hipEventDestroy(e1));
-            tuned_us_phased = best[0];
-            tuned_us_sliced = best[1];
-            use_sliced = best[1] < 0.95f * best[0];
-            if (!use_sliced) sliced = SlicedMatrix();   // release the unused copy
-            if (getenv("IPXK_VERBOSE"))
-                fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld: phased %.1f us, sliced %.1f us -> %s\n", nrows,
-                        ncols, (long long)nnz, best[0], best[1], use_sliced ? "sliced" : "phased");
-        }
+    if (layout == "phased") return;
+    if (layout == "sliced" || layout == "fused") {
+        build_sliced(hptr, hidx, hval, s, layout == "fused" ? 1 : 0);
+        use_sliced = sliced.built;
+        return;
     }
+    // auto: time every eligible layout on this matrix (the gathered values do not matter for the
+    // memory system) and keep the fastest; the phased layout wins ties (5 % margin)
+    DevBuf<double> tx((size_t)std::max(ncols, 1)), tout((size_t)std::max(nrows, 1));
+    IPXK_HIP(hipMemsetAsync(tx.get(), 0, tx.size() * sizeof(double), s));
+    hipEvent_t e0, e1;
+    IPXK_HIP(hipEventCreate(&e0));
+    IPXK_HIP(hipEventCreate(&e1));
+    EpiScale epi{{}, nullptr, tout.get()};
+    auto time_current = [&]() {
+        const int reps = 5;
+        for (int w = 0; w < 2; w++) launch_spmv(*this, tx.get(), epi, nullptr, nullptr, s);
+        IPXK_HIP(hipEventRecord(e0, s));
+        for (int r = 0; r < reps; r++) launch_spmv(*this, tx.get(), epi, nullptr, nullptr, s);
+        IPXK_HIP(hipEventRecord(e1, s));
+        IPXK_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        IPXK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        return ms * 1e3f / reps;
+    };
+    // small matrices: a few microseconds either way, not worth two more copies of the matrix
+    if (nnz >= (1 << 16)) {
+        tuned_us_phased = time_current();
+        float best = 0.95f * tuned_us_phased;
+        SlicedMatrix keep;
+        for (int variant = 0; variant < 2; variant++) {      // 0: fused single slice, 1: XCD slices
+            sliced = SlicedMatrix();
+            build_sliced(hptr, hidx, hval, s, variant == 0 ? 1 : 0);
+            if (!sliced.built) continue;
+            use_sliced = true;
+            const float us = time_current();
+            use_sliced = false;
+            (variant == 0 ? tuned_us_fused : tuned_us_sliced) = us;
+            if (us < best) { best = us; keep = std::move(sliced); }
+        }
+        sliced = std::move(keep);
+        use_sliced = sliced.built;
+        if (getenv("IPXK_VERBOSE"))
+            fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld: phased %.1f us, fused %.1f us, sliced %.1f us -> %s\n",
+                    nrows, ncols, (long long)nnz, tuned_us_phased, tuned_us_fused, tuned_us_sliced,
+                    !use_sliced ? "phased" : sliced.nslices == 1 ? "fused" : "sliced");
+    }
+    IPXK_HIP(hipEventDestroy(e0));
+    IPXK_HIP(hipEventDestroy(e1));
 }
 
 // Sliced layout (internal.hpp).  Eligible when x does not fit an XCD's L2, no row is "long" and
 // every tile fits the LDS staging buffer.
-void GatherMatrix::build_sliced(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s) {
+void GatherMatrix::build_sliced(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s,
+                                int ns_request) {
     const int64_t x_bytes = (int64_t)ncols * 8;
-    if (nlong > 0 || nrows == 0 || nnz == 0 || x_bytes <= (int64_t(4) << 20)) return;
-    int ns = 2;
-    while (ns < 8 && x_bytes > (int64_t)ns * (int64_t(2) << 20)) ns *= 2;
+    if (nlong > 0 || nrows == 0 || nnz == 0 || ncols == 0) return;
+    int ns = 1;
+    if (ns_request != 1) {
+        if (x_bytes <= (int64_t(4) << 20)) return;      // x fits an XCD's L2: nothing to slice
+        ns = 2;
+        while (ns < 8 && x_bytes > (int64_t)ns * (int64_t(2) << 20)) ns *= 2;
+    }
     const int64_t slice = ((ncols + ns - 1) / ns + 15) / 16 * 16;
     // rows per tile: as many as fit the LDS staging buffer (a matrix whose rows concentrate in one
     // slice, e.g. a banded one, needs smaller tiles than a uniformly random one)
@@ -277,7 +295,7 @@ void GatherMatrix::build_sliced(const ipxint* hptr, const ipxint* hidx, const do
     sliced.cnt.upload(cnt, s);
     sliced.idx.upload(ti, s);
     sliced.val.upload(tv, s);
-    sliced.partial.resize((size_t)ns * sliced.nrows_pad);
+    sliced.partial.resize(ns > 1 ? (size_t)ns * sliced.nrows_pad : 1);
     IPXK_HIP(hipStreamSynchronize(s));
     sliced.built = true;
 }

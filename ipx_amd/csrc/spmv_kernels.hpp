@@ -325,71 +325,102 @@ __global__ __launch_bounds__(kBlock) void spmv_long_fixup_kernel(GatherView M, E
 // One tile per workgroup: the tile's entries are streamed with coalesced loads (8 in flight per
 // thread, gathers issued together), their products are staged in LDS, then every thread adds up
 // the products of its 4 consecutive rows in storage order and writes the 4 partial sums (32 B).
-template <class Epi, int RPT>
+// FUSED (one slice = the whole index space): no partial vectors and no combine launch; the thread
+// starts each row from epi.init, adds the row's products in storage order (the reference's order,
+// bit for bit) and applies epi.finish itself; the tile's dot partial goes to dot_partials[tile].
+template <class Epi, int RPT, bool FUSED>
 __global__ __launch_bounds__(kBlock) void spmv_sliced_tile_kernel(SlicedView M, const double* __restrict__ x,
-                                                                  const int* done) {
+                                                                  Epi epi, double* dot_partials, const int* done) {
     if (done && *done) return;
     extern __shared__ double sl_prod[];
     __shared__ int wave_sum[kBlock / 64];
+    __shared__ double red[kBlock / 64 + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x;
-    const int s = tile % M.nslices, rb = tile / M.nslices;
-    const unsigned e0 = M.tile_ptr[tile];
-    const int ne = (int)(M.tile_ptr[tile + 1] - e0);
     // rows per thread: a thread's row counts are one 8-, 16- or 32-bit load
     static_assert(RPT == 1 || RPT == 2 || RPT == 4, "rows per thread");
     constexpr int R = kBlock * RPT;
-    const unsigned char* cbase = M.cnt + (size_t)tile * R;
-    const unsigned c4 = RPT == 4 ? reinterpret_cast<const unsigned*>(cbase)[tid]
-                      : RPT == 2 ? (unsigned)reinterpret_cast<const unsigned short*>(cbase)[tid]
-                                 : (unsigned)cbase[tid];
     constexpr int U = 8;
-    for (int base = 0; base < ne; base += kBlock * U) {
-        int ci[U];
-        double v[U], xg[U];
-        // unpredicated loads (lanes past the end re-read the tile's last entry), so that all 2*U
-        // stream loads and then all U gathers of a thread are in flight together
+    const int ntiles = M.nrb * M.nslices;
+    double dotpart = 0.0;
+    // sliced: one tile per workgroup (tile = blockIdx.x fixes the XCD); fused: a workgroup walks
+    // tiles blockIdx.x, blockIdx.x + gridDim.x, ... so that the launch has at most kMaxPartials dot partials
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int s = tile % M.nslices, rb = tile / M.nslices;
+        const unsigned e0 = M.tile_ptr[tile];
+        const int ne = (int)(M.tile_ptr[tile + 1] - e0);
+        const unsigned char* cbase = M.cnt + (size_t)tile * R;
+        const unsigned c4 = RPT == 4 ? reinterpret_cast<const unsigned*>(cbase)[tid]
+                          : RPT == 2 ? (unsigned)reinterpret_cast<const unsigned short*>(cbase)[tid]
+                                     : (unsigned)cbase[tid];
+        for (int base = 0; base < ne; base += kBlock * U) {
+            int ci[U];
+            double v[U], xg[U];
+            // unpredicated loads (lanes past the end re-read the tile's last entry), so that all 2*U
+            // stream loads and then all U gathers of a thread are in flight together
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = min(base + u * kBlock + tid, ne - 1);
-            ci[u] = __builtin_nontemporal_load(M.idx + e0 + i);
-            v[u] = __builtin_nontemporal_load(M.val + e0 + i);
+            for (int u = 0; u < U; u++) {
+                const int i = min(base + u * kBlock + tid, ne - 1);
+                ci[u] = __builtin_nontemporal_load(M.idx + e0 + i);
+                v[u] = __builtin_nontemporal_load(M.val + e0 + i);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) xg[u] = x[ci[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = base + u * kBlock + tid;
+                if (i < ne) sl_prod[lds_slot(i)] = Epi::prod(xg[u], v[u]);
+            }
         }
+        // exclusive scan of the per-thread entry counts -> first staged product of my rows
+        const int mine = (int)((c4 & 255u) + ((c4 >> 8) & 255u) + ((c4 >> 16) & 255u) + (c4 >> 24));   // unused bytes are 0
+        int incl = mine;
 #pragma unroll
-        for (int u = 0; u < U; u++) xg[u] = x[ci[u]];
+        for (int d = 1; d < 64; d <<= 1) {
+            const int nb = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += nb;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        int p = incl - mine;
+        for (int w = 0; w < wave; w++) p += wave_sum[w];
+        if (FUSED) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = base + u * kBlock + tid;
-            if (i < ne) sl_prod[lds_slot(i)] = Epi::prod(xg[u], v[u]);
+            for (int q = 0; q < RPT; q++) {
+                const int cq = (int)((c4 >> (8 * q)) & 255u);
+                const int r = rb * R + tid * RPT + q;
+                if (r < M.nrows) {
+                    double acc = epi.init(r);
+                    for (int kk = 0; kk < cq; kk++) {
+                        const double t = sl_prod[lds_slot(p + kk)];
+                        acc = Epi::kNeg ? acc - t : acc + t;
+                    }
+                    epi.finish(r, acc, dotpart);
+                }
+                p += cq;
+            }
+            __syncthreads();          // the staging buffer is reused by the next tile
+            continue;
+        }
+        double out[RPT];
+#pragma unroll
+        for (int q = 0; q < RPT; q++) {
+            const int cq = (int)((c4 >> (8 * q)) & 255u);
+            double acc = 0.0;
+            for (int kk = 0; kk < cq; kk++) acc += sl_prod[lds_slot(p + kk)];
+            p += cq;
+            out[q] = acc;
+        }
+        double* dst = M.partial + (size_t)s * M.nrows_pad + (size_t)rb * R + (size_t)tid * RPT;
+        if (RPT == 1) {
+            dst[0] = out[0];
+        } else {
+#pragma unroll
+            for (int q = 0; q < RPT; q += 2) reinterpret_cast<double2*>(dst)[q / 2] = make_double2(out[q], out[q + 1 < RPT ? q + 1 : q]);
         }
     }
-    // exclusive scan of the per-thread entry counts -> first staged product of my rows
-    const int mine = (int)((c4 & 255u) + ((c4 >> 8) & 255u) + ((c4 >> 16) & 255u) + (c4 >> 24));   // unused bytes are 0
-    int incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int nb = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += nb;
-    }
-    if (lane == 63) wave_sum[wave] = incl;
-    __syncthreads();
-    int p = incl - mine;
-    for (int w = 0; w < wave; w++) p += wave_sum[w];
-    double out[RPT];
-#pragma unroll
-    for (int q = 0; q < RPT; q++) {
-        const int cq = (int)((c4 >> (8 * q)) & 255u);
-        double acc = 0.0;
-        for (int kk = 0; kk < cq; kk++) acc += sl_prod[lds_slot(p + kk)];
-        p += cq;
-        out[q] = acc;
-    }
-    double* dst = M.partial + (size_t)s * M.nrows_pad + (size_t)rb * R + (size_t)tid * RPT;
-    if (RPT == 1) {
-        dst[0] = out[0];
-    } else {
-#pragma unroll
-        for (int q = 0; q < RPT; q += 2) reinterpret_cast<double2*>(dst)[q / 2] = make_double2(out[q], out[q + 1 < RPT ? q + 1 : q]);
+    if (FUSED && dot_partials) {
+        const double d = block_reduce<SumOp>(dotpart, red);
+        if (tid == 0) dot_partials[blockIdx.x] = d;
     }
 }
 
@@ -420,9 +451,16 @@ inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi
     const SlicedView V = M.sliced_view();
     const size_t lds = (size_t)(M.sliced.max_tile + M.sliced.max_tile / 32 + 1) * sizeof(double);
     const dim3 grid(V.nrb * V.nslices), block(kBlock);
-    if (V.R == kBlock * 4) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 4>), grid, block, lds, s, V, x, done);
-    else if (V.R == kBlock * 2) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 2>), grid, block, lds, s, V, x, done);
-    else hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 1>), grid, block, lds, s, V, x, done);
+    if (V.nslices == 1) {       // fused: the tile kernel is the whole product
+        const dim3 fgrid(M.fused_grid());
+        if (V.R == kBlock * 4) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 4, true>), fgrid, block, lds, s, V, x, epi, dot_partials, done);
+        else if (V.R == kBlock * 2) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 2, true>), fgrid, block, lds, s, V, x, epi, dot_partials, done);
+        else hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 1, true>), fgrid, block, lds, s, V, x, epi, dot_partials, done);
+        return;
+    }
+    if (V.R == kBlock * 4) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 4, false>), grid, block, lds, s, V, x, epi, dot_partials, done);
+    else if (V.R == kBlock * 2) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 2, false>), grid, block, lds, s, V, x, epi, dot_partials, done);
+    else hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 1, false>), grid, block, lds, s, V, x, epi, dot_partials, done);
     hipLaunchKernelGGL(spmv_sliced_combine_kernel<Epi>, dim3(M.combine_grid()), dim3(kBlock), 0, s, V, epi,
                        dot_partials, done);
 }

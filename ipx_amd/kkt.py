@@ -184,9 +184,9 @@ class KktContext:
     def spmv_layout(self):
         """(layout of A'y, layout of A t) as 'phased'/'sliced', and the build-time timings in us."""
         lay = (C.c_int * 2)()
-        us = (C.c_double * 4)()
+        us = (C.c_double * 6)()
         self._check(self.lib.ipxk_spmv_layout(self.h, lay, us))
-        names = ("phased", "sliced")
+        names = ("phased", "sliced", "fused")
         return (names[lay[0]], names[lay[1]]), [float(v) for v in us]
 
     def get_rowwise(self):

@@ -336,7 +336,7 @@ def test_full_size_properties(kkt):
 
 
 # --------------------------------------------------------------------------------------
-# the two SpMV layouts (phased / XCD-sliced tiles) on a matrix large enough for the sliced one
+# the three SpMV layouts (phased / XCD-sliced tiles / fused tiles) on a matrix large enough for the sliced one
 # --------------------------------------------------------------------------------------
 def test_spmv_layouts_agree(kkt, po, oracle, monkeypatch):
     m, n = 300000, 700000                      # A t gathers from 5.6 MB: sliced layout eligible
@@ -346,7 +346,7 @@ def test_spmv_layouts_agree(kkt, po, oracle, monkeypatch):
     u = rng.standard_normal(m)
     ref, ref_dot = oracle.normal_apply(ocsc(po, A), W, u)
     out = {}
-    for layout in ("phased", "sliced"):
+    for layout in ("phased", "sliced", "fused"):
         monkeypatch.setenv("IPXK_SPMV_LAYOUT", layout)
         ctx = kkt.KktContext(A)
         ctx.normal_prepare(W)
@@ -357,6 +357,9 @@ def test_spmv_layouts_agree(kkt, po, oracle, monkeypatch):
         out[layout] = (lhs, x, y, it, e)
         ctx.close()
     assert np.array_equal(out["phased"][0], ref)        # phased layout: the reference's summation order
+    assert np.array_equal(out["fused"][0], ref)         # fused tiles: one slice, same order
+    # (the dot products are reduced over different workgroup partitions, so solves agree to rounding only)
+    assert relerr(out["fused"][2], out["phased"][2]) < 1e-8 and abs(out["fused"][3] - out["phased"][3]) <= 2
     assert relerr(out["sliced"][0], out["phased"][0]) < 1e-14
     assert out["sliced"][4] == out["phased"][4] == 0 and abs(out["sliced"][3] - out["phased"][3]) <= 2
     assert relerr(out["sliced"][2], out["phased"][2]) < 1e-8
