@@ -86,3 +86,40 @@ def test_ipm_steps_free_running(kkt):
     assert np.isinf(it["xl"][~lbm]).all() and not it["zl"][~lbm].any()      # untouched without a barrier term
     assert last["presidual"] < first["presidual"] and last["dresidual"] < first["dresidual"]
     ctx.close()
+
+
+def test_ipm_step_with_basis_solver(kkt):
+    """the same step around KKTSolverBasis (planted LU factors): free and fixed variables present"""
+    from helpers import basis_problem
+    m, n = 600, 1400
+    B, _, colscale = basis_problem(m, n, seed=29, num_free=3, num_fixed=4)
+    N = n + m
+    rng = np.random.default_rng(29)
+    state = np.full(N, 2, dtype=np.uint8)
+    state[np.isinf(colscale)] = 1
+    state[colscale == 0.0] = 0
+    bar = state == 2
+    zl = 10.0 ** rng.uniform(-1, 1, N)
+    xl = colscale ** 2 * zl                     # ScalingFactor = 1/sqrt(zl/xl) = colscale on barrier variables
+    xl[~bar] = np.inf; zl[~bar] = 0.0
+    xu, zu = np.full(N, np.inf), np.zeros(N)
+    fx = state == 0
+    xl[fx] = xu[fx] = zl[fx] = zu[fx] = 0.0
+    it = dict(x=rng.uniform(-1, 1, N), y=rng.uniform(-1, 1, m), xl=xl, xu=xu, zl=zl, zu=zu)
+    lb = np.where(state == 1, -np.inf, 0.0)
+    ub = np.where(fx, 0.0, np.inf)
+    b, c = rng.uniform(-1, 1, m), rng.uniform(-1, 1, N)
+    ctx = kkt.KktContext(B["A"])
+    ctx.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
+    ctx.iterate_set(it, state)
+    r0 = ctx.iterate_residuals(b, c, lb, ub)
+    info = ctx.ipm_step(True, b, c, lb, ub, kkt_tol=0.3, maxiter=1000)
+    assert info["errflag"] == 0 and 0.0 < info["step_primal"] < 1.0 and 0.0 < info["step_dual"] < 1.0
+    assert info["kktiter_predictor"] > 0 and info["kktiter_corrector"] > 0
+    new = ctx.iterate_get()
+    assert np.array_equal(new["x"][fx], it["x"][fx])                        # fixed variables do not move
+    assert (new["xl"][bar] > 0).all() and (new["zl"][bar] > 0).all()
+    r1 = ctx.iterate_residuals(b, c, lb, ub)
+    # a damped Newton step reduces the linear residuals by (1 - step) up to the KKT tolerance
+    assert r1["presidual"] < r0["presidual"] and r1["dresidual"] < r0["dresidual"]
+    ctx.close()
