@@ -18,6 +18,9 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "context.hpp"
@@ -338,6 +341,12 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
     hipStream_t s = c->stream;
     const int m = S->m;
     const int64_t nzL = Lp[m], nzU = Up[m], nzUo = nzU - m;
+    const bool verbose = getenv("IPXK_VERBOSE") != nullptr;
+    auto now = [&] {
+        if (verbose) (void)hipStreamSynchronize(s);
+        return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    const double t0 = now();
     // factors as given
     DevBuf<ipxint> dLp, dLi, dUp, dUi;
     DevBuf<double> dLx, dUx, dscale;
@@ -345,6 +354,7 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
     dLi.upload(Li, (size_t)nzL, s);   dLx.upload(Lx, (size_t)nzL, s);
     dUi.upload(Ui, (size_t)nzU, s);   dUx.upload(Ux, (size_t)nzU, s);
     dscale.upload(uscale, s);
+    const double t1 = now();
     Scratch W;
     const size_t maxnz = (size_t)std::max<int64_t>(std::max(nzL, nzU), 1);
     W.rp.resize((size_t)m + 1); W.ri.resize(maxnz); W.rx.resize(maxnz); W.rxS.resize(maxnz);
@@ -396,6 +406,9 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
                            W.colof.get(), dUx.get(), dscale.get(), W.ri.get(), W.rx.get(), W.rxS.get());
     finish_sweep(c, W, S->Uf, m, nzUo, false, true, true);
     IPXK_HIP(hipStreamSynchronize(s));
+    if (verbose)
+        fprintf(stderr, "ipxk: device analysis: upload of L, U %.1f ms (%.0f MB), four sweeps %.1f ms\n", (t1 - t0) * 1e3,
+                ((double)(nzL + nzU) * 16 + (double)m * 24) / 1e6, (now() - t1) * 1e3);
     IPXK_HIP(hipGetLastError());
 }
 
