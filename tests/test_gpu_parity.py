@@ -365,6 +365,33 @@ def test_spmv_layouts_agree(kkt, po, oracle, monkeypatch):
     assert relerr(out["sliced"][2], out["phased"][2]) < 1e-8
 
 
+def test_fused_layout_random_shapes(kkt, po, oracle, monkeypatch):
+    """the fused-tile layout forced onto many small random shapes (ragged last tiles, empty rows and
+    columns, rows of up to 200 entries, single rows/columns): bit-identical to the oracle"""
+    import scipy.sparse as sp
+    from ipx_amd.synth import CscMatrix
+    monkeypatch.setenv("IPXK_SPMV_LAYOUT", "fused")
+    rng = np.random.default_rng(2024)
+    shapes = [(1, 1, 1.0), (1, 50, 0.5), (50, 1, 0.5), (255, 257, 0.02), (256, 1024, 0.01), (1025, 300, 0.03),
+              (2049, 4100, 0.002), (300, 40, 0.6), (40, 300, 0.6), (5000, 9000, 0.001), (777, 778, 0.25)]
+    for (m, n, dens) in shapes:
+        M = sp.random(m, n, density=dens, random_state=int(rng.integers(1 << 30)), format="csc")
+        M.sort_indices()
+        A = CscMatrix(m, n, M.indptr, M.indices, M.data)
+        ctx = kkt.KktContext(A)
+        W = 10.0 ** rng.uniform(-1, 1, n + m)
+        rhs = rng.standard_normal(m)
+        ctx.normal_prepare(W)
+        l1, d1 = ctx.normal_apply(rhs)
+        l2, d2 = oracle.normal_apply(ocsc(po, A), W, rhs)
+        assert np.array_equal(l1, l2), (m, n)
+        assert abs(d1 - d2) <= 1e-12 * max(abs(d2), 1e-300), (m, n)
+        assert ctx.diag_factorize(W, False) == 0
+        P, err = oracle.diag_factorize(ocsc(po, A), W, 10 ** 9, False)
+        assert np.array_equal(ctx.diag_get()[0], P.get()[0]), (m, n)
+        ctx.close()
+
+
 # --------------------------------------------------------------------------------------
 # the collective code path (RCCL), exercised with a one-rank communicator: IPXK_FORCE_COMM
 # routes a single rank through finalize + all-gather + all-reduce exactly as N ranks would run
