@@ -229,9 +229,12 @@ void GatherMatrix::build_sliced(const ipxint* hptr, const ipxint* hidx, const do
     if (nlong > 0 || nrows == 0 || nnz == 0 || ncols == 0) return;
     int ns = 1;
     if (ns_request != 1) {
-        if (x_bytes <= (int64_t(4) << 20)) return;      // x fits an XCD's L2: nothing to slice
+        int64_t slice_bytes = int64_t(2) << 20;          // half of an XCD's L2
+        if (const char* e = getenv("IPXK_SLICE_TEST_KB"))   // tests: make small matrices eligible
+            if (atoi(e) > 0) slice_bytes = (int64_t)atoi(e) << 10;
+        if (x_bytes <= 2 * slice_bytes) return;          // x fits an XCD's L2: nothing to slice
         ns = 2;
-        while (ns < 8 && x_bytes > (int64_t)ns * (int64_t(2) << 20)) ns *= 2;
+        while (ns < 8 && x_bytes > (int64_t)ns * slice_bytes) ns *= 2;
     }
     const int64_t slice = ((ncols + ns - 1) / ns + 15) / 16 * 16;
     // rows per tile: as many as fit the LDS staging buffer (a matrix whose rows concentrate in one

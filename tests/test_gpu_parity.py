@@ -392,6 +392,32 @@ def test_fused_layout_random_shapes(kkt, po, oracle, monkeypatch):
         ctx.close()
 
 
+def test_sliced_layout_random_shapes(kkt, po, oracle, monkeypatch):
+    """the XCD-sliced layout on small ragged shapes (slice size shrunk to 1 KB of x so that they are
+    eligible): 2, 4 and 8 slices, empty rows / columns / tiles; 1e-13 of the oracle (sums are
+    associated per slice)"""
+    import scipy.sparse as sp
+    from ipx_amd.synth import CscMatrix
+    monkeypatch.setenv("IPXK_SPMV_LAYOUT", "sliced")
+    monkeypatch.setenv("IPXK_SLICE_TEST_KB", "1")
+    rng = np.random.default_rng(77)
+    for (m, n, dens) in [(300, 300, 0.05), (257, 513, 0.02), (1025, 1500, 0.01), (2049, 4100, 0.002),
+                         (600, 700, 0.3), (5000, 9000, 0.001), (3, 2000, 0.05)]:
+        M = sp.random(m, n, density=dens, random_state=int(rng.integers(1 << 30)), format="csc")
+        M.sort_indices()
+        A = CscMatrix(m, n, M.indptr, M.indices, M.data)
+        ctx = kkt.KktContext(A)
+        lay, _ = ctx.spmv_layout()
+        assert "sliced" in lay, (m, n, lay)                   # at least one of the two products is sliced
+        W = 10.0 ** rng.uniform(-1, 1, n + m)
+        rhs = rng.standard_normal(m)
+        ctx.normal_prepare(W)
+        l1, d1 = ctx.normal_apply(rhs)
+        l2, d2 = oracle.normal_apply(ocsc(po, A), W, rhs)
+        assert relerr(l1, l2) <= 1e-13 and abs(d1 - d2) <= 1e-12 * max(abs(d2), 1e-300), (m, n)
+        ctx.close()
+
+
 # --------------------------------------------------------------------------------------
 # the collective code path (RCCL), exercised with a one-rank communicator: IPXK_FORCE_COMM
 # routes a single rank through finalize + all-gather + all-reduce exactly as N ranks would run
