@@ -365,6 +365,30 @@ def test_spmv_layouts_agree(kkt, po, oracle, monkeypatch):
     assert relerr(out["sliced"][2], out["phased"][2]) < 1e-8
 
 
+@pytest.mark.parametrize("prepare", ["device", "host"])
+def test_deep_level_structure(kkt, po, oracle, monkeypatch, prepare):
+    """banded planted factors: thousands of narrow levels (SURVEY 8d stress point) -- runs longer than
+    one LDS tail launch can hold, many relaxation rounds in the device-side level analysis"""
+    monkeypatch.setenv("IPXK_PREPARE", prepare)
+    m, n = 6000, 12500
+    B, st, colscale = basis_problem(m, n, seed=47, band=12)
+    A, L, U = B["A"], B["L"], B["U"]
+    ctx = kkt.KktContext(A)
+    ctx.split_prepare(L, U, B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
+    lv = ctx.split_levels()
+    assert min(lv) > 600, lv                                   # deeper than kTailLevelsLds
+    S = oracle.split_prepare(ocsc(po, A.with_identity()), n, ocsc(po, L), ocsc(po, U), B["rowperm"], B["colperm"],
+                             B["basis"], B["status"], colscale)
+    Us = po.Csc(m, m, U.p, U.i, S.get()["Ux"])
+    rhs = np.random.default_rng(4).standard_normal(m)
+    assert np.array_equal(ctx.forward_solve(rhs), oracle.forward_solve(ocsc(po, L), Us, rhs))
+    assert np.array_equal(ctx.backward_solve(rhs), oracle.backward_solve(ocsc(po, L), Us, rhs))
+    l1, d1 = ctx.split_apply(rhs)
+    l2, d2 = S.apply(rhs)
+    assert relerr(l1, l2) <= 1e-10
+    ctx.close()
+
+
 def test_fused_layout_random_shapes(kkt, po, oracle, monkeypatch):
     """the fused-tile layout forced onto many small random shapes (ragged last tiles, empty rows and
     columns, rows of up to 200 entries, single rows/columns): bit-identical to the oracle"""
