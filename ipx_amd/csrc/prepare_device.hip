@@ -238,8 +238,15 @@ int bits_for(int64_t n) {   // bits needed for values in [0, n)
     return b;
 }
 
+// Deep dependency graphs: the relaxation needs as many rounds as there are levels, each a pass over
+// all entries.  After kMaxRelaxRounds rounds the levels are computed by one sequential O(nnz) scan on
+// the host instead (the unknowns' processing order is a topological order) and uploaded.
+constexpr int kMaxRelaxRounds = 24;    // x 8 launches: a few milliseconds at 1M rows
+
 // levels, order, level-ordered rows and launch plan of one sweep from its natural-order row list
-void finish_sweep(Context* c, Scratch& W, Sweep& S, int dim, int64_t nz, bool ascending, bool running, bool scaled) {
+template <class HostLevels>
+void finish_sweep(Context* c, Scratch& W, Sweep& S, int dim, int64_t nz, bool ascending, bool running, bool scaled,
+                  HostLevels&& host_levels) {
     hipStream_t s = c->stream;
     S.dim = dim;
     S.running = running;
@@ -250,7 +257,12 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, int dim, int64_t nz, bool as
     DevBuf<int> changed(1);
     if (!W.h_flag) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&W.h_flag), sizeof(int)));
     for (int round = 0; dim > 0; round++) {
-        IPXK_REQUIRE(round < (1 << 20), "level relaxation does not terminate (cyclic dependencies)");
+        if (round >= kMaxRelaxRounds) {
+            std::vector<int> lv((size_t)dim, 0);
+            host_levels(lv);
+            W.level.upload(lv, s);
+            break;
+        }
         IPXK_HIP(hipMemsetAsync(changed.get(), 0, sizeof(int), s));
         for (int r = 0; r < 8; r++)
             hipLaunchKernelGGL(relax_levels_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, W.rp.get(),
@@ -369,13 +381,25 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
         hipLaunchKernelGGL(ut_rows_kernel, dim3(g), dim3(kBlock), 0, s, m, dUp.get(), dUi.get(), dUx.get(),
                            dscale.get(), W.rp.get(), W.ri.get(), W.rx.get(), W.rxS.get(), W.dgn.get(), W.dgnS.get());
     else IPXK_HIP(hipMemsetAsync(W.rp.get(), 0, sizeof(int), s));
-    finish_sweep(c, W, S->Ut, m, nzUo, true, false, true);
+    finish_sweep(c, W, S->Ut, m, nzUo, true, false, true, [&](std::vector<int>& lv) {
+        for (int k = 0; k < m; k++) {                       // unknown k gathers rows i < k of column k
+            int l = 0;
+            for (ipxint q = Up[k]; q < Up[k + 1] - 1; q++) l = std::max(l, lv[Ui[q]] + 1);
+            lv[k] = l;
+        }
+    });
 
     // --- L' sweep: unknown k gathers column k of L (rows > k), descending, unit diagonal
     hipLaunchKernelGGL(lt_rows_kernel, dim3(grid_for(std::max<int64_t>(nzL, m + 1))), dim3(kBlock), 0, s, m, nzL,
                        dLp.get(), dLi.get(), dLx.get(), W.rp.get(), W.ri.get(), W.rx.get());
     hipLaunchKernelGGL(fill_double_kernel, dim3(g), dim3(kBlock), 0, s, (int64_t)m, 1.0, W.dgn.get());
-    finish_sweep(c, W, S->Lt, m, nzL, false, false, false);
+    finish_sweep(c, W, S->Lt, m, nzL, false, false, false, [&](std::vector<int>& lv) {
+        for (int k = m - 1; k >= 0; k--) {                  // unknown k gathers rows i > k of column k
+            int l = 0;
+            for (ipxint q = Lp[k]; q < Lp[k + 1]; q++) l = std::max(l, lv[Li[q]] + 1);
+            lv[k] = l;
+        }
+    });
 
     // --- L sweep: row i of L, ascending column order (sparse_matrix.cc:283-297)
     if (m > 0 && nzL > 0) {
@@ -389,7 +413,10 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
         hipLaunchKernelGGL(rows_from_perm_kernel, dim3(grid_for(nzL)), dim3(kBlock), 0, s, nzL, W.vals2.get(),
                            W.colof.get(), dLx.get(), (const double*)nullptr, W.ri.get(), W.rx.get(),
                            (double*)nullptr);
-    finish_sweep(c, W, S->Lf, m, nzL, true, true, false);
+    finish_sweep(c, W, S->Lf, m, nzL, true, true, false, [&](std::vector<int>& lv) {
+        for (int j = 0; j < m; j++)                         // column j is final when reached: push to rows i > j
+            for (ipxint q = Lp[j]; q < Lp[j + 1]; q++) lv[Li[q]] = std::max(lv[Li[q]], lv[j] + 1);
+    });
 
     // --- U sweep: row i of U without the diagonal, DESCENDING column order (sparse_matrix.cc:267-281)
     if (m > 0) {
@@ -404,7 +431,10 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
     if (nzUo > 0)
         hipLaunchKernelGGL(rows_from_perm_kernel, dim3(grid_for(nzUo)), dim3(kBlock), 0, s, nzUo, W.vals2.get(),
                            W.colof.get(), dUx.get(), dscale.get(), W.ri.get(), W.rx.get(), W.rxS.get());
-    finish_sweep(c, W, S->Uf, m, nzUo, false, true, true);
+    finish_sweep(c, W, S->Uf, m, nzUo, false, true, true, [&](std::vector<int>& lv) {
+        for (int j = m - 1; j >= 0; j--)                    // descending: push to rows i < j
+            for (ipxint q = Up[j]; q < Up[j + 1] - 1; q++) lv[Ui[q]] = std::max(lv[Ui[q]], lv[j] + 1);
+    });
     IPXK_HIP(hipStreamSynchronize(s));
     if (verbose)
         fprintf(stderr, "ipxk: device analysis: upload of L, U %.1f ms (%.0f MB), four sweeps %.1f ms\n", (t1 - t0) * 1e3,
