@@ -34,6 +34,22 @@ int grid_for(int64_t n) { return (int)std::min<int64_t>(4096, std::max<int64_t>(
 
 #define IPXK_GRID_STRIDE(i, n) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
+// ---- step 0: the factors must be what the contract says (lu_update.h:43-60) before any kernel trusts
+//      their indices: an out-of-range row index would be an out-of-bounds access on the device
+__global__ void validate_factors_kernel(int m, const ipxint* __restrict__ Lp, const ipxint* __restrict__ Li,
+                                        const ipxint* __restrict__ Up, const ipxint* __restrict__ Ui, int* bad) {
+    IPXK_GRID_STRIDE(k, m) {
+        const ipxint l0 = Lp[k], l1 = Lp[k + 1], u0 = Up[k], u1 = Up[k + 1];
+        bool ok = l0 <= l1 && u0 < u1;
+        if (ok) {
+            for (ipxint p = l0; p < l1; p++) ok &= Li[p] > k && Li[p] < m;           // strictly lower
+            for (ipxint p = u0; p < u1 - 1; p++) ok &= Ui[p] >= 0 && Ui[p] < k;       // strictly upper
+            ok &= Ui[u1 - 1] == k;                                                   // diagonal last
+        }
+        if (!ok) *bad = 1;
+    }
+}
+
 // ---- step 1: row lists ---------------------------------------------------------------
 __global__ void ut_rows_kernel(int m, const ipxint* __restrict__ Up, const ipxint* __restrict__ Ui,
                                const double* __restrict__ Ux, const double* __restrict__ uscale,
@@ -366,6 +382,17 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
     dLi.upload(Li, (size_t)nzL, s);   dLx.upload(Lx, (size_t)nzL, s);
     dUi.upload(Ui, (size_t)nzU, s);   dUx.upload(Ux, (size_t)nzU, s);
     dscale.upload(uscale, s);
+    if (m > 0) {
+        // column pointers were checked on the host (monotone, totals); indices are checked here
+        DevBuf<int> bad(1);
+        IPXK_HIP(hipMemsetAsync(bad.get(), 0, sizeof(int), s));
+        hipLaunchKernelGGL(validate_factors_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, dLp.get(), dLi.get(),
+                           dUp.get(), dUi.get(), bad.get());
+        int flag = 0;
+        bad.download(&flag, 1, s);
+        if (flag) throw Error(IPXK_E_ARGUMENT, "L or U violates the factor contract (index out of range, L not "
+                                               "strictly lower, U not upper with its diagonal last)");
+    }
     const double t1 = now();
     Scratch W;
     const size_t maxnz = (size_t)std::max<int64_t>(std::max(nzL, nzU), 1);

@@ -681,10 +681,20 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
     hipStream_t s = c->stream;
     IPXK_REQUIRE(c->nranks == 1, "the basis path does not shard: run it as independent replicas");
     IPXK_REQUIRE(Lp[m] < (int64_t(1) << 31) && Up[m] < (int64_t(1) << 31), "factor nnz exceeds 32 bits");
+    IPXK_REQUIRE(Lp[0] == 0 && Up[0] == 0, "column pointers must start at 0");
     for (int k = 0; k < m; k++) {
-        IPXK_REQUIRE(Up[k + 1] > Up[k] && Ui[Up[k + 1] - 1] == k, "U must hold its diagonal last in each column");
+        IPXK_REQUIRE(Lp[k + 1] >= Lp[k] && Up[k + 1] > Up[k] && Up[k + 1] <= Up[m] && Lp[k + 1] <= Lp[m],
+                     "factor column pointers not monotone");
+        IPXK_REQUIRE(Ui[Up[k + 1] - 1] == k, "U must hold its diagonal last in each column");
         IPXK_REQUIRE(basis[k] >= 0 && basis[k] < n + m, "basis entry out of range");
         IPXK_REQUIRE(rowperm[k] >= 0 && rowperm[k] < m && colperm[k] >= 0 && colperm[k] < m, "permutation entry out of range");
+    }
+    {   // rowperm, colperm are permutations; basis entries distinct is the caller's contract
+        std::vector<unsigned char> seen_r(m, 0), seen_c(m, 0);
+        for (int k = 0; k < m; k++) {
+            IPXK_REQUIRE(!seen_r[rowperm[k]] && !seen_c[colperm[k]], "rowperm / colperm is not a permutation");
+            seen_r[rowperm[k]] = seen_c[colperm[k]] = 1;
+        }
     }
     if (c->split) { destroy_split(c->split); c->split = nullptr; }
     std::unique_ptr<SplitOperator> S(new SplitOperator);
@@ -781,6 +791,12 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
         analyse_sweeps_device(c, S.get(), Lp, Li, Lx, Up, Ui, Ux, uscale);
         tp1 = now();
     } else {
+        for (int k = 0; k < m; k++) {       // the device path checks the indices in a kernel
+            for (ipxint p = Lp[k]; p < Lp[k + 1]; p++)
+                IPXK_REQUIRE(Li[p] > k && Li[p] < m, "L must be strictly lower triangular with indices in range");
+            for (ipxint p = Up[k]; p < Up[k + 1] - 1; p++)
+                IPXK_REQUIRE(Ui[p] >= 0 && Ui[p] < k, "U must be upper triangular with indices in range");
+        }
         // the analyses are independent and sequential each: one host thread per sweep
         std::exception_ptr err[3];
         auto guard = [&](int i, auto job) { return std::thread([&, i, job] { try { job(); } catch (...) { err[i] = std::current_exception(); } }); };

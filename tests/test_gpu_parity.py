@@ -366,6 +366,34 @@ def test_spmv_layouts_agree(kkt, po, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("prepare", ["device", "host"])
+def test_split_prepare_rejects_bad_factors(kkt, monkeypatch, prepare):
+    """indices that violate the factor contract (src/lu_update.h:43-60) are refused before any kernel uses them"""
+    monkeypatch.setenv("IPXK_PREPARE", prepare)
+    m, n = 300, 700
+    B, st, colscale = basis_problem(m, n, seed=51)
+    ctx = kkt.KktContext(B["A"])
+    args = lambda L, U, rp=B["rowperm"], cp=B["colperm"]: (L, U, rp, cp, B["basis"], B["status"], colscale)
+    ctx.split_prepare(*args(B["L"], B["U"]))                        # the good factors are accepted
+    from ipx_amd.synth import CscMatrix
+    L, U = B["L"], B["U"]
+    bad_i = L.i.copy(); bad_i[len(bad_i) // 2] = m + 5               # row index out of range
+    with pytest.raises(kkt.KktError):
+        ctx.split_prepare(*args(CscMatrix(m, m, L.p, bad_i, L.x), U))
+    bad_i = L.i.copy(); bad_i[0] = 0                                  # not strictly lower (column 0 holds row 0)
+    with pytest.raises(kkt.KktError):
+        ctx.split_prepare(*args(CscMatrix(m, m, L.p, bad_i, L.x), U))
+    bad_u = U.i.copy(); bad_u[U.p[m // 2 + 1] - 1] = 0                # diagonal not last
+    with pytest.raises(kkt.KktError):
+        ctx.split_prepare(*args(L, CscMatrix(m, m, U.p, bad_u, U.x)))
+    rp = B["rowperm"].copy(); rp[1] = rp[0]                           # not a permutation
+    with pytest.raises(kkt.KktError):
+        ctx.split_prepare(*args(L, U, rp=rp))
+    ctx.split_prepare(*args(L, U))                                    # and the context is still usable
+    assert ctx.split_levels()[0] >= 1
+    ctx.close()
+
+
+@pytest.mark.parametrize("prepare", ["device", "host"])
 def test_deep_level_structure(kkt, po, oracle, monkeypatch, prepare):
     """banded planted factors: thousands of narrow levels (SURVEY 8d stress point) -- runs longer than
     one LDS tail launch can hold, many relaxation rounds in the device-side level analysis"""
