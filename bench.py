@@ -219,6 +219,11 @@ def main():
                                                                    local_rank, tdev)
     if rehearsal:
         out["config"]["transport"] = "REHEARSAL: host shared memory instead of RCCL, all ranks on one GPU"
+    if rank == 0 and world == 1:
+        # what a plain streaming kernel reaches on this box (report next to the 8 TB/s spec peak)
+        triad = measure_triad(torch)
+        out["roofline"]["measured_triad_GBps"] = triad
+        out["roofline"]["frac_of_measured_triad"] = achieved / triad
     if rank == 0 and world == 1 and not args.no_banded:
         out["roofline"]["banded_matrix_probe"] = bench_banded(kkt, synth, m, n)
     if rank == 0 and world == 1 and args.basis:
@@ -329,6 +334,24 @@ def bench_newton(kkt, synth, ctx, m, n, args):
                             "step_dual": info["step_dual"],
                             "note": "Factorize + predictor + corrector + step sizes + update, nothing crosses PCIe"}
     return res
+
+
+def measure_triad(torch, nbytes=1 << 29):
+    """a = b + 1.5*c over three 512 MB fp64 vectors (plumbing kernel of torch): bytes moved / time"""
+    n = nbytes // 8
+    bt = torch.ones(n, dtype=torch.float64, device="cuda")
+    ct = torch.ones(n, dtype=torch.float64, device="cuda")
+    at = torch.empty_like(bt)
+    for _ in range(3):
+        torch.add(bt, ct, alpha=1.5, out=at)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        torch.add(bt, ct, alpha=1.5, out=at)
+    e1.record()
+    torch.cuda.synchronize()
+    return 3.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def bench_banded(kkt, synth, m, n):
