@@ -171,6 +171,25 @@ def test_diag_path_vs_oracle(kkt, po, oracle, m, n, num_dense, spread):
     ctx.close()
 
 
+def test_diag_path_stress_spread3(kkt, po, oracle):
+    """SURVEY 8d stress point: scaling spread s = 3 (W spans 12 decades): the diag-preconditioned CR
+    does not converge within the cap; both sides stop at the cap with errflag 201 (or agree on an earlier
+    breakdown flag)"""
+    m, n = 3000, 6200
+    A, st = diag_problem(m, n, seed=23, spread=3.0)
+    Ao = ocsc(po, A)
+    ctx = kkt.KktContext(A)
+    assert ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"]) == 0
+    ko = oracle.kkt_diag(Ao, maxiter=300)
+    assert ko.factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"]) == 0
+    tol = 0.3 * np.sqrt(st["mu"])
+    x1, y1, it1, e1, _ = ctx.kkt_diag_solve(st["a"], st["b"], tol, 300)
+    x2, y2, it2, e2, _ = ko.solve(st["a"], st["b"], tol)
+    assert e1 == e2 and e1 in (201, 204, 202, 203) and iters_close(it1, it2)
+    assert np.isfinite(y1).all() and np.isfinite(x1).all()
+    ctx.close()
+
+
 def ko_precond_apply(oracle, Ao, W, nzd, rhs):
     P, err = oracle.diag_factorize(Ao, W, nzd, True)
     assert err == 0
