@@ -44,9 +44,12 @@ def parse():
     ap.add_argument("--spread", type=float, default=1.0)
     ap.add_argument("--maxiter", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--basis", action="store_true", help="also time the basis-preconditioned solve (extra field)")
-    ap.add_argument("--newton", action="store_true",
-                    help="also time IPM::SolveNewtonSystem around the diag solve, all vectors resident (extra field)")
+    ap.add_argument("--basis", action="store_true", help="(default at N = 1; kept for compatibility)")
+    ap.add_argument("--no-basis", action="store_true",
+                    help="skip the basis-preconditioned solve on planted LU factors (config.basis_path)")
+    ap.add_argument("--newton", action="store_true", help="(default at N = 1; kept for compatibility)")
+    ap.add_argument("--no-newton", action="store_true",
+                    help="skip the resident Newton step / IPM iteration measurements (config.newton_step)")
     ap.add_argument("--no-column-partition", action="store_true",
                     help="N > 1: skip the extra measurement of the column partition (config.column_partition)")
     ap.add_argument("--no-banded", action="store_true", help="skip the banded-matrix probe of the SpMV (extra field of roofline)")
@@ -226,9 +229,9 @@ def main():
         out["roofline"]["frac_of_measured_triad"] = achieved / triad
     if rank == 0 and world == 1 and not args.no_banded:
         out["roofline"]["banded_matrix_probe"] = bench_banded(kkt, synth, m, n)
-    if rank == 0 and world == 1 and args.basis:
+    if rank == 0 and world == 1 and not args.no_basis:
         out["config"]["basis_path"] = bench_basis(kkt, synth, m, n, args)
-    if rank == 0 and world == 1 and args.newton:
+    if rank == 0 and world == 1 and not args.no_newton:
         out["config"]["newton_step"] = bench_newton(kkt, synth, ctx, m, n, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ctx.set_pointer_mode(False)
