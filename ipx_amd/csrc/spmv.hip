@@ -212,6 +212,10 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
         }
         sliced = std::move(keep);
         use_sliced = sliced.built;
+        if (use_sliced) {        // the phased copy of the entries is not needed any more
+            idx.release(); val.release(); counts.release(); step_ptr.release();
+            wg_chunk_ptr.release(); chunk_start.release(); chunk_info.release(); chunk_step.release();
+        }
         if (getenv("IPXK_VERBOSE"))
             fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld: phased %.1f us, fused %.1f us, sliced %.1f us -> %s\n",
                     nrows, ncols, (long long)nnz, tuned_us_phased, tuned_us_fused, tuned_us_sliced,
