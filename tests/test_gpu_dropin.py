@@ -34,3 +34,21 @@ def test_host_classes_compile_against_reference_headers():
         subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only"] + inc + [os.path.join(ROOT, "ipx_amd", "host", f)])
     subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++"] + inc + ["-"],
                    input='#include "linear_operators_hip.h"\n', text=True, check=True)
+
+
+@pytest.mark.gpu
+def test_example_ipm_loop():
+    """examples/ipm_loop.cc: an interior-point loop through the C ABI only (C++, no Python in the path) --
+    factorize from the resident iterate, predictor-corrector step, repeat; residuals and mu must fall."""
+    import re
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples")])
+    r = subprocess.run([os.path.join(ROOT, "examples", "ipm_loop"), "2000", "5000", "6"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = [ln.split() for ln in r.stdout.splitlines() if re.match(r"\s*\d+\s", ln)]
+    assert len(rows) == 6
+    pres = [float(x[1]) for x in rows]
+    dres = [float(x[2]) for x in rows]
+    mu = [float(x[3]) for x in rows]
+    assert all(b < a for a, b in zip(pres, pres[1:])) and all(b < a for a, b in zip(dres, dres[1:]))
+    assert mu[-1] < 0.1 * mu[0] and pres[-1] < 0.02 * pres[0]
