@@ -7,7 +7,7 @@ rows = list(csv.DictReader(open(one(trace_dir, "kernel_trace.csv"))))
 dur = collections.defaultdict(list)
 for r in rows:
     dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-lines = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-banded   (MI355X)",
+lines = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-banded --no-basis --no-newton   (MI355X)",
          "# avg over ALL calls includes the early-exit no-op launches after CR termination; 'working' = duration > 20 us",
          "# for the SpMV kernels (launches that did work)",
          "kernel,calls,total_ms,avg_us_all,calls_working,avg_us_working,median_us_working"]
