@@ -164,6 +164,16 @@ int ipxk_split_prepare(ipxk_context* ctx, const ipxint* Lp, const ipxint* Li,
                        const double* Ux, const ipxint* rowperm,
                        const ipxint* colperm, const ipxint* basis,
                        const ipxint* status, const double* colscale);
+/* Prepare when ONLY the scaling factors changed: KKTSolverBasis::_Factorize
+ * keeps the factorization when the basis was not updated
+ * (src/kkt_solver_basis.cc:59-64), and then all that differs for the operator is
+ * the scaling of U's columns and of N and the free positions
+ * (src/splitted_normal_matrix.cc:30-64).  Reuses the level schedule and the
+ * packed factors of the last ipxk_split_prepare (same L, U, permutations and
+ * basis) and rebuilds only what depends on status / colscale; the result is
+ * bit-identical to a full ipxk_split_prepare with the same arguments. */
+int ipxk_split_rescale(ipxk_context* ctx, const ipxint* status,
+                       const double* colscale);
 /* _Apply (src/splitted_normal_matrix.cc:90-117) */
 int ipxk_split_apply(ipxk_context* ctx, const double* rhs, double* lhs,
                      double* rhs_dot_lhs);

@@ -637,6 +637,15 @@ int ipxk_split_prepare(ipxk_context* c, const ipxint* Lp, const ipxint* Li, cons
     });
 }
 
+int ipxk_split_rescale(ipxk_context* c, const ipxint* status, const double* colscale) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && status && colscale, "NULL argument");
+        IPXK_REQUIRE(c->split != nullptr, "SplittedNormalMatrix not prepared");
+        bind_device(c);
+        split_rescale_host(c, status, colscale);
+    });
+}
+
 int ipxk_split_apply(ipxk_context* c, const double* rhs, double* lhs, double* rhs_dot_lhs) {
     return guarded([&] {
         IPXK_REQUIRE(c && rhs && lhs, "NULL argument");
@@ -663,8 +672,8 @@ static int inplace_solve(ipxk_context* c, double* x, bool forward) {
         const size_t m = (size_t)c->m;
         double* dx = stage_out(c, x, m, c->v_lhs);
         if (c->pointer_mode == IPXK_POINTER_HOST) staged_h2d(dx, x, m * sizeof(double), c->stream);
-        if (forward) forward_solve_dev(c, dx, true, nullptr);
-        else backward_solve_dev(c, dx, true, nullptr);
+        if (forward) forward_solve_dev(c, dx, dx, true, nullptr);
+        else backward_solve_dev(c, dx, dx, true, nullptr);
         IPXK_HIP(hipGetLastError());
         finish_out(c, x, dx, m);
         IPXK_HIP(hipStreamSynchronize(c->stream));

@@ -186,8 +186,10 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
                         const double* colscale);
 // lhs = C rhs (device vectors), dot partials -> part(kPartCdot); returns # partials
 int split_apply_dev(Context* c, const double* rhs, double* lhs, const int* done);
-void forward_solve_dev(Context* c, double* x, bool scaled, const int* done);
-void backward_solve_dev(Context* c, double* x, bool scaled, const int* done);
+void split_rescale_host(Context* c, const ipxint* status, const double* colscale);
+// out = inverse(B) in / inverse(B') in on the (scaled) factors; in may be out
+void forward_solve_dev(Context* c, const double* in, double* out, bool scaled, const int* done);
+void backward_solve_dev(Context* c, const double* in, double* out, bool scaled, const int* done);
 void solve_dense_dev(Context* c, const double* rhs, double* lhs, char trans);
 CrResult kkt_basis_solve_dev(Context* c, const double* a, const double* b, double tol,
                              ipxint maxiter, double* x, double* y, ipxk_interrupt_fn interrupt,

@@ -78,6 +78,8 @@ public:
         if (n > 0) IPXK_HIP(hipMalloc(reinterpret_cast<void**>(&p_), n * sizeof(T)));
         n_ = n;
     }
+    // grow-only variant of resize: keeps the allocation when it is already large enough
+    void ensure(size_t n) { if (n > n_) resize(n); }
     void release() {
         if (p_) (void)hipFree(p_);
         p_ = nullptr;

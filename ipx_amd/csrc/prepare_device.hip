@@ -2,20 +2,26 @@
 // (reference src/splitted_normal_matrix.cc:18-66 hands over L, U; the sweeps are those of
 // TriangularSolve, src/sparse_matrix.cc:224-301).
 //
-// The factors change every IPM iteration, so the level schedule has to be rebuilt every time.  On
+// The factors change whenever the basis changes, so the level schedule has to be rebuilt then.  On
 // the host that is ~100 ms of pointer chasing at 1M rows; here L and U are uploaded as given and
 // everything else runs on the GPU:
 //   1. row lists in natural order: U' and L' read the columns directly; the forward sweeps need
-//      the row-wise forms -- a stable radix sort of the entries by row index (rocPRIM via hipCUB;
-//      entries enumerated in ascending column order for L and in DESCENDING column order for U, the
-//      order in which the reference's column loops update a row);
-//   2. dependency levels by relaxation level[i] = max(level[dep] + 1) until nothing changes
-//      (as many sweeps over the entries as the DAG is deep);
-//   3. a stable sort of the unknowns (in processing order) by level, levels padded to 64 positions;
-//   4. row extents by a prefix sum, rows gathered into level order.
-// The host only sees O(#levels) numbers (level sizes, long-row flags, entry offsets) from which it
-// derives the launch plan (plan_sweep).  The result is identical to analyse_sweep's host arrays.
-#include <hipcub/hipcub.hpp>
+//      the row-wise forms -- a stable radix sort of the entries by row index (rocPRIM; entries
+//      enumerated in ascending column order for L and in DESCENDING column order for U, the order
+//      in which the reference's column loops update a row);
+//   2. dependency levels by relaxation level[i] = max(level[dep] + 1) until nothing changes;
+//   3. a stable sort of the unknowns (in processing order) by (level, row class): inside a level the
+//      rows come grouped by length -- long rows (> 8 entries, 8 lanes each), then rows of 5..8,
+//      3..4, 1..2 and 0 entries (one lane each, ELL blocks of width 8 / 4 / 2 / 0) -- so that every
+//      wavefront-sized chunk is homogeneous;
+//   4. the rows packed chunk by chunk (trisolve.hpp: ChunkDesc).
+// The host only sees O(#levels) numbers (group sizes) from which it lays out the chunks and derives
+// the launch plan (plan_sweep).  The column-scaled value sets of the U sweeps are derived from the
+// packed unscaled ones (rescale_sweeps_device), which is also all that a change of the scaling
+// factors alone needs (ipxk_split_rescale).
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -52,22 +58,18 @@ __global__ void validate_factors_kernel(int m, const ipxint* __restrict__ Lp, co
 
 // ---- step 1: row lists ---------------------------------------------------------------
 __global__ void ut_rows_kernel(int m, const ipxint* __restrict__ Up, const ipxint* __restrict__ Ui,
-                               const double* __restrict__ Ux, const double* __restrict__ uscale,
-                               int* __restrict__ rp, int* __restrict__ ri, double* __restrict__ rx,
-                               double* __restrict__ rxS, double* __restrict__ dgn, double* __restrict__ dgnS) {
+                               const double* __restrict__ Ux, int* __restrict__ rp, int* __restrict__ ri,
+                               double* __restrict__ rx, double* __restrict__ dgn) {
     IPXK_GRID_STRIDE(k, m) {
         const ipxint p0 = Up[k], p1 = Up[k + 1] - 1;      // diagonal last
         const int base = (int)(p0 - k);
         rp[k] = base;
-        const double sc = uscale[k];
         for (ipxint p = p0; p < p1; p++) {
             const int q = base + (int)(p - p0);
             ri[q] = (int)Ui[p];
             rx[q] = Ux[p];
-            rxS[q] = Ux[p] * sc;
         }
         dgn[k] = Ux[p1];
-        dgnS[k] = Ux[p1] * sc;
         if (k == m - 1) rp[m] = (int)(Up[m] - m);
     }
 }
@@ -123,26 +125,32 @@ __global__ void lower_bound_kernel(int dim, int64_t nz, const int* __restrict__ 
     }
 }
 
+// out[i] = first position of a key >= bkeys[i] in the sorted keys
+__global__ void lower_bound_keys_kernel(int nb, int64_t nz, const int* __restrict__ sorted_keys, const int* __restrict__ bkeys,
+                                        int* __restrict__ out) {
+    IPXK_GRID_STRIDE(i, nb) {
+        const int key = bkeys[i];
+        int64_t lo = 0, hi = nz;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (sorted_keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        out[i] = (int)lo;
+    }
+}
+
 __global__ void rows_from_perm_kernel(int64_t nz, const int* __restrict__ perm, const int* __restrict__ colof,
-                                      const double* __restrict__ X, const double* __restrict__ uscale,
-                                      int* __restrict__ ri, double* __restrict__ rx, double* __restrict__ rxS) {
+                                      const double* __restrict__ X, int* __restrict__ ri, double* __restrict__ rx) {
     IPXK_GRID_STRIDE(t, nz) {
         const int p = perm[t];
-        const int col = colof[p];
-        ri[t] = col;
+        ri[t] = colof[p];
         rx[t] = X[p];
-        if (rxS) rxS[t] = X[p] * uscale[col];
     }
 }
 
 __global__ void u_diag_kernel(int m, const ipxint* __restrict__ Up, const double* __restrict__ Ux,
-                              const double* __restrict__ uscale, double* __restrict__ dgn,
-                              double* __restrict__ dgnS) {
-    IPXK_GRID_STRIDE(k, m) {
-        const double d = Ux[Up[k + 1] - 1];
-        dgn[k] = d;
-        dgnS[k] = d * uscale[k];
-    }
+                              double* __restrict__ dgn) {
+    IPXK_GRID_STRIDE(k, m) dgn[k] = Ux[Up[k + 1] - 1];
 }
 
 // ---- step 2: levels -----------------------------------------------------------------------
@@ -161,91 +169,128 @@ __global__ void relax_levels_kernel(int dim, const int* __restrict__ rp, const i
     }
 }
 
-// ---- step 3: order ------------------------------------------------------------------------
-__global__ void level_keys_kernel(int dim, int ascending, const int* __restrict__ level, int* __restrict__ keys,
-                                  int* __restrict__ vals) {
+// ---- step 3: order by (level, descending row length) -------------------------------------------------
+__global__ void level_keys_kernel(int dim, int ascending, const int* __restrict__ level, const int* __restrict__ rp,
+                                  int* __restrict__ keys, int* __restrict__ vals) {
     IPXK_GRID_STRIDE(t, dim) {
         const int i = ascending ? (int)t : dim - 1 - (int)t;
-        keys[t] = level[i];
+        const int len = rp[i + 1] - rp[i];
+        keys[t] = (level[i] << kLenKeyBits) | (255 - (len < 255 ? len : 255));
         vals[t] = i;
     }
 }
 
-__global__ void place_kernel(int dim, const int* __restrict__ sorted_level, const int* __restrict__ sorted_unknown,
-                             const int* __restrict__ lstart, const int* __restrict__ lptr,
-                             const int* __restrict__ rp, int* __restrict__ order, int* __restrict__ posof,
-                             unsigned char* __restrict__ level_long) {
+// ---- step 4: rows into chunks ---------------------------------------------------------------
+// per level l: sorted unknowns [lstart[2l], lstart[2l+1]) are its long rows, [lstart[2l+1], lstart[2l+2]) its
+// short ones; lpos[2l], lpos[2l+1] = first position of either part
+__global__ void place_kernel(int dim, const int* __restrict__ sorted_key, const int* __restrict__ sorted_unknown,
+                             const int* __restrict__ lstart, const int* __restrict__ lpos,
+                             const int* __restrict__ rp, const double* __restrict__ dgn, int* __restrict__ order,
+                             double* __restrict__ diag, int* __restrict__ len) {
     IPXK_GRID_STRIDE(t, dim) {
-        const int l = sorted_level[t], i = sorted_unknown[t];
-        const int pos = lptr[l] + ((int)t - lstart[l]);
+        const int key = sorted_key[t], i = sorted_unknown[t];
+        const int l = key >> kLenKeyBits;
+        const int part = (int)t >= lstart[2 * l + 1] ? 1 : 0;
+        const int pos = lpos[2 * l + part] + ((int)t - lstart[2 * l + part]);
         order[pos] = i;
-        posof[i] = pos;
-        if (rp[i + 1] - rp[i] > kShortRow) level_long[l] = 1;
+        diag[pos] = dgn[i];
+        len[pos] = rp[i + 1] - rp[i];
     }
 }
 
-// ---- step 4: rows into level order -----------------------------------------------------------
-__global__ void row_length_kernel(int npos, const int* __restrict__ order, const int* __restrict__ rp,
-                                  int* __restrict__ len) {
-    IPXK_GRID_STRIDE(k, (int64_t)npos + 1) {
-        const int i = k < npos ? order[k] : -1;
-        len[k] = i >= 0 ? rp[i + 1] - rp[i] : 0;
+// entry slots a chunk needs: 64 * (its longest row, rounded up to whole steps of 8 for long rows);
+// also completes the descriptor's width
+__global__ void chunk_size_kernel(int nchunks, ChunkDesc* __restrict__ chunks, const int* __restrict__ len,
+                                  int* __restrict__ size) {
+    IPXK_GRID_STRIDE(c, nchunks) {
+        ChunkDesc d = chunks[c];
+        int mx = 0;
+        for (int q = 0; q < d.npos; q++) mx = max(mx, len[d.pos0 + q]);
+        if (d.width < 0) { const int steps = (mx + kLongLanes - 1) / kLongLanes; d.width = -max(steps, 1); size[c] = max(steps, 1) * 64; }
+        else { d.width = mx; size[c] = mx * 64; }
+        chunks[c].width = d.width;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) size[nchunks] = 0;
 }
 
-__global__ void gather_rows_kernel(int npos, const int* __restrict__ order, const int* __restrict__ ptr,
-                                   const int* __restrict__ rp, const int* __restrict__ ri,
-                                   const double* __restrict__ rx, const double* __restrict__ rxS,
-                                   const double* __restrict__ dgn, const double* __restrict__ dgnS,
-                                   int* __restrict__ idx, double* __restrict__ val, double* __restrict__ valS,
-                                   double* __restrict__ dg, double* __restrict__ dgS) {
-    IPXK_GRID_STRIDE(k, npos) {
-        const int i = order[k];
-        if (i < 0) {
-            dg[k] = 1.0;
-            if (dgS) dgS[k] = 1.0;
-            continue;
+__global__ void chunk_ent0_kernel(int nchunks, ChunkDesc* __restrict__ chunks, const int* __restrict__ ent0) {
+    IPXK_GRID_STRIDE(c, nchunks) chunks[c].ent0 = ent0[c];
+}
+
+// one wavefront per chunk copies the rows of its chunk into the chunk's block
+__global__ __launch_bounds__(kBlock) void pack_entries_kernel(int nchunks, const ChunkDesc* __restrict__ chunks,
+                                                              const int* __restrict__ order, const int* __restrict__ rp,
+                                                              const int* __restrict__ ri, const double* __restrict__ rx,
+                                                              int* __restrict__ idx, double* __restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    for (int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); c < nchunks; c += gridDim.x * (kBlock / 64)) {
+        const ChunkDesc d = chunks[c];
+        if (d.width >= 0) {
+            const int i = order[d.pos0 + lane];
+            if (i < 0) continue;
+            const int p0 = rp[i], n = rp[i + 1] - p0;
+            for (int e = 0; e < n; e++) {
+                idx[d.ent0 + e * 64 + lane] = ri[p0 + e];
+                val[d.ent0 + e * 64 + lane] = rx[p0 + e];
+            }
+        } else {
+            const int i = order[d.pos0 + (lane >> 3)], gl = lane & 7;
+            if (i < 0) continue;
+            const int p0 = rp[i], n = rp[i + 1] - p0;
+            for (int e = gl; e < n; e += kLongLanes) {
+                idx[d.ent0 + (e >> 3) * 64 + lane] = ri[p0 + e];
+                val[d.ent0 + (e >> 3) * 64 + lane] = rx[p0 + e];
+            }
         }
-        int put = ptr[k];
-        for (int p = rp[i]; p < rp[i + 1]; p++, put++) {
-            idx[put] = ri[p];
-            val[put] = rx[p];
-            if (valS) valS[put] = rxS[p];
-        }
-        dg[k] = dgn[i];
-        if (dgS) dgS[k] = dgnS[i];
     }
 }
 
-__global__ void gather_int_kernel(int n, const int* __restrict__ src, const int* __restrict__ at, int* __restrict__ out) {
-    IPXK_GRID_STRIDE(i, n) out[i] = src[at[i]];
-}
-
-// dependency-slot table of one tail run (tail_lds_kernel)
-__global__ void tslot_kernel(int ne, int e0, int k0, int k1, const int* __restrict__ idx,
-                             const int* __restrict__ posof, short* __restrict__ tslot) {
-    IPXK_GRID_STRIDE(e, ne) {
-        const int pj = posof[idx[e0 + e]];
-        tslot[e] = pj >= k0 && pj < k1 ? (short)(pj - k0) : (short)-1;
+// ---- column-scaled value sets (splitted_normal_matrix.cc:30-39) -----------------------------------
+// MODE 1 (U' sweep): unknown k gathers column k of U: every entry and the diagonal times uscale[k]
+// MODE 2 (U sweep): unknown i walks row i of U: entry (i, k) times uscale[k], the diagonal times uscale[i]
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void rescale_kernel(SweepView S, int nchunks, const double* __restrict__ uscale,
+                                                         double* __restrict__ valS, double* __restrict__ diagS) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (c >= nchunks) return;
+    const ChunkDesc d = S.chunks[c];
+    const bool ell = d.width >= 0;
+    const int pos = ell ? d.pos0 + lane : d.pos0 + (lane >> 3), gl = lane & 7;
+    const int r = S.order[pos];
+    if (r < 0) { if (ell || gl == 0) diagS[pos] = 1.0; return; }
+    const double own = uscale[r];
+    if (ell || gl == 0) diagS[pos] = S.diag[pos] * own;
+    const int len = S.len[pos];
+    for (int e = ell ? 0 : gl; e < len; e += ell ? 1 : kLongLanes) {
+        const int64_t slot = ell ? (int64_t)d.ent0 + e * 64 + lane : (int64_t)d.ent0 + (e >> 3) * 64 + lane;
+        valS[slot] = S.val[slot] * (MODE == 1 ? own : uscale[S.idx[slot]]);
     }
 }
 
 struct Scratch {   // reused by the four sweeps of one Prepare
-    DevBuf<int> keys, vals, keys2, vals2, colof, level, posof, len, lstart, lptr, at, tmpi;
-    DevBuf<unsigned char> level_long, cub;
+    DevBuf<int> keys, vals, keys2, vals2, colof, level, lstart, lpos, csize, cent0;
+    DevBuf<unsigned char> tmp;
     DevBuf<int> rp, ri;
-    DevBuf<double> rx, rxS, dgn, dgnS;
+    DevBuf<double> rx, dgn;
     int* h_flag = nullptr;   // pinned
     ~Scratch() { if (h_flag) (void)hipHostFree(h_flag); }
 };
 
 void sort_pairs(Scratch& W, int64_t n, int end_bit, hipStream_t s) {
     size_t bytes = 0;
-    IPXK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, W.keys.get(), W.keys2.get(), W.vals.get(),
-                                                W.vals2.get(), (int)n, 0, end_bit, s));
-    if (W.cub.size() < bytes) W.cub.resize(bytes);
-    IPXK_HIP(hipcub::DeviceRadixSort::SortPairs(W.cub.get(), bytes, W.keys.get(), W.keys2.get(), W.vals.get(),
-                                                W.vals2.get(), (int)n, 0, end_bit, s));
+    IPXK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, W.keys.get(), W.keys2.get(), W.vals.get(), W.vals2.get(),
+                                       (size_t)n, 0u, (unsigned)end_bit, s));
+    if (W.tmp.size() < bytes) W.tmp.resize(bytes);
+    IPXK_HIP(rocprim::radix_sort_pairs(W.tmp.get(), bytes, W.keys.get(), W.keys2.get(), W.vals.get(), W.vals2.get(),
+                                       (size_t)n, 0u, (unsigned)end_bit, s));
+}
+
+void exclusive_scan(Scratch& W, const int* in, int* out, size_t n, hipStream_t s) {
+    size_t bytes = 0;
+    IPXK_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, n, rocprim::plus<int>(), s));
+    if (W.tmp.size() < bytes) W.tmp.resize(bytes);
+    IPXK_HIP(rocprim::exclusive_scan(W.tmp.get(), bytes, in, out, 0, n, rocprim::plus<int>(), s));
 }
 
 int bits_for(int64_t n) {   // bits needed for values in [0, n)
@@ -255,117 +300,154 @@ int bits_for(int64_t n) {   // bits needed for values in [0, n)
 }
 
 // Deep dependency graphs: the relaxation needs as many rounds as there are levels, each a pass over
-// all entries.  After kMaxRelaxRounds rounds the levels are computed by one sequential O(nnz) scan on
-// the host instead (the unknowns' processing order is a topological order) and uploaded.
-constexpr int kMaxRelaxRounds = 24;    // x 8 launches: a few milliseconds at 1M rows
+// all entries.  After kMaxRelaxLaunches launches the levels are computed by one sequential O(nnz) scan
+// on the host instead (the unknowns' processing order is a topological order) and uploaded.
+constexpr int kMaxRelaxLaunches = 200;   // a few milliseconds at 1M rows
 
-// levels, order, level-ordered rows and launch plan of one sweep from its natural-order row list
+// levels, order, packed rows and launch plan of one sweep from its natural-order row list
 template <class HostLevels>
-void finish_sweep(Context* c, Scratch& W, Sweep& S, int dim, int64_t nz, bool ascending, bool running, bool scaled,
-                  HostLevels&& host_levels) {
+void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim, int64_t nz, bool ascending, bool running,
+                  int scale_mode, HostLevels&& host_levels) {
     hipStream_t s = c->stream;
     S.dim = dim;
     S.running = running;
-    S.has_scaled = scaled;
-    // 2. levels
-    W.level.resize(std::max(dim, 1));
+    S.scale_mode = scale_mode;
+    // 2. levels: rounds of relaxation launches, twice as many each time (one host round trip per round)
+    W.level.ensure(std::max(dim, 1));
     IPXK_HIP(hipMemsetAsync(W.level.get(), 0, sizeof(int) * std::max(dim, 1), s));
     DevBuf<int> changed(1);
     if (!W.h_flag) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&W.h_flag), sizeof(int)));
-    for (int round = 0; dim > 0; round++) {
-        if (round >= kMaxRelaxRounds) {
+    for (int launched = 0, batch = 8; dim > 0; batch = std::min(batch * 2, 64)) {
+        if (launched >= kMaxRelaxLaunches) {
             std::vector<int> lv((size_t)dim, 0);
             host_levels(lv);
             W.level.upload(lv, s);
             break;
         }
         IPXK_HIP(hipMemsetAsync(changed.get(), 0, sizeof(int), s));
-        for (int r = 0; r < 8; r++)
+        for (int r = 0; r < batch; r++) {
+            if (r == batch - 1) IPXK_HIP(hipMemsetAsync(changed.get(), 0, sizeof(int), s));   // only the last launch decides
             hipLaunchKernelGGL(relax_levels_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, W.rp.get(),
                                W.ri.get(), W.level.get(), changed.get());
+        }
+        launched += batch;
         IPXK_HIP(hipMemcpyAsync(W.h_flag, changed.get(), sizeof(int), hipMemcpyDeviceToHost, s));
         IPXK_HIP(hipStreamSynchronize(s));
         if (*W.h_flag == 0) break;
     }
-    // 3. stable sort of the unknowns in processing order by level
-    W.keys.resize(std::max<int64_t>(std::max<int64_t>(dim, nz), 1));
-    W.vals.resize(W.keys.size()); W.keys2.resize(W.keys.size()); W.vals2.resize(W.keys.size());
+    // 3. stable sort of the unknowns in processing order by (level, descending length)
+    const size_t need = (size_t)std::max<int64_t>(std::max<int64_t>(dim, nz), 1);
+    W.keys.ensure(need); W.vals.ensure(need); W.keys2.ensure(need); W.vals2.ensure(need);
     int nlev = 0;
-    std::vector<int> lstart, lptr;
+    std::vector<int> lstart;     // [2*nlev + 1]: first sorted unknown of (level, long part / short part)
     if (dim > 0) {
         hipLaunchKernelGGL(level_keys_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, ascending ? 1 : 0,
-                           W.level.get(), W.keys.get(), W.vals.get());
+                           W.level.get(), W.rp.get(), W.keys.get(), W.vals.get());
         sort_pairs(W, dim, 31, s);
-        // the last sorted key is the deepest level
+        // the last sorted key belongs to the deepest level
         IPXK_HIP(hipMemcpyAsync(W.h_flag, W.keys2.get() + (dim - 1), sizeof(int), hipMemcpyDeviceToHost, s));
         IPXK_HIP(hipStreamSynchronize(s));
-        nlev = *W.h_flag + 1;
-        W.lstart.resize(nlev + 1);
-        hipLaunchKernelGGL(lower_bound_kernel, dim3(grid_for(nlev + 1)), dim3(kBlock), 0, s, nlev, (int64_t)dim,
-                           W.keys2.get(), W.lstart.get());
-        lstart.resize(nlev + 1);
-        W.lstart.download(lstart.data(), (size_t)nlev + 1, s);
+        nlev = (*W.h_flag >> kLenKeyBits) + 1;
+        IPXK_REQUIRE(nlev < (1 << (31 - kLenKeyBits)), "dependency graph too deep for the 32-bit sort key");
+        // boundaries: key (l << 8) starts level l, key (l << 8 | 255 - kShortRow) starts its short rows
+        std::vector<int> bkeys((size_t)2 * nlev + 1);
+        for (int l = 0; l < nlev; l++) { bkeys[2 * l] = l << kLenKeyBits; bkeys[2 * l + 1] = (l << kLenKeyBits) | (255 - kShortRow); }
+        bkeys[2 * nlev] = nlev << kLenKeyBits;
+        DevBuf<int> dk; dk.upload(bkeys, s);
+        W.lstart.ensure(bkeys.size());
+        hipLaunchKernelGGL(lower_bound_keys_kernel, dim3(grid_for((int64_t)bkeys.size())), dim3(kBlock), 0, s, (int)bkeys.size(),
+                           (int64_t)dim, W.keys2.get(), dk.get(), W.lstart.get());
+        lstart.resize(bkeys.size());
+        W.lstart.download(lstart.data(), lstart.size(), s);
         IPXK_HIP(hipStreamSynchronize(s));
     }
-    lptr.assign(nlev + 1, 0);
-    for (int l = 0; l < nlev; l++) lptr[l + 1] = lptr[l] + (lstart[l + 1] - lstart[l] + 63) / 64 * 64;
-    const int npos = lptr[nlev];
+    // chunk layout (host arithmetic over the part sizes): positions and chunk -> position; widths and
+    // entry offsets are completed on the device
+    std::vector<int> lpos((size_t)2 * std::max(nlev, 1), 0);
+    std::vector<ChunkDesc> chunks;
+    S.level_chunk.assign((size_t)nlev + 1, 0);
+    S.level_width.assign((size_t)nlev, 0);
+    int64_t pos = 0;
+    for (int l = 0; l < nlev; l++) {
+        S.level_chunk[l] = (int)chunks.size();
+        const int nl = lstart[2 * l + 1] - lstart[2 * l], ns = lstart[2 * l + 2] - lstart[2 * l + 1];
+        S.level_width[l] = nl + ns;
+        lpos[2 * l] = (int)pos;
+        const int nlpad = (nl + kLongLanes - 1) / kLongLanes * kLongLanes;
+        for (int q = 0; q < nlpad; q += kLongLanes) chunks.push_back({(int)pos + q, 0, -1, kLongLanes});
+        pos += nlpad;
+        lpos[2 * l + 1] = (int)pos;
+        const int nspad = (ns + 63) / 64 * 64;
+        for (int q = 0; q < nspad; q += 64) chunks.push_back({(int)pos + q, 0, 0, 64});
+        pos += nspad;
+        IPXK_REQUIRE(pos < (int64_t(1) << 31), "packed factor exceeds 32-bit offsets");
+    }
+    S.level_chunk[nlev] = (int)chunks.size();
+    const int npos = (int)pos, nchunks = (int)chunks.size();
     S.nlevels = nlev;
     S.npos = npos;
-    S.level_ptr = lptr;
-    S.level_ptr_dev.upload(lptr, s);
-    S.order.resize(std::max(npos, 1));
-    IPXK_HIP(hipMemsetAsync(S.order.get(), 0xff, sizeof(int) * std::max(npos, 1), s));
-    W.posof.resize(std::max(dim, 1));
-    W.level_long.resize(std::max(nlev, 1));
-    IPXK_HIP(hipMemsetAsync(W.level_long.get(), 0, std::max(nlev, 1), s));
-    if (dim > 0)
+    S.nchunks = nchunks;
+    const size_t np1 = (size_t)std::max(npos, 1), nc1 = (size_t)std::max(nchunks, 1);
+    S.chunks.ensure(nc1);
+    if (nchunks) S.chunks.upload(chunks.data(), chunks.size(), s);
+    S.order.ensure(np1); S.diag.ensure(np1); S.len.ensure(np1);
+    IPXK_HIP(hipMemsetAsync(S.order.get(), 0xff, sizeof(int) * np1, s));
+    IPXK_HIP(hipMemsetAsync(S.len.get(), 0, sizeof(int) * np1, s));
+    if (npos > 0) hipLaunchKernelGGL(fill_double_kernel, dim3(grid_for(npos)), dim3(kBlock), 0, s, (int64_t)npos, 1.0, S.diag.get());
+    int64_t slots = 0;
+    if (dim > 0) {
+        W.lpos.ensure(lpos.size());
+        W.lpos.upload(lpos, s);
         hipLaunchKernelGGL(place_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, W.keys2.get(), W.vals2.get(),
-                           W.lstart.get(), S.level_ptr_dev.get(), W.rp.get(), S.order.get(), W.posof.get(),
-                           W.level_long.get());
-    // 4. row extents and rows in level order
-    W.len.resize((size_t)npos + 1);
-    S.ptr.resize((size_t)npos + 1);
-    hipLaunchKernelGGL(row_length_kernel, dim3(grid_for(npos + 1)), dim3(kBlock), 0, s, npos, S.order.get(),
-                       W.rp.get(), W.len.get());
-    {
-        size_t bytes = 0;
-        IPXK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, W.len.get(), S.ptr.get(), npos + 1, s));
-        if (W.cub.size() < bytes) W.cub.resize(bytes);
-        IPXK_HIP(hipcub::DeviceScan::ExclusiveSum(W.cub.get(), bytes, W.len.get(), S.ptr.get(), npos + 1, s));
+                           W.lstart.get(), W.lpos.get(), W.rp.get(), W.dgn.get(), S.order.get(), S.diag.get(), S.len.get());
+        W.csize.ensure(nc1 + 1); W.cent0.ensure(nc1 + 1);
+        hipLaunchKernelGGL(chunk_size_kernel, dim3(grid_for(nchunks)), dim3(kBlock), 0, s, nchunks, S.chunks.get(),
+                           S.len.get(), W.csize.get());
+        exclusive_scan(W, W.csize.get(), W.cent0.get(), (size_t)nchunks + 1, s);
+        hipLaunchKernelGGL(chunk_ent0_kernel, dim3(grid_for(nchunks)), dim3(kBlock), 0, s, nchunks, S.chunks.get(), W.cent0.get());
+        IPXK_HIP(hipMemcpyAsync(W.h_flag, W.cent0.get() + nchunks, sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        slots = *W.h_flag;
+        IPXK_REQUIRE(slots >= 0, "packed factor exceeds 32-bit offsets");
     }
-    const size_t nzs = (size_t)std::max<int64_t>(nz, 1);
-    S.idx.resize(nzs); S.val.resize(nzs); S.diag.resize(std::max(npos, 1));
-    if (scaled) { S.valS.resize(nzs); S.diagS.resize(std::max(npos, 1)); }
-    if (npos > 0)
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(npos)), dim3(kBlock), 0, s, npos, S.order.get(),
-                           S.ptr.get(), W.rp.get(), W.ri.get(), W.rx.get(), scaled ? W.rxS.get() : nullptr,
-                           W.dgn.get(), scaled ? W.dgnS.get() : nullptr, S.idx.get(), S.val.get(),
-                           scaled ? S.valS.get() : nullptr, S.diag.get(), scaled ? S.diagS.get() : nullptr);
-    // the O(#levels) numbers the host needs for the launch plan
-    std::vector<unsigned char> level_long(nlev, 0);
-    std::vector<int> lev_entry(nlev + 1, 0);
-    W.tmpi.resize((size_t)nlev + 1);
-    hipLaunchKernelGGL(gather_int_kernel, dim3(grid_for(nlev + 1)), dim3(kBlock), 0, s, nlev + 1, S.ptr.get(),
-                       S.level_ptr_dev.get(), W.tmpi.get());
-    W.tmpi.download(lev_entry.data(), (size_t)nlev + 1, s);
-    if (nlev > 0) W.level_long.download(level_long.data(), (size_t)nlev, s);
-    IPXK_HIP(hipStreamSynchronize(s));
-    const int ntslot = plan_sweep(S, lptr, level_long, lev_entry);
-    S.tslot.resize((size_t)std::max(ntslot, 1));
-    for (const Sweep::Launch& L : S.plan)
-        if (L.tail && L.ne > 0)
-            hipLaunchKernelGGL(tslot_kernel, dim3(grid_for(L.ne)), dim3(kBlock), 0, s, L.ne, L.e0, lptr[L.l0],
-                               lptr[L.l1], S.idx.get(), W.posof.get(), S.tslot.get() + L.tslot_off);
-    S.chunk_long.upload(sweep_chunk_flags(lptr, level_long), s);
-    IPXK_HIP(hipStreamSynchronize(s));
+    S.nentries = slots;
+    const size_t ns1 = (size_t)std::max<int64_t>(slots, 1);
+    S.idx.ensure(ns1); S.val.ensure(ns1);
+    IPXK_HIP(hipMemsetAsync(S.idx.get(), 0, sizeof(int) * ns1, s));
+    IPXK_HIP(hipMemsetAsync(S.val.get(), 0, sizeof(double) * ns1, s));
+    if (nchunks > 0)
+        hipLaunchKernelGGL(pack_entries_kernel, dim3(std::min(grid_for((int64_t)nchunks * 64), 2048)), dim3(kBlock), 0, s, nchunks,
+                           S.chunks.get(), S.order.get(), W.rp.get(), W.ri.get(), W.rx.get(), S.idx.get(), S.val.get());
+    if (scale_mode) { S.valS.ensure(ns1); S.diagS.ensure(np1); }
+    plan_sweep(S, level_launches);
+    IPXK_HIP(hipStreamSynchronize(s));    // host vectors uploaded above go out of scope
+    if (getenv("IPXK_SWEEP_STATS")) {
+        fprintf(stderr, "sweep(%s,%s): %d levels, %d positions for %d unknowns, %d chunks, %lld entry slots for %lld entries\n",
+                running ? "fwd" : "trans", ascending ? "asc" : "desc", nlev, npos, dim, S.nchunks, (long long)slots, (long long)nz);
+        for (const Sweep::Launch& L : S.plan)
+            fprintf(stderr, "   launch chunks %d..%d %s\n", L.c0, L.c1, L.one_xcd ? "one XCD" : "all XCDs");
+    }
 }
 
 }  // namespace
 
+void rescale_sweeps_device(Context* c, SplitOperator* S) {
+    hipStream_t s = c->stream;
+    for (Sweep* W : {&S->Ut, &S->Uf}) {
+        if (W->nchunks == 0) continue;
+        const int g = (W->nchunks + kBlock / 64 - 1) / (kBlock / 64);
+        if (W->scale_mode == 1)
+            hipLaunchKernelGGL(rescale_kernel<1>, dim3(g), dim3(kBlock), 0, s, W->view(false), W->nchunks,
+                               S->uscale.get(), W->valS.get(), W->diagS.get());
+        else
+            hipLaunchKernelGGL(rescale_kernel<2>, dim3(g), dim3(kBlock), 0, s, W->view(false), W->nchunks,
+                               S->uscale.get(), W->valS.get(), W->diagS.get());
+    }
+    IPXK_HIP(hipGetLastError());
+}
+
 void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const ipxint* Li, const double* Lx,
-                           const ipxint* Up, const ipxint* Ui, const double* Ux,
-                           const std::vector<double>& uscale) {
+                           const ipxint* Up, const ipxint* Ui, const double* Ux) {
     hipStream_t s = c->stream;
     const int m = S->m;
     const int64_t nzL = Lp[m], nzU = Up[m], nzUo = nzU - m;
@@ -377,11 +459,10 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
     const double t0 = now();
     // factors as given
     DevBuf<ipxint> dLp, dLi, dUp, dUi;
-    DevBuf<double> dLx, dUx, dscale;
+    DevBuf<double> dLx, dUx;
     dLp.upload(Lp, (size_t)m + 1, s); dUp.upload(Up, (size_t)m + 1, s);
     dLi.upload(Li, (size_t)nzL, s);   dLx.upload(Lx, (size_t)nzL, s);
     dUi.upload(Ui, (size_t)nzU, s);   dUx.upload(Ux, (size_t)nzU, s);
-    dscale.upload(uscale, s);
     if (m > 0) {
         // column pointers were checked on the host (monotone, totals); indices are checked here
         DevBuf<int> bad(1);
@@ -396,19 +477,20 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
     const double t1 = now();
     Scratch W;
     const size_t maxnz = (size_t)std::max<int64_t>(std::max(nzL, nzU), 1);
-    W.rp.resize((size_t)m + 1); W.ri.resize(maxnz); W.rx.resize(maxnz); W.rxS.resize(maxnz);
-    W.dgn.resize(std::max(m, 1)); W.dgnS.resize(std::max(m, 1));
+    W.rp.resize((size_t)m + 1); W.ri.resize(maxnz); W.rx.resize(maxnz);
+    W.dgn.resize(std::max(m, 1));
     W.keys.resize(std::max<size_t>(maxnz, (size_t)m + 1)); W.vals.resize(W.keys.size());
     W.keys2.resize(W.keys.size()); W.vals2.resize(W.keys.size()); W.colof.resize(maxnz);
     const int g = grid_for(m);
     const int rowbits = bits_for(std::max(m, 2));
+    const bool ll = S->level_launches;
 
     // --- U' sweep: unknown k gathers the rows above the diagonal of column k, ascending
     if (m > 0)
         hipLaunchKernelGGL(ut_rows_kernel, dim3(g), dim3(kBlock), 0, s, m, dUp.get(), dUi.get(), dUx.get(),
-                           dscale.get(), W.rp.get(), W.ri.get(), W.rx.get(), W.rxS.get(), W.dgn.get(), W.dgnS.get());
+                           W.rp.get(), W.ri.get(), W.rx.get(), W.dgn.get());
     else IPXK_HIP(hipMemsetAsync(W.rp.get(), 0, sizeof(int), s));
-    finish_sweep(c, W, S->Ut, m, nzUo, true, false, true, [&](std::vector<int>& lv) {
+    finish_sweep(c, W, S->Ut, ll, m, nzUo, true, false, 1, [&](std::vector<int>& lv) {
         for (int k = 0; k < m; k++) {                       // unknown k gathers rows i < k of column k
             int l = 0;
             for (ipxint q = Up[k]; q < Up[k + 1] - 1; q++) l = std::max(l, lv[Ui[q]] + 1);
@@ -420,7 +502,7 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
     hipLaunchKernelGGL(lt_rows_kernel, dim3(grid_for(std::max<int64_t>(nzL, m + 1))), dim3(kBlock), 0, s, m, nzL,
                        dLp.get(), dLi.get(), dLx.get(), W.rp.get(), W.ri.get(), W.rx.get());
     hipLaunchKernelGGL(fill_double_kernel, dim3(g), dim3(kBlock), 0, s, (int64_t)m, 1.0, W.dgn.get());
-    finish_sweep(c, W, S->Lt, m, nzL, false, false, false, [&](std::vector<int>& lv) {
+    finish_sweep(c, W, S->Lt, ll, m, nzL, false, false, 0, [&](std::vector<int>& lv) {
         for (int k = m - 1; k >= 0; k--) {                  // unknown k gathers rows i > k of column k
             int l = 0;
             for (ipxint q = Lp[k]; q < Lp[k + 1]; q++) l = std::max(l, lv[Li[q]] + 1);
@@ -438,9 +520,8 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
                        W.rp.get());
     if (nzL > 0)
         hipLaunchKernelGGL(rows_from_perm_kernel, dim3(grid_for(nzL)), dim3(kBlock), 0, s, nzL, W.vals2.get(),
-                           W.colof.get(), dLx.get(), (const double*)nullptr, W.ri.get(), W.rx.get(),
-                           (double*)nullptr);
-    finish_sweep(c, W, S->Lf, m, nzL, true, true, false, [&](std::vector<int>& lv) {
+                           W.colof.get(), dLx.get(), W.ri.get(), W.rx.get());
+    finish_sweep(c, W, S->Lf, ll, m, nzL, true, true, 0, [&](std::vector<int>& lv) {
         for (int j = 0; j < m; j++)                         // column j is final when reached: push to rows i > j
             for (ipxint q = Lp[j]; q < Lp[j + 1]; q++) lv[Li[q]] = std::max(lv[Li[q]], lv[j] + 1);
     });
@@ -450,15 +531,14 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
         hipLaunchKernelGGL(uf_keys_kernel, dim3(g), dim3(kBlock), 0, s, m, dUp.get(), dUi.get(), W.keys.get(),
                            W.vals.get(), W.colof.get());
         if (nzUo > 0) sort_pairs(W, nzUo, rowbits, s);
-        hipLaunchKernelGGL(u_diag_kernel, dim3(g), dim3(kBlock), 0, s, m, dUp.get(), dUx.get(), dscale.get(),
-                           W.dgn.get(), W.dgnS.get());
+        hipLaunchKernelGGL(u_diag_kernel, dim3(g), dim3(kBlock), 0, s, m, dUp.get(), dUx.get(), W.dgn.get());
     }
     hipLaunchKernelGGL(lower_bound_kernel, dim3(grid_for(m + 1)), dim3(kBlock), 0, s, m, nzUo, W.keys2.get(),
                        W.rp.get());
     if (nzUo > 0)
         hipLaunchKernelGGL(rows_from_perm_kernel, dim3(grid_for(nzUo)), dim3(kBlock), 0, s, nzUo, W.vals2.get(),
-                           W.colof.get(), dUx.get(), dscale.get(), W.ri.get(), W.rx.get(), W.rxS.get());
-    finish_sweep(c, W, S->Uf, m, nzUo, false, true, true, [&](std::vector<int>& lv) {
+                           W.colof.get(), dUx.get(), W.ri.get(), W.rx.get());
+    finish_sweep(c, W, S->Uf, ll, m, nzUo, false, true, 2, [&](std::vector<int>& lv) {
         for (int j = m - 1; j >= 0; j--)                    // descending: push to rows i < j
             for (ipxint q = Up[j]; q < Up[j + 1] - 1; q++) lv[Ui[q]] = std::max(lv[Ui[q]], lv[j] + 1);
     });

@@ -1,5 +1,5 @@
 // Shared declarations of the basis-preconditioned operator: level-ordered triangular factors on the
-// device (trisolve.hip: kernels, solves, host-side analysis; prepare_device.hip: device-side analysis).
+// device (trisolve.hip: sweep kernels, solves; prepare_device.hip: device-side analysis and packing).
 #pragma once
 
 #include <vector>
@@ -8,38 +8,53 @@
 
 namespace ipxk {
 
-constexpr int kTailWidth = 1024;
 constexpr int kShortRow = 8;     // rows up to this many entries are solved by one lane
+constexpr int kLongLanes = 8;    // lanes per unknown for longer rows
+constexpr int kLenKeyBits = 8;   // sort key = level << kLenKeyBits | (255 - min(len, 255)): inside a level the
+                                 // rows come in descending length, the long ones (> kShortRow) first
+
+// One chunk = the work of one wavefront; inside a level the rows are sorted by length, so the rows of
+// a chunk have (nearly) the same length and a chunk is a small dense block:
+//   width >= 0: 64 consecutive level-ordered positions, one lane each; entry e of lane t lives at
+//               ent0 + e*64 + t, e < width = longest row of the chunk (<= kShortRow)
+//   width <  0: 8 consecutive positions with 8 lanes each ("long rows"), -width steps of 8 entries per
+//               row; in step s lane (row q, g) holds entry 8*s + g of its row at ent0 + s*64 + 8*q + g
+// Slots beyond a row's length hold zeros and are never used (lanes stop at their length).  Either way a
+// wavefront reads its chunk with fully coalesced loads whose addresses depend on the descriptor only.
+struct ChunkDesc { int pos0, ent0, width, npos; };
 
 struct SweepView {
-    const int* order;      // [dim] unknown index of level-ordered position k
-    const int* ptr;        // [dim+1]
-    const int* idx;        // dependency unknown index
+    const ChunkDesc* chunks;
+    const int* order;            // [npos] unknown of level-ordered position k, -1 for padding
+    const double* diag;          // [npos] divisor (1.0 for unit triangular and padding)
+    const int* len;              // [npos] entries of the row
+    const int* idx;              // dependency unknown index
     const double* val;
-    const double* diag;    // [dim] diagonal (1.0 for unit triangular)
 };
 
+// A sweep is a sequence of launches, each a run of consecutive levels (= a range of chunks):
+//   all-XCD run: every workgroup takes part, results are stored write-through (visible chip-wide)
+//   one-XCD run: for runs of narrow levels; only the workgroups of ONE XCD take part, so that the
+//                hand-off of a value from its producer to its consumers goes through that XCD's L2
 struct Sweep {
-    int dim = 0, nlevels = 0, npos = 0;   // npos: level-ordered positions incl. padding
+    int dim = 0, nlevels = 0, npos = 0, nchunks = 0;
+    int64_t nentries = 0;          // entry slots (padding included)
     bool running = false;          // forward ('n') sweeps subtract one product at a time
-    DevBuf<int> order, ptr, idx;
+    int scale_mode = 0;            // 0: no scaled copy; 1: column scale of the unknown itself (U');
+                                   // 2: column scale of the dependency (U)
+    DevBuf<ChunkDesc> chunks;
+    DevBuf<int> order, idx, len;
     DevBuf<double> val, diag;      // as given
     DevBuf<double> valS, diagS;    // column-scaled copy (U sweeps only)
-    bool has_scaled = false;
-    std::vector<int> level_ptr;    // host, [nlevels+1]
-    DevBuf<int> level_ptr_dev;
-    // tail: a run of narrow levels in one LDS-resident single-workgroup launch (tslot_off: offset of
-    // its dependency-slot table in `tslot`; e0/ne: its entries); otherwise one level with gl lanes
-    // per unknown (1, or 8 for long rows)
-    struct Launch { int l0, l1; bool tail; int gl; int tslot_off, e0, ne; };
-    DevBuf<short> tslot;
-    DevBuf<unsigned char> chunk_long;   // sync-free sweep: chunk holds rows longer than kShortRow
+    std::vector<int> level_chunk;  // host, [nlevels+1] first chunk of each level
+    std::vector<int> level_width;  // host, [nlevels] unknowns per level
+    struct Launch { int c0, c1; bool one_xcd; };
     std::vector<Launch> plan;
     SweepView view(bool scaled) const {
         SweepView V;
-        V.order = order.get(); V.ptr = ptr.get(); V.idx = idx.get();
-        V.val = (scaled && has_scaled) ? valS.get() : val.get();
-        V.diag = (scaled && has_scaled) ? diagS.get() : diag.get();
+        V.chunks = chunks.get(); V.order = order.get(); V.len = len.get(); V.idx = idx.get();
+        V.val = (scaled && scale_mode) ? valS.get() : val.get();
+        V.diag = (scaled && scale_mode) ? diagS.get() : diag.get();
         return V;
     }
 };
@@ -49,39 +64,29 @@ struct SplitOperator {
     Sweep Ut, Lt, Lf, Uf;
     DevBuf<double> Wsplit;                 // n+m: colscale^2 on NONBASIC columns, else 0
     DevBuf<int> rowperm, rowperm_inv, colperm, basis, status;
+    DevBuf<ipxint> status_raw;             // n+m, as handed over
+    DevBuf<int> counters;                  // scratch flags / counts of the scaling kernels
     DevBuf<double> colscale;
+    DevBuf<double> uscale;                 // m, pivot order: column scaling of U (1 where none)
     DevBuf<unsigned char> free_mask;       // m, pivot order
     int num_free = 0;
     DevBuf<double> w0, w1, w2, w3;         // m workspaces
-    DevBuf<double> wsf;                    // intermediate vector of a sync-free solve pair
-    DevBuf<int> ticket, abort_flag;
-    bool syncfree = false;                 // IPXK_TRISOLVE=syncfree selects the single-launch sweeps
+    DevBuf<double> sw0, sw1;               // intermediate vectors of the sweeps
+    DevBuf<unsigned long long> xcc_slots;  // one-XCD runs: placement consensus words
+    unsigned epoch = 0;                    // launch counter of the one-XCD runs
+    DevBuf<int> abort_flag;
     DevBuf<double> tI;                     // m
+    bool level_launches = false;           // IPXK_TRISOLVE=levels: one launch per level (debugging aid)
 };
 
-constexpr int kTailSlots = 4096;      // unknowns (level-ordered positions) per LDS tail launch
-constexpr int kTailEntries = 7168;    // entries per LDS tail launch
-constexpr int kTailLevelsLds = 512;   // levels per LDS tail launch
-constexpr int kTailMinLevels = 4;     // shorter runs are cheaper as one launch per level
-constexpr int kTailLevelWidth = 2048; // widest level (positions) that may join a run
-constexpr int kChunkRows = 256;       // sync-free sweep: positions per ticket
-
 // Launch plan of a sweep from its level structure (host arithmetic, O(#levels)).
-//   lptr[l]        first level-ordered position of level l (levels padded to 64 positions)
-//   level_long[l]  the level has a row with more than kShortRow entries
-//   lev_entry[l]   first entry of level l in the level-ordered entry arrays
-// Fills S.plan (with the offsets of the tail runs' dependency-slot tables) and returns the total
-// number of slot-table entries.
-int plan_sweep(Sweep& S, const std::vector<int>& lptr, const std::vector<unsigned char>& level_long,
-               const std::vector<int>& lev_entry);
-// chunk flags of the sync-free sweep
-std::vector<unsigned char> sweep_chunk_flags(const std::vector<int>& lptr, const std::vector<unsigned char>& level_long);
+void plan_sweep(Sweep& S, bool level_launches);
 
 // Device-side analysis of the four sweeps (prepare_device.hip): uploads L and U as given, builds
-// the row lists, computes dependency levels, orders the unknowns and gathers the rows on the GPU.
-// uscale: column scaling of U in pivot order (1 where none).
+// the row lists, computes dependency levels, orders the unknowns and packs the rows on the GPU.
 void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const ipxint* Li, const double* Lx,
-                           const ipxint* Up, const ipxint* Ui, const double* Ux,
-                           const std::vector<double>& uscale);
+                           const ipxint* Up, const ipxint* Ui, const double* Ux);
+// (re)computes the column-scaled value sets of the U sweeps from S->uscale
+void rescale_sweeps_device(Context* c, SplitOperator* S);
 
 }  // namespace ipxk

@@ -28,7 +28,7 @@ EXPORTS = [
     "ipxk_set_stream", "ipxk_synchronize", "ipxk_set_profiling", "ipxk_num_dense_cols", "ipxk_get_rowwise",
     "ipxk_normal_prepare", "ipxk_normal_apply", "ipxk_diag_factorize", "ipxk_diag_apply",
     "ipxk_diag_get", "ipxk_pcr_solve", "ipxk_kkt_diag_factorize", "ipxk_kkt_diag_solve",
-    "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_apply", "ipxk_forward_solve",
+    "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_rescale", "ipxk_split_apply", "ipxk_forward_solve",
     "ipxk_backward_solve", "ipxk_solve_dense", "ipxk_split_levels", "ipxk_cr_solve",
     "ipxk_kkt_basis_solve", "ipxk_newton_solve", "ipxk_iterate_set", "ipxk_iterate_get", "ipxk_iterate_update",
     "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_ipm_step", "ipxk_iterate_factorize_diag", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns",
@@ -395,6 +395,10 @@ class KktContext:
         self._check(self.lib.ipxk_split_prepare(
             self.h, _ip(args[0]), _ip(args[1]), _fp(args[2]), _ip(args[3]), _ip(args[4]),
             _fp(args[5]), _ip(args[6]), _ip(args[7]), _ip(args[8]), _ip(args[9]), _fp(args[10])))
+
+    def split_rescale(self, status, colscale):
+        status, colscale = _I(status), _F(colscale)
+        self._check(self.lib.ipxk_split_rescale(self.h, _ip(status), _fp(colscale)))
 
     def split_apply(self, rhs, want_dot=True):
         rhs = _F(rhs)

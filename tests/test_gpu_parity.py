@@ -11,6 +11,8 @@ Tolerances ("Parity gate"):
 """
 import os
 
+import time
+
 import numpy as np
 import pytest
 
@@ -226,12 +228,27 @@ def test_pcr_trajectory_vs_oracle(kkt, po, oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode", ["levels", "syncfree", "levels-hostanalysis"])
+def synth_identity_model(m, n):
+    """any model matrix of the right shape (the sweeps under test only see L and U)"""
+    from ipx_amd import synth
+    return synth.synthetic_lp(m, n, 4, 99)
+
+
+SWEEP_MODES = {
+    "default": {},                                   # one-XCD runs for narrow levels, all-XCD runs otherwise
+    "levels": {"IPXK_TRISOLVE": "levels"},           # one launch per level
+    "allxcd": {"IPXK_SWEEP_NARROW": "0"},            # every run chip-wide (write-through hand-off)
+    "onexcd": {"IPXK_SWEEP_NARROW": "1000000000", "IPXK_SWEEP_MINLEVELS": "1"},   # every run on one XCD
+    "onexcd-2wgs": {"IPXK_SWEEP_NARROW": "1000000000", "IPXK_SWEEP_MINLEVELS": "1", "IPXK_SWEEP_XCD_WGS": "2"},
+}
+
+
+@pytest.mark.parametrize("mode", list(SWEEP_MODES))
 @pytest.mark.parametrize("m,n,num_free,num_fixed", [(150, 320, 0, 0), (2500, 5200, 6, 9)])
 def test_basis_path_vs_oracle(kkt, po, oracle, monkeypatch, mode, m, n, num_free, num_fixed):
-    # one launch per level / single-launch sync-free sweeps; level analysis on the device (default) or host
-    monkeypatch.setenv("IPXK_TRISOLVE", mode.split("-")[0])
-    monkeypatch.setenv("IPXK_PREPARE", "host" if mode.endswith("hostanalysis") else "device")
+    # the sweeps as runs of levels in single launches (the launch plan forced into each of its forms)
+    for k, v in SWEEP_MODES[mode].items():
+        monkeypatch.setenv(k, v)
     B, st, colscale = basis_problem(m, n, seed=41, num_free=num_free, num_fixed=num_fixed)
     A, L, U = B["A"], B["L"], B["U"]
     AI = A.with_identity()
@@ -384,10 +401,8 @@ def test_spmv_layouts_agree(kkt, po, oracle, monkeypatch):
     assert relerr(out["sliced"][2], out["phased"][2]) < 1e-8
 
 
-@pytest.mark.parametrize("prepare", ["device", "host"])
-def test_split_prepare_rejects_bad_factors(kkt, monkeypatch, prepare):
+def test_split_prepare_rejects_bad_factors(kkt):
     """indices that violate the factor contract (src/lu_update.h:43-60) are refused before any kernel uses them"""
-    monkeypatch.setenv("IPXK_PREPARE", prepare)
     m, n = 300, 700
     B, st, colscale = basis_problem(m, n, seed=51)
     ctx = kkt.KktContext(B["A"])
@@ -412,11 +427,64 @@ def test_split_prepare_rejects_bad_factors(kkt, monkeypatch, prepare):
     ctx.close()
 
 
-@pytest.mark.parametrize("prepare", ["device", "host"])
-def test_deep_level_structure(kkt, po, oracle, monkeypatch, prepare):
-    """banded planted factors: thousands of narrow levels (SURVEY 8d stress point) -- runs longer than
-    one LDS tail launch can hold, many relaxation rounds in the device-side level analysis"""
-    monkeypatch.setenv("IPXK_PREPARE", prepare)
+@pytest.mark.parametrize("mode", ["default", "allxcd", "onexcd"])
+def test_sweeps_with_dense_rows_and_columns(kkt, po, oracle, monkeypatch, mode):
+    """factors with a few rows AND columns of 70 / 300 / 1500 entries next to short ones: rows longer than
+    one 64-entry round of the 8-lane form in all four sweeps (dense rows of L and U in the forward sweeps,
+    dense columns in the transposed ones); still bit-identical to the sequential reference arithmetic"""
+    import scipy.sparse as sp
+    from ipx_amd.synth import CscMatrix
+    for k, v in SWEEP_MODES[mode].items():
+        monkeypatch.setenv(k, v)
+    m, n = 3000, 6100
+    rng = np.random.default_rng(77)
+
+    def strict_lower():
+        rows, cols = [], []
+        for j in range(m - 1):                                    # 0..3 random entries below the diagonal
+            k = rng.integers(0, 4)
+            r = np.unique(rng.integers(j + 1, m, size=k))
+            rows.append(r); cols.append(np.full(r.size, j))
+        for i, cnt in ((m - 1, 1500), (m - 7, 300), (m // 2, 70)):  # dense rows
+            c = rng.choice(i, size=cnt, replace=False)
+            rows.append(np.full(cnt, i)); cols.append(c)
+        for j, cnt in ((0, 1500), (5, 300), (m // 3, 70)):          # dense columns
+            r = j + 1 + rng.choice(m - j - 1, size=cnt, replace=False)
+            rows.append(r); cols.append(np.full(cnt, j))
+        rows, cols = np.concatenate(rows), np.concatenate(cols)
+        vals = rng.uniform(0.05, 0.3, rows.size) * rng.choice([-1.0, 1.0], rows.size) / np.sqrt(1 + np.bincount(rows, minlength=m)[rows])
+        T = sp.coo_matrix((vals, (rows, cols)), shape=(m, m)).tocsc()
+        T.sum_duplicates(); T.sort_indices()
+        return T
+
+    Lm = strict_lower()
+    Um = (strict_lower().T + sp.diags(rng.uniform(0.5, 2.0, m) * rng.choice([-1.0, 1.0], m))).tocsc()
+    Um.sort_indices()                                                # diagonal last in each column
+    mk = lambda M: CscMatrix(m, m, M.indptr, M.indices, M.data)
+    L, U = mk(Lm), mk(Um)
+    A = synth_identity_model(m, n)
+    ctx = kkt.KktContext(A)
+    ident = np.arange(m, dtype=np.int64)
+    status = np.full(n + m, -1, dtype=np.int64); status[:m] = 0
+    colscale = 10.0 ** rng.uniform(-1, 1, n + m)
+    ctx.split_prepare(L, U, ident, ident, ident, status, colscale)
+    Us = po.Csc(m, m, U.p, U.i, U.x * np.repeat(colscale[:m], np.diff(U.p)))     # ScaleColumn of the BASIC columns
+    rhs = rng.standard_normal(m)
+    assert np.array_equal(ctx.forward_solve(rhs), oracle.forward_solve(ocsc(po, L), Us, rhs))
+    assert np.array_equal(ctx.backward_solve(rhs), oracle.backward_solve(ocsc(po, L), Us, rhs))
+    # unscaled factors: Basis::SolveDense with identity permutations
+    Uo = ocsc(po, U)
+    assert np.array_equal(ctx.solve_dense(rhs, "N"), oracle.forward_solve(ocsc(po, L), Uo, rhs))
+    assert np.array_equal(ctx.solve_dense(rhs, "T"), oracle.backward_solve(ocsc(po, L), Uo, rhs))
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["default", "allxcd"])
+def test_deep_level_structure(kkt, po, oracle, monkeypatch, mode):
+    """banded planted factors: thousands of narrow levels (SURVEY 8d stress point) -- one long one-XCD run,
+    and more relaxation launches than the device-side level analysis allows itself (host scan instead)"""
+    for k, v in SWEEP_MODES[mode].items():
+        monkeypatch.setenv(k, v)
     m, n = 6000, 12500
     B, st, colscale = basis_problem(m, n, seed=47, band=12)
     A, L, U = B["A"], B["L"], B["U"]
@@ -585,11 +653,29 @@ def test_basis_path_full_size_properties(kkt, monkeypatch):
     nb = B["status"] == -1
     assert np.abs(res[nb]).max() < 1e-9 * (1 + np.abs(st["a"]).max() + np.abs(g).max())   # exact on nonbasic
     assert np.abs(res[~nb] * colscale[~nb]).max() <= tol * (1 + 1e-6)                      # tol on basic
-    # the device-side level analysis (default) builds exactly what the host-side analysis builds
+    # the single-launch runs reproduce what one launch per level computes, bit for bit
     xN, xT = ctx.solve_dense(r, "N"), ctx.solve_dense(r, "T")
+    fw, bw = ctx.forward_solve(r), ctx.backward_solve(r)
     lv = ctx.split_levels()
-    monkeypatch.setenv("IPXK_PREPARE", "host")
+    monkeypatch.setenv("IPXK_TRISOLVE", "levels")
     ctx.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
     assert ctx.split_levels() == lv
     assert np.array_equal(ctx.solve_dense(r, "N"), xN) and np.array_equal(ctx.solve_dense(r, "T"), xT)
+    assert np.array_equal(ctx.forward_solve(r), fw) and np.array_equal(ctx.backward_solve(r), bw)
+    monkeypatch.delenv("IPXK_TRISOLVE")
+    # same basis, new scaling factors: ipxk_split_rescale == a full Prepare (src/kkt_solver_basis.cc:59-64)
+    cs2 = colscale * np.where(np.isfinite(colscale), 10.0 ** np.random.default_rng(5).uniform(-0.5, 0.5, colscale.size), 1.0)
+    t0 = time.time()
+    ctx.split_rescale(B["status"], cs2)
+    t_rescale = time.time() - t0
+    a1, d1 = ctx.split_apply(u)
+    f1, b1 = ctx.forward_solve(r), ctx.backward_solve(r)
+    t0 = time.time()
+    ctx.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], cs2)
+    t_prepare = time.time() - t0
+    a2, d2 = ctx.split_apply(u)
+    assert np.array_equal(a1, a2) and d1 == d2
+    assert np.array_equal(ctx.forward_solve(r), f1) and np.array_equal(ctx.backward_solve(r), b1)
+    print("prepare %.1f ms, rescale %.1f ms" % (t_prepare * 1e3, t_rescale * 1e3))
+    assert t_rescale < 0.5 * t_prepare
     ctx.close()
