@@ -184,11 +184,13 @@ struct SlicedView {
     const int* idx;
     const double* val;
     double* partial;                   // [nslices][nrows_pad]
+    const unsigned char* row_long;     // [nrows] 1 for long rows (handled by the long-row kernels), or nullptr
 };
 
 struct SlicedMatrix {
     bool built = false;
     int nslices = 0, nrb = 0, nrows_pad = 0, max_tile = 0, R = kSlicedRows;
+    double dominant_fraction = 1.0;    // share of the entries that lie in their row block's fullest slice
     DevBuf<unsigned> tile_ptr;
     DevBuf<unsigned char> cnt;
     DevBuf<int> idx;
@@ -230,9 +232,11 @@ struct GatherMatrix {
     int grid() const { return G; }
     // # dot partials a launch produces
     int num_partials() const {
-        if (!use_sliced) return G + (nlong > 0 ? 1 : 0);
-        return sliced.nslices == 1 ? fused_grid() : combine_grid();   // fused: one dot partial per workgroup
+        const int extra = nlong > 0 ? 1 : 0;      // the long-row fix-up kernel adds one
+        if (!use_sliced) return G + extra;
+        return (sliced.nslices == 1 ? fused_grid() : combine_grid()) + extra;   // fused: one dot partial per workgroup
     }
+    std::vector<unsigned char> h_row_long;   // host copy of row_long (empty: no long rows)
 };
 
 // elements of the gathered vector per phase (IPXK_SLICE_KB overrides, default 1 MiB)

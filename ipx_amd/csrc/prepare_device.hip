@@ -170,12 +170,15 @@ __global__ void relax_levels_kernel(int dim, const int* __restrict__ rp, const i
 }
 
 // ---- step 3: order by (level, descending row length) -------------------------------------------------
-__global__ void level_keys_kernel(int dim, int ascending, const int* __restrict__ level, const int* __restrict__ rp,
-                                  int* __restrict__ keys, int* __restrict__ vals) {
+__global__ void level_keys_kernel(int dim, int ascending, int by_length, const int* __restrict__ level,
+                                  const int* __restrict__ rp, int* __restrict__ keys, int* __restrict__ vals) {
     IPXK_GRID_STRIDE(t, dim) {
         const int i = ascending ? (int)t : dim - 1 - (int)t;
         const int len = rp[i + 1] - rp[i];
-        keys[t] = (level[i] << kLenKeyBits) | (255 - (len < 255 ? len : 255));
+        // by_length: descending length inside a level; otherwise only long rows before short ones, each
+        // part in processing order
+        const int sub = by_length ? 255 - (len < 255 ? len : 255) : (len > kShortRow ? 0 : 255 - kShortRow);
+        keys[t] = (level[i] << kLenKeyBits) | sub;
         vals[t] = i;
     }
 }
@@ -341,7 +344,9 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
     int nlev = 0;
     std::vector<int> lstart;     // [2*nlev + 1]: first sorted unknown of (level, long part / short part)
     if (dim > 0) {
-        hipLaunchKernelGGL(level_keys_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, ascending ? 1 : 0,
+        const char* ord = getenv("IPXK_SWEEP_ORDER");
+        const int by_length = ord && std::string(ord) == "length" ? 1 : 0;
+        hipLaunchKernelGGL(level_keys_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, ascending ? 1 : 0, by_length,
                            W.level.get(), W.rp.get(), W.keys.get(), W.vals.get());
         sort_pairs(W, dim, 31, s);
         // the last sorted key belongs to the deepest level

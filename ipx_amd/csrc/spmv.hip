@@ -83,6 +83,7 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
     lslot.push_back((int)sp0.size());
     nlong = (int)lrow.size();
     nseg = (int)sp0.size();
+    h_row_long = rlong;
 
     // counts per (row, phase) and step sizes
     std::vector<unsigned char> cnt((size_t)nsteps * RW, 0);
@@ -176,8 +177,13 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
         use_sliced = sliced.built;
         return;
     }
-    // auto: time every eligible layout on this matrix (the gathered values do not matter for the
-    // memory system) and keep the fastest; the phased layout wins ties (5 % margin)
+    // auto.  The phased and the fused layout add a row's products in the same (the reference's) order and give
+    // bit-identical results, so a timing on the spot may choose between them (the phased layout wins ties,
+    // 5 % margin).  The sliced layout associates a row's sum per slice, hence whether it is used must not
+    // depend on a timing: it is chosen by a property of the matrix alone -- x does not fit an XCD's L2 and
+    // the gathers of a row block spread over the slices (share of its fullest slice <= 1.5 / #slices: that
+    // is where confining every XCD to one slice of x pays; measured, C3-sized: uniformly random indices 256
+    // against 300 us per apply, banded ones 240-400 against 190-220).  Timings of all three are recorded.
     DevBuf<double> tx((size_t)std::max(ncols, 1)), tout((size_t)std::max(nrows, 1));
     IPXK_HIP(hipMemsetAsync(tx.get(), 0, tx.size() * sizeof(double), s));
     hipEvent_t e0, e1;
@@ -198,27 +204,25 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
     // small matrices: a few microseconds either way, not worth two more copies of the matrix
     if (nnz >= (1 << 16)) {
         tuned_us_phased = time_current();
-        float best = 0.95f * tuned_us_phased;
-        SlicedMatrix keep;
-        for (int variant = 0; variant < 2; variant++) {      // 0: fused single slice, 1: XCD slices
-            sliced = SlicedMatrix();
-            build_sliced(hptr, hidx, hval, s, variant == 0 ? 1 : 0);
-            if (!sliced.built) continue;
-            use_sliced = true;
-            const float us = time_current();
-            use_sliced = false;
-            (variant == 0 ? tuned_us_fused : tuned_us_sliced) = us;
-            if (us < best) { best = us; keep = std::move(sliced); }
-        }
-        sliced = std::move(keep);
+        SlicedMatrix fusedm, slicedm;
+        build_sliced(hptr, hidx, hval, s, 1);
+        if (sliced.built) { use_sliced = true; tuned_us_fused = time_current(); use_sliced = false; fusedm = std::move(sliced); }
+        sliced = SlicedMatrix();
+        build_sliced(hptr, hidx, hval, s, 0);
+        if (sliced.built) { use_sliced = true; tuned_us_sliced = time_current(); use_sliced = false; slicedm = std::move(sliced); }
+        sliced = SlicedMatrix();
+        const double share = slicedm.built ? slicedm.dominant_fraction : 1.0;
+        const bool spread = slicedm.built && share <= 1.5 / slicedm.nslices;
+        if (spread) sliced = std::move(slicedm);
+        else if (fusedm.built && tuned_us_fused < 0.95f * tuned_us_phased) sliced = std::move(fusedm);
         use_sliced = sliced.built;
         if (use_sliced) {        // the phased copy of the entries is not needed any more
             idx.release(); val.release(); counts.release(); step_ptr.release();
             wg_chunk_ptr.release(); chunk_start.release(); chunk_info.release(); chunk_step.release();
         }
         if (getenv("IPXK_VERBOSE"))
-            fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld: phased %.1f us, fused %.1f us, sliced %.1f us -> %s\n",
-                    nrows, ncols, (long long)nnz, tuned_us_phased, tuned_us_fused, tuned_us_sliced,
+            fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld: phased %.1f us, fused %.1f us, sliced %.1f us (fullest-slice share %.2f) -> %s\n",
+                    nrows, ncols, (long long)nnz, tuned_us_phased, tuned_us_fused, tuned_us_sliced, share,
                     !use_sliced ? "phased" : sliced.nslices == 1 ? "fused" : "sliced");
     }
     IPXK_HIP(hipEventDestroy(e0));
@@ -230,7 +234,12 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
 void GatherMatrix::build_sliced(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s,
                                 int ns_request) {
     const int64_t x_bytes = (int64_t)ncols * 8;
-    if (nlong > 0 || nrows == 0 || nnz == 0 || ncols == 0) return;
+    if (nrows == 0 || nnz == 0 || ncols == 0) return;
+    // long rows (dense columns) stay with the long-row kernels, the tiles hold everything else
+    const std::vector<unsigned char>& rlong = h_row_long;
+    int64_t nshort = nnz;
+    for (int r = 0; r < nrows && !rlong.empty(); r++) if (rlong[r]) nshort -= hptr[r + 1] - hptr[r];
+    if (nshort == 0) return;
     int ns = 1;
     if (ns_request != 1) {
         int64_t slice_bytes = int64_t(2) << 20;          // half of an XCD's L2
@@ -259,6 +268,7 @@ void GatherMatrix::build_sliced(const ipxint* hptr, const ipxint* hidx, const do
         tptr.assign((size_t)ntiles + 1, 0);
         cnt.assign((size_t)ntiles * R, 0);
         for (int r = 0; r < nrows; r++) {
+            if (!rlong.empty() && rlong[r]) continue;
             const int64_t tile0 = (int64_t)(r / R) * ns;
             const int rr = r % R;
             for (ipxint p = hptr[r]; p < hptr[r + 1]; p++) {
@@ -277,15 +287,27 @@ void GatherMatrix::build_sliced(const ipxint* hptr, const ipxint* hidx, const do
             max_tile = std::max(max_tile, (int)tptr[t + 1]);
             tptr[t + 1] += tptr[t];
         }
-        if ((int64_t)tptr[ntiles] != nnz) return;
+        if ((int64_t)tptr[ntiles] != nshort) return;
         if (max_tile <= kSlicedMaxTile) break;
+    }
+    // how concentrated the gathers of a row block are: share of the entries in the block's fullest slice
+    // (1/ns for uniformly spread indices, ~1 for a banded matrix)
+    {
+        int64_t dom = 0;
+        for (int rb = 0; rb < nrb; rb++) {
+            unsigned best = 0;
+            for (int sl = 0; sl < ns; sl++) best = std::max(best, tptr[(size_t)rb * ns + sl + 1] - tptr[(size_t)rb * ns + sl]);
+            dom += best;
+        }
+        sliced.dominant_fraction = (double)dom / (double)nshort;
     }
     // pass 2: fill, rows in order, a row's entries in storage order (no assumption that the indices
     // of a row are sorted)
-    std::vector<int> ti((size_t)nnz);
-    std::vector<double> tv((size_t)nnz);
+    std::vector<int> ti((size_t)nshort);
+    std::vector<double> tv((size_t)nshort);
     std::vector<unsigned> cursor(tptr.begin(), tptr.end() - 1);
     for (int r = 0; r < nrows; r++) {
+        if (!rlong.empty() && rlong[r]) continue;
         const int64_t tile0 = (int64_t)(r / R) * ns;
         for (ipxint p = hptr[r]; p < hptr[r + 1]; p++) {
             const unsigned put = cursor[tile0 + hidx[p] / slice]++;
@@ -312,6 +334,7 @@ SlicedView GatherMatrix::sliced_view() const {
     V.nrows = nrows; V.nrows_pad = sliced.nrows_pad; V.nslices = sliced.nslices; V.nrb = sliced.nrb; V.R = sliced.R;
     V.tile_ptr = sliced.tile_ptr.get(); V.cnt = sliced.cnt.get();
     V.idx = sliced.idx.get(); V.val = sliced.val.get(); V.partial = sliced.partial.get();
+    V.row_long = nlong > 0 ? row_long.get() : nullptr;
     return V;
 }
 

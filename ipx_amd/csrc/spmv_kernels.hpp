@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void spmv_sliced_tile_kernel(SlicedView M, 
             for (int q = 0; q < RPT; q++) {
                 const int cq = (int)((c4 >> (8 * q)) & 255u);
                 const int r = rb * R + tid * RPT + q;
-                if (r < M.nrows) {
+                if (r < M.nrows && !(M.row_long && M.row_long[r])) {
                     double acc = epi.init(r);
                     for (int kk = 0; kk < cq; kk++) {
                         const double t = sl_prod[lds_slot(p + kk)];
@@ -432,6 +432,7 @@ __global__ __launch_bounds__(kBlock) void spmv_sliced_combine_kernel(SlicedView 
     __shared__ double red[kBlock / 64 + 1];
     double dotpart = 0.0;
     for (int r = blockIdx.x * kBlock + threadIdx.x; r < M.nrows; r += gridDim.x * kBlock) {
+        if (M.row_long && M.row_long[r]) continue;       // finished by the long-row fix-up kernel
         double acc = epi.init(r);
         for (int s = 0; s < M.nslices; s++) {
             const double t = __builtin_nontemporal_load(M.partial + (size_t)s * M.nrows_pad + r);
@@ -456,13 +457,19 @@ inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi
         if (V.R == kBlock * 4) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 4, true>), fgrid, block, lds, s, V, x, epi, dot_partials, done);
         else if (V.R == kBlock * 2) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 2, true>), fgrid, block, lds, s, V, x, epi, dot_partials, done);
         else hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 1, true>), fgrid, block, lds, s, V, x, epi, dot_partials, done);
-        return;
+    } else {
+        if (V.R == kBlock * 4) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 4, false>), grid, block, lds, s, V, x, epi, dot_partials, done);
+        else if (V.R == kBlock * 2) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 2, false>), grid, block, lds, s, V, x, epi, dot_partials, done);
+        else hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 1, false>), grid, block, lds, s, V, x, epi, dot_partials, done);
+        hipLaunchKernelGGL(spmv_sliced_combine_kernel<Epi>, dim3(M.combine_grid()), dim3(kBlock), 0, s, V, epi,
+                           dot_partials, done);
     }
-    if (V.R == kBlock * 4) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 4, false>), grid, block, lds, s, V, x, epi, dot_partials, done);
-    else if (V.R == kBlock * 2) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 2, false>), grid, block, lds, s, V, x, epi, dot_partials, done);
-    else hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 1, false>), grid, block, lds, s, V, x, epi, dot_partials, done);
-    hipLaunchKernelGGL(spmv_sliced_combine_kernel<Epi>, dim3(M.combine_grid()), dim3(kBlock), 0, s, V, epi,
-                       dot_partials, done);
+    if (M.nlong > 0) {          // rows of more than kMaxRowLen entries: segment sums + ordered fix-up
+        const GatherView G = M.view();
+        hipLaunchKernelGGL(spmv_long_kernel<Epi>, dim3(M.nseg), block, 0, s, G, x, done);
+        hipLaunchKernelGGL(spmv_long_fixup_kernel<Epi>, dim3(1), block, 0, s, G, epi, dot_partials,
+                           V.nslices == 1 ? M.fused_grid() : M.combine_grid(), done);
+    }
 }
 
 // Launches the SpMV (+ long-row kernels when the matrix has long rows).  Returns

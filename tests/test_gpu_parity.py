@@ -531,6 +531,43 @@ def test_fused_layout_random_shapes(kkt, po, oracle, monkeypatch):
         ctx.close()
 
 
+@pytest.mark.parametrize("layout", ["phased", "fused", "sliced", "auto"])
+def test_long_rows_in_every_layout(kkt, po, oracle, monkeypatch, layout):
+    """a few columns AND rows of ~5k entries (dense columns, src/diagonal_precond.cc:48-101) next to short ones:
+    the long rows go to the long-row kernels, the rest of the matrix keeps the chosen layout"""
+    import scipy.sparse as sp
+    from ipx_amd.synth import CscMatrix
+    if layout != "auto":
+        monkeypatch.setenv("IPXK_SPMV_LAYOUT", layout)
+    if layout == "sliced":
+        monkeypatch.setenv("IPXK_SLICE_TEST_KB", "16")
+    m, n = 20000, 41000
+    rng = np.random.default_rng(31)
+    base = sp.random(m, n, density=8.0 / m, random_state=5, format="lil")
+    for j in (3, 17000, n - 1):                                     # dense columns (long rows of A')
+        r = rng.choice(m, 5000, replace=False)
+        base[r, j] = rng.uniform(0.5, 2.0, r.size)
+    for i in (0, 9999):                                             # dense rows (long rows of A)
+        c = rng.choice(n, 5000, replace=False)
+        base[i, c] = rng.uniform(0.5, 2.0, c.size)
+    M = base.tocsc(); M.sort_indices()
+    A = CscMatrix(m, n, M.indptr, M.indices, M.data)
+    ctx = kkt.KktContext(A)
+    lay, _ = ctx.spmv_layout()
+    if layout != "auto":
+        assert lay == (layout, layout), lay
+    W = 10.0 ** rng.uniform(-1, 1, n + m)
+    rhs = rng.standard_normal(m)
+    ctx.normal_prepare(W)
+    l1, d1 = ctx.normal_apply(rhs)
+    l2, d2 = oracle.normal_apply(ocsc(po, A), W, rhs)
+    assert relerr(l1, l2) <= 1e-12 and abs(d1 - d2) <= 1e-12 * abs(d2)
+    assert ctx.diag_factorize(W, False) == 0
+    P, err = oracle.diag_factorize(ocsc(po, A), W, 10 ** 9, False)
+    assert relerr(ctx.diag_get()[0], P.get()[0]) <= 1e-12
+    ctx.close()
+
+
 def test_sliced_layout_random_shapes(kkt, po, oracle, monkeypatch):
     """the XCD-sliced layout on small ragged shapes (slice size shrunk to 1 KB of x so that they are
     eligible): 2, 4 and 8 slices, empty rows / columns / tiles; 1e-13 of the oracle (sums are
