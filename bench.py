@@ -53,25 +53,62 @@ def parse():
     ap.add_argument("--no-column-partition", action="store_true",
                     help="N > 1: skip the extra measurement of the column partition (config.column_partition)")
     ap.add_argument("--no-banded", action="store_true", help="skip the banded-matrix probe of the SpMV (extra field of roofline)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 2 and 5 (config.other_configs)")
     return ap.parse_args()
 
 
 def cpu_baseline(A, st, tol, maxiter):
-    """One solve of the same system on one host core (bounded: ~15-25 s at the default size)."""
+    """One solve of the same system on one host core (bounded: ~10-16 s at the default size)."""
+    return reference_diag_solve(A, st, tol, maxiter, 4)
+
+
+def kkt_residual_scaled(A, W, a, b, x, y):
+    """Residual of the system KKTSolver::Solve must satisfy (reference src/kkt_solver.h:21-27) for G = inv(W),
+    recomputed on the CPU: returns (max |D*(G x + AI'y - a)| with D = sqrt(W), max |AI x - b|)."""
+    S = A.to_scipy()
+    n = A.ncol
+    aty = np.concatenate([S.T @ y, y])
+    res1 = x / W + aty - a
+    res2 = S @ x[:n] + x[n:] - b
+    return float(np.abs(res1 * np.sqrt(W)).max()), float(np.abs(res2).max())
+
+
+def pcr_trajectory_check(ctx, A, a, b, tol, nit=10):
+    """First `nit` loop-head residual norms of the preconditioned CR (reference src/conjugate_residuals.cc:129-138)
+    on this KKT system: the HIP loop against the CPU restatement in oracle/ (pinned bit for bit to the
+    reference's objects by tests/test_oracle_vs_ref.py), same right-hand side, maxiter = nit."""
     from oracle import pyoracle as po
+    m, n = A.nrow, A.ncol
+    W, resscale = ctx.kkt_diag_get()
+    S = A.to_scipy()
+    rhs = -b + S @ (W[:n] * a[:n]) + W[n:] * a[n:]          # kkt_solver_diag.cc:90-92
+    _, it1, e1, h1, _ = ctx.pcr_solve(rhs, tol, resscale, nit, hist_cap=nit + 1)
+    orc = po.Oracle()
+    Ao = po.Csc(m, n, A.p, A.i, A.x)
+    P, _ = orc.diag_factorize(Ao, W, orc.find_dense_columns(Ao)[1], True)
+    _, it2, e2, h2 = orc.pcr_solve(lambda v: orc.normal_apply(Ao, W, v), P.apply, rhs, tol, resscale, nit,
+                                   hist_cap=nit + 1)
+    k = min(len(h1), len(h2), nit)
+    return {"first_resnorms_max_rel_diff": float(np.abs(h1[:k] - h2[:k]).max() / h2[:k].max()), "compared": int(k),
+            "iter_errflag_gpu": [int(it1), int(e1)], "iter_errflag_cpu": [int(it2), int(e2)]}
+
+
+def reference_diag_solve(A, st, tol, maxiter, reps):
+    """KKTSolverDiag::Solve of the same system on ONE host core by the reference's own objects (oracle/_ref),
+    else by the restatement; returns (cpu_baseline dict, (x, y, iterations))."""
+    from oracle import pyoracle as po
+    from ipx_amd import synth
     m, n = A.nrow, A.ncol
     Ao = po.Csc(m, n, A.p, A.i, A.x)
     cpu = os.cpu_count()
     if po.ref_available():
         try:
-            from ipx_amd import synth
             ref = po.Ref()
             v = synth.lp_vectors(m, n)
             rm = ref.model(Ao, v["rhs"], v["constr_type"], v["obj"], v["lb"], v["ub"])
             if rm.m == m and rm.n == n and not rm.dualized:
                 k = rm.kkt_diag(maxiter=maxiter)
                 k.factorize(np.ones(n + m), st["xl"], st["xu"], np.zeros(m), st["zl"], st["zu"])
-                reps = 4
                 t0 = time.perf_counter()
                 for _ in range(reps):
                     x, y, it, err = k.solve(st["a"], st["b"], tol)
@@ -91,6 +128,54 @@ def cpu_baseline(A, st, tol, maxiter):
     return dict(value=1.0 / dt, unit="solves/s", cores=1, kind="port",
                 sample="1 solve of the same system by oracle/ipx_oracle.cc (%d CR iterations, errflag %d, "
                        "%.2f s; host has %d cores)" % (it, err, dt, cpu)), (x, y, it)
+
+
+def bench_diag_config(kkt, synth, label, m, n, num_dense, args, reps_cpu):
+    """Another BASELINE.json config of the diag path on this GPU (not the headline value): ms per resident solve,
+    the NormalMatrix apply against the HBM roof, parity checks and the reference's own solve as baseline."""
+    A = synth.synthetic_lp(m, n, 8, 12345, num_dense=num_dense)
+    st = synth.synthetic_ipm_state(m, n, args.spread, 12345)
+    tol = 0.3 * np.sqrt(st["mu"])
+    ctx = kkt.KktContext(A)
+    t0 = time.perf_counter()
+    err = ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"])
+    t_fact = time.perf_counter() - t0
+    assert err == 0
+    traj = pcr_trajectory_check(ctx, A, st["a"], st["b"], tol)
+    xg, yg, itg, eg, _ = ctx.kkt_diag_solve(st["a"], st["b"], tol, args.maxiter)
+    W, _ = ctx.kkt_diag_get()
+    r1, r2 = kkt_residual_scaled(A, W, st["a"], st["b"], xg, yg)
+    ctx.set_pointer_mode(True)
+    a, b = ctx.vector(n + m, st["a"]), ctx.vector(m, st["b"])
+    x, y = ctx.vector(n + m), ctx.vector(m)
+    for _ in range(2):
+        it, errflag, tm = ctx.kkt_diag_solve_resident(a, b, x, y, tol, args.maxiter)
+    ctx.synchronize()
+    K = 10
+    t0 = time.perf_counter()
+    for _ in range(K):
+        it, errflag, tm = ctx.kkt_diag_solve_resident(a, b, x, y, tol, args.maxiter)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    rhs_d, lhs_d = ctx.vector(m, np.random.default_rng(0).standard_normal(m)), ctx.vector(m)
+    ctx.time_normal_apply(rhs_d, lhs_d, 5)
+    apply_ms = ctx.time_normal_apply(rhs_d, lhs_d, 50) / 50
+    nbytes = ctx.normal_apply_bytes
+    layouts = ctx.spmv_layout()[0]
+    ctx.set_pointer_mode(False)
+    res = {"workload": label, "solves_per_sec": 1.0 / dt, "ms_per_solve": dt * 1e3, "cr_iterations": it, "errflag": errflag,
+           "factorize_ms": t_fact * 1e3, "num_dense_cols": ctx.num_dense_cols,
+           "roofline": {"bound": "hbm", "us_per_apply": apply_ms * 1e3, "algorithmic_bytes": nbytes,
+                        "achieved": nbytes / (apply_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": nbytes / (apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "layouts": list(layouts)},
+           "parity": {"pcr_trajectory": traj, "kkt_residual_scaled_over_tol": r1 / tol, "primal_residual": r2}}
+    ctx.close()
+    if not args.no_cpu_baseline:
+        base, (xc, yc, itc) = reference_diag_solve(A, st, tol, args.maxiter, reps_cpu)
+        res["cpu_baseline"] = base
+        res["gpu_over_cpu"] = res["solves_per_sec"] / base["value"]
+        res["parity"]["iter_gpu_cpu"] = [int(itg), int(itc)]
+    return res
 
 
 def main():
@@ -239,11 +324,24 @@ def main():
         base, (xc, yc, itc) = cpu_baseline(A, st, tol, args.maxiter)
         out["cpu_baseline"] = base
         out["config"]["gpu_over_cpu"] = out["value"] / base["value"]
+        Wd, _ = ctx.kkt_diag_get()
+        r1, r2 = kkt_residual_scaled(A, Wd, st["a"], st["b"], xg, yg)
         out["config"]["parity_vs_cpu"] = {"iter_gpu": it, "iter_cpu": itc,
-                                          "y_relerr": float(np.abs(yg - yc).max() / np.abs(yc).max())}
+                                          "pcr_trajectory": pcr_trajectory_check(ctx, A, st["a"], st["b"], tol),
+                                          "kkt_residual_scaled_over_tol": r1 / tol, "primal_residual": r2,
+                                          "note": "gates of SURVEY 8d: iteration counts, first residual norms of the CR loop, "
+                                                  "recomputed scaled KKT residual (src/kkt_solver.h:21-27); the final y of an "
+                                                  "80-iteration run is not gated (1 ulp in b moves it by 1e-6)"}
     elif rank == 0:
         out["cpu_baseline"] = None
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        out["config"]["other_configs"] = {
+            "C2": bench_diag_config(kkt, synth, "BASELINE config 2: m=50k n=100k 8 nnz/col, diag-precond CR", 50000, 100000, 0, args, 10),
+            "C5": bench_diag_config(kkt, synth, "BASELINE config 5: m=200k n=400k + 32 dense columns (DiagonalPrecond with "
+                                                "Sherman-Morrison-Woodbury, src/diagonal_precond.cc:48-101)", 200000, 400000, 32, args, 3)}
     if rank == 0:
+        out["multi_gpu_note"] = ("N > 1 is launched by the driver only; no 8-GPU curve exists in this repo until a "
+                                 "SCALE_rNN.json is recorded" if world == 1 else "rows of AI partitioned over the ranks")
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
@@ -376,31 +474,119 @@ def bench_banded(kkt, synth, m, n):
 
 
 def bench_basis(kkt, synth, m, n, args):
-    """KKTSolverBasis::_Solve on the planted-LU basis (synthetic factors, SURVEY 8d)."""
+    """BASELINE config 3: KKTSolverBasis::_Solve (src/kkt_solver_basis.cc:75-194) = plain CR on the basis-split
+    operator C = I + inv(B) N N' inv(B') (src/splitted_normal_matrix.cc:90-117) on the planted-LU basis (synthetic
+    factors).  Roofline per CR iteration (= one operator application + the CR vector work):
+    algorithmic bytes of SURVEY 8d, 2 (nnz L + nnz U) 12 + 2 nnz(N) 12 + vector terms, against the HIP-event time
+    of the CR loop.  CPU baseline: the reference's own ConjugateResiduals over its own BackwardSolve /
+    AddNormalProduct / ForwardSolve composed into the operator (oracle/ref_driver.cc; the reference's Prepare and
+    _Solve themselves need BASICLU and cannot run here), one core, a bounded number of iterations."""
     A0 = synth.synthetic_lp(m, n, 8, 12345)
     B = synth.planted_lu_basis(A0, offdiag=3, seed=12345)
     st = synth.synthetic_ipm_state(m, n, 1.0, 12345)
     colscale = synth.synthetic_basis_state(B["status"], 1.0, 12345)
     ctx = kkt.KktContext(B["A"])
+    ctx.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)   # first call allocates
     t0 = time.perf_counter()
     ctx.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
     prep = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ctx.split_rescale(B["status"], colscale)
+    resc = time.perf_counter() - t0
     ctx.set_pointer_mode(True)
     a, b = ctx.vector(n + m, st["a"]), ctx.vector(m, st["b"])
     x, y = ctx.vector(n + m), ctx.vector(m)
     tol = 0.3 * np.sqrt(st["mu"])
     it, err, tm = ctx.kkt_basis_solve_resident(a, b, x, y, tol, args.maxiter)
     t0 = time.perf_counter()
-    K = 3
+    K = 5
+    cr = 0.0
     for _ in range(K):
         it, err, tm = ctx.kkt_basis_solve_resident(a, b, x, y, tol, args.maxiter)
+        cr += tm.cr
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / K
+    us_iter = cr / K / max(it, 1) * 1e6
+    ctx.set_profiling(True)          # HIP events around the three parts of every operator application
+    itp, errp, tmp = ctx.kkt_basis_solve_resident(a, b, x, y, tol, args.maxiter)
+    ctx.set_profiling(False)
+    napply = itp + 1
     lv = ctx.split_levels()
+    layouts = ctx.spmv_layout()[0]
+    nnzL, nnzU = B["L"].nnz, B["U"].nnz - m            # off-diagonal entries of U
+    nb = B["status"] == -1
+    AI = B["A"].with_identity()
+    nnzN = int(np.diff(AI.p)[nb].sum())
+    # four sweeps: every factor entry (4 B index + 8 B value) once per sweep, per unknown and sweep the
+    # right-hand side, the result and the diagonal (24 B); N N': two passes over N's entries, the two
+    # permuted m-vectors, the n-vector of column products written and read, weights; CR: 9 m-vector passes
+    bytes_iter = 2 * (nnzL + nnzU) * 12 + 4 * m * 24 + 2 * nnzN * 12 + 8 * (4 * m + 3 * (n + m)) + 9 * 8 * m
+    streamed = 2 * (nnzL + nnzU) * 12 + 4 * m * 32 + 2 * B["A"].nnz * 12
+    achieved = bytes_iter / (us_iter * 1e-6) / 1e9
+    res = {"solves_per_sec": 1.0 / dt, "ms_per_solve": dt * 1e3, "cr_iterations": it, "errflag": err,
+           "levels_Ut_Lt_L_U": lv, "prepare_s": prep, "rescale_s": resc, "us_per_cr_iteration": us_iter,
+           "cr_iterations_per_sec": 1e6 / us_iter,
+           "us_per_apply_parts": {"backward_pair_Ut_Lt": tmp.solve_Bt / napply * 1e6, "N_Nt": tmp.op / napply * 1e6,
+                                  "forward_pair_L_U": tmp.solve_B / napply * 1e6},
+           "roofline": {"bound": "hbm", "kernel": "one CR iteration on the split operator = sweep_run_kernel (U', L', L, U) + N N' [%s, %s] + CR vector kernels"
+                                                  % tuple(layouts),
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "algorithmic_bytes": bytes_iter, "streamed_bytes_estimate": streamed, "traffic": None,
+                        "dependency_levels": int(sum(lv)),
+                        "us_per_level_of_the_sweeps": (tmp.solve_Bt + tmp.solve_B) / napply * 1e6 / max(sum(lv), 1),
+                        "note": "the sweeps are bound by the dependency chain (one store-to-load hand-off per level), "
+                                "not by bytes: the fraction of the HBM roof is reported next to microseconds per level"},
+           "note": "planted (synthetic) LU factors, ~3 off-diagonals per column"}
+    ctx.set_pointer_mode(False)
+    if not args.no_cpu_baseline:
+        res.update(basis_cpu_baseline(ctx, B, AI, colscale, m, n, us_iter))
     ctx.close()
-    return {"solves_per_sec": 1.0 / dt, "cr_iterations": it, "errflag": err, "levels_Ut_Lt_L_U": lv,
-            "prepare_s": prep, "us_per_cr_iteration": tm.cr / max(it, 1) * 1e6,
-            "note": "planted (synthetic) LU factors, ~3 off-diagonals per column"}
+    return res
+
+
+def basis_cpu_baseline(ctx, B, AI, colscale, m, n, us_iter_gpu, iters=8):
+    """`iters` iterations of the reference's plain CR on the operator composed from the reference's own kernels,
+    same factors; and the HIP operator / CR against it (apply 1e-12, iterate after `iters` iterations)."""
+    from oracle import pyoracle as po
+    cs = lambda M: po.Csc(M.nrow, M.ncol, M.p, M.i, M.x)
+    orc = po.Oracle()
+    t0 = time.perf_counter()
+    S = orc.split_prepare(cs(AI), n, cs(B["L"]), cs(B["U"]), B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
+    pre = S.get()                                     # N (permuted, scaled), scaled U as the reference's Prepare builds them
+    t_prep = time.perf_counter() - t0
+    rhs = np.random.default_rng(3).standard_normal(m)
+    rhs[pre["free_positions"]] = 0.0
+    out = {}
+    kind = "port"
+    if po.ref_available():
+        try:
+            ref = po.Ref()
+            op = ref.split(cs(B["L"]), po.Csc(m, m, B["U"].p, B["U"].i, pre["Ux"]), pre["N"], pre["free_positions"])
+            apply_cpu = op.apply
+            solve_cpu = lambda: op.cr_solve(rhs, 1e-300, iters)[:3]
+            kind = "reference"
+        except Exception as exc:
+            sys.stderr.write("reference kernels unavailable (%s); using the port\n" % exc)
+    if kind == "port":
+        apply_cpu = S.apply
+        solve_cpu = lambda: orc.cr_solve(S.apply, rhs, 1e-300, None, iters)[:3]
+    l_cpu, d_cpu = apply_cpu(rhs)
+    l_gpu, d_gpu = ctx.split_apply(rhs)
+    t0 = time.perf_counter()
+    y_cpu, it_cpu, e_cpu = solve_cpu()
+    dt = time.perf_counter() - t0
+    y_gpu, it_gpu, e_gpu, _, _ = ctx.cr_solve(rhs, 1e-300, None, iters)
+    out["cpu_baseline"] = dict(value=it_cpu / dt, unit="CR iterations/s", cores=1, kind=kind,
+                               sample="%d iterations of ConjugateResiduals::Solve (src/conjugate_residuals.cc:14-88) over "
+                                      "BackwardSolve / AddNormalProduct / ForwardSolve of the %s composed into the split operator "
+                                      "on the same factors (%.2f s per iteration; building the operator on the host took %.1f s)"
+                                      % (it_cpu, "reference" if kind == "reference" else "restatement", dt / max(it_cpu, 1), t_prep))
+    out["gpu_over_cpu"] = (1e6 / us_iter_gpu) / (it_cpu / dt)
+    out["parity_vs_cpu"] = {"apply_relerr": float(np.abs(l_gpu - l_cpu).max() / np.abs(l_cpu).max()),
+                            "apply_dot_relerr": float(abs(d_gpu - d_cpu) / abs(d_cpu)),
+                            "cr_iterate_relerr_after_%d_iterations" % iters: float(np.abs(y_gpu - y_cpu).max() / np.abs(y_cpu).max()),
+                            "iter_errflag_gpu": [int(it_gpu), int(e_gpu)], "iter_errflag_cpu": [int(it_cpu), int(e_cpu)]}
+    return out
 
 
 if __name__ == "__main__":

@@ -123,23 +123,36 @@ __device__ __forceinline__ bool wait_polls(const LaneRec& R, const gu64* xo, gu6
     }
 }
 
-template <bool PLAIN>
-__device__ __forceinline__ void store_result(double* xout, int r, double res) {
+__device__ __forceinline__ void store_result(double* xout, int r, double res, bool plain) {
     gu64 out = (gu64)__double_as_longlong(res);
     if (out == kSentinel) out = kPlainNan;     // a result must never look unfinished
-    if (PLAIN)   // stays in this XCD's L2 (all consumers are on this XCD)
+    if (plain)   // stays in this XCD's L2 (all consumers are on this XCD)
         __hip_atomic_store(reinterpret_cast<gu64*>(xout) + r, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else         // write-through: visible to every XCD
         __hip_atomic_store(reinterpret_cast<gu64*>(xout) + r, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// value of lane (this lane + N) of the same 16-lane row (DPP row_shl:N); lanes whose source lies outside
+// the row keep their own value
+template <int N>
+__device__ __forceinline__ double row_shift_left(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x100 + N, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x100 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // acc -= / += the products held by the first `cnt` lanes of the 8-lane group, one at a time in lane
-// order.  All shuffles are issued before the first add, so only the adds are serial.
+// order.  Only the group's FIRST lane ends up with the sum: it fetches its neighbours' products with DPP
+// row shifts (plain VALU moves, no LDS crossbar as a shuffle would need; an aligned group of 8 never
+// leaves its 16-lane row), then adds them in order.
 template <bool RUNNING>
-__device__ __forceinline__ double ordered_combine(double acc, double prod, int cnt, int gbase) {
+__device__ __forceinline__ double ordered_combine(double acc, double prod, int cnt) {
     double v[kLongLanes];
-#pragma unroll
-    for (int t = 0; t < kLongLanes; t++) v[t] = __shfl(prod, gbase + t, 64);
+    v[0] = prod;
+    v[1] = row_shift_left<1>(prod); v[2] = row_shift_left<2>(prod); v[3] = row_shift_left<3>(prod);
+    v[4] = row_shift_left<4>(prod); v[5] = row_shift_left<5>(prod); v[6] = row_shift_left<6>(prod);
+    v[7] = row_shift_left<7>(prod);
 #pragma unroll
     for (int t = 0; t < kLongLanes; t++)
         if (t < cnt) acc = RUNNING ? acc - v[t] : acc + v[t];
@@ -147,9 +160,9 @@ __device__ __forceinline__ double ordered_combine(double acc, double prod, int c
 }
 
 // solves the chunk whose records are in R (first polls already issued into bits); false on timeout
-template <bool RUNNING, bool PLAIN>
+template <bool RUNNING>
 __device__ __forceinline__ bool solve_chunk(LaneRec& R, const ChunkDesc& d, int lane, const SweepView& S, const gu64* xo,
-                                            double* xout, gu64 (&bits)[8], int* abort_flag) {
+                                            double* xout, gu64 (&bits)[8], int* abort_flag, bool plain) {
     const bool ell = d.width >= 0;
     if (!wait_polls(R, xo, bits, abort_flag)) return false;
     if (ell) {
@@ -161,10 +174,10 @@ __device__ __forceinline__ bool solve_chunk(LaneRec& R, const ChunkDesc& d, int 
                 const double prod = RUNNING ? R.a[e] * xj : xj * R.a[e];
                 acc = RUNNING ? acc - prod : acc + prod;
             }
-        if (R.r >= 0) store_result<PLAIN>(xout, R.r, (RUNNING ? acc : R.xr - acc) / R.dg);
+        if (R.r >= 0) store_result(xout, R.r, (RUNNING ? acc : R.xr - acc) / R.dg, plain);
         return true;
     }
-    const int gl = lane & 7, gbase = lane & ~7;
+    const int gl = lane & 7;
     const int len = R.r >= 0 ? R.len : 0;
     double acc = RUNNING ? R.xr : 0.0;
     for (int first = 0;;) {          // 64 entries of the row per round (one round unless the row is longer)
@@ -177,7 +190,7 @@ __device__ __forceinline__ bool solve_chunk(LaneRec& R, const ChunkDesc& d, int 
                 const double xj = __longlong_as_double((long long)bits[t]);
                 prod = RUNNING ? R.a[t] * xj : xj * R.a[t];
             }
-            acc = ordered_combine<RUNNING>(acc, prod, min(kLongLanes, len - e0), gbase);
+            acc = ordered_combine<RUNNING>(acc, prod, min(kLongLanes, len - e0));
         }
         first += 64;
         if (!__any(first < len)) break;
@@ -190,46 +203,17 @@ __device__ __forceinline__ bool solve_chunk(LaneRec& R, const ChunkDesc& d, int 
         issue_polls(R, false, gl, first, xo, bits);
         if (!wait_polls(R, xo, bits, abort_flag)) return false;
     }
-    if (gl == 0 && R.r >= 0) store_result<PLAIN>(xout, R.r, (RUNNING ? acc : R.xr - acc) / R.dg);
+    if (gl == 0 && R.r >= 0) store_result(xout, R.r, (RUNNING ? acc : R.xr - acc) / R.dg, plain);
     return true;
 }
 
-// chunk descriptor as wave-uniform (scalar) values
-__device__ __forceinline__ ChunkDesc load_desc(const SweepView& S, int c) {
-    const ChunkDesc v = S.chunks[c];
+__device__ __forceinline__ ChunkDesc scalar_desc(const ChunkDesc& v) {   // wave-uniform (scalar) values
     ChunkDesc d;
     d.pos0 = __builtin_amdgcn_readfirstlane(v.pos0);
     d.ent0 = __builtin_amdgcn_readfirstlane(v.ent0);
     d.width = __builtin_amdgcn_readfirstlane(v.width);
     d.npos = v.npos;
     return d;
-}
-
-template <bool RUNNING, bool PLAIN>
-__device__ __forceinline__ void sweep_chunks(const SweepView& S, int c0, int c1, int gw, int NW, int lane,
-                                             const double* __restrict__ xin, double* xout, int* abort_flag) {
-    const gu64* xo = reinterpret_cast<const gu64*>(xout);
-    int c = c0 + gw;
-    if (c >= c1) return;
-    ChunkDesc d = load_desc(S, c);
-    ChunkDesc dn = c + NW < c1 ? load_desc(S, c + NW) : d;
-    LaneRec A, B;
-    load_rec(A, S, d, lane, xin);
-    for (;;) {
-        const bool ell = d.width >= 0;
-        gu64 bits[8];
-        issue_polls(A, ell, lane & 7, 0, xo, bits);
-        // the next chunk's records (and the descriptor after that) travel while this chunk waits
-        const int cn = c + NW;
-        ChunkDesc dnn = dn;
-        if (cn < c1) {
-            load_rec(B, S, dn, lane, xin);
-            if (cn + NW < c1) dnn = load_desc(S, cn + NW);
-        }
-        if (!solve_chunk<RUNNING, PLAIN>(A, d, lane, S, xo, xout, bits, abort_flag)) return;
-        if (cn >= c1) return;
-        A = B; d = dn; dn = dnn; c = cn;
-    }
 }
 
 // One run of consecutive levels = chunks [c0, c1) of a sweep.
@@ -245,38 +229,61 @@ template <bool RUNNING>
 __global__ __launch_bounds__(kBlock) void sweep_run_kernel(SweepView S, int c0, int c1, const double* __restrict__ xin,
                                                            double* xout, int xcd_mode, unsigned epoch, gu64* xcc_slots,
                                                            int* abort_flag, const int* done) {
-    if (done && *done) return;
+    if (xcd_mode && (blockIdx.x & 7)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (!xcd_mode) {
-        sweep_chunks<RUNNING, false>(S, c0, c1, blockIdx.x * (kBlock / 64) + wave, gridDim.x * (kBlock / 64), lane, xin,
-                                     xout, abort_flag);
-        return;
-    }
-    if (blockIdx.x & 7) return;
-    const int part = blockIdx.x >> 3, nparts = (gridDim.x + 7) >> 3;
-    __shared__ int same_xcd;
-    if (wave == 0) {
-        unsigned id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-        id &= 0xff;
-        if (lane == 0) __hip_atomic_store(xcc_slots + part, ((gu64)epoch << 32) | id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bool same = true;
-        for (int i = lane; i < nparts; i += 64) {
-            gu64 v;
-            int spins = 0;
-            while (((v = load_sc1(xcc_slots + i)) >> 32) != epoch) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > kSpinLimit) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-            same &= (unsigned)(v & 0xff) == id && (v >> 32) == epoch;
-        }
-        same = __all(same);
-        if (lane == 0) same_xcd = same ? 1 : 0;
-    }
-    __syncthreads();
+    const int part = xcd_mode ? blockIdx.x >> 3 : blockIdx.x;
+    const int nparts = xcd_mode ? (gridDim.x + 7) >> 3 : gridDim.x;
     const int gw = part * (kBlock / 64) + wave, NW = nparts * (kBlock / 64);
-    if (same_xcd) sweep_chunks<RUNNING, true>(S, c0, c1, gw, NW, lane, xin, xout, abort_flag);
-    else sweep_chunks<RUNNING, false>(S, c0, c1, gw, NW, lane, xin, xout, abort_flag);
+    const gu64* xo = reinterpret_cast<const gu64*>(xout);
+    int c = c0 + gw;
+    const bool active = c < c1;
+    // the first two descriptors travel while the `done` flag is read
+    ChunkDesc raw = S.chunks[active ? c : c0], rawn = S.chunks[c + NW < c1 ? c + NW : c0];
+    if (done && *done) return;
+    unsigned xcc = 0;
+    if (xcd_mode && wave == 0) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xff;
+        if (lane == 0) __hip_atomic_store(xcc_slots + part, ((gu64)epoch << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ChunkDesc d = scalar_desc(raw), dn = scalar_desc(rawn);
+    LaneRec A, B;
+    if (active) load_rec(A, S, d, lane, xin);            // in flight during the placement check
+    bool plain = false;
+    if (xcd_mode) {
+        __shared__ int same_xcd;
+        if (wave == 0) {
+            bool same = true;
+            for (int i = lane; i < nparts; i += 64) {
+                gu64 v;
+                int spins = 0;
+                while (((v = load_sc1(xcc_slots + i)) >> 32) != epoch) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kSpinLimit) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                same &= (unsigned)(v & 0xff) == xcc && (v >> 32) == epoch;
+            }
+            same = __all(same);
+            if (lane == 0) same_xcd = same ? 1 : 0;
+        }
+        __syncthreads();
+        plain = same_xcd != 0;
+    }
+    if (!active) return;
+    for (;;) {
+        gu64 bits[8];
+        issue_polls(A, d.width >= 0, lane & 7, 0, xo, bits);
+        // the next chunk's records (and the descriptor after that) travel while this chunk waits
+        const int cn = c + NW;
+        ChunkDesc dnn = dn;
+        if (cn < c1) {
+            load_rec(B, S, dn, lane, xin);
+            if (cn + NW < c1) dnn = scalar_desc(S.chunks[cn + NW]);
+        }
+        if (!solve_chunk<RUNNING>(A, d, lane, S, xo, xout, bits, abort_flag, plain)) return;
+        if (cn >= c1) return;
+        A = B; d = dn; dn = dnn; c = cn;
+    }
 }
 
 // pre-fills the result vectors of a pair of sweeps
