@@ -71,6 +71,18 @@ typedef struct ipxk_times {
     double solve_Bt;  /* backward solves          -> time_cr2_Bt              */
 } ipxk_times;
 
+/* What the reference prints through control_.Debug(3) when a CR run stops on an
+ * error (src/conjugate_residuals.cc:53-56,140-152,198-202): the numbers of the
+ * last CR run on this context, for the host classes to format. */
+typedef struct ipxk_cr_diag {
+    ipxint errflag, iter, maxiter;
+    double resnorm, tol;            /* 201: residual at the last loop head, tolerance */
+    double cdot;                    /* 202: rhs-dot-lhs of the last operator application */
+    double infnorm_residual;        /* 202 */
+    double infnorm_sresidual;       /* 202 (preconditioned CR; 0 for plain CR) */
+    double rps_old, rps_new;        /* 204: resnorm_precond_system before / after the 5 iterations */
+} ipxk_cr_diag;
+
 const char* ipxk_last_error(void);
 int ipxk_device_count(void);
 
@@ -124,9 +136,17 @@ int ipxk_diag_get(const ipxk_context* ctx, double* diagonal, double* chol);
 /* Preconditioned CR (src/conjugate_residuals.cc:90-213) with C = the prepared
  * NormalMatrix and P = the factorized DiagonalPrecond.  lhs: initial iterate in,
  * solution out.  resscale may be NULL.  maxiter < 0 means m+100.
- * interrupt (may be NULL) is polled between batches of iterations and plays
- * Control::InterruptCheck() (src/control.cc:17-22): a nonzero return value
- * stops the solve and becomes *errflag.
+ * interrupt (may be NULL) plays Control::InterruptCheck()
+ * (src/control.cc:17-22): a nonzero return value stops the solve and becomes
+ * *errflag.  Granularity: the reference polls after every iteration
+ * (src/conjugate_residuals.cc:209); here the callback is polled once per cycle
+ * of 5 iterations that the host enqueues, first after the first cycle (a
+ * system whose initial residual meets tol returns errflag 0 whatever the
+ * callback says, like the reference), and the host runs up to 2 cycles ahead
+ * of the device: *iter is the last iteration that finished, up to 15
+ * iterations after the callback first returned nonzero.  On a partitioned
+ * system the flag is reduced (max) over the ranks together with the loop's
+ * `done` snapshot, so every rank leaves the loop in the same cycle.
  * resnorm_hist (may be NULL): termination-test residual norm of each pass
  * through the loop head, at most hist_cap entries (always a host pointer). */
 typedef ipxint (*ipxk_interrupt_fn)(void* user);
@@ -135,6 +155,9 @@ int ipxk_pcr_solve(ipxk_context* ctx, const double* rhs, double tol,
                    ipxint* iter, ipxint* errflag, ipxk_interrupt_fn interrupt,
                    void* interrupt_user, double* resnorm_hist, ipxint hist_cap,
                    ipxk_times* times);
+
+/* numbers of the last CR run (any of ipxk_pcr_solve, ipxk_cr_solve, the KKT solves) */
+int ipxk_cr_diagnostics(ipxk_context* ctx, ipxk_cr_diag* out);
 
 /* ---- KKTSolverDiag (src/kkt_solver_diag.h:23-49) ------------------------- */
 /* _Factorize (src/kkt_solver_diag.cc:18-65).  xl == NULL is Factorize(nullptr)

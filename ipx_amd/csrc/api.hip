@@ -3,6 +3,7 @@
 // exception -> return-code mapping.  No arithmetic lives here.
 
 #include <algorithm>
+#include <map>
 #include <thread>
 
 #include "context.hpp"
@@ -38,7 +39,17 @@ struct Staging {
         }
     }
 };
-thread_local Staging g_staging;
+// one pair of pinned chunks per (calling thread, device): events and pinned memory belong to the device
+// that was current when they were created, and a host thread may drive contexts on several devices
+// (independent replicas).  Every entry point binds its context's device before it copies anything.
+thread_local std::map<int, Staging> g_staging_by_device;
+Staging& staging_for_current_device() {
+    int dev = 0;
+    IPXK_HIP(hipGetDevice(&dev));
+    Staging& st = g_staging_by_device[dev];
+    st.ensure();
+    return st;
+}
 }  // namespace
 
 // memcpy between caller memory and a pinned chunk; large chunks are split over a few host threads
@@ -58,8 +69,7 @@ static void chunk_memcpy(void* dst, const void* src, size_t n) {
 }
 
 void staged_h2d(void* dst_dev, const void* src_host, size_t bytes, hipStream_t s) {
-    Staging& st = g_staging;
-    st.ensure();
+    Staging& st = staging_for_current_device();
     const char* src = static_cast<const char*>(src_host);
     char* dst = static_cast<char*>(dst_dev);
     int i = 0;
@@ -73,8 +83,7 @@ void staged_h2d(void* dst_dev, const void* src_host, size_t bytes, hipStream_t s
 }
 
 void staged_d2h(void* dst_host, const void* src_dev, size_t bytes, hipStream_t s) {
-    Staging& st = g_staging;
-    st.ensure();
+    Staging& st = staging_for_current_device();
     char* dst = static_cast<char*>(dst_host);
     const char* src = static_cast<const char*>(src_dev);
     // chunk c is copied out of pinned buffer c&1 while chunk c+1 is in flight into the other one
@@ -634,6 +643,14 @@ int ipxk_split_prepare(ipxk_context* c, const ipxint* Lp, const ipxint* Li, cons
         bind_device(c);
         split_prepare_host(c, Lp, Li, Lx, Up, Ui, Ux, rowperm, colperm, basis, status, colscale);
         IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+int ipxk_cr_diagnostics(ipxk_context* c, ipxk_cr_diag* out) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && out, "NULL argument");
+        bind_device(c);
+        cr_diagnostics_dev(c, out);
     });
 }
 

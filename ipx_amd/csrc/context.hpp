@@ -147,6 +147,7 @@ CrResult cr_solve_dev(Context* c, const double* rhs, double tol, const double* r
                       ipxint maxiter, double* lhs, bool lhs_is_zero, ipxk_interrupt_fn interrupt,
                       void* user, double* hist_host, ipxint hist_cap, ipxk_times* times);
 double reduce_partials_host(Context* c, int slot, int count, bool is_max);
+void cr_diagnostics_dev(Context* c, ipxk_cr_diag* out);
 // partitioned runs: finalize this rank's partials of `slot`, all-gather, return the per-rank view
 struct PartRef publish_scalar(Context* c, int slot, int count, int op);
 // finalize this rank's partials of `slot`, all-reduce the scalar; returns a one-element view

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kBlock) void residual_init_kernel(int m, const doub
 }
 
 __global__ __launch_bounds__(kBlock) void cr_init_state_kernel(CrState* st, double tol, long long maxiter,
-                                                               long long hist_cap, PartRef rsdot) {
+                                                               long long hist_cap, PartRef rsdot, int mode) {
     __shared__ double red[kBlock / 64 + 1];
     const double r = rsdot.p ? reduce_partials<SumOp>(rsdot, red) : 0.0;
     if (threadIdx.x == 0) {
@@ -80,6 +80,8 @@ __global__ __launch_bounds__(kBlock) void cr_init_state_kernel(CrState* st, doub
         st->errflag = 0;
         st->done = 0;
         st->hist_cap = hist_cap;
+        st->diag_rps_old = st->diag_rps_new = 0.0;
+        st->mode = mode;
     }
 }
 
@@ -99,8 +101,10 @@ __global__ __launch_bounds__(kBlock) void cr_control_update_kernel(
         // :195-206 monotonicity of residual'*P*residual over the last 5 iterations
         const double rsdot = reduce_partials<SumOp>(rsdot_ref, red);
         const long long c5 = k / 5;
-        if (rsdot >= st->rps[(c5 - 1) & 1]) errflag = 204;   // IPX_ERROR_cr_no_progress
-        else if (writer) st->rps[c5 & 1] = rsdot;
+        if (rsdot >= st->rps[(c5 - 1) & 1]) {
+            errflag = 204;                                     // IPX_ERROR_cr_no_progress
+            if (writer) { st->diag_rps_old = st->rps[(c5 - 1) & 1]; st->diag_rps_new = rsdot; }
+        } else if (writer) st->rps[c5 & 1] = rsdot;
     }
     double alpha = 0.0;
     if (errflag < 0) {
@@ -190,11 +194,20 @@ __global__ __launch_bounds__(kBlock) void finalize_scalar_kernel(PartRef ref, in
     if (threadIdx.x == 0) *out = v;
 }
 
-// `done` at the end of a cycle, for the host (mapped pinned memory).  Every rank of a
-// partitioned solve reads the SAME snapshot, so all ranks enqueue the same number of cycles
-// (and hence of collectives).
+// `done` at the end of a cycle, for the host (mapped pinned memory).
 __global__ void snapshot_done_kernel(const CrState* st, int* host_slot) {
     __hip_atomic_store(host_slot, st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Partitioned solves: the ranks must leave the loop in the same cycle whatever happens (every cycle
+// enqueues collectives), so what the host reads is the MAXIMUM over the ranks of (done, interrupt flag):
+// this rank's pair goes into `flags`, an all-reduce follows, the second kernel hands the result to the host.
+__global__ void cycle_flags_kernel(const CrState* st, double interrupt_flag, double* flags) {
+    flags[0] = (double)st->done;
+    flags[1] = interrupt_flag;
+}
+__global__ void snapshot_flags_kernel(const double* flags, int* host_done, int* host_interrupt) {
+    __hip_atomic_store(host_interrupt, (int)flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_done, (int)flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------
@@ -271,18 +284,6 @@ double reduce_partials_host(Context* c, int slot, int count, bool is_max) {
     return v;
 }
 
-// max over the ranks of a host-side flag (blocking; only used when an interrupt callback is set)
-static ipxint agree_on_flag(Context* c, ipxint flag) {
-    ensure_comm_buffers(c);
-    double* d = c->comm_scalars.get() + 61;
-    const double mine = (double)flag;
-    staged_h2d(d, &mine, sizeof(double), c->stream);
-    comm_allreduce_max(c, d, 1);
-    double all = 0.0;
-    staged_d2h(&all, d, sizeof(double), c->stream);
-    return (ipxint)all;
-}
-
 static void ensure_workspaces(Context* c) {
     const size_t m = (size_t)(c->m > 0 ? c->m : 1);
     if (c->v_residual.size() != m) {
@@ -339,7 +340,9 @@ static CrResult run_cr(Context* c, const CrOps& ops, const double* rhs, double t
     int* done = &st->done;
     const int g = vec_grid(m);
     const Pub pub(c);
-    for (int i = 0; i < kDoneRing; i++) c->h_cycle_done[i] = 0;   // previous solve is synchronized
+    for (int i = 0; i < 2 * kDoneRing; i++) c->h_cycle_done[i] = 0;   // previous solve is synchronized
+    const bool multi = comm_active(c);
+    if (multi) ensure_comm_buffers(c);
 
     CrVecs v;
     v.m = m; v.lhs = lhs; v.residual = c->v_residual.get(); v.sresidual = c->v_sresidual.get();
@@ -364,7 +367,7 @@ static CrResult run_cr(Context* c, const CrOps& ops, const double* rhs, double t
     const PartRef res0 = pub.ref(kPartRes0, g), res1 = pub.ref(kPartRes1, g);
     const PartRef rsdot = MODE != kModePlain ? pub.ref(kPartRsdot, nrsdot) : PartRef{nullptr, 0, 1};
     hipLaunchKernelGGL(cr_init_state_kernel, dim3(1), dim3(kBlock), 0, s, st, tol, (long long)maxiter,
-                       (long long)hist_cap, rsdot);
+                       (long long)hist_cap, rsdot, (int)MODE);
     const double* csrc = MODE == kModePlain ? v.residual : v.sresidual;
     int ncdot = ops.applyC(c, csrc, v.Cres, nullptr);
     pub.publish(kPartCdot, ncdot, 0);
@@ -376,21 +379,27 @@ static CrResult run_cr(Context* c, const CrOps& ops, const double* rhs, double t
     const PartRef pdot_ref = pub.ref(kPartPdot, npdot);
 
     // ---- main loop: cycles of 5 iterations ----
-    ipxint interrupt_flag = 0;
+    // Control::InterruptCheck (:209 / :84) is polled once per cycle of 5 iterations, not before the first
+    // cycle (a system that needs no iteration returns its result whatever the callback says).  Single rank:
+    // a nonzero flag ends the loop at once.  Partitioned: the flag travels with the cycle's `done` snapshot
+    // through one all-reduce (max), so every rank leaves in the same cycle, kWindow cycles later.
+    ipxint interrupt_flag = 0, my_interrupt = 0;
+    bool agreed_done = false;
     for (long long cycle = 0;; cycle++) {
         const long long k0 = cycle * 5;
         if (k0 > maxiter) break;
         if (cycle >= kWindow) {
             const long long cw = cycle - kWindow;
             IPXK_HIP(hipEventSynchronize(c->ev_window[cw % (kWindow + 1)]));
-            if (*(volatile int*)(c->h_cycle_done + cw % kDoneRing)) break;
+            if (*(volatile int*)(c->h_cycle_done + cw % kDoneRing)) { agreed_done = true; break; }
+            if (multi) {
+                const int agreed = *(volatile int*)(c->h_cycle_done + kDoneRing + cw % kDoneRing);
+                if (agreed != 0) { interrupt_flag = agreed; break; }
+            }
         }
-        if (interrupt) {                                                   // :209 / :84
-            interrupt_flag = interrupt(user);
-            // ranks of a partitioned solve must leave the loop together (a time limit can expire on
-            // one rank first): agree on the largest flag
-            if (comm_active(c)) interrupt_flag = agree_on_flag(c, interrupt_flag);
-            if (interrupt_flag != 0) break;
+        if (interrupt && cycle > 0) {
+            my_interrupt = interrupt(user);
+            if (!multi && my_interrupt != 0) { interrupt_flag = my_interrupt; break; }
         }
         for (long long k = k0; k < k0 + 5 && k <= maxiter; k++) {
             hipLaunchKernelGGL((cr_control_update_kernel<MODE>), dim3(g), dim3(kBlock), 0, s, st, v,
@@ -409,7 +418,15 @@ static CrResult run_cr(Context* c, const CrOps& ops, const double* rhs, double t
                 pub.publish(kPartPdot, npdot, 0);
             }
         }
-        hipLaunchKernelGGL(snapshot_done_kernel, dim3(1), dim3(1), 0, s, st, c->d_cycle_done + cycle % kDoneRing);
+        if (multi) {
+            double* flags = c->comm_scalars.get() + 56;
+            hipLaunchKernelGGL(cycle_flags_kernel, dim3(1), dim3(1), 0, s, st, (double)my_interrupt, flags);
+            comm_allreduce_max(c, flags, 2);
+            hipLaunchKernelGGL(snapshot_flags_kernel, dim3(1), dim3(1), 0, s, flags, c->d_cycle_done + cycle % kDoneRing,
+                               c->d_cycle_done + kDoneRing + cycle % kDoneRing);
+        } else {
+            hipLaunchKernelGGL(snapshot_done_kernel, dim3(1), dim3(1), 0, s, st, c->d_cycle_done + cycle % kDoneRing);
+        }
         IPXK_HIP(hipEventRecord(c->ev_window[cycle % (kWindow + 1)], s));
     }
     IPXK_HIP(hipEventRecord(c->ev_b, s));
@@ -417,6 +434,10 @@ static CrResult run_cr(Context* c, const CrOps& ops, const double* rhs, double t
     IPXK_HIP(hipStreamSynchronize(s));
     IPXK_HIP(hipGetLastError());
 
+    // the ranks of a partitioned solve take identical decisions (identical scalars); if one of them saw the
+    // others finish without finishing itself, the replicas have diverged
+    if (multi && agreed_done && !c->h_state->done)
+        throw Error(IPXK_E_HIP, "ranks of a partitioned solve diverged (another rank finished the CR loop, this one did not)");
     CrResult res;
     if (c->h_state->done) {
         res.iter = c->h_state->iter;
@@ -443,6 +464,38 @@ static CrResult run_cr(Context* c, const CrOps& ops, const double* rhs, double t
         time_collect(c, times);
     }
     return res;
+}
+
+// infinity norm of a device vector (partials + host-side finish; diagnostics only)
+__global__ __launch_bounds__(kBlock) void infnorm_partial_kernel(int m, const double* __restrict__ x, double* partial) {
+    __shared__ double red[kBlock / 64 + 1];
+    double mx = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock) mx = MaxOp::apply(mx, fabs(x[i]));
+    mx = block_reduce<MaxOp>(mx, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = mx;
+}
+
+void cr_diagnostics_dev(Context* c, ipxk_cr_diag* out) {
+    *out = ipxk_cr_diag{};
+    IPXK_REQUIRE(c->h_state != nullptr && c->state.size() > 0, "no CR run on this context yet");
+    const CrState& st = *c->h_state;            // copied back at the end of the run
+    out->errflag = st.done ? st.errflag : 0;
+    out->iter = st.done ? st.iter : st.k_finished;
+    out->maxiter = st.maxiter;
+    out->resnorm = st.resnorm;
+    out->tol = st.tol;
+    out->cdot = st.cdot[out->iter & 1];
+    out->rps_old = st.diag_rps_old;
+    out->rps_new = st.diag_rps_new;
+    if (st.done && st.errflag == 202) {         // the vectors of the run are still in the workspaces
+        const int m = (int)c->m, g = vec_grid(m);
+        auto norm = [&](const double* v) {
+            hipLaunchKernelGGL(infnorm_partial_kernel, dim3(g), dim3(kBlock), 0, c->stream, m, v, c->part(kPartScratch));
+            return reduce_partials_host(c, kPartScratch, g, true);
+        };
+        out->infnorm_residual = norm(c->v_residual.get());
+        if (st.mode != kModePlain) out->infnorm_sresidual = norm(c->v_sresidual.get());
+    }
 }
 
 CrResult pcr_solve_dev(Context* c, const double* rhs, double tol, const double* resscale,

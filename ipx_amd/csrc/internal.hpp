@@ -257,6 +257,8 @@ struct CrState {
     int errflag;             // result
     int done;
     long long hist_cap;
+    double diag_rps_old, diag_rps_new;   // errflag 204: the two values of the monotonicity check
+    int mode;                            // CrMode of the run (cr.hip)
 };
 
 struct Context;

@@ -9,18 +9,13 @@
 #include <stdexcept>
 #include <string>
 
+#include "device_glue.h"
 #include "ipx_kkt_hip.h"
 #include "model.h"
 
 namespace ipx {
 
-inline void HipCheck(int rc) {
-    if (rc == IPXK_OK) return;
-    if (rc == IPXK_E_ALLOC) throw std::bad_alloc();
-    const std::string msg = ipxk_last_error();
-    if (rc == IPXK_E_ARGUMENT) throw std::logic_error(msg);
-    throw std::runtime_error(msg);
-}
+inline void HipCheck(int rc) { ipx_hip::Check(rc); }
 
 class HipModel {
 public:

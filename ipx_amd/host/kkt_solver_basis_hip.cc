@@ -26,10 +26,16 @@ void KKTSolverBasisHip::_Factorize(Iterate* iterate, Info* info) {
     iter_ = 0;
 
     // Basis maintenance exactly as the reference does it (src/kkt_solver_basis.cc:20-63); on
-    // return the factorization of basis_ is fresh and variable states are final.
+    // return the factorization of basis_ is fresh and variable states are final.  (The reference's
+    // _Factorize is one private function, so this also runs its CPU SplittedNormalMatrix::Prepare,
+    // whose result is not used here: duplicated O(nnz) host work per IPM iteration that only a change
+    // inside src/kkt_solver_basis.cc could remove -- see INTEGRATION.md.)
+    const bool fresh_before = basis_.FactorizationIsFresh();
     cpu_.Factorize(iterate, info);
     if (info->errflag)
         return;
+    // same basis, same factorization as at the previous hand-off: only the scaling changed
+    const bool same_factors = prepared_once_ && fresh_before && cpu_.basis_changes() == 0;
 
     // Interior point column scaling after the state changes (src/iterate.cc:183-198): fixed
     // variables scale by 0, free/implied ones by infinity -- the values the reference's
@@ -46,28 +52,31 @@ void KKTSolverBasisHip::_Factorize(Iterate* iterate, Info* info) {
     // Hand-off of the LU factors: B[rowperm,colperm] = (L+I)*U (src/lu_update.h:43-60).
     SparseMatrix L, U;
     std::vector<Int> rowperm(m), colperm(m);
-    basis_.GetLuFactors(&L, &U, rowperm.data(), colperm.data());
-    HipCheck(ipxk_split_prepare(device_.get(), L.colptr(), L.rowidx(), L.values(),
-                                U.colptr(), U.rowidx(), U.values(), rowperm.data(),
-                                colperm.data(), basic.data(), status.data(), colscale.data()));
+    if (!same_factors)
+        basis_.GetLuFactors(&L, &U, rowperm.data(), colperm.data());
+    const ipx_hip::BasisHandoff h{m, n, L.colptr(), L.rowidx(), L.values(), U.colptr(), U.rowidx(),
+                                  U.values(), rowperm.data(), colperm.data(), basic.data(),
+                                  status.data(), colscale.data()};
+    ipx_hip::HandOffBasis(device_.get(), h, same_factors);
+    prepared_once_ = true;
     factorized_ = true;
 }
 
 void KKTSolverBasisHip::_Solve(const Vector& a, const Vector& b, double tol,
                                 Vector& x, Vector& y, Info* info) {
     assert(factorized_);
-    ipxint iter = 0, errflag = 0;
-    ipxk_times times;
-    HipCheck(ipxk_kkt_basis_solve(device_.get(), &a[0], &b[0], tol, maxiter_, &x[0], &y[0],
-                                  &iter, &errflag, PollInterrupt,
-                                  const_cast<Control*>(&control_), &times));
-    info->errflag = errflag;
-    info->kktiter2 += iter;
-    info->time_cr2 += times.cr;
-    info->time_cr2_NNt += times.op;
-    info->time_cr2_B += times.solve_B;
-    info->time_cr2_Bt += times.solve_Bt;
-    iter_ += iter;
+    const ipx_hip::SolveOutcome r = ipx_hip::SolveBasisOnDevice(
+        device_.get(), &a[0], &b[0], tol, maxiter_, &x[0], &y[0], PollInterrupt,
+        const_cast<Control*>(&control_), control_.parameters().debug >= 3);
+    if (!r.debug3.empty())
+        control_.Debug(3) << r.debug3;      // the reference's messages (src/conjugate_residuals.cc:53-56)
+    info->errflag = r.errflag;
+    info->kktiter2 += r.iter;
+    info->time_cr2 += r.times.cr;
+    info->time_cr2_NNt += r.times.op;
+    info->time_cr2_B += r.times.solve_B;
+    info->time_cr2_Bt += r.times.solve_Bt;
+    iter_ += r.iter;
 }
 
 }  // namespace ipx

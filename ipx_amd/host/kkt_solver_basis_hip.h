@@ -38,6 +38,7 @@ private:
     KKTSolverBasis cpu_;        // the reference's Factorize (drop / maxvolume / refactorize)
     HipModel device_;
     bool factorized_{false};
+    bool prepared_once_{false};  // the device holds the factors of an earlier hand-off
     Int maxiter_{-1};
     Int iter_{0};
 };

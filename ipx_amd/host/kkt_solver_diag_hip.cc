@@ -45,17 +45,17 @@ void KKTSolverDiagHip::_Factorize(Iterate* pt, Info* info) {
 void KKTSolverDiagHip::_Solve(const Vector& a, const Vector& b, double tol,
                                Vector& x, Vector& y, Info* info) {
     assert(factorized_);
-    ipxint iter = 0, errflag = 0;
-    ipxk_times times;
-    HipCheck(ipxk_kkt_diag_solve(device_.get(), &a[0], &b[0], tol, maxiter_, &x[0], &y[0],
-                                 &iter, &errflag, PollInterrupt,
-                                 const_cast<Control*>(&control_), &times));
-    info->errflag = errflag;
-    info->kktiter1 += iter;
-    info->time_cr1 += times.cr;
-    info->time_cr1_AAt += times.op;
-    info->time_cr1_pre += times.precond;
-    iter_ += iter;
+    const ipx_hip::SolveOutcome r = ipx_hip::SolveDiagOnDevice(
+        device_.get(), &a[0], &b[0], tol, maxiter_, &x[0], &y[0], PollInterrupt,
+        const_cast<Control*>(&control_), control_.parameters().debug >= 3);
+    if (!r.debug3.empty())
+        control_.Debug(3) << r.debug3;      // the reference's messages (src/conjugate_residuals.cc:140-152,198-202)
+    info->errflag = r.errflag;
+    info->kktiter1 += r.iter;
+    info->time_cr1 += r.times.cr;
+    info->time_cr1_AAt += r.times.op;
+    info->time_cr1_pre += r.times.precond;
+    iter_ += r.iter;
 }
 
 }  // namespace ipx

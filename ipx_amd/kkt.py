@@ -27,7 +27,7 @@ EXPORTS = [
     "ipxk_last_error", "ipxk_device_count", "ipxk_create", "ipxk_destroy", "ipxk_set_pointer_mode",
     "ipxk_set_stream", "ipxk_synchronize", "ipxk_set_profiling", "ipxk_num_dense_cols", "ipxk_get_rowwise",
     "ipxk_normal_prepare", "ipxk_normal_apply", "ipxk_diag_factorize", "ipxk_diag_apply",
-    "ipxk_diag_get", "ipxk_pcr_solve", "ipxk_kkt_diag_factorize", "ipxk_kkt_diag_solve",
+    "ipxk_diag_get", "ipxk_pcr_solve", "ipxk_cr_diagnostics", "ipxk_kkt_diag_factorize", "ipxk_kkt_diag_solve",
     "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_rescale", "ipxk_split_apply", "ipxk_forward_solve",
     "ipxk_backward_solve", "ipxk_solve_dense", "ipxk_split_levels", "ipxk_cr_solve",
     "ipxk_kkt_basis_solve", "ipxk_newton_solve", "ipxk_iterate_set", "ipxk_iterate_get", "ipxk_iterate_update",
@@ -42,6 +42,12 @@ class IpmStepInfo(C.Structure):
     _fields_ = [("step_primal", c_f64), ("step_dual", c_f64), ("mu_before", c_f64), ("mu_after", c_f64),
                 ("sigma", c_f64), ("presidual", c_f64), ("dresidual", c_f64), ("kktiter_predictor", c_i64),
                 ("kktiter_corrector", c_i64), ("errflag", c_i64)]
+
+
+class CrDiag(C.Structure):
+    _fields_ = [("errflag", c_i64), ("iter", c_i64), ("maxiter", c_i64), ("resnorm", c_f64), ("tol", c_f64),
+                ("cdot", c_f64), ("infnorm_residual", c_f64), ("infnorm_sresidual", c_f64), ("rps_old", c_f64),
+                ("rps_new", c_f64)]
 
 
 class Times(C.Structure):
@@ -251,6 +257,11 @@ class KktContext:
 
     def pcr_solve(self, rhs, tol, resscale, maxiter, lhs0=None, hist_cap=0, interrupt=None):
         return self._cr(self.lib.ipxk_pcr_solve, rhs, tol, resscale, maxiter, lhs0, hist_cap, interrupt)
+
+    def cr_diagnostics(self):
+        d = CrDiag()
+        self._check(self.lib.ipxk_cr_diagnostics(self.h, C.byref(d)))
+        return {k: getattr(d, k) for k, _ in CrDiag._fields_}
 
     def cr_solve(self, rhs, tol, resscale, maxiter, lhs0=None, hist_cap=0, interrupt=None):
         return self._cr(self.lib.ipxk_cr_solve, rhs, tol, resscale, maxiter, lhs0, hist_cap, interrupt)

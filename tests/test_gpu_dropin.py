@@ -30,10 +30,61 @@ def test_host_classes_compile_against_reference_headers():
         pytest.skip("reference sources not present")
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "ipx_amd", "host"),
            "-I" + os.path.join(ref, "include"), "-I" + os.path.join(ref, "src")]
+    subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "ipx_amd", "host"),
+                           os.path.join(ROOT, "tests", "dropin", "handoff_main.cc")])      # the glue needs no reference header
     for f in ("kkt_solver_diag_hip.cc", "kkt_solver_basis_hip.cc"):
         subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only"] + inc + [os.path.join(ROOT, "ipx_amd", "host", f)])
     subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++"] + inc + ["-"],
                    input='#include "linear_operators_hip.h"\n', text=True, check=True)
+
+
+@pytest.mark.gpu
+def test_basis_hip_glue_on_golden_fixture(tmp_path):
+    """the host-side glue of ipx::KKTSolverBasisHip (ipx_amd/host/device_glue.h) executed on plain arrays:
+    tests/dropin/handoff_main.cc runs Factorize's hand-off (full, then scaling only) and Solve on the golden
+    basis fixture; results against the fixture's reference-kernel solution and the CPU restatement"""
+    import numpy as np
+    from oracle import pyoracle as po
+    g = np.load(os.path.join(ROOT, "tests", "golden", "basis_200.npz"))
+    m, n = int(g["m"]), int(g["n"])
+    d = str(tmp_path)
+    i64, f64 = np.int64, np.float64
+    rng = np.random.default_rng(9)
+    colscale2 = g["colscale"] * np.where(np.isfinite(g["colscale"]) & (g["colscale"] > 0), 10.0 ** rng.uniform(-0.3, 0.3, n + m), 1.0)
+    a, b = rng.uniform(-0.5, 0.5, n + m), rng.uniform(-0.5, 0.5, m)
+    tol = 1e-9
+    arrays = dict(dims=np.array([m, n], i64), Ap=g["Ap"][:n + 1], Ai=g["Ai"][:g["Ap"][n]], Ax=g["Ax"][:g["Ap"][n]],
+                  Lp=g["Lp"], Li=g["Li"], Lx=g["Lx"], Up=g["Up"], Ui=g["Ui"], Ux=g["Ux"], rowperm=g["rowperm"],
+                  colperm=g["colperm"], basis=g["basis"], status=g["status"], colscale=g["colscale"], colscale2=colscale2,
+                  a=a, b=b, tol=np.array([tol]))
+    for k, v in arrays.items():
+        np.ascontiguousarray(v, dtype=i64 if np.issubdtype(np.asarray(v).dtype, np.integer) else f64).tofile(os.path.join(d, k + ".bin"))
+    exe = os.path.join(d, "handoff")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "ipx_amd", "host"),
+                           os.path.join(ROOT, "tests", "dropin", "handoff_main.cc"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "ipx_amd", "lib"), "-lipx_kkt_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "ipx_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe, d], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "DONE" in r.stdout, r.stdout + r.stderr
+    assert "DEBUG3: CR method not converged in 2 iterations. residual = " in r.stdout, r.stdout
+    rd = lambda k, t=f64: np.fromfile(os.path.join(d, k + ".bin"), dtype=t)
+    iters = rd("iters", i64)
+    assert list(iters[[1, 3, 5, 7]]) == [0, 0, 0, 201] and iters[6] == 2
+    # the CPU restatement of KKTSolverBasis::_Solve on the same inputs
+    orc = po.Oracle()
+    cs = lambda p, i, x, nr, nc: po.Csc(nr, nc, p, i, x)
+    Ap = g["Ap"][:n + 1]
+    AIp = np.concatenate([Ap, Ap[n] + 1 + np.arange(m)])
+    AI = po.Csc(m, n + m, AIp, np.concatenate([arrays["Ai"], np.arange(m)]), np.concatenate([arrays["Ax"], np.ones(m)]))
+    L, U = cs(g["Lp"], g["Li"], g["Lx"], m, m), cs(g["Up"], g["Ui"], g["Ux"], m, m)
+    for tag, csv in (("1", g["colscale"]), ("2", colscale2)):
+        S = orc.split_prepare(AI, n, L, U, g["rowperm"], g["colperm"], g["basis"], g["status"], csv)
+        xo, yo, ito, eo, _ = S.kkt_solve(a, b, tol)
+        xg, yg = rd("x" + tag), rd("y" + tag)
+        assert eo == 0 and abs(int(iters[0 if tag == "1" else 2]) - ito) <= 2
+        assert np.abs(xg - xo).max() <= 1e-6 * np.abs(xo).max() and np.abs(yg - yo).max() <= 1e-6 * np.abs(yo).max()
+    # scaling-only hand-off == full hand-off, bit for bit
+    assert np.array_equal(rd("x2"), rd("x3")) and np.array_equal(rd("y2"), rd("y3")) and iters[2] == iters[4]
 
 
 @pytest.mark.gpu
