@@ -189,13 +189,14 @@ __global__ void level_keys_kernel(int dim, int ascending, int by_length, const i
 __global__ void place_kernel(int dim, const int* __restrict__ sorted_key, const int* __restrict__ sorted_unknown,
                              const int* __restrict__ lstart, const int* __restrict__ lpos,
                              const int* __restrict__ rp, const double* __restrict__ dgn, int* __restrict__ order,
-                             double* __restrict__ diag, int* __restrict__ len) {
+                             int* __restrict__ posof, double* __restrict__ diag, int* __restrict__ len) {
     IPXK_GRID_STRIDE(t, dim) {
         const int key = sorted_key[t], i = sorted_unknown[t];
         const int l = key >> kLenKeyBits;
         const int part = (int)t >= lstart[2 * l + 1] ? 1 : 0;
         const int pos = lpos[2 * l + part] + ((int)t - lstart[2 * l + part]);
         order[pos] = i;
+        posof[i] = pos;
         diag[pos] = dgn[i];
         len[pos] = rp[i + 1] - rp[i];
     }
@@ -220,30 +221,23 @@ __global__ void chunk_ent0_kernel(int nchunks, ChunkDesc* __restrict__ chunks, c
     IPXK_GRID_STRIDE(c, nchunks) chunks[c].ent0 = ent0[c];
 }
 
-// one wavefront per chunk copies the rows of its chunk into the chunk's block
+// one wavefront per chunk copies the rows of its chunk into the chunk's block; dependencies become positions
 __global__ __launch_bounds__(kBlock) void pack_entries_kernel(int nchunks, const ChunkDesc* __restrict__ chunks,
-                                                              const int* __restrict__ order, const int* __restrict__ rp,
+                                                              const int* __restrict__ order, const int* __restrict__ posof,
+                                                              const int* __restrict__ rp,
                                                               const int* __restrict__ ri, const double* __restrict__ rx,
                                                               int* __restrict__ idx, double* __restrict__ val) {
     const int lane = threadIdx.x & 63;
     for (int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); c < nchunks; c += gridDim.x * (kBlock / 64)) {
         const ChunkDesc d = chunks[c];
-        if (d.width >= 0) {
-            const int i = order[d.pos0 + lane];
-            if (i < 0) continue;
-            const int p0 = rp[i], n = rp[i + 1] - p0;
-            for (int e = 0; e < n; e++) {
-                idx[d.ent0 + e * 64 + lane] = ri[p0 + e];
-                val[d.ent0 + e * 64 + lane] = rx[p0 + e];
-            }
-        } else {
-            const int i = order[d.pos0 + (lane >> 3)], gl = lane & 7;
-            if (i < 0) continue;
-            const int p0 = rp[i], n = rp[i + 1] - p0;
-            for (int e = gl; e < n; e += kLongLanes) {
-                idx[d.ent0 + (e >> 3) * 64 + lane] = ri[p0 + e];
-                val[d.ent0 + (e >> 3) * 64 + lane] = rx[p0 + e];
-            }
+        const bool ell = d.width >= 0;
+        const int i = order[ell ? d.pos0 + lane : d.pos0 + (lane >> 3)];
+        if (i < 0) continue;
+        const int p0 = rp[i], n = rp[i + 1] - p0;
+        for (int e = ell ? 0 : (lane & 7); e < n; e += ell ? 1 : kLongLanes) {
+            const int64_t slot = ell ? (int64_t)d.ent0 + e * 64 + lane : (int64_t)d.ent0 + (e >> 3) * 64 + lane;
+            idx[slot] = posof[ri[p0 + e]];
+            val[slot] = rx[p0 + e];
         }
     }
 }
@@ -252,7 +246,8 @@ __global__ __launch_bounds__(kBlock) void pack_entries_kernel(int nchunks, const
 // MODE 1 (U' sweep): unknown k gathers column k of U: every entry and the diagonal times uscale[k]
 // MODE 2 (U sweep): unknown i walks row i of U: entry (i, k) times uscale[k], the diagonal times uscale[i]
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void rescale_kernel(SweepView S, int nchunks, const double* __restrict__ uscale,
+__global__ __launch_bounds__(kBlock) void rescale_kernel(SweepView S, const int* __restrict__ order, int nchunks,
+                                                         const double* __restrict__ uscale,
                                                          double* __restrict__ valS, double* __restrict__ diagS) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -260,14 +255,14 @@ __global__ __launch_bounds__(kBlock) void rescale_kernel(SweepView S, int nchunk
     const ChunkDesc d = S.chunks[c];
     const bool ell = d.width >= 0;
     const int pos = ell ? d.pos0 + lane : d.pos0 + (lane >> 3), gl = lane & 7;
-    const int r = S.order[pos];
+    const int r = order[pos];
     if (r < 0) { if (ell || gl == 0) diagS[pos] = 1.0; return; }
     const double own = uscale[r];
     if (ell || gl == 0) diagS[pos] = S.diag[pos] * own;
     const int len = S.len[pos];
     for (int e = ell ? 0 : gl; e < len; e += ell ? 1 : kLongLanes) {
         const int64_t slot = ell ? (int64_t)d.ent0 + e * 64 + lane : (int64_t)d.ent0 + (e >> 3) * 64 + lane;
-        valS[slot] = S.val[slot] * (MODE == 1 ? own : uscale[S.idx[slot]]);
+        valS[slot] = S.val[slot] * (MODE == 1 ? own : uscale[order[S.idx[slot]]]);
     }
 }
 
@@ -395,7 +390,8 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
     const size_t np1 = (size_t)std::max(npos, 1), nc1 = (size_t)std::max(nchunks, 1);
     S.chunks.ensure(nc1);
     if (nchunks) S.chunks.upload(chunks.data(), chunks.size(), s);
-    S.order.ensure(np1); S.diag.ensure(np1); S.len.ensure(np1);
+    S.order.ensure(np1); S.diag.ensure(np1); S.len.ensure(np1); S.src.ensure(np1); S.y.ensure(np1);
+    S.posof.ensure((size_t)std::max(dim, 1));
     IPXK_HIP(hipMemsetAsync(S.order.get(), 0xff, sizeof(int) * np1, s));
     IPXK_HIP(hipMemsetAsync(S.len.get(), 0, sizeof(int) * np1, s));
     if (npos > 0) hipLaunchKernelGGL(fill_double_kernel, dim3(grid_for(npos)), dim3(kBlock), 0, s, (int64_t)npos, 1.0, S.diag.get());
@@ -404,7 +400,8 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
         W.lpos.ensure(lpos.size());
         W.lpos.upload(lpos, s);
         hipLaunchKernelGGL(place_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, W.keys2.get(), W.vals2.get(),
-                           W.lstart.get(), W.lpos.get(), W.rp.get(), W.dgn.get(), S.order.get(), S.diag.get(), S.len.get());
+                           W.lstart.get(), W.lpos.get(), W.rp.get(), W.dgn.get(), S.order.get(), S.posof.get(), S.diag.get(),
+                           S.len.get());
         W.csize.ensure(nc1 + 1); W.cent0.ensure(nc1 + 1);
         hipLaunchKernelGGL(chunk_size_kernel, dim3(grid_for(nchunks)), dim3(kBlock), 0, s, nchunks, S.chunks.get(),
                            S.len.get(), W.csize.get());
@@ -422,7 +419,8 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
     IPXK_HIP(hipMemsetAsync(S.val.get(), 0, sizeof(double) * ns1, s));
     if (nchunks > 0)
         hipLaunchKernelGGL(pack_entries_kernel, dim3(std::min(grid_for((int64_t)nchunks * 64), 2048)), dim3(kBlock), 0, s, nchunks,
-                           S.chunks.get(), S.order.get(), W.rp.get(), W.ri.get(), W.rx.get(), S.idx.get(), S.val.get());
+                           S.chunks.get(), S.order.get(), S.posof.get(), W.rp.get(), W.ri.get(), W.rx.get(), S.idx.get(),
+                           S.val.get());
     if (scale_mode) { S.valS.ensure(ns1); S.diagS.ensure(np1); }
     plan_sweep(S, level_launches);
     IPXK_HIP(hipStreamSynchronize(s));    // host vectors uploaded above go out of scope
@@ -430,7 +428,8 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
         fprintf(stderr, "sweep(%s,%s): %d levels, %d positions for %d unknowns, %d chunks, %lld entry slots for %lld entries\n",
                 running ? "fwd" : "trans", ascending ? "asc" : "desc", nlev, npos, dim, S.nchunks, (long long)slots, (long long)nz);
         for (const Sweep::Launch& L : S.plan)
-            fprintf(stderr, "   launch chunks %d..%d %s\n", L.c0, L.c1, L.one_xcd ? "one XCD" : "all XCDs");
+            fprintf(stderr, "   launch chunks %d..%d %s\n", L.c0, L.c1,
+                    L.kind == Sweep::kOneXcd ? "one XCD" : "all XCDs");
     }
 }
 
@@ -442,10 +441,10 @@ void rescale_sweeps_device(Context* c, SplitOperator* S) {
         if (W->nchunks == 0) continue;
         const int g = (W->nchunks + kBlock / 64 - 1) / (kBlock / 64);
         if (W->scale_mode == 1)
-            hipLaunchKernelGGL(rescale_kernel<1>, dim3(g), dim3(kBlock), 0, s, W->view(false), W->nchunks,
+            hipLaunchKernelGGL(rescale_kernel<1>, dim3(g), dim3(kBlock), 0, s, W->view(false), W->order.get(), W->nchunks,
                                S->uscale.get(), W->valS.get(), W->diagS.get());
         else
-            hipLaunchKernelGGL(rescale_kernel<2>, dim3(g), dim3(kBlock), 0, s, W->view(false), W->nchunks,
+            hipLaunchKernelGGL(rescale_kernel<2>, dim3(g), dim3(kBlock), 0, s, W->view(false), W->order.get(), W->nchunks,
                                S->uscale.get(), W->valS.get(), W->diagS.get());
     }
     IPXK_HIP(hipGetLastError());

@@ -68,10 +68,10 @@ __device__ __forceinline__ gu64 load_sc1(const gu64* p) {
 
 // What one lane needs for its part of a chunk; loaded one chunk ahead of use.
 struct LaneRec {
-    int r;          // unknown (-1: padding)
+    int src;        // index of the right-hand side in the input vector (-1: padding)
     int len;        // entries of the row
     double dg, xr;
-    int j[8];
+    int j[8];       // dependency positions
     double a[8];
 };
 
@@ -79,7 +79,7 @@ __device__ __forceinline__ void load_rec(LaneRec& R, const SweepView& S, const C
                                          const double* __restrict__ xin) {
     // every address depends on the (scalar) descriptor only: one round trip, fully coalesced
     const int pos = d.width >= 0 ? d.pos0 + lane : d.pos0 + (lane >> 3);
-    R.r = S.order[pos];
+    R.src = S.src[pos];
     R.dg = S.diag[pos];
     R.len = S.len[pos];
     const int steps = d.width >= 0 ? d.width : min(-d.width, 8);     // wave-uniform
@@ -91,20 +91,35 @@ __device__ __forceinline__ void load_rec(LaneRec& R, const SweepView& S, const C
             R.a[e] = S.val[d.ent0 + e * 64 + lane];
         }
     }
-    R.xr = R.r >= 0 ? xin[R.r] : 0.0;
+    R.xr = R.src >= 0 ? xin[R.src] : 0.0;
 }
 
-// first poll of the dependencies of the lane's (up to 8) entries starting at entry `first`
-__device__ __forceinline__ void issue_polls(const LaneRec& R, bool ell, int gl, int first, const gu64* xo, gu64 (&bits)[8]) {
+// ---- how results travel from the wavefront that computes them to the wavefronts that need them ----
+// (the value is the flag in every case: a slot holds the sentinel until its one and only store)
+// Through memory: every look at a dependency bypasses L1; results are stored write-through, or with plain
+// stores that stay in the XCD's L2 when all workgroups of the launch are known to share one XCD.
+struct HandGlobal {
+    const gu64* xo; double* xout; bool plain_store;
+    __device__ __forceinline__ gu64 look(int pj) const { return load_sc1(xo + pj); }
+    __device__ __forceinline__ void store(int pos, gu64 out) const {
+        if (plain_store) __hip_atomic_store(reinterpret_cast<gu64*>(xout) + pos, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(reinterpret_cast<gu64*>(xout) + pos, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+// first look at the dependencies of the lane's (up to 8) entries starting at entry `first`
+template <class Hand>
+__device__ __forceinline__ void issue_polls(const LaneRec& R, bool ell, int gl, int first, const Hand& H, gu64 (&bits)[8]) {
 #pragma unroll
     for (int t = 0; t < 8; t++) {
         const int e = ell ? t : first + t * 8 + gl;
-        bits[t] = (R.r >= 0 && e < R.len) ? load_sc1(xo + R.j[t]) : 0ull;
+        bits[t] = 0ull;
+        if (R.src >= 0 && e < R.len) bits[t] = H.look(R.j[t]);
     }
 }
 
 // polls until every dependency holds a value; false on timeout (abort raised)
-__device__ __forceinline__ bool wait_polls(const LaneRec& R, const gu64* xo, gu64 (&bits)[8], int* abort_flag) {
+template <class Hand>
+__device__ __forceinline__ bool wait_polls(const LaneRec& R, const Hand& H, gu64 (&bits)[8], int* abort_flag) {
     int spins = 0;
     for (;;) {
         bool ok = true;
@@ -114,7 +129,7 @@ __device__ __forceinline__ bool wait_polls(const LaneRec& R, const gu64* xo, gu6
         __builtin_amdgcn_s_sleep(1);
 #pragma unroll
         for (int t = 0; t < 8; t++)
-            if (bits[t] == kSentinel) bits[t] = load_sc1(xo + R.j[t]);
+            if (bits[t] == kSentinel) bits[t] = H.look(R.j[t]);
         if (++spins > kSpinLimit ||
             ((spins & 255) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
             __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -123,13 +138,11 @@ __device__ __forceinline__ bool wait_polls(const LaneRec& R, const gu64* xo, gu6
     }
 }
 
-__device__ __forceinline__ void store_result(double* xout, int r, double res, bool plain) {
+template <class Hand>
+__device__ __forceinline__ void store_result(const Hand& H, int pos, double res) {
     gu64 out = (gu64)__double_as_longlong(res);
     if (out == kSentinel) out = kPlainNan;     // a result must never look unfinished
-    if (plain)   // stays in this XCD's L2 (all consumers are on this XCD)
-        __hip_atomic_store(reinterpret_cast<gu64*>(xout) + r, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else         // write-through: visible to every XCD
-        __hip_atomic_store(reinterpret_cast<gu64*>(xout) + r, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    H.store(pos, out);
 }
 
 // value of lane (this lane + N) of the same 16-lane row (DPP row_shl:N); lanes whose source lies outside
@@ -159,12 +172,13 @@ __device__ __forceinline__ double ordered_combine(double acc, double prod, int c
     return acc;
 }
 
-// solves the chunk whose records are in R (first polls already issued into bits); false on timeout
-template <bool RUNNING>
-__device__ __forceinline__ bool solve_chunk(LaneRec& R, const ChunkDesc& d, int lane, const SweepView& S, const gu64* xo,
-                                            double* xout, gu64 (&bits)[8], int* abort_flag, bool plain) {
+// solves the chunk whose records are in R (first look at the dependencies already issued into bits);
+// false on timeout
+template <bool RUNNING, class Hand>
+__device__ __forceinline__ bool solve_chunk(LaneRec& R, const ChunkDesc& d, int lane, const SweepView& S, const Hand& H,
+                                            gu64 (&bits)[8], int* abort_flag) {
     const bool ell = d.width >= 0;
-    if (!wait_polls(R, xo, bits, abort_flag)) return false;
+    if (!wait_polls(R, H, bits, abort_flag)) return false;
     if (ell) {
         double acc = RUNNING ? R.xr : 0.0;
 #pragma unroll
@@ -174,11 +188,12 @@ __device__ __forceinline__ bool solve_chunk(LaneRec& R, const ChunkDesc& d, int 
                 const double prod = RUNNING ? R.a[e] * xj : xj * R.a[e];
                 acc = RUNNING ? acc - prod : acc + prod;
             }
-        if (R.r >= 0) store_result(xout, R.r, (RUNNING ? acc : R.xr - acc) / R.dg, plain);
+        // padding positions get a value too (1 wavefront = 1 contiguous store; nobody depends on them)
+        store_result(H, d.pos0 + lane, R.src >= 0 ? (RUNNING ? acc : R.xr - acc) / R.dg : 0.0);
         return true;
     }
     const int gl = lane & 7;
-    const int len = R.r >= 0 ? R.len : 0;
+    const int len = R.src >= 0 ? R.len : 0;
     double acc = RUNNING ? R.xr : 0.0;
     for (int first = 0;;) {          // 64 entries of the row per round (one round unless the row is longer)
 #pragma unroll
@@ -200,10 +215,10 @@ __device__ __forceinline__ bool solve_chunk(LaneRec& R, const ChunkDesc& d, int 
             R.j[t] = 0; R.a[t] = 0.0;
             if (step < -d.width) { R.j[t] = S.idx[d.ent0 + step * 64 + lane]; R.a[t] = S.val[d.ent0 + step * 64 + lane]; }
         }
-        issue_polls(R, false, gl, first, xo, bits);
-        if (!wait_polls(R, xo, bits, abort_flag)) return false;
+        issue_polls(R, false, gl, first, H, bits);
+        if (!wait_polls(R, H, bits, abort_flag)) return false;
     }
-    if (gl == 0 && R.r >= 0) store_result(xout, R.r, (RUNNING ? acc : R.xr - acc) / R.dg, plain);
+    if (gl == 0) store_result(H, d.pos0 + (lane >> 3), R.src >= 0 ? (RUNNING ? acc : R.xr - acc) / R.dg : 0.0);
     return true;
 }
 
@@ -214,6 +229,28 @@ __device__ __forceinline__ ChunkDesc scalar_desc(const ChunkDesc& v) {   // wave
     d.width = __builtin_amdgcn_readfirstlane(v.width);
     d.npos = v.npos;
     return d;
+}
+
+// the wavefront's chunks c, c + NW, ... < c1; A holds the records of chunk c (descriptor d), dn is the
+// descriptor of chunk c + NW
+template <bool RUNNING, class Hand>
+__device__ __forceinline__ void chunk_loop(const SweepView& S, int c, int c1, int NW, int lane, const double* __restrict__ xin,
+                                           const Hand& H, LaneRec& A, ChunkDesc d, ChunkDesc dn, int* abort_flag) {
+    LaneRec B;
+    for (;;) {
+        gu64 bits[8];
+        issue_polls(A, d.width >= 0, lane & 7, 0, H, bits);
+        // the next chunk's records (and the descriptor after that) travel while this chunk waits
+        const int cn = c + NW;
+        ChunkDesc dnn = dn;
+        if (cn < c1) {
+            load_rec(B, S, dn, lane, xin);
+            if (cn + NW < c1) dnn = scalar_desc(S.chunks[cn + NW]);
+        }
+        if (!solve_chunk<RUNNING>(A, d, lane, S, H, bits, abort_flag)) return;
+        if (cn >= c1) return;
+        A = B; d = dn; dn = dnn; c = cn;
+    }
 }
 
 // One run of consecutive levels = chunks [c0, c1) of a sweep.
@@ -247,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void sweep_run_kernel(SweepView S, int c0, 
         if (lane == 0) __hip_atomic_store(xcc_slots + part, ((gu64)epoch << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     ChunkDesc d = scalar_desc(raw), dn = scalar_desc(rawn);
-    LaneRec A, B;
+    LaneRec A;
     if (active) load_rec(A, S, d, lane, xin);            // in flight during the placement check
     bool plain = false;
     if (xcd_mode) {
@@ -270,29 +307,17 @@ __global__ __launch_bounds__(kBlock) void sweep_run_kernel(SweepView S, int c0, 
         plain = same_xcd != 0;
     }
     if (!active) return;
-    for (;;) {
-        gu64 bits[8];
-        issue_polls(A, d.width >= 0, lane & 7, 0, xo, bits);
-        // the next chunk's records (and the descriptor after that) travel while this chunk waits
-        const int cn = c + NW;
-        ChunkDesc dnn = dn;
-        if (cn < c1) {
-            load_rec(B, S, dn, lane, xin);
-            if (cn + NW < c1) dnn = scalar_desc(S.chunks[cn + NW]);
-        }
-        if (!solve_chunk<RUNNING>(A, d, lane, S, xo, xout, bits, abort_flag, plain)) return;
-        if (cn >= c1) return;
-        A = B; d = dn; dn = dnn; c = cn;
-    }
+    const HandGlobal H{xo, xout, plain};
+    chunk_loop<RUNNING>(S, c, c1, NW, lane, xin, H, A, d, dn, abort_flag);
 }
 
-// pre-fills the result vectors of a pair of sweeps
-__global__ void fill_sentinel_kernel(int m, gu64* __restrict__ a, gu64* __restrict__ b, const int* done) {
+// pre-fills the result vectors of up to four sweeps with the sentinel
+struct FillList { gu64* p[4]; int n[4]; };
+__global__ void fill_sentinel_kernel(FillList L, const int* done) {
     if (done && *done) return;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        a[i] = kSentinel;
-        if (b) b[i] = kSentinel;
-    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L.n[k]; i += gridDim.x * blockDim.x) L.p[k][i] = kSentinel;
 }
 
 // out[i] = in[perm[i]]
@@ -309,10 +334,24 @@ __global__ void scatter_perm_kernel(int m, const double* __restrict__ in, const 
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
         out[perm[i]] = in[i];
 }
+// a sweep's result (by position) into index order: out[perm ? perm[k] : k] = y[posof[k]]
+__global__ void unpack_result_kernel(int m, const double* __restrict__ y, const int* __restrict__ posof,
+                                     const int* __restrict__ perm, double* __restrict__ out) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x)
+        out[perm ? perm[k] : k] = y[posof[k]];
+}
+// out[p] = order[p] >= 0 ? map[order[p]] : -1   (map == nullptr: identity)
+__global__ void compose_kernel(int n, const int* __restrict__ order, const int* __restrict__ map, int* __restrict__ out) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        const int i = order[p];
+        out[p] = i >= 0 ? (map ? map[i] : i) : -1;
+    }
+}
 
 // lhs = free ? 0 : lhs + rhs;  partial dot rhs'lhs       (splitted_normal_matrix.cc:112-116)
 __global__ __launch_bounds__(kBlock) void split_finish_kernel(int m, const double* __restrict__ rhs,
                                                               const unsigned char* __restrict__ free_mask,
+                                                              const double* __restrict__ y, const int* __restrict__ posof,
                                                               double* __restrict__ lhs, double* partial,
                                                               const int* done) {
     if (done && *done) return;
@@ -320,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void split_finish_kernel(int m, const doubl
     double acc = 0.0;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock) {
         const double r = rhs[i];
-        const double l = free_mask[i] ? 0.0 : lhs[i] + r;
+        const double l = free_mask[i] ? 0.0 : y[posof[i]] + r;
         lhs[i] = l;
         acc += r * l;
     }
@@ -331,86 +370,98 @@ __global__ __launch_bounds__(kBlock) void split_finish_kernel(int m, const doubl
 // ---------------------------------------------------------------------------
 // launch plan and sweeps
 // ---------------------------------------------------------------------------
-// Levels of at most kNarrowLevel chunks are "narrow"; a run of at least kMinXcdLevels narrow
-// levels becomes a one-XCD launch, everything between two such runs one all-XCD launch.
+// Levels of at most kNarrowLevel chunks are "narrow"; a run of at least kMinXcdLevels narrow levels becomes
+// a one-XCD launch, everything between two such runs one all-XCD launch.
+// (Measured and dropped: runs of very narrow levels on ONE workgroup with the hand-off through LDS -- the
+// hand-off itself is 5x cheaper, but one CU streams the runs' records at 25-50 GB/s and the C3 iteration
+// got 70-200 us slower.)
 void plan_sweep(Sweep& S, bool level_launches) {
     S.plan.clear();
     const int nlev = S.nlevels;
     if (nlev == 0) return;
+    auto push = [&](int l0, int l1, int kind) {
+        if (S.level_chunk[l1] > S.level_chunk[l0]) S.plan.push_back({S.level_chunk[l0], S.level_chunk[l1], kind});
+    };
     if (level_launches) {
-        for (int l = 0; l < nlev; l++)
-            if (S.level_chunk[l + 1] > S.level_chunk[l]) S.plan.push_back({S.level_chunk[l], S.level_chunk[l + 1], false});
+        for (int l = 0; l < nlev; l++) push(l, l + 1, Sweep::kAllXcds);
         return;
     }
     int narrow_max = kNarrowLevel, min_levels = kMinXcdLevels;
     if (const char* e = getenv("IPXK_SWEEP_NARROW")) narrow_max = atoi(e);
     if (const char* e = getenv("IPXK_SWEEP_MINLEVELS")) min_levels = std::max(1, atoi(e));
-    std::vector<unsigned char> xcd(nlev, 0);
+    auto nchunks = [&](int lv) { return S.level_chunk[lv + 1] - S.level_chunk[lv]; };
+    std::vector<unsigned char> kind(nlev, Sweep::kAllXcds);
     for (int l = 0; l < nlev;) {
-        auto nchunks = [&](int lv) { return S.level_chunk[lv + 1] - S.level_chunk[lv]; };
         if (nchunks(l) > narrow_max) { l++; continue; }
         int b = l;
         while (b < nlev && nchunks(b) <= narrow_max) b++;
-        if (b - l >= min_levels) for (int t = l; t < b; t++) xcd[t] = 1;
+        if (b - l >= min_levels) for (int t = l; t < b; t++) kind[t] = Sweep::kOneXcd;
         l = b;
     }
     for (int l = 0; l < nlev;) {
         int b = l + 1;
-        while (b < nlev && xcd[b] == xcd[l]) b++;
-        if (S.level_chunk[b] > S.level_chunk[l]) S.plan.push_back({S.level_chunk[l], S.level_chunk[b], xcd[l] != 0});
+        while (b < nlev && kind[b] == kind[l]) b++;
+        push(l, b, kind[l]);
         l = b;
     }
 }
 
-// xout must hold the sentinel in every position (fill_sentinel_kernel); xin != xout
-static void run_sweep(Context* c, const Sweep& S, bool scaled, const double* xin, double* xout, const int* done) {
+// runs the sweep on the input vector xin (addressed through S.src); the result goes to S.y, which must
+// hold the sentinel in every position (fill_results)
+static void run_sweep(Context* c, const Sweep& S, bool scaled, const double* xin, const int* done) {
     SplitOperator* sp = c->split;
     const SweepView V = S.view(scaled);
+    double* xout = S.y.get();
     static const int grid_all = [] { const char* e = getenv("IPXK_SWEEP_GRID"); return e && atoi(e) > 0 ? atoi(e) : kSweepGrid; }();
     static const int wgs_xcd = [] { const char* e = getenv("IPXK_SWEEP_XCD_WGS"); return e && atoi(e) > 0 ? std::min(atoi(e), 64) : kSweepXcdWgs; }();
     for (const Sweep::Launch& L : S.plan) {
+        const bool one_xcd = L.kind == Sweep::kOneXcd;
         const int need = (L.c1 - L.c0 + kBlock / 64 - 1) / (kBlock / 64);     // workgroups with a chunk per wave
-        int grid = std::max(1, std::min(need, L.one_xcd ? wgs_xcd : grid_all));
+        int grid = std::max(1, std::min(need, one_xcd ? wgs_xcd : grid_all));
         unsigned epoch = 0;
-        if (L.one_xcd) { grid *= 8; epoch = ++sp->epoch; if (epoch == 0) epoch = ++sp->epoch; }
+        if (one_xcd) { grid *= 8; epoch = ++sp->epoch; if (epoch == 0) epoch = ++sp->epoch; }
         if (S.running)
             hipLaunchKernelGGL(sweep_run_kernel<true>, dim3(grid), dim3(kBlock), 0, c->stream, V, L.c0, L.c1, xin, xout,
-                               L.one_xcd ? 1 : 0, epoch, sp->xcc_slots.get(), sp->abort_flag.get(), done);
+                               one_xcd ? 1 : 0, epoch, sp->xcc_slots.get(), sp->abort_flag.get(), done);
         else
             hipLaunchKernelGGL(sweep_run_kernel<false>, dim3(grid), dim3(kBlock), 0, c->stream, V, L.c0, L.c1, xin, xout,
-                               L.one_xcd ? 1 : 0, epoch, sp->xcc_slots.get(), sp->abort_flag.get(), done);
+                               one_xcd ? 1 : 0, epoch, sp->xcc_slots.get(), sp->abort_flag.get(), done);
     }
 }
 
-static void fill_sentinel(Context* c, double* a, double* b, const int* done) {
+// sentinel into the result vectors of the given sweeps (one launch)
+static void fill_results(Context* c, std::initializer_list<const Sweep*> sweeps, const int* done) {
+    FillList L{};
+    int k = 0, most = 1;
+    for (const Sweep* S : sweeps) { L.p[k] = reinterpret_cast<gu64*>(S->y.get()); L.n[k] = S->npos; most = std::max(most, S->npos); k++; }
+    hipLaunchKernelGGL(fill_sentinel_kernel, dim3(vec_grid(most)), dim3(kBlock), 0, c->stream, L, done);
+}
+
+static void unpack_result(Context* c, const Sweep& S, const int* perm, double* out) {
     const int m = c->split->m;
-    hipLaunchKernelGGL(fill_sentinel_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, c->stream, m,
-                       reinterpret_cast<gu64*>(a), reinterpret_cast<gu64*>(b), done);
+    hipLaunchKernelGGL(unpack_result_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, c->stream, m, S.y.get(), S.posof.get(),
+                       perm, out);
 }
 
-// two sweeps in a row, in -> sw0 -> out (in may be out)
-static void sweep_pair(Context* c, const Sweep& first, const Sweep& second, bool scaled, const double* in,
-                       double* out, const int* done) {
-    SplitOperator* S = c->split;
-    double* mid = S->sw0.get();
-    if (in == out) {
-        fill_sentinel(c, mid, nullptr, done);
-        run_sweep(c, first, scaled, in, mid, done);
-        fill_sentinel(c, out, nullptr, done);
-    } else {
-        fill_sentinel(c, mid, out, done);
-        run_sweep(c, first, scaled, in, mid, done);
-    }
-    run_sweep(c, second, scaled, mid, out, done);
-}
-
-// ForwardSolve: L then U (sparse_matrix.cc:303-306)
+// ForwardSolve: L then U (sparse_matrix.cc:303-306) on a vector in index order; in may be out.
+// (The L sweep reads its right-hand side through rowperm, see split_prepare_host: undo that here.)
 void forward_solve_dev(Context* c, const double* in, double* out, bool scaled, const int* done) {
-    sweep_pair(c, c->split->Lf, c->split->Uf, scaled, in, out, done);
+    SplitOperator* S = c->split;
+    const int m = S->m;
+    hipLaunchKernelGGL(scatter_perm_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, c->stream, m, in, S->rowperm.get(),
+                       S->w3.get(), done);
+    fill_results(c, {&S->Lf, &S->Uf}, done);
+    run_sweep(c, S->Lf, scaled, S->w3.get(), done);
+    run_sweep(c, S->Uf, scaled, S->Lf.y.get(), done);
+    unpack_result(c, S->Uf, nullptr, out);
 }
-// BackwardSolve: U' then L' (sparse_matrix.cc:308-311)
+// BackwardSolve: U' then L' (sparse_matrix.cc:308-311); in may be out
 void backward_solve_dev(Context* c, const double* in, double* out, bool scaled, const int* done) {
-    sweep_pair(c, c->split->Ut, c->split->Lt, scaled, in, out, done);
+    SplitOperator* S = c->split;
+    fill_results(c, {&S->Ut, &S->Lt}, done);
+    run_sweep(c, S->Ut, scaled, in, done);
+    run_sweep(c, S->Lt, scaled, S->Ut.y.get(), done);
+    unpack_result(c, S->Lt, nullptr, out);
 }
 
 // raises if a sweep gave up waiting for a dependency (host side, after the stream has been synchronized)
@@ -529,7 +580,21 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
     upload_scaling(c, S.get(), status, colscale);
     const size_t mm = (size_t)std::max(m, 1);
     S->w0.resize(mm); S->w1.resize(mm); S->w2.resize(mm); S->w3.resize(mm); S->tI.resize(mm);
-    S->sw0.resize(mm); S->sw1.resize(mm);
+    // where every sweep finds its right-hand side: U' in the input vector itself, L' in the result of U'
+    // (by position), L in the input vector THROUGH rowperm (the operator's N N' product is formed in the row
+    // order of A: the permutation into pivot order is folded into the gather), U in the result of L;
+    // and where the row order of A finds the result of the backward pair
+    {
+        auto compose = [&](int n, const int* order, const int* map, int* out) {
+            if (n > 0) hipLaunchKernelGGL(compose_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, s, n, order, map, out);
+        };
+        compose(S->Ut.npos, S->Ut.order.get(), nullptr, S->Ut.src.get());
+        compose(S->Lt.npos, S->Lt.order.get(), S->Ut.posof.get(), S->Lt.src.get());
+        compose(S->Lf.npos, S->Lf.order.get(), S->rowperm.get(), S->Lf.src.get());
+        compose(S->Uf.npos, S->Uf.order.get(), S->Lf.posof.get(), S->Uf.src.get());
+        S->perm_after_backward.ensure(mm);
+        compose(m, S->rowperm_inv.get(), S->Lt.posof.get(), S->perm_after_backward.get());
+    }
     S->xcc_slots.resize(64);
     IPXK_HIP(hipMemsetAsync(S->xcc_slots.get(), 0, 64 * sizeof(gu64), s));
     S->abort_flag.resize(1);
@@ -561,26 +626,28 @@ int split_apply_dev(Context* c, const double* rhs, double* lhs, const int* done)
     const int g = vec_grid(m);
     double* work = S->w0.get();
     double* u = S->w1.get();
-    // work = inverse(B') * rhs
+    fill_results(c, {&S->Ut, &S->Lt, &S->Lf, &S->Uf}, done);
+    // inverse(B') * rhs
     time_mark(c, kTimeBt, true);
-    backward_solve_dev(c, rhs, work, true, done);
+    run_sweep(c, S->Ut, true, rhs, done);
+    run_sweep(c, S->Lt, true, S->Ut.y.get(), done);
     time_mark(c, kTimeBt, false);
     time_mark(c, kTimeOp, true);
-    // lhs = N N' work : un-permute, A (M D^2) A', permute
-    hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, work, S->rowperm_inv.get(), u, done);
+    // N N' of it: into the row order of A, A (M D^2) A'
+    hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, S->Lt.y.get(), S->perm_after_backward.get(), u, done);
     EpiScale e1{{}, S->Wsplit.get(), c->tcols.get()};
     launch_spmv(c->Acols, u, e1, nullptr, done, s);
     EpiNormalRows e2{{}, S->Wsplit.get() + n, u, work};
     launch_spmv(c->Arows, c->tcols.get(), e2, nullptr, done, s);
-    hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, work, S->rowperm.get(), u, done);
     time_mark(c, kTimeOp, false);
-    // lhs = inverse(B) * lhs
+    // inverse(B) * that (the L sweep reads `work` through rowperm)
     time_mark(c, kTimeB, true);
-    forward_solve_dev(c, u, lhs, true, done);
+    run_sweep(c, S->Lf, true, work, done);
+    run_sweep(c, S->Uf, true, S->Lf.y.get(), done);
     time_mark(c, kTimeB, false);
-    // lhs += rhs; zero free positions; dot
-    hipLaunchKernelGGL(split_finish_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs, S->free_mask.get(), lhs,
-                       c->part(kPartCdot), done);
+    // lhs = result + rhs; zero free positions; dot
+    hipLaunchKernelGGL(split_finish_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs, S->free_mask.get(), S->Uf.y.get(),
+                       S->Uf.posof.get(), lhs, c->part(kPartCdot), done);
     return g;
 }
 
@@ -590,20 +657,19 @@ void solve_dense_dev(Context* c, const double* rhs, double* lhs, char trans) {
     const int m = S->m;
     hipStream_t s = c->stream;
     const int g = vec_grid(m);
-    double* work = S->w3.get();
-    double* sol = S->sw1.get();
     if (trans == 't' || trans == 'T') {
+        double* work = S->w3.get();
         hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs, S->colperm.get(), work,
                            (const int*)nullptr);
-        backward_solve_dev(c, work, sol, false, nullptr);
-        hipLaunchKernelGGL(scatter_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, sol, S->rowperm.get(), lhs,
-                           (const int*)nullptr);
+        fill_results(c, {&S->Ut, &S->Lt}, nullptr);
+        run_sweep(c, S->Ut, false, work, nullptr);
+        run_sweep(c, S->Lt, false, S->Ut.y.get(), nullptr);
+        unpack_result(c, S->Lt, S->rowperm.get(), lhs);            // lhs[rowperm[k]] = solution[k]
     } else {
-        hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs, S->rowperm.get(), work,
-                           (const int*)nullptr);
-        forward_solve_dev(c, work, sol, false, nullptr);
-        hipLaunchKernelGGL(scatter_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, sol, S->colperm.get(), lhs,
-                           (const int*)nullptr);
+        fill_results(c, {&S->Lf, &S->Uf}, nullptr);
+        run_sweep(c, S->Lf, false, rhs, nullptr);                   // reads rhs[rowperm[.]]
+        run_sweep(c, S->Uf, false, S->Lf.y.get(), nullptr);
+        unpack_result(c, S->Uf, S->colperm.get(), lhs);            // lhs[colperm[k]] = solution[k]
     }
 }
 

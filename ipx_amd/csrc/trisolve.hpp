@@ -23,12 +23,19 @@ constexpr int kLenKeyBits = 8;   // sort key = level << kLenKeyBits | (255 - min
 // wavefront reads its chunk with fully coalesced loads whose addresses depend on the descriptor only.
 struct ChunkDesc { int pos0, ent0, width, npos; };
 
+// A sweep reads its right-hand side through `src` (position -> index into the input vector, -1 for
+// padding) and writes its result BY POSITION: y[k] = value of the unknown at level-ordered position k.
+// A wavefront's 64 results are then one contiguous 512-byte store, and all values of a cache line
+// become final together; the polls of a wavefront's 64 lanes fall on few lines.  Dependencies are positions
+// of the same result vector.  (Measured at C3: the backward pair 318 -> 259 us against results stored by
+// unknown.  Reading long-finished dependencies with ordinary cacheable loads instead of L1-bypassing ones was
+// tried on top of this and changed nothing.)
 struct SweepView {
     const ChunkDesc* chunks;
-    const int* order;            // [npos] unknown of level-ordered position k, -1 for padding
+    const int* src;              // [npos] index into the input vector, -1 for padding
     const double* diag;          // [npos] divisor (1.0 for unit triangular and padding)
     const int* len;              // [npos] entries of the row
-    const int* idx;              // dependency unknown index
+    const int* idx;              // dependency position
     const double* val;
 };
 
@@ -43,16 +50,21 @@ struct Sweep {
     int scale_mode = 0;            // 0: no scaled copy; 1: column scale of the unknown itself (U');
                                    // 2: column scale of the dependency (U)
     DevBuf<ChunkDesc> chunks;
-    DevBuf<int> order, idx, len;
+    DevBuf<int> order;             // [npos] unknown at a position (-1: padding)
+    DevBuf<int> posof;             // [dim]  position of an unknown
+    DevBuf<int> src;               // [npos] right-hand-side index (composed with the producer's layout, trisolve.hip)
+    DevBuf<int> idx, len;
+    DevBuf<double> y;              // [npos] result of the sweep, by position
     DevBuf<double> val, diag;      // as given
     DevBuf<double> valS, diagS;    // column-scaled copy (U sweeps only)
     std::vector<int> level_chunk;  // host, [nlevels+1] first chunk of each level
     std::vector<int> level_width;  // host, [nlevels] unknowns per level
-    struct Launch { int c0, c1; bool one_xcd; };
+    enum Kind { kAllXcds = 0, kOneXcd = 1 };
+    struct Launch { int c0, c1; int kind; };
     std::vector<Launch> plan;
     SweepView view(bool scaled) const {
         SweepView V;
-        V.chunks = chunks.get(); V.order = order.get(); V.len = len.get(); V.idx = idx.get();
+        V.chunks = chunks.get(); V.src = src.get(); V.len = len.get(); V.idx = idx.get();
         V.val = (scaled && scale_mode) ? valS.get() : val.get();
         V.diag = (scaled && scale_mode) ? diagS.get() : diag.get();
         return V;
@@ -71,7 +83,7 @@ struct SplitOperator {
     DevBuf<unsigned char> free_mask;       // m, pivot order
     int num_free = 0;
     DevBuf<double> w0, w1, w2, w3;         // m workspaces
-    DevBuf<double> sw0, sw1;               // intermediate vectors of the sweeps
+    DevBuf<int> perm_after_backward;       // u[i] = Lt.y[perm_after_backward[i]] is inverse(B~') rhs in row order of A
     DevBuf<unsigned long long> xcc_slots;  // one-XCD runs: placement consensus words
     unsigned epoch = 0;                    // launch counter of the one-XCD runs
     DevBuf<int> abort_flag;

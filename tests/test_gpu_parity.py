@@ -479,7 +479,7 @@ def test_sweeps_with_dense_rows_and_columns(kkt, po, oracle, monkeypatch, mode):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode", ["default", "allxcd"])
+@pytest.mark.parametrize("mode", ["default", "allxcd", "onexcd"])
 def test_deep_level_structure(kkt, po, oracle, monkeypatch, mode):
     """banded planted factors: thousands of narrow levels (SURVEY 8d stress point) -- one long one-XCD run,
     and more relaxation launches than the device-side level analysis allows itself (host scan instead)"""
