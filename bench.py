@@ -190,9 +190,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
-    # rehearsal on a one-GPU box: IPXK_COMM=hostshm carries the library's collectives through host shared
-    # memory, all ranks share GPU 0 and torch.distributed runs over gloo (RCCL refuses duplicate devices)
-    rehearsal = os.environ.get("IPXK_COMM") == "hostshm"
+    # rehearsal on a one-GPU box (IPXK_REHEARSAL=1): all ranks share GPU 0, the library's collectives run over
+    # its direct exchange (hipIpc between the processes) and torch.distributed over gloo (RCCL refuses
+    # duplicate devices)
+    rehearsal = os.environ.get("IPXK_REHEARSAL") == "1"
+    if rehearsal:
+        os.environ["IPXK_COMM"] = "direct"
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -314,7 +317,9 @@ def main():
         out["config"]["column_partition"] = bench_column_partition(kkt, dist, torch, A, st, tol, args, rank, world,
                                                                    local_rank, tdev)
     if rehearsal:
-        out["config"]["transport"] = "REHEARSAL: host shared memory instead of RCCL, all ranks on one GPU"
+        out["config"]["transport"] = "REHEARSAL: all ranks on one GPU, direct exchange between the rank processes"
+    elif world > 1:
+        out["config"]["transport"] = "direct exchange over hipIpc-mapped peer buffers" if os.environ.get("IPXK_COMM") == "direct" else "RCCL"
     if rank == 0 and world == 1:
         # what a plain streaming kernel reaches on this box (report next to the 8 TB/s spec peak)
         triad = measure_triad(torch)

@@ -98,7 +98,7 @@ struct Context {
 
     // ---- multi-GPU ----
     ncclComm* comm = nullptr;
-    struct ShmComm* shm = nullptr;      // test transport over host shared memory (IPXK_COMM=hostshm)
+    struct DirectComm* direct = nullptr;   // hand-written exchange over hipIpc-mapped peer buffers (IPXK_COMM=direct)
     int rank = 0, nranks = 1;
     int64_t m_global = 0;               // rows of the whole system (sum over ranks)
     bool force_comm = false;
@@ -209,6 +209,9 @@ bool comm_rows(const Context* c);        // active communicator, row partition
 bool comm_cols(const Context* c);        // active communicator, column partition
 void comm_allreduce_min(Context* c, double* buf, size_t count);
 void comm_destroy(Context* c);
+void comm_check(Context* c);             // raises if a collective of the direct transport timed out
+double* comm_stage(Context* c, size_t count);
+void comm_allreduce_sum_staged(Context* c, double* dst, size_t count);
 
 }  // namespace ipxk
 

@@ -433,6 +433,7 @@ static CrResult run_cr(Context* c, const CrOps& ops, const double* rhs, double t
     IPXK_HIP(hipMemcpyAsync(c->h_state, st, sizeof(CrState), hipMemcpyDeviceToHost, s));
     IPXK_HIP(hipStreamSynchronize(s));
     IPXK_HIP(hipGetLastError());
+    comm_check(c);
 
     // the ranks of a partitioned solve take identical decisions (identical scalars); if one of them saw the
     // others finish without finishing itself, the replicas have diverged

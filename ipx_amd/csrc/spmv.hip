@@ -450,18 +450,22 @@ void normal_apply_dev(Context* c, const double* W, const double* rhs, double* lh
         // this rank's columns: t_g = W_g .* (A_g' y) is local, lhs = sum over ranks of A_g t_g
         EpiScale e1{{}, W, c->tcols.get()};
         launch_spmv(c->Acols, rhs, e1, nullptr, done, c->stream);
-        EpiScale e2{{}, nullptr, lhs};
+        double* stage = comm_stage(c, (size_t)c->m);
+        EpiScale e2{{}, nullptr, stage ? stage : lhs};
         launch_spmv(c->Arows, c->tcols.get(), e2, nullptr, done, c->stream);
-        comm_allreduce_sum(c, lhs, (size_t)c->m);
+        if (stage) comm_allreduce_sum_staged(c, lhs, (size_t)c->m);
+        else comm_allreduce_sum(c, lhs, (size_t)c->m);
         const int g = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (c->m + kBlock - 1) / kBlock));
         hipLaunchKernelGGL(normal_finish_kernel, dim3(g), dim3(kBlock), 0, c->stream, (int)c->m, W + n, rhs, lhs,
                            ndot ? c->part(kPartCdot) : nullptr, done);
         if (ndot) *ndot = g;
         return;
     }
-    EpiScale e1{{}, W, c->tcols.get()};
+    double* stage = comm_rows(c) ? comm_stage(c, (size_t)n) : nullptr;
+    EpiScale e1{{}, W, stage ? stage : c->tcols.get()};
     launch_spmv(c->Acols, rhs, e1, nullptr, done, c->stream);
-    if (comm_rows(c)) comm_allreduce_sum(c, c->tcols.get(), (size_t)n);
+    if (stage) comm_allreduce_sum_staged(c, c->tcols.get(), (size_t)n);
+    else if (comm_rows(c)) comm_allreduce_sum(c, c->tcols.get(), (size_t)n);
     EpiNormalRows e2{{}, W + n, rhs, lhs};
     const int np = launch_spmv(c->Arows, c->tcols.get(), e2, ndot ? c->part(kPartCdot) : nullptr,
                                done, c->stream);

@@ -1,6 +1,6 @@
 """One rank of a partitioned KKTSolverDiag solve, started by tests/test_gpu_multirank.py as a separate
-process.  All ranks share GPU 0; the collectives travel through the library's test transport
-(IPXK_COMM=hostshm) because RCCL refuses two ranks on one device.
+process.  All ranks share GPU 0; the collectives travel through the library's direct exchange
+(IPXK_COMM=direct, hipIpc between the processes) because RCCL refuses two ranks on one device.
 argv: rank world idfile outprefix partition(rows|columns) m n seed"""
 import os
 import sys

@@ -1,8 +1,10 @@
 """GPU: partitioned solves with REAL separate rank processes.  The test boxes have one GPU and RCCL
 refuses two ranks on one device, so the ranks share GPU 0 and the library's collectives run over its
-host-shared-memory test transport (IPXK_COMM=hostshm, ipx_amd/csrc/comm.hip): everything else -- slab
-contexts, the per-rank CR loops and their lock-step control flow, scalar exchange, partial products --
-is the code the RCCL runs use.  Results are compared with the oracle's unpartitioned solve."""
+direct exchange (IPXK_COMM=direct, ipx_amd/csrc/comm.hip: buffers mapped between the processes with hipIpc,
+reduce-scatter + all-gather kernels, flag table in shared host memory) -- the same device code path that
+carries the collectives between the GPUs of a node.  Everything else -- slab contexts, the per-rank CR loops
+and their lock-step control flow, scalar exchange, partial products -- is what RCCL runs use too.  Results
+are compared with the oracle's unpartitioned solve."""
 import os
 import subprocess
 import sys
@@ -22,7 +24,7 @@ def test_partitioned_solve_multiprocess(oracle, tmp_path, part, world):
     from oracle import pyoracle as po
     kkt.load_library()
     m, n, seed = 2501, 6007, 61           # ragged slabs for 2 and 3 ranks
-    env = dict(os.environ, IPXK_COMM="hostshm")
+    env = dict(os.environ, IPXK_COMM="direct")
     idfile, out = str(tmp_path / "uid"), str(tmp_path / "res")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), str(r), str(world),
                                idfile, out, part, str(m), str(n), str(seed)], env=env, stdout=subprocess.PIPE,
