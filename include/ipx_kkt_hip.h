@@ -86,6 +86,22 @@ typedef struct ipxk_cr_diag {
 const char* ipxk_last_error(void);
 int ipxk_device_count(void);
 
+/* ---- model upload (stand-alone, host arrays, computed on `device`) ---- */
+/* Presolver::EquilibrateMatrix (src/presolver.cc:883-974): recursive row / column
+ * equilibration of the m x n structural matrix by powers of two.  Ax is scaled in
+ * place; colscale[n], rowscale[m] receive the accumulated factors (1 where none).
+ * *rounds = number of rounds that rescaled the matrix, or -1 if every entry was in
+ * range from the start (the reference then leaves its scaling vectors empty,
+ * src/presolver.cc:912-924).  All arithmetic is exact: bit-identical results. */
+int ipxk_equilibrate(ipxint m, ipxint n, const ipxint* Ap, const ipxint* Ai,
+                     double* Ax, double* colscale, double* rowscale,
+                     ipxint* rounds, int device);
+/* Transpose (src/sparse_matrix.cc:120-151): row-wise copy of an m x n CSC matrix,
+ * entries of a row in ascending source-column order (Model::AIt, src/model.h:61). */
+int ipxk_transpose(ipxint m, ipxint n, const ipxint* Ap, const ipxint* Ai,
+                   const double* Ax, ipxint* ATp, ipxint* ATi, double* ATx,
+                   int device);
+
 /* ---- context: the model's matrix, resident on one GPU -------------------- */
 /* Replaces the role of ipx::Model::AI()/AIt() for the path (src/model.h:61):
  * uploads the n structural columns of AI = [A I] (the slack identity is never

@@ -646,6 +646,22 @@ int ipxk_split_prepare(ipxk_context* c, const ipxint* Lp, const ipxint* Li, cons
     });
 }
 
+int ipxk_equilibrate(ipxint m, ipxint n, const ipxint* Ap, const ipxint* Ai, double* Ax, double* colscale,
+                     double* rowscale, ipxint* rounds, int device) {
+    return guarded([&] {
+        IPXK_REQUIRE(Ap && (Ap[n] == 0 || (Ai && Ax)) && colscale && rowscale && rounds, "NULL argument");
+        equilibrate_device(device, m, n, Ap, Ai, Ax, colscale, rowscale, rounds);
+    });
+}
+
+int ipxk_transpose(ipxint m, ipxint n, const ipxint* Ap, const ipxint* Ai, const double* Ax, ipxint* ATp, ipxint* ATi,
+                   double* ATx, int device) {
+    return guarded([&] {
+        IPXK_REQUIRE(Ap && ATp && (Ap[n] == 0 || (Ai && Ax && ATi && ATx)), "NULL argument");
+        transpose_device(device, m, n, Ap, Ai, Ax, ATp, ATi, ATx);
+    });
+}
+
 int ipxk_cr_diagnostics(ipxk_context* c, ipxk_cr_diag* out) {
     return guarded([&] {
         IPXK_REQUIRE(c && out, "NULL argument");

@@ -200,6 +200,12 @@ void check_sweep_abort(Context* c);
 void destroy_split(SplitOperator*);
 void destroy_prepare_host(PrepareHost*);
 
+// ---- presolve.hip (stand-alone, no context) ----
+void equilibrate_device(int device, int64_t m, int64_t n, const ipxint* Ap, const ipxint* Ai, double* Ax,
+                        double* colscale, double* rowscale, ipxint* rounds);
+void transpose_device(int device, int64_t m, int64_t n, const ipxint* Ap, const ipxint* Ai, const double* Ax,
+                      ipxint* Tp, ipxint* Ti, double* Tx);
+
 // ---- comm.hip ----
 void comm_allreduce_sum(Context* c, double* buf, size_t count);
 void comm_allreduce_max(Context* c, double* buf, size_t count);

@@ -32,7 +32,7 @@ EXPORTS = [
     "ipxk_backward_solve", "ipxk_solve_dense", "ipxk_split_levels", "ipxk_cr_solve",
     "ipxk_kkt_basis_solve", "ipxk_newton_solve", "ipxk_iterate_set", "ipxk_iterate_get", "ipxk_iterate_update",
     "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_ipm_step", "ipxk_iterate_factorize_diag", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns",
-    "ipxk_time_normal_apply",
+    "ipxk_time_normal_apply", "ipxk_equilibrate", "ipxk_transpose",
     "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
     "ipxk_dev_download",
 ]
@@ -81,6 +81,30 @@ def load_library():
         L.ipxk_normal_apply_bytes.restype = c_i64
         _lib = L
     return _lib
+
+
+def equilibrate(A, device=0):
+    """Presolver::EquilibrateMatrix on the device: (scaled values, colscale, rowscale, rounds)."""
+    lib = load_library()
+    x = _F(A.x).copy()
+    cs, rs = np.zeros(A.ncol, f64), np.zeros(A.nrow, f64)
+    rounds = c_i64(0)
+    rc = lib.ipxk_equilibrate(c_i64(A.nrow), c_i64(A.ncol), _ip(_I(A.p)), _ip(_I(A.i)), _fp(x), _fp(cs), _fp(rs),
+                              C.byref(rounds), C.c_int(device))
+    if rc != 0:
+        raise KktError(rc, lib.ipxk_last_error().decode())
+    return x, cs, rs, int(rounds.value)
+
+
+def transpose(A, device=0):
+    """Transpose on the device: (ATp, ATi, ATx) of the row-wise copy."""
+    lib = load_library()
+    p, i, x = np.zeros(A.nrow + 1, i64), np.zeros(A.nnz, i64), np.zeros(A.nnz, f64)
+    rc = lib.ipxk_transpose(c_i64(A.nrow), c_i64(A.ncol), _ip(_I(A.p)), _ip(_I(A.i)), _fp(_F(A.x)), _ip(p), _ip(i), _fp(x),
+                            C.c_int(device))
+    if rc != 0:
+        raise KktError(rc, lib.ipxk_last_error().decode())
+    return p, i, x
 
 
 def _ip(a):

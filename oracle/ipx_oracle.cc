@@ -72,6 +72,64 @@ extern "C" void orc_transpose(Int nrow, Int ncol, const Int* Ap, const Int* Ai,
     }
 }
 
+// src/presolver.cc:868-880 (EquilibrationFactor) and :883-974 (Presolver::EquilibrateMatrix): recursive
+// row and column equilibration by powers of 2 on the structural columns; returns the number of rounds that
+// rescaled the matrix, or -1 when all entries are in range from the start (the reference then leaves
+// colscale_ / rowscale_ empty; here they are set to 1).
+static double equilibration_factor(int expmin, int expmax, int exp) {
+    if (exp < expmin) return std::ldexp(1.0, (expmin - exp + 1) / 2);
+    if (exp > expmax) return std::ldexp(1.0, -((exp - expmax + 1) / 2));
+    return 1.0;
+}
+extern "C" Int orc_equilibrate(Int m, Int n, const Int* Ap, const Int* Ai, double* Ax, double* colscale,
+                               double* rowscale) {
+    constexpr int expmin = 0, expmax = 3;
+    constexpr Int maxround = 10;
+    for (Int j = 0; j < n; j++) colscale[j] = 1.0;
+    for (Int i = 0; i < m; i++) rowscale[i] = 1.0;
+    bool out_of_range = false;
+    for (Int p = 0; p < Ap[n]; p++) {                      // :912-924 quick return
+        int exp;
+        std::frexp(std::abs(Ax[p]), &exp);
+        if (exp < expmin || exp > expmax) { out_of_range = true; break; }
+    }
+    if (!out_of_range) return -1;
+    std::vector<double> colmax(n), rowmax(m);
+    Int rescaled = 0;
+    for (Int round = 0; round < maxround; round++) {
+        std::fill(rowmax.begin(), rowmax.end(), 0.0);      // :934-944
+        for (Int j = 0; j < n; j++) {
+            colmax[j] = 0.0;
+            for (Int p = Ap[j]; p < Ap[j + 1]; p++) {
+                const double xa = std::abs(Ax[p]);
+                colmax[j] = std::max(colmax[j], xa);
+                rowmax[Ai[p]] = std::max(rowmax[Ai[p]], xa);
+            }
+        }
+        bool out = false;                                  // :946-964
+        for (Int i = 0; i < m; i++) {
+            int exp;
+            std::frexp(rowmax[i], &exp);
+            rowmax[i] = equilibration_factor(expmin, expmax, exp);
+            if (rowmax[i] != 1.0) { out = true; rowscale[i] *= rowmax[i]; }
+        }
+        for (Int j = 0; j < n; j++) {
+            int exp;
+            std::frexp(colmax[j], &exp);
+            colmax[j] = equilibration_factor(expmin, expmax, exp);
+            if (colmax[j] != 1.0) { out = true; colscale[j] *= colmax[j]; }
+        }
+        if (!out) break;
+        for (Int j = 0; j < n; j++)                        // :967-972
+            for (Int p = Ap[j]; p < Ap[j + 1]; p++) {
+                Ax[p] *= colmax[j];
+                Ax[p] *= rowmax[Ai[p]];
+            }
+        rescaled++;
+    }
+    return rescaled;
+}
+
 // src/utils.cc:73-80
 extern "C" void orc_inverse_perm(Int m, const Int* perm, Int* invperm) {
     for (Int i = 0; i < m; i++) invperm[perm[i]] = i;

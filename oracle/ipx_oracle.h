@@ -44,6 +44,9 @@ double orc_infnorm(orc_int m, const double* x);
 
 /* ---- index / permutation arithmetic, bit-exact (row a15, a16) ----------- */
 /* src/sparse_matrix.cc:120-151 */
+/* Presolver::EquilibrateMatrix (src/presolver.cc:883-974); Ax is scaled in place */
+orc_int orc_equilibrate(orc_int m, orc_int n, const orc_int* Ap, const orc_int* Ai, double* Ax, double* colscale,
+                        double* rowscale);
 void orc_transpose(orc_int nrow, orc_int ncol, const orc_int* Ap,
                    const orc_int* Ai, const double* Ax, orc_int* ATp,
                    orc_int* ATi, double* ATx);

@@ -147,6 +147,14 @@ class Oracle:
                                _ip(ATp), _ip(ATi), _fp(ATx))
         return Csc(A.ncol, A.nrow, ATp, ATi, ATx)
 
+    def equilibrate(self, A):
+        """Presolver::EquilibrateMatrix: (scaled values, colscale, rowscale, rounds); rounds = -1: untouched"""
+        x = _F(A.x).copy()
+        cs, rs = np.zeros(A.ncol, f64), np.zeros(A.nrow, f64)
+        self.lib.orc_equilibrate.restype = c_i64
+        r = self.lib.orc_equilibrate(c_i64(A.nrow), c_i64(A.ncol), _ip(A.p), _ip(A.i), _fp(x), _fp(cs), _fp(rs))
+        return x, cs, rs, int(r)
+
     def inverse_perm(self, perm):
         perm = _I(perm)
         inv = np.zeros_like(perm)

@@ -716,3 +716,30 @@ def test_basis_path_full_size_properties(kkt, monkeypatch):
     print("prepare %.1f ms, rescale %.1f ms" % (t_prepare * 1e3, t_rescale * 1e3))
     assert t_rescale < 0.5 * t_prepare
     ctx.close()
+
+
+# --------------------------------------------------------------------------------------
+# model upload on the device: exact arithmetic, bit-identical to the oracle
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed,m,n", [(301, 150, 320), (302, 4000, 9100), (303, 20000, 7000)])
+def test_equilibrate_and_transpose_on_device(kkt, po, oracle, seed, m, n):
+    from ipx_amd import synth
+    from test_oracle_vs_ref import badly_scaled_lp
+    A = badly_scaled_lp(m, n, seed)
+    Ao = ocsc(po, A)
+    x1, cs1, rs1, r1 = kkt.equilibrate(A)
+    x2, cs2, rs2, r2 = oracle.equilibrate(Ao)
+    assert r1 == r2 >= 1
+    assert np.array_equal(x1, x2) and np.array_equal(cs1, cs2) and np.array_equal(rs1, rs2)
+    B = synth.synthetic_lp(m, n, 5, seed)                     # already in range: untouched
+    x3, cs3, rs3, r3 = kkt.equilibrate(B)
+    assert r3 == -1 and np.array_equal(x3, B.x) and np.all(cs3 == 1.0) and np.all(rs3 == 1.0)
+    # Transpose: index arithmetic, bit-exact (ascending source column inside a row)
+    p, i, x = kkt.transpose(A)
+    T = oracle.transpose(Ao)
+    assert np.array_equal(p, T.p) and np.array_equal(i, T.i) and np.array_equal(x, T.x)
+    bad = synth.CscMatrix(m, n, A.p, np.where(np.arange(A.nnz) == 7, m + 3, A.i), A.x)
+    with pytest.raises(kkt.KktError):
+        kkt.transpose(bad)
+    with pytest.raises(kkt.KktError):
+        kkt.equilibrate(bad)

@@ -123,3 +123,38 @@ def test_iterate_bitwise(oracle, ref, po, seed, m, n):
         if x[i] + a * dx[i] < 0.0:
             a, ib = -(x[i] * damp) / dx[i], i
     assert alpha == a and blk == ib and np.all(x + alpha * dx >= 0.0)
+
+
+def badly_scaled_lp(m, n, seed):
+    """entries spanning ~40 binary orders of magnitude by rows and columns, some empty rows"""
+    from ipx_amd import synth
+    rng = np.random.default_rng(seed)
+    A = synth.synthetic_lp(m, n, 5, seed)
+    rs = 2.0 ** rng.integers(-20, 21, m)
+    cs = 2.0 ** rng.integers(-20, 21, n)
+    x = A.x * rs[A.i] * np.repeat(cs, np.diff(A.p)) * rng.uniform(0.7, 1.9, A.nnz)
+    return synth.CscMatrix(m, n, A.p, A.i, x)
+
+
+@pytest.mark.parametrize("seed,m,n", [(201, 150, 320), (202, 400, 850)])
+def test_equilibrate_bitwise(oracle, ref, po, seed, m, n):
+    """Presolver::EquilibrateMatrix: the restatement against the reference's own presolver (which ScaleModel
+    runs inside PresolveModel, src/presolver.cc:266-292): scaled matrix, and the scaling factors as they show
+    in the scaled objective (obj = 1 -> c = colscale) and right-hand side (rhs = 1 -> b = rowscale)"""
+    from ipx_amd import synth
+    A = badly_scaled_lp(m, n, seed)
+    v = synth.lp_vectors(m, n)
+    Ao = po.Csc(m, n, A.p, A.i, A.x)
+    rm = ref.model(Ao, v["rhs"], v["constr_type"], v["obj"], v["lb"], v["ub"])
+    if rm.dualized:
+        pytest.skip("the reference dualizes this shape")
+    x, cs, rs, rounds = oracle.equilibrate(Ao)
+    assert rounds >= 1
+    AI = rm.AI()
+    assert np.array_equal(AI.i[: A.nnz], A.i) and np.array_equal(AI.x[: A.nnz], x)
+    b, c, lb, ub = rm.vectors()
+    assert np.array_equal(c[:n], cs) and np.array_equal(b, rs)
+    # a matrix in range is left alone
+    B = synth.synthetic_lp(m, n, 5, seed)
+    x2, cs2, rs2, r2 = oracle.equilibrate(po.Csc(m, n, B.p, B.i, B.x))
+    assert r2 == -1 and np.array_equal(x2, B.x) and np.all(cs2 == 1.0) and np.all(rs2 == 1.0)
