@@ -317,6 +317,42 @@ int ipxk_ipm_step(ipxk_context* ctx, int use_basis, const double* b,
 int ipxk_iterate_factorize_diag(ipxk_context* ctx, int precond_dense_cols,
                                 ipxint* errflag);
 
+/* Iterate::ComputeObjectives (src/iterate.cc:590-640) of the resident iterate for
+ * the model vectors: out3 = {pobjective, dobjective, offset}; pobjective + offset
+ * and dobjective + offset are the objectives after postprocessing (:203-211).
+ * Variable states as in ipxk_iterate_set (the implied states of the basis solver's
+ * drop procedures do not exist on the device). */
+int ipxk_iterate_objectives(ipxk_context* ctx, const double* b, const double* c,
+                            const double* lb, const double* ub, double out3[3]);
+
+/* IPM::Driver (src/ipm.cc:56-123) on the resident iterate with the diag solver:
+ * loop of {termination test (Iterate::term_crit_reached, src/iterate.cc:221-249,
+ * with crossover_start = 0), divergence / bad-iteration test (:71-93), iteration
+ * limit, InterruptCheck, KKTSolverDiag::Factorize, Predictor + AddCorrector +
+ * MakeStep}.  status_ipm uses the values of include/ipx_status.h
+ * (IPX_STATUS_optimal 1, primal_infeas 3, dual_infeas 4, time_limit 5,
+ * iter_limit 6, no_progress 7, failed 8).  A CR failure of the diag solver ends
+ * the loop with IPX_STATUS_failed and the CR errflag: that is where LpSolver
+ * switches to the basis solver (src/lp_solver.cc:399-418), the caller's move. */
+typedef struct ipxk_ipm_params {
+    double kkt_tol;            /* ipx_parameters::kkt_tol, 0.3 */
+    double feasibility_tol;    /* ipm_feasibility_tol, 1e-6 */
+    double optimality_tol;     /* ipm_optimality_tol, 1e-8 */
+    ipxint kkt_maxiter;        /* CR iteration cap of the diag solver (src/lp_solver.cc:393) */
+    ipxint ipm_maxiter;        /* ipm_maxiter, 300 */
+    int precond_dense_cols;
+} ipxk_ipm_params;
+typedef struct ipxk_ipm_info {
+    ipxint status_ipm, iter, errflag, kktiter;
+    double pobjective, dobjective;       /* after postprocessing */
+    double presidual, dresidual, complementarity, mu;
+    double step_primal, step_dual;       /* of the last step */
+} ipxk_ipm_info;
+int ipxk_ipm_driver(ipxk_context* ctx, const double* b, const double* c,
+                    const double* lb, const double* ub,
+                    const ipxk_ipm_params* params, ipxk_ipm_info* info,
+                    ipxk_interrupt_fn interrupt, void* interrupt_user);
+
 /* ---- multi-GPU: rows of AI partitioned over ranks, one RCCL all-reduce per
  *      NormalMatrix apply ---------------------------- */
 /* 128-byte RCCL unique id, created on rank 0 and broadcast by the launcher. */
@@ -344,9 +380,11 @@ ipxint ipxk_normal_apply_bytes(const ipxk_context* ctx);
 /* Which device layout the two sparse products of NormalMatrix::_Apply
  * (normal_matrix.cc:45-126) use on this model: layout[0] for t = W.*(A'y),
  * layout[1] for lhs = A t; 0 = phased (time-tiled), 1 = XCD-sliced tiles,
- * 2 = fused tiles (one slice, epilogue in the tile kernel).  The choice is made
- * once at ipxk_create by timing the eligible ones (IPXK_SPMV_LAYOUT=phased|
- * sliced|fused overrides); us[6] receives the measured microseconds
+ * 2 = fused tiles (one slice, epilogue in the tile kernel).  The sliced layout is
+ * chosen by a property of the matrix (x larger than an XCD's L2 and gathers that
+ * spread over the slices); otherwise a timing at ipxk_create picks the faster of
+ * phased and fused, which are bit-identical (IPXK_SPMV_LAYOUT=phased|sliced|fused
+ * overrides); us[6] receives the measured microseconds
  * {pass1 phased, sliced, fused, pass2 phased, sliced, fused} (0 = not timed). */
 int ipxk_spmv_layout(const ipxk_context* ctx, int layout[2], double us[6]);
 /* plain device allocation helpers so that callers without torch can hold

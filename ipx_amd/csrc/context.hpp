@@ -166,12 +166,17 @@ void iterate_update_dev(Context* c, double sp, const double* dx, const double* d
 void iterate_residuals_dev(Context* c, const double* b, const double* cc, const double* lb, const double* ub,
                            double* rb, double* rc, double* rl, double* ru, double* presidual, double* dresidual);
 void iterate_complementarity_dev(Context* c, double out4[4], double* num_terms = nullptr);
+void iterate_objectives_dev(Context* c, const double* b, const double* cc, const double* lb, const double* ub, double out3[3]);
+void model_norms_dev(Context* c, const double* b, const double* cc, const double* lb, const double* ub, double out2[2]);
 double step_to_boundary_dev(Context* c, const double* x, const double* dx, int64_t len, double alpha0,
                             ipxint* blocking);
 
 // ---- ipm_step.hip ----
 void ipm_step_dev(Context* c, bool use_basis, const double* b, const double* cc, const double* lb, const double* ub,
                   double kkt_tol, ipxint maxiter, ipxk_ipm_step_info* info, ipxk_interrupt_fn interrupt, void* user);
+
+void ipm_driver_dev(Context* c, const double* b, const double* cc, const double* lb, const double* ub,
+                    const ipxk_ipm_params* prm, ipxk_ipm_info* info, ipxk_interrupt_fn interrupt, void* user);
 
 // ---- kkt_diag.hip ----
 void kkt_diag_factorize_dev(Context* c, const double* xl, const double* xu, const double* zl,

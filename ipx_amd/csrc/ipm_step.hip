@@ -177,4 +177,68 @@ void ipm_step_dev(Context* c, bool use_basis, const double* b, const double* cc,
     IPXK_HIP(hipGetLastError());
 }
 
+// IPM::Driver (src/ipm.cc:56-123) on the resident iterate, around the diag solver: termination test
+// (Iterate::term_crit_reached with crossover_start = 0, src/iterate.cc:221-249), the divergence / bad-iteration
+// test with its infeasibility classification (:71-93, for a model that was not dualized), the iteration limit,
+// InterruptCheck, Factorize (kkt_solver_diag.cc:18-65 from the resident iterate), the predictor-corrector step,
+// and MakeStep's bad-iteration count and best complementarity (:520-530).  What ends the loop is reported as
+// status_ipm; a CR failure of the diag solver (errflag 201-205 -> IPX_STATUS_failed) is where LpSolver switches
+// to the basis solver (src/lp_solver.cc:399-418) -- the caller's decision, as in the reference.
+void ipm_driver_dev(Context* c, const double* b, const double* cc, const double* lb, const double* ub,
+                    const ipxk_ipm_params* prm, ipxk_ipm_info* info, ipxk_interrupt_fn interrupt, void* user) {
+    IPXK_REQUIRE(c->it_set, "no iterate on the device (ipxk_iterate_set)");
+    constexpr double kDivergeTol = 1e6;                  // src/ipm.h:55
+    *info = ipxk_ipm_info{};
+    const int N = (int)(c->n + c->m);
+    for (int k = 0; k < 12; k++) c->ipm[k].resize((size_t)std::max(k == 0 || k == 9 ? (int)c->m : N, 1));
+    double norms[2];
+    model_norms_dev(c, b, cc, lb, ub, norms);
+    double comp[4];
+    iterate_complementarity_dev(c, comp);
+    double best_complementarity = comp[0];               // :315
+    ipxint num_bad_iter = 0, errflag = 0;
+    while (true) {
+        double obj[3];
+        iterate_residuals_dev(c, b, cc, lb, ub, c->ipm[0].get(), c->ipm[1].get(), c->ipm[2].get(), c->ipm[3].get(),
+                              &info->presidual, &info->dresidual);
+        iterate_complementarity_dev(c, comp);
+        iterate_objectives_dev(c, b, cc, lb, ub, obj);
+        info->pobjective = obj[0] + obj[2];              // after postprocessing, iterate.cc:203-211
+        info->dobjective = obj[1] + obj[2];
+        info->complementarity = comp[0];
+        info->mu = comp[1];
+        const bool feasible = info->presidual <= prm->feasibility_tol * (1.0 + norms[0]) &&
+                              info->dresidual <= prm->feasibility_tol * (1.0 + norms[1]);
+        const double mid = 0.5 * (info->pobjective + info->dobjective), gap = info->pobjective - info->dobjective;
+        const bool optimal = std::abs(gap) <= prm->optimality_tol * (1.0 + std::abs(mid));
+        if (feasible && optimal) { info->status_ipm = 1; break; }                  // IPX_STATUS_optimal
+        if (num_bad_iter >= 5 || comp[0] > kDivergeTol * best_complementarity) {
+            if (info->dobjective > std::max(10.0 * std::abs(info->pobjective), 1.0)) info->status_ipm = 3;        // primal_infeas
+            else if (info->pobjective < -std::max(10.0 * std::abs(info->dobjective), 1.0)) info->status_ipm = 4;  // dual_infeas
+            else info->status_ipm = 7;                                                                            // no_progress
+            break;
+        }
+        if (info->iter >= prm->ipm_maxiter) { info->status_ipm = 6; break; }       // iter_limit
+        if (interrupt && (errflag = interrupt(user)) != 0) break;
+        kkt_diag_factorize_dev(c, c->it_xl.get(), c->it_xu.get(), c->it_zl.get(), c->it_zu.get(), comp[1],
+                               prm->precond_dense_cols != 0, &errflag);
+        if (errflag) break;
+        ipxk_ipm_step_info st;
+        ipm_step_dev(c, false, b, cc, lb, ub, prm->kkt_tol, prm->kkt_maxiter, &st, interrupt, user);
+        info->kktiter += st.kktiter_predictor + st.kktiter_corrector;
+        errflag = st.errflag;
+        if (errflag) break;
+        info->step_primal = st.step_primal;
+        info->step_dual = st.step_dual;
+        if (std::min(st.step_primal, st.step_dual) < 0.05) num_bad_iter++; else num_bad_iter = 0;   // :524-527
+        iterate_complementarity_dev(c, comp);
+        best_complementarity = std::min(best_complementarity, comp[0]);
+        info->iter++;
+    }
+    if (errflag) {                                       // :114-121
+        if (errflag == 999) { info->status_ipm = 5; info->errflag = 0; }           // IPX_ERROR_interrupt_time -> time_limit
+        else { info->status_ipm = 8; info->errflag = errflag; }                    // failed
+    }
+}
+
 }  // namespace ipxk

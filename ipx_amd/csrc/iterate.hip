@@ -139,7 +139,95 @@ __global__ __launch_bounds__(kBlock) void step_to_boundary_kernel(int len, const
     if (threadIdx.x == 0) { out_alpha[blockIdx.x] = blockbest; out_index[blockIdx.x] = blockidx; }
 }
 
+// per-block partial sums for Iterate::ComputeObjectives (iterate.cc:590-640, the branch of an iterate that has
+// not been postprocessed; fixed / free / barrier variables): [0] sum c_j x_j over non-fixed j, [1] over fixed j
+// (offset_), [2] b'y + sum lb_j zl_j - sum ub_j zu_j - sum over fixed SLACK variables of x_j y_i
+__global__ __launch_bounds__(kBlock) void iterate_objectives_kernel(int n, int m, const unsigned char* __restrict__ state,
+                                                                    const double* __restrict__ b, const double* __restrict__ c,
+                                                                    const double* __restrict__ lb, const double* __restrict__ ub,
+                                                                    const double* __restrict__ x, const double* __restrict__ y,
+                                                                    const double* __restrict__ zl, const double* __restrict__ zu,
+                                                                    double* out) {
+    __shared__ double red[kBlock / 64 + 1];
+    const int N = n + m;
+    double pobj = 0.0, offset = 0.0, dobj = 0.0;
+    for (int j = blockIdx.x * kBlock + threadIdx.x; j < N; j += gridDim.x * kBlock) {
+        const unsigned char st = state[j];
+        if (st != IPXK_STATE_FIXED) pobj += c[j] * x[j]; else offset += c[j] * x[j];
+        if (has_lb(st)) dobj += lb[j] * zl[j];
+        if (has_ub(st)) dobj -= ub[j] * zu[j];
+        if (j < m) dobj += b[j] * y[j];
+        if (st == IPXK_STATE_FIXED && j >= n) dobj -= x[j] * y[j - n];
+    }
+    pobj = block_reduce<SumOp>(pobj, red);
+    offset = block_reduce<SumOp>(offset, red);
+    dobj = block_reduce<SumOp>(dobj, red);
+    if (threadIdx.x == 0) { out[blockIdx.x] = pobj; out[gridDim.x + blockIdx.x] = offset; out[2 * gridDim.x + blockIdx.x] = dobj; }
+}
+// fixed structural variables: dot partial += x_j * (A_j'y)
+struct EpiObjFixed : ProdMul {
+    const unsigned char* state; const double* x;
+    static constexpr bool kNeg = false;
+    __device__ __forceinline__ double init(int) const { return 0.0; }
+    __device__ __forceinline__ void finish(int j, double acc, double& dot) const {
+        if (state[j] == IPXK_STATE_FIXED) dot += x[j] * acc;
+    }
+};
+// Model::ComputeNorms (model.cc:58-67): per-block maxima of |b|, finite |lb|, |ub| and of |c|
+__global__ __launch_bounds__(kBlock) void model_norms_kernel(int n, int m, const double* __restrict__ b,
+                                                             const double* __restrict__ c, const double* __restrict__ lb,
+                                                             const double* __restrict__ ub, double* out) {
+    __shared__ double red[kBlock / 64 + 1];
+    double nb = 0.0, nc = 0.0;
+    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n + m; j += gridDim.x * kBlock) {
+        if (j < m) nb = fmax(nb, fabs(b[j]));
+        if (isfinite(lb[j])) nb = fmax(nb, fabs(lb[j]));
+        if (isfinite(ub[j])) nb = fmax(nb, fabs(ub[j]));
+        nc = fmax(nc, fabs(c[j]));
+    }
+    nb = block_reduce<MaxOp>(nb, red);
+    nc = block_reduce<MaxOp>(nc, red);
+    if (threadIdx.x == 0) { out[blockIdx.x] = nb; out[gridDim.x + blockIdx.x] = nc; }
+}
+
 }  // namespace
+
+// out3 = pobjective, dobjective, offset
+void iterate_objectives_dev(Context* c, const double* b, const double* cc, const double* lb, const double* ub,
+                            double out3[3]) {
+    IPXK_REQUIRE(c->it_set, "no iterate on the device (ipxk_iterate_set)");
+    IPXK_REQUIRE(!comm_active(c), "the device iterate is not available on a partitioned system");
+    const int n = (int)c->n, m = (int)c->m, N = n + m;
+    hipStream_t s = c->stream;
+    const int g = vec_grid(N);
+    c->it_partials.resize((size_t)4 * 1024);
+    if (c->partials.size() == 0) c->partials.resize((size_t)kNumPartialSlots * kPartialStride);
+    hipLaunchKernelGGL(iterate_objectives_kernel, dim3(g), dim3(kBlock), 0, s, n, m, c->it_state.get(), b, cc, lb, ub,
+                       c->it_x.get(), c->it_y.get(), c->it_zl.get(), c->it_zu.get(), c->it_partials.get());
+    EpiObjFixed ef{{}, c->it_state.get(), c->it_x.get()};
+    const int np = launch_spmv(c->Acols, c->it_y.get(), ef, c->part(kPartScratch), nullptr, s);
+    std::vector<double> h((size_t)3 * g), hf((size_t)std::max(np, 1));
+    c->it_partials.download(h.data(), h.size(), s);
+    if (np > 0) staged_d2h(hf.data(), c->part(kPartScratch), sizeof(double) * (size_t)np, s);
+    IPXK_HIP(hipGetLastError());
+    double pobj = 0.0, offset = 0.0, dobj = 0.0, fixed = 0.0;
+    for (int i = 0; i < g; i++) { pobj += h[i]; offset += h[(size_t)g + i]; dobj += h[(size_t)2 * g + i]; }
+    for (int i = 0; i < np; i++) fixed += hf[i];
+    out3[0] = pobj; out3[1] = dobj - fixed; out3[2] = offset;
+}
+
+// out2 = norm_bounds, norm_c
+void model_norms_dev(Context* c, const double* b, const double* cc, const double* lb, const double* ub, double out2[2]) {
+    const int n = (int)c->n, m = (int)c->m, N = n + m;
+    const int g = vec_grid(N);
+    c->it_partials.resize((size_t)4 * 1024);
+    hipLaunchKernelGGL(model_norms_kernel, dim3(g), dim3(kBlock), 0, c->stream, n, m, b, cc, lb, ub, c->it_partials.get());
+    std::vector<double> h((size_t)2 * g);
+    c->it_partials.download(h.data(), h.size(), c->stream);
+    IPXK_HIP(hipGetLastError());
+    out2[0] = out2[1] = 0.0;
+    for (int i = 0; i < g; i++) { out2[0] = std::max(out2[0], h[i]); out2[1] = std::max(out2[1], h[(size_t)g + i]); }
+}
 
 void iterate_update_dev(Context* c, double sp, const double* dx, const double* dxl, const double* dxu, double sd,
                         const double* dy, const double* dzl, const double* dzu) {

@@ -412,7 +412,21 @@ static void run_sweep(Context* c, const Sweep& S, bool scaled, const double* xin
     SplitOperator* sp = c->split;
     const SweepView V = S.view(scaled);
     double* xout = S.y.get();
-    static const int grid_all = [] { const char* e = getenv("IPXK_SWEEP_GRID"); return e && atoi(e) > 0 ? atoi(e) : kSweepGrid; }();
+    // Every workgroup of a run must be resident (a wavefront may wait for a chunk that another workgroup of
+    // the same launch owns): never launch more workgroups than the device holds at once.  One block per CU
+    // is held back from what the occupancy query reports (it over-reports by one for some kernels).
+    static const int grid_all = [] {
+        const char* e = getenv("IPXK_SWEEP_GRID");
+        int want = e && atoi(e) > 0 ? atoi(e) : kSweepGrid;
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sweep_run_kernel<true>, kBlock, 0) == hipSuccess) {
+            const int resident = prop.multiProcessorCount * std::max(1, per_cu - 1);
+            want = std::max(1, std::min(want, resident));
+        }
+        return want;
+    }();
     static const int wgs_xcd = [] { const char* e = getenv("IPXK_SWEEP_XCD_WGS"); return e && atoi(e) > 0 ? std::min(atoi(e), 64) : kSweepXcdWgs; }();
     for (const Sweep::Launch& L : S.plan) {
         const bool one_xcd = L.kind == Sweep::kOneXcd;

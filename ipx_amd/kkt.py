@@ -31,7 +31,7 @@ EXPORTS = [
     "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_rescale", "ipxk_split_apply", "ipxk_forward_solve",
     "ipxk_backward_solve", "ipxk_solve_dense", "ipxk_split_levels", "ipxk_cr_solve",
     "ipxk_kkt_basis_solve", "ipxk_newton_solve", "ipxk_iterate_set", "ipxk_iterate_get", "ipxk_iterate_update",
-    "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_ipm_step", "ipxk_iterate_factorize_diag", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns",
+    "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_ipm_step", "ipxk_iterate_objectives", "ipxk_ipm_driver", "ipxk_iterate_factorize_diag", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns",
     "ipxk_time_normal_apply", "ipxk_equilibrate", "ipxk_transpose",
     "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
     "ipxk_dev_download",
@@ -48,6 +48,17 @@ class CrDiag(C.Structure):
     _fields_ = [("errflag", c_i64), ("iter", c_i64), ("maxiter", c_i64), ("resnorm", c_f64), ("tol", c_f64),
                 ("cdot", c_f64), ("infnorm_residual", c_f64), ("infnorm_sresidual", c_f64), ("rps_old", c_f64),
                 ("rps_new", c_f64)]
+
+
+class IpmParams(C.Structure):
+    _fields_ = [("kkt_tol", c_f64), ("feasibility_tol", c_f64), ("optimality_tol", c_f64), ("kkt_maxiter", c_i64),
+                ("ipm_maxiter", c_i64), ("precond_dense_cols", C.c_int)]
+
+
+class IpmInfo(C.Structure):
+    _fields_ = [("status_ipm", c_i64), ("iter", c_i64), ("errflag", c_i64), ("kktiter", c_i64), ("pobjective", c_f64),
+                ("dobjective", c_f64), ("presidual", c_f64), ("dresidual", c_f64), ("complementarity", c_f64),
+                ("mu", c_f64), ("step_primal", c_f64), ("step_dual", c_f64)]
 
 
 class Times(C.Structure):
@@ -417,6 +428,22 @@ class KktContext:
                                            lb_dev.as_arg(), ub_dev.as_arg(), c_f64(kkt_tol), c_i64(maxiter),
                                            C.byref(info), C.cast(None, INTERRUPT_FN), None))
         return {name: getattr(info, name) for name, _ in IpmStepInfo._fields_}
+
+    def iterate_objectives(self, b, c, lb, ub):
+        """Iterate::ComputeObjectives of the resident iterate: (pobjective, dobjective, offset)"""
+        out = (C.c_double * 3)()
+        self._check(self.lib.ipxk_iterate_objectives(self.h, _fp(_F(b)), _fp(_F(c)), _fp(_F(lb)), _fp(_F(ub)), out))
+        return out[0], out[1], out[2]
+
+    def ipm_driver(self, b, c, lb, ub, kkt_tol=0.3, feasibility_tol=1e-6, optimality_tol=1e-8, kkt_maxiter=-1,
+                   ipm_maxiter=300, precond_dense_cols=True, interrupt=None):
+        """IPM::Driver on the resident iterate with the diag solver (host model vectors)."""
+        prm = IpmParams(kkt_tol, feasibility_tol, optimality_tol, kkt_maxiter, ipm_maxiter, 1 if precond_dense_cols else 0)
+        info = IpmInfo()
+        cb = INTERRUPT_FN(lambda _u: int(interrupt())) if interrupt else C.cast(None, INTERRUPT_FN)
+        self._check(self.lib.ipxk_ipm_driver(self.h, _fp(_F(b)), _fp(_F(c)), _fp(_F(lb)), _fp(_F(ub)), C.byref(prm),
+                                             C.byref(info), cb, None))
+        return {name: getattr(info, name) for name, _ in IpmInfo._fields_}
 
     def kkt_diag_get(self):
         W, rs = np.zeros(self.n + self.m, f64), np.zeros(self.m, f64)

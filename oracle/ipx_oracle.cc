@@ -1264,3 +1264,107 @@ extern "C" Int orc_ipm_step_diag(orc_kkt_diag* K, const unsigned char* state,
     info[3] = comp[1];
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// Iterate::ComputeObjectives, src/iterate.cc:590-640, for an iterate that has not been postprocessed and
+// whose variables are fixed / free / barrier (the implied states are only set by the basis solver's drop
+// procedures).  out3 = pobjective, dobjective, offset (pobjective + offset is the primal objective after
+// postprocessing, :203-211).  Pinned against the reference's Iterate (tests/test_oracle_vs_ref.py).
+// ---------------------------------------------------------------------------
+extern "C" void orc_iterate_objectives(Int m, Int n, const Int* Ap, const Int* Ai, const double* Ax,
+    const unsigned char* state, const double* b, const double* c, const double* lb, const double* ub,
+    const double* x, const double* y, const double* zl, const double* zu, double* out3) {
+    const Int N = n + m;
+    double offset = 0.0, pobj = 0.0;
+    for (Int j = 0; j < N; j++) {                    // :615-626
+        if (state[j] != 0) pobj += c[j] * x[j];
+        else offset += c[j] * x[j];
+    }
+    double dobj = 0.0;                               // :627 Dot(b, y)
+    for (Int i = 0; i < m; i++) dobj += b[i] * y[i];
+    for (Int j = 0; j < N; j++) {                    // :628-638
+        if (state[j] == 2 || state[j] == 4) dobj += lb[j] * zl[j];
+        if (state[j] == 3 || state[j] == 4) dobj -= ub[j] * zu[j];
+        if (state[j] == 0) {
+            double d = 0.0;                          // DotColumn(AI, j, y)
+            if (j < n) for (Int p = Ap[j]; p < Ap[j + 1]; p++) d += y[Ai[p]] * Ax[p];
+            else d = y[j - n] * 1.0;
+            dobj -= x[j] * d;
+        }
+    }
+    out3[0] = pobj; out3[1] = dobj; out3[2] = offset;
+}
+
+// Model::ComputeNorms, src/model.cc:58-67: norm_bounds, norm_c
+extern "C" void orc_model_norms(Int m, Int n, const double* b, const double* c, const double* lb,
+                                const double* ub, double* out2) {
+    double nb = 0.0, nc = 0.0;
+    for (Int i = 0; i < m; i++) nb = std::max(nb, std::abs(b[i]));
+    for (Int j = 0; j < n + m; j++) {
+        nc = std::max(nc, std::abs(c[j]));
+        if (std::isfinite(lb[j])) nb = std::max(nb, std::abs(lb[j]));
+        if (std::isfinite(ub[j])) nb = std::max(nb, std::abs(ub[j]));
+    }
+    out2[0] = nb; out2[1] = nc;
+}
+
+// ---------------------------------------------------------------------------
+// IPM::Driver, src/ipm.cc:56-123, around KKTSolverDiag: termination test (Iterate::term_crit_reached with
+// crossover_start = 0, iterate.cc:221-249), divergence / bad-iteration test with the infeasibility
+// classification, iteration limit, Factorize, Predictor + AddCorrector + MakeStep (orc_ipm_step_diag), the
+// bad-iteration count and best complementarity of MakeStep (:520-530).  PARITY UNPINNED as a whole (ipm.cc
+// cannot be linked here); built from pinned pieces.  Returns status_ipm (IPX_STATUS_*).
+// info[10] = iter, errflag, kktiter, pobjective and dobjective after postprocessing, presidual, dresidual,
+//            complementarity, mu, last min(step_primal, step_dual)
+// ---------------------------------------------------------------------------
+extern "C" Int orc_ipm_driver_diag(orc_kkt_diag* K, const unsigned char* state, const double* b,
+    const double* c, const double* lb, const double* ub, double* x, double* xl, double* xu, double* y,
+    double* zl, double* zu, double kkt_tol, double feasibility_tol, double optimality_tol, Int ipm_maxiter,
+    double* info) {
+    const Int m = K->m, n = K->n, N = n + m;
+    constexpr double kDivergeTol = 1e6;              // src/ipm.h:55
+    double norms_model[2];
+    orc_model_norms(m, n, b, c, lb, ub, norms_model);
+    Vec rb(m), rc(N), rl(N), ru(N);
+    double comp[4], res[2], obj[3];
+    orc_iterate_complementarity(N, state, xl, xu, zl, zu, comp);
+    double best_complementarity = comp[0];           // :315
+    Int num_bad_iter = 0, iter = 0, errflag = 0, status = 0, kktiter = 0;
+    double last_step = 0.0;
+    while (true) {
+        orc_iterate_residuals(m, n, K->Ap, K->Ai, K->Ax, state, b, c, lb, ub, x, xl, xu, y, zl, zu,
+                              rb.data(), rc.data(), rl.data(), ru.data(), res);
+        orc_iterate_complementarity(N, state, xl, xu, zl, zu, comp);
+        orc_iterate_objectives(m, n, K->Ap, K->Ai, K->Ax, state, b, c, lb, ub, x, y, zl, zu, obj);
+        const double pobjective = obj[0] + obj[2], dobjective = obj[1] + obj[2];
+        info[3] = pobjective; info[4] = dobjective; info[5] = res[0]; info[6] = res[1];
+        info[7] = comp[0]; info[8] = comp[1];
+        const bool feasible = res[0] <= feasibility_tol * (1.0 + norms_model[0]) &&
+                              res[1] <= feasibility_tol * (1.0 + norms_model[1]);
+        const double mid = 0.5 * (pobjective + dobjective), gap = pobjective - dobjective;
+        const bool optimal = std::abs(gap) <= optimality_tol * (1.0 + std::abs(mid));
+        if (feasible && optimal) { status = 1; break; }                             // IPX_STATUS_optimal
+        if (num_bad_iter >= 5 || comp[0] > kDivergeTol * best_complementarity) {     // :71-93
+            if (dobjective > std::max(10.0 * std::abs(pobjective), 1.0)) status = 3;         // primal_infeas
+            else if (pobjective < -std::max(10.0 * std::abs(dobjective), 1.0)) status = 4;   // dual_infeas
+            else status = 7;                                                                 // no_progress
+            break;
+        }
+        if (iter >= ipm_maxiter) { status = 6; break; }                              // iter_limit
+        errflag = orc_kkt_diag_factorize(K, xl, xu, zl, zu, comp[1]);
+        if (errflag) break;
+        double sinfo[7];
+        errflag = orc_ipm_step_diag(K, state, b, c, lb, ub, x, xl, xu, y, zl, zu, kkt_tol, sinfo);
+        kktiter += (Int)sinfo[5] + (Int)sinfo[6];
+        if (errflag) break;
+        last_step = std::min(sinfo[0], sinfo[1]);     // :524-527
+        if (last_step < 0.05) num_bad_iter++; else num_bad_iter = 0;
+        orc_iterate_complementarity(N, state, xl, xu, zl, zu, comp);
+        best_complementarity = std::min(best_complementarity, comp[0]);
+        iter++;
+    }
+    if (errflag) status = errflag == 999 ? 5 : 8;     // :114-121 time_limit / failed
+    info[0] = (double)iter; info[1] = (double)(errflag == 999 ? 0 : errflag); info[2] = (double)kktiter;
+    info[9] = last_step;
+    return status;
+}

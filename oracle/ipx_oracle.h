@@ -209,6 +209,21 @@ orc_int orc_ipm_step_diag(orc_kkt_diag* K, const unsigned char* state, const dou
     const double* c, const double* lb, const double* ub, double* x, double* xl, double* xu,
     double* y, double* zl, double* zu, double kkt_tol, double* info);
 
+/* Iterate::ComputeObjectives (src/iterate.cc:590-640): out3 = pobjective, dobjective, offset */
+void orc_iterate_objectives(orc_int m, orc_int n, const orc_int* Ap, const orc_int* Ai, const double* Ax,
+    const unsigned char* state, const double* b, const double* c, const double* lb, const double* ub,
+    const double* x, const double* y, const double* zl, const double* zu, double* out3);
+/* Model::ComputeNorms (src/model.cc:58-67): out2 = norm_bounds, norm_c */
+void orc_model_norms(orc_int m, orc_int n, const double* b, const double* c, const double* lb,
+                     const double* ub, double* out2);
+/* IPM::Driver (src/ipm.cc:56-123) around KKTSolverDiag; parity unpinned as a whole.  Returns status_ipm;
+ * info[10] = iter, errflag, kktiter, pobjective, dobjective (after postprocessing), presidual, dresidual,
+ * complementarity, mu, last min(step_primal, step_dual). */
+orc_int orc_ipm_driver_diag(orc_kkt_diag* K, const unsigned char* state, const double* b,
+    const double* c, const double* lb, const double* ub, double* x, double* xl, double* xu, double* y,
+    double* zl, double* zu, double kkt_tol, double feasibility_tol, double optimality_tol,
+    orc_int ipm_maxiter, double* info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -155,6 +155,21 @@ class Oracle:
         r = self.lib.orc_equilibrate(c_i64(A.nrow), c_i64(A.ncol), _ip(A.p), _ip(A.i), _fp(x), _fp(cs), _fp(rs))
         return x, cs, rs, int(r)
 
+    def iterate_objectives(self, A, state, b, c, lb, ub, it):
+        """Iterate::ComputeObjectives: (pobjective, dobjective, offset)"""
+        out = np.zeros(3, f64)
+        st = np.ascontiguousarray(state, dtype=np.uint8)
+        self.lib.orc_iterate_objectives(c_i64(A.nrow), c_i64(A.ncol), _ip(A.p), _ip(A.i), _fp(A.x),
+                                        st.ctypes.data_as(C.POINTER(C.c_ubyte)), _fp(_F(b)), _fp(_F(c)), _fp(_F(lb)),
+                                        _fp(_F(ub)), _fp(_F(it["x"])), _fp(_F(it["y"])), _fp(_F(it["zl"])),
+                                        _fp(_F(it["zu"])), _fp(out))
+        return tuple(float(v) for v in out)
+
+    def model_norms(self, m, n, b, c, lb, ub):
+        out = np.zeros(2, f64)
+        self.lib.orc_model_norms(c_i64(m), c_i64(n), _fp(_F(b)), _fp(_F(c)), _fp(_F(lb)), _fp(_F(ub)), _fp(out))
+        return float(out[0]), float(out[1])
+
     def inverse_perm(self, perm):
         perm = _I(perm)
         inv = np.zeros_like(perm)
@@ -350,6 +365,23 @@ class OracleKktDiag:
         d["errflag"] = int(err)
         return out, d
 
+    def ipm_driver(self, state, b, c, lb, ub, it, kkt_tol=0.3, feasibility_tol=1e-6, optimality_tol=1e-8,
+                   ipm_maxiter=300):
+        """IPM::Driver (src/ipm.cc:56-123) around this KKTSolverDiag; returns (final iterate, info)."""
+        out = {k: _F(it[k]).copy() for k in ("x", "xl", "xu", "y", "zl", "zu")}
+        st = np.ascontiguousarray(state, dtype=np.uint8)
+        info = np.zeros(10, f64)
+        self.orc.lib.orc_ipm_driver_diag.restype = c_i64
+        status = self.orc.lib.orc_ipm_driver_diag(
+            self.h, st.ctypes.data_as(C.POINTER(C.c_ubyte)), _fp(_F(b)), _fp(_F(c)), _fp(_F(lb)), _fp(_F(ub)),
+            *[_fp(out[k]) for k in ("x", "xl", "xu", "y", "zl", "zu")], c_f64(kkt_tol), c_f64(feasibility_tol),
+            c_f64(optimality_tol), c_i64(ipm_maxiter), _fp(info))
+        keys = ("iter", "errflag", "kktiter", "pobjective", "dobjective", "presidual", "dresidual", "complementarity",
+                "mu", "last_step")
+        d = dict(zip(keys, (float(v) for v in info)))
+        d["status_ipm"] = int(status)
+        return out, d
+
     def get(self):
         W = np.zeros(self.n + self.m, f64)
         rs = np.zeros(self.m, f64)
@@ -543,6 +575,18 @@ class RefIterate:
         norms = np.zeros(2, f64)
         self.lib.ref_iterate_residuals(self.h, _fp(rb), _fp(rc), _fp(rl), _fp(ru), _fp(norms))
         return dict(rb=rb, rc=rc, rl=rl, ru=ru, presidual=float(norms[0]), dresidual=float(norms[1]))
+
+    def objectives(self):
+        """pobjective, dobjective, and both after postprocessing"""
+        out = np.zeros(4, f64)
+        self.lib.ref_iterate_objectives(self.h, _fp(out))
+        return tuple(float(v) for v in out)
+
+    def termination(self, feasibility_tol=1e-6, optimality_tol=1e-8):
+        """(feasible, optimal, term_crit_reached) with crossover_start = 0"""
+        out = np.zeros(3, i64)
+        self.lib.ref_iterate_termination(self.h, c_f64(feasibility_tol), c_f64(optimality_tol), _ip(out))
+        return tuple(bool(v) for v in out)
 
     def complementarity(self):
         out = np.zeros(4, f64)

@@ -461,4 +461,24 @@ void ref_iterate_complementarity(void* ith, double* out4) {
     out4[3] = it->mu_max();
 }
 
+// ComputeObjectives, :590-640: pobjective, dobjective, and both after postprocessing (+ offset_)
+void ref_iterate_objectives(void* ith, double* out4) {
+    ipx::Iterate* it = static_cast<ipx::Iterate*>(ith);
+    out4[0] = it->pobjective();
+    out4[1] = it->dobjective();
+    out4[2] = it->pobjective_after_postproc();
+    out4[3] = it->dobjective_after_postproc();
+}
+
+// feasible(), optimal(), term_crit_reached() (:221-249) for the given tolerances, crossover_start = 0
+void ref_iterate_termination(void* ith, double feasibility_tol, double optimality_tol, Int* out3) {
+    ipx::Iterate* it = static_cast<ipx::Iterate*>(ith);
+    it->feasibility_tol(feasibility_tol);
+    it->optimality_tol(optimality_tol);
+    it->crossover_start(0.0);
+    out3[0] = it->feasible();
+    out3[1] = it->optimal();
+    out3[2] = it->term_crit_reached();
+}
+
 }  // extern "C"

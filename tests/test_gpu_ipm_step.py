@@ -123,3 +123,86 @@ def test_ipm_step_with_basis_solver(kkt):
     # a damped Newton step reduces the linear residuals by (1 - step) up to the KKT tolerance
     assert r1["presidual"] < r0["presidual"] and r1["dresidual"] < r0["dresidual"]
     ctx.close()
+
+
+def feasible_lp(m, n, seed):
+    """min c'x, A x + s = b, x, s >= 0 with an interior primal-dual point by construction (so an optimum
+    exists), and the starting iterate x = xl = zl = 1, y = 0 of a barrier-lb variable everywhere."""
+    rng = np.random.default_rng(seed)
+    A = synth.synthetic_lp(m, n, 6, seed)
+    S = A.to_scipy()
+    x0, s0 = rng.uniform(0.5, 2.0, n), rng.uniform(0.5, 2.0, m)
+    y0 = -rng.uniform(0.5, 1.5, m)
+    b = S @ x0 + s0
+    c = np.concatenate([S.T @ y0 + rng.uniform(0.5, 2.0, n), np.zeros(m)])     # slack: 0 = y0_i + zs_i, zs_i = -y0_i > 0
+    N = n + m
+    lbs, ubs = np.zeros(N), np.full(N, np.inf)
+    state = np.full(N, 2, dtype=np.uint8)
+    it = dict(x=np.ones(N), xl=np.ones(N), xu=np.full(N, np.inf), y=np.zeros(m), zl=np.ones(N), zu=np.zeros(N))
+    return A, b, c, lbs, ubs, state, it
+
+
+def test_iterate_objectives_vs_oracle(kkt, oracle):
+    """Iterate::ComputeObjectives incl. fixed variables (offset, and the right-hand side shift A_j'y x_j)"""
+    from oracle import pyoracle as po
+    m, n = 400, 900
+    P = synth.synthetic_iterate(m, n, 43)
+    A, state = P["A"], P["state"].copy()
+    rng = np.random.default_rng(5)
+    fx = np.concatenate([rng.choice(n, 40, replace=False), n + rng.choice(m, 15, replace=False)])
+    state[fx] = 0                                                              # fixed: no barrier terms
+    it = {k: v.copy() for k, v in P["it"].items()}
+    for k in ("xl", "xu"):
+        it[k][fx] = np.inf
+    for k in ("zl", "zu"):
+        it[k][fx] = 0.0
+    b, c = P["rhs"], np.concatenate([P["obj"], np.zeros(m)])
+    Ao = po.Csc(m, n, A.p, A.i, A.x)
+    ctx = kkt.KktContext(A)
+    ctx.iterate_set(it, state)
+    got = ctx.iterate_objectives(b, c, P["lbs"], P["ubs"])
+    want = oracle.iterate_objectives(Ao, state, b, c, P["lbs"], P["ubs"], it)
+    scale = max(abs(v) for v in want) + 1.0
+    assert all(abs(g - w) <= 1e-12 * scale for g, w in zip(got, want)), (got, want)
+    assert want[2] != 0.0                                                      # the offset of the fixed variables is there
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed,m,n", [(71, 60, 150), (72, 300, 640)])
+def test_ipm_driver_vs_oracle(kkt, oracle, seed, m, n):
+    """IPM::Driver (src/ipm.cc:56-123) on the device against the oracle's restatement: an LP with an optimum is
+    driven from the unit starting point to IPX_STATUS_optimal; same status, iteration counts within one, the
+    objectives to the optimality tolerance.  Then the loop's other exits: iteration limit, interrupt, a CR cap
+    that makes the diag solver fail (where LpSolver switches to the basis solver)."""
+    from oracle import pyoracle as po
+    A, b, c, lbs, ubs, state, it = feasible_lp(m, n, seed)
+    Ao = po.Csc(m, n, A.p, A.i, A.x)
+    k = oracle.kkt_diag(Ao, maxiter=5000)
+    final_o, io = k.ipm_driver(state, b, c, lbs, ubs, it, ipm_maxiter=100)
+    ctx = kkt.KktContext(A)
+    ctx.iterate_set(it, state)
+    ig = ctx.ipm_driver(b, c, lbs, ubs, kkt_maxiter=5000, ipm_maxiter=100)
+    assert io["status_ipm"] == ig["status_ipm"] == 1, (io, ig)                 # IPX_STATUS_optimal
+    assert abs(ig["iter"] - io["iter"]) <= 1 and 5 <= ig["iter"] <= 60
+    for key in ("pobjective", "dobjective"):
+        assert abs(ig[key] - io[key]) <= 1e-6 * (1.0 + abs(io[key])), (key, ig[key], io[key])
+    assert abs(ig["pobjective"] - ig["dobjective"]) <= 1e-8 * (1.0 + abs(ig["pobjective"]))
+    nb, nc = oracle.model_norms(m, n, b, c, lbs, ubs)
+    assert ig["presidual"] <= 1e-6 * (1 + nb) and ig["dresidual"] <= 1e-6 * (1 + nc)
+    # the optimal value against an independent LP solver
+    from scipy.optimize import linprog
+    S = A.to_scipy()
+    r = linprog(c[:n], A_ub=S, b_ub=b, bounds=[(0, None)] * n, method="highs")
+    assert r.status == 0 and abs(ig["pobjective"] - r.fun) <= 1e-6 * (1.0 + abs(r.fun))
+    # other exits
+    ctx.iterate_set(it, state)
+    g2 = ctx.ipm_driver(b, c, lbs, ubs, kkt_maxiter=5000, ipm_maxiter=3)
+    assert g2["status_ipm"] == 6 and g2["iter"] == 3                           # IPX_STATUS_iter_limit
+    ctx.iterate_set(it, state)
+    calls = []
+    g3 = ctx.ipm_driver(b, c, lbs, ubs, kkt_maxiter=5000, ipm_maxiter=100, interrupt=lambda: (calls.append(1), 999 if len(calls) > 2 else 0)[1])
+    assert g3["status_ipm"] == 5 and g3["errflag"] == 0 and g3["iter"] <= 3     # IPX_STATUS_time_limit
+    ctx.iterate_set(it, state)
+    g4 = ctx.ipm_driver(b, c, lbs, ubs, kkt_maxiter=1, ipm_maxiter=100)
+    assert g4["status_ipm"] == 8 and g4["errflag"] == 201                       # failed: CR iteration limit
+    ctx.close()

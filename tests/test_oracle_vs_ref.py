@@ -104,6 +104,15 @@ def test_iterate_bitwise(oracle, ref, po, seed, m, n):
         assert np.array_equal(r1[key], r2[key]), key
     assert r1["presidual"] == r2["presidual"] and r1["dresidual"] == r2["dresidual"]
     assert ri.complementarity() == oracle.iterate_complementarity(P["state"], P["it"])
+    # ComputeObjectives and the termination tests of IPM::Driver
+    pobj, dobj, pobj_pp, dobj_pp = ri.objectives()
+    po_, do_, off_ = oracle.iterate_objectives(Ao, P["state"], b, c, lbs, ubs, P["it"])
+    assert (pobj, dobj) == (po_, do_) and (pobj_pp, dobj_pp) == (po_ + off_, do_ + off_)
+    nb, nc = oracle.model_norms(m, n, b, c, lbs, ubs)
+    for ftol, otol in ((1e-6, 1e-8), (1e3, 1e3), (1e3, 1e-8), (1e-6, 1e3)):
+        feas = r2["presidual"] <= ftol * (1.0 + nb) and r2["dresidual"] <= ftol * (1.0 + nc)
+        opt = abs(pobj_pp - dobj_pp) <= otol * (1.0 + abs(0.5 * (pobj_pp + dobj_pp)))
+        assert ri.termination(ftol, otol) == (feas, opt, feas and opt)
     st = P["step"]
     for sp_, sd_, skip in ((0.7, 0.4, ()), (1.0, 1.0, ("dxu", "dzl")), (3.0, 5.0, ())):   # last: clamps at kBarrierMin
         args = {k: (None if k in skip else st[k]) for k in ("dx", "dxl", "dxu", "dy", "dzl", "dzu")}
