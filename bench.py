@@ -54,6 +54,8 @@ def parse():
                     help="N > 1: skip the extra measurement of the column partition (config.column_partition)")
     ap.add_argument("--no-banded", action="store_true", help="skip the banded-matrix probe of the SpMV (extra field of roofline)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 2 and 5 (config.other_configs)")
+    ap.add_argument("--no-direct-exchange", action="store_true",
+                    help="N > 1: skip the extra measurement over the direct (hipIpc) exchange (config.direct_exchange)")
     return ap.parse_args()
 
 
@@ -316,6 +318,12 @@ def main():
         # every rank takes part; reported next to the north-star row partition, never as `value`
         out["config"]["column_partition"] = bench_column_partition(kkt, dist, torch, A, st, tol, args, rank, world,
                                                                    local_rank, tdev)
+    if world > 1 and not args.no_direct_exchange and (os.environ.get("IPXK_COMM") != "direct" or
+                                                       os.environ.get("IPXK_BENCH_DIRECT_AGAIN")):
+        # the same row-partitioned solve over the library's direct exchange (hipIpc-mapped peer buffers) next to
+        # the RCCL measurement above; never `value`.  Any failure is recorded instead of a number.
+        out["config"]["direct_exchange"] = bench_direct_exchange(kkt, dist, torch, A, st, tol, args, rank, world,
+                                                                 local_rank, it, tdev)
     if rehearsal:
         out["config"]["transport"] = "REHEARSAL: all ranks on one GPU, direct exchange between the rank processes"
     elif world > 1:
@@ -358,6 +366,67 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_direct_exchange(kkt, dist, torch, A, st, tol, args, rank, world, local_rank, it_rccl, tdev="cuda"):
+    """Row partition again, collectives through IPXK_COMM=direct.  Every rank runs the same sequence; an error on
+    any rank (set-up, a bounded wait that expired) is agreed on through torch.distributed and reported."""
+    from ipx_amd.partition import row_slab
+    res, ctx, failed = {}, None, 0
+    try:
+        slab = row_slab(A, st, rank, world)
+        ctx = kkt.KktContext(slab.A, device=local_rank)
+        before = os.environ.get("IPXK_COMM")
+        os.environ["IPXK_COMM"] = "direct"
+        try:
+            ids = [ctx.comm_unique_id() if rank == 0 else None]
+        finally:
+            if before is None:
+                os.environ.pop("IPXK_COMM", None)
+            else:
+                os.environ["IPXK_COMM"] = before
+    except Exception as exc:                                 # noqa: BLE001 - recorded, not raised
+        res["error"] = "set-up: %s" % exc
+        ids, failed = [None], 1
+    flag = torch.tensor([failed], dtype=torch.int32, device=tdev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        return res or {"error": "set-up failed on another rank"}
+    dist.broadcast_object_list(ids, src=0)
+    try:
+        ctx.comm_init(ids[0], rank, world)
+        assert ctx.kkt_diag_factorize(slab.xl, slab.xu, slab.zl, slab.zu, st["mu"]) == 0
+        ctx.set_pointer_mode(True)
+        mg = slab.A.nrow
+        n = A.ncol
+        a, b = ctx.vector(n + mg, slab.a), ctx.vector(mg, slab.b)
+        x, y = ctx.vector(n + mg), ctx.vector(mg)
+        for _ in range(args.warmup):
+            it, errflag, tm = ctx.kkt_diag_solve_resident(a, b, x, y, tol, args.maxiter)
+        ctx.synchronize(); torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            it, errflag, tm = ctx.kkt_diag_solve_resident(a, b, x, y, tol, args.maxiter)
+        ctx.synchronize(); torch.cuda.synchronize(); dist.barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        rhs_d, lhs_d = ctx.vector(mg, np.random.default_rng(0).standard_normal(mg)), ctx.vector(mg)
+        ctx.time_normal_apply(rhs_d, lhs_d, 5)
+        apply_ms = ctx.time_normal_apply(rhs_d, lhs_d, 50) / 50
+        res = {"solves_per_sec": args.steps / dt, "ms_per_solve": dt / args.steps * 1e3, "cr_iterations": it,
+               "errflag": errflag, "us_per_apply": apply_ms * 1e3, "cr_iterations_rccl_run": it_rccl,
+               "exchange": "reduce-scatter + all-gather kernels over hipIpc-mapped peer buffers (DESIGN section 7)"}
+    except Exception as exc:                                 # noqa: BLE001
+        res = {"error": str(exc)}
+    finally:
+        try:
+            if ctx is not None:
+                ctx.close()
+        except Exception:                                    # noqa: BLE001
+            pass
+    return res
 
 
 def bench_column_partition(kkt, dist, torch, A, st, tol, args, rank, world, local_rank, tdev="cuda"):

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void direct_allgather_kernel(PeerTable P, i
 struct DirectComm {
     struct Header { std::atomic<int> count; std::atomic<int> generation; };
     // segment layout: Header | pad to 256 | handles: R x 2 x 64 B | pad to 4096 | flags: 2 x R x 64 B
-    static constexpr size_t kHandlesAt = 256, kFlagsAt = 4096;
+    static constexpr size_t kHandlesAt = 256, kDevicesAt = 2400, kFlagsAt = 4096;
     std::string name;
     int rank = 0, nranks = 1;
     bool owner = false;
@@ -238,7 +238,17 @@ struct DirectComm {
         static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
         memcpy(seg + kHandlesAt + (size_t)r * 128, &hs, 64);
         memcpy(seg + kHandlesAt + (size_t)r * 128 + 64, &ht, 64);
+        int my_device = 0;
+        IPXK_HIP(hipGetDevice(&my_device));
+        int* devices = reinterpret_cast<int*>(seg + kDevicesAt);
+        devices[r] = my_device;
         host_barrier();                                   // every handle is in the segment
+        for (int q = 0; q < n; q++) {                     // peers on other GPUs must be reachable over xGMI / PCIe
+            if (devices[q] == my_device) continue;
+            int can = 0;
+            IPXK_HIP(hipDeviceCanAccessPeer(&can, my_device, devices[q]));
+            if (!can) throw Error(IPXK_E_UNSUPPORTED, "direct exchange: no peer access between the GPUs of two ranks");
+        }
         for (int q = 0; q < n; q++) {
             if (q == r) { peers.S[q] = S; peers.T[q] = T; continue; }
             hipIpcMemHandle_t a, b;

@@ -743,3 +743,35 @@ def test_equilibrate_and_transpose_on_device(kkt, po, oracle, seed, m, n):
         kkt.transpose(bad)
     with pytest.raises(kkt.KktError):
         kkt.equilibrate(bad)
+
+
+def test_sweep_edge_cases(kkt, po, oracle, monkeypatch):
+    """degenerate factor shapes: a 1 x 1 system, L without entries and U diagonal only (every unknown in level 0),
+    and a bidiagonal pair (a chain: as many levels as unknowns, one unknown each -- the pure hand-off chain)"""
+    import scipy.sparse as sp
+    from ipx_amd.synth import CscMatrix
+    rng = np.random.default_rng(11)
+
+    def check(Lm, Um, m):
+        n = 2 * m + 3
+        mk = lambda M: CscMatrix(m, m, M.indptr, M.indices, M.data)
+        L, U = mk(sp.csc_matrix(Lm)), mk(sp.csc_matrix(Um))
+        ctx = kkt.KktContext(synth_identity_model(m, n))
+        ident = np.arange(m, dtype=np.int64)
+        status = np.full(n + m, -1, dtype=np.int64); status[:m] = 0
+        ctx.split_prepare(L, U, ident, ident, ident, status, np.ones(n + m))
+        rhs = rng.standard_normal(m)
+        assert np.array_equal(ctx.forward_solve(rhs), oracle.forward_solve(ocsc(po, L), ocsc(po, U), rhs))
+        assert np.array_equal(ctx.backward_solve(rhs), oracle.backward_solve(ocsc(po, L), ocsc(po, U), rhs))
+        lv = ctx.split_levels()
+        ctx.close()
+        return lv
+
+    assert check(sp.csc_matrix((1, 1)), sp.csc_matrix([[2.5]]), 1) == [1, 1, 1, 1]
+    m = 777
+    assert check(sp.csc_matrix((m, m)), sp.diags(rng.uniform(0.5, 2.0, m)).tocsc(), m) == [1, 1, 1, 1]
+    m = 3000
+    Lc = sp.diags(rng.uniform(-0.9, 0.9, m - 1), -1, shape=(m, m)).tocsc()
+    Uc = (sp.diags(rng.uniform(-0.9, 0.9, m - 1), 1, shape=(m, m)) + sp.diags(rng.uniform(1.0, 2.0, m))).tocsc()
+    Uc.sort_indices()
+    assert check(Lc, Uc, m) == [m, m, m, m]
