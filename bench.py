@@ -141,8 +141,11 @@ def bench_diag_config(kkt, synth, label, m, n, num_dense, args, reps_cpu):
     ctx = kkt.KktContext(A)
     t0 = time.perf_counter()
     err = ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"])
-    t_fact = time.perf_counter() - t0
+    t_fact_first = time.perf_counter() - t0          # builds the dense-column structures once per model
     assert err == 0
+    t0 = time.perf_counter()
+    assert ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"]) == 0
+    t_fact = time.perf_counter() - t0                # what every IPM iteration pays (host vectors over PCIe included)
     traj = pcr_trajectory_check(ctx, A, st["a"], st["b"], tol)
     xg, yg, itg, eg, _ = ctx.kkt_diag_solve(st["a"], st["b"], tol, args.maxiter)
     W, _ = ctx.kkt_diag_get()
@@ -166,7 +169,7 @@ def bench_diag_config(kkt, synth, label, m, n, num_dense, args, reps_cpu):
     layouts = ctx.spmv_layout()[0]
     ctx.set_pointer_mode(False)
     res = {"workload": label, "solves_per_sec": 1.0 / dt, "ms_per_solve": dt * 1e3, "cr_iterations": it, "errflag": errflag,
-           "factorize_ms": t_fact * 1e3, "num_dense_cols": ctx.num_dense_cols,
+           "factorize_ms": t_fact * 1e3, "first_factorize_ms": t_fact_first * 1e3, "num_dense_cols": ctx.num_dense_cols,
            "roofline": {"bound": "hbm", "us_per_apply": apply_ms * 1e3, "algorithmic_bytes": nbytes,
                         "achieved": nbytes / (apply_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": nbytes / (apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "layouts": list(layouts)},

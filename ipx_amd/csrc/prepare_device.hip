@@ -187,7 +187,7 @@ __global__ void level_keys_kernel(int dim, int ascending, int by_length, const i
 // per level l: sorted unknowns [lstart[2l], lstart[2l+1]) are its long rows, [lstart[2l+1], lstart[2l+2]) its
 // short ones; lpos[2l], lpos[2l+1] = first position of either part
 __global__ void place_kernel(int dim, const int* __restrict__ sorted_key, const int* __restrict__ sorted_unknown,
-                             const int* __restrict__ lstart, const int* __restrict__ lpos,
+                             const int* __restrict__ lstart, const int* __restrict__ lpos, const int* __restrict__ lsub,
                              const int* __restrict__ rp, const double* __restrict__ dgn, int* __restrict__ order,
                              int* __restrict__ posof, double* __restrict__ diag, int* __restrict__ len) {
     IPXK_GRID_STRIDE(t, dim) {
@@ -198,18 +198,19 @@ __global__ void place_kernel(int dim, const int* __restrict__ sorted_key, const 
         order[pos] = i;
         posof[i] = pos;
         diag[pos] = dgn[i];
-        len[pos] = rp[i + 1] - rp[i];
+        len[pos] = (rp[i + 1] - rp[i]) | (lsub[l] << kLenBits);     // lsub: the level's place inside a merged chunk
     }
 }
 
 // entry slots a chunk needs: 64 * (its longest row, rounded up to whole steps of 8 for long rows);
 // also completes the descriptor's width
 __global__ void chunk_size_kernel(int nchunks, ChunkDesc* __restrict__ chunks, const int* __restrict__ len,
-                                  int* __restrict__ size) {
+                                  int* __restrict__ size, int* too_long) {
     IPXK_GRID_STRIDE(c, nchunks) {
         ChunkDesc d = chunks[c];
         int mx = 0;
-        for (int q = 0; q < d.npos; q++) mx = max(mx, len[d.pos0 + q]);
+        for (int q = 0; q < d.npos; q++) mx = max(mx, len[d.pos0 + q] & ((1 << kLenBits) - 1));
+        if (d.sub > 1 && d.width < 0 && mx > 64) *too_long = 1;     // merged long rows must fit one round of 64 entries
         if (d.width < 0) { const int steps = (mx + kLongLanes - 1) / kLongLanes; d.width = -max(steps, 1); size[c] = max(steps, 1) * 64; }
         else { d.width = mx; size[c] = mx * 64; }
         chunks[c].width = d.width;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void rescale_kernel(SweepView S, const int*
     if (r < 0) { if (ell || gl == 0) diagS[pos] = 1.0; return; }
     const double own = uscale[r];
     if (ell || gl == 0) diagS[pos] = S.diag[pos] * own;
-    const int len = S.len[pos];
+    const int len = S.len[pos] & ((1 << kLenBits) - 1);
     for (int e = ell ? 0 : gl; e < len; e += ell ? 1 : kLongLanes) {
         const int64_t slot = ell ? (int64_t)d.ent0 + e * 64 + lane : (int64_t)d.ent0 + (e >> 3) * 64 + lane;
         valS[slot] = S.val[slot] * (MODE == 1 ? own : uscale[order[S.idx[slot]]]);
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void rescale_kernel(SweepView S, const int*
 }
 
 struct Scratch {   // reused by the four sweeps of one Prepare
-    DevBuf<int> keys, vals, keys2, vals2, colof, level, lstart, lpos, csize, cent0;
+    DevBuf<int> keys, vals, keys2, vals2, colof, level, lstart, lpos, lsub, csize, cent0;
     DevBuf<unsigned char> tmp;
     DevBuf<int> rp, ri;
     DevBuf<double> rx, dgn;
@@ -361,66 +362,126 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
         W.lstart.download(lstart.data(), lstart.size(), s);
         IPXK_HIP(hipStreamSynchronize(s));
     }
-    // chunk layout (host arithmetic over the part sizes): positions and chunk -> position; widths and
-    // entry offsets are completed on the device
-    std::vector<int> lpos((size_t)2 * std::max(nlev, 1), 0);
-    std::vector<ChunkDesc> chunks;
-    S.level_chunk.assign((size_t)nlev + 1, 0);
-    S.level_width.assign((size_t)nlev, 0);
-    int64_t pos = 0;
-    for (int l = 0; l < nlev; l++) {
-        S.level_chunk[l] = (int)chunks.size();
-        const int nl = lstart[2 * l + 1] - lstart[2 * l], ns = lstart[2 * l + 2] - lstart[2 * l + 1];
-        S.level_width[l] = nl + ns;
-        lpos[2 * l] = (int)pos;
-        const int nlpad = (nl + kLongLanes - 1) / kLongLanes * kLongLanes;
-        for (int q = 0; q < nlpad; q += kLongLanes) chunks.push_back({(int)pos + q, 0, -1, kLongLanes});
-        pos += nlpad;
-        lpos[2 * l + 1] = (int)pos;
-        const int nspad = (ns + 63) / 64 * 64;
-        for (int q = 0; q < nspad; q += 64) chunks.push_back({(int)pos + q, 0, 0, 64});
-        pos += nspad;
-        IPXK_REQUIRE(pos < (int64_t(1) << 31), "packed factor exceeds 32-bit offsets");
-    }
-    S.level_chunk[nlev] = (int)chunks.size();
-    const int npos = (int)pos, nchunks = (int)chunks.size();
-    S.nlevels = nlev;
-    S.npos = npos;
-    S.nchunks = nchunks;
-    const size_t np1 = (size_t)std::max(npos, 1), nc1 = (size_t)std::max(nchunks, 1);
-    S.chunks.ensure(nc1);
-    if (nchunks) S.chunks.upload(chunks.data(), chunks.size(), s);
-    S.order.ensure(np1); S.diag.ensure(np1); S.len.ensure(np1); S.src.ensure(np1); S.y.ensure(np1);
-    S.posof.ensure((size_t)std::max(dim, 1));
-    IPXK_HIP(hipMemsetAsync(S.order.get(), 0xff, sizeof(int) * np1, s));
-    IPXK_HIP(hipMemsetAsync(S.len.get(), 0, sizeof(int) * np1, s));
-    if (npos > 0) hipLaunchKernelGGL(fill_double_kernel, dim3(grid_for(npos)), dim3(kBlock), 0, s, (int64_t)npos, 1.0, S.diag.get());
+    const bool merge_levels = [] { const char* e = getenv("IPXK_SWEEP_MERGE"); return !(e && e[0] == '0'); }();
+    size_t np1 = 1, ns1 = 1;
+    int npos = 0;
     int64_t slots = 0;
-    if (dim > 0) {
-        W.lpos.ensure(lpos.size());
-        W.lpos.upload(lpos, s);
-        hipLaunchKernelGGL(place_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, W.keys2.get(), W.vals2.get(),
-                           W.lstart.get(), W.lpos.get(), W.rp.get(), W.dgn.get(), S.order.get(), S.posof.get(), S.diag.get(),
-                           S.len.get());
-        W.csize.ensure(nc1 + 1); W.cent0.ensure(nc1 + 1);
-        hipLaunchKernelGGL(chunk_size_kernel, dim3(grid_for(nchunks)), dim3(kBlock), 0, s, nchunks, S.chunks.get(),
-                           S.len.get(), W.csize.get());
-        exclusive_scan(W, W.csize.get(), W.cent0.get(), (size_t)nchunks + 1, s);
-        hipLaunchKernelGGL(chunk_ent0_kernel, dim3(grid_for(nchunks)), dim3(kBlock), 0, s, nchunks, S.chunks.get(), W.cent0.get());
-        IPXK_HIP(hipMemcpyAsync(W.h_flag, W.cent0.get() + nchunks, sizeof(int), hipMemcpyDeviceToHost, s));
-        IPXK_HIP(hipStreamSynchronize(s));
-        slots = *W.h_flag;
-        IPXK_REQUIRE(slots >= 0, "packed factor exceeds 32-bit offsets");
+    auto layout = [&](bool merge_long) -> bool {
+        // chunk layout (host arithmetic over the part sizes): positions and chunk -> position; widths and
+        // entry offsets are completed on the device.  Consecutive tiny levels whose rows are all short (<= 64 in
+        // total) or all long (<= 8 in total) share one MERGED chunk (trisolve.hpp).
+        std::vector<int> lpos((size_t)2 * std::max(nlev, 1), 0), lsub((size_t)std::max(nlev, 1), 0);
+        std::vector<ChunkDesc> chunks;
+        S.level_chunk.assign((size_t)nlev + 1, 0);
+        S.level_width.assign((size_t)nlev, 0);
+        int64_t pos = 0;
+        auto counts = [&](int l, int& nl, int& ns) { nl = lstart[2 * l + 1] - lstart[2 * l]; ns = lstart[2 * l + 2] - lstart[2 * l + 1]; };
+        for (int l = 0; l < nlev;) {
+            int nl, ns;
+            counts(l, nl, ns);
+            // how many levels starting at l can share a chunk
+            int last = l, total = nl + ns;
+            const bool long_only = ns == 0 && nl > 0, short_only = nl == 0 && ns > 0;
+            const int cap = long_only ? kLongLanes : 64;
+            if (merge_levels && (long_only ? merge_long : short_only) && total <= cap) {
+                while (last + 1 < nlev && last + 1 - l < kMaxSubLevels) {
+                    int nl2, ns2;
+                    counts(last + 1, nl2, ns2);
+                    const bool same = long_only ? (ns2 == 0 && nl2 > 0) : (nl2 == 0 && ns2 > 0);
+                    if (!same || total + nl2 + ns2 > cap) break;
+                    total += nl2 + ns2;
+                    last++;
+                }
+            }
+            if (last > l) {                                   // merged chunk for levels l..last
+                const int c = (int)chunks.size();
+                int p = (int)pos;
+                for (int t = l; t <= last; t++) {
+                    int a, b2;
+                    counts(t, a, b2);
+                    S.level_chunk[t] = c;
+                    S.level_width[t] = a + b2;
+                    lsub[t] = t - l;
+                    lpos[2 * t] = p; lpos[2 * t + 1] = p;    // one of the two parts is empty
+                    p += a + b2;
+                }
+                chunks.push_back({(int)pos, 0, long_only ? -1 : 0, cap, last - l + 1, 0, 0, 0});
+                pos += cap;
+                l = last + 1;
+                continue;
+            }
+            S.level_chunk[l] = (int)chunks.size();
+            S.level_width[l] = nl + ns;
+            lpos[2 * l] = (int)pos;
+            const int nlpad = (nl + kLongLanes - 1) / kLongLanes * kLongLanes;
+            for (int q = 0; q < nlpad; q += kLongLanes) chunks.push_back({(int)pos + q, 0, -1, kLongLanes, 1, 0, 0, 0});
+            pos += nlpad;
+            lpos[2 * l + 1] = (int)pos;
+            const int nspad = (ns + 63) / 64 * 64;
+            for (int q = 0; q < nspad; q += 64) chunks.push_back({(int)pos + q, 0, 0, 64, 1, 0, 0, 0});
+            pos += nspad;
+            IPXK_REQUIRE(pos < (int64_t(1) << 31), "packed factor exceeds 32-bit offsets");
+            l++;
+        }
+        S.level_chunk[nlev] = (int)chunks.size();
+        npos = (int)pos;
+        const int nchunks = (int)chunks.size();
+        S.nlevels = nlev;
+        S.npos = npos;
+        S.nchunks = nchunks;
+        np1 = (size_t)std::max(npos, 1);
+        const size_t nc1 = (size_t)std::max(nchunks, 1);
+        S.chunks.ensure(nc1);
+        if (nchunks) S.chunks.upload(chunks.data(), chunks.size(), s);
+        S.merged_prefix.assign((size_t)nchunks + 1, 0);
+        for (int c = 0; c < nchunks; c++) S.merged_prefix[c + 1] = S.merged_prefix[c] + (chunks[c].sub > 1 ? 1 : 0);
+        S.order.ensure(np1); S.diag.ensure(np1); S.len.ensure(np1); S.src.ensure(np1); S.y.ensure(np1);
+        S.posof.ensure((size_t)std::max(dim, 1));
+        IPXK_HIP(hipMemsetAsync(S.order.get(), 0xff, sizeof(int) * np1, s));
+        IPXK_HIP(hipMemsetAsync(S.len.get(), 0, sizeof(int) * np1, s));
+        if (npos > 0) hipLaunchKernelGGL(fill_double_kernel, dim3(grid_for(npos)), dim3(kBlock), 0, s, (int64_t)npos, 1.0, S.diag.get());
+        slots = 0;
+        if (dim > 0) {
+            W.lpos.ensure(lpos.size()); W.lsub.ensure(lsub.size());
+            W.lpos.upload(lpos, s);
+            W.lsub.upload(lsub, s);
+            hipLaunchKernelGGL(place_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, W.keys2.get(), W.vals2.get(),
+                               W.lstart.get(), W.lpos.get(), W.lsub.get(), W.rp.get(), W.dgn.get(), S.order.get(), S.posof.get(),
+                               S.diag.get(), S.len.get());
+            W.csize.ensure(nc1 + 1); W.cent0.ensure(nc1 + 1);
+            DevBuf<int> too_long(1);
+            IPXK_HIP(hipMemsetAsync(too_long.get(), 0, sizeof(int), s));
+            hipLaunchKernelGGL(chunk_size_kernel, dim3(grid_for(nchunks)), dim3(kBlock), 0, s, nchunks, S.chunks.get(),
+                               S.len.get(), W.csize.get(), too_long.get());
+            int tl = 0;
+            too_long.download(&tl, 1, s);
+            if (tl) return false;                             // a merged long row exceeds one round: lay out again without
+            exclusive_scan(W, W.csize.get(), W.cent0.get(), (size_t)nchunks + 1, s);
+            hipLaunchKernelGGL(chunk_ent0_kernel, dim3(grid_for(nchunks)), dim3(kBlock), 0, s, nchunks, S.chunks.get(), W.cent0.get());
+            IPXK_HIP(hipMemcpyAsync(W.h_flag, W.cent0.get() + nchunks, sizeof(int), hipMemcpyDeviceToHost, s));
+            IPXK_HIP(hipStreamSynchronize(s));
+            slots = *W.h_flag;
+            IPXK_REQUIRE(slots >= 0, "packed factor exceeds 32-bit offsets");
+        }
+        S.nentries = slots;
+        ns1 = (size_t)std::max<int64_t>(slots, 1);
+        S.idx.ensure(ns1); S.val.ensure(ns1);
+        IPXK_HIP(hipMemsetAsync(S.idx.get(), 0, sizeof(int) * ns1, s));
+        IPXK_HIP(hipMemsetAsync(S.val.get(), 0, sizeof(double) * ns1, s));
+        if (nchunks > 0)
+            hipLaunchKernelGGL(pack_entries_kernel, dim3(std::min(grid_for((int64_t)nchunks * 64), 2048)), dim3(kBlock), 0, s, nchunks,
+                               S.chunks.get(), S.order.get(), S.posof.get(), W.rp.get(), W.ri.get(), W.rx.get(), S.idx.get(),
+                               S.val.get());
+        return true;
+    };
+    // long rows are merged only on request (IPXK_SWEEP_MERGE=long): every round of a merged chunk recomputes
+    // all its rows, which for rows of 10-40 entries costs more than the hand-offs it saves (C3: +9 us per
+    // forward pair)
+    const bool want_long = [] { const char* e = getenv("IPXK_SWEEP_MERGE"); return e && std::string(e) == "long"; }();
+    if (!layout(want_long)) {
+        const bool ok = layout(false);
+        IPXK_REQUIRE(ok, "chunk layout failed");
     }
-    S.nentries = slots;
-    const size_t ns1 = (size_t)std::max<int64_t>(slots, 1);
-    S.idx.ensure(ns1); S.val.ensure(ns1);
-    IPXK_HIP(hipMemsetAsync(S.idx.get(), 0, sizeof(int) * ns1, s));
-    IPXK_HIP(hipMemsetAsync(S.val.get(), 0, sizeof(double) * ns1, s));
-    if (nchunks > 0)
-        hipLaunchKernelGGL(pack_entries_kernel, dim3(std::min(grid_for((int64_t)nchunks * 64), 2048)), dim3(kBlock), 0, s, nchunks,
-                           S.chunks.get(), S.order.get(), S.posof.get(), W.rp.get(), W.ri.get(), W.rx.get(), S.idx.get(),
-                           S.val.get());
     if (scale_mode) { S.valS.ensure(ns1); S.diagS.ensure(np1); }
     plan_sweep(S, level_launches);
     IPXK_HIP(hipStreamSynchronize(s));    // host vectors uploaded above go out of scope

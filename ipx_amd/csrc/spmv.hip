@@ -245,7 +245,8 @@ void GatherMatrix::build_sliced(const ipxint* hptr, const ipxint* hidx, const do
         int64_t slice_bytes = int64_t(2) << 20;          // half of an XCD's L2
         if (const char* e = getenv("IPXK_SLICE_TEST_KB"))   // tests: make small matrices eligible
             if (atoi(e) > 0) slice_bytes = (int64_t)atoi(e) << 10;
-        if (x_bytes <= 2 * slice_bytes) return;          // x fits an XCD's L2: nothing to slice
+        // x fits an XCD's L2: nothing to slice (IPXK_SLICE_FORCE2: experiments with two slices)
+        if (x_bytes <= 2 * slice_bytes && !(getenv("IPXK_SLICE_FORCE2") && x_bytes > slice_bytes)) return;
         ns = 2;
         while (ns < 8 && x_bytes > (int64_t)ns * slice_bytes) ns *= 2;
     }

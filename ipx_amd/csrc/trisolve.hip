@@ -70,6 +70,7 @@ __device__ __forceinline__ gu64 load_sc1(const gu64* p) {
 struct LaneRec {
     int src;        // index of the right-hand side in the input vector (-1: padding)
     int len;        // entries of the row
+    int sub;        // merged chunks: which of the chunk's levels the row belongs to
     double dg, xr;
     int j[8];       // dependency positions
     double a[8];
@@ -81,7 +82,9 @@ __device__ __forceinline__ void load_rec(LaneRec& R, const SweepView& S, const C
     const int pos = d.width >= 0 ? d.pos0 + lane : d.pos0 + (lane >> 3);
     R.src = S.src[pos];
     R.dg = S.diag[pos];
-    R.len = S.len[pos];
+    const int lenword = S.len[pos];
+    R.len = lenword & ((1 << kLenBits) - 1);
+    R.sub = lenword >> kLenBits;
     const int steps = d.width >= 0 ? d.width : min(-d.width, 8);     // wave-uniform
 #pragma unroll
     for (int e = 0; e < 8; e++) {
@@ -106,14 +109,16 @@ struct HandGlobal {
         else __hip_atomic_store(reinterpret_cast<gu64*>(xout) + pos, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 };
-// first look at the dependencies of the lane's (up to 8) entries starting at entry `first`
+// first look at the dependencies of the lane's (up to 8) entries starting at entry `first`; dependencies at
+// positions [lo, hi) belong to the (merged) chunk itself and travel through lane shuffles instead
 template <class Hand>
-__device__ __forceinline__ void issue_polls(const LaneRec& R, bool ell, int gl, int first, const Hand& H, gu64 (&bits)[8]) {
+__device__ __forceinline__ void issue_polls(const LaneRec& R, bool ell, int gl, int first, const Hand& H, gu64 (&bits)[8],
+                                            int lo = 0, int hi = 0) {
 #pragma unroll
     for (int t = 0; t < 8; t++) {
         const int e = ell ? t : first + t * 8 + gl;
         bits[t] = 0ull;
-        if (R.src >= 0 && e < R.len) bits[t] = H.look(R.j[t]);
+        if (R.src >= 0 && e < R.len && !(R.j[t] >= lo && R.j[t] < hi)) bits[t] = H.look(R.j[t]);
     }
 }
 
@@ -172,13 +177,60 @@ __device__ __forceinline__ double ordered_combine(double acc, double prod, int c
     return acc;
 }
 
+// A MERGED chunk (trisolve.hpp): `nsub` consecutive tiny levels in one chunk.  The dependencies outside the
+// chunk have been polled (bits); the wavefront runs the levels in order, every lane recomputes its row in every
+// round and keeps the value of the round that is its own level -- by then all its dependencies inside the chunk
+// (rows of earlier levels: other lanes of this wavefront) hold their results, which travel by lane shuffles.
+// Each row is still summed in its own order: bit-identical to the unmerged form.
+template <bool RUNNING, class Hand>
+__device__ __forceinline__ void solve_merged(const LaneRec& R, const ChunkDesc& d, int lane, const Hand& H, const gu64 (&bits)[8]) {
+    const bool ell = d.width >= 0;
+    const int gl = lane & 7;
+    const int npos = ell ? 64 : kLongLanes;
+    const int len = R.src >= 0 ? R.len : 0;
+    double result = 0.0;
+    const int steps = ell ? d.width : min(-d.width, 8);            // wave-uniform: entries (ELL) / steps of 8 (long rows)
+    // where each dependency comes from: a lane of this wavefront (rows of earlier levels of the chunk) or memory
+    int from[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int e = ell ? t : t * 8 + gl;
+        const int off = R.j[t] - d.pos0;
+        from[t] = (t < steps && e < len && off >= 0 && off < npos) ? (ell ? off : off << 3) : -1;
+    }
+    for (int s = 0; s < d.sub; s++) {
+        // all shuffles of the round are issued before the first use, so their latencies overlap
+        double xin[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            if (t < steps) xin[t] = __shfl(result, from[t] >= 0 ? from[t] : lane, 64);
+        double acc = RUNNING ? R.xr : 0.0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            if (t >= steps) break;                                  // wave-uniform
+            const int e = ell ? t : t * 8 + gl;
+            double prod = 0.0;
+            if (e < len) {
+                const double xj = from[t] >= 0 ? xin[t] : __longlong_as_double((long long)bits[t]);
+                prod = RUNNING ? R.a[t] * xj : xj * R.a[t];
+            }
+            if (ell) { if (e < len) acc = RUNNING ? acc - prod : acc + prod; }
+            else acc = ordered_combine<RUNNING>(acc, prod, min(kLongLanes, len - t * 8));
+        }
+        if (R.sub == s && (ell || gl == 0)) result = R.src >= 0 ? (RUNNING ? acc : R.xr - acc) / R.dg : 0.0;
+    }
+    if (ell) store_result(H, d.pos0 + lane, result);
+    else if (gl == 0) store_result(H, d.pos0 + (lane >> 3), result);
+}
+
 // solves the chunk whose records are in R (first look at the dependencies already issued into bits);
 // false on timeout
-template <bool RUNNING, class Hand>
+template <bool RUNNING, bool MERGED, class Hand>
 __device__ __forceinline__ bool solve_chunk(LaneRec& R, const ChunkDesc& d, int lane, const SweepView& S, const Hand& H,
                                             gu64 (&bits)[8], int* abort_flag) {
     const bool ell = d.width >= 0;
     if (!wait_polls(R, H, bits, abort_flag)) return false;
+    if (MERGED && d.sub > 1) { solve_merged<RUNNING>(R, d, lane, H, bits); return true; }
     if (ell) {
         double acc = RUNNING ? R.xr : 0.0;
 #pragma unroll
@@ -228,18 +280,20 @@ __device__ __forceinline__ ChunkDesc scalar_desc(const ChunkDesc& v) {   // wave
     d.ent0 = __builtin_amdgcn_readfirstlane(v.ent0);
     d.width = __builtin_amdgcn_readfirstlane(v.width);
     d.npos = v.npos;
+    d.sub = __builtin_amdgcn_readfirstlane(v.sub);
     return d;
 }
 
 // the wavefront's chunks c, c + NW, ... < c1; A holds the records of chunk c (descriptor d), dn is the
 // descriptor of chunk c + NW
-template <bool RUNNING, class Hand>
+template <bool RUNNING, bool MERGED, class Hand>
 __device__ __forceinline__ void chunk_loop(const SweepView& S, int c, int c1, int NW, int lane, const double* __restrict__ xin,
                                            const Hand& H, LaneRec& A, ChunkDesc d, ChunkDesc dn, int* abort_flag) {
     LaneRec B;
     for (;;) {
         gu64 bits[8];
-        issue_polls(A, d.width >= 0, lane & 7, 0, H, bits);
+        const int own = MERGED && d.sub > 1 ? (d.width >= 0 ? 64 : kLongLanes) : 0;     // merged: the chunk's own positions
+        issue_polls(A, d.width >= 0, lane & 7, 0, H, bits, d.pos0, d.pos0 + own);
         // the next chunk's records (and the descriptor after that) travel while this chunk waits
         const int cn = c + NW;
         ChunkDesc dnn = dn;
@@ -247,7 +301,7 @@ __device__ __forceinline__ void chunk_loop(const SweepView& S, int c, int c1, in
             load_rec(B, S, dn, lane, xin);
             if (cn + NW < c1) dnn = scalar_desc(S.chunks[cn + NW]);
         }
-        if (!solve_chunk<RUNNING>(A, d, lane, S, H, bits, abort_flag)) return;
+        if (!solve_chunk<RUNNING, MERGED>(A, d, lane, S, H, bits, abort_flag)) return;
         if (cn >= c1) return;
         A = B; d = dn; dn = dnn; c = cn;
     }
@@ -262,7 +316,8 @@ __device__ __forceinline__ void chunk_loop(const SweepView& S, int c, int c1, in
 //   reads everybody else's; only if all agree are plain stores used, otherwise every participant
 //   falls back to write-through stores (all participants see the same ids and decide alike).
 //   Correctness therefore never depends on where workgroups land, only the speed does.
-template <bool RUNNING>
+// MERGED: the run contains merged chunks (the lean instantiation without that path serves all other runs)
+template <bool RUNNING, bool MERGED>
 __global__ __launch_bounds__(kBlock) void sweep_run_kernel(SweepView S, int c0, int c1, const double* __restrict__ xin,
                                                            double* xout, int xcd_mode, unsigned epoch, gu64* xcc_slots,
                                                            int* abort_flag, const int* done) {
@@ -308,7 +363,7 @@ __global__ __launch_bounds__(kBlock) void sweep_run_kernel(SweepView S, int c0, 
     }
     if (!active) return;
     const HandGlobal H{xo, xout, plain};
-    chunk_loop<RUNNING>(S, c, c1, NW, lane, xin, H, A, d, dn, abort_flag);
+    chunk_loop<RUNNING, MERGED>(S, c, c1, NW, lane, xin, H, A, d, dn, abort_flag);
 }
 
 // pre-fills the result vectors of up to four sweeps with the sentinel
@@ -380,7 +435,8 @@ void plan_sweep(Sweep& S, bool level_launches) {
     const int nlev = S.nlevels;
     if (nlev == 0) return;
     auto push = [&](int l0, int l1, int kind) {
-        if (S.level_chunk[l1] > S.level_chunk[l0]) S.plan.push_back({S.level_chunk[l0], S.level_chunk[l1], kind});
+        const int c0 = S.level_chunk[l0], c1 = S.level_chunk[l1];
+        if (c1 > c0) S.plan.push_back({c0, c1, kind, S.merged_prefix[c1] > S.merged_prefix[c0]});
     };
     if (level_launches) {
         for (int l = 0; l < nlev; l++) push(l, l + 1, Sweep::kAllXcds);
@@ -421,7 +477,7 @@ static void run_sweep(Context* c, const Sweep& S, bool scaled, const double* xin
         int dev = 0, per_cu = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sweep_run_kernel<true>, kBlock, 0) == hipSuccess) {
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sweep_run_kernel<true, true>, kBlock, 0) == hipSuccess) {
             const int resident = prop.multiProcessorCount * std::max(1, per_cu - 1);
             want = std::max(1, std::min(want, resident));
         }
@@ -434,12 +490,10 @@ static void run_sweep(Context* c, const Sweep& S, bool scaled, const double* xin
         int grid = std::max(1, std::min(need, one_xcd ? wgs_xcd : grid_all));
         unsigned epoch = 0;
         if (one_xcd) { grid *= 8; epoch = ++sp->epoch; if (epoch == 0) epoch = ++sp->epoch; }
-        if (S.running)
-            hipLaunchKernelGGL(sweep_run_kernel<true>, dim3(grid), dim3(kBlock), 0, c->stream, V, L.c0, L.c1, xin, xout,
-                               one_xcd ? 1 : 0, epoch, sp->xcc_slots.get(), sp->abort_flag.get(), done);
-        else
-            hipLaunchKernelGGL(sweep_run_kernel<false>, dim3(grid), dim3(kBlock), 0, c->stream, V, L.c0, L.c1, xin, xout,
-                               one_xcd ? 1 : 0, epoch, sp->xcc_slots.get(), sp->abort_flag.get(), done);
+        auto kernel = S.running ? (L.merged ? sweep_run_kernel<true, true> : sweep_run_kernel<true, false>)
+                                : (L.merged ? sweep_run_kernel<false, true> : sweep_run_kernel<false, false>);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, c->stream, V, L.c0, L.c1, xin, xout, one_xcd ? 1 : 0, epoch,
+                           sp->xcc_slots.get(), sp->abort_flag.get(), done);
     }
 }
 

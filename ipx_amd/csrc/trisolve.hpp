@@ -21,7 +21,14 @@ constexpr int kLenKeyBits = 8;   // sort key = level << kLenKeyBits | (255 - min
 //               row; in step s lane (row q, g) holds entry 8*s + g of its row at ent0 + s*64 + 8*q + g
 // Slots beyond a row's length hold zeros and are never used (lanes stop at their length).  Either way a
 // wavefront reads its chunk with fully coalesced loads whose addresses depend on the descriptor only.
-struct ChunkDesc { int pos0, ent0, width, npos; };
+// MERGED chunks: consecutive tiny levels that fit one chunk together (all their rows short and <= 64 in total,
+// or all long and <= 8 in total) share a chunk; `sub` = number of levels in it (1 for an ordinary chunk).  The
+// wavefront then runs the levels one after the other and passes values between them through lane shuffles
+// instead of memory -- a chain of tiny levels costs ~0.15 us per level instead of one memory hand-off each.
+// The per-position sub-level is kept in the upper half of `len` (kLenBits).
+struct ChunkDesc { int pos0, ent0, width, npos, sub, pad0, pad1, pad2; };
+constexpr int kLenBits = 16;            // len word of a position: entries | sub-level << kLenBits
+constexpr int kMaxSubLevels = 32;
 
 // A sweep reads its right-hand side through `src` (position -> index into the input vector, -1 for
 // padding) and writes its result BY POSITION: y[k] = value of the unknown at level-ordered position k.
@@ -60,7 +67,8 @@ struct Sweep {
     std::vector<int> level_chunk;  // host, [nlevels+1] first chunk of each level
     std::vector<int> level_width;  // host, [nlevels] unknowns per level
     enum Kind { kAllXcds = 0, kOneXcd = 1 };
-    struct Launch { int c0, c1; int kind; };
+    struct Launch { int c0, c1; int kind; bool merged; };   // merged: the run contains merged chunks
+    std::vector<int> merged_prefix;  // host, [nchunks+1] number of merged chunks before chunk c
     std::vector<Launch> plan;
     SweepView view(bool scaled) const {
         SweepView V;

@@ -238,6 +238,7 @@ SWEEP_MODES = {
     "default": {},                                   # one-XCD runs for narrow levels, all-XCD runs otherwise
     "levels": {"IPXK_TRISOLVE": "levels"},           # one launch per level
     "allxcd": {"IPXK_SWEEP_NARROW": "0"},            # every run chip-wide (write-through hand-off)
+    "nomerge": {"IPXK_SWEEP_MERGE": "0"},            # tiny levels keep a chunk each (no merged chunks)
     "onexcd": {"IPXK_SWEEP_NARROW": "1000000000", "IPXK_SWEEP_MINLEVELS": "1"},   # every run on one XCD
     "onexcd-2wgs": {"IPXK_SWEEP_NARROW": "1000000000", "IPXK_SWEEP_MINLEVELS": "1", "IPXK_SWEEP_XCD_WGS": "2"},
 }
@@ -427,7 +428,7 @@ def test_split_prepare_rejects_bad_factors(kkt):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode", ["default", "allxcd", "onexcd"])
+@pytest.mark.parametrize("mode", ["default", "allxcd", "onexcd", "nomerge"])
 def test_sweeps_with_dense_rows_and_columns(kkt, po, oracle, monkeypatch, mode):
     """factors with a few rows AND columns of 70 / 300 / 1500 entries next to short ones: rows longer than
     one 64-entry round of the 8-lane form in all four sweeps (dense rows of L and U in the forward sweeps,
@@ -479,7 +480,7 @@ def test_sweeps_with_dense_rows_and_columns(kkt, po, oracle, monkeypatch, mode):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode", ["default", "allxcd", "onexcd"])
+@pytest.mark.parametrize("mode", ["default", "allxcd", "onexcd", "nomerge"])
 def test_deep_level_structure(kkt, po, oracle, monkeypatch, mode):
     """banded planted factors: thousands of narrow levels (SURVEY 8d stress point) -- one long one-XCD run,
     and more relaxation launches than the device-side level analysis allows itself (host scan instead)"""
