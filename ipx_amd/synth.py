@@ -249,3 +249,71 @@ def synthetic_iterate(m, n, seed, frac_special=0.15):
     step = dict(dx=U(N), dxl=U(N), dxu=U(N), dy=U(m), dzl=U(N), dzu=U(N))
     return dict(A=A, rhs=rng.uniform(-1, 1, m), constr_type="".join(ct), obj=rng.uniform(-1, 1, n), lb=lb, ub=ub,
                 lbs=lbs, ubs=ubs, state=state, it=it, step=step)
+
+
+def lp_like_basis_matrix(dim, bump=64, frac_rowsing=0.2, frac_slack=0.5, offdiag=2, window=None,
+                         bump_density=0.3, num_dependent=0, seed=12345):
+    """A nearly triangular matrix of the kind LP bases are (SURVEY 8f rank 1: the input of Basis::Factorize,
+    reference src/basis.cc:116-156): in a hidden pivot order it is
+        [ T   X   X ]   T: upper triangular, `frac_slack` of its columns unit columns, the others with up to
+        [ 0   D   0 ]      `offdiag` entries above the diagonal (uniform rows, or the `window` rows above);
+        [ 0   Y   R ]   R: LOWER triangular (its rows are row singletons once T is gone), entries below the diagonal;
+                        D: the bump (bump x bump, `bump_density`, every row and column >= 2 entries);
+    X, Y sparse.  `num_dependent` bump columns are made copies of other bump columns (a singular basis).
+    Rows and columns are scrambled.  Returns dict(Bp, Bi, Bx (CSC, unsorted), dim, plus the planted sizes)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed + 7)
+    n3 = int(frac_rowsing * (dim - bump))
+    n1 = dim - bump - n3
+    r, c, v = [], [], []
+
+    def vals(k):
+        return rng.uniform(0.5, 4.0, k) * rng.choice([-1.0, 1.0], k)
+
+    def add(rows, cols):
+        r.append(rows.astype(i64)); c.append(cols.astype(i64)); v.append(vals(rows.size))
+
+    # T: diagonal + entries above it in the non-slack columns
+    add(np.arange(n1), np.arange(n1))
+    nonslack = np.nonzero(rng.random(n1) >= frac_slack)[0]
+    cols = np.repeat(nonslack, offdiag)
+    span = cols if window is None else np.minimum(cols, window)
+    ok = span > 0
+    rows = cols - 1 - (rng.random(cols.size) * span).astype(i64)
+    add(rows[ok], cols[ok])
+    # X: bump and R columns reach into the rows of T
+    if n1 > 0:
+        cols = np.repeat(np.arange(n1, dim), offdiag)
+        add((rng.random(cols.size) * n1).astype(i64), cols)
+    # D
+    if bump > 0:
+        D = (rng.random((bump, bump)) < bump_density)
+        D[np.arange(bump), np.arange(bump)] = True
+        D[np.arange(bump), (np.arange(bump) + 1) % bump] = True if bump > 1 else D[0, 0]
+        rr, cc = np.nonzero(D)
+        add(n1 + rr, n1 + cc)
+    # R: diagonal + entries below it; Y: R's rows reach into the bump columns
+    if n3 > 0:
+        base = n1 + bump
+        add(base + np.arange(n3), base + np.arange(n3))
+        cols = np.repeat(np.arange(n3), offdiag)
+        span = n3 - 1 - cols
+        ok = span > 0
+        rows = cols + 1 + (rng.random(cols.size) * span).astype(i64)
+        add(base + rows[ok], base + cols[ok])
+        if bump > 0:
+            rows = np.repeat(np.arange(n3), 1)
+            add(base + rows, n1 + (rng.random(rows.size) * bump).astype(i64))
+    R, Cc, V = np.concatenate(r), np.concatenate(c), np.concatenate(v)
+    M = sp.coo_matrix((V, (R, Cc)), shape=(dim, dim)).tocsc()
+    M.sum_duplicates()                       # duplicates add up (still nonzero with probability 1)
+    if num_dependent and bump > 2:           # copies of bump columns: a numerically singular bump
+        M = M.tolil()
+        for t in range(num_dependent):
+            M[:, n1 + bump - 1 - t] = M[:, n1 + t] * 2.0
+        M = M.tocsc()
+    rowperm, colperm = rng.permutation(dim), rng.permutation(dim)
+    Mc = M.tocoo()
+    B = sp.coo_matrix((Mc.data, (rowperm[Mc.row], colperm[Mc.col])), shape=(dim, dim)).tocsc()
+    return dict(dim=dim, Bp=B.indptr.astype(i64), Bi=B.indices.astype(i64), Bx=B.data.astype(f64),
+                planted=dict(T=n1, bump=bump, R=n3))

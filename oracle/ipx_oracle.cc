@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <utility>
 #include <vector>
 
@@ -1368,3 +1369,230 @@ extern "C" Int orc_ipm_driver_diag(orc_kkt_diag* K, const unsigned char* state, 
     info[9] = last_step;
     return status;
 }
+
+// ---------------------------------------------------------------------------
+// LU factorization of a basis matrix behind the reference's LuFactorization contract
+// (src/lu_factorization.h:21-58):  B[rowperm,colperm] = (L+I)*U, L strictly lower without its diagonal,
+// U upper with the diagonal last in each column, indices sorted, dependent columns replaced by unit
+// columns and listed.  The reference's kernel for this is BASICLU (third party, NOT in /root/reference:
+// install.txt:1-3, pinned commit 7b41d962cd345057946b84ac41d525efaba4b871, call site
+// src/basiclu_kernel.cc:31-82): its published scheme -- pivot the column singletons and the row singletons
+// first (no arithmetic, no fill), then factorize the remaining "bump" with threshold pivoting -- is what is
+// restated here, in the form the device code uses it:
+//   * the singletons are taken in ROUNDS (all current column singletons, then all current row singletons,
+//     until neither exists); within a round the pivots are independent, ordered by column (row) index;
+//     two singleton columns in one row: the smaller column index wins; two singleton rows in one column:
+//     the larger |entry| wins (ties: smaller row index); a row singleton must pass the relative threshold
+//     |a| >= pivottol * max|active entries of its column| as well as the absolute one;
+//   * the bump is factorized as a dense matrix with partial pivoting (largest |entry| of the column among
+//     the rows not yet pivoted, ties: smaller row), columns in ascending index order; a column whose largest
+//     entry is below the absolute tolerance (kLuDependencyTol if strict_abs_pivottol, src/ipx_internal.h:26,
+//     else 1e-14, BASICLU's default) is dependent;
+//   * dependent columns come last, paired with the left-over rows in ascending order.
+// PARITY UNPINNED against BASICLU's pivot order and values (no fixture in the reference holds them:
+// check/solver.cc asserts statuses only).  What IS pinned: the contract, through the reference's own
+// LuFactorization::Factorize / stability() (src/lu_factorization.cc:87-127) and ForrestTomlin
+// (src/forrest_tomlin.cc) running on these factors in oracle/ref_driver.cc.
+// ---------------------------------------------------------------------------
+struct orc_lu {
+    Int dim = 0;
+    std::vector<Int> Lp, Li, Up, Ui, rowperm, colperm, dependent;
+    std::vector<double> Lx, Ux;
+    Int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // col singletons, row singletons, bump size, rounds, dependent
+};
+
+extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend, const Int* Bi, const double* Bx,
+                                    double pivottol, int strict_abs_pivottol, Int bump_limit) {
+    const double abstol = strict_abs_pivottol ? 1e-3 : 1e-14;
+    std::unique_ptr<orc_lu> F(new orc_lu);
+    F->dim = dim;
+    // row-wise copy: entries of row i in ascending column order
+    std::vector<Int> rp(dim + 1, 0);
+    for (Int j = 0; j < dim; j++)
+        for (Int p = Bbegin[j]; p < Bend[j]; p++) rp[Bi[p] + 1]++;
+    for (Int i = 0; i < dim; i++) rp[i + 1] += rp[i];
+    std::vector<Int> rj(rp[dim]);
+    std::vector<double> rx(rp[dim]);
+    {
+        std::vector<Int> cur(rp.begin(), rp.end() - 1);
+        for (Int j = 0; j < dim; j++)
+            for (Int p = Bbegin[j]; p < Bend[j]; p++) { rj[cur[Bi[p]]] = j; rx[cur[Bi[p]]++] = Bx[p]; }
+    }
+    std::vector<Int> rstage(dim, -1), cstage(dim, -1), rc(dim), cc(dim);
+    std::vector<double> pivot(dim, 0.0);             // by column
+    std::vector<char> ckind(dim, 0);                 // 1 column singleton, 2 row singleton, 3 bump, 4 dependent
+    for (Int j = 0; j < dim; j++) cc[j] = Bend[j] - Bbegin[j];
+    for (Int i = 0; i < dim; i++) rc[i] = rp[i + 1] - rp[i];
+    Int npiv = 0, rounds = 0;
+    while (true) {
+        Int found = 0;
+        // ---- column singletons
+        {
+            std::vector<Int> claim(dim, -1), piv_row(dim, -1);
+            for (Int j = 0; j < dim; j++) {
+                if (cstage[j] >= 0 || cc[j] != 1) continue;
+                for (Int p = Bbegin[j]; p < Bend[j]; p++) {
+                    const Int i = Bi[p];
+                    if (rstage[i] >= 0) continue;
+                    if (std::abs(Bx[p]) >= abstol && claim[i] < 0) { claim[i] = j; piv_row[j] = i; pivot[j] = Bx[p]; }
+                    break;
+                }
+            }
+            std::vector<Int> winners;
+            for (Int j = 0; j < dim; j++) if (piv_row[j] >= 0) winners.push_back(j);
+            for (Int j : winners) {
+                const Int i = piv_row[j];
+                rstage[i] = cstage[j] = npiv++;
+                ckind[j] = 1;
+            }
+            for (Int j : winners) {
+                const Int i = piv_row[j];
+                for (Int q = rp[i]; q < rp[i + 1]; q++)
+                    if (cstage[rj[q]] < 0) cc[rj[q]]--;
+            }
+            found += (Int)winners.size();
+            F->info[0] += (Int)winners.size();
+        }
+        // ---- row singletons
+        {
+            std::vector<Int> best_row(dim, -1), piv_col(dim, -1);
+            std::vector<double> best_abs(dim, 0.0);
+            for (Int i = 0; i < dim; i++) {
+                if (rstage[i] >= 0 || rc[i] != 1) continue;
+                for (Int q = rp[i]; q < rp[i + 1]; q++) {
+                    const Int j = rj[q];
+                    if (cstage[j] >= 0) continue;
+                    const double a = std::abs(rx[q]);
+                    double colmax = 0.0;
+                    for (Int p = Bbegin[j]; p < Bend[j]; p++)
+                        if (rstage[Bi[p]] < 0) colmax = std::max(colmax, std::abs(Bx[p]));
+                    if (a >= abstol && a >= pivottol * colmax && a > best_abs[j]) { best_abs[j] = a; best_row[j] = i; }
+                    break;
+                }
+            }
+            std::vector<Int> winners;                 // rows, ascending
+            for (Int j = 0; j < dim; j++) if (best_row[j] >= 0) piv_col[best_row[j]] = j;
+            for (Int i = 0; i < dim; i++) if (piv_col[i] >= 0) winners.push_back(i);
+            for (Int i : winners) {
+                const Int j = piv_col[i];
+                rstage[i] = cstage[j] = npiv++;
+                ckind[j] = 2;
+                for (Int q = rp[i]; q < rp[i + 1]; q++) if (rj[q] == j) pivot[j] = rx[q];
+            }
+            for (Int i : winners) {
+                const Int j = piv_col[i];
+                for (Int p = Bbegin[j]; p < Bend[j]; p++)
+                    if (rstage[Bi[p]] < 0) rc[Bi[p]]--;
+            }
+            found += (Int)winners.size();
+            F->info[1] += (Int)winners.size();
+        }
+        rounds++;
+        if (found == 0) break;
+    }
+    F->info[3] = rounds;
+    // ---- bump: dense, partial pivoting
+    std::vector<Int> brow, bcol, rloc(dim, -1), cloc(dim, -1);
+    for (Int i = 0; i < dim; i++) if (rstage[i] < 0) { rloc[i] = (Int)brow.size(); brow.push_back(i); }
+    for (Int j = 0; j < dim; j++) if (cstage[j] < 0) { cloc[j] = (Int)bcol.size(); bcol.push_back(j); }
+    const Int kb = (Int)bcol.size();
+    F->info[2] = kb;
+    if (bump_limit >= 0 && kb > bump_limit) return nullptr;
+    std::vector<double> D((size_t)kb * kb, 0.0);      // column-major
+    for (Int c = 0; c < kb; c++)
+        for (Int p = Bbegin[bcol[c]]; p < Bend[bcol[c]]; p++)
+            if (rloc[Bi[p]] >= 0) D[(size_t)c * kb + rloc[Bi[p]]] = Bx[p];
+    std::vector<Int> brstep(kb, -1), bcstep(kb, -1);   // bump-local pivot step of a row / column
+    Int bstep = 0;
+    for (Int c = 0; c < kb; c++) {
+        double* col = &D[(size_t)c * kb];
+        Int pr = -1;
+        double best = 0.0;
+        for (Int r = 0; r < kb; r++)
+            if (brstep[r] < 0 && std::abs(col[r]) > best) { best = std::abs(col[r]); pr = r; }
+        if (pr < 0 || best < abstol) continue;         // dependent
+        brstep[pr] = bcstep[c] = bstep++;
+        const double piv = col[pr];
+        for (Int r = 0; r < kb; r++)
+            if (brstep[r] < 0) col[r] /= piv;           // multipliers stay in place
+        for (Int c2 = c + 1; c2 < kb; c2++) {
+            double* col2 = &D[(size_t)c2 * kb];
+            const double u = col2[pr];
+            if (u == 0.0) continue;
+            for (Int r = 0; r < kb; r++)
+                if (brstep[r] < 0) col2[r] -= col[r] * u;
+        }
+    }
+    // stages of the bump pivots, then the dependent columns with the left-over rows
+    for (Int c = 0; c < kb; c++)
+        if (bcstep[c] >= 0) { cstage[bcol[c]] = npiv + bcstep[c]; ckind[bcol[c]] = 3; }
+    for (Int r = 0; r < kb; r++)
+        if (brstep[r] >= 0) rstage[brow[r]] = npiv + brstep[r];
+    npiv += bstep;
+    {
+        std::vector<Int> lrows;
+        for (Int r = 0; r < kb; r++) if (brstep[r] < 0) lrows.push_back(r);
+        size_t t = 0;
+        for (Int c = 0; c < kb; c++)
+            if (bcstep[c] < 0) {
+                cstage[bcol[c]] = npiv; ckind[bcol[c]] = 4;
+                rstage[brow[lrows[t++]]] = npiv;
+                F->dependent.push_back(npiv++);
+            }
+    }
+    F->info[4] = (Int)F->dependent.size();
+    F->rowperm.assign(dim, 0); F->colperm.assign(dim, 0);
+    for (Int i = 0; i < dim; i++) F->rowperm[rstage[i]] = i;
+    for (Int j = 0; j < dim; j++) F->colperm[cstage[j]] = j;
+    // ---- assemble: column k of L and U, indices ascending
+    F->Lp.assign(1, 0); F->Up.assign(1, 0);
+    std::vector<std::pair<Int, double>> lcol, ucol;
+    for (Int k = 0; k < dim; k++) {
+        const Int j = F->colperm[k];
+        lcol.clear(); ucol.clear();
+        if (ckind[j] == 4) {
+            ucol.emplace_back(k, 1.0);
+        } else {
+            const Int c = cloc[j];
+            for (Int p = Bbegin[j]; p < Bend[j]; p++) {
+                const Int i = Bi[p];
+                if (c >= 0 && rloc[i] >= 0) continue;                 // bump x bump: from the dense result
+                const Int s = rstage[i];
+                if (s < k) ucol.emplace_back(s, Bx[p]);
+                else if (s > k) lcol.emplace_back(s, Bx[p] / pivot[j]);
+            }
+            if (c >= 0) {
+                const double* col = &D[(size_t)c * kb];
+                for (Int r = 0; r < kb; r++) {
+                    const Int s = rstage[brow[r]];
+                    if (s == k) { pivot[j] = col[r]; continue; }
+                    if (col[r] == 0.0) continue;
+                    if (s < k) ucol.emplace_back(s, col[r]); else lcol.emplace_back(s, col[r]);
+                }
+            }
+            std::sort(ucol.begin(), ucol.end());
+            std::sort(lcol.begin(), lcol.end());
+            ucol.emplace_back(k, pivot[j]);
+        }
+        for (auto& e : lcol) { F->Li.push_back(e.first); F->Lx.push_back(e.second); }
+        for (auto& e : ucol) { F->Ui.push_back(e.first); F->Ux.push_back(e.second); }
+        F->Lp.push_back((Int)F->Li.size());
+        F->Up.push_back((Int)F->Ui.size());
+    }
+    return F.release();
+}
+
+extern "C" void orc_lu_sizes(const orc_lu* F, Int* lnz, Int* unz, Int* ndep, Int* info) {
+    *lnz = (Int)F->Li.size(); *unz = (Int)F->Ui.size(); *ndep = (Int)F->dependent.size();
+    if (info) std::copy(F->info, F->info + 8, info);
+}
+extern "C" void orc_lu_get(const orc_lu* F, Int* Lp, Int* Li, double* Lx, Int* Up, Int* Ui, double* Ux,
+                           Int* rowperm, Int* colperm, Int* dependent) {
+    std::copy(F->Lp.begin(), F->Lp.end(), Lp); std::copy(F->Li.begin(), F->Li.end(), Li);
+    std::copy(F->Lx.begin(), F->Lx.end(), Lx); std::copy(F->Up.begin(), F->Up.end(), Up);
+    std::copy(F->Ui.begin(), F->Ui.end(), Ui); std::copy(F->Ux.begin(), F->Ux.end(), Ux);
+    std::copy(F->rowperm.begin(), F->rowperm.end(), rowperm);
+    std::copy(F->colperm.begin(), F->colperm.end(), colperm);
+    std::copy(F->dependent.begin(), F->dependent.end(), dependent);
+}
+extern "C" void orc_lu_free(orc_lu* F) { delete F; }

@@ -224,6 +224,18 @@ orc_int orc_ipm_driver_diag(orc_kkt_diag* K, const unsigned char* state, const d
     double* zl, double* zu, double kkt_tol, double feasibility_tol, double optimality_tol,
     orc_int ipm_maxiter, double* info);
 
+/* ---- LU factorization behind src/lu_factorization.h:21-58 (section 8f rank 1) ------------------------------
+ * singleton rounds + dense bump with partial pivoting; see ipx_oracle.cc.  Returns NULL when the bump exceeds
+ * bump_limit rows (bump_limit < 0: no limit).  info[8] = column singletons, row singletons, bump size, rounds,
+ * dependent columns, 0, 0, 0. */
+typedef struct orc_lu orc_lu;
+orc_lu* orc_lu_factorize(orc_int dim, const orc_int* Bbegin, const orc_int* Bend, const orc_int* Bi, const double* Bx,
+                         double pivottol, int strict_abs_pivottol, orc_int bump_limit);
+void orc_lu_sizes(const orc_lu* F, orc_int* lnz, orc_int* unz, orc_int* ndep, orc_int* info);
+void orc_lu_get(const orc_lu* F, orc_int* Lp, orc_int* Li, double* Lx, orc_int* Up, orc_int* Ui, double* Ux,
+                orc_int* rowperm, orc_int* colperm, orc_int* dependent);
+void orc_lu_free(orc_lu* F);
+
 #ifdef __cplusplus
 }
 #endif

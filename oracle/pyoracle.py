@@ -90,7 +90,7 @@ class Oracle:
                      "orc_kkt_diag_solve", "orc_trisolve", "orc_split_get_sizes",
                      "orc_kkt_basis_solve", "orc_newton_solve_diag", "orc_newton_solve_basis", "orc_ipm_step_diag"):
             getattr(L, name).restype = c_i64
-        for name in ("orc_diag_factorize", "orc_kkt_diag_new", "orc_split_prepare"):
+        for name in ("orc_diag_factorize", "orc_kkt_diag_new", "orc_split_prepare", "orc_lu_factorize"):
             getattr(L, name).restype = C.c_void_p
 
     # ---- Iterate / StepToBoundary ---------------------------------------------
@@ -146,6 +146,28 @@ class Oracle:
         self.lib.orc_transpose(c_i64(A.nrow), c_i64(A.ncol), _ip(A.p), _ip(A.i), _fp(A.x),
                                _ip(ATp), _ip(ATi), _fp(ATx))
         return Csc(A.ncol, A.nrow, ATp, ATi, ATx)
+
+    def lu_factorize(self, dim, Bbegin, Bend, Bi, Bx, pivottol=0.1, strict=False, bump_limit=-1):
+        """LuFactorization contract (src/lu_factorization.h:21-58): returns dict(L, U, rowperm, colperm, dependent,
+        info) with L, U as Csc, or None when the bump exceeds bump_limit."""
+        Bbegin, Bend, Bi, Bx = _I(Bbegin), _I(Bend), _I(Bi), _F(Bx)
+        h = self.lib.orc_lu_factorize(c_i64(dim), _ip(Bbegin), _ip(Bend), _ip(Bi), _fp(Bx), c_f64(pivottol),
+                                      C.c_int(1 if strict else 0), c_i64(bump_limit))
+        if not h:
+            return None
+        h = C.c_void_p(h)
+        lnz, unz, ndep = c_i64(), c_i64(), c_i64()
+        info = np.zeros(8, i64)
+        self.lib.orc_lu_sizes(h, C.byref(lnz), C.byref(unz), C.byref(ndep), _ip(info))
+        Lp, Up = np.zeros(dim + 1, i64), np.zeros(dim + 1, i64)
+        Li, Lx = np.zeros(lnz.value, i64), np.zeros(lnz.value, f64)
+        Ui, Ux = np.zeros(unz.value, i64), np.zeros(unz.value, f64)
+        rowperm, colperm, dep = np.zeros(dim, i64), np.zeros(dim, i64), np.zeros(ndep.value, i64)
+        self.lib.orc_lu_get(h, _ip(Lp), _ip(Li), _fp(Lx), _ip(Up), _ip(Ui), _fp(Ux), _ip(rowperm), _ip(colperm), _ip(dep))
+        self.lib.orc_lu_free(h)
+        return dict(L=Csc(dim, dim, Lp, Li, Lx), U=Csc(dim, dim, Up, Ui, Ux), rowperm=rowperm, colperm=colperm,
+                    dependent=dep, info=dict(col_singletons=int(info[0]), row_singletons=int(info[1]),
+                                             bump=int(info[2]), rounds=int(info[3]), dependent=int(info[4])))
 
     def equilibrate(self, A):
         """Presolver::EquilibrateMatrix: (scaled values, colscale, rowscale, rounds); rounds = -1: untouched"""
