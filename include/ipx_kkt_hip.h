@@ -213,6 +213,51 @@ int ipxk_split_prepare(ipxk_context* ctx, const ipxint* Lp, const ipxint* Li,
  * bit-identical to a full ipxk_split_prepare with the same arguments. */
 int ipxk_split_rescale(ipxk_context* ctx, const ipxint* status,
                        const double* colscale);
+/* ---- basis LU factorization on the device ------------------
+ * The LuFactorization contract, src/lu_factorization.h:21-58:
+ *     B[rowperm,colperm] = (L+I)*U
+ * with L strictly lower (no diagonal stored), U upper with the diagonal last in
+ * each column, indices sorted; dependent columns are replaced by unit columns in
+ * the product and their positions in colperm are listed.  Replaces the kernel
+ * behind BasicLuKernel::_Factorize (src/basiclu_kernel.cc:31-82, BASICLU); call
+ * sites ForrestTomlin::_Factorize (src/forrest_tomlin.cc:28-30) and, through
+ * LuUpdate::Factorize, Basis::Factorize (src/basis.cc:116-156).  Method: rounds of
+ * column / row singletons, then the remaining bump as a dense matrix with partial
+ * pivoting (any pivottol in (0,1] is therefore met inside the bump; a row
+ * singleton must pass |a| >= pivottol * max|active column|).  Absolute pivot
+ * tolerance: kLuDependencyTol = 1e-3 (src/ipx_internal.h:26) if
+ * strict_abs_pivottol, else 1e-14.  A bump of more than IPXK_LU_BUMP_MAX rows
+ * (environment, default 4096) returns IPXK_E_UNSUPPORTED.
+ * Columns of B are Bi/Bx[Bbegin[j] .. Bend[j]-1] (4-array form, as Basis passes
+ * AI's arrays); indices need not be sorted.  The factors stay on the device;
+ * ipxk_lu_get_factors copies them out (array sizes from ipxk_lu_info; any
+ * pointer may be NULL). */
+typedef struct {
+  ipxint lnz, unz;          /* entries of L (no diagonal) and of U (with it) */
+  ipxint num_dependent;     /* columns replaced by unit columns */
+  ipxint col_singletons, row_singletons, bump, rounds;
+  double seconds_singletons, seconds_bump, seconds_assemble;
+} ipxk_lu_info;
+int ipxk_lu_factorize(ipxk_context* ctx, ipxint dim, const ipxint* Bbegin,
+                      const ipxint* Bend, const ipxint* Bi, const double* Bx,
+                      double pivottol, int strict_abs_pivottol,
+                      ipxk_lu_info* info);
+int ipxk_lu_get_factors(ipxk_context* ctx, ipxint* Lp, ipxint* Li, double* Lx,
+                        ipxint* Up, ipxint* Ui, double* Ux, ipxint* rowperm,
+                        ipxint* colperm, ipxint* dependent_cols);
+/* B = AI[:, basis[0..m-1]] taken from the matrix resident in the context (slack
+ * columns j >= n are unit columns): Basis::Factorize (src/basis.cc:116-156)
+ * without B crossing PCIe -- only the m basis indices do. */
+int ipxk_lu_factorize_basis(ipxk_context* ctx, const ipxint* basis,
+                            double pivottol, int strict_abs_pivottol,
+                            ipxk_lu_info* info);
+/* SplittedNormalMatrix::Prepare (src/splitted_normal_matrix.cc:18-66) on the
+ * factors of the last ipxk_lu_factorize_basis, which never leave the device:
+ * the GetLuFactors hand-off of src/basis.cc:162-166 without a host round trip.
+ * Fails (IPXK_E_ARGUMENT) when that factorization found dependent columns: the
+ * reference repairs the basis first (Basis::AdaptToSingularFactorization). */
+int ipxk_split_prepare_lu(ipxk_context* ctx, const ipxint* status,
+                          const double* colscale);
 /* _Apply (src/splitted_normal_matrix.cc:90-117) */
 int ipxk_split_apply(ipxk_context* ctx, const double* rhs, double* lhs,
                      double* rhs_dot_lhs);

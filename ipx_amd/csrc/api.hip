@@ -16,6 +16,7 @@ void set_last_error(const std::string& msg) { g_last_error = msg; }
 Context::~Context() {
     if (split) destroy_split(split);
     if (prepare_host) destroy_prepare_host(prepare_host);
+    if (lu) destroy_lu(lu);
     comm_destroy(this);
     if (h_state) (void)hipHostFree(h_state);
     if (h_cycle_done) (void)hipHostFree(h_cycle_done);
@@ -690,6 +691,41 @@ int ipxk_transpose(ipxint m, ipxint n, const ipxint* Ap, const ipxint* Ai, const
     return guarded([&] {
         IPXK_REQUIRE(Ap && ATp && (Ap[n] == 0 || (Ai && Ax && ATi && ATx)), "NULL argument");
         transpose_device(device, m, n, Ap, Ai, Ax, ATp, ATi, ATx);
+    });
+}
+
+int ipxk_lu_factorize(ipxk_context* c, ipxint dim, const ipxint* Bbegin, const ipxint* Bend, const ipxint* Bi,
+                      const double* Bx, double pivottol, int strict_abs_pivottol, ipxk_lu_info* info) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && dim >= 0 && (dim == 0 || (Bbegin && Bend)), "NULL argument");
+        bind_device(c);
+        lu_factorize_host(c, dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol != 0, info);
+    });
+}
+
+int ipxk_lu_factorize_basis(ipxk_context* c, const ipxint* basis, double pivottol, int strict_abs_pivottol,
+                            ipxk_lu_info* info) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && (basis || c->m == 0), "NULL argument");
+        bind_device(c);
+        lu_factorize_basis(c, basis, pivottol, strict_abs_pivottol != 0, info);
+    });
+}
+
+int ipxk_lu_get_factors(ipxk_context* c, ipxint* Lp, ipxint* Li, double* Lx, ipxint* Up, ipxint* Ui, double* Ux,
+                        ipxint* rowperm, ipxint* colperm, ipxint* dependent_cols) {
+    return guarded([&] {
+        IPXK_REQUIRE(c, "NULL argument");
+        bind_device(c);
+        lu_get_factors(c, Lp, Li, Lx, Up, Ui, Ux, rowperm, colperm, dependent_cols);
+    });
+}
+
+int ipxk_split_prepare_lu(ipxk_context* c, const ipxint* status, const double* colscale) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && status && colscale, "NULL argument");
+        bind_device(c);
+        split_prepare_lu(c, status, colscale);
     });
 }
 

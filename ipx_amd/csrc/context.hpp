@@ -24,6 +24,7 @@ enum PartialSlot {
 
 struct SplitOperator;   // trisolve.hip
 struct PrepareHost;     // trisolve.hip
+struct LuState;         // lu.hip
 
 struct Context {
     int device = 0;
@@ -95,6 +96,7 @@ struct Context {
     // ---- basis path ----
     SplitOperator* split = nullptr;
     PrepareHost* prepare_host = nullptr;   // host workspaces of split_prepare (trisolve.hip)
+    LuState* lu = nullptr;                 // factors of the last ipxk_lu_factorize* (lu.hip)
 
     // ---- multi-GPU ----
     ncclComm* comm = nullptr;
@@ -205,6 +207,14 @@ void check_sweep_abort(Context* c);
 void destroy_split(SplitOperator*);
 void destroy_prepare_host(PrepareHost*);
 
+// ---- lu.hip ----
+void lu_factorize_host(Context* c, int64_t dim, const ipxint* Bbegin, const ipxint* Bend, const ipxint* Bi,
+                       const double* Bx, double pivottol, bool strict, ipxk_lu_info* info);
+void lu_factorize_basis(Context* c, const ipxint* basis, double pivottol, bool strict, ipxk_lu_info* info);
+void lu_get_factors(Context* c, ipxint* Lp, ipxint* Li, double* Lx, ipxint* Up, ipxint* Ui, double* Ux,
+                    ipxint* rowperm, ipxint* colperm, ipxint* dependent);
+void split_prepare_lu(Context* c, const ipxint* status, const double* colscale);
+void destroy_lu(LuState*);
 // ---- presolve.hip (stand-alone, no context) ----
 void equilibrate_device(int device, int64_t m, int64_t n, const ipxint* Ap, const ipxint* Ai, double* Ax,
                         double* colscale, double* rowscale, ipxint* rounds);

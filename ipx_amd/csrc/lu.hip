@@ -1,0 +1,822 @@
+// Basis LU factorization on the device behind the reference's
+// LuFactorization contract, src/lu_factorization.h:21-58:
+//     B[rowperm,colperm] = (L+I)*U,  L strictly lower without its diagonal, U upper with the diagonal last in
+//     each column, indices sorted; dependent columns replaced by unit columns and listed.
+// It takes the place of the reference's kernel src/basiclu_kernel.cc:31-82 (BASICLU, third party); the call
+// sites are ForrestTomlin::_Factorize (src/forrest_tomlin.cc:28-30) and, through LuUpdate::Factorize,
+// Basis::Factorize (src/basis.cc:116-156).
+//
+// LP bases are nearly triangular, and that is what this code is built for:
+//   1. SINGLETON ROUNDS.  A column with one entry in the active rows is a pivot without arithmetic (its other
+//      entries are entries of U); so is a row with one entry in the active columns (the rest of the pivot column,
+//      divided by the pivot, is a column of L; nothing fills in).  All current column singletons, then all
+//      current row singletons, are taken per round -- they are independent of each other -- until neither
+//      exists.  Integer work over the CSC and a row-wise copy of B: one thread per column (row), conflicts (two
+//      singleton columns in one row, two singleton rows in one column) settled by atomic min / max, the pivot
+//      order inside a round fixed by a prefix sum over the indices, so the result does not depend on timing.
+//   2. THE BUMP that remains (for LP bases: tens to a few thousand rows) is factorized as a DENSE matrix with
+//      partial pivoting, right-looking, in panels of 32 columns: a one-workgroup panel kernel (pivot search,
+//      scaling, update inside the panel), a kernel that finishes the panel's rows of U, and a tiled update of
+//      the trailing matrix.  Every entry receives its updates one pivot at a time in pivot order, products
+//      rounded before they are subtracted: the arithmetic of the plain column-by-column elimination, bit for
+//      bit.  Rows are never swapped (a row carries the step at which it was pivoted).
+//   3. ASSEMBLY.  Every entry of B outside the bump and every nonzero of the factorized bump is keyed by
+//      (pivot stage of its column, pivot stage of its row); one radix sort per factor orders the columns and,
+//      inside them, the rows.
+// The rules (tolerances, tie breaks, order of the dependent columns) are restated on the CPU by the test
+// infrastructure, which the tests compare against entry by entry; the reference's own
+// LuFactorization::Factorize (stability estimate) and ForrestTomlin judge the factors there as well.
+// Limit: a bump of more than IPXK_LU_BUMP_MAX rows (default 4096) is refused (IPXK_E_UNSUPPORTED): a
+// sparse Markowitz elimination of a large bump is not built.
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <chrono>
+#include <climits>
+#include <cstdlib>
+
+#include "context.hpp"
+#include "trisolve.hpp"
+
+namespace ipxk {
+
+namespace {
+
+using u64 = unsigned long long;
+constexpr int kPanel = 32;           // columns per panel of the dense elimination
+constexpr int kPanelThreads = 1024;
+constexpr u64 kNoKey = ~0ull;
+
+int grid_for(int64_t n) { return (int)std::min<int64_t>(4096, std::max<int64_t>(1, (n + kBlock - 1) / kBlock)); }
+int bits_for(int64_t n) { int b = 1; while ((int64_t(1) << b) < n) b++; return b; }
+
+#define IPXK_GRID_STRIDE(i, n) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+struct Tmp {
+    DevBuf<unsigned char> bytes;
+    void* need(size_t n) { if (bytes.size() < n) bytes.resize(n); return bytes.get(); }
+};
+
+void scan_exclusive(Tmp& T, const int* in, int* out, size_t n, hipStream_t s) {
+    size_t bytes = 0;
+    IPXK_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, n, rocprim::plus<int>(), s));
+    IPXK_HIP(rocprim::exclusive_scan(T.need(bytes), bytes, in, out, 0, n, rocprim::plus<int>(), s));
+}
+
+// ---- row-wise copy ------------------------------------------------------------------------------
+__global__ void lu_expand_kernel(int dim, const int* __restrict__ Bp, const int* __restrict__ Bi, int* __restrict__ colof,
+                                 int* __restrict__ keys, int* __restrict__ pos, int* __restrict__ rc, int* __restrict__ cc,
+                                 int* bad) {
+    IPXK_GRID_STRIDE(j, dim) {
+        cc[j] = Bp[j + 1] - Bp[j];
+        for (int p = Bp[j]; p < Bp[j + 1]; p++) {
+            const int i = Bi[p];
+            if (i < 0 || i >= dim) { *bad = 1; continue; }
+            colof[p] = (int)j;
+            keys[p] = i;
+            pos[p] = p;
+            atomicAdd(rc + i, 1);
+        }
+    }
+}
+__global__ void lu_rows_kernel(int64_t nb, const int* __restrict__ pos_sorted, const int* __restrict__ colof, int* __restrict__ Rj) {
+    IPXK_GRID_STRIDE(q, nb) Rj[q] = colof[pos_sorted[q]];
+}
+__global__ void lu_fill_int_kernel(int64_t n, int v, int* a) { IPXK_GRID_STRIDE(i, n) a[i] = v; }
+__global__ void lu_fill_u64_kernel(int64_t n, u64 v, u64* a) { IPXK_GRID_STRIDE(i, n) a[i] = v; }
+
+// ---- singleton rounds ---------------------------------------------------------------------------
+struct Rounds {
+    int dim;
+    const int *Bp, *Bi;
+    const double* Bx;
+    const int *Rp, *Rj, *Rpos;
+    int *rstage, *cstage, *rc, *cc;
+    double* pivot;
+    unsigned char* ckind;
+    int *cand, *flag, *rank, *claim;
+    u64 *cand_bits, *claim_abs;
+    int* counters;        // [0] pivots so far, [1] column singletons, [2] row singletons, [3] found in this batch's last iteration
+    double abstol, pivottol;
+};
+
+__global__ void lu_col_find_kernel(Rounds R) {
+    IPXK_GRID_STRIDE(j, R.dim) {
+        int cr = -1;
+        if (R.cstage[j] < 0 && R.cc[j] == 1) {
+            for (int p = R.Bp[j]; p < R.Bp[j + 1]; p++) {
+                const int i = R.Bi[p];
+                if (R.rstage[i] >= 0) continue;
+                if (fabs(R.Bx[p]) >= R.abstol) { cr = i; atomicMin(R.claim + i, (int)j); }
+                break;
+            }
+        }
+        R.cand[j] = cr;
+    }
+}
+__global__ void lu_col_flag_kernel(Rounds R) {
+    IPXK_GRID_STRIDE(j, R.dim) R.flag[j] = (R.cand[j] >= 0 && R.claim[R.cand[j]] == (int)j) ? 1 : 0;
+}
+__global__ void lu_col_commit_kernel(Rounds R) {
+    const int base = R.counters[0];
+    IPXK_GRID_STRIDE(j, R.dim) {
+        if (!R.flag[j]) continue;
+        const int i = R.cand[j], k = base + R.rank[j];
+        for (int p = R.Bp[j]; p < R.Bp[j + 1]; p++)
+            if (R.Bi[p] == i) R.pivot[j] = R.Bx[p];
+        R.cstage[j] = k;
+        R.rstage[i] = k;
+        R.ckind[j] = 1;
+        R.claim[i] = INT_MAX;
+        // row i leaves the active submatrix: its other columns lose an active entry (none of them is a pivot of
+        // this round: such a column would have had two active entries)
+        for (int q = R.Rp[i]; q < R.Rp[i + 1]; q++) {
+            const int j2 = R.Rj[q];
+            if (j2 != (int)j && R.cstage[j2] < 0) atomicSub(R.cc + j2, 1);
+        }
+    }
+}
+// counters[0] += # pivots of the round; which: 1 column round, 2 row round; first: clears the found count
+__global__ void lu_advance_kernel(Rounds R, int which, int first) {
+    const int found = R.rank[R.dim - 1] + R.flag[R.dim - 1];
+    R.counters[0] += found;
+    R.counters[which] += found;
+    R.counters[3] = (first ? 0 : R.counters[3]) + found;
+}
+__global__ void lu_row_find_kernel(Rounds R) {
+    IPXK_GRID_STRIDE(i, R.dim) {
+        int cj = -1;
+        u64 bits = 0;
+        if (R.rstage[i] < 0 && R.rc[i] == 1) {
+            for (int q = R.Rp[i]; q < R.Rp[i + 1]; q++) {
+                const int j = R.Rj[q];
+                if (R.cstage[j] >= 0) continue;
+                const double a = fabs(R.Bx[R.Rpos[q]]);
+                double colmax = 0.0;
+                for (int p = R.Bp[j]; p < R.Bp[j + 1]; p++)
+                    if (R.rstage[R.Bi[p]] < 0) colmax = fmax(colmax, fabs(R.Bx[p]));
+                if (a >= R.abstol && a >= R.pivottol * colmax) {
+                    cj = j;
+                    bits = (u64)__double_as_longlong(a);
+                    atomicMax(R.claim_abs + j, bits);
+                }
+                break;
+            }
+        }
+        R.cand[i] = cj;
+        R.cand_bits[i] = bits;
+    }
+}
+__global__ void lu_row_pick_kernel(Rounds R) {
+    IPXK_GRID_STRIDE(i, R.dim) {
+        const int j = R.cand[i];
+        if (j >= 0 && R.cand_bits[i] == R.claim_abs[j]) atomicMin(R.claim + j, (int)i);
+    }
+}
+__global__ void lu_row_flag_kernel(Rounds R) {
+    IPXK_GRID_STRIDE(i, R.dim) R.flag[i] = (R.cand[i] >= 0 && R.claim[R.cand[i]] == (int)i) ? 1 : 0;
+}
+__global__ void lu_row_commit_kernel(Rounds R) {
+    const int base = R.counters[0];
+    IPXK_GRID_STRIDE(i, R.dim) {
+        if (!R.flag[i]) continue;
+        const int j = R.cand[i], k = base + R.rank[i];
+        R.rstage[i] = k;
+        R.cstage[j] = k;
+        R.ckind[j] = 2;
+        R.claim[j] = INT_MAX;
+        R.claim_abs[j] = 0;
+        // column j leaves: its other active rows lose an active entry (they become entries of L)
+        for (int p = R.Bp[j]; p < R.Bp[j + 1]; p++) {
+            const int r = R.Bi[p];
+            if (r == (int)i) R.pivot[j] = R.Bx[p];
+            else if (R.rstage[r] < 0) atomicSub(R.rc + r, 1);
+        }
+    }
+}
+
+// ---- bump ---------------------------------------------------------------------------------------
+__global__ void lu_active_flag_kernel(int dim, const int* __restrict__ stage, int* __restrict__ flag) {
+    IPXK_GRID_STRIDE(i, dim) flag[i] = stage[i] < 0 ? 1 : 0;
+}
+__global__ void lu_compact_kernel(int dim, const int* __restrict__ flag, const int* __restrict__ rank, int* __restrict__ loc,
+                                  int* __restrict__ list) {
+    IPXK_GRID_STRIDE(i, dim) {
+        loc[i] = flag[i] ? rank[i] : -1;
+        if (flag[i]) list[rank[i]] = (int)i;
+    }
+}
+__global__ void lu_dense_fill_kernel(int kb, const int* __restrict__ bcol, const int* __restrict__ Bp, const int* __restrict__ Bi,
+                                     const double* __restrict__ Bx, const int* __restrict__ rloc, double* __restrict__ D) {
+    IPXK_GRID_STRIDE(c, kb) {
+        const int j = bcol[c];
+        for (int p = Bp[j]; p < Bp[j + 1]; p++) {
+            const int r = rloc[Bi[p]];
+            if (r >= 0) D[(size_t)c * kb + r] = Bx[p];
+        }
+    }
+}
+
+struct Dense {
+    int kb;
+    double* D;             // column-major kb x kb
+    int *brstep, *bcstep;  // pivot step of a bump row / column, -1 while unpivoted / for a dependent column
+    int* bstep;            // [0] # pivots so far; [1] # pivots of the current panel
+    int *prow, *pcol;      // rows / columns of the current panel's pivots
+    double abstol;
+};
+
+// One panel of columns [c0, c1): partial pivoting (largest |entry| among the unpivoted rows, ties: smaller
+// row), scaling, update of the panel's later columns.  One workgroup; the panel lives in L2.
+__global__ __launch_bounds__(kPanelThreads) void lu_panel_kernel(Dense A, int c0, int c1) {
+    __shared__ double red_v[kPanelThreads / 64];
+    __shared__ int red_r[kPanelThreads / 64];
+    __shared__ double su[kPanel];
+    __shared__ int s_pr;
+    __shared__ double s_piv;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kb = A.kb;
+    int np = 0;
+    int step = A.bstep[0];
+    for (int c = c0; c < c1; c++) {
+        double* col = A.D + (size_t)c * kb;
+        double best = 0.0;
+        int br = INT_MAX;
+        for (int r = tid; r < kb; r += kPanelThreads)
+            if (A.brstep[r] < 0) {
+                const double a = fabs(col[r]);
+                if (a > best) { best = a; br = r; }
+            }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double ov = __shfl_xor(best, d, 64);
+            const int orr = __shfl_xor(br, d, 64);
+            if (ov > best || (ov == best && orr < br)) { best = ov; br = orr; }
+        }
+        if (lane == 0) { red_v[wave] = best; red_r[wave] = br; }
+        __syncthreads();
+        if (tid == 0) {
+            double bv = 0.0;
+            int r = INT_MAX;
+            for (int w = 0; w < kPanelThreads / 64; w++)
+                if (red_v[w] > bv || (red_v[w] == bv && red_r[w] < r)) { bv = red_v[w]; r = red_r[w]; }
+            if (r == INT_MAX || !(bv >= A.abstol) || bv == 0.0) {
+                s_pr = -1;
+                A.bcstep[c] = -1;
+            } else {
+                s_pr = r;
+                s_piv = col[r];
+                A.brstep[r] = step;
+                A.bcstep[c] = step;
+                A.prow[np] = r;
+                A.pcol[np] = c;
+            }
+        }
+        __syncthreads();
+        const int pr = s_pr;
+        if (pr < 0) continue;                 // dependent column (uniform over the workgroup)
+        const double piv = s_piv;
+        np++;
+        step++;
+        if (tid < c1 - c - 1) su[tid] = A.D[(size_t)(c + 1 + tid) * kb + pr];
+        __syncthreads();
+        for (int r = tid; r < kb; r += kPanelThreads) {
+            if (A.brstep[r] >= 0) continue;   // pivoted rows (this step's included) keep their values
+            const double l = col[r] / piv;
+            col[r] = l;
+            for (int c2 = c + 1; c2 < c1; c2++) {
+                const double u = su[c2 - c - 1];
+                if (u != 0.0) A.D[(size_t)c2 * kb + r] -= l * u;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { A.bstep[0] = step; A.bstep[1] = np; }
+}
+
+// The panel's rows of U in the trailing columns: row prow[t] of column c2 receives the updates of the panel's
+// earlier pivots, in pivot order.  One thread per trailing column.
+__global__ __launch_bounds__(kBlock) void lu_panel_rows_kernel(Dense A, int c1) {
+    __shared__ double l11[kPanel][kPanel];
+    __shared__ int prow[kPanel];
+    const int np = A.bstep[1], kb = A.kb;
+    for (int e = threadIdx.x; e < kPanel * kPanel; e += kBlock) {
+        const int t2 = e / kPanel, t = e % kPanel;
+        l11[t2][t] = (t < t2 && t2 < np) ? A.D[(size_t)A.pcol[t] * kb + A.prow[t2]] : 0.0;
+    }
+    if (threadIdx.x < kPanel) prow[threadIdx.x] = threadIdx.x < np ? A.prow[threadIdx.x] : 0;
+    __syncthreads();
+    if (np == 0) return;
+    IPXK_GRID_STRIDE(cc, kb - c1) {
+        double* col = A.D + (size_t)(c1 + cc) * kb;
+        double v[kPanel];
+#pragma unroll
+        for (int t = 0; t < kPanel; t++) v[t] = t < np ? col[prow[t]] : 0.0;
+#pragma unroll
+        for (int t = 0; t < kPanel; t++) {
+            const double u = v[t];
+            if (t < np && u != 0.0) {
+#pragma unroll
+                for (int t2 = t + 1; t2 < kPanel; t2++)
+                    if (t2 < np) v[t2] -= l11[t2][t] * u;
+            }
+        }
+#pragma unroll
+        for (int t = 1; t < kPanel; t++)
+            if (t < np) col[prow[t]] = v[t];
+    }
+}
+
+// Trailing update: D[r][c2] -= sum over the panel's pivots t (in order, one rounded product at a time) of
+// multiplier[r][t] * U[t][c2], for the rows not pivoted yet.  64 x 64 tile per workgroup, 4 x 4 per thread.
+__global__ __launch_bounds__(kBlock) void lu_trailing_kernel(Dense A, int c1) {
+    __shared__ double Ls[kPanel][64];
+    __shared__ double Us[kPanel][64];
+    __shared__ int live[64];
+    const int np = A.bstep[1], kb = A.kb;
+    if (np == 0) return;
+    const int r0 = blockIdx.x * 64, cb = c1 + blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < kPanel * 64; e += kBlock) {
+        const int t = e / 64, x = e % 64;
+        const int r = r0 + x, c2 = cb + x;
+        Ls[t][x] = (t < np && r < kb) ? A.D[(size_t)A.pcol[t] * kb + r] : 0.0;
+        Us[t][x] = (t < np && c2 < kb) ? A.D[(size_t)c2 * kb + A.prow[t]] : 0.0;
+    }
+    if (tid < 64) live[tid] = (r0 + tid < kb && A.brstep[r0 + tid] < 0) ? 1 : 0;
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int xc = ty + 16 * b, c2 = cb + xc;
+        if (c2 >= kb) continue;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const int xr = tx + 16 * a;
+            if (!live[xr]) continue;
+            double* d = A.D + (size_t)c2 * kb + r0 + xr;
+            double acc = *d;
+            for (int t = 0; t < np; t++) {
+                const double u = Us[t][xc];
+                if (u != 0.0) acc -= Ls[t][xr] * u;
+            }
+            *d = acc;
+        }
+    }
+}
+
+// stages of the bump's pivots; dependent columns and left-over rows are flagged for the ranking that follows
+__global__ void lu_bump_stage_kernel(int kb, int base, const int* __restrict__ step, const int* __restrict__ list,
+                                     int* __restrict__ stage, int* __restrict__ flag, unsigned char* kind) {
+    IPXK_GRID_STRIDE(x, kb) {
+        const int s = step[x];
+        flag[x] = s < 0 ? 1 : 0;
+        if (s >= 0) {
+            stage[list[x]] = base + s;
+            if (kind) kind[list[x]] = 3;
+        }
+    }
+}
+__global__ void lu_bump_rest_kernel(int kb, int base, const int* __restrict__ flag, const int* __restrict__ rank,
+                                    const int* __restrict__ list, int* __restrict__ stage, unsigned char* kind,
+                                    ipxint* dependent) {
+    IPXK_GRID_STRIDE(x, kb) {
+        if (!flag[x]) continue;
+        stage[list[x]] = base + rank[x];
+        if (kind) kind[list[x]] = 4;
+        if (dependent) dependent[rank[x]] = base + rank[x];
+    }
+}
+
+// ---- assembly -----------------------------------------------------------------------------------
+struct Assemble {
+    int dim, kb;
+    const int *Bp, *Bi, *colof;
+    const double* Bx;
+    const int *rstage, *cstage, *rloc, *cloc, *brow, *bcol, *bcstep;
+    const double *pivot, *D;
+    const unsigned char* ckind;
+    u64 *lkey, *ukey;
+    double *lval, *uval;
+};
+__global__ void lu_keys_sparse_kernel(Assemble A, int64_t nb) {
+    IPXK_GRID_STRIDE(p, nb) {
+        const int j = A.colof[p], i = A.Bi[p];
+        if (A.ckind[j] == 4) continue;                          // replaced by a unit column
+        if (A.cloc[j] >= 0 && A.rloc[i] >= 0) continue;         // bump x bump: from the dense result
+        const int k = A.cstage[j], s = A.rstage[i];
+        const u64 key = ((u64)(unsigned)k << 32) | (unsigned)s;
+        if (s <= k) { A.ukey[p] = key; A.uval[p] = A.Bx[p]; }
+        else { A.lkey[p] = key; A.lval[p] = A.Bx[p] / A.pivot[j]; }
+    }
+}
+__global__ void lu_keys_dense_kernel(Assemble A, int64_t nb) {
+    const int kb = A.kb;
+    IPXK_GRID_STRIDE(e, (int64_t)kb * kb) {
+        const int c = (int)(e / kb), r = (int)(e % kb);
+        if (A.bcstep[c] < 0) continue;
+        const int k = A.cstage[A.bcol[c]], s = A.rstage[A.brow[r]];
+        const double v = A.D[e];
+        const u64 key = ((u64)(unsigned)k << 32) | (unsigned)s;
+        if (s == k) { A.ukey[nb + e] = key; A.uval[nb + e] = v; }
+        else if (v != 0.0) {
+            if (s < k) { A.ukey[nb + e] = key; A.uval[nb + e] = v; }
+            else { A.lkey[nb + e] = key; A.lval[nb + e] = v; }
+        }
+    }
+}
+__global__ void lu_keys_unit_kernel(Assemble A, int64_t off) {
+    IPXK_GRID_STRIDE(j, A.dim) {
+        if (A.ckind[j] != 4) continue;
+        const int k = A.cstage[j];
+        A.ukey[off + j] = ((u64)(unsigned)k << 32) | (unsigned)k;
+        A.uval[off + j] = 1.0;
+    }
+}
+// column pointers of a factor from its sorted keys: ptr[k] = first key >= (k << 32), k = 0..dim
+__global__ void lu_colptr_kernel(int dim, int64_t n, const u64* __restrict__ keys, ipxint* __restrict__ ptr) {
+    IPXK_GRID_STRIDE(k, (int64_t)dim + 1) {
+        const u64 want = (u64)k << 32;
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        ptr[k] = lo;
+    }
+}
+__global__ void lu_rowidx_kernel(int64_t nz, const u64* __restrict__ keys, ipxint* __restrict__ idx) {
+    IPXK_GRID_STRIDE(q, nz) idx[q] = (ipxint)(keys[q] & 0xffffffffull);
+}
+__global__ void lu_perm_kernel(int dim, const int* __restrict__ stage, ipxint* __restrict__ perm, int* bad) {
+    IPXK_GRID_STRIDE(i, dim) {
+        const int k = stage[i];
+        if (k < 0 || k >= dim) *bad = 1; else perm[k] = i;
+    }
+}
+// compact CSC of B = AI[:, basis] from the structural matrix resident on the device (slack columns: unit)
+__global__ void lu_basis_count_kernel(int m, int n, const ipxint* __restrict__ basis, const int* __restrict__ Ap,
+                                      int* __restrict__ cnt, int* bad) {
+    IPXK_GRID_STRIDE(k, m) {
+        const ipxint j = basis[k];
+        if (j < 0 || j >= (ipxint)n + m) { *bad = 1; cnt[k] = 0; continue; }
+        cnt[k] = j < n ? Ap[j + 1] - Ap[j] : 1;
+    }
+}
+__global__ void lu_basis_fill_kernel(int m, int n, const ipxint* __restrict__ basis, const int* __restrict__ Ap,
+                                     const int* __restrict__ Ai, const double* __restrict__ Ax, const int* __restrict__ Bp,
+                                     int* __restrict__ Bi, double* __restrict__ Bx) {
+    IPXK_GRID_STRIDE(k, m) {
+        const ipxint j = basis[k];
+        int q = Bp[k];
+        if (j < n) {
+            for (int p = Ap[j]; p < Ap[j + 1]; p++, q++) { Bi[q] = Ai[p]; Bx[q] = Ax[p]; }
+        } else {
+            Bi[q] = (int)(j - n);
+            Bx[q] = 1.0;
+        }
+    }
+}
+
+void sort_keys(Tmp& T, u64* keys, u64* keys2, double* vals, double* vals2, size_t n, int end_bit, hipStream_t s) {
+    size_t bytes = 0;
+    IPXK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys, keys2, vals, vals2, n, 0u, (unsigned)end_bit, s));
+    IPXK_HIP(rocprim::radix_sort_pairs(T.need(bytes), bytes, keys, keys2, vals, vals2, n, 0u, (unsigned)end_bit, s));
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+struct LuState {
+    int dim = 0;
+    int64_t lnz = 0, unz = 0;
+    int ndep = 0;
+    bool valid = false, from_basis = false;
+    DevBuf<ipxint> Lp, Li, Up, Ui, rowperm, colperm, dependent, basis;
+    DevBuf<double> Lx, Ux;
+    // plain CSC of the structural matrix (32-bit), uploaded at the first ipxk_lu_factorize_basis
+    DevBuf<int> Ap, Ai;
+    DevBuf<double> Ax;
+    bool have_A = false;
+};
+
+void destroy_lu(LuState* S) { delete S; }
+
+static LuState* lu_state(Context* c) {
+    if (!c->lu) c->lu = new LuState;
+    return c->lu;
+}
+
+// B as compact 32-bit CSC on the device -> factors in S
+static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, const int* Bp, const int* Bi,
+                                const double* Bx, double pivottol, bool strict, ipxk_lu_info* info) {
+    hipStream_t s = c->stream;
+    S->valid = false;
+    S->dim = dim;
+    ipxk_lu_info I{};
+    const double abstol = strict ? 1e-3 : 1e-14;      // kLuDependencyTol (src/ipx_internal.h:26) / BASICLU's default
+    const double t0 = now_s();
+    Tmp T;
+    const size_t d1 = (size_t)std::max(dim, 1), nz1 = (size_t)std::max<int64_t>(nb, 1);
+    DevBuf<int> colof(nz1), keys(nz1), pos(nz1), keys2(nz1), Rpos(nz1), Rj(nz1), Rp(d1 + 1);
+    DevBuf<int> rstage(d1), cstage(d1), rc(d1), cc(d1), cand(d1), flag(d1), rank(d1), claim(d1), counters(8);
+    DevBuf<u64> cand_bits(d1), claim_abs(d1);
+    DevBuf<double> pivot(d1);
+    DevBuf<unsigned char> ckind(d1);
+    int* h = nullptr;                                   // pinned: counters read back per batch of rounds
+    IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&h), 8 * sizeof(int)));
+    struct Unpin { int* p; ~Unpin() { (void)hipHostFree(p); } } unpin{h};
+    IPXK_HIP(hipMemsetAsync(rc.get(), 0, d1 * sizeof(int), s));
+    IPXK_HIP(hipMemsetAsync(counters.get(), 0, 8 * sizeof(int), s));
+    IPXK_HIP(hipMemsetAsync(claim_abs.get(), 0, d1 * sizeof(u64), s));
+    IPXK_HIP(hipMemsetAsync(ckind.get(), 0, d1, s));
+    IPXK_HIP(hipMemsetAsync(pivot.get(), 0, d1 * sizeof(double), s));
+    const int g = grid_for(dim);
+    if (dim > 0) {
+        hipLaunchKernelGGL(lu_fill_int_kernel, dim3(g), dim3(kBlock), 0, s, (int64_t)dim, -1, rstage.get());
+        hipLaunchKernelGGL(lu_fill_int_kernel, dim3(g), dim3(kBlock), 0, s, (int64_t)dim, -1, cstage.get());
+        hipLaunchKernelGGL(lu_fill_int_kernel, dim3(g), dim3(kBlock), 0, s, (int64_t)dim, INT_MAX, claim.get());
+        hipLaunchKernelGGL(lu_expand_kernel, dim3(g), dim3(kBlock), 0, s, dim, Bp, Bi, colof.get(), keys.get(), pos.get(),
+                           rc.get(), cc.get(), counters.get() + 7);
+        if (nb > 0) {
+            size_t bytes = 0;
+            IPXK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys.get(), keys2.get(), pos.get(), Rpos.get(), (size_t)nb, 0u,
+                                               (unsigned)bits_for(std::max(dim, 2)), s));
+            IPXK_HIP(rocprim::radix_sort_pairs(T.need(bytes), bytes, keys.get(), keys2.get(), pos.get(), Rpos.get(), (size_t)nb,
+                                               0u, (unsigned)bits_for(std::max(dim, 2)), s));
+            hipLaunchKernelGGL(lu_rows_kernel, dim3(grid_for(nb)), dim3(kBlock), 0, s, nb, Rpos.get(), colof.get(), Rj.get());
+        }
+        scan_exclusive(T, rc.get(), Rp.get(), (size_t)dim, s);
+        const int nb32 = (int)nb;
+        IPXK_HIP(hipMemcpyAsync(Rp.get() + dim, &nb32, sizeof(int), hipMemcpyHostToDevice, s));
+        IPXK_HIP(hipStreamSynchronize(s));             // nb32 is a stack variable
+    }
+    // ---- 1. singleton rounds
+    Rounds R{dim, Bp, Bi, Bx, Rp.get(), Rj.get(), Rpos.get(), rstage.get(), cstage.get(), rc.get(), cc.get(), pivot.get(),
+             ckind.get(), cand.get(), flag.get(), rank.get(), claim.get(), cand_bits.get(), claim_abs.get(), counters.get(),
+             abstol, pivottol};
+    int rounds = 0;
+    const int batch = 4;
+    while (dim > 0) {
+        for (int b = 0; b < batch; b++) {
+            hipLaunchKernelGGL(lu_col_find_kernel, dim3(g), dim3(kBlock), 0, s, R);
+            hipLaunchKernelGGL(lu_col_flag_kernel, dim3(g), dim3(kBlock), 0, s, R);
+            scan_exclusive(T, flag.get(), rank.get(), (size_t)dim, s);
+            hipLaunchKernelGGL(lu_col_commit_kernel, dim3(g), dim3(kBlock), 0, s, R);
+            hipLaunchKernelGGL(lu_advance_kernel, dim3(1), dim3(1), 0, s, R, 1, 1);
+            hipLaunchKernelGGL(lu_row_find_kernel, dim3(g), dim3(kBlock), 0, s, R);
+            hipLaunchKernelGGL(lu_row_pick_kernel, dim3(g), dim3(kBlock), 0, s, R);
+            hipLaunchKernelGGL(lu_row_flag_kernel, dim3(g), dim3(kBlock), 0, s, R);
+            scan_exclusive(T, flag.get(), rank.get(), (size_t)dim, s);
+            hipLaunchKernelGGL(lu_row_commit_kernel, dim3(g), dim3(kBlock), 0, s, R);
+            hipLaunchKernelGGL(lu_advance_kernel, dim3(1), dim3(1), 0, s, R, 2, 0);
+        }
+        IPXK_HIP(hipMemcpyAsync(h, counters.get(), 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        if (h[7]) throw Error(IPXK_E_ARGUMENT, "row index of B out of range");
+        rounds += batch;
+        if (h[3] == 0 || h[0] == dim) break;            // the batch's last iteration found nothing
+    }
+    const int npiv_sing = dim > 0 ? h[0] : 0;
+    I.col_singletons = dim > 0 ? h[1] : 0;
+    I.row_singletons = dim > 0 ? h[2] : 0;
+    I.rounds = rounds;
+    const double t1 = now_s();
+    // ---- 2. bump
+    DevBuf<int> rloc(d1), cloc(d1), brow, bcol, brstep, bcstep, bstep(2), prow(kPanel), pcol(kPanel);
+    DevBuf<double> D;
+    int kb = 0;
+    if (dim > 0) {
+        hipLaunchKernelGGL(lu_active_flag_kernel, dim3(g), dim3(kBlock), 0, s, dim, rstage.get(), flag.get());
+        scan_exclusive(T, flag.get(), rank.get(), (size_t)dim, s);
+        kb = dim - npiv_sing;
+        brow.resize((size_t)std::max(kb, 1)); bcol.resize((size_t)std::max(kb, 1));
+        hipLaunchKernelGGL(lu_compact_kernel, dim3(g), dim3(kBlock), 0, s, dim, flag.get(), rank.get(), rloc.get(), brow.get());
+        hipLaunchKernelGGL(lu_active_flag_kernel, dim3(g), dim3(kBlock), 0, s, dim, cstage.get(), flag.get());
+        scan_exclusive(T, flag.get(), rank.get(), (size_t)dim, s);
+        hipLaunchKernelGGL(lu_compact_kernel, dim3(g), dim3(kBlock), 0, s, dim, flag.get(), rank.get(), cloc.get(), bcol.get());
+    }
+    I.bump = kb;
+    int kb_max = 4096;
+    if (const char* e = getenv("IPXK_LU_BUMP_MAX")) kb_max = std::max(0, atoi(e));
+    if (kb > kb_max) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "LU: after the singletons a bump of %d rows remains (limit %d, IPXK_LU_BUMP_MAX)", kb, kb_max);
+        throw Error(IPXK_E_UNSUPPORTED, msg);
+    }
+    int bpiv = 0;
+    brstep.resize((size_t)std::max(kb, 1)); bcstep.resize((size_t)std::max(kb, 1));
+    if (kb > 0) {
+        D.resize((size_t)kb * kb);
+        IPXK_HIP(hipMemsetAsync(D.get(), 0, (size_t)kb * kb * sizeof(double), s));
+        IPXK_HIP(hipMemsetAsync(bstep.get(), 0, 2 * sizeof(int), s));
+        const int gk = grid_for(kb);
+        hipLaunchKernelGGL(lu_fill_int_kernel, dim3(gk), dim3(kBlock), 0, s, (int64_t)kb, -1, brstep.get());
+        hipLaunchKernelGGL(lu_fill_int_kernel, dim3(gk), dim3(kBlock), 0, s, (int64_t)kb, -1, bcstep.get());
+        hipLaunchKernelGGL(lu_dense_fill_kernel, dim3(gk), dim3(kBlock), 0, s, kb, bcol.get(), Bp, Bi, Bx, rloc.get(), D.get());
+        Dense A{kb, D.get(), brstep.get(), bcstep.get(), bstep.get(), prow.get(), pcol.get(), abstol};
+        for (int c0 = 0; c0 < kb; c0 += kPanel) {
+            const int c1 = std::min(kb, c0 + kPanel);
+            hipLaunchKernelGGL(lu_panel_kernel, dim3(1), dim3(kPanelThreads), 0, s, A, c0, c1);
+            if (c1 < kb) {
+                hipLaunchKernelGGL(lu_panel_rows_kernel, dim3(grid_for(kb - c1)), dim3(kBlock), 0, s, A, c1);
+                hipLaunchKernelGGL(lu_trailing_kernel, dim3((kb + 63) / 64, (kb - c1 + 63) / 64), dim3(kBlock), 0, s, A, c1);
+            }
+        }
+        IPXK_HIP(hipMemcpyAsync(h, bstep.get(), 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        bpiv = h[0];
+    }
+    const int ndep = kb - bpiv;
+    I.num_dependent = ndep;
+    S->ndep = ndep;
+    S->dependent.ensure((size_t)std::max(ndep, 1));
+    if (kb > 0) {
+        const int gk = grid_for(kb);
+        // pivots of the bump, then the dependent columns paired with the left-over rows, both ascending
+        hipLaunchKernelGGL(lu_bump_stage_kernel, dim3(gk), dim3(kBlock), 0, s, kb, npiv_sing, bcstep.get(), bcol.get(),
+                           cstage.get(), flag.get(), ckind.get());
+        scan_exclusive(T, flag.get(), rank.get(), (size_t)kb, s);
+        hipLaunchKernelGGL(lu_bump_rest_kernel, dim3(gk), dim3(kBlock), 0, s, kb, npiv_sing + bpiv, flag.get(), rank.get(),
+                           bcol.get(), cstage.get(), ckind.get(), S->dependent.get());
+        hipLaunchKernelGGL(lu_bump_stage_kernel, dim3(gk), dim3(kBlock), 0, s, kb, npiv_sing, brstep.get(), brow.get(),
+                           rstage.get(), flag.get(), (unsigned char*)nullptr);
+        scan_exclusive(T, flag.get(), rank.get(), (size_t)kb, s);
+        hipLaunchKernelGGL(lu_bump_rest_kernel, dim3(gk), dim3(kBlock), 0, s, kb, npiv_sing + bpiv, flag.get(), rank.get(),
+                           brow.get(), rstage.get(), (unsigned char*)nullptr, (ipxint*)nullptr);
+    }
+    const double t2 = now_s();
+    // ---- 3. assembly
+    S->rowperm.ensure(d1); S->colperm.ensure(d1);
+    S->Lp.ensure(d1 + 1); S->Up.ensure(d1 + 1);
+    const int64_t kbsq = (int64_t)kb * kb;
+    const int64_t nl = nb + kbsq, nu = nb + kbsq + dim;
+    int64_t lnz = 0, unz = 0;
+    if (dim > 0) {
+        DevBuf<u64> lkey((size_t)std::max<int64_t>(nl, 1)), lkey2((size_t)std::max<int64_t>(nl, 1)), ukey((size_t)nu), ukey2((size_t)nu);
+        DevBuf<double> lval((size_t)std::max<int64_t>(nl, 1)), lval2((size_t)std::max<int64_t>(nl, 1)), uval((size_t)nu), uval2((size_t)nu);
+        if (nl > 0) hipLaunchKernelGGL(lu_fill_u64_kernel, dim3(grid_for(nl)), dim3(kBlock), 0, s, nl, kNoKey, lkey.get());
+        hipLaunchKernelGGL(lu_fill_u64_kernel, dim3(grid_for(nu)), dim3(kBlock), 0, s, nu, kNoKey, ukey.get());
+        Assemble A{dim, kb, Bp, Bi, colof.get(), Bx, rstage.get(), cstage.get(), rloc.get(), cloc.get(), brow.get(), bcol.get(),
+                   bcstep.get(), pivot.get(), D.get(), ckind.get(), lkey.get(), ukey.get(), lval.get(), uval.get()};
+        if (nb > 0) hipLaunchKernelGGL(lu_keys_sparse_kernel, dim3(grid_for(nb)), dim3(kBlock), 0, s, A, nb);
+        if (kb > 0) hipLaunchKernelGGL(lu_keys_dense_kernel, dim3(grid_for(kbsq)), dim3(kBlock), 0, s, A, nb);
+        hipLaunchKernelGGL(lu_keys_unit_kernel, dim3(g), dim3(kBlock), 0, s, A, nb + kbsq);
+        if (nl > 0) sort_keys(T, lkey.get(), lkey2.get(), lval.get(), lval2.get(), (size_t)nl, 64, s);
+        sort_keys(T, ukey.get(), ukey2.get(), uval.get(), uval2.get(), (size_t)nu, 64, s);
+        hipLaunchKernelGGL(lu_colptr_kernel, dim3(grid_for(dim + 1)), dim3(kBlock), 0, s, dim, nl, lkey2.get(), S->Lp.get());
+        hipLaunchKernelGGL(lu_colptr_kernel, dim3(grid_for(dim + 1)), dim3(kBlock), 0, s, dim, nu, ukey2.get(), S->Up.get());
+        ipxint ends[2] = {0, 0};
+        IPXK_HIP(hipMemcpyAsync(&ends[0], S->Lp.get() + dim, sizeof(ipxint), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipMemcpyAsync(&ends[1], S->Up.get() + dim, sizeof(ipxint), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        lnz = ends[0]; unz = ends[1];
+        S->Li.ensure((size_t)std::max<int64_t>(lnz, 1)); S->Lx.ensure((size_t)std::max<int64_t>(lnz, 1));
+        S->Ui.ensure((size_t)std::max<int64_t>(unz, 1)); S->Ux.ensure((size_t)std::max<int64_t>(unz, 1));
+        if (lnz > 0) {
+            hipLaunchKernelGGL(lu_rowidx_kernel, dim3(grid_for(lnz)), dim3(kBlock), 0, s, lnz, lkey2.get(), S->Li.get());
+            IPXK_HIP(hipMemcpyAsync(S->Lx.get(), lval2.get(), (size_t)lnz * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+        hipLaunchKernelGGL(lu_rowidx_kernel, dim3(grid_for(unz)), dim3(kBlock), 0, s, unz, ukey2.get(), S->Ui.get());
+        IPXK_HIP(hipMemcpyAsync(S->Ux.get(), uval2.get(), (size_t)unz * sizeof(double), hipMemcpyDeviceToDevice, s));
+        IPXK_HIP(hipMemsetAsync(counters.get() + 6, 0, sizeof(int), s));
+        hipLaunchKernelGGL(lu_perm_kernel, dim3(g), dim3(kBlock), 0, s, dim, rstage.get(), S->rowperm.get(), counters.get() + 6);
+        hipLaunchKernelGGL(lu_perm_kernel, dim3(g), dim3(kBlock), 0, s, dim, cstage.get(), S->colperm.get(), counters.get() + 6);
+        IPXK_HIP(hipMemcpyAsync(h, counters.get(), 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));               // the key buffers go out of scope
+        if (h[6]) throw Error(IPXK_E_HIP, "LU: a pivot stage is missing");
+    } else {
+        IPXK_HIP(hipMemsetAsync(S->Lp.get(), 0, sizeof(ipxint), s));
+        IPXK_HIP(hipMemsetAsync(S->Up.get(), 0, sizeof(ipxint), s));
+        IPXK_HIP(hipStreamSynchronize(s));
+    }
+    S->lnz = lnz; S->unz = unz;
+    I.lnz = lnz; I.unz = unz;
+    I.seconds_singletons = t1 - t0;
+    I.seconds_bump = t2 - t1;
+    I.seconds_assemble = now_s() - t2;
+    S->valid = true;
+    if (info) *info = I;
+    if (getenv("IPXK_VERBOSE"))
+        fprintf(stderr, "ipxk: LU dim %d nnz %lld: %lld column + %lld row singletons in %d rounds (%.2f ms), bump %d (%.2f ms, %d dependent), "
+                "assembly %.2f ms; nnz(L) %lld nnz(U) %lld\n", dim, (long long)nb, (long long)I.col_singletons, (long long)I.row_singletons,
+                rounds, I.seconds_singletons * 1e3, kb, I.seconds_bump * 1e3, ndep, I.seconds_assemble * 1e3, (long long)lnz, (long long)unz);
+}
+
+bool lu_view(const Context* c, LuView* out) {
+    const LuState* S = c->lu;
+    if (!S || !S->valid) return false;
+    out->dim = S->dim;
+    out->ndep = S->ndep;
+    out->from_basis = S->from_basis;
+    out->F = DeviceFactors{S->Lp.get(), S->Li.get(), S->Up.get(), S->Ui.get(), S->Lx.get(), S->Ux.get(), S->lnz, S->unz};
+    out->rowperm = S->rowperm.get();
+    out->colperm = S->colperm.get();
+    out->basis = S->basis.get();
+    return true;
+}
+
+void lu_factorize_host(Context* c, int64_t dim64, const ipxint* Bbegin, const ipxint* Bend, const ipxint* Bi,
+                       const double* Bx, double pivottol, bool strict, ipxk_lu_info* info) {
+    IPXK_REQUIRE(dim64 >= 0 && dim64 < (int64_t(1) << 30), "dimension out of range");
+    IPXK_REQUIRE(pivottol > 0.0 && pivottol <= 1.0, "pivottol must lie in (0,1]");
+    const int dim = (int)dim64;
+    hipStream_t s = c->stream;
+    LuState* S = lu_state(c);
+    S->from_basis = false;
+    // pack the columns (they are ranges of a larger array on the caller's side, src/basis.cc:122-128)
+    std::vector<int> bp((size_t)dim + 1, 0), bi;
+    std::vector<double> bx;
+    int64_t nb = 0;
+    for (int j = 0; j < dim; j++) {
+        IPXK_REQUIRE(Bend[j] >= Bbegin[j], "Bend < Bbegin");
+        nb += Bend[j] - Bbegin[j];
+    }
+    IPXK_REQUIRE(nb < (int64_t(1) << 31), "nnz(B) exceeds 32 bits");
+    bi.resize((size_t)nb); bx.resize((size_t)nb);
+    int64_t q = 0;
+    for (int j = 0; j < dim; j++) {
+        for (ipxint p = Bbegin[j]; p < Bend[j]; p++, q++) {
+            IPXK_REQUIRE(Bi[p] >= 0 && Bi[p] < dim, "row index of B out of range");
+            bi[(size_t)q] = (int)Bi[p];
+            bx[(size_t)q] = Bx[p];
+        }
+        bp[(size_t)j + 1] = (int)q;
+    }
+    DevBuf<int> dBp, dBi;
+    DevBuf<double> dBx;
+    dBp.upload(bp, s); dBi.upload(bi, s); dBx.upload(bx, s);
+    dBi.ensure(1); dBx.ensure(1);
+    IPXK_HIP(hipStreamSynchronize(s));
+    lu_factorize_device(c, S, dim, nb, dBp.get(), dBi.get(), dBx.get(), pivottol, strict, info);
+}
+
+void lu_factorize_basis(Context* c, const ipxint* basis, double pivottol, bool strict, ipxk_lu_info* info) {
+    IPXK_REQUIRE(pivottol > 0.0 && pivottol <= 1.0, "pivottol must lie in (0,1]");
+    IPXK_REQUIRE(c->nranks == 1, "the basis path does not shard: run it as independent replicas");
+    const int m = (int)c->m, n = (int)c->n;
+    hipStream_t s = c->stream;
+    LuState* S = lu_state(c);
+    if (!S->have_A) {
+        IPXK_REQUIRE(c->nnz < (int64_t(1) << 31), "nnz(A) exceeds 32 bits");
+        std::vector<int> ap((size_t)n + 1), ai((size_t)c->nnz);
+        for (int j = 0; j <= n; j++) ap[(size_t)j] = (int)c->h_Ap[(size_t)j];
+        for (int64_t p = 0; p < c->nnz; p++) ai[(size_t)p] = (int)c->h_Ai[(size_t)p];
+        S->Ap.upload(ap, s); S->Ai.upload(ai, s); S->Ax.upload(c->h_Ax, s);
+        S->Ai.ensure(1); S->Ax.ensure(1);
+        IPXK_HIP(hipStreamSynchronize(s));
+        S->have_A = true;
+    }
+    S->basis.upload(basis, (size_t)m, s);
+    S->basis.ensure(1);
+    const size_t m1 = (size_t)std::max(m, 1);
+    DevBuf<int> cnt(m1), dBp(m1 + 1), bad(1);
+    Tmp T;
+    IPXK_HIP(hipMemsetAsync(bad.get(), 0, sizeof(int), s));
+    int64_t nb = 0;
+    DevBuf<int> dBi;
+    DevBuf<double> dBx;
+    if (m > 0) {
+        hipLaunchKernelGGL(lu_basis_count_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, n, S->basis.get(), S->Ap.get(), cnt.get(), bad.get());
+        scan_exclusive(T, cnt.get(), dBp.get(), (size_t)m, s);
+        int last[2] = {0, 0}, hbad = 0;
+        IPXK_HIP(hipMemcpyAsync(&last[0], dBp.get() + m - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipMemcpyAsync(&last[1], cnt.get() + m - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipMemcpyAsync(&hbad, bad.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        if (hbad) throw Error(IPXK_E_ARGUMENT, "basis entry out of range");
+        nb = (int64_t)last[0] + last[1];
+        const int nb32 = (int)nb;
+        IPXK_HIP(hipMemcpyAsync(dBp.get() + m, &nb32, sizeof(int), hipMemcpyHostToDevice, s));
+        dBi.resize((size_t)std::max<int64_t>(nb, 1)); dBx.resize((size_t)std::max<int64_t>(nb, 1));
+        hipLaunchKernelGGL(lu_basis_fill_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, n, S->basis.get(), S->Ap.get(), S->Ai.get(),
+                           S->Ax.get(), dBp.get(), dBi.get(), dBx.get());
+        IPXK_HIP(hipStreamSynchronize(s));               // nb32
+    } else {
+        IPXK_HIP(hipMemsetAsync(dBp.get(), 0, sizeof(int), s));
+        dBi.resize(1); dBx.resize(1);
+    }
+    lu_factorize_device(c, S, m, nb, dBp.get(), dBi.get(), dBx.get(), pivottol, strict, info);
+    S->from_basis = true;
+}
+
+void lu_get_factors(Context* c, ipxint* Lp, ipxint* Li, double* Lx, ipxint* Up, ipxint* Ui, double* Ux,
+                    ipxint* rowperm, ipxint* colperm, ipxint* dependent) {
+    LuState* S = c->lu;
+    IPXK_REQUIRE(S && S->valid, "no LU factorization in this context");
+    hipStream_t s = c->stream;
+    const size_t dim = (size_t)S->dim;
+    if (Lp) S->Lp.download(Lp, dim + 1, s);
+    if (Li) S->Li.download(Li, (size_t)S->lnz, s);
+    if (Lx) S->Lx.download(Lx, (size_t)S->lnz, s);
+    if (Up) S->Up.download(Up, dim + 1, s);
+    if (Ui) S->Ui.download(Ui, (size_t)S->unz, s);
+    if (Ux) S->Ux.download(Ux, (size_t)S->unz, s);
+    if (rowperm) S->rowperm.download(rowperm, dim, s);
+    if (colperm) S->colperm.download(colperm, dim, s);
+    if (dependent) S->dependent.download(dependent, (size_t)S->ndep, s);
+    IPXK_HIP(hipStreamSynchronize(s));
+}
+
+}  // namespace ipxk

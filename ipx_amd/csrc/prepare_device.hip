@@ -154,19 +154,110 @@ __global__ void u_diag_kernel(int m, const ipxint* __restrict__ Up, const double
 }
 
 // ---- step 2: levels -----------------------------------------------------------------------
-__global__ void relax_levels_kernel(int dim, const int* __restrict__ rp, const int* __restrict__ ri,
-                                    int* level, int* changed) {
-    IPXK_GRID_STRIDE(i, dim) {
+// One pass of level[i] = max(level[dep] + 1) over the rows of at most kRelaxLong entries.  Two things let a
+// single launch settle many levels: the threads take the unknowns in PROCESSING order (descending sweeps from
+// the far end), so that the workgroups dispatched first hold the dependencies of those dispatched later; and
+// a workgroup repeats its pass while one of its own unknowns moved.
+constexpr int kRelaxInner = 64;
+constexpr int kRelaxLong = 64;
+constexpr int kRelaxLongThreads = 1024;
+__global__ __launch_bounds__(kBlock) void relax_levels_kernel(int dim, int ascending, const int* __restrict__ rp,
+                                                              const int* __restrict__ ri, int* level, int* changed) {
+    for (int64_t t0 = (int64_t)blockIdx.x * kBlock; t0 < dim; t0 += (int64_t)gridDim.x * kBlock) {
+        const int64_t t = t0 + threadIdx.x;
+        int i = t < dim ? (ascending ? (int)t : dim - 1 - (int)t) : -1;
+        if (i >= 0 && rp[i + 1] - rp[i] > kRelaxLong) i = -1;          // relax_long_rows_kernel's
+        int mine = i >= 0 ? level[i] : 0;
+        bool moved = false;
+        for (int inner = 0; inner < kRelaxInner; inner++) {
+            bool ch = false;
+            if (i >= 0) {
+                int lv = 0;
+                for (int p = rp[i]; p < rp[i + 1]; p++) {
+                    const int l = __hip_atomic_load(level + ri[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                    lv = l > lv ? l : lv;
+                }
+                if (lv > mine) {
+                    mine = lv;
+                    __hip_atomic_store(level + i, lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ch = true;
+                }
+            }
+            moved |= ch;
+            if (!__syncthreads_or(ch ? 1 : 0)) break;
+        }
+        if (moved) *changed = 1;
+    }
+}
+// The rows of more than kRelaxLong entries (the rows of an LU's dense bump: a chain as long as the bump), one
+// after the other in processing order by ONE workgroup whose threads share a row's entries: a chain among them
+// settles in a single launch instead of one launch per link.
+__global__ __launch_bounds__(kRelaxLongThreads) void relax_long_rows_kernel(int nlong, const int* __restrict__ rows,
+                                                                             const int* __restrict__ rp,
+                                                                             const int* __restrict__ ri, int* level,
+                                                                             int* changed) {
+    __shared__ int red[kRelaxLongThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bool moved = false;
+    for (int q = 0; q < nlong; q++) {
+        const int i = rows[q];
         int lv = 0;
-        for (int p = rp[i]; p < rp[i + 1]; p++) {
+        for (int p = rp[i] + tid; p < rp[i + 1]; p += kRelaxLongThreads) {
             const int l = __hip_atomic_load(level + ri[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
             lv = l > lv ? l : lv;
         }
-        if (lv > level[i]) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int o = __shfl_xor(lv, d, 64);
+            lv = o > lv ? o : lv;
+        }
+        if (lane == 0) red[wave] = lv;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < kRelaxLongThreads / 64; w++) lv = red[w] > lv ? red[w] : lv;
+            if (lv > level[i]) {
+                __hip_atomic_store(level + i, lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                moved = true;
+            }
+        }
+        __syncthreads();          // the next row may read this one's level; red is reused
+    }
+    if (tid == 0 && moved) *changed = 1;
+}
+// the same rows in parallel, one wavefront each: enough where they do not depend on each other
+__global__ __launch_bounds__(kBlock) void relax_long_rows_parallel_kernel(int nlong, const int* __restrict__ rows,
+                                                                           const int* __restrict__ rp,
+                                                                           const int* __restrict__ ri, int* level,
+                                                                           int* changed) {
+    const int lane = threadIdx.x & 63;
+    for (int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); q < nlong; q += gridDim.x * (kBlock / 64)) {
+        const int i = rows[q];
+        int lv = 0;
+        for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
+            const int l = __hip_atomic_load(level + ri[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            lv = l > lv ? l : lv;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int o = __shfl_xor(lv, d, 64);
+            lv = o > lv ? o : lv;
+        }
+        if (lane == 0 && lv > level[i]) {
             __hip_atomic_store(level + i, lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *changed = 1;
         }
     }
+}
+__global__ void relax_long_flag_kernel(int dim, int ascending, const int* __restrict__ rp, int* __restrict__ flag) {
+    IPXK_GRID_STRIDE(t, dim) {
+        const int i = ascending ? (int)t : dim - 1 - (int)t;
+        flag[t] = rp[i + 1] - rp[i] > kRelaxLong ? 1 : 0;
+    }
+}
+__global__ void relax_long_list_kernel(int dim, int ascending, const int* __restrict__ flag, const int* __restrict__ rank,
+                                       int* __restrict__ rows) {
+    IPXK_GRID_STRIDE(t, dim)
+        if (flag[t]) rows[rank[t]] = ascending ? (int)t : dim - 1 - (int)t;
 }
 
 // ---- step 3: order by (level, descending row length) -------------------------------------------------
@@ -301,7 +392,7 @@ int bits_for(int64_t n) {   // bits needed for values in [0, n)
 // Deep dependency graphs: the relaxation needs as many rounds as there are levels, each a pass over
 // all entries.  After kMaxRelaxLaunches launches the levels are computed by one sequential O(nnz) scan
 // on the host instead (the unknowns' processing order is a topological order) and uploaded.
-constexpr int kMaxRelaxLaunches = 200;   // a few milliseconds at 1M rows
+constexpr int kMaxRelaxLaunches = 1024;  // ~10 ms at 1M rows
 
 // levels, order, packed rows and launch plan of one sweep from its natural-order row list
 template <class HostLevels>
@@ -316,7 +407,28 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
     IPXK_HIP(hipMemsetAsync(W.level.get(), 0, sizeof(int) * std::max(dim, 1), s));
     DevBuf<int> changed(1);
     if (!W.h_flag) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&W.h_flag), sizeof(int)));
-    for (int launched = 0, batch = 8; dim > 0; batch = std::min(batch * 2, 64)) {
+    // long rows, in processing order
+    int nlong = 0;
+    DevBuf<int> long_rows;
+    if (dim > 0) {
+        W.keys.ensure((size_t)dim); W.vals.ensure((size_t)dim);
+        hipLaunchKernelGGL(relax_long_flag_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, ascending ? 1 : 0, W.rp.get(), W.keys.get());
+        exclusive_scan(W, W.keys.get(), W.vals.get(), (size_t)dim, s);
+        int last[2] = {0, 0};
+        IPXK_HIP(hipMemcpyAsync(&last[0], W.keys.get() + dim - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipMemcpyAsync(&last[1], W.vals.get() + dim - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        nlong = last[0] + last[1];
+        if (nlong > 0) {
+            long_rows.resize((size_t)nlong);
+            hipLaunchKernelGGL(relax_long_list_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, ascending ? 1 : 0, W.keys.get(),
+                               W.vals.get(), long_rows.get());
+        }
+    }
+    // a cycle = one pass over the short rows + (if any) one over the long ones, a wavefront each; every batch
+    // of cycles (twice as many each time, one host round trip per batch) starts with the sequential pass over
+    // the long rows, which settles a chain among them at once
+    for (int launched = 0, batch = nlong > 0 ? 4 : 8; dim > 0; batch = std::min(batch * 2, 64)) {
         if (launched >= kMaxRelaxLaunches) {
             std::vector<int> lv((size_t)dim, 0);
             host_levels(lv);
@@ -325,14 +437,23 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
         }
         IPXK_HIP(hipMemsetAsync(changed.get(), 0, sizeof(int), s));
         for (int r = 0; r < batch; r++) {
-            if (r == batch - 1) IPXK_HIP(hipMemsetAsync(changed.get(), 0, sizeof(int), s));   // only the last launch decides
-            hipLaunchKernelGGL(relax_levels_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, W.rp.get(),
+            if (r == batch - 1) IPXK_HIP(hipMemsetAsync(changed.get(), 0, sizeof(int), s));   // only the last cycle decides
+            hipLaunchKernelGGL(relax_levels_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, ascending ? 1 : 0, W.rp.get(),
                                W.ri.get(), W.level.get(), changed.get());
+            if (nlong > 0 && r == 0)
+                hipLaunchKernelGGL(relax_long_rows_kernel, dim3(1), dim3(kRelaxLongThreads), 0, s, nlong, long_rows.get(), W.rp.get(),
+                                   W.ri.get(), W.level.get(), changed.get());
+            else if (nlong > 0)
+                hipLaunchKernelGGL(relax_long_rows_parallel_kernel, dim3((nlong + 3) / 4), dim3(kBlock), 0, s, nlong, long_rows.get(),
+                                   W.rp.get(), W.ri.get(), W.level.get(), changed.get());
         }
         launched += batch;
         IPXK_HIP(hipMemcpyAsync(W.h_flag, changed.get(), sizeof(int), hipMemcpyDeviceToHost, s));
         IPXK_HIP(hipStreamSynchronize(s));
-        if (*W.h_flag == 0) break;
+        if (*W.h_flag == 0) {
+            if (getenv("IPXK_VERBOSE")) fprintf(stderr, "ipxk: levels settled within %d relaxation cycles (%d long rows)\n", launched, nlong);
+            break;
+        }
     }
     // 3. stable sort of the unknowns in processing order by (level, descending length)
     const size_t need = (size_t)std::max<int64_t>(std::max<int64_t>(dim, nz), 1);
@@ -511,25 +632,56 @@ void rescale_sweeps_device(Context* c, SplitOperator* S) {
     IPXK_HIP(hipGetLastError());
 }
 
+// host copies of the index arrays of L and U for the fall-back level computation of finish_sweep: the caller's
+// arrays, or -- factors that were computed on the device -- downloaded when (and only when) the fall-back runs
+struct HostIndices {
+    const ipxint *Lp = nullptr, *Li = nullptr, *Up = nullptr, *Ui = nullptr;
+    std::vector<ipxint> own[4];
+    void fetch(const DeviceFactors& F, int m, hipStream_t s) {
+        if (Lp) return;
+        own[0].resize((size_t)m + 1); own[1].resize((size_t)std::max<int64_t>(F.nzL, 1));
+        own[2].resize((size_t)m + 1); own[3].resize((size_t)std::max<int64_t>(F.nzU, 1));
+        IPXK_HIP(hipMemcpyAsync(own[0].data(), F.Lp, ((size_t)m + 1) * sizeof(ipxint), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipMemcpyAsync(own[1].data(), F.Li, (size_t)F.nzL * sizeof(ipxint), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipMemcpyAsync(own[2].data(), F.Up, ((size_t)m + 1) * sizeof(ipxint), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipMemcpyAsync(own[3].data(), F.Ui, (size_t)F.nzU * sizeof(ipxint), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        Lp = own[0].data(); Li = own[1].data(); Up = own[2].data(); Ui = own[3].data();
+    }
+};
+
 void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const ipxint* Li, const double* Lx,
                            const ipxint* Up, const ipxint* Ui, const double* Ux) {
     hipStream_t s = c->stream;
     const int m = S->m;
-    const int64_t nzL = Lp[m], nzU = Up[m], nzUo = nzU - m;
+    // factors as given
+    DevBuf<ipxint> dLp, dLi, dUp, dUi;
+    DevBuf<double> dLx, dUx;
+    const int64_t nzL = Lp[m], nzU = Up[m];
+    dLp.upload(Lp, (size_t)m + 1, s); dUp.upload(Up, (size_t)m + 1, s);
+    dLi.upload(Li, (size_t)nzL, s);   dLx.upload(Lx, (size_t)nzL, s);
+    dUi.upload(Ui, (size_t)nzU, s);   dUx.upload(Ux, (size_t)nzU, s);
+    const DeviceFactors F{dLp.get(), dLi.get(), dUp.get(), dUi.get(), dLx.get(), dUx.get(), nzL, nzU};
+    analyse_sweeps_resident(c, S, F, Lp, Li, Up, Ui);
+}
+
+void analyse_sweeps_resident(Context* c, SplitOperator* S, const DeviceFactors& F, const ipxint* hLp, const ipxint* hLi,
+                             const ipxint* hUp, const ipxint* hUi) {
+    hipStream_t s = c->stream;
+    const int m = S->m;
+    const int64_t nzL = F.nzL, nzU = F.nzU, nzUo = nzU - m;
     const bool verbose = getenv("IPXK_VERBOSE") != nullptr;
     auto now = [&] {
         if (verbose) (void)hipStreamSynchronize(s);
         return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     };
     const double t0 = now();
-    // factors as given
-    DevBuf<ipxint> dLp, dLi, dUp, dUi;
-    DevBuf<double> dLx, dUx;
-    dLp.upload(Lp, (size_t)m + 1, s); dUp.upload(Up, (size_t)m + 1, s);
-    dLi.upload(Li, (size_t)nzL, s);   dLx.upload(Lx, (size_t)nzL, s);
-    dUi.upload(Ui, (size_t)nzU, s);   dUx.upload(Ux, (size_t)nzU, s);
+    HostIndices H;
+    H.Lp = hLp; H.Li = hLi; H.Up = hUp; H.Ui = hUi;
+    struct { const ipxint* p; const ipxint* get() const { return p; } } dLp{F.Lp}, dLi{F.Li}, dUp{F.Up}, dUi{F.Ui};
+    struct { const double* p; const double* get() const { return p; } } dLx{F.Lx}, dUx{F.Ux};
     if (m > 0) {
-        // column pointers were checked on the host (monotone, totals); indices are checked here
+        // column pointers were checked by the producer (monotone, totals); indices are checked here
         DevBuf<int> bad(1);
         IPXK_HIP(hipMemsetAsync(bad.get(), 0, sizeof(int), s));
         hipLaunchKernelGGL(validate_factors_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, dLp.get(), dLi.get(),
@@ -556,6 +708,8 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
                            W.rp.get(), W.ri.get(), W.rx.get(), W.dgn.get());
     else IPXK_HIP(hipMemsetAsync(W.rp.get(), 0, sizeof(int), s));
     finish_sweep(c, W, S->Ut, ll, m, nzUo, true, false, 1, [&](std::vector<int>& lv) {
+        H.fetch(F, m, s);
+        const ipxint *Up = H.Up, *Ui = H.Ui;
         for (int k = 0; k < m; k++) {                       // unknown k gathers rows i < k of column k
             int l = 0;
             for (ipxint q = Up[k]; q < Up[k + 1] - 1; q++) l = std::max(l, lv[Ui[q]] + 1);
@@ -568,6 +722,8 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
                        dLp.get(), dLi.get(), dLx.get(), W.rp.get(), W.ri.get(), W.rx.get());
     hipLaunchKernelGGL(fill_double_kernel, dim3(g), dim3(kBlock), 0, s, (int64_t)m, 1.0, W.dgn.get());
     finish_sweep(c, W, S->Lt, ll, m, nzL, false, false, 0, [&](std::vector<int>& lv) {
+        H.fetch(F, m, s);
+        const ipxint *Lp = H.Lp, *Li = H.Li;
         for (int k = m - 1; k >= 0; k--) {                  // unknown k gathers rows i > k of column k
             int l = 0;
             for (ipxint q = Lp[k]; q < Lp[k + 1]; q++) l = std::max(l, lv[Li[q]] + 1);
@@ -587,6 +743,8 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
         hipLaunchKernelGGL(rows_from_perm_kernel, dim3(grid_for(nzL)), dim3(kBlock), 0, s, nzL, W.vals2.get(),
                            W.colof.get(), dLx.get(), W.ri.get(), W.rx.get());
     finish_sweep(c, W, S->Lf, ll, m, nzL, true, true, 0, [&](std::vector<int>& lv) {
+        H.fetch(F, m, s);
+        const ipxint *Lp = H.Lp, *Li = H.Li;
         for (int j = 0; j < m; j++)                         // column j is final when reached: push to rows i > j
             for (ipxint q = Lp[j]; q < Lp[j + 1]; q++) lv[Li[q]] = std::max(lv[Li[q]], lv[j] + 1);
     });
@@ -604,12 +762,14 @@ void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const
         hipLaunchKernelGGL(rows_from_perm_kernel, dim3(grid_for(nzUo)), dim3(kBlock), 0, s, nzUo, W.vals2.get(),
                            W.colof.get(), dUx.get(), W.ri.get(), W.rx.get());
     finish_sweep(c, W, S->Uf, ll, m, nzUo, false, true, 2, [&](std::vector<int>& lv) {
+        H.fetch(F, m, s);
+        const ipxint *Up = H.Up, *Ui = H.Ui;
         for (int j = m - 1; j >= 0; j--)                    // descending: push to rows i < j
             for (ipxint q = Up[j]; q < Up[j + 1] - 1; q++) lv[Ui[q]] = std::max(lv[Ui[q]], lv[j] + 1);
     });
     IPXK_HIP(hipStreamSynchronize(s));
     if (verbose)
-        fprintf(stderr, "ipxk: device analysis: upload of L, U %.1f ms (%.0f MB), four sweeps %.1f ms\n", (t1 - t0) * 1e3,
+        fprintf(stderr, "ipxk: device analysis: validation of L, U %.1f ms (%.0f MB), four sweeps %.1f ms\n", (t1 - t0) * 1e3,
                 ((double)(nzL + nzU) * 16 + (double)m * 24) / 1e6, (now() - t1) * 1e3);
     IPXK_HIP(hipGetLastError());
 }

@@ -600,6 +600,37 @@ static void upload_scaling(Context* c, SplitOperator* S, const ipxint* status, c
     rescale_sweeps_device(c, S);
 }
 
+// what follows the analysis of the factors and the upload of the permutations in a Prepare: scaling, work
+// vectors, the composed gather maps of the four sweeps
+static void finish_prepare(Context* c, SplitOperator* S, const ipxint* status, const double* colscale) {
+    const int m = S->m;
+    hipStream_t s = c->stream;
+    upload_scaling(c, S, status, colscale);
+    const size_t mm = (size_t)std::max(m, 1);
+    S->w0.resize(mm); S->w1.resize(mm); S->w2.resize(mm); S->w3.resize(mm); S->tI.resize(mm);
+    // where every sweep finds its right-hand side: U' in the input vector itself, L' in the result of U'
+    // (by position), L in the input vector THROUGH rowperm (the operator's N N' product is formed in the row
+    // order of A: the permutation into pivot order is folded into the gather), U in the result of L;
+    // and where the row order of A finds the result of the backward pair
+    {
+        auto compose = [&](int n, const int* order, const int* map, int* out) {
+            if (n > 0) hipLaunchKernelGGL(compose_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, s, n, order, map, out);
+        };
+        compose(S->Ut.npos, S->Ut.order.get(), nullptr, S->Ut.src.get());
+        compose(S->Lt.npos, S->Lt.order.get(), S->Ut.posof.get(), S->Lt.src.get());
+        compose(S->Lf.npos, S->Lf.order.get(), S->rowperm.get(), S->Lf.src.get());
+        compose(S->Uf.npos, S->Uf.order.get(), S->Lf.posof.get(), S->Uf.src.get());
+        S->perm_after_backward.ensure(mm);
+        compose(m, S->rowperm_inv.get(), S->Lt.posof.get(), S->perm_after_backward.get());
+    }
+    S->xcc_slots.resize(64);
+    IPXK_HIP(hipMemsetAsync(S->xcc_slots.get(), 0, 64 * sizeof(gu64), s));
+    S->abort_flag.resize(1);
+    IPXK_HIP(hipMemsetAsync(S->abort_flag.get(), 0, sizeof(int), s));
+    if (c->partials.size() == 0) c->partials.resize((size_t)kNumPartialSlots * kPartialStride);
+    IPXK_HIP(hipStreamSynchronize(s));
+}
+
 void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const double* Lx,
                         const ipxint* Up, const ipxint* Ui, const double* Ux, const ipxint* rowperm,
                         const ipxint* colperm, const ipxint* basis, const ipxint* status,
@@ -645,33 +676,49 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
         S->colperm.upload(cpm, s);
         S->basis.upload(bs, s);
     }
-    upload_scaling(c, S.get(), status, colscale);
-    const size_t mm = (size_t)std::max(m, 1);
-    S->w0.resize(mm); S->w1.resize(mm); S->w2.resize(mm); S->w3.resize(mm); S->tI.resize(mm);
-    // where every sweep finds its right-hand side: U' in the input vector itself, L' in the result of U'
-    // (by position), L in the input vector THROUGH rowperm (the operator's N N' product is formed in the row
-    // order of A: the permutation into pivot order is folded into the gather), U in the result of L;
-    // and where the row order of A finds the result of the backward pair
-    {
-        auto compose = [&](int n, const int* order, const int* map, int* out) {
-            if (n > 0) hipLaunchKernelGGL(compose_kernel, dim3(vec_grid(n)), dim3(kBlock), 0, s, n, order, map, out);
-        };
-        compose(S->Ut.npos, S->Ut.order.get(), nullptr, S->Ut.src.get());
-        compose(S->Lt.npos, S->Lt.order.get(), S->Ut.posof.get(), S->Lt.src.get());
-        compose(S->Lf.npos, S->Lf.order.get(), S->rowperm.get(), S->Lf.src.get());
-        compose(S->Uf.npos, S->Uf.order.get(), S->Lf.posof.get(), S->Uf.src.get());
-        S->perm_after_backward.ensure(mm);
-        compose(m, S->rowperm_inv.get(), S->Lt.posof.get(), S->perm_after_backward.get());
-    }
-    S->xcc_slots.resize(64);
-    IPXK_HIP(hipMemsetAsync(S->xcc_slots.get(), 0, 64 * sizeof(gu64), s));
-    S->abort_flag.resize(1);
-    IPXK_HIP(hipMemsetAsync(S->abort_flag.get(), 0, sizeof(int), s));
-    if (c->partials.size() == 0) c->partials.resize((size_t)kNumPartialSlots * kPartialStride);
-    IPXK_HIP(hipStreamSynchronize(s));
+    finish_prepare(c, S.get(), status, colscale);
     if (verbose)
         fprintf(stderr, "ipxk: split_prepare: analysis and packing %.1f ms, permutations/scaling %.1f ms\n",
                 (tp1 - tp0) * 1e3, (now() - tp1) * 1e3);
+    c->split = S.release();
+}
+
+// 64-bit permutations / basis list on the device -> the operator's 32-bit copies (+ InversePerm, utils.cc:73-80)
+__global__ void perms_from_lu_kernel(int m, const ipxint* __restrict__ rowperm, const ipxint* __restrict__ colperm,
+                                     const ipxint* __restrict__ basis, int* __restrict__ rpm, int* __restrict__ rpi,
+                                     int* __restrict__ cpm, int* __restrict__ bs) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x) {
+        const int r = (int)rowperm[k];
+        rpm[k] = r;
+        rpi[r] = k;
+        cpm[k] = (int)colperm[k];
+        bs[k] = (int)basis[k];
+    }
+}
+
+// Prepare from the factors of the last ipxk_lu_factorize_basis: Basis::GetLuFactors (basis.cc:162-166) +
+// SplittedNormalMatrix::Prepare (splitted_normal_matrix.cc:18-66) with L, U and the permutations never leaving the
+// device.
+void split_prepare_lu(Context* c, const ipxint* status, const double* colscale) {
+    LuView V;
+    IPXK_REQUIRE(lu_view(c, &V) && V.from_basis, "no LU factorization of a basis of this context's matrix (ipxk_lu_factorize_basis)");
+    IPXK_REQUIRE(V.ndep == 0, "the factorization replaced dependent columns: repair the basis and factorize again "
+                              "(Basis::AdaptToSingularFactorization, src/basis.cc)");
+    const int m = (int)c->m;
+    IPXK_REQUIRE(V.dim == m, "dimension mismatch");
+    IPXK_REQUIRE(c->nranks == 1, "the basis path does not shard: run it as independent replicas");
+    hipStream_t s = c->stream;
+    std::unique_ptr<SplitOperator> S(c->split ? c->split : new SplitOperator);
+    c->split = nullptr;
+    S->m = m;
+    if (const char* e = getenv("IPXK_TRISOLVE")) S->level_launches = std::string(e) == "levels";
+    analyse_sweeps_resident(c, S.get(), V.F, nullptr, nullptr, nullptr, nullptr);
+    const size_t mm = (size_t)std::max(m, 1);
+    S->rowperm.ensure(mm); S->rowperm_inv.ensure(mm); S->colperm.ensure(mm); S->basis.ensure(mm);
+    if (m > 0)
+        hipLaunchKernelGGL(perms_from_lu_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, m, V.rowperm, V.colperm, V.basis,
+                           S->rowperm.get(), S->rowperm_inv.get(), S->colperm.get(), S->basis.get());
+    finish_prepare(c, S.get(), status, colscale);
     c->split = S.release();
 }
 

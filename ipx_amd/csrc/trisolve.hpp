@@ -104,6 +104,23 @@ void plan_sweep(Sweep& S, bool level_launches);
 
 // Device-side analysis of the four sweeps (prepare_device.hip): uploads L and U as given, builds
 // the row lists, computes dependency levels, orders the unknowns and packs the rows on the GPU.
+// L and U in the reference's form (64-bit indices, column-wise, U's diagonal last) resident on the device
+struct DeviceFactors {
+    const ipxint *Lp, *Li, *Up, *Ui;
+    const double *Lx, *Ux;
+    int64_t nzL, nzU;
+};
+// hL*/hU*: host copies of the index arrays if the caller has them (else NULL: fetched only if the fall-back needs them)
+void analyse_sweeps_resident(Context* c, SplitOperator* S, const DeviceFactors& F, const ipxint* hLp, const ipxint* hLi,
+                             const ipxint* hUp, const ipxint* hUi);
+// the factors of the last LU factorization of this context (lu.hip); false if there is none
+struct LuView {
+    int dim = 0, ndep = 0;
+    bool from_basis = false;
+    DeviceFactors F{};
+    const ipxint *rowperm = nullptr, *colperm = nullptr, *basis = nullptr;
+};
+bool lu_view(const Context* c, LuView* out);
 void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const ipxint* Li, const double* Lx,
                            const ipxint* Up, const ipxint* Ui, const double* Ux);
 // (re)computes the column-scaled value sets of the U sweeps from S->uscale

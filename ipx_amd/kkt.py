@@ -32,7 +32,8 @@ EXPORTS = [
     "ipxk_backward_solve", "ipxk_solve_dense", "ipxk_split_levels", "ipxk_cr_solve",
     "ipxk_kkt_basis_solve", "ipxk_newton_solve", "ipxk_iterate_set", "ipxk_iterate_get", "ipxk_iterate_update",
     "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_ipm_step", "ipxk_iterate_objectives", "ipxk_ipm_driver", "ipxk_iterate_factorize_diag", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns",
-    "ipxk_time_normal_apply", "ipxk_equilibrate", "ipxk_transpose",
+    "ipxk_time_normal_apply", "ipxk_equilibrate", "ipxk_transpose", "ipxk_lu_factorize", "ipxk_lu_factorize_basis",
+    "ipxk_lu_get_factors", "ipxk_split_prepare_lu",
     "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
     "ipxk_dev_download",
 ]
@@ -48,6 +49,12 @@ class CrDiag(C.Structure):
     _fields_ = [("errflag", c_i64), ("iter", c_i64), ("maxiter", c_i64), ("resnorm", c_f64), ("tol", c_f64),
                 ("cdot", c_f64), ("infnorm_residual", c_f64), ("infnorm_sresidual", c_f64), ("rps_old", c_f64),
                 ("rps_new", c_f64)]
+
+
+class LuInfo(C.Structure):
+    _fields_ = [("lnz", c_i64), ("unz", c_i64), ("num_dependent", c_i64), ("col_singletons", c_i64),
+                ("row_singletons", c_i64), ("bump", c_i64), ("rounds", c_i64), ("seconds_singletons", c_f64),
+                ("seconds_bump", c_f64), ("seconds_assemble", c_f64)]
 
 
 class IpmParams(C.Structure):
@@ -457,6 +464,41 @@ class KktContext:
         self._check(self.lib.ipxk_split_prepare(
             self.h, _ip(args[0]), _ip(args[1]), _fp(args[2]), _ip(args[3]), _ip(args[4]),
             _fp(args[5]), _ip(args[6]), _ip(args[7]), _ip(args[8]), _ip(args[9]), _fp(args[10])))
+
+    # ---- LU factorization (LuFactorization contract, reference src/lu_factorization.h:21-58) ----
+    def _lu_result(self, dim, info, download):
+        out = {name: getattr(info, name) for name, _ in LuInfo._fields_}
+        if not download:
+            return out
+        Lp, Up = np.zeros(dim + 1, i64), np.zeros(dim + 1, i64)
+        Li, Lx = np.zeros(info.lnz, i64), np.zeros(info.lnz, f64)
+        Ui, Ux = np.zeros(info.unz, i64), np.zeros(info.unz, f64)
+        rowperm, colperm, dep = np.zeros(dim, i64), np.zeros(dim, i64), np.zeros(info.num_dependent, i64)
+        self._check(self.lib.ipxk_lu_get_factors(self.h, _ip(Lp), _ip(Li), _fp(Lx), _ip(Up), _ip(Ui), _fp(Ux),
+                                                 _ip(rowperm), _ip(colperm), _ip(dep)))
+        from .synth import CscMatrix
+        out.update(L=CscMatrix(dim, dim, Lp, Li, Lx), U=CscMatrix(dim, dim, Up, Ui, Ux), rowperm=rowperm,
+                   colperm=colperm, dependent=dep)
+        return out
+
+    def lu_factorize(self, dim, Bbegin, Bend, Bi, Bx, pivottol=0.1, strict=False, download=True):
+        Bbegin, Bend, Bi, Bx = _I(Bbegin), _I(Bend), _I(Bi), _F(Bx)
+        info = LuInfo()
+        self._check(self.lib.ipxk_lu_factorize(self.h, c_i64(dim), _ip(Bbegin), _ip(Bend), _ip(Bi), _fp(Bx),
+                                               c_f64(pivottol), C.c_int(1 if strict else 0), C.byref(info)))
+        return self._lu_result(dim, info, download)
+
+    def lu_factorize_basis(self, basis, pivottol=0.1, strict=False, download=True):
+        basis = _I(basis)
+        assert basis.size == self.m
+        info = LuInfo()
+        self._check(self.lib.ipxk_lu_factorize_basis(self.h, _ip(basis), c_f64(pivottol), C.c_int(1 if strict else 0),
+                                                     C.byref(info)))
+        return self._lu_result(self.m, info, download)
+
+    def split_prepare_lu(self, status, colscale):
+        status, colscale = _I(status), _F(colscale)
+        self._check(self.lib.ipxk_split_prepare_lu(self.h, _ip(status), _fp(colscale)))
 
     def split_rescale(self, status, colscale):
         status, colscale = _I(status), _F(colscale)

@@ -275,7 +275,9 @@ def lp_like_basis_matrix(dim, bump=64, frac_rowsing=0.2, frac_slack=0.5, offdiag
 
     # T: diagonal + entries above it in the non-slack columns
     add(np.arange(n1), np.arange(n1))
-    nonslack = np.nonzero(rng.random(n1) >= frac_slack)[0]
+    is_slack = rng.random(n1) < frac_slack
+    v[-1][is_slack] = 1.0                    # unit columns: slack columns of [A I]
+    nonslack = np.nonzero(~is_slack)[0]
     cols = np.repeat(nonslack, offdiag)
     span = cols if window is None else np.minimum(cols, window)
     ok = span > 0
@@ -315,5 +317,42 @@ def lp_like_basis_matrix(dim, bump=64, frac_rowsing=0.2, frac_slack=0.5, offdiag
     rowperm, colperm = rng.permutation(dim), rng.permutation(dim)
     Mc = M.tocoo()
     B = sp.coo_matrix((Mc.data, (rowperm[Mc.row], colperm[Mc.col])), shape=(dim, dim)).tocsc()
+    slack_cols = colperm[np.nonzero(is_slack)[0]]          # columns of B that are unit columns e_i ...
+    slack_rows = rowperm[np.nonzero(is_slack)[0]]          # ... and their rows i
     return dict(dim=dim, Bp=B.indptr.astype(i64), Bi=B.indices.astype(i64), Bx=B.data.astype(f64),
-                planted=dict(T=n1, bump=bump, R=n3))
+                planted=dict(T=n1, bump=bump, R=n3), slack_cols=slack_cols, slack_rows=slack_rows)
+
+
+def lp_like_basis(m, n, seed=12345, **kw):
+    """An LP [A I] (m x n structural columns) with a nearly triangular basis: lp_like_basis_matrix planted into it.
+    The unit columns of B are slack columns n+i, its other columns are structural columns of A (scattered),
+    the remaining structural columns are random (8 entries).  Returns dict(A, basis, status, G) with basis[k] the
+    variable in column k of B and status as Basis::BasicStatus (BASIC 0 / NONBASIC -1)."""
+    import scipy.sparse as sp
+    G = lp_like_basis_matrix(m, seed=seed, **kw)
+    rng = np.random.default_rng(seed + 11)
+    B = sp.csc_matrix((G["Bx"], G["Bi"], G["Bp"]), shape=(m, m))
+    is_slack = np.zeros(m, dtype=bool)
+    is_slack[G["slack_cols"]] = True
+    struct_cols = np.nonzero(~is_slack)[0]
+    nb = struct_cols.size
+    assert nb <= n
+    where = np.sort(rng.choice(n, nb, replace=False))       # positions of B's structural columns inside A
+    rest = synthetic_lp(m, n - nb, 8, seed + 1).to_scipy() if n > nb else None
+    cols = [None] * n
+    A = sp.lil_matrix((m, n))
+    Bs = B[:, struct_cols].tocsc()
+    other = np.setdiff1d(np.arange(n), where)
+    blocks = sp.hstack([Bs] + ([rest] if rest is not None else [])).tocsc()
+    order = np.empty(n, dtype=i64)
+    order[where] = np.arange(nb)
+    order[other] = nb + np.arange(n - nb)
+    Anew = blocks[:, order].tocsc()
+    Anew.sort_indices()
+    basis = np.empty(m, dtype=i64)
+    basis[struct_cols] = where
+    basis[G["slack_cols"]] = n + G["slack_rows"]
+    status = np.full(n + m, -1, dtype=i64)
+    status[basis] = 0
+    return dict(A=CscMatrix(m, n, Anew.indptr, Anew.indices, Anew.data), basis=basis, status=status, G=G)
+

@@ -492,11 +492,11 @@ def ref_available():
 class Ref:
     def __init__(self, path=REF_SO):
         self.lib = L = C.CDLL(path)
-        for name in ("ref_model_new", "ref_kktdiag_new", "ref_split_new"):
+        for name in ("ref_model_new", "ref_kktdiag_new", "ref_split_new", "ref_lu_new"):
             getattr(L, name).restype = C.c_void_p
         for name in ("ref_model_is_dense", "ref_diagprec_apply", "ref_pcr_solve",
                      "ref_kktdiag_factorize", "ref_kktdiag_solve", "ref_trisolve",
-                     "ref_split_cr_solve"):
+                     "ref_split_cr_solve", "ref_lu_update", "ref_lu_updates"):
             getattr(L, name).restype = c_i64
         L.ref_dot.restype = c_f64
         L.ref_infnorm.restype = c_f64
@@ -560,6 +560,55 @@ class Ref:
 
     def split(self, L, U, N, free_positions):
         return RefSplit(self, L, U, N, free_positions)
+
+    def lu(self, dim, Bbegin, Bend, Bi, Bx, F):
+        """The reference's LuFactorization::Factorize (stability estimate) + ForrestTomlin on the factors F =
+        dict(L, U, rowperm, colperm, dependent) computed by the code under test."""
+        return RefLu(self, dim, Bbegin, Bend, Bi, Bx, F)
+
+
+class RefLu:
+    def __init__(self, ref, dim, Bbegin, Bend, Bi, Bx, F):
+        self.lib, self.dim = ref.lib, dim
+        self.keep = [_I(Bbegin), _I(Bend), _I(Bi), _F(Bx)]
+        L, U = F["L"], F["U"]
+        dep = _I(F["dependent"])
+        self.h = C.c_void_p(self.lib.ref_lu_new(c_i64(dim), *[_ip(a) for a in self.keep[:3]], _fp(self.keep[3]),
+                                                _ip(L.p), _ip(L.i), _fp(L.x), _ip(U.p), _ip(U.i), _fp(U.x),
+                                                _ip(_I(F["rowperm"])), _ip(_I(F["colperm"])), c_i64(dep.size), _ip(dep)))
+        out = np.zeros(3, f64)
+        self.lib.ref_lu_info(self.h, _fp(out))
+        self.flag, self.stability, self.fill_factor = int(out[0]), float(out[1]), float(out[2])
+
+    def solve_dense(self, rhs, trans=False):
+        lhs = np.zeros(self.dim, f64)
+        self.lib.ref_lu_solve_dense(self.h, _fp(_F(rhs)), _fp(lhs), c_i64(1 if trans else 0))
+        return lhs
+
+    def ftran(self, bi, bx):
+        bi, bx = _I(bi), _F(bx)
+        lhs = np.zeros(self.dim, f64)
+        self.lib.ref_lu_ftran(self.h, c_i64(bi.size), _ip(bi), _fp(bx), _fp(lhs))
+        return lhs
+
+    def btran(self, p):
+        lhs = np.zeros(self.dim, f64)
+        self.lib.ref_lu_btran(self.h, c_i64(p), _fp(lhs))
+        return lhs
+
+    def update(self, pivot):
+        return int(self.lib.ref_lu_update(self.h, c_f64(pivot)))
+
+    def updates(self):
+        return int(self.lib.ref_lu_updates(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.ref_lu_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 class RefIterate:

@@ -26,8 +26,11 @@
 #include "conjugate_residuals.h"
 #include "control.h"
 #include "diagonal_precond.h"
+#include "forrest_tomlin.h"
+#include "indexed_vector.h"
 #include "iterate.h"
 #include "kkt_solver_diag.h"
+#include "lu_factorization.h"
 #include "model.h"
 #include "normal_matrix.h"
 #include "presolver.h"
@@ -480,5 +483,81 @@ void ref_iterate_termination(void* ith, double feasibility_tol, double optimalit
     out3[1] = it->optimal();
     out3[2] = it->term_crit_reached();
 }
+
+
+// ---- LU: the reference's LuFactorization / ForrestTomlin on factors computed elsewhere -----------------------
+// The reference's LU kernel is BASICLU (absent).  Its OWN code around that kernel builds here: the wrapper
+// LuFactorization::Factorize with the stability estimate (src/lu_factorization.cc:87-127) and ForrestTomlin,
+// the LuUpdate the reference uses with lu_kernel = 1 (src/basis.cc:24-29; dense SolveDense / FtranForUpdate /
+// BtranForUpdate / Update, src/forrest_tomlin.cc).  GivenFactors is an LuFactorization whose kernel hands back
+// factors computed by the code under test (the oracle's or the device's LU), so that the reference's own
+// objects judge them (stability) and run on them.
+class GivenFactors : public ipx::LuFactorization {
+public:
+    ipx::SparseMatrix L, U;
+    std::vector<Int> rowperm, colperm, dependent;
+private:
+    void _Factorize(Int, const Int*, const Int*, const Int*, const double*, double, bool,
+                    ipx::SparseMatrix* Lout, ipx::SparseMatrix* Uout, std::vector<Int>* rp,
+                    std::vector<Int>* cp, std::vector<Int>* dep) override {
+        *Lout = L; *Uout = U; *rp = rowperm; *cp = colperm; *dep = dependent;
+    }
+};
+
+struct RefLu {
+    ipx::Control control;
+    std::unique_ptr<ipx::ForrestTomlin> ft;
+    Int dim = 0, flag = 0;
+    GivenFactors* given = nullptr;      // owned by ft
+};
+
+void* ref_lu_new(Int dim, const Int* Bbegin, const Int* Bend, const Int* Bi, const double* Bx,
+                 const Int* Lp, const Int* Li, const double* Lx, const Int* Up, const Int* Ui, const double* Ux,
+                 const Int* rowperm, const Int* colperm, Int ndep, const Int* dependent) {
+    RefLu* R = new RefLu;
+    ipx::Parameters p;
+    p.display = 0;
+    R->control.parameters(p);
+    R->dim = dim;
+    GivenFactors* G = new GivenFactors;
+    G->L = ToCsc(dim, dim, Lp, Li, Lx);
+    G->U = ToCsc(dim, dim, Up, Ui, Ux);
+    G->rowperm.assign(rowperm, rowperm + dim);
+    G->colperm.assign(colperm, colperm + dim);
+    G->dependent.assign(dependent, dependent + ndep);
+    R->given = G;
+    std::unique_ptr<ipx::LuFactorization> lu(G);
+    R->ft.reset(new ipx::ForrestTomlin(R->control, dim, lu));
+    R->flag = R->ft->Factorize(Bbegin, Bend, Bi, Bx, false);
+    return R;
+}
+void ref_lu_free(void* h) { delete static_cast<RefLu*>(h); }
+// out[3] = return flag of LuUpdate::Factorize (bit 0 unstable, bit 1 singular), stability(), fill_factor()
+void ref_lu_info(void* h, double* out) {
+    RefLu* R = static_cast<RefLu*>(h);
+    out[0] = (double)R->flag;
+    out[1] = R->given->stability();
+    out[2] = R->ft->fill_factor();
+}
+void ref_lu_solve_dense(void* h, const double* rhs, double* lhs, Int trans) {
+    RefLu* R = static_cast<RefLu*>(h);
+    Vector r = ToVector(rhs, R->dim), l(R->dim);
+    R->ft->SolveDense(r, l, trans ? 'T' : 'N');
+    FromVector(l, lhs);
+}
+void ref_lu_ftran(void* h, Int nz, const Int* bi, const double* bx, double* lhs) {
+    RefLu* R = static_cast<RefLu*>(h);
+    ipx::IndexedVector v(R->dim);
+    R->ft->FtranForUpdate(nz, bi, bx, v);
+    for (Int i = 0; i < R->dim; i++) lhs[i] = v[i];
+}
+void ref_lu_btran(void* h, Int p, double* lhs) {
+    RefLu* R = static_cast<RefLu*>(h);
+    ipx::IndexedVector v(R->dim);
+    R->ft->BtranForUpdate(p, v);
+    for (Int i = 0; i < R->dim; i++) lhs[i] = v[i];
+}
+Int ref_lu_update(void* h, double pivot) { return static_cast<RefLu*>(h)->ft->Update(pivot); }
+Int ref_lu_updates(void* h) { return static_cast<RefLu*>(h)->ft->updates(); }
 
 }  // extern "C"

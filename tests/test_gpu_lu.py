@@ -1,0 +1,154 @@
+"""GPU: the device LU factorization (ipxk_lu_factorize*) through the C ABI
+  * against the CPU restatement: permutations, patterns and dependent columns bit-exact, values bit-exact
+    (the singleton part divides original entries by pivots; the dense bump applies its updates one pivot at a
+    time in the restatement's order);
+  * against the contract B[rowperm,colperm] = (L+I)U (src/lu_factorization.h:21-58);
+  * under the reference's own objects: LuFactorization::Factorize's stability estimate and ForrestTomlin
+    (oracle/_ref, where built);
+  * Prepare straight from the device-resident factors against Prepare from the downloaded ones."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from ipx_amd import synth
+from test_lu_oracle import CASES, check_contract
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kkt():
+    from ipx_amd import kkt as k
+    k.load_library()
+    assert k.load_library().ipxk_device_count() > 0, "no GPU visible"
+    return k
+
+
+@pytest.fixture(scope="module")
+def ctx(kkt):
+    c = kkt.KktContext(synth.synthetic_lp(8, 12, 2, 1))     # the stand-alone entry point only needs a device
+    yield c
+    c.close()
+
+
+def same_factors(F, Fo):
+    for key in ("rowperm", "colperm", "dependent"):
+        assert np.array_equal(F[key], Fo[key]), key
+    for key in ("L", "U"):
+        assert np.array_equal(F[key].p, Fo[key].p) and np.array_equal(F[key].i, Fo[key].i), key
+        assert np.array_equal(F[key].x, Fo[key].x), key
+
+
+BIG = [dict(dim=20000, bump=600, offdiag=3), dict(dim=5000, bump=97, window=4, frac_rowsing=0.4),
+       dict(dim=3000, bump=1100, bump_density=0.05), dict(dim=700, bump=64, num_dependent=3)]
+
+
+@pytest.mark.parametrize("kw", CASES + BIG, ids=[str(i) for i in range(len(CASES) + len(BIG))])
+def test_lu_vs_oracle_and_contract(ctx, oracle, kw):
+    G = synth.lp_like_basis_matrix(seed=3, **kw)
+    dim = G["dim"]
+    F = ctx.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
+    Fo = oracle.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
+    assert (F["col_singletons"], F["row_singletons"], F["bump"], F["num_dependent"]) == \
+        (Fo["info"]["col_singletons"], Fo["info"]["row_singletons"], Fo["info"]["bump"], Fo["info"]["dependent"])
+    assert F["bump"] == kw["bump"]
+    same_factors(F, Fo)
+    assert check_contract(G, F) < 1e-12
+
+
+@pytest.mark.parametrize("kw", [CASES[0], CASES[3], BIG[1]], ids=["plain", "singular", "big"])
+def test_lu_under_the_reference(ctx, ref, kw):
+    G = synth.lp_like_basis_matrix(seed=5, **kw)
+    dim = G["dim"]
+    F = ctx.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
+    R = ref.lu(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], F)
+    assert R.stability < 1e-12 and R.flag == (2 if F["num_dependent"] else 0)
+    if R.flag == 0:
+        B = sp.csc_matrix((G["Bx"].copy(), G["Bi"].copy(), G["Bp"].copy()), shape=(dim, dim))
+        x = np.random.default_rng(0).standard_normal(dim)
+        for trans in (False, True):
+            y = R.solve_dense(x, trans)
+            assert np.abs((B.T if trans else B) @ y - x).max() <= 1e-9 * (1 + np.abs(y).max())
+
+
+def test_lu_unsorted_strict_and_limits(ctx, oracle, kkt, monkeypatch):
+    G = synth.lp_like_basis_matrix(dim=400, bump=25, seed=9)
+    rng = np.random.default_rng(1)
+    Bp, Bi, Bx = G["Bp"], G["Bi"].copy(), G["Bx"].copy()
+    for j in range(400):
+        q = rng.permutation(Bp[j + 1] - Bp[j]) + Bp[j]
+        Bi[Bp[j]:Bp[j + 1]], Bx[Bp[j]:Bp[j + 1]] = Bi[q], Bx[q]
+    F = ctx.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx)
+    same_factors(F, oracle.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx))
+    jb = F["colperm"][400 - 3]
+    Bx2 = Bx.copy()
+    Bx2[Bp[jb]:Bp[jb + 1]] *= 1e-5
+    for strict in (False, True):
+        Fs = ctx.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx2, 0.1, strict)
+        same_factors(Fs, oracle.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx2, 0.1, strict))
+        assert (Fs["num_dependent"] >= 1) == strict
+    # columns given as ranges of a larger array (Basis::Factorize passes AI's arrays), in any order
+    order = rng.permutation(400)
+    begin = np.zeros(400, np.int64)
+    big_i, big_x, at = [], [], 0
+    for j in order:
+        begin[j] = at + 3
+        big_i += [0, 0, 0] + list(Bi[Bp[j]:Bp[j + 1]])
+        big_x += [9.0, 9.0, 9.0] + list(Bx[Bp[j]:Bp[j + 1]])
+        at = len(big_i)
+    end = begin + np.diff(Bp)
+    same_factors(ctx.lu_factorize(400, begin, end, np.array(big_i), np.array(big_x)), F)
+    # errors: bump over the limit, bad index, bad tolerance
+    monkeypatch.setenv("IPXK_LU_BUMP_MAX", "24")
+    with pytest.raises(kkt.KktError, match="bump of 25 rows"):
+        ctx.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx)
+    monkeypatch.delenv("IPXK_LU_BUMP_MAX")
+    bad = Bi.copy()
+    bad[7] = 400
+    with pytest.raises(kkt.KktError, match="out of range"):
+        ctx.lu_factorize(400, Bp[:-1], Bp[1:], bad, Bx)
+    with pytest.raises(kkt.KktError, match="pivottol"):
+        ctx.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx, 0.0)
+    # dimension 0 (src/basiclu_kernel.cc:39-46)
+    F0 = ctx.lu_factorize(0, np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0))
+    assert F0["lnz"] == F0["unz"] == 0 and F0["L"].p.tolist() == [0]
+
+
+@pytest.mark.parametrize("m,n,bump", [(300, 700, 20), (6000, 13000, 250)])
+def test_basis_factorize_and_prepare_on_device(kkt, oracle, m, n, bump):
+    """ipxk_lu_factorize_basis takes B = AI[:, basis] from the resident matrix; ipxk_split_prepare_lu builds the
+    split operator from the factors without a host round trip: same operator as ipxk_split_prepare on the
+    downloaded factors, bit for bit"""
+    P = synth.lp_like_basis(m, n, seed=4, bump=bump)
+    colscale = synth.synthetic_basis_state(P["status"], 1.0, 4)
+    ctx = kkt.KktContext(P["A"])
+    F = ctx.lu_factorize_basis(P["basis"], 0.1)
+    G = P["G"]
+    same_factors(F, oracle.lu_factorize(m, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1))
+    assert F["num_dependent"] == 0 and F["bump"] == bump
+    ctx.split_prepare_lu(P["status"], colscale)
+    rhs = np.random.default_rng(2).standard_normal(m)
+    lhs1, dot1 = ctx.split_apply(rhs)
+    f1, b1 = ctx.forward_solve(rhs), ctx.backward_solve(rhs)
+    ctx.split_prepare(F["L"], F["U"], F["rowperm"], F["colperm"], P["basis"], P["status"], colscale)
+    lhs2, dot2 = ctx.split_apply(rhs)
+    assert np.array_equal(lhs1, lhs2) and dot1 == dot2
+    assert np.array_equal(f1, ctx.forward_solve(rhs)) and np.array_equal(b1, ctx.backward_solve(rhs))
+    # and it is the inverse of B: SolveDense
+    AI = sp.hstack([P["A"].to_scipy(), sp.identity(m)]).tocsc()
+    B = AI[:, P["basis"]]
+    x = ctx.solve_dense(rhs, "n")
+    assert np.abs(B @ x - rhs).max() <= 1e-9 * (1 + np.abs(x).max())
+    # a singular basis is refused by Prepare
+    basis2 = P["basis"].copy()
+    dup = np.nonzero(basis2 < n)[0][:2]
+    basis2[dup[1]] = basis2[dup[0]]                       # the same column twice
+    ctx2 = kkt.KktContext(P["A"])
+    F2 = ctx2.lu_factorize_basis(basis2, 0.1, download=False)
+    assert F2["num_dependent"] >= 1
+    with pytest.raises(kkt.KktError, match="dependent columns"):
+        ctx2.split_prepare_lu(P["status"], colscale)
+    ctx3 = kkt.KktContext(P["A"])
+    with pytest.raises(kkt.KktError, match="ipxk_lu_factorize_basis"):
+        ctx3.split_prepare_lu(P["status"], colscale)
+    ctx.close(); ctx2.close(); ctx3.close()
