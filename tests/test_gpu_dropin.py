@@ -32,7 +32,7 @@ def test_host_classes_compile_against_reference_headers():
            "-I" + os.path.join(ref, "include"), "-I" + os.path.join(ref, "src")]
     subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "ipx_amd", "host"),
                            os.path.join(ROOT, "tests", "dropin", "handoff_main.cc")])      # the glue needs no reference header
-    for f in ("kkt_solver_diag_hip.cc", "kkt_solver_basis_hip.cc"):
+    for f in ("kkt_solver_diag_hip.cc", "kkt_solver_basis_hip.cc", "lu_kernel_hip.cc"):
         subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only"] + inc + [os.path.join(ROOT, "ipx_amd", "host", f)])
     subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++"] + inc + ["-"],
                    input='#include "linear_operators_hip.h"\n', text=True, check=True)
@@ -103,3 +103,38 @@ def test_example_ipm_loop():
     mu = [float(x[3]) for x in rows]
     assert all(b < a for a, b in zip(pres, pres[1:])) and all(b < a for a, b in zip(dres, dres[1:]))
     assert mu[-1] < 0.1 * mu[0] and pres[-1] < 0.02 * pres[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,bump,nrep", [(400, 30, 12), (30000, 500, 40)])
+def test_lu_kernel_hip_under_the_reference_forrest_tomlin(tmp_path, dim, bump, nrep):
+    """ipx::LuKernelHip as the LuFactorization of the reference's own ForrestTomlin (oracle/_ref/test_lu_dropin,
+    tests/dropin/lu_main.cc): factorize (flag 0, the reference's stability estimate < 1e-12), SolveDense both
+    ways, then column replacements through FtranForUpdate / BtranForUpdate / Update and solves with the updated
+    basis -- all arithmetic after the factorization is the reference's, on factors from the MI355X"""
+    import numpy as np
+    from ipx_amd import synth
+    exe = os.path.join(ROOT, "oracle", "_ref", "test_lu_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/test_lu_dropin not built (needs the reference sources at build time)")
+    G = synth.lp_like_basis_matrix(dim=dim, bump=bump, seed=21)
+    rng = np.random.default_rng(5)
+    d = str(tmp_path)
+    i64, f64 = np.int64, np.float64
+    np.array([dim, nrep], i64).tofile(os.path.join(d, "dims.bin"))
+    for k in ("Bp", "Bi"):
+        np.ascontiguousarray(G[k], i64).tofile(os.path.join(d, k + ".bin"))
+    np.ascontiguousarray(G["Bx"], f64).tofile(os.path.join(d, "Bx.bin"))
+    for k, pos in enumerate(rng.choice(dim, nrep, replace=False)):
+        # the entering column: the leaving one perturbed plus a few new entries (keeps the basis nonsingular)
+        ci, cx = G["Bi"][G["Bp"][pos]:G["Bp"][pos + 1]], G["Bx"][G["Bp"][pos]:G["Bp"][pos + 1]]
+        extra = np.setdiff1d(rng.choice(dim, 3, replace=False), ci)
+        ni = np.concatenate([ci, extra])
+        nx = np.concatenate([cx * rng.uniform(0.7, 1.4, cx.size), rng.uniform(-0.3, 0.3, extra.size)])
+        np.array([pos], i64).tofile(os.path.join(d, "pos_%d.bin" % k))
+        ni.astype(i64).tofile(os.path.join(d, "ci_%d.bin" % k))
+        nx.astype(f64).tofile(os.path.join(d, "cx_%d.bin" % k))
+    r = subprocess.run([exe, d], capture_output=True, text=True, timeout=600)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "DONE" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("PASS") == 5 and "bump %d " % bump in r.stdout
