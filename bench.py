@@ -52,6 +52,7 @@ def parse():
                     help="skip the resident Newton step / IPM iteration measurements (config.newton_step)")
     ap.add_argument("--no-column-partition", action="store_true",
                     help="N > 1: skip the extra measurement of the column partition (config.column_partition)")
+    ap.add_argument("--no-lu", action="store_true", help="skip the basis LU factorization on the device (config.lu_path)")
     ap.add_argument("--no-banded", action="store_true", help="skip the banded-matrix probe of the SpMV (extra field of roofline)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 2 and 5 (config.other_configs)")
     ap.add_argument("--no-direct-exchange", action="store_true",
@@ -340,6 +341,8 @@ def main():
         out["roofline"]["banded_matrix_probe"] = bench_banded(kkt, synth, m, n)
     if rank == 0 and world == 1 and not args.no_basis:
         out["config"]["basis_path"] = bench_basis(kkt, synth, m, n, args)
+    if rank == 0 and world == 1 and not args.no_lu:
+        out["config"]["lu_path"] = bench_lu(kkt, synth, m, n, args)
     if rank == 0 and world == 1 and not args.no_newton:
         out["config"]["newton_step"] = bench_newton(kkt, synth, ctx, m, n, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -624,6 +627,58 @@ def bench_basis(kkt, synth, m, n, args):
     ctx.set_pointer_mode(False)
     if not args.no_cpu_baseline:
         res.update(basis_cpu_baseline(ctx, B, AI, colscale, m, n, us_iter))
+    ctx.close()
+    return res
+
+
+def bench_lu(kkt, synth, m, n, args, bump=1000):
+    """SURVEY 8f rank 1: Basis::Factorize + GetLuFactors + SplittedNormalMatrix::Prepare (src/basis.cc:116-166,
+    src/splitted_normal_matrix.cc:18-66) on the device for a nearly triangular basis of the C3 model size (planted:
+    ~91 % column singletons, ~9 % row singletons, a bump of `bump` rows): ipxk_lu_factorize_basis takes B from the
+    resident matrix, ipxk_split_prepare_lu builds the operator from the resident factors.  CPU baseline: the
+    repo's restatement of the same method on one core ("port": the reference's LU kernel is BASICLU, absent)."""
+    P = synth.lp_like_basis(m, n, seed=12345, bump=bump, offdiag=3)
+    colscale = synth.synthetic_basis_state(P["status"], 1.0, 12345)
+    G = P["G"]
+    ctx = kkt.KktContext(P["A"])
+    ctx.lu_factorize_basis(P["basis"], 0.1, download=False)       # first call uploads the plain CSC copy of A
+    ctx.split_prepare_lu(P["status"], colscale)
+    K = 3
+    tf = tp = 0.0
+    for _ in range(K):
+        t0 = time.perf_counter()
+        F = ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+        t1 = time.perf_counter()
+        ctx.split_prepare_lu(P["status"], colscale)
+        tf += t1 - t0
+        tp += time.perf_counter() - t1
+    rhs = np.random.default_rng(1).standard_normal(m)
+    x = ctx.solve_dense(rhs, "n")
+    import scipy.sparse as sp
+    B = sp.csc_matrix((G["Bx"].copy(), G["Bi"].copy(), G["Bp"].copy()), shape=(m, m))
+    resid = float(np.abs(B @ x - rhs).max() / (1.0 + np.abs(x).max()))
+    nb = int(G["Bp"][-1])
+    res = {"workload": "nearly triangular basis of the %d x %d model (nnz(B) %d): planted column / row singletons and a dense-ish bump of %d rows"
+                       % (m, n, nb, bump),
+           "factorize_ms": tf / K * 1e3, "prepare_from_resident_factors_ms": tp / K * 1e3,
+           "phases_ms": {"singleton_rounds": F["seconds_singletons"] * 1e3, "dense_bump": F["seconds_bump"] * 1e3,
+                         "assembly": F["seconds_assemble"] * 1e3},
+           "col_singletons": F["col_singletons"], "row_singletons": F["row_singletons"], "bump": F["bump"], "rounds": F["rounds"],
+           "nnz_L": F["lnz"], "nnz_U": F["unz"], "fill_factor": (F["lnz"] + F["unz"]) / nb, "levels_Ut_Lt_L_U": ctx.split_levels(),
+           "parity": {"solve_dense_residual": resid}}
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle
+        Fd = ctx.lu_factorize_basis(P["basis"], 0.1, download=True)
+        t0 = time.perf_counter()
+        Fo = pyoracle.Oracle().lu_factorize(m, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
+        tc = time.perf_counter() - t0
+        same = all(np.array_equal(Fd[k], Fo[k]) for k in ("rowperm", "colperm", "dependent")) and \
+            all(np.array_equal(getattr(Fd[f], a), getattr(Fo[f], a)) for f in ("L", "U") for a in ("p", "i", "x"))
+        res["parity"]["factors_equal_cpu_restatement_bitwise"] = bool(same)
+        res["cpu_baseline"] = {"value": 1.0 / tc, "unit": "factorizations/s", "cores": 1, "kind": "port",
+                               "sample": "1 x the same factorization by the repo's CPU restatement of the method (%.2f s); the reference's "
+                                         "kernel for it, BASICLU, is not in the image" % tc}
+        res["gpu_over_cpu"] = tc / (tf / K)
     ctx.close()
     return res
 

@@ -87,6 +87,10 @@ __global__ void lu_fill_int_kernel(int64_t n, int v, int* a) { IPXK_GRID_STRIDE(
 __global__ void lu_fill_u64_kernel(int64_t n, u64 v, u64* a) { IPXK_GRID_STRIDE(i, n) a[i] = v; }
 
 // ---- singleton rounds ---------------------------------------------------------------------------
+// While the rounds run, rstage / cstage hold -1 for active rows / columns and the TAG of the round that pivoted
+// them otherwise (2 * iteration for a column round, + 1 for a row round); the dense pivot stages are assigned
+// afterwards by one sort of (tag, column index | row index): the order inside a round is by index whatever the
+// order in which the threads ran.
 struct Rounds {
     int dim;
     const int *Bp, *Bi;
@@ -95,9 +99,9 @@ struct Rounds {
     int *rstage, *cstage, *rc, *cc;
     double* pivot;
     unsigned char* ckind;
-    int *cand, *flag, *rank, *claim;
+    int *cand, *claim, *pivrow;
     u64 *cand_bits, *claim_abs;
-    int* counters;        // [0] pivots so far, [1] column singletons, [2] row singletons, [3] found in this batch's last iteration
+    int* counters;        // [8 + b]: iteration b of the batch found a pivot
     double abstol, pivottol;
 };
 
@@ -115,18 +119,16 @@ __global__ void lu_col_find_kernel(Rounds R) {
         R.cand[j] = cr;
     }
 }
-__global__ void lu_col_flag_kernel(Rounds R) {
-    IPXK_GRID_STRIDE(j, R.dim) R.flag[j] = (R.cand[j] >= 0 && R.claim[R.cand[j]] == (int)j) ? 1 : 0;
-}
-__global__ void lu_col_commit_kernel(Rounds R) {
-    const int base = R.counters[0];
+__global__ __launch_bounds__(kBlock) void lu_col_commit_kernel(Rounds R, int tag, int slot) {
     IPXK_GRID_STRIDE(j, R.dim) {
-        if (!R.flag[j]) continue;
-        const int i = R.cand[j], k = base + R.rank[j];
+        if (!(R.cand[j] >= 0 && R.claim[R.cand[j]] == (int)j)) continue;
+        R.counters[slot] = 1;                      // "this iteration found a pivot" (same value from every writer)
+        const int i = R.cand[j];
         for (int p = R.Bp[j]; p < R.Bp[j + 1]; p++)
             if (R.Bi[p] == i) R.pivot[j] = R.Bx[p];
-        R.cstage[j] = k;
-        R.rstage[i] = k;
+        R.cstage[j] = tag;
+        R.rstage[i] = tag;
+        R.pivrow[j] = i;
         R.ckind[j] = 1;
         R.claim[i] = INT_MAX;
         // row i leaves the active submatrix: its other columns lose an active entry (none of them is a pivot of
@@ -136,13 +138,6 @@ __global__ void lu_col_commit_kernel(Rounds R) {
             if (j2 != (int)j && R.cstage[j2] < 0) atomicSub(R.cc + j2, 1);
         }
     }
-}
-// counters[0] += # pivots of the round; which: 1 column round, 2 row round; first: clears the found count
-__global__ void lu_advance_kernel(Rounds R, int which, int first) {
-    const int found = R.rank[R.dim - 1] + R.flag[R.dim - 1];
-    R.counters[0] += found;
-    R.counters[which] += found;
-    R.counters[3] = (first ? 0 : R.counters[3]) + found;
 }
 __global__ void lu_row_find_kernel(Rounds R) {
     IPXK_GRID_STRIDE(i, R.dim) {
@@ -174,18 +169,16 @@ __global__ void lu_row_pick_kernel(Rounds R) {
         if (j >= 0 && R.cand_bits[i] == R.claim_abs[j]) atomicMin(R.claim + j, (int)i);
     }
 }
-__global__ void lu_row_flag_kernel(Rounds R) {
-    IPXK_GRID_STRIDE(i, R.dim) R.flag[i] = (R.cand[i] >= 0 && R.claim[R.cand[i]] == (int)i) ? 1 : 0;
-}
-__global__ void lu_row_commit_kernel(Rounds R) {
-    const int base = R.counters[0];
+__global__ __launch_bounds__(kBlock) void lu_row_commit_kernel(Rounds R, int tag, int slot) {
     IPXK_GRID_STRIDE(i, R.dim) {
-        if (!R.flag[i]) continue;
-        const int j = R.cand[i], k = base + R.rank[i];
-        R.rstage[i] = k;
-        R.cstage[j] = k;
+        if (!(R.cand[i] >= 0 && R.claim[R.cand[i]] == (int)i)) continue;
+        R.counters[slot] = 1;
+        const int j = R.cand[i];
+        R.rstage[i] = tag;
+        R.cstage[j] = tag;
+        R.pivrow[j] = (int)i;
         R.ckind[j] = 2;
-        R.claim[j] = INT_MAX;
+        R.claim[j] = INT_MAX;          // (a loser reads the winner's index or this: neither is its own)
         R.claim_abs[j] = 0;
         // column j leaves: its other active rows lose an active entry (they become entries of L)
         for (int p = R.Bp[j]; p < R.Bp[j + 1]; p++) {
@@ -193,6 +186,36 @@ __global__ void lu_row_commit_kernel(Rounds R) {
             if (r == (int)i) R.pivot[j] = R.Bx[p];
             else if (R.rstage[r] < 0) atomicSub(R.rc + r, 1);
         }
+    }
+}
+// # column / row singletons: block-wise sums of the kinds, one atomic per workgroup
+__global__ __launch_bounds__(kBlock) void lu_count_kinds_kernel(int dim, const unsigned char* __restrict__ ckind, int* counters) {
+    __shared__ int s1, s2;
+    if (threadIdx.x == 0) { s1 = 0; s2 = 0; }
+    __syncthreads();
+    int n1 = 0, n2 = 0;
+    IPXK_GRID_STRIDE(j, dim) { n1 += ckind[j] == 1; n2 += ckind[j] == 2; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { n1 += __shfl_xor(n1, d, 64); n2 += __shfl_xor(n2, d, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s1, n1); atomicAdd(&s2, n2); }
+    __syncthreads();
+    if (threadIdx.x == 0) { if (s1) atomicAdd(counters + 1, s1); if (s2) atomicAdd(counters + 2, s2); }
+}
+// tags -> sort keys; after the sort: dense stages
+__global__ void lu_stage_keys_kernel(int dim, const int* __restrict__ cstage, const int* __restrict__ pivrow,
+                                     u64* __restrict__ keys, int* __restrict__ vals) {
+    IPXK_GRID_STRIDE(j, dim) {
+        const int tag = cstage[j];
+        keys[j] = tag < 0 ? kNoKey : ((u64)(unsigned)tag << 32) | (unsigned)((tag & 1) ? pivrow[j] : (int)j);
+        vals[j] = (int)j;
+    }
+}
+__global__ void lu_stage_assign_kernel(int npiv, const int* __restrict__ order, const int* __restrict__ pivrow,
+                                       int* __restrict__ cstage, int* __restrict__ rstage) {
+    IPXK_GRID_STRIDE(q, npiv) {
+        const int j = order[q];
+        cstage[j] = (int)q;
+        rstage[pivrow[j]] = (int)q;
     }
 }
 
@@ -292,6 +315,90 @@ __global__ __launch_bounds__(kPanelThreads) void lu_panel_kernel(Dense A, int c0
         __syncthreads();
     }
     if (tid == 0) { A.bstep[0] = step; A.bstep[1] = np; }
+}
+
+// The same for bumps of at most kPanelThreads rows: a thread owns one row of the panel in registers, the pivot
+// row travels through LDS; the panel is read and written once.  Same arithmetic, same order.  (The column steps
+// are instantiated one by one: v[] must be indexed by constants to stay in registers.)
+struct PanelShared {
+    double red_v[kPanelThreads / 64];
+    int red_r[kPanelThreads / 64];
+    double su[kPanel];
+    int s_pr;
+};
+template <int T>
+__device__ __forceinline__ void panel_small_steps(const Dense& A, PanelShared& sh, double (&v)[kPanel], int c0, int c1, int r,
+                                                  bool& active, int& np, int& step) {
+    if constexpr (T < kPanel) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const bool col = c0 + T < c1;                  // uniform
+        double best = (col && active) ? fabs(v[T]) : 0.0;
+        int br = best > 0.0 ? r : INT_MAX;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double ov = __shfl_xor(best, d, 64);
+            const int orr = __shfl_xor(br, d, 64);
+            if (ov > best || (ov == best && orr < br)) { best = ov; br = orr; }
+        }
+        if (lane == 0) { sh.red_v[wave] = best; sh.red_r[wave] = br; }
+        __syncthreads();
+        if (tid == 0) {
+            double bv = 0.0;
+            int rr = INT_MAX;
+            for (int w = 0; w < kPanelThreads / 64; w++)
+                if (sh.red_v[w] > bv || (sh.red_v[w] == bv && sh.red_r[w] < rr)) { bv = sh.red_v[w]; rr = sh.red_r[w]; }
+            if (!col) {
+                sh.s_pr = -1;
+            } else if (rr == INT_MAX || !(bv >= A.abstol) || bv == 0.0) {
+                sh.s_pr = -1;
+                A.bcstep[c0 + T] = -1;
+            } else {
+                sh.s_pr = rr;
+                A.brstep[rr] = step;
+                A.bcstep[c0 + T] = step;
+                A.prow[np] = rr;
+                A.pcol[np] = c0 + T;
+            }
+        }
+        __syncthreads();
+        const int pr = sh.s_pr;                        // uniform over the workgroup
+        if (pr >= 0) { np++; step++; }
+        if (pr >= 0 && r == pr) {
+            active = false;
+#pragma unroll
+            for (int t2 = 0; t2 < kPanel; t2++) sh.su[t2] = v[t2];
+        }
+        __syncthreads();
+        if (pr >= 0 && active) {
+            const double l = v[T] / sh.su[T];
+            v[T] = l;
+#pragma unroll
+            for (int t2 = T + 1; t2 < kPanel; t2++) {
+                const double u = sh.su[t2];
+                if (c0 + t2 < c1 && u != 0.0) v[t2] -= l * u;
+            }
+        }
+        __syncthreads();                               // su and red_* are reused by the next column
+        panel_small_steps<T + 1>(A, sh, v, c0, c1, r, active, np, step);
+    }
+}
+__global__ __launch_bounds__(kPanelThreads) void lu_panel_small_kernel(Dense A, int c0, int c1) {
+    __shared__ PanelShared sh;
+    const int kb = A.kb, r = threadIdx.x;
+    const bool have = r < kb;
+    bool active = have && A.brstep[r] < 0;
+    double v[kPanel];
+#pragma unroll
+    for (int t = 0; t < kPanel; t++) v[t] = (have && c0 + t < c1) ? A.D[(size_t)(c0 + t) * kb + r] : 0.0;
+    int np = 0;
+    int step = A.bstep[0];
+    panel_small_steps<0>(A, sh, v, c0, c1, r, active, np, step);
+    if (have) {
+#pragma unroll
+        for (int t = 0; t < kPanel; t++)
+            if (c0 + t < c1) A.D[(size_t)(c0 + t) * kb + r] = v[t];
+    }
+    if (threadIdx.x == 0) { A.bstep[0] = step; A.bstep[1] = np; }
 }
 
 // The panel's rows of U in the trailing columns: row prow[t] of column c2 receives the updates of the panel's
@@ -488,7 +595,22 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 }  // namespace
 
+// workspaces of a factorization, kept from one call to the next (grow-only)
+struct LuWork {
+    DevBuf<int> colof, keys, pos, keys2, Rpos, Rj, Rp, rstage, cstage, rc, cc, cand, flag, rank, claim, pivrow, counters;
+    DevBuf<int> rloc, cloc, brow, bcol, brstep, bcstep, bstep, prow, pcol;
+    DevBuf<u64> cand_bits, claim_abs, skey, skey2, lkey, lkey2, ukey, ukey2;
+    DevBuf<double> pivot, D, lval, lval2, uval, uval2;
+    DevBuf<unsigned char> ckind;
+    DevBuf<int> Bp, Bi, cnt;          // B = AI[:, basis] (ipxk_lu_factorize_basis)
+    DevBuf<double> Bx;
+    Tmp T;
+    int* h = nullptr;                 // pinned: counters read back per batch of rounds
+    ~LuWork() { if (h) (void)hipHostFree(h); }
+};
+
 struct LuState {
+    LuWork work;
     int dim = 0;
     int64_t lnz = 0, unz = 0;
     int ndep = 0;
@@ -517,18 +639,23 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
     ipxk_lu_info I{};
     const double abstol = strict ? 1e-3 : 1e-14;      // kLuDependencyTol (src/ipx_internal.h:26) / BASICLU's default
     const double t0 = now_s();
-    Tmp T;
+    LuWork& W = S->work;
+    Tmp& T = W.T;
     const size_t d1 = (size_t)std::max(dim, 1), nz1 = (size_t)std::max<int64_t>(nb, 1);
-    DevBuf<int> colof(nz1), keys(nz1), pos(nz1), keys2(nz1), Rpos(nz1), Rj(nz1), Rp(d1 + 1);
-    DevBuf<int> rstage(d1), cstage(d1), rc(d1), cc(d1), cand(d1), flag(d1), rank(d1), claim(d1), counters(8);
-    DevBuf<u64> cand_bits(d1), claim_abs(d1);
-    DevBuf<double> pivot(d1);
-    DevBuf<unsigned char> ckind(d1);
-    int* h = nullptr;                                   // pinned: counters read back per batch of rounds
-    IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&h), 8 * sizeof(int)));
-    struct Unpin { int* p; ~Unpin() { (void)hipHostFree(p); } } unpin{h};
+    DevBuf<int> &colof = W.colof, &keys = W.keys, &pos = W.pos, &keys2 = W.keys2, &Rpos = W.Rpos, &Rj = W.Rj, &Rp = W.Rp;
+    DevBuf<int> &rstage = W.rstage, &cstage = W.cstage, &rc = W.rc, &cc = W.cc, &cand = W.cand, &flag = W.flag, &rank = W.rank,
+                &claim = W.claim, &pivrow = W.pivrow, &counters = W.counters;
+    DevBuf<u64> &cand_bits = W.cand_bits, &claim_abs = W.claim_abs;
+    DevBuf<double>& pivot = W.pivot;
+    DevBuf<unsigned char>& ckind = W.ckind;
+    for (DevBuf<int>* b : {&colof, &keys, &pos, &keys2, &Rpos, &Rj}) b->ensure(nz1);
+    for (DevBuf<int>* b : {&rstage, &cstage, &rc, &cc, &cand, &flag, &rank, &claim, &pivrow}) b->ensure(d1);
+    Rp.ensure(d1 + 1); counters.ensure(32);
+    cand_bits.ensure(d1); claim_abs.ensure(d1); pivot.ensure(d1); ckind.ensure(d1);
+    if (!W.h) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&W.h), 32 * sizeof(int)));
+    int* h = W.h;
     IPXK_HIP(hipMemsetAsync(rc.get(), 0, d1 * sizeof(int), s));
-    IPXK_HIP(hipMemsetAsync(counters.get(), 0, 8 * sizeof(int), s));
+    IPXK_HIP(hipMemsetAsync(counters.get(), 0, 32 * sizeof(int), s));
     IPXK_HIP(hipMemsetAsync(claim_abs.get(), 0, d1 * sizeof(u64), s));
     IPXK_HIP(hipMemsetAsync(ckind.get(), 0, d1, s));
     IPXK_HIP(hipMemsetAsync(pivot.get(), 0, d1 * sizeof(double), s));
@@ -554,44 +681,59 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
     }
     // ---- 1. singleton rounds
     Rounds R{dim, Bp, Bi, Bx, Rp.get(), Rj.get(), Rpos.get(), rstage.get(), cstage.get(), rc.get(), cc.get(), pivot.get(),
-             ckind.get(), cand.get(), flag.get(), rank.get(), claim.get(), cand_bits.get(), claim_abs.get(), counters.get(),
+             ckind.get(), cand.get(), claim.get(), pivrow.get(), cand_bits.get(), claim_abs.get(), counters.get(),
              abstol, pivottol};
     int rounds = 0;
-    const int batch = 4;
+    const int batch = 8;
     while (dim > 0) {
+        IPXK_HIP(hipMemsetAsync(counters.get() + 8, 0, batch * sizeof(int), s));
         for (int b = 0; b < batch; b++) {
+            const int tag = 2 * (rounds + b);
             hipLaunchKernelGGL(lu_col_find_kernel, dim3(g), dim3(kBlock), 0, s, R);
-            hipLaunchKernelGGL(lu_col_flag_kernel, dim3(g), dim3(kBlock), 0, s, R);
-            scan_exclusive(T, flag.get(), rank.get(), (size_t)dim, s);
-            hipLaunchKernelGGL(lu_col_commit_kernel, dim3(g), dim3(kBlock), 0, s, R);
-            hipLaunchKernelGGL(lu_advance_kernel, dim3(1), dim3(1), 0, s, R, 1, 1);
+            hipLaunchKernelGGL(lu_col_commit_kernel, dim3(g), dim3(kBlock), 0, s, R, tag, 8 + b);
             hipLaunchKernelGGL(lu_row_find_kernel, dim3(g), dim3(kBlock), 0, s, R);
             hipLaunchKernelGGL(lu_row_pick_kernel, dim3(g), dim3(kBlock), 0, s, R);
-            hipLaunchKernelGGL(lu_row_flag_kernel, dim3(g), dim3(kBlock), 0, s, R);
-            scan_exclusive(T, flag.get(), rank.get(), (size_t)dim, s);
-            hipLaunchKernelGGL(lu_row_commit_kernel, dim3(g), dim3(kBlock), 0, s, R);
-            hipLaunchKernelGGL(lu_advance_kernel, dim3(1), dim3(1), 0, s, R, 2, 0);
+            hipLaunchKernelGGL(lu_row_commit_kernel, dim3(g), dim3(kBlock), 0, s, R, tag + 1, 8 + b);
         }
-        IPXK_HIP(hipMemcpyAsync(h, counters.get(), 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipMemcpyAsync(h, counters.get(), 16 * sizeof(int), hipMemcpyDeviceToHost, s));
         IPXK_HIP(hipStreamSynchronize(s));
         if (h[7]) throw Error(IPXK_E_ARGUMENT, "row index of B out of range");
-        rounds += batch;
-        if (h[3] == 0 || h[0] == dim) break;            // the batch's last iteration found nothing
+        int last_busy = -1;
+        for (int b = 0; b < batch; b++) if (h[8 + b] > 0) last_busy = b;
+        rounds += last_busy + 1 < batch ? last_busy + 2 : batch;      // the iteration that found nothing counts
+        if (last_busy < batch - 1) break;
     }
-    const int npiv_sing = dim > 0 ? h[0] : 0;
+    if (dim > 0) {
+        hipLaunchKernelGGL(lu_count_kinds_kernel, dim3(g), dim3(kBlock), 0, s, dim, ckind.get(), counters.get());
+        IPXK_HIP(hipMemcpyAsync(h, counters.get(), 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+    }
     I.col_singletons = dim > 0 ? h[1] : 0;
     I.row_singletons = dim > 0 ? h[2] : 0;
+    const int npiv_sing = (int)(I.col_singletons + I.row_singletons);
     I.rounds = rounds;
+    if (npiv_sing > 0) {           // dense stages: rounds in order, inside a round by index
+        DevBuf<u64>& k1 = W.skey; DevBuf<u64>& k2 = W.skey2;
+        k1.ensure(d1); k2.ensure(d1);
+        hipLaunchKernelGGL(lu_stage_keys_kernel, dim3(g), dim3(kBlock), 0, s, dim, cstage.get(), pivrow.get(), k1.get(), cand.get());
+        size_t bytes = 0;
+        IPXK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, k1.get(), k2.get(), cand.get(), claim.get(), (size_t)dim, 0u, 64u, s));
+        IPXK_HIP(rocprim::radix_sort_pairs(T.need(bytes), bytes, k1.get(), k2.get(), cand.get(), claim.get(), (size_t)dim, 0u, 64u, s));
+        hipLaunchKernelGGL(lu_stage_assign_kernel, dim3(grid_for(npiv_sing)), dim3(kBlock), 0, s, npiv_sing, claim.get(), pivrow.get(),
+                           cstage.get(), rstage.get());
+    }
     const double t1 = now_s();
     // ---- 2. bump
-    DevBuf<int> rloc(d1), cloc(d1), brow, bcol, brstep, bcstep, bstep(2), prow(kPanel), pcol(kPanel);
-    DevBuf<double> D;
+    DevBuf<int> &rloc = W.rloc, &cloc = W.cloc, &brow = W.brow, &bcol = W.bcol, &brstep = W.brstep, &bcstep = W.bcstep,
+                &bstep = W.bstep, &prow = W.prow, &pcol = W.pcol;
+    DevBuf<double>& D = W.D;
+    rloc.ensure(d1); cloc.ensure(d1); bstep.ensure(2); prow.ensure(kPanel); pcol.ensure(kPanel);
     int kb = 0;
     if (dim > 0) {
         hipLaunchKernelGGL(lu_active_flag_kernel, dim3(g), dim3(kBlock), 0, s, dim, rstage.get(), flag.get());
         scan_exclusive(T, flag.get(), rank.get(), (size_t)dim, s);
         kb = dim - npiv_sing;
-        brow.resize((size_t)std::max(kb, 1)); bcol.resize((size_t)std::max(kb, 1));
+        brow.ensure((size_t)std::max(kb, 1)); bcol.ensure((size_t)std::max(kb, 1));
         hipLaunchKernelGGL(lu_compact_kernel, dim3(g), dim3(kBlock), 0, s, dim, flag.get(), rank.get(), rloc.get(), brow.get());
         hipLaunchKernelGGL(lu_active_flag_kernel, dim3(g), dim3(kBlock), 0, s, dim, cstage.get(), flag.get());
         scan_exclusive(T, flag.get(), rank.get(), (size_t)dim, s);
@@ -606,9 +748,9 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
         throw Error(IPXK_E_UNSUPPORTED, msg);
     }
     int bpiv = 0;
-    brstep.resize((size_t)std::max(kb, 1)); bcstep.resize((size_t)std::max(kb, 1));
+    brstep.ensure((size_t)std::max(kb, 1)); bcstep.ensure((size_t)std::max(kb, 1));
     if (kb > 0) {
-        D.resize((size_t)kb * kb);
+        D.ensure((size_t)kb * kb);
         IPXK_HIP(hipMemsetAsync(D.get(), 0, (size_t)kb * kb * sizeof(double), s));
         IPXK_HIP(hipMemsetAsync(bstep.get(), 0, 2 * sizeof(int), s));
         const int gk = grid_for(kb);
@@ -618,7 +760,8 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
         Dense A{kb, D.get(), brstep.get(), bcstep.get(), bstep.get(), prow.get(), pcol.get(), abstol};
         for (int c0 = 0; c0 < kb; c0 += kPanel) {
             const int c1 = std::min(kb, c0 + kPanel);
-            hipLaunchKernelGGL(lu_panel_kernel, dim3(1), dim3(kPanelThreads), 0, s, A, c0, c1);
+            if (kb <= kPanelThreads) hipLaunchKernelGGL(lu_panel_small_kernel, dim3(1), dim3(kPanelThreads), 0, s, A, c0, c1);
+            else hipLaunchKernelGGL(lu_panel_kernel, dim3(1), dim3(kPanelThreads), 0, s, A, c0, c1);
             if (c1 < kb) {
                 hipLaunchKernelGGL(lu_panel_rows_kernel, dim3(grid_for(kb - c1)), dim3(kBlock), 0, s, A, c1);
                 hipLaunchKernelGGL(lu_trailing_kernel, dim3((kb + 63) / 64, (kb - c1 + 63) / 64), dim3(kBlock), 0, s, A, c1);
@@ -654,8 +797,12 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
     const int64_t nl = nb + kbsq, nu = nb + kbsq + dim;
     int64_t lnz = 0, unz = 0;
     if (dim > 0) {
-        DevBuf<u64> lkey((size_t)std::max<int64_t>(nl, 1)), lkey2((size_t)std::max<int64_t>(nl, 1)), ukey((size_t)nu), ukey2((size_t)nu);
-        DevBuf<double> lval((size_t)std::max<int64_t>(nl, 1)), lval2((size_t)std::max<int64_t>(nl, 1)), uval((size_t)nu), uval2((size_t)nu);
+        DevBuf<u64> &lkey = W.lkey, &lkey2 = W.lkey2, &ukey = W.ukey, &ukey2 = W.ukey2;
+        DevBuf<double> &lval = W.lval, &lval2 = W.lval2, &uval = W.uval, &uval2 = W.uval2;
+        for (DevBuf<u64>* b : {&lkey, &lkey2}) b->ensure((size_t)std::max<int64_t>(nl, 1));
+        for (DevBuf<u64>* b : {&ukey, &ukey2}) b->ensure((size_t)nu);
+        for (DevBuf<double>* b : {&lval, &lval2}) b->ensure((size_t)std::max<int64_t>(nl, 1));
+        for (DevBuf<double>* b : {&uval, &uval2}) b->ensure((size_t)nu);
         if (nl > 0) hipLaunchKernelGGL(lu_fill_u64_kernel, dim3(grid_for(nl)), dim3(kBlock), 0, s, nl, kNoKey, lkey.get());
         hipLaunchKernelGGL(lu_fill_u64_kernel, dim3(grid_for(nu)), dim3(kBlock), 0, s, nu, kNoKey, ukey.get());
         Assemble A{dim, kb, Bp, Bi, colof.get(), Bx, rstage.get(), cstage.get(), rloc.get(), cloc.get(), brow.get(), bcol.get(),
@@ -771,12 +918,14 @@ void lu_factorize_basis(Context* c, const ipxint* basis, double pivottol, bool s
     S->basis.upload(basis, (size_t)m, s);
     S->basis.ensure(1);
     const size_t m1 = (size_t)std::max(m, 1);
-    DevBuf<int> cnt(m1), dBp(m1 + 1), bad(1);
-    Tmp T;
+    LuWork& W = S->work;
+    DevBuf<int> &cnt = W.cnt, &dBp = W.Bp, &dBi = W.Bi;
+    DevBuf<double>& dBx = W.Bx;
+    DevBuf<int> bad(1);
+    cnt.ensure(m1); dBp.ensure(m1 + 1);
+    Tmp& T = W.T;
     IPXK_HIP(hipMemsetAsync(bad.get(), 0, sizeof(int), s));
     int64_t nb = 0;
-    DevBuf<int> dBi;
-    DevBuf<double> dBx;
     if (m > 0) {
         hipLaunchKernelGGL(lu_basis_count_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, n, S->basis.get(), S->Ap.get(), cnt.get(), bad.get());
         scan_exclusive(T, cnt.get(), dBp.get(), (size_t)m, s);
@@ -789,13 +938,13 @@ void lu_factorize_basis(Context* c, const ipxint* basis, double pivottol, bool s
         nb = (int64_t)last[0] + last[1];
         const int nb32 = (int)nb;
         IPXK_HIP(hipMemcpyAsync(dBp.get() + m, &nb32, sizeof(int), hipMemcpyHostToDevice, s));
-        dBi.resize((size_t)std::max<int64_t>(nb, 1)); dBx.resize((size_t)std::max<int64_t>(nb, 1));
+        dBi.ensure((size_t)std::max<int64_t>(nb, 1)); dBx.ensure((size_t)std::max<int64_t>(nb, 1));
         hipLaunchKernelGGL(lu_basis_fill_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, n, S->basis.get(), S->Ap.get(), S->Ai.get(),
                            S->Ax.get(), dBp.get(), dBi.get(), dBx.get());
         IPXK_HIP(hipStreamSynchronize(s));               // nb32
     } else {
         IPXK_HIP(hipMemsetAsync(dBp.get(), 0, sizeof(int), s));
-        dBi.resize(1); dBx.resize(1);
+        dBi.ensure(1); dBx.ensure(1);
     }
     lu_factorize_device(c, S, m, nb, dBp.get(), dBi.get(), dBx.get(), pivottol, strict, info);
     S->from_basis = true;
