@@ -356,3 +356,14 @@ def lp_like_basis(m, n, seed=12345, **kw):
     status[basis] = 0
     return dict(A=CscMatrix(m, n, Anew.indptr, Anew.indices, Anew.data), basis=basis, status=status, G=G)
 
+
+
+def synthetic_maxvolume_state(status, spread=1.0, seed=12345):
+    """Scaling factors that do NOT favour the current basis (log-uniform over 2*spread decades for every variable):
+    the situation Maxvolume::RunHeuristic repairs (reference src/kkt_solver_basis.cc:46-50).  BASIC_FREE -> inf,
+    NONBASIC_FIXED -> 0 as Iterate::ScalingFactor gives them."""
+    rng = np.random.default_rng(seed + 5)
+    d = 10.0 ** (spread * rng.uniform(-1.0, 1.0, status.size))
+    d[status == 1] = np.inf
+    d[status == -2] = 0.0
+    return d

@@ -1596,3 +1596,259 @@ extern "C" void orc_lu_get(const orc_lu* F, Int* Lp, Int* Li, double* Lx, Int* U
     std::copy(F->dependent.begin(), F->dependent.end(), dependent);
 }
 extern "C" void orc_lu_free(orc_lu* F) { delete F; }
+
+// ---------------------------------------------------------------------------
+// Maxvolume: Maxvolume::RunHeuristic / Driver / ScaleFtran / FindLargest
+// (src/maxvolume.cc:108-153, 179-320, 322-337) and the part of ipx::Basis it drives: SolveDense,
+// SolveForUpdate, TableauRow (dense branch), ExchangeIfStable (src/basis.cc:162-330; status encoding
+// src/basis.h:317-340).
+// The reference keeps its factorization current with BASICLU's or ForrestTomlin's update (src/lu_update.h).
+// Here -- as on the device -- the factorization of the LAST refactorized basis B0 stays fixed and every
+// exchange appends a product-form eta:  B = B0 E_1 ... E_k,  E_t = I + (eta_t - e_p) e_p'  with eta_t the
+// FTRAN of the entering column.  Any exact update represents the same matrix, so tableau columns / rows and
+// hence the heuristic's decisions are those of the reference up to rounding (tests pin FTRAN / BTRAN after
+// exchanges against the reference's own ForrestTomlin, oracle/ref_driver.cc).  Stability test of an exchange:
+// the pivot from the tableau row (BTRAN) against the one from the tableau column (FTRAN), relative 1e-8
+// (the role of kFtDiagErrorTol, src/ipx_internal.h:37); on failure, and after max_etas exchanges, the basis is
+// refactorized (Basis::ExchangeIfStable :299-306, :318-319).
+// PARITY UNPINNED as a whole: Maxvolume needs a live ipx::Basis (BASICLU).
+// ---------------------------------------------------------------------------
+struct orc_basis {
+    Int m = 0, n = 0;
+    const Int *Ap = nullptr, *Ai = nullptr;
+    const double* Ax = nullptr;
+    std::vector<Int> basis, map2basis;      // map2basis: position, position + m (BASIC_FREE), -1 NONBASIC, -2 NONBASIC_FIXED
+    std::unique_ptr<orc_lu> F;
+    std::vector<Int> eta_pos;
+    std::vector<double> eta_piv;
+    std::vector<std::vector<std::pair<Int, double>>> eta;
+    Vec last_ftran;                          // unscaled tableau column of the last SolveForUpdate(nonbasic)
+    Int last_ftran_var = -1;
+    Int max_etas = 100, num_factorizations = 0, num_updates = 0, num_ftran = 0, num_btran = 0;
+    double pivottol = 0.1;
+
+    Int position_of(Int j) const { const Int p = map2basis[j]; return p < 0 ? -1 : p < m ? p : p - m; }
+    int status_of(Int j) const { const Int p = map2basis[j]; return p < 0 ? (p == -1 ? ORC_NONBASIC : ORC_NONBASIC_FIXED) : (p < m ? ORC_BASIC : ORC_BASIC_FREE); }
+
+    Int factorize() {      // Basis::Factorize, src/basis.cc:116-156 (no tightening of the pivot tolerance here)
+        std::vector<Int> begin(m), end(m), slack_i;
+        std::vector<double> slack_x;
+        // AI's arrays with the slack columns appended, as Model::AI() holds them
+        std::vector<Int> bi(Ai, Ai + Ap[n]);
+        std::vector<double> bx(Ax, Ax + Ap[n]);
+        for (Int i = 0; i < m; i++) { bi.push_back(i); bx.push_back(1.0); }
+        for (Int p = 0; p < m; p++) {
+            const Int j = basis[p];
+            begin[p] = j < n ? Ap[j] : Ap[n] + (j - n);
+            end[p] = j < n ? Ap[j + 1] : Ap[n] + (j - n) + 1;
+        }
+        F.reset(orc_lu_factorize(m, begin.data(), end.data(), bi.data(), bx.data(), pivottol, 0, -1));
+        eta_pos.clear(); eta_piv.clear(); eta.clear();
+        num_factorizations++;
+        return F->dependent.empty() ? 0 : 301;       // IPX_ERROR_basis_singular
+    }
+    // Basis::SolveDense (:168-170) = ForrestTomlin::_SolveDense (src/forrest_tomlin.cc:67-78) on B0, then the etas
+    void solve_dense(const double* rhs, double* lhs, char trans) const {
+        Vec work(m);
+        if (trans == 't' || trans == 'T') {
+            Vec v(rhs, rhs + m);                     // position space
+            for (Int t = (Int)eta.size() - 1; t >= 0; t--) {
+                double sum = 0.0;
+                for (const auto& e : eta[t]) sum += e.second * v[e.first];
+                v[eta_pos[t]] = (v[eta_pos[t]] - sum) / eta_piv[t];
+            }
+            for (Int i = 0; i < m; i++) work[i] = v[F->colperm[i]];
+            orc_backward_solve(m, F->Lp.data(), F->Li.data(), F->Lx.data(), F->Up.data(), F->Ui.data(), F->Ux.data(), work.data());
+            for (Int i = 0; i < m; i++) lhs[F->rowperm[i]] = work[i];
+        } else {
+            for (Int i = 0; i < m; i++) work[i] = rhs[F->rowperm[i]];
+            orc_forward_solve(m, F->Lp.data(), F->Li.data(), F->Lx.data(), F->Up.data(), F->Ui.data(), F->Ux.data(), work.data());
+            for (Int i = 0; i < m; i++) lhs[F->colperm[i]] = work[i];
+            for (size_t t = 0; t < eta.size(); t++) {
+                const double vp = lhs[eta_pos[t]] / eta_piv[t];
+                for (const auto& e : eta[t]) lhs[e.first] -= e.second * vp;
+                lhs[eta_pos[t]] = vp;
+            }
+        }
+    }
+    // Basis::SolveForUpdate (:172-196): tableau column of a nonbasic variable / row of inverse(B) of a basic one
+    void solve_for_update(Int j, double* lhs) {
+        const Int p = position_of(j);
+        Vec rhs(m, 0.0);
+        if (p < 0) {
+            if (j < n) for (Int q = Ap[j]; q < Ap[j + 1]; q++) rhs[Ai[q]] = Ax[q];
+            else rhs[j - n] = 1.0;
+            solve_dense(rhs.data(), lhs, 'N');
+            last_ftran.assign(lhs, lhs + m);
+            last_ftran_var = j;
+            num_ftran++;
+        } else {
+            rhs[p] = 1.0;
+            solve_dense(rhs.data(), lhs, 'T');
+            num_btran++;
+        }
+    }
+    // Basis::TableauRow (:221-284), dense branch (the sparse branch computes the same numbers in another order)
+    void tableau_row(Int jb, double* btran, double* row, bool ignore_fixed) {
+        solve_for_update(jb, btran);
+        for (Int j = 0; j < n + m; j++) {
+            double result = 0.0;
+            if (map2basis[j] == -1 || (map2basis[j] == -2 && !ignore_fixed)) {
+                if (j < n) for (Int q = Ap[j]; q < Ap[j + 1]; q++) result += Ax[q] * btran[Ai[q]];
+                else result += 1.0 * btran[j - n];
+            }
+            row[j] = result;
+        }
+    }
+    // Basis::ExchangeIfStable (:286-321) with sys = 0
+    Int exchange_if_stable(Int jb, Int jn, double tableau_entry, bool* exchanged) {
+        *exchanged = false;
+        const Int ib = position_of(jb);
+        const double piv_ftran = last_ftran[ib];
+        const bool unstable = last_ftran_var != jn ||
+                              !(std::abs(piv_ftran - tableau_entry) <= 1e-8 * std::abs(piv_ftran)) || piv_ftran == 0.0;
+        if (unstable) {
+            if (eta.empty()) return 306;             // IPX_ERROR_basis_too_ill_conditioned: nothing to refresh
+            return factorize();                      // refactorizes the OLD basis; the caller tries again
+        }
+        std::vector<std::pair<Int, double>> e;
+        for (Int p = 0; p < m; p++) if (p != ib && last_ftran[p] != 0.0) e.emplace_back(p, last_ftran[p]);
+        eta.push_back(std::move(e));
+        eta_pos.push_back(ib);
+        eta_piv.push_back(piv_ftran);
+        basis[ib] = jn;
+        map2basis[jn] = ib;
+        map2basis[jb] = -1;
+        num_updates++;
+        last_ftran_var = -1;
+        *exchanged = true;
+        if ((Int)eta.size() >= max_etas) return factorize();
+        return 0;
+    }
+};
+
+extern "C" orc_basis* orc_basis_new(Int m, Int n, const Int* Ap, const Int* Ai, const double* Ax, const Int* basis,
+                                    const Int* status, Int max_etas, Int* errflag) {
+    std::unique_ptr<orc_basis> B(new orc_basis);
+    B->m = m; B->n = n; B->Ap = Ap; B->Ai = Ai; B->Ax = Ax;
+    B->basis.assign(basis, basis + m);
+    B->map2basis.assign(n + m, -1);
+    for (Int j = 0; j < n + m; j++) if (status[j] == ORC_NONBASIC_FIXED) B->map2basis[j] = -2;
+    for (Int p = 0; p < m; p++) B->map2basis[basis[p]] = status[basis[p]] == ORC_BASIC_FREE ? p + m : p;
+    if (max_etas > 0) B->max_etas = max_etas;
+    *errflag = B->factorize();
+    return B.release();
+}
+extern "C" void orc_basis_free(orc_basis* B) { delete B; }
+extern "C" void orc_basis_get(const orc_basis* B, Int* basis, Int* status, Int* counts) {
+    std::copy(B->basis.begin(), B->basis.end(), basis);
+    for (Int j = 0; j < B->n + B->m; j++) status[j] = B->status_of(j);
+    if (counts) {
+        counts[0] = B->num_factorizations; counts[1] = B->num_updates; counts[2] = B->num_ftran;
+        counts[3] = B->num_btran; counts[4] = (Int)B->eta.size();
+    }
+}
+extern "C" void orc_basis_solve_dense(const orc_basis* B, const double* rhs, double* lhs, char trans) {
+    Vec tmp(rhs, rhs + B->m);
+    B->solve_dense(tmp.data(), lhs, trans);
+}
+extern "C" void orc_basis_solve_for_update(orc_basis* B, Int j, double* lhs) { B->solve_for_update(j, lhs); }
+extern "C" void orc_basis_tableau_row(orc_basis* B, Int jb, double* btran, double* row, int ignore_fixed) {
+    B->tableau_row(jb, btran, row, ignore_fixed != 0);
+}
+extern "C" Int orc_basis_exchange_if_stable(orc_basis* B, Int jb, Int jn, double tableau_entry, Int* exchanged) {
+    bool ex = false;
+    const Int err = B->exchange_if_stable(jb, jn, tableau_entry, &ex);
+    *exchanged = ex ? 1 : 0;
+    return err;
+}
+
+// Maxvolume::RunHeuristic (src/maxvolume.cc:108-153) with Driver (:202-320).  colscale: n+m scaling factors
+// (KKTSolverBasis::_Factorize passes Iterate::ScalingFactor, src/kkt_solver_basis.cc:28-29,46-50).
+// info[8] = updates, skipped, slices, volinc, # exchanges that were refused as unstable, errflag, 0, 0.
+// log (may be NULL, capacity log_cap pairs): the accepted exchanges (jb, jn) in order.
+extern "C" Int orc_maxvolume_heuristic(orc_basis* B, const double* colscale_in, double volume_tol, Int maxskip_updates,
+                                       Int rows_per_slice, double* info, Int* log, Int log_cap) {
+    const Int m = B->m, n = B->n;
+    constexpr double kPivotZeroTol = 1e-7;            // src/maxvolume.h:34
+    Vec colscale(n + m, 0.0), invscale_basic(m, 0.0), colweights(n + m, 0.0), work(m), lhs(m), row(n + m);
+    std::vector<char> used(m, 0);
+    Int updates = 0, skipped_total = 0, refused = 0, errflag = 0;
+    double volinc = 0.0;
+    Int num_slices = 5 + std::max<Int>(m / rows_per_slice, 0);     // :116-117
+    num_slices = std::min(num_slices, m);
+    for (Int p = 0; p < m; p++)                                     // :120-126
+        if (B->status_of(B->basis[p]) == ORC_BASIC) invscale_basic[p] = colscale_in ? 1.0 / colscale_in[B->basis[p]] : 1.0;
+    for (Int j = 0; j < n + m; j++)                                 // :130-133
+        if (B->status_of(j) == ORC_NONBASIC) colscale[j] = colscale_in ? colscale_in[j] : 1.0;
+    std::vector<std::pair<double, Int>> vi(m);                      // Sortperm, src/utils.cc:87-104
+    for (Int i = 0; i < m; i++) vi[i] = std::make_pair(invscale_basic[i], i);
+    std::sort(vi.begin(), vi.end());
+    const double volumetol = std::max(volume_tol, 1.0);
+    for (Int s = 0; s < num_slices && !errflag; s++) {
+        for (Int i = 0; i < m; i++) used[vi[i].second] = i % num_slices == s;
+        // ---- Driver
+        for (Int p = 0; p < m; p++) work[p] = used[p] ? invscale_basic[p] : 0.0;     // :221-223
+        {
+            Vec tmp(work);
+            B->solve_dense(tmp.data(), work.data(), 'T');
+        }
+        for (Int j = 0; j < n + m; j++) {                            // :224-232
+            if (colscale[j] != 0.0) {
+                double sum = 0.0;
+                if (j < n) for (Int q = B->Ap[j]; q < B->Ap[j + 1]; q++) sum += B->Ax[q] * work[B->Ai[q]];
+                else sum = work[j - n];                              // DotColumn over the unit column: 1.0 * work[i]
+                colweights[j] = sum * colscale[j];
+            } else colweights[j] = 0.0;
+        }
+        Int skipped = 0;
+        while (true) {
+            Int jn = 0;                                              // FindLargest (:179-200): first largest |w|
+            double wmax = 0.0;
+            for (Int j = 0; j < n + m; j++) if (std::abs(colweights[j]) > wmax) { wmax = std::abs(colweights[j]); jn = j; }
+            const double weight = colweights[jn];
+            if (weight == 0.0) break;
+            B->solve_for_update(jn, lhs.data());                     // :253
+            double vmax = 0.0;                                       // ScaleFtran :322-337
+            Int pmax = 0;
+            for (Int p = 0; p < m; p++) {
+                const double pivot = lhs[p];
+                const double scaled = pivot * colscale[jn] * invscale_basic[p];
+                const double v = std::abs(scaled);
+                if (v > vmax && std::abs(pivot) > kPivotZeroTol) { vmax = v; pmax = p; }
+                lhs[p] = scaled;
+            }
+            vmax = std::abs(lhs[pmax]);                              // :255-256 (pmax = 0 if no entry qualified)
+            if (vmax <= volumetol) {                                 // :259-266
+                colweights[jn] = 0.0;
+                colscale[jn] = 0.0;
+                if (++skipped > maxskip_updates && maxskip_updates >= 0) break;
+                continue;
+            }
+            double weight_recomp = 0.0;                              // :269-275
+            for (Int p = 0; p < m; p++) if (used[p]) weight_recomp += lhs[p];
+            const Int jb = B->basis[pmax];
+            B->tableau_row(jb, lhs.data(), row.data(), true);        // :279 (lhs is overwritten by the BTRAN)
+            const double pivot = row[jn];
+            bool exchanged = false;
+            errflag = B->exchange_if_stable(jb, jn, pivot, &exchanged);   // :287
+            if (errflag) break;
+            if (!exchanged) { refused++; continue; }
+            if (log && updates < log_cap) { log[2 * updates] = jb; log[2 * updates + 1] = jn; }
+            updates++;
+            volinc += std::log2(vmax);
+            const double dn = colscale[jn], dbinv = invscale_basic[pmax];       // :296-304
+            colscale[jb] = 1.0 / invscale_basic[pmax];
+            invscale_basic[pmax] = 1.0 / colscale[jn];
+            colscale[jn] = 0.0;
+            const double alpha = ((used[pmax] ? 1.0 : 0.0) - weight_recomp) / (dn * pivot);   // :307-314
+            for (Int j = 0; j < n + m; j++) colweights[j] += alpha * row[j] * colscale[j];
+            colweights[jb] = (used[pmax] ? 1.0 : 0.0) + alpha / dbinv;
+            colweights[jn] = 0.0;
+        }
+        skipped_total += skipped;
+    }
+    info[0] = (double)updates; info[1] = (double)skipped_total; info[2] = (double)num_slices; info[3] = volinc;
+    info[4] = (double)refused; info[5] = (double)errflag; info[6] = info[7] = 0.0;
+    return errflag;
+}

@@ -236,6 +236,22 @@ void orc_lu_get(const orc_lu* F, orc_int* Lp, orc_int* Li, double* Lx, orc_int* 
                 orc_int* rowperm, orc_int* colperm, orc_int* dependent);
 void orc_lu_free(orc_lu* F);
 
+/* ---- Maxvolume (section 8f rank 2): src/maxvolume.cc:108-337 over the part of ipx::Basis it drives
+ * (src/basis.cc:162-330), with product-form updates of a fixed factorization; see ipx_oracle.cc.  status: the
+ * ORC_* values above.  The matrix arrays must outlive the object. */
+typedef struct orc_basis orc_basis;
+orc_basis* orc_basis_new(orc_int m, orc_int n, const orc_int* Ap, const orc_int* Ai, const double* Ax,
+                         const orc_int* basis, const orc_int* status, orc_int max_etas, orc_int* errflag);
+void orc_basis_free(orc_basis* B);
+/* counts[5] = factorizations, updates, ftrans, btrans, etas since the last factorization */
+void orc_basis_get(const orc_basis* B, orc_int* basis, orc_int* status, orc_int* counts);
+void orc_basis_solve_dense(const orc_basis* B, const double* rhs, double* lhs, char trans);
+void orc_basis_solve_for_update(orc_basis* B, orc_int j, double* lhs);
+void orc_basis_tableau_row(orc_basis* B, orc_int jb, double* btran, double* row, int ignore_fixed);
+orc_int orc_basis_exchange_if_stable(orc_basis* B, orc_int jb, orc_int jn, double tableau_entry, orc_int* exchanged);
+orc_int orc_maxvolume_heuristic(orc_basis* B, const double* colscale, double volume_tol, orc_int maxskip_updates,
+                                orc_int rows_per_slice, double* info, orc_int* log, orc_int log_cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,7 +90,7 @@ class Oracle:
                      "orc_kkt_diag_solve", "orc_trisolve", "orc_split_get_sizes",
                      "orc_kkt_basis_solve", "orc_newton_solve_diag", "orc_newton_solve_basis", "orc_ipm_step_diag"):
             getattr(L, name).restype = c_i64
-        for name in ("orc_diag_factorize", "orc_kkt_diag_new", "orc_split_prepare", "orc_lu_factorize"):
+        for name in ("orc_diag_factorize", "orc_kkt_diag_new", "orc_split_prepare", "orc_lu_factorize", "orc_basis_new"):
             getattr(L, name).restype = C.c_void_p
 
     # ---- Iterate / StepToBoundary ---------------------------------------------
@@ -168,6 +168,10 @@ class Oracle:
         return dict(L=Csc(dim, dim, Lp, Li, Lx), U=Csc(dim, dim, Up, Ui, Ux), rowperm=rowperm, colperm=colperm,
                     dependent=dep, info=dict(col_singletons=int(info[0]), row_singletons=int(info[1]),
                                              bump=int(info[2]), rounds=int(info[3]), dependent=int(info[4])))
+
+    def basis(self, A, basis, status, max_etas=100):
+        """ipx::Basis as far as Maxvolume needs it, over [A I] (A: Csc m x n)"""
+        return OracleBasis(self, A, basis, status, max_etas)
 
     def equilibrate(self, A):
         """Presolver::EquilibrateMatrix: (scaled values, colscale, rowscale, rounds); rounds = -1: untouched"""
@@ -303,6 +307,61 @@ def _wrap_apply(fn, m):
         if dot_p:
             dot_p[0] = dot
     return APPLY_FN(cb)
+
+
+class OracleBasis:
+    def __init__(self, orc, A, basis, status, max_etas=100):
+        self.lib, self.m, self.n = orc.lib, A.nrow, A.ncol
+        self.keep = (_I(A.p), _I(A.i), _F(A.x))
+        err = c_i64(0)
+        self.lib.orc_basis_exchange_if_stable.restype = c_i64
+        self.lib.orc_maxvolume_heuristic.restype = c_i64
+        self.h = C.c_void_p(self.lib.orc_basis_new(c_i64(self.m), c_i64(self.n), _ip(self.keep[0]), _ip(self.keep[1]),
+                                                   _fp(self.keep[2]), _ip(_I(basis)), _ip(_I(status)), c_i64(max_etas),
+                                                   C.byref(err)))
+        self.errflag = err.value
+
+    def get(self):
+        basis, status, counts = np.zeros(self.m, i64), np.zeros(self.n + self.m, i64), np.zeros(5, i64)
+        self.lib.orc_basis_get(self.h, _ip(basis), _ip(status), _ip(counts))
+        return basis, status, dict(zip(("factorizations", "updates", "ftran", "btran", "etas"), counts.tolist()))
+
+    def solve_dense(self, rhs, trans):
+        lhs = np.zeros(self.m, f64)
+        self.lib.orc_basis_solve_dense(self.h, _fp(_F(rhs)), _fp(lhs), C.c_char(trans.encode()))
+        return lhs
+
+    def solve_for_update(self, j):
+        lhs = np.zeros(self.m, f64)
+        self.lib.orc_basis_solve_for_update(self.h, c_i64(j), _fp(lhs))
+        return lhs
+
+    def tableau_row(self, jb, ignore_fixed=True):
+        btran, row = np.zeros(self.m, f64), np.zeros(self.n + self.m, f64)
+        self.lib.orc_basis_tableau_row(self.h, c_i64(jb), _fp(btran), _fp(row), C.c_int(1 if ignore_fixed else 0))
+        return btran, row
+
+    def exchange_if_stable(self, jb, jn, tableau_entry):
+        ex = c_i64(0)
+        err = self.lib.orc_basis_exchange_if_stable(self.h, c_i64(jb), c_i64(jn), c_f64(tableau_entry), C.byref(ex))
+        return int(err), bool(ex.value)
+
+    def maxvolume(self, colscale, volume_tol=2.0, maxskip_updates=10, rows_per_slice=10000, log_cap=100000):
+        info = np.zeros(8, f64)
+        log = np.zeros(2 * log_cap, i64)
+        err = self.lib.orc_maxvolume_heuristic(self.h, _fp(_F(colscale)), c_f64(volume_tol), c_i64(maxskip_updates),
+                                               c_i64(rows_per_slice), _fp(info), _ip(log), c_i64(log_cap))
+        k = int(info[0])
+        return dict(errflag=int(err), updates=k, skipped=int(info[1]), slices=int(info[2]), volinc=float(info[3]),
+                    refused=int(info[4]), exchanges=log[: 2 * min(k, log_cap)].reshape(-1, 2))
+
+    def close(self):
+        if self.h:
+            self.lib.orc_basis_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 class OracleDiagPrecond:
