@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-column-partition", action="store_true",
                     help="N > 1: skip the extra measurement of the column partition (config.column_partition)")
     ap.add_argument("--no-lu", action="store_true", help="skip the basis LU factorization on the device (config.lu_path)")
+    ap.add_argument("--no-maxvolume", action="store_true", help="skip Maxvolume on the device (config.maxvolume_path)")
     ap.add_argument("--no-banded", action="store_true", help="skip the banded-matrix probe of the SpMV (extra field of roofline)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 2 and 5 (config.other_configs)")
     ap.add_argument("--no-direct-exchange", action="store_true",
@@ -343,6 +344,8 @@ def main():
         out["config"]["basis_path"] = bench_basis(kkt, synth, m, n, args)
     if rank == 0 and world == 1 and not args.no_lu:
         out["config"]["lu_path"] = bench_lu(kkt, synth, m, n, args)
+    if rank == 0 and world == 1 and not args.no_maxvolume:
+        out["config"]["maxvolume_path"] = bench_maxvolume(kkt, synth, m, n, args)
     if rank == 0 and world == 1 and not args.no_newton:
         out["config"]["newton_step"] = bench_newton(kkt, synth, ctx, m, n, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -680,6 +683,44 @@ def bench_lu(kkt, synth, m, n, args, bump=1000):
                                          "kernel for it, BASICLU, is not in the image" % tc}
         res["gpu_over_cpu"] = tc / (tf / K)
     ctx.close()
+    return res
+
+
+def bench_maxvolume(kkt, synth, m, n, args, entering=300):
+    """SURVEY 8f rank 2: Maxvolume::RunHeuristic (src/maxvolume.cc:108-337) + the refactorization and Prepare that
+    follow it in KKTSolverBasis::_Factorize (src/kkt_solver_basis.cc:46-61), on the device, from the slack basis
+    of the C3 model with `entering` structural variables carrying large scaling factors (the first Maxvolume call
+    of a solve).  CPU baseline: the repo's restatement on one core ("port": Maxvolume needs ipx::Basis, hence
+    BASICLU, and cannot run in the reference here; its dense tableau rows cost O(nnz(A)) per step where the
+    reference would take its hypersparse branch)."""
+    A = synth.synthetic_lp(m, n, 8, 12345)
+    basis, status, colscale = synth.slack_basis_crash_state(m, n, entering, 1.0, 12345)
+    ctx = kkt.KktContext(A)
+    ctx.lu_factorize_basis(basis, 0.1, download=False)
+    ctx.split_prepare_lu(status, colscale)
+    t0 = time.perf_counter()
+    r = ctx.maxvolume(status, colscale)
+    dt = time.perf_counter() - t0
+    steps = r["updates"] + r["skipped"]
+    res = {"workload": "slack basis of the %d x %d model, %d structural variables with large scaling factors; volume_tol 2, "
+                       "maxskip_updates 10, rows_per_slice 10000 (the reference's defaults)" % (m, n, entering),
+           "seconds": dt, "updates": r["updates"], "skipped": r["skipped"], "slices": r["slices"], "refused": r["refused"],
+           "refactorizations": r["factorizations"], "volinc": r["volinc"], "ms_per_step": dt * 1e3 / max(steps, 1),
+           "note": "a step = one candidate column: FindLargest, tableau column, ScaleFtran, and for an exchange the tableau "
+                   "row, the eta and the weight update; the time includes the refactorizations (LU + Prepare on the device)"}
+    ctx.close()
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle
+        t0 = time.perf_counter()
+        B = pyoracle.Oracle().basis(pyoracle.Csc(m, n, A.p, A.i, A.x), basis, status)
+        w = B.maxvolume(colscale)
+        tc = time.perf_counter() - t0
+        res["parity"] = {"same_exchanges_in_the_same_order": bool(np.array_equal(w["exchanges"], r["exchanges"])),
+                         "same_final_basis": bool(np.array_equal(B.get()[0], r["basis"])),
+                         "volinc_rel_diff": abs(w["volinc"] - r["volinc"]) / max(abs(w["volinc"]), 1e-300)}
+        res["cpu_baseline"] = {"value": 1.0 / tc, "unit": "runs/s", "cores": 1, "kind": "port",
+                               "sample": "1 x the same Maxvolume run by the repo's CPU restatement (%.1f s)" % tc}
+        res["gpu_over_cpu"] = tc / dt
     return res
 
 

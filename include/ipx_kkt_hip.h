@@ -258,6 +258,41 @@ int ipxk_lu_factorize_basis(ipxk_context* ctx, const ipxint* basis,
  * reference repairs the basis first (Basis::AdaptToSingularFactorization). */
 int ipxk_split_prepare_lu(ipxk_context* ctx, const ipxint* status,
                           const double* colscale);
+/* ---- Maxvolume on the device -------------------------------
+ * Maxvolume::RunHeuristic (src/maxvolume.cc:108-153 with Driver :202-320,
+ * ScaleFtran :322-337, FindLargest :179-200) over the part of ipx::Basis it
+ * drives (SolveDense, SolveForUpdate, TableauRow, ExchangeIfStable,
+ * src/basis.cc:162-330), followed by the tail of KKTSolverBasis::_Factorize
+ * (src/kkt_solver_basis.cc:46-61): a fresh factorization of the final basis and
+ * the split operator built from it.  Precondition: ipxk_lu_factorize_basis +
+ * ipxk_split_prepare_lu for the current basis.  status / colscale: n+m entries
+ * as for ipxk_split_prepare (BASIC_FREE variables never leave, NONBASIC_FIXED
+ * ones never enter).  The factorization is kept current by product-form etas on
+ * the resident factors and refactorized after max_etas exchanges or when an
+ * exchange fails the stability test (the pivot from the tableau row against the
+ * one from the tableau column, relative 1e-8).  On return basis_out[m] /
+ * status_out[n+m] hold the new basis (either may be NULL), the context the
+ * operator for it, exchange_log (may be NULL) the accepted exchanges as pairs
+ * (leaving variable, entering variable), at most log_cap of them.
+ * info.errflag: 0, or IPX_ERROR_basis_too_ill_conditioned (306). */
+typedef struct {
+  double volume_tol;        /* ipx_parameters.volume_tol, default 2.0 */
+  ipxint maxskip_updates;   /* default 10 */
+  ipxint rows_per_slice;    /* default 10000 */
+  ipxint max_etas;          /* exchanges between refactorizations, default 100 */
+} ipxk_maxvolume_params;
+typedef struct {
+  ipxint updates, skipped, slices;   /* Maxvolume::updates() / skipped() / slices() */
+  ipxint refused;                    /* exchanges refused as unstable (then refactorized) */
+  ipxint factorizations;             /* refactorizations, the final one included */
+  ipxint errflag;
+  double volinc;                     /* Maxvolume::volinc(): log2 of the volume gained */
+  double seconds;
+} ipxk_maxvolume_info;
+int ipxk_maxvolume(ipxk_context* ctx, const ipxint* status, const double* colscale,
+                   const ipxk_maxvolume_params* params, ipxint* basis_out,
+                   ipxint* status_out, ipxk_maxvolume_info* info,
+                   ipxint* exchange_log, ipxint log_cap);
 /* _Apply (src/splitted_normal_matrix.cc:90-117) */
 int ipxk_split_apply(ipxk_context* ctx, const double* rhs, double* lhs,
                      double* rhs_dot_lhs);

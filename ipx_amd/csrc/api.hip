@@ -17,6 +17,7 @@ Context::~Context() {
     if (split) destroy_split(split);
     if (prepare_host) destroy_prepare_host(prepare_host);
     if (lu) destroy_lu(lu);
+    if (maxvol) destroy_maxvol(maxvol);
     comm_destroy(this);
     if (h_state) (void)hipHostFree(h_state);
     if (h_cycle_done) (void)hipHostFree(h_cycle_done);
@@ -726,6 +727,16 @@ int ipxk_split_prepare_lu(ipxk_context* c, const ipxint* status, const double* c
         IPXK_REQUIRE(c && status && colscale, "NULL argument");
         bind_device(c);
         split_prepare_lu(c, status, colscale);
+    });
+}
+
+int ipxk_maxvolume(ipxk_context* c, const ipxint* status, const double* colscale, const ipxk_maxvolume_params* params,
+                   ipxint* basis_out, ipxint* status_out, ipxk_maxvolume_info* info, ipxint* exchange_log, ipxint log_cap) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && status && colscale, "NULL argument");
+        IPXK_REQUIRE(log_cap >= 0 && (exchange_log || log_cap == 0), "bad log arguments");
+        bind_device(c);
+        maxvolume_dev(c, status, colscale, params, basis_out, status_out, info, exchange_log, log_cap);
     });
 }
 

@@ -25,6 +25,7 @@ enum PartialSlot {
 struct SplitOperator;   // trisolve.hip
 struct PrepareHost;     // trisolve.hip
 struct LuState;         // lu.hip
+struct MaxvolState;     // maxvolume.hip
 
 struct Context {
     int device = 0;
@@ -97,6 +98,7 @@ struct Context {
     SplitOperator* split = nullptr;
     PrepareHost* prepare_host = nullptr;   // host workspaces of split_prepare (trisolve.hip)
     LuState* lu = nullptr;                 // factors of the last ipxk_lu_factorize* (lu.hip)
+    MaxvolState* maxvol = nullptr;         // workspaces of ipxk_maxvolume (maxvolume.hip)
 
     // ---- multi-GPU ----
     ncclComm* comm = nullptr;
@@ -215,6 +217,10 @@ void lu_get_factors(Context* c, ipxint* Lp, ipxint* Li, double* Lx, ipxint* Up, 
                     ipxint* rowperm, ipxint* colperm, ipxint* dependent);
 void split_prepare_lu(Context* c, const ipxint* status, const double* colscale);
 void destroy_lu(LuState*);
+// ---- maxvolume.hip ----
+void maxvolume_dev(Context* c, const ipxint* status, const double* colscale, const ipxk_maxvolume_params* prm,
+                   ipxint* basis_out, ipxint* status_out, ipxk_maxvolume_info* info, ipxint* log, ipxint log_cap);
+void destroy_maxvol(MaxvolState*);
 // ---- presolve.hip (stand-alone, no context) ----
 void equilibrate_device(int device, int64_t m, int64_t n, const ipxint* Ap, const ipxint* Ai, double* Ax,
                         double* colscale, double* rowscale, ipxint* rounds);

@@ -864,6 +864,13 @@ bool lu_view(const Context* c, LuView* out) {
     return true;
 }
 
+// the plain CSC copy of the structural matrix that ipxk_lu_factorize_basis keeps on the device
+void lu_plain_matrix(const Context* c, const int** Ap, const int** Ai, const double** Ax) {
+    const LuState* S = c->lu;
+    IPXK_REQUIRE(S && S->have_A, "no resident copy of the matrix (ipxk_lu_factorize_basis)");
+    *Ap = S->Ap.get(); *Ai = S->Ai.get(); *Ax = S->Ax.get();
+}
+
 void lu_factorize_host(Context* c, int64_t dim64, const ipxint* Bbegin, const ipxint* Bend, const ipxint* Bi,
                        const double* Bx, double pivottol, bool strict, ipxk_lu_info* info) {
     IPXK_REQUIRE(dim64 >= 0 && dim64 < (int64_t(1) << 30), "dimension out of range");

@@ -1,0 +1,474 @@
+// Maxvolume on the device: Maxvolume::RunHeuristic with its Driver, ScaleFtran and
+// FindLargest (reference src/maxvolume.cc:108-153, 179-337) and the part of ipx::Basis they drive -- SolveDense,
+// SolveForUpdate, TableauRow, ExchangeIfStable (src/basis.cc:162-330) -- on the basis whose LU factors are
+// resident (ipxk_lu_factorize_basis + ipxk_split_prepare_lu).
+//
+// What an exchange step costs on the CPU is a handful of sparse solves; here every piece is a data-parallel pass
+// over vectors that stay in HBM, and the host only reads a block of scalars twice per step to take the
+// reference's decisions:
+//   * FindLargest: arg max |colweights| over the n+m columns (fixed-tree reduction, first index on ties);
+//   * tableau column (FTRAN): the entering column scattered into an m-vector, the two forward sweeps on the
+//     unscaled factors (trisolve.hip), then the update etas;
+//   * ScaleFtran + the recomputed column weight: one fused reduction over the m positions;
+//   * tableau row: e_p through the etas (transposed, last first), the two backward sweeps, then one gather
+//     product A' btran masked to the NONBASIC columns (the SpMV of the KKT path; slack columns elementwise);
+//   * the update of colweights / colscale / invscale_basic: one elementwise pass.
+// The factorization is NOT updated in place: the factors of the last refactorized basis B0 stay fixed (so do the
+// level schedules of the sweeps) and every exchange appends a product-form eta, B = B0 E_1 ... E_k with
+// E_t = I + (eta_t - e_p) e_p', eta_t the tableau column of the entering variable.  The etas are applied by ONE
+// workgroup in a single launch (they are sequential, and short for LP bases); after max_etas exchanges, or when an
+// exchange fails the stability test (pivot from the row against pivot from the column, relative 1e-8 -- the role
+// of kFtDiagErrorTol in the reference's Forrest-Tomlin update, src/ipx_internal.h:37), the basis is refactorized
+// on the device (lu.hip) and the operator rebuilt (Basis::ExchangeIfStable, src/basis.cc:299-306, 318-319).
+// Any exact update represents the same matrix, so the decisions are the reference's up to rounding; the CPU
+// restatement the tests compare with keeps the same etas.
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <vector>
+
+#include "context.hpp"
+#include "spmv_kernels.hpp"
+#include "trisolve.hpp"
+
+namespace ipxk {
+
+namespace {
+
+constexpr int kRedGrid = 512;            // workgroups of the two-stage reductions
+constexpr int kEtaThreads = 1024;
+constexpr double kPivotZeroTol = 1e-7;   // src/maxvolume.h:34
+
+int grid_for(int64_t n) { return (int)std::min<int64_t>(4096, std::max<int64_t>(1, (n + kBlock - 1) / kBlock)); }
+#define IPXK_GRID_STRIDE(i, n) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+// the scalars of one step, written by the device, read by the host
+struct Scalars {
+    int jn;                  // FindLargest
+    double weight;
+    int pmax, jb;            // ScaleFtran
+    double vmax, weight_recomp, colscale_jn, invscale_pmax, pivot_col;
+    int used_pmax, eta_nnz;
+    double pivot_row;        // row[jn]
+    int eta_total;           // entries of all etas after the last exchange
+};
+
+struct Part { double v; int i; double s; int c; };     // per-workgroup partial of the reductions
+
+// ---- FindLargest (src/maxvolume.cc:179-200): first index of the largest |w| ----------------------------------
+__global__ __launch_bounds__(kBlock) void mv_argmax_kernel(int64_t N, const double* __restrict__ w, Part* part) {
+    __shared__ double sv[kBlock / 64];
+    __shared__ int si[kBlock / 64];
+    double best = 0.0;
+    int bi = INT_MAX;
+    IPXK_GRID_STRIDE(j, N) {
+        const double a = fabs(w[j]);
+        if (a > best || (a == best && a > 0.0 && (int)j < bi)) { best = a; bi = (int)j; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double ov = __shfl_xor(best, d, 64);
+        const int oi = __shfl_xor(bi, d, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kBlock / 64; k++)
+            if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+        part[blockIdx.x].v = best;
+        part[blockIdx.x].i = bi;
+    }
+}
+__global__ void mv_argmax_final_kernel(int nparts, const Part* part, const double* __restrict__ w, Scalars* S) {
+    double best = 0.0;
+    int bi = INT_MAX;
+    for (int k = 0; k < nparts; k++)
+        if (part[k].v > best || (part[k].v == best && part[k].i < bi)) { best = part[k].v; bi = part[k].i; }
+    S->jn = bi == INT_MAX ? 0 : bi;                 // all weights zero: index 0, weight 0 (the loop ends)
+    S->weight = w[S->jn];
+}
+
+// ---- tableau column -----------------------------------------------------------------------------------------
+__global__ void mv_scatter_column_kernel(int n, const Scalars* S, const int* __restrict__ Ap, const int* __restrict__ Ai,
+                                         const double* __restrict__ Ax, double* __restrict__ rhs) {
+    const int j = S->jn;
+    if (j >= n) { if (blockIdx.x == 0 && threadIdx.x == 0) rhs[j - n] = 1.0; return; }
+    for (int q = Ap[j] + blockIdx.x * blockDim.x + threadIdx.x; q < Ap[j + 1]; q += gridDim.x * blockDim.x) rhs[Ai[q]] = Ax[q];
+}
+// the etas, B^{-1} direction, oldest first: v_p <- v_p / piv; v_i <- v_i - eta_i v_p
+__global__ __launch_bounds__(kEtaThreads) void mv_eta_ftran_kernel(int K, const int* __restrict__ ptr, const int* __restrict__ pos,
+                                                                   const double* __restrict__ piv, const int* __restrict__ idx,
+                                                                   const double* __restrict__ val, double* v) {
+    __shared__ double s_vp;
+    for (int t = 0; t < K; t++) {
+        if (threadIdx.x == 0) { s_vp = v[pos[t]] / piv[t]; v[pos[t]] = s_vp; }
+        __syncthreads();
+        const double vp = s_vp;
+        for (int e = ptr[t] + threadIdx.x; e < ptr[t + 1]; e += kEtaThreads) v[idx[e]] -= val[e] * vp;
+        __syncthreads();
+    }
+}
+// transposed direction, newest first: v_p <- (v_p - sum_i eta_i v_i) / piv
+__global__ __launch_bounds__(kEtaThreads) void mv_eta_btran_kernel(int K, const int* __restrict__ ptr, const int* __restrict__ pos,
+                                                                   const double* __restrict__ piv, const int* __restrict__ idx,
+                                                                   const double* __restrict__ val, double* v) {
+    __shared__ double red[kEtaThreads / 64];
+    for (int t = K - 1; t >= 0; t--) {
+        double sum = 0.0;
+        for (int e = ptr[t] + threadIdx.x; e < ptr[t + 1]; e += kEtaThreads) sum += val[e] * v[idx[e]];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int k = 0; k < kEtaThreads / 64; k++) tot += red[k];
+            v[pos[t]] = (v[pos[t]] - tot) / piv[t];
+        }
+        __syncthreads();
+    }
+}
+// ---- ScaleFtran (src/maxvolume.cc:322-337) + the recomputed weight (:269-275) + # nonzeros of the column ----
+__global__ __launch_bounds__(kBlock) void mv_scale_ftran_kernel(int m, const Scalars* S, const double* __restrict__ lhs,
+                                                                const double* __restrict__ colscale, const double* __restrict__ invscale,
+                                                                const int* __restrict__ slice_of, int slice, Part* part) {
+    __shared__ double sv[kBlock / 64], ss[kBlock / 64];
+    __shared__ int si[kBlock / 64], sc[kBlock / 64];
+    const double dj = colscale[S->jn];
+    double best = 0.0, sum = 0.0;
+    int bi = INT_MAX, cnt = 0;
+    IPXK_GRID_STRIDE(p, m) {
+        const double pivot = lhs[p];
+        const double scaled = pivot * dj * invscale[p];
+        const double v = fabs(scaled);
+        if (fabs(pivot) > kPivotZeroTol && (v > best || (v == best && v > 0.0 && (int)p < bi))) { best = v; bi = (int)p; }
+        if (slice_of[p] == slice) sum += scaled;
+        cnt += pivot != 0.0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double ov = __shfl_xor(best, d, 64);
+        const int oi = __shfl_xor(bi, d, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        sum += __shfl_xor(sum, d, 64);
+        cnt += __shfl_xor(cnt, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sv[w] = best; si[w] = bi; ss[w] = sum; sc[w] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kBlock / 64; k++) {
+            if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+            sum += ss[k];
+            cnt += sc[k];
+        }
+        part[blockIdx.x] = Part{best, bi, sum, cnt};
+    }
+}
+__global__ void mv_scale_ftran_final_kernel(int nparts, const Part* part, const double* __restrict__ lhs,
+                                            const double* __restrict__ colscale, const double* __restrict__ invscale,
+                                            const int* __restrict__ slice_of, int slice, const ipxint* __restrict__ basis, Scalars* S) {
+    double best = 0.0, sum = 0.0;
+    int bi = INT_MAX, cnt = 0;
+    for (int k = 0; k < nparts; k++) {
+        if (part[k].v > best || (part[k].v == best && part[k].i < bi)) { best = part[k].v; bi = part[k].i; }
+        sum += part[k].s;
+        cnt += part[k].c;
+    }
+    const int pmax = bi == INT_MAX ? 0 : bi;        // no entry qualified: position 0 (:325, :255-256)
+    const double dj = colscale[S->jn];
+    S->pmax = pmax;
+    S->jb = (int)basis[pmax];
+    S->vmax = fabs(lhs[pmax] * dj * invscale[pmax]);
+    S->weight_recomp = sum;
+    S->colscale_jn = dj;
+    S->invscale_pmax = invscale[pmax];
+    S->pivot_col = lhs[pmax];
+    S->used_pmax = slice_of[pmax] == slice ? 1 : 0;
+    S->eta_nnz = cnt;
+}
+// skipped column (:259-266)
+__global__ void mv_skip_kernel(const Scalars* S, double* colweights, double* colscale) {
+    colweights[S->jn] = 0.0;
+    colscale[S->jn] = 0.0;
+}
+// ---- tableau row ----------------------------------------------------------------------------------------------
+__global__ void mv_unit_kernel(int m, const Scalars* S, double* v) {
+    IPXK_GRID_STRIDE(p, m) v[p] = (int)p == S->pmax ? 1.0 : 0.0;
+}
+__global__ void mv_row_slack_kernel(int m, int n, const double* __restrict__ btran, const double* __restrict__ mask,
+                                    double* __restrict__ row) {
+    IPXK_GRID_STRIDE(i, m) row[n + i] = mask[n + i] != 0.0 ? btran[i] : 0.0;
+}
+__global__ void mv_read_pivot_kernel(const double* __restrict__ row, Scalars* S) { S->pivot_row = row[S->jn]; }
+// ---- exchange ---------------------------------------------------------------------------------------------------
+__global__ void mv_eta_flag_kernel(int m, const Scalars* S, const double* __restrict__ lhs, int* __restrict__ flag) {
+    IPXK_GRID_STRIDE(p, m) flag[p] = ((int)p != S->pmax && lhs[p] != 0.0) ? 1 : 0;
+}
+__global__ void mv_eta_store_kernel(int m, int K, const Scalars* S, const double* __restrict__ lhs, const int* __restrict__ flag,
+                                    const int* __restrict__ rank, int* ptr, int* pos, double* piv, int* idx, double* val, Scalars* Sout) {
+    const int base = ptr[K];
+    IPXK_GRID_STRIDE(p, m) {
+        if (flag[p]) { idx[base + rank[p]] = (int)p; val[base + rank[p]] = lhs[p]; }
+        if (p == m - 1) {
+            ptr[K + 1] = base + rank[p] + flag[p];
+            pos[K] = S->pmax;
+            piv[K] = lhs[S->pmax];
+            Sout->eta_total = base + rank[p] + flag[p];
+        }
+    }
+}
+// colweights update (:307-314); colscale / invscale_basic / basis / the NONBASIC mask by the kernel that follows
+__global__ void mv_weights_kernel(int64_t N, const Scalars* S, double alpha, const double* __restrict__ row,
+                                  const double* __restrict__ colscale, double* __restrict__ colweights) {
+    const int jn = S->jn, jb = S->jb;
+    const double wjb = (double)S->used_pmax + alpha / S->invscale_pmax;
+    IPXK_GRID_STRIDE(j, N) {
+        if ((int)j == jb) colweights[j] = wjb;
+        else if ((int)j == jn) colweights[j] = 0.0;
+        else colweights[j] += alpha * row[j] * colscale[j];
+    }
+}
+__global__ void mv_exchange_kernel(const Scalars* S, ipxint* basis, int* map2basis, double* colscale, double* invscale, double* mask) {
+    const int jn = S->jn, jb = S->jb, p = S->pmax;
+    colscale[jb] = 1.0 / S->invscale_pmax;          // :301-303
+    invscale[p] = 1.0 / S->colscale_jn;
+    colscale[jn] = 0.0;
+    basis[p] = jn;                                  // Basis::ExchangeIfStable :308-313
+    map2basis[jn] = p;
+    map2basis[jb] = -1;
+    mask[jn] = 0.0;
+    mask[jb] = 1.0;
+}
+// ---- set-up -------------------------------------------------------------------------------------------------------
+__global__ void mv_init_columns_kernel(int64_t N, const ipxint* __restrict__ status, const double* __restrict__ colscale_in,
+                                       double* __restrict__ colscale, double* __restrict__ mask, int* __restrict__ map2basis) {
+    IPXK_GRID_STRIDE(j, N) {
+        const ipxint st = status[j];
+        colscale[j] = st == IPXK_NONBASIC ? colscale_in[j] : 0.0;        // :130-133
+        mask[j] = st == IPXK_NONBASIC ? 1.0 : 0.0;                       // TableauRow with ignore_fixed
+        map2basis[j] = st == IPXK_NONBASIC_FIXED ? -2 : -1;              // basic ones by mv_init_basis_kernel
+    }
+}
+__global__ void mv_init_basis_kernel(int m, const ipxint* __restrict__ basis, const ipxint* __restrict__ status,
+                                     const double* __restrict__ colscale_in, double* __restrict__ invscale, int* __restrict__ map2basis) {
+    IPXK_GRID_STRIDE(p, m) {
+        const ipxint j = basis[p];
+        invscale[p] = status[j] == IPXK_BASIC ? 1.0 / colscale_in[j] : 0.0;   // :120-126 (BASIC_FREE: 0, never leaves)
+        map2basis[j] = status[j] == IPXK_BASIC_FREE ? (int)p + m : (int)p;
+    }
+}
+__global__ void mv_slice_work_kernel(int m, const double* __restrict__ invscale, const int* __restrict__ slice_of, int slice,
+                                     double* __restrict__ work) {
+    IPXK_GRID_STRIDE(p, m) work[p] = slice_of[p] == slice ? invscale[p] : 0.0;     // :221-223
+}
+__global__ void mv_weights_slack_kernel(int m, int n, const double* __restrict__ work, const double* __restrict__ colscale,
+                                        double* __restrict__ colweights) {
+    IPXK_GRID_STRIDE(i, m) colweights[n + i] = colscale[n + i] != 0.0 ? work[i] * colscale[n + i] : 0.0;
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+struct MaxvolState {
+    DevBuf<double> colscale, invscale, colweights, row, mask, rhs, lhs, unit, btran, work;
+    DevBuf<int> map2basis, slice_of, flag, rank, eta_ptr, eta_pos, eta_idx;
+    DevBuf<double> eta_piv, eta_val;
+    DevBuf<ipxint> basis, status;
+    DevBuf<Part> part;
+    DevBuf<Scalars> scalars;
+    DevBuf<unsigned char> tmp;
+    Scalars* h = nullptr;      // pinned
+    ~MaxvolState() { if (h) (void)hipHostFree(h); }
+};
+void destroy_maxvol(MaxvolState* M) { delete M; }
+
+void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_in, const ipxk_maxvolume_params* prm_in,
+                   ipxint* basis_out, ipxint* status_out, ipxk_maxvolume_info* info, ipxint* log, ipxint log_cap) {
+    const ipxk_maxvolume_params defaults{2.0, 10, 10000, 100};       // include/ipx_parameters.h:69-71
+    const ipxk_maxvolume_params* prm = prm_in ? prm_in : &defaults;
+    LuView V;
+    IPXK_REQUIRE(lu_view(c, &V) && V.from_basis && V.ndep == 0, "maxvolume needs the factorization of the current basis (ipxk_lu_factorize_basis)");
+    IPXK_REQUIRE(c->split, "maxvolume needs the operator of the current basis (ipxk_split_prepare_lu)");
+    const int m = (int)c->m, n = (int)c->n;
+    const int64_t N = (int64_t)n + m;
+    IPXK_REQUIRE(m > 0, "empty model");
+    hipStream_t s = c->stream;
+    if (!c->maxvol) c->maxvol = new MaxvolState;
+    MaxvolState& M = *c->maxvol;
+    const double t_start = now_s();
+    const double volumetol = std::max(prm->volume_tol, 1.0);
+    const int max_etas = (int)std::max<ipxint>(1, prm->max_etas > 0 ? prm->max_etas : 100);
+    const int64_t eta_cap = std::max<int64_t>(4 * (int64_t)m, int64_t(1) << 20);
+
+    for (DevBuf<double>* b : {&M.colscale, &M.colweights, &M.row, &M.mask}) b->ensure((size_t)N);
+    for (DevBuf<double>* b : {&M.invscale, &M.rhs, &M.lhs, &M.unit, &M.btran, &M.work}) b->ensure((size_t)m);
+    M.map2basis.ensure((size_t)N); M.slice_of.ensure((size_t)m); M.flag.ensure((size_t)m); M.rank.ensure((size_t)m);
+    M.eta_ptr.ensure((size_t)max_etas + 1); M.eta_pos.ensure((size_t)max_etas); M.eta_piv.ensure((size_t)max_etas);
+    M.eta_idx.ensure((size_t)eta_cap + m); M.eta_val.ensure((size_t)eta_cap + m);
+    M.part.ensure(kRedGrid); M.scalars.ensure(1);
+    if (!M.h) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&M.h), sizeof(Scalars)));
+
+    // host mirrors of basis and status (refactorizations, results)
+    std::vector<ipxint> basis_h((size_t)m), status_h(status_in, status_in + N);
+    IPXK_HIP(hipMemcpyAsync(basis_h.data(), V.basis, (size_t)m * sizeof(ipxint), hipMemcpyDeviceToHost, s));
+    DevBuf<double> colscale_dev;
+    colscale_dev.upload(colscale_in, (size_t)N, s);
+    M.status.upload(status_in, (size_t)N, s);
+    M.basis.ensure((size_t)m);
+    IPXK_HIP(hipMemcpyAsync(M.basis.get(), V.basis, (size_t)m * sizeof(ipxint), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(mv_init_columns_kernel, dim3(grid_for(N)), dim3(kBlock), 0, s, N, M.status.get(), colscale_dev.get(),
+                       M.colscale.get(), M.mask.get(), M.map2basis.get());
+    hipLaunchKernelGGL(mv_init_basis_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, M.basis.get(), M.status.get(), colscale_dev.get(),
+                       M.invscale.get(), M.map2basis.get());
+    // slices: Sortperm of invscale_basic ascending (value, index), row perm[i] belongs to slice i % num_slices (:138-142)
+    std::vector<double> inv_h((size_t)m);
+    M.invscale.download(inv_h.data(), (size_t)m, s);
+    IPXK_HIP(hipStreamSynchronize(s));
+    for (int p = 0; p < m; p++) IPXK_REQUIRE(basis_h[p] >= 0 && basis_h[p] < N && status_h[basis_h[p]] >= 0, "status of a basic variable is not BASIC / BASIC_FREE");
+    int num_slices = (int)std::min<int64_t>(m, 5 + std::max<int64_t>(m / std::max<ipxint>(prm->rows_per_slice, 1), 0));
+    {
+        std::vector<std::pair<double, int>> vi((size_t)m);
+        for (int p = 0; p < m; p++) vi[p] = std::make_pair(inv_h[p], p);
+        std::sort(vi.begin(), vi.end());
+        std::vector<int> slice_of((size_t)m);
+        for (int i = 0; i < m; i++) slice_of[vi[i].second] = i % num_slices;
+        M.slice_of.upload(slice_of, s);
+    }
+    const int zero = 0;
+    IPXK_HIP(hipMemcpyAsync(M.eta_ptr.get(), &zero, sizeof(int), hipMemcpyHostToDevice, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+
+    const int *Ap = nullptr, *Ai = nullptr;
+    const double* Ax = nullptr;
+    lu_plain_matrix(c, &Ap, &Ai, &Ax);
+
+    int K = 0;                                   // etas since the last factorization
+    int64_t eta_used = 0;
+    ipxk_maxvolume_info I{};
+    I.slices = num_slices;
+    auto read_scalars = [&]() {
+        IPXK_HIP(hipMemcpyAsync(M.h, M.scalars.get(), sizeof(Scalars), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+    };
+    auto apply_etas = [&](bool transposed, double* v) {
+        if (K == 0) return;
+        if (transposed) hipLaunchKernelGGL(mv_eta_btran_kernel, dim3(1), dim3(kEtaThreads), 0, s, K, M.eta_ptr.get(), M.eta_pos.get(),
+                                           M.eta_piv.get(), M.eta_idx.get(), M.eta_val.get(), v);
+        else hipLaunchKernelGGL(mv_eta_ftran_kernel, dim3(1), dim3(kEtaThreads), 0, s, K, M.eta_ptr.get(), M.eta_pos.get(),
+                                M.eta_piv.get(), M.eta_idx.get(), M.eta_val.get(), v);
+    };
+    auto refactorize = [&]() {                   // Basis::Factorize (src/basis.cc:116-156) + the operator of the sweeps
+        ipxk_lu_info li{};
+        lu_factorize_basis(c, basis_h.data(), 0.1, false, &li);
+        if (li.num_dependent > 0) throw Error(IPXK_E_ARGUMENT, "maxvolume: the basis became singular (IPX_ERROR_basis_singular)");
+        split_prepare_lu(c, status_h.data(), colscale_in);
+        lu_plain_matrix(c, &Ap, &Ai, &Ax);
+        K = 0;
+        eta_used = 0;
+        IPXK_HIP(hipMemcpyAsync(M.eta_ptr.get(), &zero, sizeof(int), hipMemcpyHostToDevice, s));
+        I.factorizations++;
+    };
+    const int gm = grid_for(m), gN = grid_for(N);
+    const bool verbose = getenv("IPXK_VERBOSE") != nullptr && getenv("IPXK_VERBOSE")[0] == '2';
+
+    for (int slice = 0; slice < num_slices; slice++) {
+        // ---- Driver: column weights of the slice (:221-232)
+        hipLaunchKernelGGL(mv_slice_work_kernel, dim3(gm), dim3(kBlock), 0, s, m, M.invscale.get(), M.slice_of.get(), slice, M.unit.get());
+        apply_etas(true, M.unit.get());
+        solve_dense_dev(c, M.unit.get(), M.work.get(), 'T');
+        {
+            EpiScale e{{}, M.colscale.get(), M.colweights.get()};
+            launch_spmv(c->Acols, M.work.get(), e, nullptr, nullptr, s);
+            hipLaunchKernelGGL(mv_weights_slack_kernel, dim3(gm), dim3(kBlock), 0, s, m, n, M.work.get(), M.colscale.get(), M.colweights.get());
+        }
+        int64_t skipped = 0;
+        while (true) {
+            // FindLargest, tableau column, ScaleFtran
+            hipLaunchKernelGGL(mv_argmax_kernel, dim3(kRedGrid), dim3(kBlock), 0, s, N, M.colweights.get(), M.part.get());
+            hipLaunchKernelGGL(mv_argmax_final_kernel, dim3(1), dim3(1), 0, s, kRedGrid, M.part.get(), M.colweights.get(), M.scalars.get());
+            IPXK_HIP(hipMemsetAsync(M.rhs.get(), 0, (size_t)m * sizeof(double), s));
+            hipLaunchKernelGGL(mv_scatter_column_kernel, dim3(4), dim3(kBlock), 0, s, n, M.scalars.get(), Ap, Ai, Ax, M.rhs.get());
+            solve_dense_dev(c, M.rhs.get(), M.lhs.get(), 'N');
+            apply_etas(false, M.lhs.get());
+            hipLaunchKernelGGL(mv_scale_ftran_kernel, dim3(kRedGrid), dim3(kBlock), 0, s, m, M.scalars.get(), M.lhs.get(), M.colscale.get(),
+                               M.invscale.get(), M.slice_of.get(), slice, M.part.get());
+            hipLaunchKernelGGL(mv_scale_ftran_final_kernel, dim3(1), dim3(1), 0, s, kRedGrid, M.part.get(), M.lhs.get(), M.colscale.get(),
+                               M.invscale.get(), M.slice_of.get(), slice, M.basis.get(), M.scalars.get());
+            read_scalars();
+            const Scalars a = *M.h;
+            if (verbose)
+                fprintf(stderr, "ipxk: maxvolume slice %d: jn %d weight %.3e pmax %d jb %d vmax %.3e (etas %d, updates %lld, skipped %lld)\n", slice,
+                        a.jn, a.weight, a.pmax, a.jb, a.vmax, K, (long long)I.updates, (long long)skipped);
+            if (a.weight == 0.0) break;                                             // :243-244
+            if (a.vmax <= volumetol) {                                              // :259-266
+                hipLaunchKernelGGL(mv_skip_kernel, dim3(1), dim3(1), 0, s, M.scalars.get(), M.colweights.get(), M.colscale.get());
+                if (++skipped > prm->maxskip_updates && prm->maxskip_updates >= 0) break;
+                continue;
+            }
+            // tableau row of the leaving variable (:278-280)
+            hipLaunchKernelGGL(mv_unit_kernel, dim3(gm), dim3(kBlock), 0, s, m, M.scalars.get(), M.unit.get());
+            apply_etas(true, M.unit.get());
+            solve_dense_dev(c, M.unit.get(), M.btran.get(), 'T');
+            {
+                EpiScale e{{}, M.mask.get(), M.row.get()};
+                launch_spmv(c->Acols, M.btran.get(), e, nullptr, nullptr, s);
+                hipLaunchKernelGGL(mv_row_slack_kernel, dim3(gm), dim3(kBlock), 0, s, m, n, M.btran.get(), M.mask.get(), M.row.get());
+            }
+            hipLaunchKernelGGL(mv_read_pivot_kernel, dim3(1), dim3(1), 0, s, M.row.get(), M.scalars.get());
+            read_scalars();
+            const double pivot = M.h->pivot_row;
+            // Basis::ExchangeIfStable (:286-321): the pivot from the row against the pivot from the column
+            const bool stable = a.pivot_col != 0.0 && std::abs(a.pivot_col - pivot) <= 1e-8 * std::abs(a.pivot_col);
+            if (!stable) {
+                I.refused++;
+                if (K == 0) { I.errflag = 306; break; }                             // IPX_ERROR_basis_too_ill_conditioned
+                refactorize();
+                continue;                                                           // "try again" (:290-291)
+            }
+            // the eta of this exchange
+            hipLaunchKernelGGL(mv_eta_flag_kernel, dim3(gm), dim3(kBlock), 0, s, m, M.scalars.get(), M.lhs.get(), M.flag.get());
+            {
+                size_t bytes = 0;
+                IPXK_HIP(rocprim::exclusive_scan(nullptr, bytes, M.flag.get(), M.rank.get(), 0, (size_t)m, rocprim::plus<int>(), s));
+                if (M.tmp.size() < bytes) M.tmp.resize(bytes);
+                IPXK_HIP(rocprim::exclusive_scan(M.tmp.get(), bytes, M.flag.get(), M.rank.get(), 0, (size_t)m, rocprim::plus<int>(), s));
+            }
+            hipLaunchKernelGGL(mv_eta_store_kernel, dim3(gm), dim3(kBlock), 0, s, m, K, M.scalars.get(), M.lhs.get(), M.flag.get(), M.rank.get(),
+                               M.eta_ptr.get(), M.eta_pos.get(), M.eta_piv.get(), M.eta_idx.get(), M.eta_val.get(), M.scalars.get());
+            const double alpha = ((double)a.used_pmax - a.weight_recomp) / (a.colscale_jn * pivot);      // :307
+            hipLaunchKernelGGL(mv_weights_kernel, dim3(gN), dim3(kBlock), 0, s, N, M.scalars.get(), alpha, M.row.get(), M.colscale.get(),
+                               M.colweights.get());
+            hipLaunchKernelGGL(mv_exchange_kernel, dim3(1), dim3(1), 0, s, M.scalars.get(), M.basis.get(), M.map2basis.get(), M.colscale.get(),
+                               M.invscale.get(), M.mask.get());
+            K++;
+            eta_used += a.eta_nnz;
+            if (log && I.updates < log_cap) { log[2 * I.updates] = a.jb; log[2 * I.updates + 1] = a.jn; }
+            I.updates++;
+            I.volinc += std::log2(a.vmax);                                          // :294
+            basis_h[(size_t)a.pmax] = a.jn;
+            status_h[(size_t)a.jn] = IPXK_BASIC;
+            status_h[(size_t)a.jb] = IPXK_NONBASIC;
+            if (K >= max_etas || eta_used + m > eta_cap) refactorize();             // NeedFreshFactorization (:318-319)
+        }
+        I.skipped += skipped;
+        if (I.errflag) break;
+    }
+    IPXK_HIP(hipStreamSynchronize(s));
+    check_sweep_abort(c);
+    // the tail of KKTSolverBasis::_Factorize (src/kkt_solver_basis.cc:56-61): a fresh factorization of the final
+    // basis and the operator built from it
+    // (IPXK_MAXVOL_SKIP_FINAL=1, measurements only: leaves the context with the factors of the last refactorized basis)
+    if (K > 0 && !I.errflag && !getenv("IPXK_MAXVOL_SKIP_FINAL")) refactorize();
+    IPXK_HIP(hipStreamSynchronize(s));
+    I.seconds = now_s() - t_start;
+    if (basis_out) std::copy(basis_h.begin(), basis_h.end(), basis_out);
+    if (status_out) std::copy(status_h.begin(), status_h.end(), status_out);
+    if (info) *info = I;
+}
+
+}  // namespace ipxk

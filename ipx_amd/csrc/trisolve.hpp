@@ -121,6 +121,7 @@ struct LuView {
     const ipxint *rowperm = nullptr, *colperm = nullptr, *basis = nullptr;
 };
 bool lu_view(const Context* c, LuView* out);
+void lu_plain_matrix(const Context* c, const int** Ap, const int** Ai, const double** Ax);
 void analyse_sweeps_device(Context* c, SplitOperator* S, const ipxint* Lp, const ipxint* Li, const double* Lx,
                            const ipxint* Up, const ipxint* Ui, const double* Ux);
 // (re)computes the column-scaled value sets of the U sweeps from S->uscale

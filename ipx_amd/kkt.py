@@ -33,7 +33,7 @@ EXPORTS = [
     "ipxk_kkt_basis_solve", "ipxk_newton_solve", "ipxk_iterate_set", "ipxk_iterate_get", "ipxk_iterate_update",
     "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_ipm_step", "ipxk_iterate_objectives", "ipxk_ipm_driver", "ipxk_iterate_factorize_diag", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns",
     "ipxk_time_normal_apply", "ipxk_equilibrate", "ipxk_transpose", "ipxk_lu_factorize", "ipxk_lu_factorize_basis",
-    "ipxk_lu_get_factors", "ipxk_split_prepare_lu",
+    "ipxk_lu_get_factors", "ipxk_split_prepare_lu", "ipxk_maxvolume",
     "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
     "ipxk_dev_download",
 ]
@@ -55,6 +55,15 @@ class LuInfo(C.Structure):
     _fields_ = [("lnz", c_i64), ("unz", c_i64), ("num_dependent", c_i64), ("col_singletons", c_i64),
                 ("row_singletons", c_i64), ("bump", c_i64), ("rounds", c_i64), ("seconds_singletons", c_f64),
                 ("seconds_bump", c_f64), ("seconds_assemble", c_f64)]
+
+
+class MaxvolumeParams(C.Structure):
+    _fields_ = [("volume_tol", c_f64), ("maxskip_updates", c_i64), ("rows_per_slice", c_i64), ("max_etas", c_i64)]
+
+
+class MaxvolumeInfo(C.Structure):
+    _fields_ = [("updates", c_i64), ("skipped", c_i64), ("slices", c_i64), ("refused", c_i64), ("factorizations", c_i64),
+                ("errflag", c_i64), ("volinc", c_f64), ("seconds", c_f64)]
 
 
 class IpmParams(C.Structure):
@@ -499,6 +508,21 @@ class KktContext:
     def split_prepare_lu(self, status, colscale):
         status, colscale = _I(status), _F(colscale)
         self._check(self.lib.ipxk_split_prepare_lu(self.h, _ip(status), _fp(colscale)))
+
+    def maxvolume(self, status, colscale, volume_tol=2.0, maxskip_updates=10, rows_per_slice=10000, max_etas=100,
+                  log_cap=100000):
+        """Maxvolume::RunHeuristic + refactorization + Prepare on the resident basis; returns dict(basis, status,
+        exchanges, info fields)"""
+        status, colscale = _I(status), _F(colscale)
+        prm = MaxvolumeParams(volume_tol, maxskip_updates, rows_per_slice, max_etas)
+        info = MaxvolumeInfo()
+        basis_out, status_out = np.zeros(self.m, i64), np.zeros(self.n + self.m, i64)
+        log = np.zeros(2 * max(log_cap, 1), i64)
+        self._check(self.lib.ipxk_maxvolume(self.h, _ip(status), _fp(colscale), C.byref(prm), _ip(basis_out), _ip(status_out),
+                                            C.byref(info), _ip(log), c_i64(log_cap)))
+        out = {name: getattr(info, name) for name, _ in MaxvolumeInfo._fields_}
+        out.update(basis=basis_out, status=status_out, exchanges=log[: 2 * min(info.updates, log_cap)].reshape(-1, 2))
+        return out
 
     def split_rescale(self, status, colscale):
         status, colscale = _I(status), _F(colscale)

@@ -252,7 +252,7 @@ def synthetic_iterate(m, n, seed, frac_special=0.15):
 
 
 def lp_like_basis_matrix(dim, bump=64, frac_rowsing=0.2, frac_slack=0.5, offdiag=2, window=None,
-                         bump_density=0.3, num_dependent=0, seed=12345):
+                         bump_density=0.3, num_dependent=0, seed=12345, shallow=False):
     """A nearly triangular matrix of the kind LP bases are (SURVEY 8f rank 1: the input of Basis::Factorize,
     reference src/basis.cc:116-156): in a hidden pivot order it is
         [ T   X   X ]   T: upper triangular, `frac_slack` of its columns unit columns, the others with up to
@@ -260,6 +260,9 @@ def lp_like_basis_matrix(dim, bump=64, frac_rowsing=0.2, frac_slack=0.5, offdiag
         [ 0   Y   R ]   R: LOWER triangular (its rows are row singletons once T is gone), entries below the diagonal;
                         D: the bump (bump x bump, `bump_density`, every row and column >= 2 entries);
     X, Y sparse.  `num_dependent` bump columns are made copies of other bump columns (a singular basis).
+    shallow: the unit columns of T come first and the other columns of T only reach into THEIR rows (a slack-heavy
+    basis: every structural column depends on slack rows only, so an exchanged column disturbs the triangular
+    order locally instead of blocking everything downstream of its row).
     Rows and columns are scrambled.  Returns dict(Bp, Bi, Bx (CSC, unsorted), dim, plus the planted sizes)."""
     import scipy.sparse as sp
     rng = np.random.default_rng(seed + 7)
@@ -276,12 +279,18 @@ def lp_like_basis_matrix(dim, bump=64, frac_rowsing=0.2, frac_slack=0.5, offdiag
     # T: diagonal + entries above it in the non-slack columns
     add(np.arange(n1), np.arange(n1))
     is_slack = rng.random(n1) < frac_slack
+    if shallow:
+        is_slack = np.arange(n1) < int(frac_slack * n1)
     v[-1][is_slack] = 1.0                    # unit columns: slack columns of [A I]
     nonslack = np.nonzero(~is_slack)[0]
     cols = np.repeat(nonslack, offdiag)
     span = cols if window is None else np.minimum(cols, window)
+    if shallow:
+        span = np.full(cols.size, int(frac_slack * n1))
     ok = span > 0
     rows = cols - 1 - (rng.random(cols.size) * span).astype(i64)
+    if shallow:
+        rows = (rng.random(cols.size) * span).astype(i64)
     add(rows[ok], cols[ok])
     # X: bump and R columns reach into the rows of T
     if n1 > 0:
@@ -320,7 +329,8 @@ def lp_like_basis_matrix(dim, bump=64, frac_rowsing=0.2, frac_slack=0.5, offdiag
     slack_cols = colperm[np.nonzero(is_slack)[0]]          # columns of B that are unit columns e_i ...
     slack_rows = rowperm[np.nonzero(is_slack)[0]]          # ... and their rows i
     return dict(dim=dim, Bp=B.indptr.astype(i64), Bi=B.indices.astype(i64), Bx=B.data.astype(f64),
-                planted=dict(T=n1, bump=bump, R=n3), slack_cols=slack_cols, slack_rows=slack_rows)
+                planted=dict(T=n1, bump=bump, R=n3), slack_cols=slack_cols, slack_rows=slack_rows,
+                rowperm=rowperm.astype(i64), colperm=colperm.astype(i64), is_slack_stage=is_slack)
 
 
 def lp_like_basis(m, n, seed=12345, **kw):
@@ -367,3 +377,54 @@ def synthetic_maxvolume_state(status, spread=1.0, seed=12345):
     d[status == 1] = np.inf
     d[status == -2] = 0.0
     return d
+
+
+def synthetic_misplaced_state(status, num_misplaced, spread=1.0, seed=12345):
+    """Scaling factors of an IPM iterate whose basis is nearly the maximum volume one: synthetic_basis_state (basic
+    variables large, nonbasic ones small), except that `num_misplaced` nonbasic variables have grown large and as
+    many basic ones small -- the few exchanges per IPM iteration that Maxvolume::RunHeuristic performs late in a
+    solve (reference src/kkt_solver_basis.cc:46-50)."""
+    rng = np.random.default_rng(seed + 9)
+    d = synthetic_basis_state(status, spread, seed)
+    nb = rng.choice(np.nonzero(status == -1)[0], num_misplaced, replace=False)
+    bs = rng.choice(np.nonzero(status == 0)[0], num_misplaced, replace=False)
+    d[nb] = 10.0 ** (spread * (1.0 + rng.uniform(0.0, 1.0, num_misplaced)))
+    d[bs] = 0.3 * 10.0 ** (-spread * rng.uniform(0.0, 1.0, num_misplaced))
+    return d
+
+
+def synthetic_slack_entering_state(P, num_entering, spread=1.0, seed=12345, gap=2.0):
+    """Scaling factors for the exchanges typical late in an interior point solve: `num_entering` constraints have
+    become inactive, i.e. their (nonbasic) slack variables have grown large while the structural variable that
+    is pivoted on that row in the planted triangular order has become small.  Maxvolume then brings those slacks
+    into the basis; a unit column entering on its own row leaves the triangular order of the basis intact, so
+    refactorizations stay within the reach of a singleton-based LU.  All other variables are well separated
+    (`gap` decades between basic and nonbasic scaling factors), as they are when the IPM has nearly converged.
+    P: result of lp_like_basis."""
+    rng = np.random.default_rng(seed + 13)
+    status, basis, G = P["status"], P["basis"], P["G"]
+    n = P["A"].ncol
+    d = synthetic_basis_state(status, spread, seed)
+    d = np.where(status >= 0, d * 10.0 ** gap, d * 10.0 ** (-gap))
+    n1 = G["planted"]["T"]
+    stages = np.nonzero(~G["is_slack_stage"])[0]                 # triangular stages pivoted by a structural column
+    pick = rng.choice(stages, num_entering, replace=False)
+    rows = G["rowperm"][pick]                                    # their pivot rows ...
+    leaving = basis[G["colperm"][pick]]                          # ... and the structural variables pivoted there
+    assert np.all(status[n + rows] == -1) and np.all(leaving < n)
+    d[n + rows] = 10.0 ** (gap + spread * (1.0 + rng.uniform(0.0, 1.0, num_entering)))
+    d[leaving] = 0.3 * 10.0 ** (-gap - spread * rng.uniform(0.0, 1.0, num_entering))
+    return d
+
+
+def slack_basis_crash_state(m, n, num_entering, spread=1.0, seed=12345):
+    """The situation of the first Maxvolume call of a solve: the basis is the slack basis (reference
+    src/lp_solver.cc builds its starting basis from the slack basis by Maxvolume) and `num_entering` structural
+    variables carry large scaling factors, all others small ones.  With num_entering^2 << m the entering columns
+    hardly share rows, so the basis stays triangular by singletons.  Returns (basis, status, colscale)."""
+    rng = np.random.default_rng(seed + 17)
+    status = np.concatenate([np.full(n, -1, dtype=i64), np.zeros(m, dtype=i64)])
+    basis = n + np.arange(m, dtype=i64)
+    d = np.concatenate([0.3 * 10.0 ** (-spread * rng.uniform(0.0, 1.0, n)), 10.0 ** (spread * rng.uniform(0.0, 1.0, m))])
+    d[rng.choice(n, num_entering, replace=False)] = 10.0 ** (2.0 + spread * rng.uniform(0.0, 1.0, num_entering))
+    return basis, status, d

@@ -1,0 +1,78 @@
+"""GPU: Maxvolume on the device (ipxk_maxvolume) against the CPU restatement of
+Maxvolume::RunHeuristic (oracle; its basis operations are pinned against the reference's ForrestTomlin in
+tests/test_maxvolume_oracle.py): the same exchanges in the same order, the same final basis, the same counters;
+the volume gained to 1e-9; and on return the context holds the operator of the NEW basis."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from ipx_amd import synth
+from test_maxvolume_oracle import basis_matrix, setup
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kkt():
+    from ipx_amd import kkt as k
+    k.load_library()
+    assert k.load_library().ipxk_device_count() > 0, "no GPU visible"
+    return k
+
+
+@pytest.fixture(scope="module")
+def po():
+    from oracle import pyoracle
+    return pyoracle
+
+
+@pytest.mark.parametrize("m,n,bump,seed,free,fixed,max_etas,rps", [
+    (300, 700, 20, 4, 0, 0, 100, 100), (1200, 2600, 60, 8, 0, 0, 7, 100), (200, 450, 15, 5, 3, 6, 4, 50),
+    (1000, 2300, 50, 11, 2, 5, 25, 300)])
+def test_maxvolume_vs_oracle(kkt, oracle, po, m, n, bump, seed, free, fixed, max_etas, rps):
+    P, status, colscale, Ao = setup(po, m, n, bump, seed, num_free=free, num_fixed=fixed)
+    B = oracle.basis(Ao, P["basis"], status, max_etas=max_etas)
+    want = B.maxvolume(colscale, volume_tol=2.0, maxskip_updates=10, rows_per_slice=rps)
+    assert want["errflag"] == 0 and want["updates"] > 5
+    ctx = kkt.KktContext(P["A"])
+    ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+    ctx.split_prepare_lu(status, colscale)
+    got = ctx.maxvolume(status, colscale, volume_tol=2.0, maxskip_updates=10, rows_per_slice=rps, max_etas=max_etas)
+    assert got["errflag"] == 0
+    assert np.array_equal(got["exchanges"], want["exchanges"])
+    assert (got["updates"], got["skipped"], got["slices"], got["refused"]) == \
+        (want["updates"], want["skipped"], want["slices"], want["refused"])
+    assert got["volinc"] == pytest.approx(want["volinc"], rel=1e-9)
+    basis_o, status_o, counts = B.get()
+    assert np.array_equal(got["basis"], basis_o) and np.array_equal(got["status"], status_o)
+    assert got["factorizations"] == counts["factorizations"] - 1 + (1 if counts["etas"] > 0 else 0)
+    # the context now holds the fresh factorization and the operator of the new basis
+    Bm = basis_matrix(Ao, got["basis"])
+    rhs = np.random.default_rng(3).standard_normal(m)
+    x = ctx.solve_dense(rhs, "n")
+    assert np.abs(Bm @ x - rhs).max() <= 1e-8 * (1 + np.abs(x).max())
+    lhs1, dot1 = ctx.split_apply(rhs)
+    F = ctx.lu_factorize_basis(got["basis"], 0.1)
+    ctx.split_prepare(F["L"], F["U"], F["rowperm"], F["colperm"], got["basis"], got["status"], colscale)
+    lhs2, dot2 = ctx.split_apply(rhs)
+    assert np.array_equal(lhs1, lhs2) and dot1 == dot2
+    ctx.close()
+
+
+def test_maxvolume_preconditions_and_no_op(kkt, po, oracle):
+    P, status, colscale, Ao = setup(po, 300, 700, 20, 4)
+    ctx = kkt.KktContext(P["A"])
+    with pytest.raises(kkt.KktError, match="ipxk_lu_factorize_basis"):
+        ctx.maxvolume(status, colscale)
+    ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+    with pytest.raises(kkt.KktError, match="ipxk_split_prepare_lu"):
+        ctx.maxvolume(status, colscale)
+    # a basis that already holds the large scaling factors: nothing to exchange, nothing refactorized
+    good = synth.synthetic_basis_state(status, 1.0, 4)
+    ctx.split_prepare_lu(status, good)
+    got = ctx.maxvolume(status, good, volume_tol=2.0)
+    want = oracle.basis(Ao, P["basis"], status).maxvolume(good, volume_tol=2.0)
+    assert got["updates"] == want["updates"] and got["skipped"] == want["skipped"]
+    if got["updates"] == 0:
+        assert got["factorizations"] == 0 and np.array_equal(got["basis"], P["basis"])
+    ctx.close()

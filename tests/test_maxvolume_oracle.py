@@ -37,7 +37,7 @@ def po():
     return pyoracle
 
 
-@pytest.mark.parametrize("m,n,bump,seed", [(300, 700, 20, 4), (1200, 2600, 60, 8)])
+@pytest.mark.parametrize("m,n,bump,seed", [(300, 700, 20, 4), (700, 1600, 40, 8)])
 def test_basis_operations_against_reference_forrest_tomlin(oracle, ref, po, m, n, bump, seed):
     P, status, colscale, Ao = setup(po, m, n, bump, seed)
     B = oracle.basis(Ao, P["basis"], status, max_etas=7)         # several refactorizations on the way
