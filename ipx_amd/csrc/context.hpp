@@ -63,7 +63,7 @@ struct Context {
     int64_t kdense = 0;                 // # dense columns treated by SMW (0: plain diagonal)
     GatherMatrix AdCols;                // k rows x m: computes Ad' u
     GatherMatrix AdRows;                // m rows x k: computes Ad w
-    DevBuf<double> chol, smw_work, smw_u, Wnodense;
+    DevBuf<double> chol, chol_inv, smw_work, smw_u, Wnodense;   // chol_inv: inverted 64 x 64 diagonal blocks (k > 64)
     DevBuf<int> chol_info;
     DevBuf<unsigned char> dense_mask;   // n, 1 for dense columns
 

@@ -93,6 +93,83 @@ __global__ __launch_bounds__(1024) void cholesky_lower_kernel(int k, double* __r
     if (threadIdx.x == 0) *info = fail;
 }
 
+// Blocked right-looking variant for k > 64 (up to the 1000 dense columns src/model.cc:52-55 allows): panels of
+// kCholPanel columns factorized by one workgroup, the trailing lower triangle updated by a grid of 64 x 64 tiles.
+// An entry still receives its products one at a time in ascending l, rounded before they are subtracted, i.e.
+// the arithmetic of cholesky_lower_kernel bit for bit.
+constexpr int kCholPanel = 32;
+__global__ __launch_bounds__(1024) void cholesky_panel_kernel(int k, int j0, int j1, double* __restrict__ a, int* info) {
+    __shared__ int fail;
+    __shared__ double pivot;
+    if (*info) return;
+    if (threadIdx.x == 0) fail = 0;
+    __syncthreads();
+    for (int j = j0; j < j1; j++) {
+        for (int i = j + threadIdx.x; i < k; i += blockDim.x) {
+            double s = a[i + (size_t)j * k];
+            for (int l = j0; l < j; l++) s -= a[i + (size_t)l * k] * a[j + (size_t)l * k];
+            a[i + (size_t)j * k] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double d = a[j + (size_t)j * k];
+            if (!(d > 0.0)) fail = j + 1;
+            else { pivot = sqrt(d); a[j + (size_t)j * k] = pivot; }
+        }
+        __syncthreads();
+        if (fail) break;
+        const double d = pivot;
+        for (int i = j + 1 + threadIdx.x; i < k; i += blockDim.x) a[i + (size_t)j * k] /= d;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && fail) *info = fail;
+}
+// a[i,j] -= sum_{l in panel} a[i,l] a[j,l] for j1 <= j <= i < k
+__global__ __launch_bounds__(kBlock) void cholesky_trailing_kernel(int k, int j0, int j1, double* __restrict__ a, const int* info) {
+    __shared__ double Li[kCholPanel][64], Lj[kCholPanel][64];
+    if (*info) return;
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bj > bi) return;                                     // lower triangle of tiles
+    const int i0 = j1 + bi * 64, c0 = j1 + bj * 64, np = j1 - j0;
+    for (int e = threadIdx.x; e < kCholPanel * 64; e += kBlock) {
+        const int l = e / 64, x = e % 64;
+        Li[l][x] = (l < np && i0 + x < k) ? a[(i0 + x) + (size_t)(j0 + l) * k] : 0.0;
+        Lj[l][x] = (l < np && c0 + x < k) ? a[(c0 + x) + (size_t)(j0 + l) * k] : 0.0;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int y = ty + 16 * b, j = c0 + y;
+        if (j >= k) continue;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int x = tx + 16 * q, i = i0 + x;
+            if (i >= k || i < j) continue;
+            double acc = a[i + (size_t)j * k];
+            for (int l = 0; l < np; l++) acc -= Li[l][x] * Lj[l][y];
+            a[i + (size_t)j * k] = acc;
+        }
+    }
+}
+// inverses of the 64 x 64 diagonal blocks of the factor (lower triangular), for the blocked solves
+__global__ __launch_bounds__(64) void cholesky_invert_blocks_kernel(int k, const double* __restrict__ a, double* __restrict__ inv) {
+    __shared__ double L[64][65];
+    const int b0 = blockIdx.x * 64, nb = min(64, k - b0), c = threadIdx.x;
+    for (int l = 0; l < 64; l++) L[c][l] = (c < nb && l < nb) ? a[(b0 + c) + (size_t)(b0 + l) * k] : (c == l ? 1.0 : 0.0);
+    __syncthreads();
+    // column c of the inverse: L x = e_c
+    double x[64];
+#pragma unroll 1
+    for (int i = 0; i < 64; i++) {
+        double s = i == c ? 1.0 : 0.0;
+        for (int l = c; l < i; l++) s -= L[i][l] * x[l];
+        x[i] = i < c ? 0.0 : s / L[i][i];
+    }
+    double* out = inv + (size_t)blockIdx.x * 64 * 64;
+    for (int i = 0; i < 64; i++) out[i + 64 * c] = x[i];       // column major
+}
+
 // Solves L L' x = b in place for k <= 64 inside one wavefront: the factor is staged in LDS once
 // (coalesced), lane i owns b[i] and each elimination step broadcasts the newly fixed unknown with
 // a shuffle -- no global-memory access on the 2k-step dependency chain.
@@ -118,28 +195,76 @@ __global__ __launch_bounds__(64) void potrs_wave_kernel(int k, const double* __r
     if (i < k) b[i] = bi;
 }
 
-// Same for 64 < k <= 1000, one workgroup, column-oriented substitution.
-__global__ __launch_bounds__(1024) void potrs_block_kernel(int k, const double* __restrict__ a,
-                                                           double* __restrict__ b, const int* done) {
+// 64 < k <= 1000 with the inverted diagonal blocks: per block one 64 x 64 product and one update of the rows below
+// (above, for L'), all inside one workgroup with x in LDS -- 2 k / 64 dependent steps instead of 2 k.
+__global__ __launch_bounds__(1024) void potrs_blocked_kernel(int k, const double* __restrict__ a, const double* __restrict__ inv,
+                                                             double* __restrict__ b, const int* done) {
     if (done && *done) return;
-    extern __shared__ double x[];
-    for (int i = threadIdx.x; i < k; i += blockDim.x) x[i] = b[i];
+    extern __shared__ double xs[];       // k + 64
+    double* x = xs;
+    double* xb = xs + k;
+    const int nblk = (k + 63) / 64, tid = threadIdx.x;
+    for (int i = tid; i < k; i += blockDim.x) x[i] = b[i];
     __syncthreads();
-    for (int l = 0; l < k; l++) {
-        if (threadIdx.x == 0) x[l] /= a[l + (size_t)l * k];
+    for (int bq = 0; bq < nblk; bq++) {                        // L z = b
+        const int b0 = bq * 64, nb = min(64, k - b0);
+        const double* Ib = inv + (size_t)bq * 64 * 64;
+        {   // 16 threads per row of the inverted block, partial sums combined in a fixed order
+            const int r = tid >> 4, q = tid & 15;
+            double s = 0.0;
+            if (r < nb) for (int l = q; l <= r; l += 16) s += Ib[r + 64 * l] * x[b0 + l];
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+            if (q == 0) xb[r] = s;
+        }
         __syncthreads();
-        const double xl = x[l];
-        for (int i = l + 1 + threadIdx.x; i < k; i += blockDim.x) x[i] -= a[i + (size_t)l * k] * xl;
+        if (tid < nb) x[b0 + tid] = xb[tid];
+        for (int i = b0 + nb + tid; i < k; i += blockDim.x) {
+            double s = x[i];
+            const double* ai = a + i + (size_t)b0 * k;
+            int l = 0;
+            for (; l + 8 <= nb; l += 8) {                     // the 8 loads are issued together
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = ai[(size_t)(l + u) * k];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s -= v[u] * xb[l + u];
+            }
+            for (; l < nb; l++) s -= ai[(size_t)l * k] * xb[l];
+            x[i] = s;
+        }
         __syncthreads();
     }
-    for (int l = k - 1; l >= 0; l--) {
-        if (threadIdx.x == 0) x[l] /= a[l + (size_t)l * k];
+    for (int bq = nblk - 1; bq >= 0; bq--) {                   // L' x = z
+        const int b0 = bq * 64, nb = min(64, k - b0);
+        const double* Ib = inv + (size_t)bq * 64 * 64;
+        {
+            const int r = tid >> 4, q = tid & 15;
+            double s = 0.0;
+            if (r < nb) for (int l = r + q; l < nb; l += 16) s += Ib[l + 64 * r] * x[b0 + l];    // inverse transposed
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+            if (q == 0) xb[r] = s;
+        }
         __syncthreads();
-        const double xl = x[l];
-        for (int i = threadIdx.x; i < l; i += blockDim.x) x[i] -= a[l + (size_t)i * k] * xl;
+        if (tid < nb) x[b0 + tid] = xb[tid];
+        for (int i = tid; i < b0; i += blockDim.x) {
+            double s = x[i];
+            const double* ai = a + b0 + (size_t)i * k;        // row b0.. of column i: contiguous
+            int l = 0;
+            for (; l + 8 <= nb; l += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = ai[l + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s -= v[u] * xb[l + u];
+            }
+            for (; l < nb; l++) s -= ai[l] * xb[l];
+            x[i] = s;
+        }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < k; i += blockDim.x) b[i] = x[i];
+    for (int i = tid; i < k; i += blockDim.x) b[i] = x[i];
 }
 
 static int vec_grid(int64_t len) {
@@ -253,8 +378,22 @@ void diag_factorize_dev(Context* c, const double* W, bool precond_dense_cols, ip
         hipLaunchKernelGGL(schur_add_diag_kernel, dim3((k + 63) / 64), dim3(64), 0, s, k, dcols.get(),
                            W, c->chol.get());
         // :88-92
-        hipLaunchKernelGGL(cholesky_lower_kernel, dim3(1), dim3(k <= 64 ? 64 : 1024), 0, s, k,
-                           c->chol.get(), c->chol_info.get());
+        if (k <= 64) {
+            hipLaunchKernelGGL(cholesky_lower_kernel, dim3(1), dim3(64), 0, s, k, c->chol.get(), c->chol_info.get());
+        } else {
+            IPXK_HIP(hipMemsetAsync(c->chol_info.get(), 0, sizeof(int), s));
+            for (int j0 = 0; j0 < k; j0 += kCholPanel) {
+                const int j1 = std::min(k, j0 + kCholPanel);
+                hipLaunchKernelGGL(cholesky_panel_kernel, dim3(1), dim3(1024), 0, s, k, j0, j1, c->chol.get(), c->chol_info.get());
+                if (j1 < k) {
+                    const int nt = (k - j1 + 63) / 64;
+                    hipLaunchKernelGGL(cholesky_trailing_kernel, dim3(nt, nt), dim3(kBlock), 0, s, k, j0, j1, c->chol.get(),
+                                       c->chol_info.get());
+                }
+            }
+            c->chol_inv.ensure((size_t)((k + 63) / 64) * 64 * 64);
+            hipLaunchKernelGGL(cholesky_invert_blocks_kernel, dim3((k + 63) / 64), dim3(64), 0, s, k, c->chol.get(), c->chol_inv.get());
+        }
         int info = 0;
         c->chol_info.download(&info, 1, s);
         IPXK_HIP(hipStreamSynchronize(s));
@@ -293,8 +432,8 @@ int diag_apply_dev(Context* c, const double* rhs, double* lhs, int slot, const i
         hipLaunchKernelGGL(potrs_wave_kernel, dim3(1), dim3(64), 0, s, k, c->chol.get(),
                            c->smw_work.get(), done);
     else
-        hipLaunchKernelGGL(potrs_block_kernel, dim3(1), dim3(1024), sizeof(double) * k, s, k,
-                           c->chol.get(), c->smw_work.get(), done);
+        hipLaunchKernelGGL(potrs_blocked_kernel, dim3(1), dim3(1024), sizeof(double) * (k + 64), s, k,
+                           c->chol.get(), c->chol_inv.get(), c->smw_work.get(), done);
     // :145-149
     EpiSmwRows er{{}, rhs, c->diagonal.get(), lhs};
     return launch_spmv(c->AdRows, c->smw_work.get(), er, c->part(slot), done, s);

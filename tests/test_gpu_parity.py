@@ -133,7 +133,8 @@ def test_golden_basis(kkt):
 # HIP vs oracle on seeded inputs
 # --------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,num_dense,spread", [(64, 100, 0, 1.0), (2000, 4100, 0, 1.0),
-                                                  (3000, 6000, 5, 1.0), (5000, 9000, 0, 0.0)])
+                                                  (3000, 6000, 5, 1.0), (5000, 9000, 0, 0.0),
+                                                  (1500, 3100, 100, 1.0), (1600, 3300, 330, 1.0)])   # blocked Cholesky / solves
 def test_diag_path_vs_oracle(kkt, po, oracle, m, n, num_dense, spread):
     A, st = diag_problem(m, n, seed=21, spread=spread, num_dense=num_dense)
     Ao = ocsc(po, A)
@@ -164,7 +165,10 @@ def test_diag_path_vs_oracle(kkt, po, oracle, m, n, num_dense, spread):
     x1, y1, it1, e1, _ = ctx.kkt_diag_solve(st["a"], st["b"], tol, 500)
     x2, y2, it2, e2, _ = ko.solve(st["a"], st["b"], tol)
     assert e1 == e2 == 0 and iters_close(it1, it2)
-    assert relerr(y1, y2) < 1e-6 and relerr(x1, x2) < 1e-5
+    # many dense columns: the Schur complement is ill-conditioned enough for two runs that stop at the same
+    # tolerance to differ by more (the preconditioner applications above agree to 1e-12; the contract below holds)
+    loose = 100.0 if num_dense >= 100 else 1.0
+    assert relerr(y1, y2) < 1e-6 * loose and relerr(x1, x2) < 1e-5 * loose
     # the returned point satisfies the contract of src/kkt_solver.h:21-27
     res1, res2 = kkt_residual_diag(A, W2, st["a"], st["b"], x1, y1)
     assert np.abs(res2).max() < 1e-9 * max(1.0, np.abs(st["b"]).max() + np.abs(x1).max())
