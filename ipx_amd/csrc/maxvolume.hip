@@ -83,13 +83,30 @@ __global__ __launch_bounds__(kBlock) void mv_argmax_kernel(int64_t N, const doub
         part[blockIdx.x].i = bi;
     }
 }
-__global__ void mv_argmax_final_kernel(int nparts, const Part* part, const double* __restrict__ w, Scalars* S) {
-    double best = 0.0;
-    int bi = INT_MAX;
-    for (int k = 0; k < nparts; k++)
-        if (part[k].v > best || (part[k].v == best && part[k].i < bi)) { best = part[k].v; bi = part[k].i; }
-    S->jn = bi == INT_MAX ? 0 : bi;                 // all weights zero: index 0, weight 0 (the loop ends)
-    S->weight = w[S->jn];
+// one workgroup of kRedGrid threads: thread k holds partial k, the tree keeps (largest value, smallest index)
+__device__ __forceinline__ void final_argmax(double& best, int& bi, double* sv, int* si) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double ov = __shfl_xor(best, d, 64);
+        const int oi = __shfl_xor(bi, d, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 1; k < kRedGrid / 64; k++)
+            if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+}
+__global__ __launch_bounds__(kRedGrid) void mv_argmax_final_kernel(int nparts, const Part* part, const double* __restrict__ w, Scalars* S) {
+    __shared__ double sv[kRedGrid / 64];
+    __shared__ int si[kRedGrid / 64];
+    double best = (int)threadIdx.x < nparts ? part[threadIdx.x].v : 0.0;
+    int bi = (int)threadIdx.x < nparts ? part[threadIdx.x].i : INT_MAX;
+    final_argmax(best, bi, sv, si);
+    if (threadIdx.x == 0) {
+        S->jn = bi == INT_MAX ? 0 : bi;             // all weights zero: index 0, weight 0 (the loop ends)
+        S->weight = w[S->jn];
+    }
 }
 
 // ---- tableau column -----------------------------------------------------------------------------------------
@@ -168,16 +185,20 @@ __global__ __launch_bounds__(kBlock) void mv_scale_ftran_kernel(int m, const Sca
         part[blockIdx.x] = Part{best, bi, sum, cnt};
     }
 }
-__global__ void mv_scale_ftran_final_kernel(int nparts, const Part* part, const double* __restrict__ lhs,
+__global__ __launch_bounds__(kRedGrid) void mv_scale_ftran_final_kernel(int nparts, const Part* part, const double* __restrict__ lhs,
                                             const double* __restrict__ colscale, const double* __restrict__ invscale,
                                             const int* __restrict__ slice_of, int slice, const ipxint* __restrict__ basis, Scalars* S) {
-    double best = 0.0, sum = 0.0;
-    int bi = INT_MAX, cnt = 0;
-    for (int k = 0; k < nparts; k++) {
-        if (part[k].v > best || (part[k].v == best && part[k].i < bi)) { best = part[k].v; bi = part[k].i; }
-        sum += part[k].s;
-        cnt += part[k].c;
-    }
+    __shared__ double sv[kRedGrid / 64], ss[kRedGrid / 64];
+    __shared__ int si[kRedGrid / 64], sc[kRedGrid / 64];
+    const bool have = (int)threadIdx.x < nparts;
+    double best = have ? part[threadIdx.x].v : 0.0, sum = have ? part[threadIdx.x].s : 0.0;
+    int bi = have ? part[threadIdx.x].i : INT_MAX, cnt = have ? part[threadIdx.x].c : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { sum += __shfl_xor(sum, d, 64); cnt += __shfl_xor(cnt, d, 64); }
+    if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = sum; sc[threadIdx.x >> 6] = cnt; }
+    final_argmax(best, bi, sv, si);                  // (its barrier also publishes ss / sc)
+    if (threadIdx.x != 0) return;
+    for (int k = 1; k < kRedGrid / 64; k++) { sum += ss[k]; cnt += sc[k]; }
     const int pmax = bi == INT_MAX ? 0 : bi;        // no entry qualified: position 0 (:325, :255-256)
     const double dj = colscale[S->jn];
     S->pmax = pmax;
@@ -390,14 +411,14 @@ void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_i
         while (true) {
             // FindLargest, tableau column, ScaleFtran
             hipLaunchKernelGGL(mv_argmax_kernel, dim3(kRedGrid), dim3(kBlock), 0, s, N, M.colweights.get(), M.part.get());
-            hipLaunchKernelGGL(mv_argmax_final_kernel, dim3(1), dim3(1), 0, s, kRedGrid, M.part.get(), M.colweights.get(), M.scalars.get());
+            hipLaunchKernelGGL(mv_argmax_final_kernel, dim3(1), dim3(kRedGrid), 0, s, kRedGrid, M.part.get(), M.colweights.get(), M.scalars.get());
             IPXK_HIP(hipMemsetAsync(M.rhs.get(), 0, (size_t)m * sizeof(double), s));
             hipLaunchKernelGGL(mv_scatter_column_kernel, dim3(4), dim3(kBlock), 0, s, n, M.scalars.get(), Ap, Ai, Ax, M.rhs.get());
             solve_dense_dev(c, M.rhs.get(), M.lhs.get(), 'N');
             apply_etas(false, M.lhs.get());
             hipLaunchKernelGGL(mv_scale_ftran_kernel, dim3(kRedGrid), dim3(kBlock), 0, s, m, M.scalars.get(), M.lhs.get(), M.colscale.get(),
                                M.invscale.get(), M.slice_of.get(), slice, M.part.get());
-            hipLaunchKernelGGL(mv_scale_ftran_final_kernel, dim3(1), dim3(1), 0, s, kRedGrid, M.part.get(), M.lhs.get(), M.colscale.get(),
+            hipLaunchKernelGGL(mv_scale_ftran_final_kernel, dim3(1), dim3(kRedGrid), 0, s, kRedGrid, M.part.get(), M.lhs.get(), M.colscale.get(),
                                M.invscale.get(), M.slice_of.get(), slice, M.basis.get(), M.scalars.get());
             read_scalars();
             const Scalars a = *M.h;

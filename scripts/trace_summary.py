@@ -7,7 +7,7 @@ f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 dur = collections.defaultdict(list)
 for r in rows:
-    name = r["Kernel_Name"].split("(")[0].replace("void ipxk::", "").replace("ipxk::", "")
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ipxk::", "").replace("ipxk::", "")
     key = name
     if "sweep_run_kernel" in name:
         key = "%s grid=%s" % (name, r.get("Grid_Size_X", r.get("Grid_Size", "?")))
