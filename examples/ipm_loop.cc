@@ -4,6 +4,9 @@
 // in solver form (AI = [A I]), puts an interior iterate on the device and repeats what IPM::Driver
 // does per iteration (reference src/ipm.cc:74-150): KKTSolver::Factorize for the current iterate, then
 // predictor + corrector + step sizes + update (ipxk_ipm_step).  Prints the residual norms and mu.
+// Then -- as LpSolver does when it switches from the initial to the main IPM (src/lp_solver.cc:375-462) -- the
+// basis-preconditioned phase: ipxk_ipm_driver_basis runs IPM::Driver around the basis solver (Maxvolume, LU
+// factorization and Prepare on the device every iteration) from the slack basis until the termination test holds.
 //
 //   g++ -std=c++14 -O2 -Iinclude examples/ipm_loop.cc -Lipx_amd/lib -lipx_kkt_hip -Wl,-rpath,$PWD/ipx_amd/lib -o ipm_loop
 #include <algorithm>
@@ -72,6 +75,14 @@ int main(int argc, char** argv) {
     double comp[4];
     CHECK(ipxk_iterate_complementarity(ctx, comp));
     std::printf("final mu %.3e\n", comp[1]);
+    if (argc > 4 && std::atoi(argv[4]) != 0) {           // main IPM with the basis solver
+        ipxk_ipm_params prm{0.3, 1e-6, 1e-8, -1, 100, 1};
+        ipxk_ipm_info info;
+        CHECK(ipxk_ipm_driver_basis(ctx, b.data(), c.data(), lb.data(), ub.data(), &prm, &info, nullptr, nullptr, nullptr, nullptr));
+        std::printf("main IPM: status %ld after %ld iterations, %ld CR iterations, %ld basis updates; pobjective %.10e dobjective %.10e "
+                    "presidual %.2e dresidual %.2e\n", (long)info.status_ipm, (long)info.iter, (long)info.kktiter, (long)info.basis_updates,
+                    info.pobjective, info.dobjective, info.presidual, info.dresidual);
+    }
     ipxk_destroy(ctx);
     return 0;
 }

@@ -427,11 +427,27 @@ typedef struct ipxk_ipm_info {
     double pobjective, dobjective;       /* after postprocessing */
     double presidual, dresidual, complementarity, mu;
     double step_primal, step_dual;       /* of the last step */
+    ipxint basis_updates;                /* ipxk_ipm_driver_basis: exchanges by Maxvolume (Info::updates_ipm) */
 } ipxk_ipm_info;
 int ipxk_ipm_driver(ipxk_context* ctx, const double* b, const double* c,
                     const double* lb, const double* ub,
                     const ipxk_ipm_params* params, ipxk_ipm_info* info,
                     ipxk_interrupt_fn interrupt, void* interrupt_user);
+
+/* The main IPM phase (LpSolver::RunMainIPM, src/lp_solver.cc:456-462): IPM::Driver around KKTSolverBasis.
+ * Every iteration's KKTSolverBasis::_Factorize (src/kkt_solver_basis.cc:20-63) runs on the device: scaling
+ * factors from the resident iterate (Iterate::ScalingFactor, src/iterate.cc:183-198), Maxvolume
+ * (ipxk_maxvolume), fresh factorization, Prepare; then the predictor-corrector step with the basis-
+ * preconditioned solves.  The starting basis is the slack basis (ConstructBasisFromWeights with
+ * crash_basis = 0, src/basis.cc:353-385); DropPrimal / DropDual (:36-43) are not taken.  Models whose
+ * iterate holds free or fixed variables are refused (IPXK_E_UNSUPPORTED).  basis_out[m] / status_out[n+m]
+ * (either may be NULL) return the final basis.  params->kkt_maxiter is ignored (KKTSolverBasis runs CR with
+ * maxiter = -1).  Limits of the refactorizations: see ipxk_lu_factorize (dense bump). */
+int ipxk_ipm_driver_basis(ipxk_context* ctx, const double* b, const double* c,
+                          const double* lb, const double* ub,
+                          const ipxk_ipm_params* params, ipxk_ipm_info* info,
+                          ipxint* basis_out, ipxint* status_out,
+                          ipxk_interrupt_fn interrupt, void* interrupt_user);
 
 /* ---- multi-GPU: rows of AI partitioned over ranks, one RCCL all-reduce per
  *      NormalMatrix apply ---------------------------- */

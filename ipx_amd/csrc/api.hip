@@ -654,6 +654,23 @@ int ipxk_ipm_driver(ipxk_context* c, const double* b, const double* cc, const do
     });
 }
 
+int ipxk_ipm_driver_basis(ipxk_context* c, const double* b, const double* cc, const double* lb, const double* ub,
+                          const ipxk_ipm_params* params, ipxk_ipm_info* info, ipxint* basis_out, ipxint* status_out,
+                          ipxk_interrupt_fn interrupt, void* interrupt_user) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && b && cc && lb && ub && params && info, "NULL argument");
+        IPXK_REQUIRE(!comm_active(c), "ipxk_ipm_driver_basis is not available on a partitioned system");
+        bind_device(c);
+        const size_t m = (size_t)c->m, N = (size_t)(c->n + c->m);
+        const double* db = stage_in(c, b, m, c->nw_in[0]);
+        const double* dc = stage_in(c, cc, N, c->nw_in[1]);
+        const double* dlb = stage_in(c, lb, N, c->nw_in[2]);
+        const double* dub = stage_in(c, ub, N, c->nw_in[3]);
+        ipm_driver_dev(c, db, dc, dlb, dub, params, info, interrupt, interrupt_user, true, basis_out, status_out);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
 int ipxk_iterate_factorize_diag(ipxk_context* c, int precond_dense_cols, ipxint* errflag) {
     return guarded([&] {
         IPXK_REQUIRE(c && errflag && c->it_set, "no iterate on the device (ipxk_iterate_set)");

@@ -180,7 +180,8 @@ void ipm_step_dev(Context* c, bool use_basis, const double* b, const double* cc,
                   double kkt_tol, ipxint maxiter, ipxk_ipm_step_info* info, ipxk_interrupt_fn interrupt, void* user);
 
 void ipm_driver_dev(Context* c, const double* b, const double* cc, const double* lb, const double* ub,
-                    const ipxk_ipm_params* prm, ipxk_ipm_info* info, ipxk_interrupt_fn interrupt, void* user);
+                    const ipxk_ipm_params* prm, ipxk_ipm_info* info, ipxk_interrupt_fn interrupt, void* user,
+                    bool use_basis = false, ipxint* basis_out = nullptr, ipxint* status_out = nullptr);
 
 // ---- kkt_diag.hip ----
 void kkt_diag_factorize_dev(Context* c, const double* xl, const double* xu, const double* zl,

@@ -184,9 +184,65 @@ void ipm_step_dev(Context* c, bool use_basis, const double* b, const double* cc,
 // and MakeStep's bad-iteration count and best complementarity (:520-530).  What ends the loop is reported as
 // status_ipm; a CR failure of the diag solver (errflag 201-205 -> IPX_STATUS_failed) is where LpSolver switches
 // to the basis solver (src/lp_solver.cc:399-418) -- the caller's decision, as in the reference.
+// Iterate::ScalingFactor (src/iterate.cc:183-198): 0 for fixed, inf for free variables, else 1/sqrt(zl/xl + zu/xu);
+// flags any variable that is not in a barrier state
+__global__ void scaling_factor_kernel(int N, const unsigned char* __restrict__ state, const double* __restrict__ xl,
+                                      const double* __restrict__ xu, const double* __restrict__ zl, const double* __restrict__ zu,
+                                      double* __restrict__ colscale, int* nonbarrier) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+        const unsigned char st = state[j];
+        double d;
+        if (st == IPXK_STATE_FIXED) { d = 0.0; *nonbarrier = 1; }
+        else if (st == IPXK_STATE_FREE) { d = __builtin_huge_val(); *nonbarrier = 1; }
+        else d = 1.0 / sqrt(zl[j] / xl[j] + zu[j] / xu[j]);
+        colscale[j] = d;
+    }
+}
+
+// KKTSolverBasis::_Factorize (src/kkt_solver_basis.cc:20-63) on the device: scaling factors from the iterate,
+// Maxvolume, fresh factorization, Prepare.  DropPrimal / DropDual (:36-43) are not taken (they move nearly
+// degenerate variables out of the barrier problem; leaving them in is a valid, if slower, interior point step).
+// The first call builds the slack basis (Basis::SetToSlackBasis; ConstructBasisFromWeights with crash_basis = 0,
+// src/basis.cc:353-385, for a model without free or fixed variables).
+static void basis_factorize_dev(Context* c, std::vector<ipxint>& basis, std::vector<ipxint>& status, std::vector<double>& colscale,
+                                bool first, ipxk_ipm_info* info) {
+    const int m = (int)c->m, n = (int)c->n, N = n + m;
+    hipStream_t s = c->stream;
+    DevBuf<double> d((size_t)N);
+    DevBuf<int> flag(1);
+    IPXK_HIP(hipMemsetAsync(flag.get(), 0, sizeof(int), s));
+    hipLaunchKernelGGL(scaling_factor_kernel, dim3(vec_grid(N)), dim3(kBlock), 0, s, N, c->it_state.get(), c->it_xl.get(), c->it_xu.get(),
+                       c->it_zl.get(), c->it_zu.get(), d.get(), flag.get());
+    int nonbarrier = 0;
+    flag.download(&nonbarrier, 1, s);
+    d.download(colscale.data(), (size_t)N, s);
+    IPXK_HIP(hipStreamSynchronize(s));
+    if (nonbarrier) throw Error(IPXK_E_UNSUPPORTED, "the basis phase of ipxk_ipm_driver handles barrier variables only (no free or fixed ones)");
+    if (first) {
+        for (int j = 0; j < n; j++) status[j] = IPXK_NONBASIC;
+        for (int i = 0; i < m; i++) { status[n + i] = IPXK_BASIC; basis[i] = n + i; }
+        ipxk_lu_info li{};
+        lu_factorize_basis(c, basis.data(), 0.1, false, &li);
+        split_prepare_lu(c, status.data(), colscale.data());
+    }
+    ipxk_maxvolume_info mi{};
+    std::vector<ipxint> nb(basis.size()), ns(status.size());
+    maxvolume_dev(c, status.data(), colscale.data(), nullptr, nb.data(), ns.data(), &mi, nullptr, 0);
+    if (mi.errflag) { info->errflag = mi.errflag; return; }
+    info->basis_updates += mi.updates;
+    basis.swap(nb);
+    status.swap(ns);
+    if (mi.updates == 0 && !first) split_rescale_host(c, status.data(), colscale.data());   // same basis, new scaling (:59-64)
+}
+
 void ipm_driver_dev(Context* c, const double* b, const double* cc, const double* lb, const double* ub,
-                    const ipxk_ipm_params* prm, ipxk_ipm_info* info, ipxk_interrupt_fn interrupt, void* user) {
+                    const ipxk_ipm_params* prm, ipxk_ipm_info* info, ipxk_interrupt_fn interrupt, void* user, bool use_basis,
+                    ipxint* basis_out, ipxint* status_out) {
     IPXK_REQUIRE(c->it_set, "no iterate on the device (ipxk_iterate_set)");
+    std::vector<ipxint> basis, status;
+    std::vector<double> colscale;
+    if (use_basis) { basis.resize((size_t)c->m); status.resize((size_t)(c->n + c->m)); colscale.resize((size_t)(c->n + c->m)); }
+    bool first_factorize = true;
     constexpr double kDivergeTol = 1e6;                  // src/ipm.h:55
     *info = ipxk_ipm_info{};
     const int N = (int)(c->n + c->m);
@@ -220,11 +276,17 @@ void ipm_driver_dev(Context* c, const double* b, const double* cc, const double*
         }
         if (info->iter >= prm->ipm_maxiter) { info->status_ipm = 6; break; }       // iter_limit
         if (interrupt && (errflag = interrupt(user)) != 0) break;
-        kkt_diag_factorize_dev(c, c->it_xl.get(), c->it_xu.get(), c->it_zl.get(), c->it_zu.get(), comp[1],
-                               prm->precond_dense_cols != 0, &errflag);
+        if (use_basis) {
+            basis_factorize_dev(c, basis, status, colscale, first_factorize, info);
+            first_factorize = false;
+            errflag = info->errflag;
+        } else {
+            kkt_diag_factorize_dev(c, c->it_xl.get(), c->it_xu.get(), c->it_zl.get(), c->it_zu.get(), comp[1],
+                                   prm->precond_dense_cols != 0, &errflag);
+        }
         if (errflag) break;
         ipxk_ipm_step_info st;
-        ipm_step_dev(c, false, b, cc, lb, ub, prm->kkt_tol, prm->kkt_maxiter, &st, interrupt, user);
+        ipm_step_dev(c, use_basis, b, cc, lb, ub, prm->kkt_tol, use_basis ? -1 : prm->kkt_maxiter, &st, interrupt, user);
         info->kktiter += st.kktiter_predictor + st.kktiter_corrector;
         errflag = st.errflag;
         if (errflag) break;
@@ -238,6 +300,10 @@ void ipm_driver_dev(Context* c, const double* b, const double* cc, const double*
     if (errflag) {                                       // :114-121
         if (errflag == 999) { info->status_ipm = 5; info->errflag = 0; }           // IPX_ERROR_interrupt_time -> time_limit
         else { info->status_ipm = 8; info->errflag = errflag; }                    // failed
+    }
+    if (use_basis && !first_factorize) {
+        if (basis_out) std::copy(basis.begin(), basis.end(), basis_out);
+        if (status_out) std::copy(status.begin(), status.end(), status_out);
     }
 }
 

@@ -721,6 +721,7 @@ void analyse_sweeps_resident(Context* c, SplitOperator* S, const DeviceFactors& 
     hipLaunchKernelGGL(lt_rows_kernel, dim3(grid_for(std::max<int64_t>(nzL, m + 1))), dim3(kBlock), 0, s, m, nzL,
                        dLp.get(), dLi.get(), dLx.get(), W.rp.get(), W.ri.get(), W.rx.get());
     hipLaunchKernelGGL(fill_double_kernel, dim3(g), dim3(kBlock), 0, s, (int64_t)m, 1.0, W.dgn.get());
+    S->Lt.newest_first = true;      // a row's first entries (rows k+1, k+2, ... of column k) are the unknowns solved last
     finish_sweep(c, W, S->Lt, ll, m, nzL, false, false, 0, [&](std::vector<int>& lv) {
         H.fetch(F, m, s);
         const ipxint *Lp = H.Lp, *Li = H.Li;

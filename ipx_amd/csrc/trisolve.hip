@@ -76,6 +76,12 @@ struct LaneRec {
     double a[8];
 };
 
+// long chunks: step of the row at which the FIRST round of 8 steps starts (0, or the last 8 steps when the
+// rounds are taken from the end of the row)
+__device__ __forceinline__ int first_round_step(const SweepView& S, const ChunkDesc& d) {
+    return (d.width < -8 && S.newest_first && d.sub <= 1) ? -d.width - 8 : 0;
+}
+
 __device__ __forceinline__ void load_rec(LaneRec& R, const SweepView& S, const ChunkDesc& d, int lane,
                                          const double* __restrict__ xin) {
     // every address depends on the (scalar) descriptor only: one round trip, fully coalesced
@@ -86,12 +92,13 @@ __device__ __forceinline__ void load_rec(LaneRec& R, const SweepView& S, const C
     R.len = lenword & ((1 << kLenBits) - 1);
     R.sub = lenword >> kLenBits;
     const int steps = d.width >= 0 ? d.width : min(-d.width, 8);     // wave-uniform
+    const int base = d.width >= 0 ? 0 : first_round_step(S, d);
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         R.j[e] = 0; R.a[e] = 0.0;
         if (e < steps) {
-            R.j[e] = S.idx[d.ent0 + e * 64 + lane];
-            R.a[e] = S.val[d.ent0 + e * 64 + lane];
+            R.j[e] = S.idx[d.ent0 + (base + e) * 64 + lane];
+            R.a[e] = S.val[d.ent0 + (base + e) * 64 + lane];
         }
     }
     R.xr = R.src >= 0 ? xin[R.src] : 0.0;
@@ -118,7 +125,7 @@ __device__ __forceinline__ void issue_polls(const LaneRec& R, bool ell, int gl, 
     for (int t = 0; t < 8; t++) {
         const int e = ell ? t : first + t * 8 + gl;
         bits[t] = 0ull;
-        if (R.src >= 0 && e < R.len && !(R.j[t] >= lo && R.j[t] < hi)) bits[t] = H.look(R.j[t]);
+        if (R.src >= 0 && e >= 0 && e < R.len && !(R.j[t] >= lo && R.j[t] < hi)) bits[t] = H.look(R.j[t]);
     }
 }
 
@@ -246,11 +253,14 @@ __device__ __forceinline__ bool solve_chunk(LaneRec& R, const ChunkDesc& d, int 
     }
     const int gl = lane & 7;
     const int len = R.src >= 0 ? R.len : 0;
+    const int nsteps = -d.width;
+    const bool rev = nsteps > 8 && S.newest_first && d.sub <= 1;   // rounds from the end of the row (SweepView)
     double acc = RUNNING ? R.xr : 0.0;
-    for (int first = 0;;) {          // 64 entries of the row per round (one round unless the row is longer)
+    for (int base = first_round_step(S, d);;) {  // 8 steps = 64 entries of the row per round (one round unless the row is longer)
 #pragma unroll
         for (int t = 0; t < 8; t++) {
-            const int e0 = first + t * 8;                   // first entry of this step of the group
+            const int e0 = (base + t) * 8;                  // first entry of this step of the group
+            if (e0 < 0) continue;                           // wave-uniform (the head round of a reversed row)
             if (!__any(e0 < len)) break;                    // wave-uniform
             double prod = 0.0;
             if (e0 + gl < len) {
@@ -259,15 +269,15 @@ __device__ __forceinline__ bool solve_chunk(LaneRec& R, const ChunkDesc& d, int 
             }
             acc = ordered_combine<RUNNING>(acc, prod, min(kLongLanes, len - e0));
         }
-        first += 64;
-        if (!__any(first < len)) break;
+        if (rev) { base -= 8; if (base <= -8) break; }
+        else { base += 8; if (!__any(base * 8 < len)) break; }
 #pragma unroll
         for (int t = 0; t < 8; t++) {
-            const int step = first / 8 + t;                 // wave-uniform
+            const int step = base + t;                      // wave-uniform
             R.j[t] = 0; R.a[t] = 0.0;
-            if (step < -d.width) { R.j[t] = S.idx[d.ent0 + step * 64 + lane]; R.a[t] = S.val[d.ent0 + step * 64 + lane]; }
+            if (step >= 0 && step < nsteps) { R.j[t] = S.idx[d.ent0 + step * 64 + lane]; R.a[t] = S.val[d.ent0 + step * 64 + lane]; }
         }
-        issue_polls(R, false, gl, first, H, bits);
+        issue_polls(R, false, gl, base * 8, H, bits);
         if (!wait_polls(R, H, bits, abort_flag)) return false;
     }
     if (gl == 0) store_result(H, d.pos0 + (lane >> 3), R.src >= 0 ? (RUNNING ? acc : R.xr - acc) / R.dg : 0.0);
@@ -293,7 +303,7 @@ __device__ __forceinline__ void chunk_loop(const SweepView& S, int c, int c1, in
     for (;;) {
         gu64 bits[8];
         const int own = MERGED && d.sub > 1 ? (d.width >= 0 ? 64 : kLongLanes) : 0;     // merged: the chunk's own positions
-        issue_polls(A, d.width >= 0, lane & 7, 0, H, bits, d.pos0, d.pos0 + own);
+        issue_polls(A, d.width >= 0, lane & 7, d.width >= 0 ? 0 : first_round_step(S, d) * 8, H, bits, d.pos0, d.pos0 + own);
         // the next chunk's records (and the descriptor after that) travel while this chunk waits
         const int cn = c + NW;
         ChunkDesc dnn = dn;

@@ -44,6 +44,10 @@ struct SweepView {
     const int* len;              // [npos] entries of the row
     const int* idx;              // dependency position
     const double* val;
+    // rows of more than 64 entries are summed in rounds of 64; newest_first: the row's FIRST entries are the
+    // dependencies that become available last (the L' sweep: descending unknowns, ascending storage order), so
+    // its rounds are taken from the end of the row -- all but the last round then run ahead of the chain
+    int newest_first;
 };
 
 // A sweep is a sequence of launches, each a run of consecutive levels (= a range of chunks):
@@ -54,6 +58,7 @@ struct Sweep {
     int dim = 0, nlevels = 0, npos = 0, nchunks = 0;
     int64_t nentries = 0;          // entry slots (padding included)
     bool running = false;          // forward ('n') sweeps subtract one product at a time
+    bool newest_first = false;     // see SweepView
     int scale_mode = 0;            // 0: no scaled copy; 1: column scale of the unknown itself (U');
                                    // 2: column scale of the dependency (U)
     DevBuf<ChunkDesc> chunks;
@@ -75,6 +80,7 @@ struct Sweep {
         V.chunks = chunks.get(); V.src = src.get(); V.len = len.get(); V.idx = idx.get();
         V.val = (scaled && scale_mode) ? valS.get() : val.get();
         V.diag = (scaled && scale_mode) ? diagS.get() : diag.get();
+        V.newest_first = newest_first ? 1 : 0;
         return V;
     }
 };

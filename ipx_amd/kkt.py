@@ -33,7 +33,7 @@ EXPORTS = [
     "ipxk_kkt_basis_solve", "ipxk_newton_solve", "ipxk_iterate_set", "ipxk_iterate_get", "ipxk_iterate_update",
     "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_ipm_step", "ipxk_iterate_objectives", "ipxk_ipm_driver", "ipxk_iterate_factorize_diag", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns",
     "ipxk_time_normal_apply", "ipxk_equilibrate", "ipxk_transpose", "ipxk_lu_factorize", "ipxk_lu_factorize_basis",
-    "ipxk_lu_get_factors", "ipxk_split_prepare_lu", "ipxk_maxvolume",
+    "ipxk_lu_get_factors", "ipxk_split_prepare_lu", "ipxk_maxvolume", "ipxk_ipm_driver_basis",
     "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
     "ipxk_dev_download",
 ]
@@ -74,7 +74,7 @@ class IpmParams(C.Structure):
 class IpmInfo(C.Structure):
     _fields_ = [("status_ipm", c_i64), ("iter", c_i64), ("errflag", c_i64), ("kktiter", c_i64), ("pobjective", c_f64),
                 ("dobjective", c_f64), ("presidual", c_f64), ("dresidual", c_f64), ("complementarity", c_f64),
-                ("mu", c_f64), ("step_primal", c_f64), ("step_dual", c_f64)]
+                ("mu", c_f64), ("step_primal", c_f64), ("step_dual", c_f64), ("basis_updates", c_i64)]
 
 
 class Times(C.Structure):
@@ -460,6 +460,20 @@ class KktContext:
         self._check(self.lib.ipxk_ipm_driver(self.h, _fp(_F(b)), _fp(_F(c)), _fp(_F(lb)), _fp(_F(ub)), C.byref(prm),
                                              C.byref(info), cb, None))
         return {name: getattr(info, name) for name, _ in IpmInfo._fields_}
+
+    def ipm_driver_basis(self, b, c, lb, ub, kkt_tol=0.3, feasibility_tol=1e-6, optimality_tol=1e-8, ipm_maxiter=300,
+                         interrupt=None):
+        """IPM::Driver on the resident iterate with the basis solver (LpSolver::RunMainIPM); returns the info fields
+        plus the final basis and statuses"""
+        prm = IpmParams(kkt_tol, feasibility_tol, optimality_tol, -1, ipm_maxiter, 1)
+        info = IpmInfo()
+        basis, status = np.zeros(self.m, i64), np.zeros(self.n + self.m, i64)
+        cb = INTERRUPT_FN(lambda _u: int(interrupt())) if interrupt else C.cast(None, INTERRUPT_FN)
+        self._check(self.lib.ipxk_ipm_driver_basis(self.h, _fp(_F(b)), _fp(_F(c)), _fp(_F(lb)), _fp(_F(ub)), C.byref(prm),
+                                                   C.byref(info), _ip(basis), _ip(status), cb, None))
+        out = {name: getattr(info, name) for name, _ in IpmInfo._fields_}
+        out.update(basis=basis, status=status)
+        return out
 
     def kkt_diag_get(self):
         W, rs = np.zeros(self.n + self.m, f64), np.zeros(self.m, f64)

@@ -103,6 +103,14 @@ def test_example_ipm_loop():
     mu = [float(x[3]) for x in rows]
     assert all(b < a for a, b in zip(pres, pres[1:])) and all(b < a for a, b in zip(dres, dres[1:]))
     assert mu[-1] < 0.1 * mu[0] and pres[-1] < 0.02 * pres[0]
+    # with the fourth argument the example goes on with the basis-preconditioned phase until optimal
+    r = subprocess.run([os.path.join(ROOT, "examples", "ipm_loop"), "1500", "3500", "4", "1"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    mo = re.search(r"main IPM: status (\d+) after (\d+) iterations.*pobjective (\S+) dobjective (\S+)", r.stdout)
+    assert mo and int(mo.group(1)) == 1, r.stdout                               # IPX_STATUS_optimal
+    po_, do_ = float(mo.group(3)), float(mo.group(4))
+    assert abs(po_ - do_) <= 1e-8 * (1 + abs(po_))
 
 
 @pytest.mark.gpu

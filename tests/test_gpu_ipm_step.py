@@ -206,3 +206,36 @@ def test_ipm_driver_vs_oracle(kkt, oracle, seed, m, n):
     g4 = ctx.ipm_driver(b, c, lbs, ubs, kkt_maxiter=1, ipm_maxiter=100)
     assert g4["status_ipm"] == 8 and g4["errflag"] == 201                       # failed: CR iteration limit
     ctx.close()
+
+
+@pytest.mark.parametrize("seed,m,n", [(71, 60, 150), (72, 600, 1500)])
+def test_ipm_two_phases_on_the_device(kkt, seed, m, n):
+    """LpSolver::RunInitialIPM -> RunMainIPM (src/lp_solver.cc:375-462) without leaving the device: a few iterations
+    with the diag solver (stopped at `switchiter`), then IPM::Driver around the basis solver -- per iteration
+    Maxvolume from the resident iterate's scaling factors, LU factorization and Prepare on the device, the
+    basis-preconditioned predictor-corrector step -- from the slack basis to IPX_STATUS_optimal.  The optimal
+    value against an independent LP solver; the final basis is nonsingular and holds the large scaling factors."""
+    import scipy.sparse as sp
+    from scipy.optimize import linprog
+    A, b, c, lbs, ubs, state, it = feasible_lp(m, n, seed)
+    ctx = kkt.KktContext(A)
+    ctx.iterate_set(it, state)
+    g1 = ctx.ipm_driver(b, c, lbs, ubs, kkt_maxiter=5000, ipm_maxiter=4)         # switchiter = 4
+    assert g1["status_ipm"] == 6 and g1["iter"] == 4                              # iter_limit -> not_run, go on
+    g2 = ctx.ipm_driver_basis(b, c, lbs, ubs, ipm_maxiter=100)
+    assert g2["status_ipm"] == 1, g2                                              # IPX_STATUS_optimal
+    assert g2["basis_updates"] > 0 and 2 <= g2["iter"] <= 60
+    r = linprog(c[:n], A_ub=A.to_scipy(), b_ub=b, bounds=[(0, None)] * n, method="highs")
+    assert r.status == 0 and abs(g2["pobjective"] - r.fun) <= 1e-6 * (1.0 + abs(r.fun))
+    assert abs(g2["pobjective"] - g2["dobjective"]) <= 1e-8 * (1.0 + abs(g2["pobjective"]))
+    basis, status = g2["basis"], g2["status"]
+    assert sorted(basis) == sorted(np.nonzero(status == 0)[0]) and len(basis) == m
+    AI = sp.hstack([A.to_scipy(), sp.identity(m)]).tocsc()
+    rhs = np.random.default_rng(1).standard_normal(m)
+    x = ctx.solve_dense(rhs, "n")                                                 # the context holds the final factorization
+    assert np.abs(AI[:, basis] @ x - rhs).max() <= 1e-7 * (1 + np.abs(x).max())
+    # the basis phase from the very start (slack basis at the unit starting point) reaches the same optimum
+    ctx.iterate_set(it, state)
+    g3 = ctx.ipm_driver_basis(b, c, lbs, ubs, ipm_maxiter=100)
+    assert g3["status_ipm"] == 1 and abs(g3["pobjective"] - r.fun) <= 1e-6 * (1.0 + abs(r.fun))
+    ctx.close()
