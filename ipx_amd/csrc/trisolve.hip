@@ -92,13 +92,13 @@ __device__ __forceinline__ void load_rec(LaneRec& R, const SweepView& S, const C
     R.len = lenword & ((1 << kLenBits) - 1);
     R.sub = lenword >> kLenBits;
     const int steps = d.width >= 0 ? d.width : min(-d.width, 8);     // wave-uniform
-    const int base = d.width >= 0 ? 0 : first_round_step(S, d);
+    const int ent = d.ent0 + first_round_step(S, d) * 64;            // scalar
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         R.j[e] = 0; R.a[e] = 0.0;
         if (e < steps) {
-            R.j[e] = S.idx[d.ent0 + (base + e) * 64 + lane];
-            R.a[e] = S.val[d.ent0 + (base + e) * 64 + lane];
+            R.j[e] = S.idx[ent + e * 64 + lane];
+            R.a[e] = S.val[ent + e * 64 + lane];
         }
     }
     R.xr = R.src >= 0 ? xin[R.src] : 0.0;
@@ -253,32 +253,58 @@ __device__ __forceinline__ bool solve_chunk(LaneRec& R, const ChunkDesc& d, int 
     }
     const int gl = lane & 7;
     const int len = R.src >= 0 ? R.len : 0;
-    const int nsteps = -d.width;
-    const bool rev = nsteps > 8 && S.newest_first && d.sub <= 1;   // rounds from the end of the row (SweepView)
     double acc = RUNNING ? R.xr : 0.0;
-    for (int base = first_round_step(S, d);;) {  // 8 steps = 64 entries of the row per round (one round unless the row is longer)
+    if (first_round_step(S, d) == 0) {
+        for (int first = 0;;) {          // 64 entries of the row per round (one round unless the row is longer)
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const int e0 = (base + t) * 8;                  // first entry of this step of the group
-            if (e0 < 0) continue;                           // wave-uniform (the head round of a reversed row)
-            if (!__any(e0 < len)) break;                    // wave-uniform
-            double prod = 0.0;
-            if (e0 + gl < len) {
-                const double xj = __longlong_as_double((long long)bits[t]);
-                prod = RUNNING ? R.a[t] * xj : xj * R.a[t];
+            for (int t = 0; t < 8; t++) {
+                const int e0 = first + t * 8;                   // first entry of this step of the group
+                if (!__any(e0 < len)) break;                    // wave-uniform
+                double prod = 0.0;
+                if (e0 + gl < len) {
+                    const double xj = __longlong_as_double((long long)bits[t]);
+                    prod = RUNNING ? R.a[t] * xj : xj * R.a[t];
+                }
+                acc = ordered_combine<RUNNING>(acc, prod, min(kLongLanes, len - e0));
             }
-            acc = ordered_combine<RUNNING>(acc, prod, min(kLongLanes, len - e0));
-        }
-        if (rev) { base -= 8; if (base <= -8) break; }
-        else { base += 8; if (!__any(base * 8 < len)) break; }
+            first += 64;
+            if (!__any(first < len)) break;
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const int step = base + t;                      // wave-uniform
-            R.j[t] = 0; R.a[t] = 0.0;
-            if (step >= 0 && step < nsteps) { R.j[t] = S.idx[d.ent0 + step * 64 + lane]; R.a[t] = S.val[d.ent0 + step * 64 + lane]; }
+            for (int t = 0; t < 8; t++) {
+                const int step = first / 8 + t;                 // wave-uniform
+                R.j[t] = 0; R.a[t] = 0.0;
+                if (step < -d.width) { R.j[t] = S.idx[d.ent0 + step * 64 + lane]; R.a[t] = S.val[d.ent0 + step * 64 + lane]; }
+            }
+            issue_polls(R, false, gl, first, H, bits);
+            if (!wait_polls(R, H, bits, abort_flag)) return false;
         }
-        issue_polls(R, false, gl, base * 8, H, bits);
-        if (!wait_polls(R, H, bits, abort_flag)) return false;
+    } else {
+        // rounds from the END of the row (SweepView::newest_first, rows of more than 64 entries): all rounds but
+        // the last one wait for unknowns that were solved long ago
+        const int nsteps = -d.width;
+        for (int base = nsteps - 8;;) {
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int e0 = (base + t) * 8;
+                if (e0 < 0 || !__any(e0 < len)) continue;       // wave-uniform
+                double prod = 0.0;
+                if (e0 + gl < len) {
+                    const double xj = __longlong_as_double((long long)bits[t]);
+                    prod = RUNNING ? R.a[t] * xj : xj * R.a[t];
+                }
+                acc = ordered_combine<RUNNING>(acc, prod, min(kLongLanes, len - e0));
+            }
+            base -= 8;
+            if (base <= -8) break;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int step = base + t;                      // wave-uniform
+                R.j[t] = 0; R.a[t] = 0.0;
+                if (step >= 0) { R.j[t] = S.idx[d.ent0 + step * 64 + lane]; R.a[t] = S.val[d.ent0 + step * 64 + lane]; }
+            }
+            issue_polls(R, false, gl, base * 8, H, bits);
+            if (!wait_polls(R, H, bits, abort_flag)) return false;
+        }
     }
     if (gl == 0) store_result(H, d.pos0 + (lane >> 3), R.src >= 0 ? (RUNNING ? acc : R.xr - acc) / R.dg : 0.0);
     return true;
