@@ -401,6 +401,107 @@ __global__ __launch_bounds__(kPanelThreads) void lu_panel_small_kernel(Dense A, 
     if (threadIdx.x == 0) { A.bstep[0] = step; A.bstep[1] = np; }
 }
 
+// Bumps of more than kPanelThreads rows: panels of kNarrow columns, a thread owns R rows of the panel in registers
+// (R * kPanelThreads >= rows).  Same arithmetic, same order; the two kernels that follow a panel take the number
+// of its pivots from bstep[1], so they serve both panel widths.
+constexpr int kNarrow = 8;
+template <int R, int T>
+__device__ __forceinline__ void panel_multi_steps(const Dense& A, PanelShared& sh, double (&v)[R][kNarrow], int c0, int c1,
+                                                  unsigned& active, int& np, int& step) {
+    if constexpr (T < kNarrow) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const bool col = c0 + T < c1;                  // uniform
+        double best = 0.0;
+        int br = INT_MAX;
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const double a = (col && ((active >> q) & 1u)) ? fabs(v[q][T]) : 0.0;
+            if (a > best) { best = a; br = tid + q * kPanelThreads; }      // rows ascend with q: the first maximum stays
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double ov = __shfl_xor(best, d, 64);
+            const int orr = __shfl_xor(br, d, 64);
+            if (ov > best || (ov == best && orr < br)) { best = ov; br = orr; }
+        }
+        if (lane == 0) { sh.red_v[wave] = best; sh.red_r[wave] = br; }
+        __syncthreads();
+        if (tid == 0) {
+            double bv = 0.0;
+            int rr = INT_MAX;
+            for (int w = 0; w < kPanelThreads / 64; w++)
+                if (sh.red_v[w] > bv || (sh.red_v[w] == bv && sh.red_r[w] < rr)) { bv = sh.red_v[w]; rr = sh.red_r[w]; }
+            if (!col) {
+                sh.s_pr = -1;
+            } else if (rr == INT_MAX || !(bv >= A.abstol) || bv == 0.0) {
+                sh.s_pr = -1;
+                A.bcstep[c0 + T] = -1;
+            } else {
+                sh.s_pr = rr;
+                A.brstep[rr] = step;
+                A.bcstep[c0 + T] = step;
+                A.prow[np] = rr;
+                A.pcol[np] = c0 + T;
+            }
+        }
+        __syncthreads();
+        const int pr = sh.s_pr;                        // uniform over the workgroup
+        if (pr >= 0) { np++; step++; }
+        if (pr >= 0 && (pr % kPanelThreads) == tid) {
+            const int qp = pr / kPanelThreads;
+#pragma unroll
+            for (int q = 0; q < R; q++)
+                if (q == qp) {
+                    active &= ~(1u << q);
+#pragma unroll
+                    for (int t2 = 0; t2 < kNarrow; t2++) sh.su[t2] = v[q][t2];
+                }
+        }
+        __syncthreads();
+        if (pr >= 0) {
+#pragma unroll
+            for (int q = 0; q < R; q++)
+                if ((active >> q) & 1u) {
+                    const double l = v[q][T] / sh.su[T];
+                    v[q][T] = l;
+#pragma unroll
+                    for (int t2 = T + 1; t2 < kNarrow; t2++) {
+                        const double u = sh.su[t2];
+                        if (c0 + t2 < c1 && u != 0.0) v[q][t2] -= l * u;
+                    }
+                }
+        }
+        __syncthreads();
+        panel_multi_steps<R, T + 1>(A, sh, v, c0, c1, active, np, step);
+    }
+}
+template <int R>
+__global__ __launch_bounds__(kPanelThreads) void lu_panel_multi_kernel(Dense A, int c0, int c1) {
+    __shared__ PanelShared sh;
+    const int kb = A.kb, tid = threadIdx.x;
+    unsigned active = 0, have = 0;
+    double v[R][kNarrow];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+        const int r = tid + q * kPanelThreads;
+        if (r < kb) { have |= 1u << q; if (A.brstep[r] < 0) active |= 1u << q; }
+#pragma unroll
+        for (int t = 0; t < kNarrow; t++) v[q][t] = (r < kb && c0 + t < c1) ? A.D[(size_t)(c0 + t) * kb + r] : 0.0;
+    }
+    int np = 0;
+    int step = A.bstep[0];
+    panel_multi_steps<R, 0>(A, sh, v, c0, c1, active, np, step);
+#pragma unroll
+    for (int q = 0; q < R; q++)
+        if ((have >> q) & 1u) {
+            const int r = tid + q * kPanelThreads;
+#pragma unroll
+            for (int t = 0; t < kNarrow; t++)
+                if (c0 + t < c1) A.D[(size_t)(c0 + t) * kb + r] = v[q][t];
+        }
+    if (tid == 0) { A.bstep[0] = step; A.bstep[1] = np; }
+}
+
 // The panel's rows of U in the trailing columns: row prow[t] of column c2 receives the updates of the panel's
 // earlier pivots, in pivot order.  One thread per trailing column.
 __global__ __launch_bounds__(kBlock) void lu_panel_rows_kernel(Dense A, int c1) {
@@ -758,9 +859,12 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
         hipLaunchKernelGGL(lu_fill_int_kernel, dim3(gk), dim3(kBlock), 0, s, (int64_t)kb, -1, bcstep.get());
         hipLaunchKernelGGL(lu_dense_fill_kernel, dim3(gk), dim3(kBlock), 0, s, kb, bcol.get(), Bp, Bi, Bx, rloc.get(), D.get());
         Dense A{kb, D.get(), brstep.get(), bcstep.get(), bstep.get(), prow.get(), pcol.get(), abstol};
-        for (int c0 = 0; c0 < kb; c0 += kPanel) {
-            const int c1 = std::min(kb, c0 + kPanel);
+        const int width = kb <= kPanelThreads ? kPanel : kb <= 4 * kPanelThreads ? kNarrow : kPanel;
+        for (int c0 = 0; c0 < kb; c0 += width) {
+            const int c1 = std::min(kb, c0 + width);
             if (kb <= kPanelThreads) hipLaunchKernelGGL(lu_panel_small_kernel, dim3(1), dim3(kPanelThreads), 0, s, A, c0, c1);
+            else if (kb <= 2 * kPanelThreads) hipLaunchKernelGGL(lu_panel_multi_kernel<2>, dim3(1), dim3(kPanelThreads), 0, s, A, c0, c1);
+            else if (kb <= 4 * kPanelThreads) hipLaunchKernelGGL(lu_panel_multi_kernel<4>, dim3(1), dim3(kPanelThreads), 0, s, A, c0, c1);
             else hipLaunchKernelGGL(lu_panel_kernel, dim3(1), dim3(kPanelThreads), 0, s, A, c0, c1);
             if (c1 < kb) {
                 hipLaunchKernelGGL(lu_panel_rows_kernel, dim3(grid_for(kb - c1)), dim3(kBlock), 0, s, A, c1);

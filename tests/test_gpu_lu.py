@@ -40,7 +40,8 @@ def same_factors(F, Fo):
 
 
 BIG = [dict(dim=20000, bump=600, offdiag=3), dict(dim=5000, bump=97, window=4, frac_rowsing=0.4),
-       dict(dim=3000, bump=1100, bump_density=0.05), dict(dim=700, bump=64, num_dependent=3)]
+       dict(dim=3000, bump=1100, bump_density=0.05), dict(dim=700, bump=64, num_dependent=3),
+       dict(dim=4000, bump=2300, bump_density=0.01)]
 
 
 @pytest.mark.parametrize("kw", CASES + BIG, ids=[str(i) for i in range(len(CASES) + len(BIG))])
