@@ -715,6 +715,7 @@ struct LuState {
     int dim = 0;
     int64_t lnz = 0, unz = 0;
     int ndep = 0;
+    int bump_start = 0, bump_size = 0;      // pivot stages [bump_start, bump_start + bump_size) came from the dense bump
     bool valid = false, from_basis = false;
     DevBuf<ipxint> Lp, Li, Up, Ui, rowperm, colperm, dependent, basis;
     DevBuf<double> Lx, Ux;
@@ -878,6 +879,8 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
     const int ndep = kb - bpiv;
     I.num_dependent = ndep;
     S->ndep = ndep;
+    S->bump_start = npiv_sing;
+    S->bump_size = bpiv;
     S->dependent.ensure((size_t)std::max(ndep, 1));
     if (kb > 0) {
         const int gk = grid_for(kb);
@@ -961,6 +964,8 @@ bool lu_view(const Context* c, LuView* out) {
     out->dim = S->dim;
     out->ndep = S->ndep;
     out->from_basis = S->from_basis;
+    out->bump_start = S->bump_start;
+    out->bump_size = S->bump_size;
     out->F = DeviceFactors{S->Lp.get(), S->Li.get(), S->Up.get(), S->Ui.get(), S->Lx.get(), S->Ux.get(), S->lnz, S->unz};
     out->rowperm = S->rowperm.get();
     out->colperm = S->colperm.get();

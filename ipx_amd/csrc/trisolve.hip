@@ -43,6 +43,8 @@ void destroy_split(SplitOperator* s) { delete s; }
 struct PrepareHost {};                       // (host-side analysis workspaces: none any more)
 void destroy_prepare_host(PrepareHost* p) { delete p; }
 
+static void bump_between(Context* c, bool trans, double* y, const int* done);   // dense bump of an LU from the device (below)
+
 static int vec_grid(int64_t len) {
     int64_t g = (len + kBlock - 1) / kBlock;
     if (g < 1) g = 1;
@@ -556,6 +558,7 @@ void forward_solve_dev(Context* c, const double* in, double* out, bool scaled, c
                        S->w3.get(), done);
     fill_results(c, {&S->Lf, &S->Uf}, done);
     run_sweep(c, S->Lf, scaled, S->w3.get(), done);
+    bump_between(c, false, S->Lf.y.get(), done);
     run_sweep(c, S->Uf, scaled, S->Lf.y.get(), done);
     unpack_result(c, S->Uf, nullptr, out);
 }
@@ -564,6 +567,7 @@ void backward_solve_dev(Context* c, const double* in, double* out, bool scaled, 
     SplitOperator* S = c->split;
     fill_results(c, {&S->Ut, &S->Lt}, done);
     run_sweep(c, S->Ut, scaled, in, done);
+    bump_between(c, true, S->Ut.y.get(), done);
     run_sweep(c, S->Lt, scaled, S->Ut.y.get(), done);
     unpack_result(c, S->Lt, nullptr, out);
 }
@@ -700,6 +704,7 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
     const bool verbose = getenv("IPXK_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tp0 = now();
+    S->bump_start = S->bump_size = 0;          // factors from the host: no dense block is known
     analyse_sweeps_device(c, S.get(), Lp, Li, Lx, Up, Ui, Ux);
     const double tp1 = now();
     // permutations (InversePerm, utils.cc:73-80) and bookkeeping for KKTSolverBasis::_Solve
@@ -717,6 +722,163 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
         fprintf(stderr, "ipxk: split_prepare: analysis and packing %.1f ms, permutations/scaling %.1f ms\n",
                 (tp1 - tp0) * 1e3, (now() - tp1) * 1e3);
     c->split = S.release();
+}
+
+// ---------------------------------------------------------------------------
+// The dense bump of an LU from the device (SplitOperator::bump_*, trisolve.hpp)
+// ---------------------------------------------------------------------------
+constexpr int kBumpMin = 32;          // smaller bumps stay in the level-scheduled structure
+constexpr int kBumpThreads = 1024;
+
+// D22: bump column t = pivot stage s0 + t; U22 on and above the diagonal, L22 (multipliers) below
+__global__ void bump_extract_kernel(int s0, int kb, const ipxint* __restrict__ Lp, const ipxint* __restrict__ Li,
+                                    const double* __restrict__ Lx, const ipxint* __restrict__ Up, const ipxint* __restrict__ Ui,
+                                    const double* __restrict__ Ux, double* __restrict__ D) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < kb; t += gridDim.x * blockDim.x) {
+        const int j = s0 + t;
+        for (ipxint p = Up[j]; p < Up[j + 1]; p++)
+            if (Ui[p] >= s0) D[(size_t)t * kb + (Ui[p] - s0)] = Ux[p];
+        for (ipxint p = Lp[j]; p < Lp[j + 1]; p++) D[(size_t)t * kb + (Li[p] - s0)] = Lx[p];
+    }
+}
+// U~: columns < s0 as they are; a bump column keeps its entries above the bump (a prefix: indices ascend) and gets
+// the diagonal 1.  L~: columns >= s0 are empty (their entries all lie inside the bump).
+__global__ void bump_ucount_kernel(int m, int s0, const ipxint* __restrict__ Up, const ipxint* __restrict__ Ui, int* __restrict__ cnt) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
+        int c = (int)(Up[j + 1] - Up[j]);
+        if (j >= s0) {
+            c = 1;
+            for (ipxint p = Up[j]; p < Up[j + 1] && Ui[p] < s0; p++) c++;
+        }
+        cnt[j] = c;
+    }
+}
+// first entry of every column of U~: unchanged in front of the bump, then the bump columns' counts accumulated
+__global__ void bump_ustart_kernel(int m, int s0, const ipxint* __restrict__ Up, const int* __restrict__ cnt, int* __restrict__ start) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x)
+        if (j <= s0) start[j] = (int)Up[j];
+}
+__global__ void bump_ustart_tail_kernel(int m, int s0, const ipxint* __restrict__ Up, const int* __restrict__ cnt, int* __restrict__ start) {
+    for (int j = s0 + 1; j < m; j++) start[j] = start[j - 1] + cnt[j - 1];     // <= 4096 columns, once per Prepare
+}
+__global__ void bump_ufill_kernel(int m, int s0, const ipxint* __restrict__ Up, const ipxint* __restrict__ Ui, const double* __restrict__ Ux,
+                                  const int* __restrict__ start, const int* __restrict__ cnt, ipxint* __restrict__ Tp,
+                                  ipxint* __restrict__ Ti, double* __restrict__ Tx, const ipxint* __restrict__ Lp, ipxint* __restrict__ TLp) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j <= m; j += gridDim.x * blockDim.x) {
+        TLp[j] = Lp[j < s0 ? j : s0];
+        if (j == m) { Tp[m] = start[m - 1] + cnt[m - 1]; continue; }
+        const int q0 = start[j], c = cnt[j];
+        Tp[j] = q0;
+        for (int e = 0; e < c; e++) { Ti[q0 + e] = Ui[Up[j] + e]; Tx[q0 + e] = Ux[Up[j] + e]; }
+        if (j >= s0) { Ti[q0 + c - 1] = j; Tx[q0 + c - 1] = 1.0; }
+    }
+}
+// inverses of the 64 x 64 diagonal blocks of L22+I (unit lower, from below the diagonal of D) or of U22 (upper)
+__global__ __launch_bounds__(64) void bump_invert_blocks_kernel(int kb, const double* __restrict__ D, double* __restrict__ inv, int upper) {
+    __shared__ double T[64][65];
+    const int b0 = blockIdx.x * 64, nb = min(64, kb - b0), c = threadIdx.x;
+    for (int l = 0; l < 64; l++) {
+        double v = c == l ? 1.0 : 0.0;
+        if (c < nb && l < nb) {
+            const double d = D[(size_t)(b0 + l) * kb + (b0 + c)];            // element (row c, column l) of the block
+            if (upper) v = c <= l ? d : 0.0;
+            else v = c > l ? d : (c == l ? 1.0 : 0.0);
+        }
+        T[c][l] = v;
+    }
+    __syncthreads();
+    double x[64];
+    if (!upper) {
+#pragma unroll 1
+        for (int i = 0; i < 64; i++) {                         // column c of the inverse: T x = e_c, forward
+            double s2 = i == c ? 1.0 : 0.0;
+            for (int l = c; l < i; l++) s2 -= T[i][l] * x[l];
+            x[i] = i < c ? 0.0 : s2 / T[i][i];
+        }
+    } else {
+#pragma unroll 1
+        for (int i = 63; i >= 0; i--) {                        // backward
+            double s2 = i == c ? 1.0 : 0.0;
+            for (int l = i + 1; l <= c; l++) s2 -= T[i][l] * x[l];
+            x[i] = i > c ? 0.0 : s2 / T[i][i];
+        }
+    }
+    double* out = inv + (size_t)blockIdx.x * 64 * 64;
+    for (int i = 0; i < 64; i++) out[i + 64 * c] = x[i];       // column major
+}
+// x_bump <- inverse(D22) x_bump (TRANS: inverse(D22')) in place in a sweep's result vector, between the two sweeps
+// of a pair.  One workgroup, x in LDS; per 64-block one product with the inverted diagonal block and one update
+// of the part of x still to be solved.
+template <bool TRANS>
+__global__ __launch_bounds__(kBumpThreads) void bump_solve_kernel(int kb, const double* __restrict__ D, const double* __restrict__ invL,
+                                                                  const double* __restrict__ invU, const int* __restrict__ pos,
+                                                                  double* y, const int* done) {
+    if (done && *done) return;
+    extern __shared__ double xs[];       // kb + 64
+    double* x = xs;
+    double* xb = xs + kb;
+    const int nblk = (kb + 63) / 64, tid = threadIdx.x;
+    for (int t = tid; t < kb; t += kBumpThreads) x[t] = y[pos[t]];
+    __syncthreads();
+    // two triangular solves; `first` is the lower-triangular-type one (blocks ascending)
+    for (int phase = 0; phase < 2; phase++) {
+        const bool lower = phase == 0;                       // !TRANS: L22+I then U22;  TRANS: U22' then (L22+I)'
+        const double* inv = TRANS ? (lower ? invU : invL) : (lower ? invL : invU);
+        for (int q = 0; q < nblk; q++) {
+            const int bq = lower ? q : nblk - 1 - q;
+            const int b0 = bq * 64, nb = min(64, kb - b0);
+            const double* Ib = inv + (size_t)bq * 64 * 64;
+            {   // x_b <- inverse(block) x_b (TRANS: its transpose); 16 threads per row, fixed combination order
+                const int r = tid >> 4, g = tid & 15;
+                double s2 = 0.0;
+                if (r < nb)
+                    for (int l = g; l < nb; l += 16) s2 += (TRANS ? Ib[l + 64 * r] : Ib[r + 64 * l]) * x[b0 + l];
+#pragma unroll
+                for (int d = 8; d >= 1; d >>= 1) s2 += __shfl_xor(s2, d, 64);
+                if (g == 0 && r < 64) xb[r] = s2;
+            }
+            __syncthreads();
+            if (tid < nb) x[b0 + tid] = xb[tid];
+            // the unknowns still to come lose this block's contribution
+            const int i0 = lower ? b0 + nb : 0, i1 = lower ? kb : b0;
+            for (int i = i0 + tid; i < i1; i += kBumpThreads) {
+                double s2 = x[i];
+                // element (row i, column b0 + l) of the triangular matrix of this phase
+                //   !TRANS: D[(b0+l)*kb + i]   (L22 below / U22 above the diagonal, column major)
+                //    TRANS: D[i*kb + b0 + l]   (the transposed factor)
+                int l = 0;
+                for (; l + 8 <= nb; l += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = TRANS ? D[(size_t)i * kb + b0 + l + u] : D[(size_t)(b0 + l + u) * kb + i];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) s2 -= v[u] * xb[l + u];
+                }
+                for (; l < nb; l++) s2 -= (TRANS ? D[(size_t)i * kb + b0 + l] : D[(size_t)(b0 + l) * kb + i]) * xb[l];
+                x[i] = s2;
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = tid; t < kb; t += kBumpThreads) y[pos[t]] = x[t];
+}
+__global__ void bump_positions_kernel(int s0, int kb, const int* __restrict__ posof_fwd, const int* __restrict__ posof_bwd,
+                                      int* __restrict__ pf, int* __restrict__ pb) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < kb; t += gridDim.x * blockDim.x) {
+        pf[t] = posof_fwd[s0 + t];
+        pb[t] = posof_bwd[s0 + t];
+    }
+}
+// between the two sweeps of a pair: `y` is the result of the first one
+static void bump_between(Context* c, bool trans, double* y, const int* done) {
+    SplitOperator* S = c->split;
+    if (S->bump_size == 0) return;
+    const int kb = S->bump_size;
+    const size_t lds = (size_t)(kb + 64) * sizeof(double);
+    if (trans) hipLaunchKernelGGL(bump_solve_kernel<true>, dim3(1), dim3(kBumpThreads), lds, c->stream, kb, S->bumpD.get(), S->bump_invL.get(),
+                                  S->bump_invU.get(), S->bump_pos_bwd.get(), y, done);
+    else hipLaunchKernelGGL(bump_solve_kernel<false>, dim3(1), dim3(kBumpThreads), lds, c->stream, kb, S->bumpD.get(), S->bump_invL.get(),
+                            S->bump_invU.get(), S->bump_pos_fwd.get(), y, done);
 }
 
 // 64-bit permutations / basis list on the device -> the operator's 32-bit copies (+ InversePerm, utils.cc:73-80)
@@ -748,8 +910,45 @@ void split_prepare_lu(Context* c, const ipxint* status, const double* colscale) 
     c->split = nullptr;
     S->m = m;
     if (const char* e = getenv("IPXK_TRISOLVE")) S->level_launches = std::string(e) == "levels";
-    analyse_sweeps_resident(c, S.get(), V.F, nullptr, nullptr, nullptr, nullptr);
+    // the dense bump leaves the level-scheduled structure (SplitOperator::bump_*)
+    DeviceFactors F = V.F;
+    DevBuf<ipxint> TLp, TUp, TUi;
+    DevBuf<double> TUx;
+    S->bump_start = S->bump_size = 0;
+    const char* dense_env = getenv("IPXK_BUMP_DENSE");
+    const int bump_min = getenv("IPXK_BUMP_MIN") ? atoi(getenv("IPXK_BUMP_MIN")) : kBumpMin;      // (tests)
+    if (V.bump_size >= bump_min && V.bump_size > 0 && V.bump_start + V.bump_size == m && !(dense_env && dense_env[0] == '0')) {
+        const int s0 = V.bump_start, kb = V.bump_size, nblk = (kb + 63) / 64;
+        S->bumpD.ensure((size_t)kb * kb);
+        IPXK_HIP(hipMemsetAsync(S->bumpD.get(), 0, (size_t)kb * kb * sizeof(double), s));
+        hipLaunchKernelGGL(bump_extract_kernel, dim3(vec_grid(kb)), dim3(kBlock), 0, s, s0, kb, V.F.Lp, V.F.Li, V.F.Lx, V.F.Up, V.F.Ui,
+                           V.F.Ux, S->bumpD.get());
+        DevBuf<int> cnt((size_t)m), start((size_t)m);
+        hipLaunchKernelGGL(bump_ucount_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, m, s0, V.F.Up, V.F.Ui, cnt.get());
+        hipLaunchKernelGGL(bump_ustart_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, m, s0, V.F.Up, cnt.get(), start.get());
+        hipLaunchKernelGGL(bump_ustart_tail_kernel, dim3(1), dim3(1), 0, s, m, s0, V.F.Up, cnt.get(), start.get());
+        TLp.resize((size_t)m + 1); TUp.resize((size_t)m + 1);
+        TUi.resize((size_t)std::max<int64_t>(V.F.nzU, 1)); TUx.resize((size_t)std::max<int64_t>(V.F.nzU, 1));
+        hipLaunchKernelGGL(bump_ufill_kernel, dim3(vec_grid(m + 1)), dim3(kBlock), 0, s, m, s0, V.F.Up, V.F.Ui, V.F.Ux, start.get(), cnt.get(),
+                           TUp.get(), TUi.get(), TUx.get(), V.F.Lp, TLp.get());
+        ipxint ends[2] = {0, 0};
+        IPXK_HIP(hipMemcpyAsync(&ends[0], TLp.get() + m, sizeof(ipxint), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipMemcpyAsync(&ends[1], TUp.get() + m, sizeof(ipxint), hipMemcpyDeviceToHost, s));
+        S->bump_invL.ensure((size_t)nblk * 64 * 64); S->bump_invU.ensure((size_t)nblk * 64 * 64);
+        hipLaunchKernelGGL(bump_invert_blocks_kernel, dim3(nblk), dim3(64), 0, s, kb, S->bumpD.get(), S->bump_invL.get(), 0);
+        hipLaunchKernelGGL(bump_invert_blocks_kernel, dim3(nblk), dim3(64), 0, s, kb, S->bumpD.get(), S->bump_invU.get(), 1);
+        IPXK_HIP(hipStreamSynchronize(s));               // cnt / start go out of scope; ends
+        F = DeviceFactors{TLp.get(), V.F.Li, TUp.get(), TUi.get(), V.F.Lx, TUx.get(), ends[0], ends[1]};
+        S->bump_start = s0;
+        S->bump_size = kb;
+    }
+    analyse_sweeps_resident(c, S.get(), F, nullptr, nullptr, nullptr, nullptr);
     const size_t mm = (size_t)std::max(m, 1);
+    if (S->bump_size > 0) {
+        S->bump_pos_fwd.ensure((size_t)S->bump_size); S->bump_pos_bwd.ensure((size_t)S->bump_size);
+        hipLaunchKernelGGL(bump_positions_kernel, dim3(vec_grid(S->bump_size)), dim3(kBlock), 0, s, S->bump_start, S->bump_size,
+                           S->Lf.posof.get(), S->Ut.posof.get(), S->bump_pos_fwd.get(), S->bump_pos_bwd.get());
+    }
     S->rowperm.ensure(mm); S->rowperm_inv.ensure(mm); S->colperm.ensure(mm); S->basis.ensure(mm);
     if (m > 0)
         hipLaunchKernelGGL(perms_from_lu_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, m, V.rowperm, V.colperm, V.basis,
@@ -781,6 +980,7 @@ int split_apply_dev(Context* c, const double* rhs, double* lhs, const int* done)
     // inverse(B') * rhs
     time_mark(c, kTimeBt, true);
     run_sweep(c, S->Ut, true, rhs, done);
+    bump_between(c, true, S->Ut.y.get(), done);
     run_sweep(c, S->Lt, true, S->Ut.y.get(), done);
     time_mark(c, kTimeBt, false);
     time_mark(c, kTimeOp, true);
@@ -794,6 +994,7 @@ int split_apply_dev(Context* c, const double* rhs, double* lhs, const int* done)
     // inverse(B) * that (the L sweep reads `work` through rowperm)
     time_mark(c, kTimeB, true);
     run_sweep(c, S->Lf, true, work, done);
+    bump_between(c, false, S->Lf.y.get(), done);
     run_sweep(c, S->Uf, true, S->Lf.y.get(), done);
     time_mark(c, kTimeB, false);
     // lhs = result + rhs; zero free positions; dot
@@ -814,11 +1015,13 @@ void solve_dense_dev(Context* c, const double* rhs, double* lhs, char trans) {
                            (const int*)nullptr);
         fill_results(c, {&S->Ut, &S->Lt}, nullptr);
         run_sweep(c, S->Ut, false, work, nullptr);
+        bump_between(c, true, S->Ut.y.get(), nullptr);
         run_sweep(c, S->Lt, false, S->Ut.y.get(), nullptr);
         unpack_result(c, S->Lt, S->rowperm.get(), lhs);            // lhs[rowperm[k]] = solution[k]
     } else {
         fill_results(c, {&S->Lf, &S->Uf}, nullptr);
         run_sweep(c, S->Lf, false, rhs, nullptr);                   // reads rhs[rowperm[.]]
+        bump_between(c, false, S->Lf.y.get(), nullptr);
         run_sweep(c, S->Uf, false, S->Lf.y.get(), nullptr);
         unpack_result(c, S->Uf, S->colperm.get(), lhs);            // lhs[colperm[k]] = solution[k]
     }

@@ -103,6 +103,14 @@ struct SplitOperator {
     DevBuf<int> abort_flag;
     DevBuf<double> tI;                     // m
     bool level_launches = false;           // IPXK_TRISOLVE=levels: one launch per level (debugging aid)
+    // Dense bump of the factorization (factors that came from the device LU): with the bump's block D22 =
+    // (L22+I) U22 cut out of L and U,  (L+I) U = (L~+I) blockdiag(I, D22) U~,  L~ = L without L22, U~ = U with U22
+    // replaced by I.  The level-scheduled sweeps run on L~ and U~ (no chain as long as the bump), and BETWEEN the
+    // two sweeps of a pair one workgroup solves with the dense block in place (bump_solve_kernel, trisolve.hip).
+    int bump_start = 0, bump_size = 0;     // 0: no dense block
+    DevBuf<double> bumpD;                  // bump_size^2, column major: U22 on and above the diagonal, L22 below
+    DevBuf<double> bump_invL, bump_invU;   // inverted 64 x 64 diagonal blocks of L22+I and of U22
+    DevBuf<int> bump_pos_fwd, bump_pos_bwd;   // position of bump unknown t in the result of the L sweep / of the U' sweep
 };
 
 // Launch plan of a sweep from its level structure (host arithmetic, O(#levels)).
@@ -122,6 +130,7 @@ void analyse_sweeps_resident(Context* c, SplitOperator* S, const DeviceFactors& 
 // the factors of the last LU factorization of this context (lu.hip); false if there is none
 struct LuView {
     int dim = 0, ndep = 0;
+    int bump_start = 0, bump_size = 0;     // the last pivots (stages) of the factorization came from a dense bump
     bool from_basis = false;
     DeviceFactors F{};
     const ipxint *rowperm = nullptr, *colperm = nullptr, *basis = nullptr;

@@ -129,12 +129,20 @@ def test_basis_factorize_and_prepare_on_device(kkt, oracle, m, n, bump):
     assert F["num_dependent"] == 0 and F["bump"] == bump
     ctx.split_prepare_lu(P["status"], colscale)
     rhs = np.random.default_rng(2).standard_normal(m)
+    assert ctx.split_levels()[0] < (bump if bump >= 32 else 10 ** 9)      # the dense block is not a chain of levels
     lhs1, dot1 = ctx.split_apply(rhs)
     f1, b1 = ctx.forward_solve(rhs), ctx.backward_solve(rhs)
     ctx.split_prepare(F["L"], F["U"], F["rowperm"], F["colperm"], P["basis"], P["status"], colscale)
     lhs2, dot2 = ctx.split_apply(rhs)
-    assert np.array_equal(lhs1, lhs2) and dot1 == dot2
-    assert np.array_equal(f1, ctx.forward_solve(rhs)) and np.array_equal(b1, ctx.backward_solve(rhs))
+    if bump < 32:
+        assert np.array_equal(lhs1, lhs2) and dot1 == dot2
+        assert np.array_equal(f1, ctx.forward_solve(rhs)) and np.array_equal(b1, ctx.backward_solve(rhs))
+    else:
+        # from the resident factors a bump of >= 32 rows is solved as a dense block between the sweeps of a pair
+        # (blocked, inverted diagonal blocks) instead of a chain of levels: same operator, other rounding
+        rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+        assert rel(lhs1, lhs2) < 1e-11 and abs(dot1 - dot2) <= 1e-11 * abs(dot2)
+        assert rel(f1, ctx.forward_solve(rhs)) < 1e-11 and rel(b1, ctx.backward_solve(rhs)) < 1e-11
     # and it is the inverse of B: SolveDense
     AI = sp.hstack([P["A"].to_scipy(), sp.identity(m)]).tocsc()
     B = AI[:, P["basis"]]

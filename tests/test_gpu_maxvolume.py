@@ -55,7 +55,8 @@ def test_maxvolume_vs_oracle(kkt, oracle, po, m, n, bump, seed, free, fixed, max
     F = ctx.lu_factorize_basis(got["basis"], 0.1)
     ctx.split_prepare(F["L"], F["U"], F["rowperm"], F["colperm"], got["basis"], got["status"], colscale)
     lhs2, dot2 = ctx.split_apply(rhs)
-    assert np.array_equal(lhs1, lhs2) and dot1 == dot2
+    # (a bump of >= 32 rows is solved as a dense block when the factors are resident: same operator, other rounding)
+    assert np.abs(lhs1 - lhs2).max() <= 1e-10 * np.abs(lhs2).max() and abs(dot1 - dot2) <= 1e-10 * abs(dot2)
     ctx.close()
 
 
