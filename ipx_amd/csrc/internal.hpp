@@ -160,6 +160,7 @@ struct GatherView {                // passed to kernels by value
     const int* long_slot;          // [nlong+1] segment range of each long row
     double* long_partials;         // [nseg]
     unsigned long long* stamps;    // tuning aid: wall clock at the start of each step (or nullptr)
+    int masked;                    // val / lval are masked copies: entries with value zero are not gathered
 };
 
 // XCD-sliced tile layout (alternative to the phased layout for large gathered vectors).  The
@@ -185,6 +186,7 @@ struct SlicedView {
     const double* val;
     double* partial;                   // [nslices][nrows_pad]
     const unsigned char* row_long;     // [nrows] 1 for long rows (handled by the long-row kernels), or nullptr
+    int masked;                        // val is a masked copy: entries with value zero are not gathered
 };
 
 struct SlicedMatrix {
@@ -230,6 +232,14 @@ struct GatherMatrix {
 
     GatherView view() const;
     int grid() const { return G; }
+    // Masked products (the basis path's N N' on the model matrix: entries of BASIC / fixed columns count for
+    // nothing): a second value array of the layout in use in which those entries are zero -- the kernels issue no
+    // gather for an entry whose value is zero.  mask_values() fills it from a weight per ROW of the gather matrix
+    // (by_row) or per GATHERED index; use_masked switches the views to it.
+    DevBuf<double> valM, lvalM;
+    DevBuf<int> rowof;                  // row of every stored short entry (built on first use by mask_values(by_row))
+    bool use_masked = false;
+    void mask_values(const double* weight, bool by_row, hipStream_t s);
     // # dot partials a launch produces
     int num_partials() const {
         const int extra = nlong > 0 ? 1 : 0;      // the long-row fix-up kernel adds one

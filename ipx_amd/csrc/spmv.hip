@@ -334,8 +334,9 @@ SlicedView GatherMatrix::sliced_view() const {
     SlicedView V;
     V.nrows = nrows; V.nrows_pad = sliced.nrows_pad; V.nslices = sliced.nslices; V.nrb = sliced.nrb; V.R = sliced.R;
     V.tile_ptr = sliced.tile_ptr.get(); V.cnt = sliced.cnt.get();
-    V.idx = sliced.idx.get(); V.val = sliced.val.get(); V.partial = sliced.partial.get();
+    V.idx = sliced.idx.get(); V.val = use_masked ? valM.get() : sliced.val.get(); V.partial = sliced.partial.get();
     V.row_long = nlong > 0 ? row_long.get() : nullptr;
+    V.masked = use_masked ? 1 : 0;
     return V;
 }
 
@@ -346,14 +347,108 @@ GatherView GatherMatrix::view() const {
     V.step_ptr = step_ptr.get(); V.counts = counts.get();
     V.wg_chunk_ptr = wg_chunk_ptr.get(); V.chunk_start = chunk_start.get();
     V.chunk_info = chunk_info.get(); V.chunk_step = chunk_step.get();
-    V.idx = idx.get(); V.val = val.get();
+    V.idx = idx.get(); V.val = (use_masked && !use_sliced) ? valM.get() : val.get();
     V.row_long = nlong > 0 ? row_long.get() : nullptr;
     V.nseg = nseg; V.seg_p0 = seg_p0.get(); V.seg_p1 = seg_p1.get();
-    V.lidx = lidx.get(); V.lval = lval.get();
+    V.lidx = lidx.get(); V.lval = (use_masked && nlong > 0) ? lvalM.get() : lval.get();
     V.nlong = nlong; V.long_row = long_row.get(); V.long_slot = long_slot.get();
     V.long_partials = long_partials.get();
     V.stamps = stamps.size() ? stamps.get() : nullptr;
+    V.masked = use_masked ? 1 : 0;
     return V;
+}
+
+// ---------------------------------------------------------------------------
+// masked values (GatherMatrix::mask_values)
+// ---------------------------------------------------------------------------
+// row of every stored entry.  Both layouts store a unit (tile / step) row by row with one count per row:
+// a workgroup scans the counts of its unit and labels the entries.
+__global__ __launch_bounds__(kBlock) void rowof_sliced_kernel(SlicedView M, int* __restrict__ rowof) {
+    __shared__ int wsum[kBlock / 64];
+    const int tile = blockIdx.x, rb = tile / M.nslices, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rpt = M.R / kBlock;
+    const unsigned char* cb = M.cnt + (size_t)tile * M.R + (size_t)tid * rpt;
+    int mine = 0;
+    for (int q = 0; q < rpt; q++) mine += cb[q];
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int p = (int)M.tile_ptr[tile] + incl - mine;
+    for (int w = 0; w < wave; w++) p += wsum[w];
+    for (int q = 0; q < rpt; q++) {
+        const int r = rb * M.R + tid * rpt + q;
+        for (int k = 0; k < cb[q]; k++) rowof[p++] = r;
+    }
+}
+__global__ __launch_bounds__(kBlock) void rowof_phased_kernel(GatherView M, int64_t RW, int* __restrict__ rowof) {
+    __shared__ int total;
+    // one step per workgroup; its rows in order of the count slots (thread-serial scan in chunks of kBlock slots)
+    const int64_t st = blockIdx.x;
+    const int w = (int)(st % M.G), q = (int)(st / ((int64_t)M.P * M.G));
+    const int64_t row0 = (int64_t)q * M.G * M.RWrows + (int64_t)w * M.RWrows;
+    __shared__ int wsum[kBlock / 64];
+    int base = M.step_ptr[st];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int64_t l0 = 0; l0 < RW; l0 += kBlock) {
+        const int64_t lr = l0 + tid;
+        const int mine = lr < RW ? M.counts[(size_t)st * RW + lr] : 0;
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int p = base + incl - mine;
+        for (int ww = 0; ww < wave; ww++) p += wsum[ww];
+        for (int k = 0; k < mine; k++) rowof[p + k] = (int)(row0 + lr);
+        if (tid == kBlock - 1) total = p + mine;
+        __syncthreads();
+        base = total;
+        __syncthreads();
+    }
+}
+__global__ void mask_values_kernel(int64_t nz, const double* __restrict__ val, const int* __restrict__ key,
+                                   const double* __restrict__ weight, double* __restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nz; e += (int64_t)gridDim.x * blockDim.x)
+        out[e] = weight[key[e]] != 0.0 ? val[e] : 0.0;
+}
+__global__ void mask_long_rows_kernel(GatherView M, const double* __restrict__ weight, int by_row, double* __restrict__ out) {
+    const int l = blockIdx.x;
+    const int r = M.long_row[l];
+    for (int sgm = M.long_slot[l]; sgm < M.long_slot[l + 1]; sgm++)
+        for (int p = M.seg_p0[sgm] + threadIdx.x; p < M.seg_p1[sgm]; p += blockDim.x)
+            out[p] = weight[by_row ? r : M.lidx[p]] != 0.0 ? M.lval[p] : 0.0;
+}
+
+void GatherMatrix::mask_values(const double* weight, bool by_row, hipStream_t s) {
+    const bool was = use_masked;
+    use_masked = false;                                    // the views below must show the original values
+    const int64_t nz = use_sliced ? (int64_t)sliced.idx.size() : (int64_t)idx.size();
+    const int* gidx = use_sliced ? sliced.idx.get() : idx.get();
+    const double* gval = use_sliced ? sliced.val.get() : val.get();
+    if (by_row && rowof.size() == 0 && nz > 0) {
+        rowof.resize((size_t)nz);
+        IPXK_HIP(hipMemsetAsync(rowof.get(), 0, (size_t)nz * sizeof(int), s));
+        if (use_sliced) {
+            const SlicedView V = sliced_view();
+            hipLaunchKernelGGL(rowof_sliced_kernel, dim3(V.nrb * V.nslices), dim3(kBlock), 0, s, V, rowof.get());
+        } else {
+            const GatherView V = view();
+            const int64_t nsteps = (int64_t)Q * P * G;
+            hipLaunchKernelGGL(rowof_phased_kernel, dim3((unsigned)nsteps), dim3(kBlock), 0, s, V, (int64_t)kBlock * RT, rowof.get());
+        }
+    }
+    valM.ensure((size_t)std::max<int64_t>(nz, 1));
+    if (nz > 0)
+        hipLaunchKernelGGL(mask_values_kernel, dim3((unsigned)std::min<int64_t>(4096, (nz + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, nz, gval,
+                           by_row ? rowof.get() : gidx, weight, valM.get());
+    if (nlong > 0) {
+        lvalM.ensure(lval.size());
+        hipLaunchKernelGGL(mask_long_rows_kernel, dim3(nlong), dim3(kBlock), 0, s, view(), weight, by_row ? 1 : 0, lvalM.get());
+    }
+    use_masked = was;
+    IPXK_HIP(hipGetLastError());
 }
 
 // ---------------------------------------------------------------------------

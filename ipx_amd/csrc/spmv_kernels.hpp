@@ -162,7 +162,7 @@ __device__ __forceinline__ void issue_stream(const GatherView& M, int k, int ken
     }
 }
 
-template <class Epi, int RT>
+template <class Epi, int RT, bool MASKED = false>
 __global__ __launch_bounds__(kBlock, 4) void spmv_phased_kernel(GatherView M, const double* __restrict__ x,
                                                              Epi epi, double* dot_partials,
                                                              const int* done) {
@@ -196,7 +196,10 @@ __global__ __launch_bounds__(kBlock, 4) void spmv_phased_kernel(GatherView M, co
         issue_stream<RT>(M, kbeg, kend, w, tid, cur);
         issue_stream<RT>(M, kbeg + 1, kend, w, tid, nxt);
 #pragma unroll
-        for (int e = 0; e < kPerThread; e++) xg[e] = x[cur.c[e]];   // gathers of chunk 0
+        for (int e = 0; e < kPerThread; e++) {                      // gathers of chunk 0
+            if (MASKED) xg[e] = cur.v[e] != 0.0 ? x[cur.c[e]] : 0.0;    // masked value array (trisolve.hip): no gather for a zero entry
+            else xg[e] = x[cur.c[e]];
+        }
 
         int buf = 0, step_n0 = 0;
         int cnt[RT], off[RT];      // my rows' entry counts and first positions within the current step
@@ -232,7 +235,10 @@ __global__ __launch_bounds__(kBlock, 4) void spmv_phased_kernel(GatherView M, co
                 }
             }
 #pragma unroll
-            for (int e = 0; e < kPerThread; e++) xg[e] = x[nxt.c[e]];
+            for (int e = 0; e < kPerThread; e++) {
+                if (MASKED) xg[e] = nxt.v[e] != 0.0 ? x[nxt.c[e]] : 0.0;
+                else xg[e] = x[nxt.c[e]];
+            }
             cur = nxt;
             issue_stream<RT>(M, k + 2, kend, w, tid, nxt);
             __syncthreads();
@@ -291,8 +297,10 @@ __global__ __launch_bounds__(kBlock) void spmv_long_kernel(GatherView M, const d
     __shared__ double red[kBlock / 64 + 1];
     const int sgm = blockIdx.x;
     double acc = 0.0;
-    for (int p = M.seg_p0[sgm] + threadIdx.x; p < M.seg_p1[sgm]; p += kBlock)
-        acc += Epi::prod(x[M.lidx[p]], __builtin_nontemporal_load(M.lval + p));
+    for (int p = M.seg_p0[sgm] + threadIdx.x; p < M.seg_p1[sgm]; p += kBlock) {
+        const double v = __builtin_nontemporal_load(M.lval + p);
+        acc += Epi::prod(v != 0.0 ? x[M.lidx[p]] : 0.0, v);
+    }
     acc = block_reduce<SumOp>(acc, red);
     if (threadIdx.x == 0) M.long_partials[sgm] = acc;
 }
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(kBlock) void spmv_long_fixup_kernel(GatherView M, E
 // FUSED (one slice = the whole index space): no partial vectors and no combine launch; the thread
 // starts each row from epi.init, adds the row's products in storage order (the reference's order,
 // bit for bit) and applies epi.finish itself; the tile's dot partial goes to dot_partials[tile].
-template <class Epi, int RPT, bool FUSED>
+template <class Epi, int RPT, bool FUSED, bool MASKED = false>
 __global__ __launch_bounds__(kBlock) void spmv_sliced_tile_kernel(SlicedView M, const double* __restrict__ x,
                                                                   Epi epi, double* dot_partials, const int* done) {
     if (done && *done) return;
@@ -364,7 +372,10 @@ __global__ __launch_bounds__(kBlock) void spmv_sliced_tile_kernel(SlicedView M, 
                 v[u] = __builtin_nontemporal_load(M.val + e0 + i);
             }
 #pragma unroll
-            for (int u = 0; u < U; u++) xg[u] = x[ci[u]];
+            for (int u = 0; u < U; u++) {
+                if (MASKED) xg[u] = v[u] != 0.0 ? x[ci[u]] : 0.0;   // masked value array (trisolve.hip): a zero entry needs no gather
+                else xg[u] = x[ci[u]];
+            }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int i = base + u * kBlock + tid;
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void spmv_sliced_combine_kernel(SlicedView 
     }
 }
 
-template <class Epi>
+template <class Epi, bool MASKED = false>
 inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi& epi, double* dot_partials,
                                const int* done, hipStream_t s) {
     const SlicedView V = M.sliced_view();
@@ -454,13 +465,13 @@ inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi
     const dim3 grid(V.nrb * V.nslices), block(kBlock);
     if (V.nslices == 1) {       // fused: the tile kernel is the whole product
         const dim3 fgrid(M.fused_grid());
-        if (V.R == kBlock * 4) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 4, true>), fgrid, block, lds, s, V, x, epi, dot_partials, done);
-        else if (V.R == kBlock * 2) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 2, true>), fgrid, block, lds, s, V, x, epi, dot_partials, done);
-        else hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 1, true>), fgrid, block, lds, s, V, x, epi, dot_partials, done);
+        if (V.R == kBlock * 4) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 4, true, MASKED>), fgrid, block, lds, s, V, x, epi, dot_partials, done);
+        else if (V.R == kBlock * 2) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 2, true, MASKED>), fgrid, block, lds, s, V, x, epi, dot_partials, done);
+        else hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 1, true, MASKED>), fgrid, block, lds, s, V, x, epi, dot_partials, done);
     } else {
-        if (V.R == kBlock * 4) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 4, false>), grid, block, lds, s, V, x, epi, dot_partials, done);
-        else if (V.R == kBlock * 2) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 2, false>), grid, block, lds, s, V, x, epi, dot_partials, done);
-        else hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 1, false>), grid, block, lds, s, V, x, epi, dot_partials, done);
+        if (V.R == kBlock * 4) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 4, false, MASKED>), grid, block, lds, s, V, x, epi, dot_partials, done);
+        else if (V.R == kBlock * 2) hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 2, false, MASKED>), grid, block, lds, s, V, x, epi, dot_partials, done);
+        else hipLaunchKernelGGL((spmv_sliced_tile_kernel<Epi, 1, false, MASKED>), grid, block, lds, s, V, x, epi, dot_partials, done);
         hipLaunchKernelGGL(spmv_sliced_combine_kernel<Epi>, dim3(M.combine_grid()), dim3(kBlock), 0, s, V, epi,
                            dot_partials, done);
     }
@@ -474,20 +485,20 @@ inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi
 
 // Launches the SpMV (+ long-row kernels when the matrix has long rows).  Returns
 // the number of dot partials written (0 when dot_partials == nullptr).
-template <class Epi>
+template <class Epi, bool MASKED = false>
 inline int launch_spmv(const GatherMatrix& M, const double* x, const Epi& epi, double* dot_partials,
                        const int* done, hipStream_t s) {
     if (M.use_sliced) {
-        launch_spmv_sliced(M, x, epi, dot_partials, done, s);
+        launch_spmv_sliced<Epi, MASKED>(M, x, epi, dot_partials, done, s);
         return dot_partials ? M.num_partials() : 0;
     }
     const GatherView V = M.view();
     const dim3 grid(M.G), block(kBlock);
     switch (M.RT) {
-        case 1: hipLaunchKernelGGL((spmv_phased_kernel<Epi, 1>), grid, block, 0, s, V, x, epi, dot_partials, done); break;
-        case 2: hipLaunchKernelGGL((spmv_phased_kernel<Epi, 2>), grid, block, 0, s, V, x, epi, dot_partials, done); break;
-        case 4: hipLaunchKernelGGL((spmv_phased_kernel<Epi, 4>), grid, block, 0, s, V, x, epi, dot_partials, done); break;
-        default: hipLaunchKernelGGL((spmv_phased_kernel<Epi, 8>), grid, block, 0, s, V, x, epi, dot_partials, done); break;
+        case 1: hipLaunchKernelGGL((spmv_phased_kernel<Epi, 1, MASKED>), grid, block, 0, s, V, x, epi, dot_partials, done); break;
+        case 2: hipLaunchKernelGGL((spmv_phased_kernel<Epi, 2, MASKED>), grid, block, 0, s, V, x, epi, dot_partials, done); break;
+        case 4: hipLaunchKernelGGL((spmv_phased_kernel<Epi, 4, MASKED>), grid, block, 0, s, V, x, epi, dot_partials, done); break;
+        default: hipLaunchKernelGGL((spmv_phased_kernel<Epi, 8, MASKED>), grid, block, 0, s, V, x, epi, dot_partials, done); break;
     }
     if (M.nlong > 0) {
         hipLaunchKernelGGL(spmv_long_kernel<Epi>, dim3(M.nseg), block, 0, s, V, x, done);

@@ -638,6 +638,13 @@ static void upload_scaling(Context* c, SplitOperator* S, const ipxint* status, c
     if (h[0]) throw Error(IPXK_E_ARGUMENT, "status entry out of range");
     S->num_free = h[1];
     rescale_sweeps_device(c, S);
+    // N N' runs on the model matrix with weights that are zero on the BASIC and fixed columns: value arrays in
+    // which those columns' entries are zero let both passes skip the gathers of those entries (spmv.hip)
+    S->masked_values = !(getenv("IPXK_MASKED_VALUES") && getenv("IPXK_MASKED_VALUES")[0] == '0');
+    if (S->masked_values) {
+        c->Acols.mask_values(S->Wsplit.get(), true, s);      // a row of the gather matrix = a structural column
+        c->Arows.mask_values(S->Wsplit.get(), false, s);     // the gathered index = a structural column
+    }
 }
 
 // what follows the analysis of the factors and the upload of the permutations in a Prepare: scaling, work
@@ -987,9 +994,17 @@ int split_apply_dev(Context* c, const double* rhs, double* lhs, const int* done)
     // N N' of it: into the row order of A, A (M D^2) A'
     hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, S->Lt.y.get(), S->perm_after_backward.get(), u, done);
     EpiScale e1{{}, S->Wsplit.get(), c->tcols.get()};
-    launch_spmv(c->Acols, u, e1, nullptr, done, s);
     EpiNormalRows e2{{}, S->Wsplit.get() + n, u, work};
-    launch_spmv(c->Arows, c->tcols.get(), e2, nullptr, done, s);
+    if (S->masked_values) {
+        // the entries of BASIC / fixed columns have weight zero in both passes: masked value arrays, no gathers for them
+        c->Acols.use_masked = c->Arows.use_masked = true;
+        launch_spmv<EpiScale, true>(c->Acols, u, e1, nullptr, done, s);
+        launch_spmv<EpiNormalRows, true>(c->Arows, c->tcols.get(), e2, nullptr, done, s);
+        c->Acols.use_masked = c->Arows.use_masked = false;
+    } else {
+        launch_spmv(c->Acols, u, e1, nullptr, done, s);
+        launch_spmv(c->Arows, c->tcols.get(), e2, nullptr, done, s);
+    }
     time_mark(c, kTimeOp, false);
     // inverse(B) * that (the L sweep reads `work` through rowperm)
     time_mark(c, kTimeB, true);
