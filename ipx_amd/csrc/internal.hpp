@@ -226,19 +226,18 @@ struct GatherMatrix {
     float tuned_us_phased = 0.f, tuned_us_sliced = 0.f, tuned_us_fused = 0.f;
     // ns_request: 0 = as many slices as x needs (>= 2), 1 = the fused single-slice variant
     void build_sliced(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s, int ns_request);
-    SlicedView sliced_view() const;
+    SlicedView sliced_view(bool masked = false) const;
     int fused_grid() const { return std::min(sliced.nrb, kMaxPartials); }
     int combine_grid() const { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, ((int64_t)nrows + kBlock - 1) / kBlock)); }
 
-    GatherView view() const;
+    GatherView view(bool masked = false) const;
     int grid() const { return G; }
     // Masked products (the basis path's N N' on the model matrix: entries of BASIC / fixed columns count for
     // nothing): a second value array of the layout in use in which those entries are zero -- the kernels issue no
     // gather for an entry whose value is zero.  mask_values() fills it from a weight per ROW of the gather matrix
-    // (by_row) or per GATHERED index; use_masked switches the views to it.
+    // (by_row) or per GATHERED index; view(true) / sliced_view(true) show it (launch_spmv<Epi, true>).
     DevBuf<double> valM, lvalM;
     DevBuf<int> rowof;                  // row of every stored short entry (built on first use by mask_values(by_row))
-    bool use_masked = false;
     void mask_values(const double* weight, bool by_row, hipStream_t s);
     // # dot partials a launch produces
     int num_partials() const {

@@ -330,7 +330,7 @@ void GatherMatrix::build_sliced(const ipxint* hptr, const ipxint* hidx, const do
     sliced.built = true;
 }
 
-SlicedView GatherMatrix::sliced_view() const {
+SlicedView GatherMatrix::sliced_view(bool use_masked) const {
     SlicedView V;
     V.nrows = nrows; V.nrows_pad = sliced.nrows_pad; V.nslices = sliced.nslices; V.nrb = sliced.nrb; V.R = sliced.R;
     V.tile_ptr = sliced.tile_ptr.get(); V.cnt = sliced.cnt.get();
@@ -340,7 +340,7 @@ SlicedView GatherMatrix::sliced_view() const {
     return V;
 }
 
-GatherView GatherMatrix::view() const {
+GatherView GatherMatrix::view(bool use_masked) const {
     GatherView V;
     V.nrows = nrows; V.ncols = ncols;
     V.P = P; V.G = G; V.RT = RT; V.Q = Q; V.RWrows = RWrows;
@@ -422,8 +422,6 @@ __global__ void mask_long_rows_kernel(GatherView M, const double* __restrict__ w
 }
 
 void GatherMatrix::mask_values(const double* weight, bool by_row, hipStream_t s) {
-    const bool was = use_masked;
-    use_masked = false;                                    // the views below must show the original values
     const int64_t nz = use_sliced ? (int64_t)sliced.idx.size() : (int64_t)idx.size();
     const int* gidx = use_sliced ? sliced.idx.get() : idx.get();
     const double* gval = use_sliced ? sliced.val.get() : val.get();
@@ -447,7 +445,6 @@ void GatherMatrix::mask_values(const double* weight, bool by_row, hipStream_t s)
         lvalM.ensure(lval.size());
         hipLaunchKernelGGL(mask_long_rows_kernel, dim3(nlong), dim3(kBlock), 0, s, view(), weight, by_row ? 1 : 0, lvalM.get());
     }
-    use_masked = was;
     IPXK_HIP(hipGetLastError());
 }
 

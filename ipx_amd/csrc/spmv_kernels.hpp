@@ -460,7 +460,7 @@ __global__ __launch_bounds__(kBlock) void spmv_sliced_combine_kernel(SlicedView 
 template <class Epi, bool MASKED = false>
 inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi& epi, double* dot_partials,
                                const int* done, hipStream_t s) {
-    const SlicedView V = M.sliced_view();
+    const SlicedView V = M.sliced_view(MASKED);
     const size_t lds = (size_t)(M.sliced.max_tile + M.sliced.max_tile / 32 + 1) * sizeof(double);
     const dim3 grid(V.nrb * V.nslices), block(kBlock);
     if (V.nslices == 1) {       // fused: the tile kernel is the whole product
@@ -476,7 +476,7 @@ inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi
                            dot_partials, done);
     }
     if (M.nlong > 0) {          // rows of more than kMaxRowLen entries: segment sums + ordered fix-up
-        const GatherView G = M.view();
+        const GatherView G = M.view(MASKED);
         hipLaunchKernelGGL(spmv_long_kernel<Epi>, dim3(M.nseg), block, 0, s, G, x, done);
         hipLaunchKernelGGL(spmv_long_fixup_kernel<Epi>, dim3(1), block, 0, s, G, epi, dot_partials,
                            V.nslices == 1 ? M.fused_grid() : M.combine_grid(), done);
@@ -492,7 +492,7 @@ inline int launch_spmv(const GatherMatrix& M, const double* x, const Epi& epi, d
         launch_spmv_sliced<Epi, MASKED>(M, x, epi, dot_partials, done, s);
         return dot_partials ? M.num_partials() : 0;
     }
-    const GatherView V = M.view();
+    const GatherView V = M.view(MASKED);
     const dim3 grid(M.G), block(kBlock);
     switch (M.RT) {
         case 1: hipLaunchKernelGGL((spmv_phased_kernel<Epi, 1, MASKED>), grid, block, 0, s, V, x, epi, dot_partials, done); break;

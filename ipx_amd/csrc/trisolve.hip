@@ -997,10 +997,8 @@ int split_apply_dev(Context* c, const double* rhs, double* lhs, const int* done)
     EpiNormalRows e2{{}, S->Wsplit.get() + n, u, work};
     if (S->masked_values) {
         // the entries of BASIC / fixed columns have weight zero in both passes: masked value arrays, no gathers for them
-        c->Acols.use_masked = c->Arows.use_masked = true;
         launch_spmv<EpiScale, true>(c->Acols, u, e1, nullptr, done, s);
         launch_spmv<EpiNormalRows, true>(c->Arows, c->tcols.get(), e2, nullptr, done, s);
-        c->Acols.use_masked = c->Arows.use_masked = false;
     } else {
         launch_spmv(c->Acols, u, e1, nullptr, done, s);
         launch_spmv(c->Arows, c->tcols.get(), e2, nullptr, done, s);
