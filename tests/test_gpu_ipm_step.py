@@ -239,3 +239,22 @@ def test_ipm_two_phases_on_the_device(kkt, seed, m, n):
     g3 = ctx.ipm_driver_basis(b, c, lbs, ubs, ipm_maxiter=100)
     assert g3["status_ipm"] == 1 and abs(g3["pobjective"] - r.fun) <= 1e-6 * (1.0 + abs(r.fun))
     ctx.close()
+
+
+def test_ipm_driver_basis_refuses_what_it_does_not_handle(kkt):
+    """the device-side main phase starts from the slack basis of a model whose variables are all in a barrier state;
+    free or fixed variables (PivotFreeVariablesIntoBasis / PivotFixedVariablesOutOfBasis, src/basis.cc:379-384) are
+    refused loudly, not mishandled"""
+    A, b, c, lbs, ubs, state, it = feasible_lp(60, 150, 71)
+    ctx = kkt.KktContext(A)
+    st2 = state.copy()
+    st2[3] = 1                                                   # a free variable
+    it2 = {k: v.copy() for k, v in it.items()}
+    it2["xl"][3] = np.inf; it2["zl"][3] = 0.0
+    ctx.iterate_set(it2, st2)
+    with pytest.raises(kkt.KktError, match="barrier variables only"):
+        ctx.ipm_driver_basis(b, c, lbs, ubs, ipm_maxiter=5)
+    ctx.iterate_set(it, state)
+    g = ctx.ipm_driver_basis(b, c, lbs, ubs, ipm_maxiter=2)      # iteration limit of the basis phase
+    assert g["status_ipm"] == 6 and g["iter"] == 2 and g["basis_updates"] > 0
+    ctx.close()
