@@ -161,3 +161,45 @@ def test_basis_factorize_and_prepare_on_device(kkt, oracle, m, n, bump):
     with pytest.raises(kkt.KktError, match="ipxk_lu_factorize_basis"):
         ctx3.split_prepare_lu(P["status"], colscale)
     ctx.close(); ctx2.close(); ctx3.close()
+
+
+def test_lu_and_maxvolume_at_baseline_size(kkt, ref):
+    """BASELINE config 3 size (m = 1M, n = 2M) through size-independent properties: the LU of a nearly triangular
+    basis satisfies the reference's own stability estimate and solves B x = b, B'y = b; Maxvolume from the slack
+    basis brings exactly the variables with large scaling factors in, never refuses an exchange, gains volume with
+    every exchange, and leaves a factorization that solves with the NEW basis"""
+    import scipy.sparse as sp
+    m, n, bump = 1000000, 2000000, 1000
+    P = synth.lp_like_basis(m, n, seed=12345, bump=bump, offdiag=3)
+    G = P["G"]
+    ctx = kkt.KktContext(P["A"])
+    F = ctx.lu_factorize_basis(P["basis"], 0.1)
+    assert F["bump"] == bump and F["num_dependent"] == 0 and F["col_singletons"] + F["row_singletons"] + bump == m
+    R = ref.lu(m, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], F)
+    assert R.flag == 0 and R.stability < 1e-12                       # kLuStabilityThreshold
+    colscale = synth.synthetic_basis_state(P["status"], 1.0, 12345)
+    ctx.split_prepare_lu(P["status"], colscale)
+    B = sp.csc_matrix((G["Bx"].copy(), G["Bi"].copy(), G["Bp"].copy()), shape=(m, m))
+    rhs = np.random.default_rng(1).standard_normal(m)
+    for trans in ("n", "t"):
+        x = ctx.solve_dense(rhs, trans)
+        assert np.abs((B.T if trans == "t" else B) @ x - rhs).max() <= 1e-9 * (1 + np.abs(x).max())
+    ctx.close()
+    # Maxvolume from the slack basis
+    A = synth.synthetic_lp(m, n, 8, 12345)
+    basis, status, colscale = synth.slack_basis_crash_state(m, n, 300, 1.0, 12345)
+    ctx = kkt.KktContext(A)
+    ctx.lu_factorize_basis(basis, 0.1, download=False)
+    ctx.split_prepare_lu(status, colscale)
+    r = ctx.maxvolume(status, colscale)
+    assert r["errflag"] == 0 and r["refused"] == 0 and r["updates"] == 300 and r["slices"] == 105
+    entered = r["exchanges"][:, 1]
+    assert np.all(colscale[entered] >= 100.0) and len(set(entered)) == 300      # exactly the 300 large ones
+    assert np.all(r["exchanges"][:, 0] >= n)                                     # slack variables left
+    assert r["volinc"] >= 300.0                                                  # > volume_tol = 2 per exchange
+    assert sorted(r["basis"]) == sorted(np.nonzero(r["status"] == 0)[0])
+    AI = sp.hstack([A.to_scipy(), sp.identity(m, format="csc")]).tocsc()
+    Bn = AI[:, r["basis"]]
+    x = ctx.solve_dense(rhs, "n")
+    assert np.abs(Bn @ x - rhs).max() <= 1e-9 * (1 + np.abs(x).max())
+    ctx.close()
