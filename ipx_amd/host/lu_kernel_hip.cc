@@ -13,7 +13,14 @@ void LuKernelHip::_Factorize(Int dim, const Int* Bbegin, const Int* Bend, const 
     // Errors: out of memory -> std::bad_alloc (the one failure lu_factorization.h:49-50 allows); a bump beyond
     // the dense limit (IPXK_E_UNSUPPORTED) -> std::runtime_error, i.e. IPX_STATUS_internal_error at
     // src/lp_solver.cc:98-105 -- a caller that wants to go on would factorize that basis with BasicLuKernel.
-    ipx_hip::Check(ipxk_lu_factorize(ctx_, dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol ? 1 : 0, &info_));
+    const int rc = ipxk_lu_factorize(ctx_, dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol ? 1 : 0, &info_);
+    if (rc == IPXK_E_UNSUPPORTED && fallback_) {      // not a nearly triangular basis: the CPU kernel takes it
+        fallbacks_++;
+        fallback_->Factorize(dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol, L, U, rowperm, colperm,
+                             dependent_cols);
+        return;
+    }
+    ipx_hip::Check(rc);
     L->resize(dim, dim, info_.lnz);
     U->resize(dim, dim, info_.unz);
     rowperm->resize(dim);

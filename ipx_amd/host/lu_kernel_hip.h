@@ -11,6 +11,8 @@
 #ifndef IPX_LU_KERNEL_HIP_H_
 #define IPX_LU_KERNEL_HIP_H_
 
+#include <memory>
+
 #include "ipx_kkt_hip.h"
 #include "lu_factorization.h"
 
@@ -19,7 +21,14 @@ namespace ipx {
 class LuKernelHip : public LuFactorization {
 public:
     // @ctx: a context on the GPU to use (e.g. the one of KKTSolverBasisHip); not owned, must outlive the object
-    explicit LuKernelHip(ipxk_context* ctx) : ctx_(ctx) {}
+    // @fallback: optional kernel for the bases the device LU declines (a bump beyond its dense limit,
+    //            IPXK_E_UNSUPPORTED) -- inside IPX: new BasicLuKernel.  Without one such a basis makes
+    //            Factorize() throw std::runtime_error.
+    explicit LuKernelHip(ipxk_context* ctx, std::unique_ptr<LuFactorization> fallback = nullptr)
+        : ctx_(ctx), fallback_(std::move(fallback)) {}
+
+    // # factorizations handed to the fallback kernel so far
+    Int fallbacks() const { return fallbacks_; }
 
     // statistics of the last factorization (singletons, bump size, phase timings)
     const ipxk_lu_info& info() const { return info_; }
@@ -31,6 +40,8 @@ private:
                     std::vector<Int>* dependent_cols) override;
 
     ipxk_context* ctx_;
+    std::unique_ptr<LuFactorization> fallback_;
+    Int fallbacks_{0};
     ipxk_lu_info info_{};
 };
 

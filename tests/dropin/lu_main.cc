@@ -8,6 +8,8 @@
 // ci_k.bin / cx_k.bin (the entering column).  Built by `make -C oracle lu_dropin`; run by tests/test_gpu_dropin.py.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
 #include <fstream>
 #include <memory>
 #include <string>
@@ -20,6 +22,20 @@
 
 using ipx::Int;
 using ipx::Vector;
+
+// hands back factors computed earlier: stands in for the CPU kernel (BasicLuKernel) that LuKernelHip delegates to
+class Replay : public ipx::LuFactorization {
+public:
+    ipx::SparseMatrix L, U;
+    std::vector<Int> rowperm, colperm, dependent;
+    int* calls;
+private:
+    void _Factorize(Int, const Int*, const Int*, const Int*, const double*, double, bool, ipx::SparseMatrix* Lout,
+                    ipx::SparseMatrix* Uout, std::vector<Int>* rp, std::vector<Int>* cp, std::vector<Int>* dep) override {
+        *Lout = L; *Uout = U; *rp = rowperm; *cp = colperm; *dep = dependent;
+        (*calls)++;
+    }
+};
 
 template <class T>
 static std::vector<T> ReadBin(const std::string& path) {
@@ -113,6 +129,31 @@ int main(int argc, char** argv) {
         const double r = Residual(dim, ci, cx, x, b, trans != 0);
         std::printf("solve %c after updates: residual %.3e\n", trans ? 'T' : 'N', r);
         if (!(r < 1e-8) || done == 0) { std::printf("FAIL updated solve\n"); fails++; } else std::printf("PASS updated solve\n");
+    }
+    // a basis the device LU declines goes to the fallback kernel given to the constructor
+    {
+        ipx::LuKernelHip direct(ctx);
+        Replay* rep = new Replay;
+        int calls = 0;
+        rep->calls = &calls;
+        direct.Factorize(dim, Bp.data(), Bp.data() + 1, Bi.data(), Bx.data(), 0.1, false, &rep->L, &rep->U, &rep->rowperm,
+                         &rep->colperm, &rep->dependent);
+        setenv("IPXK_LU_BUMP_MAX", "1", 1);               // now every bump is "too large" for the device
+        ipx::LuKernelHip with_fallback(ctx, std::unique_ptr<ipx::LuFactorization>(rep));
+        ipx::SparseMatrix L2, U2;
+        std::vector<Int> rp2, cp2, dep2;
+        with_fallback.Factorize(dim, Bp.data(), Bp.data() + 1, Bi.data(), Bx.data(), 0.1, false, &L2, &U2, &rp2, &cp2, &dep2);
+        bool threw = false;
+        try {
+            ipx::LuKernelHip none(ctx);
+            none.Factorize(dim, Bp.data(), Bp.data() + 1, Bi.data(), Bx.data(), 0.1, false, &L2, &U2, &rp2, &cp2, &dep2);
+        } catch (const std::exception& e) { threw = true; }
+        unsetenv("IPXK_LU_BUMP_MAX");
+        const bool ok = calls == 1 && with_fallback.fallbacks() == 1 && with_fallback.stability() < 1e-12 && threw &&
+                        direct.info().bump > 1;
+        std::printf("fallback: calls %d, counted %ld, stability %.2e, without a fallback it throws: %d\n", calls,
+                    (long)with_fallback.fallbacks(), with_fallback.stability(), (int)threw);
+        if (!ok) { std::printf("FAIL fallback\n"); fails++; } else std::printf("PASS fallback\n");
     }
     ipxk_destroy(ctx);
     std::printf(fails ? "FAILED\n" : "DONE\n");

@@ -145,4 +145,4 @@ def test_lu_kernel_hip_under_the_reference_forrest_tomlin(tmp_path, dim, bump, n
     r = subprocess.run([exe, d], capture_output=True, text=True, timeout=600)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "DONE" in r.stdout, r.stdout + r.stderr
-    assert r.stdout.count("PASS") == 5 and "bump %d " % bump in r.stdout
+    assert r.stdout.count("PASS") == 6 and "bump %d " % bump in r.stdout        # ... and the fallback delegation
