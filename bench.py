@@ -563,6 +563,16 @@ def bench_banded(kkt, synth, m, n):
             "layouts": list(layouts)}
 
 
+def basis_traffic(layouts):
+    """HBM-side bytes per basis CR iteration from the committed PMC summary (profiles/pmc_traffic_basis.json, collected
+    with rocprofv3 --pmc in separate passes as MI355X_MICROARCH.md prescribes), if it was taken for the layouts in use"""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_basis.json")))
+        return pm["traffic_bytes_per_iteration"] if list(layouts) == ["sliced", "sliced"] else None
+    except Exception:
+        return None
+
+
 def bench_basis(kkt, synth, m, n, args):
     """BASELINE config 3: KKTSolverBasis::_Solve (src/kkt_solver_basis.cc:75-194) = plain CR on the basis-split
     operator C = I + inv(B) N N' inv(B') (src/splitted_normal_matrix.cc:90-117) on the planted-LU basis (synthetic
@@ -621,7 +631,7 @@ def bench_basis(kkt, synth, m, n, args):
            "roofline": {"bound": "hbm", "kernel": "one CR iteration on the split operator = sweep_run_kernel (U', L', L, U) + N N' [%s, %s] + CR vector kernels"
                                                   % tuple(layouts),
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "algorithmic_bytes": bytes_iter, "streamed_bytes_estimate": streamed, "traffic": None,
+                        "algorithmic_bytes": bytes_iter, "streamed_bytes_estimate": streamed, "traffic": basis_traffic(layouts),
                         "dependency_levels": int(sum(lv)),
                         "us_per_level_of_the_sweeps": (tmp.solve_Bt + tmp.solve_B) / napply * 1e6 / max(sum(lv), 1),
                         "note": "the sweeps are bound by the dependency chain (one store-to-load hand-off per level), "
