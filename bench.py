@@ -283,14 +283,8 @@ def main():
     layouts, tuned_us = ctx.spmv_layout()
     kernel_names = {"phased": "spmv_phased_kernel", "sliced": "spmv_sliced_tile_kernel+spmv_sliced_combine_kernel",
                     "fused": "spmv_sliced_tile_kernel<fused>"}
-    traffic = None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if (world == 1 and pm["workload"] == "C3 m=%d n=%d nnz=%d" % (m, n, nnz)
-                and pm.get("layouts", ["phased", "phased"]) == list(layouts)):
-            traffic = pm["traffic_bytes_per_apply"]
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic, traffic_note = pmc_traffic("pmc_traffic.json", "traffic_bytes_per_apply",
+                                        "C3 m=%d n=%d nnz=%d" % (m, n, nnz) if world == 1 else None, layouts)
 
     out = {
         "metric": "kkt_solves_per_sec",
@@ -315,7 +309,7 @@ def main():
                      "kernel": "NormalMatrix apply = pass 1 t=W.*(A'y) [%s] + pass 2 lhs=A t [%s]"
                                % (kernel_names[layouts[0]], kernel_names[layouts[1]]),
                      "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                     "traffic": traffic, "us_per_apply": apply_ms * 1e3, "algorithmic_bytes": bytes_apply,
+                     "traffic": traffic, "traffic_note": traffic_note, "us_per_apply": apply_ms * 1e3, "algorithmic_bytes": bytes_apply,
                      "layouts": list(layouts), "layout_tuning_us": tuned_us},
     }
 
@@ -563,14 +557,47 @@ def bench_banded(kkt, synth, m, n):
             "layouts": list(layouts)}
 
 
-def basis_traffic(layouts):
-    """HBM-side bytes per basis CR iteration from the committed PMC summary (profiles/pmc_traffic_basis.json, collected
-    with rocprofv3 --pmc in separate passes as MI355X_MICROARCH.md prescribes), if it was taken for the layouts in use"""
+# Sources whose kernels move the bytes the PMC summaries under profiles/ report.  A summary names the git blob hash
+# of each of these files as it was when the counters were collected; bench.py cannot collect counters on itself
+# (rocprofv3 --pmc runs are separate passes), so it reports a committed figure only while those files are unchanged.
+PMC_SOURCES = ("ipx_amd/csrc/spmv_kernels.hpp", "ipx_amd/csrc/spmv.hip", "ipx_amd/csrc/trisolve.hip",
+               "ipx_amd/csrc/trisolve.hpp", "ipx_amd/csrc/cr.hip", "ipx_amd/csrc/internal.hpp")
+
+
+def blob_hash(path):
+    """git's blob hash of a working-tree file (sha1 of 'blob <size>\\0' + content), without needing git"""
+    import hashlib
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_basis.json")))
-        return pm["traffic_bytes_per_iteration"] if list(layouts) == ["sliced", "sliced"] else None
-    except Exception:
+        data = open(os.path.join(ROOT, path), "rb").read()
+    except OSError:
         return None
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def source_hashes():
+    return {p: blob_hash(p) for p in PMC_SOURCES if blob_hash(p) is not None}
+
+
+def pmc_traffic(fname, key, workload, layouts):
+    """(bytes, note): the committed PMC figure if it was collected for this workload, these layouts and THESE kernel
+    sources (blob hashes stored next to the figure); otherwise (None, reason)"""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", fname)))
+    except (OSError, ValueError):
+        return None, "no PMC summary profiles/%s" % fname
+    if workload is None or pm.get("workload") != workload:
+        return None, "PMC summary is for another workload (%s)" % pm.get("workload")
+    if list(pm.get("layouts", [])) != list(layouts):
+        return None, "PMC summary is for layouts %s, this run uses %s" % (pm.get("layouts"), list(layouts))
+    have = pm.get("source_hashes")
+    if not have:
+        return None, "PMC summary carries no source hashes: cannot tell whether it matches these kernels"
+    now = source_hashes()
+    changed = sorted(p for p in have if now.get(p) != have[p])
+    if changed:
+        return None, "kernel sources changed since the PMC run (%s): re-run scripts/prof_r03.sh" % ", ".join(changed)
+    return pm[key], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s; sources unchanged since (%d files hashed)" % (
+        pm.get("source", "profiles/"), len(have))
 
 
 def bench_basis(kkt, synth, m, n, args):
@@ -623,6 +650,8 @@ def bench_basis(kkt, synth, m, n, args):
     bytes_iter = 2 * (nnzL + nnzU) * 12 + 4 * m * 24 + 2 * nnzN * 12 + 8 * (4 * m + 3 * (n + m)) + 9 * 8 * m
     streamed = 2 * (nnzL + nnzU) * 12 + 4 * m * 32 + 2 * B["A"].nnz * 12
     achieved = bytes_iter / (us_iter * 1e-6) / 1e9
+    btraffic, btraffic_note = pmc_traffic("pmc_traffic_basis.json", "traffic_bytes_per_iteration",
+                                          "C3 basis path, planted factors: one operator application + CR vector kernels", layouts)
     res = {"solves_per_sec": 1.0 / dt, "ms_per_solve": dt * 1e3, "cr_iterations": it, "errflag": err,
            "levels_Ut_Lt_L_U": lv, "prepare_s": prep, "rescale_s": resc, "us_per_cr_iteration": us_iter,
            "cr_iterations_per_sec": 1e6 / us_iter,
@@ -631,7 +660,7 @@ def bench_basis(kkt, synth, m, n, args):
            "roofline": {"bound": "hbm", "kernel": "one CR iteration on the split operator = sweep_run_kernel (U', L', L, U) + N N' [%s, %s] + CR vector kernels"
                                                   % tuple(layouts),
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "algorithmic_bytes": bytes_iter, "streamed_bytes_estimate": streamed, "traffic": basis_traffic(layouts),
+                        "algorithmic_bytes": bytes_iter, "streamed_bytes_estimate": streamed, "traffic": btraffic, "traffic_note": btraffic_note,
                         "dependency_levels": int(sum(lv)),
                         "us_per_level_of_the_sweeps": (tmp.solve_Bt + tmp.solve_B) / napply * 1e6 / max(sum(lv), 1),
                         "note": "the sweeps are bound by the dependency chain (one store-to-load hand-off per level), "

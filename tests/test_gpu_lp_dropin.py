@@ -1,0 +1,258 @@
+"""GPU: the drop-in classes under the reference's own LpSolver.
+
+oracle/_ref/test_lp_ref and oracle/_ref/test_lp_hip (tests/dropin/lp_main.cc, built in the build container by
+`make -C oracle lp_dropin`) are the reference's whole solver -- presolve, IPM::ComputeStartingPoint, the initial
+IPM, starting basis, IPM::Driver with basis preconditioning, crossover -- linked once with the reference's
+lp_solver.cc as it is and once with the three declarations of INTEGRATION.md changed, so that the reference's IPM
+drives ipx::KKTSolverDiagHip and ipx::KKTSolverBasisHip on the MI355X.  In both programs every LU factorization of
+ipx::Basis is computed by ipx::LuKernelHip (BASICLU is not in the image; tests/dropin/basiclu_absent.cc), so the
+two runs differ in the KKT solver classes only.
+
+What is compared: status_ipm / status_crossover, the number of IPM iterations, kktiter2 (CR iterations of the main
+phase) within 2 %, the objectives, the number of basis updates.  The small cases restate the models and the
+expected statuses of the reference's own end-to-end tests (check/solver.cc:153-251: 0-, 1- and 2-row models,
+switchiter = 0 straight into the basis phase, with and without dualization) -- data and expectations, not code.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "test_lp_ref")
+HIP_BIN = os.path.join(ROOT, "oracle", "_ref", "test_lp_hip")
+INF = np.inf
+
+IPX_STATUS_optimal, IPX_STATUS_primal_infeas, IPX_STATUS_dual_infeas = 1, 3, 4
+IPX_STATUS_not_run = 0
+
+
+def _need_bins():
+    if not (os.path.exists(REF_BIN) and os.path.exists(HIP_BIN)):
+        pytest.skip("oracle/_ref/test_lp_{ref,hip} not built (needs the reference sources at build time)")
+
+
+def write_model(d, obj, lb, ub, Ap, Ai, Ax, rhs, ct, **params):
+    os.makedirs(d, exist_ok=True)
+    i64, f64 = np.int64, np.float64
+    np.array([len(obj), len(rhs)], i64).tofile(os.path.join(d, "dims.bin"))
+    for k, v in (("obj", obj), ("lb", lb), ("ub", ub), ("rhs", rhs), ("Ax", Ax)):
+        np.ascontiguousarray(v, f64).tofile(os.path.join(d, k + ".bin"))
+    for k, v in (("Ap", Ap), ("Ai", Ai)):
+        np.ascontiguousarray(v, i64).tofile(os.path.join(d, k + ".bin"))
+    with open(os.path.join(d, "constr_type.bin"), "wb") as f:
+        f.write("".join(ct).encode())
+    with open(os.path.join(d, "params.txt"), "w") as f:
+        for k, v in params.items():
+            f.write("%s %r\n" % (k, v))
+
+
+def run(exe, din, dout, timeout=900):
+    os.makedirs(dout, exist_ok=True)
+    r = subprocess.run([exe, din, dout], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0 and "DONE" in r.stdout, (exe, r.stdout[-2000:], r.stderr[-2000:])
+    info = {}
+    for ln in open(os.path.join(dout, "info.txt")):
+        k, v = ln.split()
+        info[k] = float(v)
+    arr = {}
+    for k in ("x", "y", "slack", "zl", "zu", "bx"):
+        p = os.path.join(dout, k + ".bin")
+        if os.path.exists(p):
+            arr[k] = np.fromfile(p, np.float64)
+    return info, arr, r.stdout
+
+
+def both(tmp_path, tag, *model, **params):
+    din = str(tmp_path / (tag + "_in"))
+    write_model(din, *model, **params)
+    ref = run(REF_BIN, din, str(tmp_path / (tag + "_ref")))
+    hip = run(HIP_BIN, din, str(tmp_path / (tag + "_hip")))
+    return ref, hip
+
+
+def close(a, b, rel):
+    return abs(a - b) <= rel * (1.0 + max(abs(a), abs(b)))
+
+
+def compare_runs(ref, hip, obj_tol=1e-8, kkt_rel=0.10, upd_rel=0.05):
+    """The two runs take the same path through the reference's IPM: identical statuses, identical IPM iteration
+    counts, objectives to 1e-8.  The CR iteration counts and the number of basis updates are NOT expected to be
+    equal: every KKT solve stops at the reference's tolerance 0.3 sqrt(mu) (src/ipm.cc:572), the two
+    implementations' solutions differ at that level, so from the second IPM iteration on the iterates differ in
+    the 6th-9th digit and Maxvolume's threshold decisions flip for borderline columns (measured on the MI355X:
+    kktiter2 583 / 595, 2023 / 2032, 676 / 663, 821 / 772; updates_ipm 419 / 410, 1893 / 1962, 1170 / 1174,
+    1480 / 1485).  Bounds: 10 % on kktiter2, 5 % on the updates."""
+    ri, ra, rout = ref
+    hi, ha, hout = hip
+    msg = "\nREF: " + rout + "\nHIP: " + hout
+    for k in ("status", "status_ipm", "status_crossover", "errflag", "dualized", "dependent_rows", "dependent_cols",
+              "rows_inconsistent", "cols_inconsistent"):
+        assert ri[k] == hi[k], (k, ri[k], hi[k], msg)
+    assert ri["iter"] == hi["iter"], msg
+    assert abs(ri["kktiter2"] - hi["kktiter2"]) <= max(2.0 * max(ri["iter"], 1), kkt_rel * ri["kktiter2"]), msg
+    assert abs(ri["kktiter1"] - hi["kktiter1"]) <= max(2.0 * max(ri["iter"], 1), 0.02 * ri["kktiter1"]), msg
+    if ri["status_ipm"] == IPX_STATUS_optimal:
+        assert close(ri["pobjval"], hi["pobjval"], obj_tol) and close(ri["dobjval"], hi["dobjval"], obj_tol), msg
+    assert abs(ri["updates_ipm"] - hi["updates_ipm"]) <= max(3.0, upd_rel * ri["updates_ipm"]), msg
+    assert abs(ri["updates_start"] - hi["updates_start"]) <= max(3.0, upd_rel * ri["updates_start"]), msg
+    if ri["status_crossover"] == IPX_STATUS_optimal:
+        assert close(ri["objval"], hi["objval"], 1e-9), msg
+
+
+# ---- models of check/solver.cc (data + expected statuses) ------------------------------------------------------
+
+def _test_model(num_var, num_constr, ct):
+    return dict(obj=[0.0] * num_var, lb=[0.0] * num_var, ub=[1.0] * num_var, Ap=[0] * (num_var + 1), Ai=[], Ax=[],
+                rhs=[0.0] * num_constr, ct=[ct] * num_constr)
+
+
+def _add_column(M, obj, idx, val, lb, ub):
+    M["obj"].append(obj); M["lb"].append(lb); M["ub"].append(ub)
+    M["Ai"] += list(idx); M["Ax"] += list(val); M["Ap"].append(len(M["Ai"]))
+    return M
+
+
+def _args(M):
+    return (M["obj"], M["lb"], M["ub"], M["Ap"], M["Ai"], M["Ax"], M["rhs"], M["ct"])
+
+
+def solver_cc_cases():
+    cases = []
+    # "no constraints" (check/solver.cc:153-185)
+    for name, lb, ub in (("boxed", [0, 0], [1, 1]), ("lower", [0, 0], [INF, INF]), ("upper", [-INF, -INF], [1, 1]),
+                         ("free", [-INF, -INF], [INF, INF]), ("fixed", [0, 0], [0, 0])):
+        M = _test_model(2, 0, "=")
+        M["lb"], M["ub"] = list(map(float, lb)), list(map(float, ub))
+        cases.append(("noconstr_" + name, M, {}, IPX_STATUS_optimal, IPX_STATUS_optimal))
+    M = _test_model(5, 0, "=")
+    M["ub"] = [1.0, INF, -1.0, INF, 1.0]
+    M["lb"] = [0.0, 1.0, -INF, -INF, 1.0]
+    cases.append(("noconstr_mixed", M, {}, IPX_STATUS_optimal, IPX_STATUS_optimal))
+    # "single constraint" (:187-205)
+    for ct in "=><":
+        M = _test_model(0, 1, ct)
+        _add_column(M, 1.0, [0], [1.0], 0.0, 1.0)
+        _add_column(M, 1.0, [0], [2.0], 1.0, INF)
+        _add_column(M, -1.0, [0], [3.0], -INF, -1.0)
+        _add_column(M, 0.0, [0], [4.0], -INF, INF)
+        _add_column(M, -1.0, [0], [5.0], 1.0, 1.0)
+        M["rhs"][0] = 0.5
+        cases.append(("single_" + {"=": "eq", ">": "ge", "<": "le"}[ct], M, {}, IPX_STATUS_optimal, IPX_STATUS_optimal))
+    # "dependent equality constraints" (:207-229), switchiter = 0
+    for name, rhs0, st, sc in (("consistent", 0.0, IPX_STATUS_optimal, IPX_STATUS_optimal),
+                               ("inconsistent", 1.0, IPX_STATUS_primal_infeas, IPX_STATUS_not_run)):
+        M = _test_model(0, 2, "=")
+        _add_column(M, 0.0, [0, 1], [1.0, 2.0], 0.0, 1.0)
+        _add_column(M, 0.0, [0, 1], [1.0, 2.0], 0.0, 1.0)
+        M["rhs"][0] = rhs0
+        cases.append(("depeq_" + name, M, {"switchiter": 0}, st, sc))
+    # "dependent free variables" (:231-251), switchiter = 0
+    for name, obj0, st, sc in (("consistent", 1.0, IPX_STATUS_optimal, IPX_STATUS_optimal),
+                               ("inconsistent", -1.0, IPX_STATUS_dual_infeas, IPX_STATUS_not_run)):
+        M = _test_model(0, 2, "=")
+        _add_column(M, 1.0, [0, 1], [1.0, 1.0], -INF, INF)
+        _add_column(M, 2.0, [0, 1], [2.0, 2.0], -INF, INF)
+        M["obj"][0] = obj0
+        cases.append(("depfree_" + name, M, {"switchiter": 0}, st, sc))
+    return cases
+
+
+@pytest.mark.gpu
+def test_reference_solver_expectations_with_the_hip_solvers(tmp_path):
+    """the reference's own end-to-end expectations (check/solver.cc:125-251) replayed on the program built with
+    KKTSolverDiagHip / KKTSolverBasisHip / LuKernelHip -- and, next to it, on the one with the reference's KKT
+    solvers: same statuses, dualized or not"""
+    _need_bins()
+    failures = []
+    for name, M, params, st_ipm, st_cross in solver_cc_cases():
+        for dualize in (0, 1):
+            din = str(tmp_path / ("%s_%d" % (name, dualize)))
+            write_model(din, *_args(M), crossover=1, debug=3, dualize=dualize, **params)
+            for tag, exe in (("ref", REF_BIN), ("hip", HIP_BIN)):
+                info, arr, out = run(exe, din, din + "_" + tag)
+                if (info["status_ipm"], info["status_crossover"]) != (st_ipm, st_cross):
+                    failures.append((name, dualize, tag, info["status_ipm"], info["status_crossover"], out))
+                if info["status_ipm"] != IPX_STATUS_not_run and "x" in arr:
+                    # sign conditions of check_sign_conditions (check/solver.cc:19-58)
+                    lb, ub = np.array(M["lb"]), np.array(M["ub"])
+                    zl, zu = arr["zl"], arr["zu"]
+                    assert np.all(zl[np.isfinite(lb)] >= 0) and np.all(zl[~np.isfinite(lb)] == 0), (name, tag)
+                    assert np.all(zu[np.isfinite(ub)] >= 0) and np.all(zu[~np.isfinite(ub)] == 0), (name, tag)
+                    for i, c in enumerate(M["ct"]):
+                        s, y = arr["slack"][i], arr["y"][i]
+                        assert (s == 0.0) if c == "=" else (s >= 0 and y <= 0) if c == "<" else (s <= 0 and y >= 0)
+    assert not failures, failures
+
+
+def afiro_model():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden
+    A, rhs, ct, obj, lb, ub = make_golden.afiro()
+    return (obj, lb, ub, A.p, A.i, A.x, rhs, list(ct))
+
+
+def general_lp(m, n, seed, k=6, frac_eq=0.2, frac_free=0.03, frac_boxed=0.2):
+    """a feasible, bounded LP with every kind of variable and constraint: an interior primal-dual point exists by
+    construction"""
+    from ipx_amd import synth
+    rng = np.random.default_rng(seed)
+    A = synth.synthetic_lp(m, n, k, seed)
+    S = A.to_scipy()
+    x0 = rng.uniform(0.5, 2.0, n)
+    lb, ub = np.zeros(n), np.full(n, INF)
+    kind = rng.uniform(size=n)
+    free = kind < frac_free
+    boxed = (kind >= frac_free) & (kind < frac_free + frac_boxed)
+    lb[free] = -INF
+    ub[boxed] = x0[boxed] + rng.uniform(0.5, 2.0, boxed.sum())
+    lb[boxed] = x0[boxed] - rng.uniform(0.5, 2.0, boxed.sum())
+    ct = np.where(rng.uniform(size=m) < frac_eq, "=", "<")
+    s0 = np.where(ct == "=", 0.0, rng.uniform(0.5, 2.0, m))
+    rhs = S @ x0 + s0
+    y0 = np.where(ct == "=", rng.uniform(-1.0, 1.0, m), -rng.uniform(0.5, 1.5, m))
+    zl = np.where(np.isfinite(lb), rng.uniform(0.5, 2.0, n), 0.0)
+    zu = np.where(np.isfinite(ub), rng.uniform(0.5, 2.0, n), 0.0)
+    obj = S.T @ y0 + zl - zu
+    return (obj, lb, ub, A.p, A.i, A.x, rhs, list(ct))
+
+
+@pytest.mark.gpu
+def test_afiro_through_both_solvers(tmp_path):
+    """example/afiro.cc through the whole solver: the optimum -464.753142857 of the reference's example"""
+    _need_bins()
+    ref, hip = both(tmp_path, "afiro", *afiro_model(), crossover=1)
+    compare_runs(ref, hip)
+    for info, _, _ in (ref, hip):
+        assert info["status_ipm"] == IPX_STATUS_optimal and info["status_crossover"] == IPX_STATUS_optimal
+        assert abs(info["objval"] - (-464.75314285714)) <= 1e-8 * 465
+    # and straight into the basis phase
+    ref, hip = both(tmp_path, "afiro0", *afiro_model(), crossover=1, switchiter=0)
+    compare_runs(ref, hip)
+    # (kktiter1 > 0 also here: IPM::ComputeStartingPoint solves with the diag solver; the initial IPM is skipped)
+    assert hip[0]["kktiter1"] == ref[0]["kktiter1"] and hip[0]["kktiter2"] > 0 and hip[0]["status_ipm"] == IPX_STATUS_optimal
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,seed,params", [
+    (2000, 5000, 31, dict()),
+    (2000, 5000, 32, dict(switchiter=0)),
+    (1200, 3000, 33, dict(switchiter=3, update_heuristic=0)),
+    (1500, 2500, 34, dict(dualize=1, switchiter=2)),
+])
+def test_synthetic_lp_through_both_solvers(tmp_path, m, n, seed, params):
+    """IPM::Driver over KKTSolverBasisHip (and the initial phase over KKTSolverDiagHip) against the same driver over
+    the reference's classes: same statuses and IPM iteration count, kktiter2 within 2 %, objectives 1e-8, the same
+    number of basis updates (Maxvolume, DropPrimal / DropDual take the same decisions)"""
+    _need_bins()
+    ref, hip = both(tmp_path, "lp", *general_lp(m, n, seed), crossover=1, **params)
+    compare_runs(ref, hip)
+    hi = hip[0]
+    assert hi["status_ipm"] == IPX_STATUS_optimal, hip[2]
+    assert hi["kktiter2"] > 0 and hi["lu_factorizations"] > 0
+    print("ref:", ref[2], "hip:", hip[2])
+    print("time_ipm2 ref %.3f hip %.3f; cr2 ref %.3f hip %.3f; factorize ref %.3f hip %.3f; LU on device %.3f s in %d calls, largest bump %d"
+          % (ref[0]["time_ipm2"], hi["time_ipm2"], ref[0]["time_cr2"], hi["time_cr2"], ref[0]["time_kkt_factorize"],
+             hi["time_kkt_factorize"], hi["lu_device_seconds"], hi["lu_factorizations"], hi["lu_max_bump"]))
