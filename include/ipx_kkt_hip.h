@@ -227,7 +227,12 @@ int ipxk_split_rescale(ipxk_context* ctx, const ipxint* status,
  * singleton must pass |a| >= pivottol * max|active column|).  Absolute pivot
  * tolerance: kLuDependencyTol = 1e-3 (src/ipx_internal.h:26) if
  * strict_abs_pivottol, else 1e-14.  A bump of more than IPXK_LU_BUMP_MAX rows
- * (environment, default 4096) returns IPXK_E_UNSUPPORTED.
+ * (environment, default 4096) is torn first: whenever the rounds stall, the
+ * active columns with the most active entries are set aside as spikes and the
+ * rounds go on; the spikes are carried through the row singleton pivots by a
+ * forward substitution and end in a dense block of one row per spike
+ * (bump-and-spike ordering; ipxk_lu_info.spikes).  IPXK_E_UNSUPPORTED is
+ * returned only if that block would exceed the limit.
  * Columns of B are Bi/Bx[Bbegin[j] .. Bend[j]-1] (4-array form, as Basis passes
  * AI's arrays); indices need not be sorted.  The factors stay on the device;
  * ipxk_lu_get_factors copies them out (array sizes from ipxk_lu_info; any
@@ -237,6 +242,8 @@ typedef struct {
   ipxint num_dependent;     /* columns replaced by unit columns */
   ipxint col_singletons, row_singletons, bump, rounds;
   double seconds_singletons, seconds_bump, seconds_assemble;
+  ipxint spikes;            /* columns torn off a bump beyond the dense limit (0: the bump
+                               was factorized as it stood); then bump == spikes */
 } ipxk_lu_info;
 int ipxk_lu_factorize(ipxk_context* ctx, ipxint dim, const ipxint* Bbegin,
                       const ipxint* Bend, const ipxint* Bi, const double* Bx,

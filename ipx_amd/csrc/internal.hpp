@@ -199,6 +199,40 @@ struct SlicedMatrix {
     DevBuf<double> val, partial;
 };
 
+// Sorted sub-tiles: the sliced layout with the gathers of a tile issued in ADDRESS order.
+// Measured (profiles/r03_gather_sorted_microbench.txt): random 8-byte gathers from an L2-resident slice cost
+// ~41 us per 16M for issue + ~48 us per 16M L1->L2 line requests; lanes of one instruction (and consecutive
+// instructions of a CU) that fall on the same 128-byte line share a request, so a tile whose entries are sorted by
+// gathered index needs only as many requests as it touches lines: 0.63 of its entries when it holds as many
+// entries as its slice has lines (72 instead of 88 us), 0.43 at two entries per line (60 us).  Layout:
+//   * row blocks of RB = 1024 * RPT rows (8192 at C3), slices as in the sliced layout, every slice cut into `nsub`
+//     sub-slices; sub-tile (rb, s, h) holds the entries of the block in sub-slice h of slice s SORTED by gathered
+//     index, at most kSortedMaxSub of them;
+//   * an entry is one 32-bit word (slot << 18 | index - first index of the slice) + its value: slot = the place of
+//     the entry when the sub-tile's entries are listed row by row in storage order -- the product goes to that LDS
+//     slot, and after one barrier every thread adds up the products of its RPT consecutive rows from consecutive
+//     slots, continuing the running sums of the previous sub-tile: a row's sum is formed slice by slice in storage
+//     order exactly as in the sliced layout (bit-identical partial sums), one workgroup of 1024 threads per (rb, s);
+//   * partial vectors and the combine kernel are the sliced layout's.
+constexpr int kSortedThreads = 1024;
+constexpr int kSortedMaxSub = 8192;    // entries per sub-tile: 13 bits of slot
+constexpr int kSortedOffBits = 18;     // index inside a slice of at most 2 MiB of x
+struct SortedView {
+    int nrows, nrows_pad, nslices, nsub, nrb, RB, slice_elems;
+    const unsigned* sub_ptr;           // [nrb*nslices*nsub + 1]
+    const unsigned char* cnt;          // [nrb*nslices*nsub][RB] entries per row of the sub-tile
+    const unsigned* pack;
+    const double* val;
+    double* partial;                   // [nslices][nrows_pad]
+};
+struct SortedMatrix {
+    bool built = false;
+    int nslices = 0, nsub = 0, nrb = 0, RB = 0, nrows_pad = 0, max_sub = 0, slice_elems = 0;
+    DevBuf<unsigned> sub_ptr, pack;
+    DevBuf<unsigned char> cnt;
+    DevBuf<double> val, partial;
+};
+
 struct GatherMatrix {
     int nrows = 0, ncols = 0;
     int64_t nnz = 0;
@@ -223,10 +257,16 @@ struct GatherMatrix {
     // auto times both once at build time on this matrix and keeps the faster one)
     SlicedMatrix sliced;
     bool use_sliced = false;
-    float tuned_us_phased = 0.f, tuned_us_sliced = 0.f, tuned_us_fused = 0.f;
+    // the sliced layout's tiles with sorted gathers (bit-identical results: a timing may choose between the two)
+    SortedMatrix sorted;
+    bool use_sorted = false;           // only with use_sliced and sliced.nslices > 1
+    void build_sorted(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s);
+    SortedView sorted_view() const;
+    float tuned_us_phased = 0.f, tuned_us_sliced = 0.f, tuned_us_fused = 0.f, tuned_us_sorted = 0.f;
     // ns_request: 0 = as many slices as x needs (>= 2), 1 = the fused single-slice variant
     void build_sliced(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s, int ns_request);
-    SlicedView sliced_view(bool masked = false) const;
+    // which: 0 = the matrix, 1 = the masked value array (mask_values), 2 = the compacted copy (compact_tiles)
+    SlicedView sliced_view(int which = 0) const;
     int fused_grid() const { return std::min(sliced.nrb, kMaxPartials); }
     int combine_grid() const { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, ((int64_t)nrows + kBlock - 1) / kBlock)); }
 
@@ -237,6 +277,19 @@ struct GatherMatrix {
     // gather for an entry whose value is zero.  mask_values() fills it from a weight per ROW of the gather matrix
     // (by_row) or per GATHERED index; view(true) / sliced_view(true) show it (launch_spmv<Epi, true>).
     DevBuf<double> valM, lvalM;
+    // Compacted copy of the tile layout (sliced / fused): only the entries whose weight is nonzero, tile by tile
+    // in the same order, with their own tile pointers and per-row counts -- the basis path's N as a matrix of its
+    // own (SplittedNormalMatrix::Prepare copies N, src/splitted_normal_matrix.cc:42-55; here the copy is a stream
+    // compaction of the resident tiles on the device).  Same arithmetic as the masked form (the entries left out
+    // contributed exact zeros), but the kernels no longer stream them.  Long rows keep their masked values.
+    struct CompactTiles {
+        bool valid = false;
+        DevBuf<unsigned> tile_ptr, tile_kept;
+        DevBuf<unsigned char> cnt;
+        DevBuf<int> idx;
+        DevBuf<double> val;
+    } compact;
+    void compact_tiles(const double* weight, bool by_row, hipStream_t s);
     DevBuf<int> rowof;                  // row of every stored short entry (built on first use by mask_values(by_row))
     void mask_values(const double* weight, bool by_row, hipStream_t s);
     // # dot partials a launch produces

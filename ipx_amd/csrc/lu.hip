@@ -26,8 +26,18 @@
 // The rules (tolerances, tie breaks, order of the dependent columns) are restated on the CPU by the test
 // infrastructure, which the tests compare against entry by entry; the reference's own
 // LuFactorization::Factorize (stability estimate) and ForrestTomlin judge the factors there as well.
-// Limit: a bump of more than IPXK_LU_BUMP_MAX rows (default 4096) is refused (IPXK_E_UNSUPPORTED): a
-// sparse Markowitz elimination of a large bump is not built.
+//   2b. TEARING.  A bump of more than IPXK_LU_BUMP_MAX rows (default 4096) is not factorized densely as it stands.
+//      LP bumps are sparse and nearly triangular themselves -- a few columns (the ones recent basis exchanges
+//      brought in) block the singleton rounds, and singleton peeling is all-or-nothing along dependency chains.
+//      Whenever the rounds stall, the T active columns with the most active entries (ties: smaller index) are set
+//      aside as SPIKES (T = 1, doubled up to 1024 while a tear frees fewer than 64 pivots, back to 1 otherwise)
+//      and the rounds go on without them until no active column is left: the bump-and-spike ordering of
+//      Hellerman and Rarick in rounds.  Round pivots still cost no arithmetic outside the spikes.  The spikes
+//      receive the updates of the row singleton pivots in pivot order: a forward substitution with the L columns
+//      found so far, run for 64 spikes at a time as a dense dim x 64 block (one wavefront per row, one lane per
+//      spike, rows of one half-round in one launch, every row's products subtracted in pivot order).  Their
+//      entries in pivoted rows become entries of U, their entries in the never-pivoted rows form the dense block
+//      of step 2.  Only if THAT block exceeds the limit is the basis refused (IPXK_E_UNSUPPORTED).
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -62,6 +72,16 @@ void scan_exclusive(Tmp& T, const int* in, int* out, size_t n, hipStream_t s) {
     size_t bytes = 0;
     IPXK_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, n, rocprim::plus<int>(), s));
     IPXK_HIP(rocprim::exclusive_scan(T.need(bytes), bytes, in, out, 0, n, rocprim::plus<int>(), s));
+}
+
+// grows a buffer to at least `need` elements, keeping its first `used` ones
+template <class T>
+void grow_keep(DevBuf<T>& b, size_t used, size_t need, hipStream_t s) {
+    if (need <= b.size()) return;
+    DevBuf<T> nb(std::max(need, 2 * b.size()));
+    if (used) IPXK_HIP(hipMemcpyAsync(nb.get(), b.get(), used * sizeof(T), hipMemcpyDeviceToDevice, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    b = std::move(nb);
 }
 
 // ---- row-wise copy ------------------------------------------------------------------------------
@@ -108,7 +128,7 @@ struct Rounds {
 __global__ void lu_col_find_kernel(Rounds R) {
     IPXK_GRID_STRIDE(j, R.dim) {
         int cr = -1;
-        if (R.cstage[j] < 0 && R.cc[j] == 1) {
+        if (R.cstage[j] == -1 && R.cc[j] == 1) {          // -1: active; -2: a spike (torn), never a round pivot
             for (int p = R.Bp[j]; p < R.Bp[j + 1]; p++) {
                 const int i = R.Bi[p];
                 if (R.rstage[i] >= 0) continue;
@@ -146,7 +166,7 @@ __global__ void lu_row_find_kernel(Rounds R) {
         if (R.rstage[i] < 0 && R.rc[i] == 1) {
             for (int q = R.Rp[i]; q < R.Rp[i + 1]; q++) {
                 const int j = R.Rj[q];
-                if (R.cstage[j] >= 0) continue;
+                if (R.cstage[j] != -1) continue;
                 const double a = fabs(R.Bx[R.Rpos[q]]);
                 double colmax = 0.0;
                 for (int p = R.Bp[j]; p < R.Bp[j + 1]; p++)
@@ -216,6 +236,105 @@ __global__ void lu_stage_assign_kernel(int npiv, const int* __restrict__ order, 
         const int j = order[q];
         cstage[j] = (int)q;
         rstage[pivrow[j]] = (int)q;
+    }
+}
+
+// ---- tearing ------------------------------------------------------------------------------------
+// candidates for spikes: active columns by descending number of active entries, then ascending index
+__global__ void lu_tear_keys_kernel(int dim, const int* __restrict__ cstage, const int* __restrict__ cc, u64* __restrict__ keys) {
+    IPXK_GRID_STRIDE(j, dim)
+        keys[j] = cstage[j] == -1 ? ((u64)(0x7fffffffu - (unsigned)cc[j]) << 32) | (unsigned)j : kNoKey;
+}
+// the first `take` candidates become spikes: they leave the active columns, their active rows lose an entry
+__global__ void lu_tear_apply_kernel(Rounds R, const u64* __restrict__ sorted, int take) {
+    IPXK_GRID_STRIDE(t, take) {
+        const int j = (int)(sorted[t] & 0xffffffffull);
+        R.cstage[j] = -2;
+        for (int p = R.Bp[j]; p < R.Bp[j + 1]; p++) {
+            const int i = R.Bi[p];
+            if (R.rstage[i] < 0) atomicSub(R.rc + i, 1);
+        }
+    }
+}
+// the entries of L found by the rounds, keyed (stage of the row | stage of the pivot): an entry (r, j) of a row
+// singleton column j below its pivot, i.e. r was still active when j was pivoted.  Rows that were never pivoted
+// count as stages npiv.. in ascending row order.
+__global__ void lu_lentry_keys_kernel(int64_t nb, const int* __restrict__ colof, const int* __restrict__ Bi,
+                                      const double* __restrict__ Bx, const unsigned char* __restrict__ ckind,
+                                      const int* __restrict__ pivrow, const int* __restrict__ rstage, const int* __restrict__ cstage,
+                                      const int* __restrict__ rloc, const double* __restrict__ pivot, int npiv,
+                                      u64* __restrict__ key, double* __restrict__ val) {
+    IPXK_GRID_STRIDE(p, nb) {
+        const int j = colof[p], r = Bi[p];
+        key[p] = kNoKey;
+        val[p] = 0.0;
+        if (ckind[j] != 2 || r == pivrow[j]) continue;
+        const int rs = rstage[r] >= 0 ? rstage[r] : npiv + rloc[r];
+        if (rs < cstage[j]) continue;                          // pivoted before j: an entry of U
+        key[p] = ((u64)(unsigned)rs << 32) | (unsigned)cstage[j];
+        val[p] = Bx[p] / pivot[j];
+    }
+}
+// L entries of the rows of each half-round (tag): which launches of the substitution have work
+__global__ void lu_tagwork_kernel(int ntags, const ipxint* __restrict__ tagptr, const ipxint* __restrict__ lrp, int* __restrict__ work) {
+    IPXK_GRID_STRIDE(t, ntags) work[t] = (int)(lrp[tagptr[t + 1]] - lrp[tagptr[t]]);
+}
+constexpr int kSpikeBatch = 64;      // spikes per dense block: one lane each
+// X[stage of row][lane] = entries of the batch's spikes (X zero before)
+__global__ void lu_spike_scatter_kernel(int nlanes, int c0, const int* __restrict__ bcol, const int* __restrict__ Bp,
+                                        const int* __restrict__ Bi, const double* __restrict__ Bx, const int* __restrict__ rstage,
+                                        const int* __restrict__ rloc, int npiv, double* __restrict__ X) {
+    const int l = blockIdx.x;
+    if (l >= nlanes) return;
+    const int j = bcol[c0 + l];
+    for (int p = Bp[j] + threadIdx.x; p < Bp[j + 1]; p += blockDim.x) {
+        const int r = Bi[p];
+        const int rs = rstage[r] >= 0 ? rstage[r] : npiv + rloc[r];
+        X[(size_t)rs * kSpikeBatch + l] = Bx[p];
+    }
+}
+// rows [s0, s1) of the substitution: x[r] -= l_rj * x[stage of j] for the row's entries of L in pivot order, products
+// rounded before they are subtracted (the elimination's own arithmetic); one wavefront per row, one lane per spike
+__global__ __launch_bounds__(kBlock) void lu_spike_round_kernel(int s0, int s1, const ipxint* __restrict__ lrp, const u64* __restrict__ lkey,
+                                                                const double* __restrict__ lval, double* __restrict__ X) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)s0 + (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); r < s1; r += (int64_t)gridDim.x * (kBlock / 64)) {
+        const ipxint e0 = lrp[r], e1 = lrp[r + 1];
+        if (e0 == e1) continue;
+        double acc = X[(size_t)r * kSpikeBatch + lane];
+        for (ipxint e = e0; e < e1; e++) {
+            const size_t src = (size_t)(lkey[e] & 0xffffffffull);
+            const double prod = lval[e] * X[src * kSpikeBatch + lane];
+            acc = acc - prod;
+        }
+        X[(size_t)r * kSpikeBatch + lane] = acc;
+    }
+}
+// the batch's part of the dense block: rows that were never pivoted
+__global__ void lu_spike_dense_kernel(int kb, int nlanes, int c0, int npiv, const double* __restrict__ X, double* __restrict__ D) {
+    IPXK_GRID_STRIDE(e, (int64_t)kb * nlanes) {
+        const int l = (int)(e % nlanes), t = (int)(e / nlanes);
+        D[(size_t)(c0 + l) * kb + t] = X[(size_t)(npiv + t) * kSpikeBatch + l];
+    }
+}
+// the batch's entries in pivoted rows (future entries of U): counted, then appended as (bump column, stage, value)
+__global__ void lu_spike_count_kernel(int npiv, int nlanes, const double* __restrict__ X, int* count) {
+    int mine = 0;
+    IPXK_GRID_STRIDE(e, (int64_t)npiv * kSpikeBatch) mine += (int)(e % kSpikeBatch) < nlanes && X[e] != 0.0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);
+}
+__global__ void lu_spike_append_kernel(int npiv, int nlanes, int c0, const double* __restrict__ X, int* cursor,
+                                       int* __restrict__ spk_c, int* __restrict__ spk_s, double* __restrict__ spk_v) {
+    IPXK_GRID_STRIDE(e, (int64_t)npiv * kSpikeBatch) {
+        const int l = (int)(e % kSpikeBatch);
+        const double v = X[e];
+        if (l >= nlanes || v == 0.0) continue;
+        const int at = atomicAdd(cursor, 1);           // the order is irrelevant: the entries are sorted by key later
+        spk_c[at] = c0 + l;
+        spk_s[at] = (int)(e / kSpikeBatch);
+        spk_v[at] = v;
     }
 }
 
@@ -606,12 +725,13 @@ struct Assemble {
     const unsigned char* ckind;
     u64 *lkey, *ukey;
     double *lval, *uval;
+    int tearing;           // the bump's columns are spikes: their entries above the dense block come from the substitution
 };
 __global__ void lu_keys_sparse_kernel(Assemble A, int64_t nb) {
     IPXK_GRID_STRIDE(p, nb) {
         const int j = A.colof[p], i = A.Bi[p];
         if (A.ckind[j] == 4) continue;                          // replaced by a unit column
-        if (A.cloc[j] >= 0 && A.rloc[i] >= 0) continue;         // bump x bump: from the dense result
+        if (A.cloc[j] >= 0 && (A.tearing || A.rloc[i] >= 0)) continue;   // bump x bump: from the dense result; a spike: lu_keys_spike_kernel
         const int k = A.cstage[j], s = A.rstage[i];
         const u64 key = ((u64)(unsigned)k << 32) | (unsigned)s;
         if (s <= k) { A.ukey[p] = key; A.uval[p] = A.Bx[p]; }
@@ -631,6 +751,16 @@ __global__ void lu_keys_dense_kernel(Assemble A, int64_t nb) {
             if (s < k) { A.ukey[nb + e] = key; A.uval[nb + e] = v; }
             else { A.lkey[nb + e] = key; A.lval[nb + e] = v; }
         }
+    }
+}
+__global__ void lu_keys_spike_kernel(Assemble A, int64_t off, int nspk, const int* __restrict__ spk_c, const int* __restrict__ spk_s,
+                                     const double* __restrict__ spk_v) {
+    IPXK_GRID_STRIDE(e, nspk) {
+        const int c = spk_c[e];
+        if (A.bcstep[c] < 0) continue;                          // a dependent spike is replaced by a unit column
+        const int k = A.cstage[A.bcol[c]];
+        A.ukey[off + e] = ((u64)(unsigned)k << 32) | (unsigned)spk_s[e];
+        A.uval[off + e] = spk_v[e];
     }
 }
 __global__ void lu_keys_unit_kernel(Assemble A, int64_t off) {
@@ -703,6 +833,10 @@ struct LuWork {
     DevBuf<u64> cand_bits, claim_abs, skey, skey2, lkey, lkey2, ukey, ukey2;
     DevBuf<double> pivot, D, lval, lval2, uval, uval2;
     DevBuf<unsigned char> ckind;
+    DevBuf<u64> tkey, tkey2;          // tearing: candidate keys
+    DevBuf<ipxint> lrp, tagptr;       // tearing: row pointers of the L entries by stage; first stage of each half-round
+    DevBuf<int> tagwork, spk_c, spk_s;
+    DevBuf<double> X, spk_v;
     DevBuf<int> Bp, Bi, cnt;          // B = AI[:, basis] (ipxk_lu_factorize_basis)
     DevBuf<double> Bx;
     Tmp T;
@@ -787,6 +921,10 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
              abstol, pivottol};
     int rounds = 0;
     const int batch = 8;
+    int kb_max = 4096;
+    if (const char* e = getenv("IPXK_LU_BUMP_MAX")) kb_max = std::max(0, atoi(e));
+    bool tearing = false;
+    int ntorn = 0, tear_width = 1, npiv_at_tear = 0;
     while (dim > 0) {
         IPXK_HIP(hipMemsetAsync(counters.get() + 8, 0, batch * sizeof(int), s));
         for (int b = 0; b < batch; b++) {
@@ -803,9 +941,40 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
         int last_busy = -1;
         for (int b = 0; b < batch; b++) if (h[8 + b] > 0) last_busy = b;
         rounds += last_busy + 1 < batch ? last_busy + 2 : batch;      // the iteration that found nothing counts
-        if (last_busy < batch - 1) break;
+        if (last_busy == batch - 1) continue;
+        // the rounds stall: done, or (a bump beyond the dense limit) tear spikes off and go on
+        IPXK_HIP(hipMemsetAsync(counters.get() + 1, 0, 2 * sizeof(int), s));
+        hipLaunchKernelGGL(lu_count_kinds_kernel, dim3(g), dim3(kBlock), 0, s, dim, ckind.get(), counters.get());
+        IPXK_HIP(hipMemcpyAsync(h, counters.get(), 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        const int npiv = h[1] + h[2], nact = dim - npiv - ntorn;
+        if (nact == 0) break;
+        if (!tearing) {
+            if (nact <= kb_max) break;                                  // small enough: dense as it stands
+            tearing = true;
+        } else {
+            tear_width = npiv - npiv_at_tear < 64 ? std::min(2 * tear_width, 1024) : 1;
+        }
+        const int take = std::min(tear_width, nact);
+        W.tkey.ensure(d1); W.tkey2.ensure(d1);
+        hipLaunchKernelGGL(lu_tear_keys_kernel, dim3(g), dim3(kBlock), 0, s, dim, cstage.get(), cc.get(), W.tkey.get());
+        {
+            size_t bytes = 0;
+            IPXK_HIP(rocprim::radix_sort_keys(nullptr, bytes, W.tkey.get(), W.tkey2.get(), (size_t)dim, 0u, 64u, s));
+            IPXK_HIP(rocprim::radix_sort_keys(T.need(bytes), bytes, W.tkey.get(), W.tkey2.get(), (size_t)dim, 0u, 64u, s));
+        }
+        hipLaunchKernelGGL(lu_tear_apply_kernel, dim3(grid_for(take)), dim3(kBlock), 0, s, R, W.tkey2.get(), take);
+        ntorn += take;
+        npiv_at_tear = npiv;
+        if (ntorn > kb_max) {
+            char msg[200];
+            snprintf(msg, sizeof msg, "LU: %d spikes torn off the bump and %d columns still active: the dense block would exceed %d rows "
+                     "(IPXK_LU_BUMP_MAX)", ntorn, nact - take, kb_max);
+            throw Error(IPXK_E_UNSUPPORTED, msg);
+        }
     }
     if (dim > 0) {
+        IPXK_HIP(hipMemsetAsync(counters.get() + 1, 0, 2 * sizeof(int), s));
         hipLaunchKernelGGL(lu_count_kinds_kernel, dim3(g), dim3(kBlock), 0, s, dim, ckind.get(), counters.get());
         IPXK_HIP(hipMemcpyAsync(h, counters.get(), 8 * sizeof(int), hipMemcpyDeviceToHost, s));
         IPXK_HIP(hipStreamSynchronize(s));
@@ -842,14 +1011,14 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
         hipLaunchKernelGGL(lu_compact_kernel, dim3(g), dim3(kBlock), 0, s, dim, flag.get(), rank.get(), cloc.get(), bcol.get());
     }
     I.bump = kb;
-    int kb_max = 4096;
-    if (const char* e = getenv("IPXK_LU_BUMP_MAX")) kb_max = std::max(0, atoi(e));
+    I.spikes = tearing ? ntorn : 0;
     if (kb > kb_max) {
         char msg[160];
         snprintf(msg, sizeof msg, "LU: after the singletons a bump of %d rows remains (limit %d, IPXK_LU_BUMP_MAX)", kb, kb_max);
         throw Error(IPXK_E_UNSUPPORTED, msg);
     }
     int bpiv = 0;
+    int64_t nspk = 0;                  // tearing: entries of the spikes in pivoted rows (future entries of U)
     brstep.ensure((size_t)std::max(kb, 1)); bcstep.ensure((size_t)std::max(kb, 1));
     if (kb > 0) {
         D.ensure((size_t)kb * kb);
@@ -858,7 +1027,66 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
         const int gk = grid_for(kb);
         hipLaunchKernelGGL(lu_fill_int_kernel, dim3(gk), dim3(kBlock), 0, s, (int64_t)kb, -1, brstep.get());
         hipLaunchKernelGGL(lu_fill_int_kernel, dim3(gk), dim3(kBlock), 0, s, (int64_t)kb, -1, bcstep.get());
-        hipLaunchKernelGGL(lu_dense_fill_kernel, dim3(gk), dim3(kBlock), 0, s, kb, bcol.get(), Bp, Bi, Bx, rloc.get(), D.get());
+        if (!tearing) {
+            hipLaunchKernelGGL(lu_dense_fill_kernel, dim3(gk), dim3(kBlock), 0, s, kb, bcol.get(), Bp, Bi, Bx, rloc.get(), D.get());
+        } else {
+            // ---- 2b. the spikes through the row singleton pivots (forward substitution, 64 spikes at a time)
+            DevBuf<u64> &lkey = W.lkey, &lkey2 = W.lkey2;
+            DevBuf<double> &lval = W.lval, &lval2 = W.lval2;
+            for (DevBuf<u64>* b : {&lkey, &lkey2}) b->ensure(nz1);
+            for (DevBuf<double>* b : {&lval, &lval2}) b->ensure(nz1);
+            hipLaunchKernelGGL(lu_lentry_keys_kernel, dim3(grid_for(nb)), dim3(kBlock), 0, s, nb, colof.get(), Bi, Bx, ckind.get(),
+                               pivrow.get(), rstage.get(), cstage.get(), rloc.get(), pivot.get(), npiv_sing, lkey.get(), lval.get());
+            sort_keys(T, lkey.get(), lkey2.get(), lval.get(), lval2.get(), (size_t)nb, 64, s);
+            W.lrp.ensure(d1 + 1);
+            hipLaunchKernelGGL(lu_colptr_kernel, dim3(grid_for(dim + 1)), dim3(kBlock), 0, s, dim, nb, lkey2.get(), W.lrp.get());
+            // first stage of every half-round (the stage sort left the tags in W.skey2), and which of them have work
+            const int ntags = npiv_sing > 0 ? 2 * rounds : 0;
+            W.tagptr.ensure((size_t)ntags + 1); W.tagwork.ensure((size_t)ntags);
+            hipLaunchKernelGGL(lu_colptr_kernel, dim3(grid_for(ntags + 1)), dim3(kBlock), 0, s, ntags, (int64_t)dim, W.skey2.get(), W.tagptr.get());
+            hipLaunchKernelGGL(lu_tagwork_kernel, dim3(grid_for(ntags)), dim3(kBlock), 0, s, ntags, W.tagptr.get(), W.lrp.get(), W.tagwork.get());
+            std::vector<ipxint> tagptr((size_t)ntags + 1);
+            std::vector<int> tagwork((size_t)ntags);
+            IPXK_HIP(hipMemcpyAsync(tagptr.data(), W.tagptr.get(), tagptr.size() * sizeof(ipxint), hipMemcpyDeviceToHost, s));
+            IPXK_HIP(hipMemcpyAsync(tagwork.data(), W.tagwork.get(), tagwork.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+            IPXK_HIP(hipStreamSynchronize(s));
+            W.X.ensure((size_t)dim * kSpikeBatch);
+            nspk = 0;
+            for (int c0 = 0; c0 < kb; c0 += kSpikeBatch) {
+                const int nl = std::min(kSpikeBatch, kb - c0);
+                IPXK_HIP(hipMemsetAsync(W.X.get(), 0, (size_t)dim * kSpikeBatch * sizeof(double), s));
+                hipLaunchKernelGGL(lu_spike_scatter_kernel, dim3(nl), dim3(kBlock), 0, s, nl, c0, bcol.get(), Bp, Bi, Bx, rstage.get(),
+                                   rloc.get(), npiv_sing, W.X.get());
+                auto rows = [&](int64_t s0, int64_t s1) {
+                    if (s1 <= s0) return;
+                    const int64_t wgs = std::min<int64_t>(2048, (s1 - s0 + kBlock / 64 - 1) / (kBlock / 64));
+                    hipLaunchKernelGGL(lu_spike_round_kernel, dim3((unsigned)wgs), dim3(kBlock), 0, s, (int)s0, (int)s1, W.lrp.get(),
+                                       lkey2.get(), lval2.get(), W.X.get());
+                };
+                for (int t = 0; t < ntags; t++)
+                    if (tagwork[t] > 0) rows(tagptr[t], tagptr[t + 1]);
+                rows(npiv_sing, dim);                                   // the rows that were never pivoted
+                hipLaunchKernelGGL(lu_spike_dense_kernel, dim3(grid_for((int64_t)kb * nl)), dim3(kBlock), 0, s, kb, nl, c0, npiv_sing,
+                                   W.X.get(), D.get());
+                IPXK_HIP(hipMemsetAsync(counters.get() + 3, 0, sizeof(int), s));
+                hipLaunchKernelGGL(lu_spike_count_kernel, dim3(grid_for((int64_t)npiv_sing * kSpikeBatch)), dim3(kBlock), 0, s, npiv_sing, nl,
+                                   W.X.get(), counters.get() + 3);
+                IPXK_HIP(hipMemcpyAsync(h, counters.get(), 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+                IPXK_HIP(hipStreamSynchronize(s));
+                const int add = h[3];
+                if (add > 0) {
+                    grow_keep(W.spk_c, (size_t)nspk, (size_t)nspk + add, s);
+                    grow_keep(W.spk_s, (size_t)nspk, (size_t)nspk + add, s);
+                    grow_keep(W.spk_v, (size_t)nspk, (size_t)nspk + add, s);
+                    const int cur = (int)nspk;
+                    IPXK_HIP(hipMemcpyAsync(counters.get() + 3, &cur, sizeof(int), hipMemcpyHostToDevice, s));
+                    hipLaunchKernelGGL(lu_spike_append_kernel, dim3(grid_for((int64_t)npiv_sing * kSpikeBatch)), dim3(kBlock), 0, s, npiv_sing,
+                                       nl, c0, W.X.get(), counters.get() + 3, W.spk_c.get(), W.spk_s.get(), W.spk_v.get());
+                    IPXK_HIP(hipStreamSynchronize(s));                  // `cur` is a stack variable
+                    nspk += add;
+                }
+            }
+        }
         Dense A{kb, D.get(), brstep.get(), bcstep.get(), bstep.get(), prow.get(), pcol.get(), abstol};
         const int width = kb <= kPanelThreads ? kPanel : kb <= 4 * kPanelThreads ? kNarrow : kPanel;
         for (int c0 = 0; c0 < kb; c0 += width) {
@@ -901,7 +1129,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
     S->rowperm.ensure(d1); S->colperm.ensure(d1);
     S->Lp.ensure(d1 + 1); S->Up.ensure(d1 + 1);
     const int64_t kbsq = (int64_t)kb * kb;
-    const int64_t nl = nb + kbsq, nu = nb + kbsq + dim;
+    const int64_t nl = nb + kbsq, nu = nb + kbsq + dim + nspk;
     int64_t lnz = 0, unz = 0;
     if (dim > 0) {
         DevBuf<u64> &lkey = W.lkey, &lkey2 = W.lkey2, &ukey = W.ukey, &ukey2 = W.ukey2;
@@ -913,10 +1141,13 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
         if (nl > 0) hipLaunchKernelGGL(lu_fill_u64_kernel, dim3(grid_for(nl)), dim3(kBlock), 0, s, nl, kNoKey, lkey.get());
         hipLaunchKernelGGL(lu_fill_u64_kernel, dim3(grid_for(nu)), dim3(kBlock), 0, s, nu, kNoKey, ukey.get());
         Assemble A{dim, kb, Bp, Bi, colof.get(), Bx, rstage.get(), cstage.get(), rloc.get(), cloc.get(), brow.get(), bcol.get(),
-                   bcstep.get(), pivot.get(), D.get(), ckind.get(), lkey.get(), ukey.get(), lval.get(), uval.get()};
+                   bcstep.get(), pivot.get(), D.get(), ckind.get(), lkey.get(), ukey.get(), lval.get(), uval.get(), tearing ? 1 : 0};
         if (nb > 0) hipLaunchKernelGGL(lu_keys_sparse_kernel, dim3(grid_for(nb)), dim3(kBlock), 0, s, A, nb);
         if (kb > 0) hipLaunchKernelGGL(lu_keys_dense_kernel, dim3(grid_for(kbsq)), dim3(kBlock), 0, s, A, nb);
         hipLaunchKernelGGL(lu_keys_unit_kernel, dim3(g), dim3(kBlock), 0, s, A, nb + kbsq);
+        if (nspk > 0)
+            hipLaunchKernelGGL(lu_keys_spike_kernel, dim3(grid_for(nspk)), dim3(kBlock), 0, s, A, nb + kbsq + dim, (int)nspk,
+                               W.spk_c.get(), W.spk_s.get(), W.spk_v.get());
         if (nl > 0) sort_keys(T, lkey.get(), lkey2.get(), lval.get(), lval2.get(), (size_t)nl, 64, s);
         sort_keys(T, ukey.get(), ukey2.get(), uval.get(), uval2.get(), (size_t)nu, 64, s);
         hipLaunchKernelGGL(lu_colptr_kernel, dim3(grid_for(dim + 1)), dim3(kBlock), 0, s, dim, nl, lkey2.get(), S->Lp.get());

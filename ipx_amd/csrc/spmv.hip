@@ -172,9 +172,12 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
     std::string layout = "auto";
     if (const char* e = getenv("IPXK_SPMV_LAYOUT")) layout = e;
     if (layout == "phased") return;
-    if (layout == "sliced" || layout == "fused") {
+    use_sorted = false;
+    sorted = SortedMatrix();
+    if (layout == "sliced" || layout == "fused" || layout == "sorted") {
         build_sliced(hptr, hidx, hval, s, layout == "fused" ? 1 : 0);
         use_sliced = sliced.built;
+        if (layout == "sorted") { build_sorted(hptr, hidx, hval, s); use_sorted = sorted.built; }
         return;
     }
     // auto.  The phased and the fused layout add a row's products in the same (the reference's) order and give
@@ -216,14 +219,25 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
         if (spread) sliced = std::move(slicedm);
         else if (fusedm.built && tuned_us_fused < 0.95f * tuned_us_phased) sliced = std::move(fusedm);
         use_sliced = sliced.built;
+        if (spread && !(getenv("IPXK_SPMV_SORTED") && getenv("IPXK_SPMV_SORTED")[0] == '0')) {
+            // the same slices with the gathers of a tile in address order: bit-identical partial sums, so the faster
+            // of the two is kept (the sliced arrays stay: the basis path compacts them)
+            build_sorted(hptr, hidx, hval, s);
+            if (sorted.built) {
+                use_sorted = true;
+                tuned_us_sorted = time_current();
+                use_sorted = tuned_us_sorted < tuned_us_sliced || (getenv("IPXK_SPMV_SORTED") && getenv("IPXK_SPMV_SORTED")[0] == '1');
+                if (!use_sorted) sorted = SortedMatrix();
+            }
+        }
         if (use_sliced) {        // the phased copy of the entries is not needed any more
             idx.release(); val.release(); counts.release(); step_ptr.release();
             wg_chunk_ptr.release(); chunk_start.release(); chunk_info.release(); chunk_step.release();
         }
         if (getenv("IPXK_VERBOSE"))
-            fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld: phased %.1f us, fused %.1f us, sliced %.1f us (fullest-slice share %.2f) -> %s\n",
-                    nrows, ncols, (long long)nnz, tuned_us_phased, tuned_us_fused, tuned_us_sliced, share,
-                    !use_sliced ? "phased" : sliced.nslices == 1 ? "fused" : "sliced");
+            fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld: phased %.1f us, fused %.1f us, sliced %.1f us, sorted %.1f us (fullest-slice share %.2f) -> %s\n",
+                    nrows, ncols, (long long)nnz, tuned_us_phased, tuned_us_fused, tuned_us_sliced, tuned_us_sorted, share,
+                    !use_sliced ? "phased" : sliced.nslices == 1 ? "fused" : use_sorted ? "sorted" : "sliced");
     }
     IPXK_HIP(hipEventDestroy(e0));
     IPXK_HIP(hipEventDestroy(e1));
@@ -330,13 +344,110 @@ void GatherMatrix::build_sliced(const ipxint* hptr, const ipxint* hidx, const do
     sliced.built = true;
 }
 
-SlicedView GatherMatrix::sliced_view(bool use_masked) const {
+// Sorted sub-tiles (internal.hpp): the slices of the sliced layout, which must exist.
+void GatherMatrix::build_sorted(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s) {
+    sorted = SortedMatrix();
+    if (!sliced.built || sliced.nslices < 2) return;
+    const int ns = sliced.nslices;
+    const int64_t slice = ((ncols + ns - 1) / ns + 15) / 16 * 16;        // as in build_sliced
+    if (slice > (int64_t(1) << kSortedOffBits)) return;
+    const int nsub = 2;
+    const int64_t half = (slice / nsub + 15) / 16 * 16;
+    const std::vector<unsigned char>& rlong = h_row_long;
+    const bool verbose = getenv("IPXK_VERBOSE") != nullptr;
+    int RB = 8 * kSortedThreads, nrb = 0, max_sub = 0;
+    int64_t nsubs = 0, nshort = 0;
+    std::vector<unsigned> sptr;
+    std::vector<unsigned char> cnt;
+    for (;; RB /= 2) {
+        if (RB < kSortedThreads) {
+            if (verbose) fprintf(stderr, "ipxk: sorted layout not used for %d x %d: a sub-tile of %d rows holds %d entries\n", nrows, ncols, 2 * RB, max_sub);
+            return;
+        }
+        nrb = (nrows + RB - 1) / RB;
+        nsubs = (int64_t)nrb * ns * nsub;
+        sptr.assign((size_t)nsubs + 1, 0);
+        cnt.assign((size_t)nsubs * RB, 0);
+        bool ok = true;
+        for (int r = 0; r < nrows && ok; r++) {
+            if (!rlong.empty() && rlong[r]) continue;
+            const int64_t tile0 = (int64_t)(r / RB) * ns;
+            for (ipxint p = hptr[r]; p < hptr[r + 1]; p++) {
+                const int64_t sl = hidx[p] / slice, off = hidx[p] - sl * slice;
+                const int64_t sub = (tile0 + sl) * nsub + std::min<int64_t>(off / half, nsub - 1);
+                unsigned char& cc = cnt[(size_t)sub * RB + r % RB];
+                if (cc == 255) { ok = false; break; }
+                cc++;
+                sptr[sub + 1]++;
+            }
+        }
+        if (!ok) return;                 // a row with > 255 entries in one sub-slice
+        max_sub = 0;
+        for (int64_t t = 0; t < nsubs; t++) { max_sub = std::max(max_sub, (int)sptr[t + 1]); sptr[t + 1] += sptr[t]; }
+        nshort = sptr[nsubs];
+        if (max_sub <= kSortedMaxSub) break;
+    }
+    if (nshort == 0) return;
+    // entries row by row (slot = place in that order), then every sub-tile sorted by gathered index
+    std::vector<unsigned> pk((size_t)nshort);
+    std::vector<double> tv((size_t)nshort);
+    {
+        std::vector<unsigned> cursor(sptr.begin(), sptr.end() - 1);
+        for (int r = 0; r < nrows; r++) {
+            if (!rlong.empty() && rlong[r]) continue;
+            const int64_t tile0 = (int64_t)(r / RB) * ns;
+            for (ipxint p = hptr[r]; p < hptr[r + 1]; p++) {
+                const int64_t sl = hidx[p] / slice, off = hidx[p] - sl * slice;
+                const int64_t sub = (tile0 + sl) * nsub + std::min<int64_t>(off / half, nsub - 1);
+                const unsigned put = cursor[sub]++;
+                pk[put] = ((put - sptr[sub]) << kSortedOffBits) | (unsigned)off;
+                tv[put] = hval[p];
+            }
+        }
+        std::vector<std::pair<unsigned, double>> tmp;
+        const unsigned mask = (1u << kSortedOffBits) - 1u;
+        for (int64_t t = 0; t < nsubs; t++) {
+            const unsigned a = sptr[t], b = sptr[t + 1];
+            if (b - a < 2) continue;
+            tmp.resize(b - a);
+            for (unsigned e = a; e < b; e++) tmp[e - a] = {pk[e], tv[e]};
+            std::sort(tmp.begin(), tmp.end(), [&](const std::pair<unsigned, double>& x, const std::pair<unsigned, double>& y) {
+                const unsigned ox = x.first & mask, oy = y.first & mask;
+                return ox != oy ? ox < oy : x.first < y.first;
+            });
+            for (unsigned e = a; e < b; e++) { pk[e] = tmp[e - a].first; tv[e] = tmp[e - a].second; }
+        }
+    }
+    sorted.nslices = ns; sorted.nsub = nsub; sorted.nrb = nrb; sorted.RB = RB; sorted.nrows_pad = nrb * RB;
+    sorted.max_sub = max_sub; sorted.slice_elems = (int)slice;
+    sorted.sub_ptr.upload(sptr, s);
+    sorted.cnt.upload(cnt, s);
+    sorted.pack.upload(pk, s);
+    sorted.val.upload(tv, s);
+    sorted.partial.resize((size_t)ns * sorted.nrows_pad);
+    IPXK_HIP(hipStreamSynchronize(s));
+    sorted.built = true;
+}
+
+SortedView GatherMatrix::sorted_view() const {
+    SortedView V;
+    V.nrows = nrows; V.nrows_pad = sorted.nrows_pad; V.nslices = sorted.nslices; V.nsub = sorted.nsub; V.nrb = sorted.nrb;
+    V.RB = sorted.RB; V.slice_elems = sorted.slice_elems;
+    V.sub_ptr = sorted.sub_ptr.get(); V.cnt = sorted.cnt.get(); V.pack = sorted.pack.get(); V.val = sorted.val.get();
+    V.partial = sorted.partial.get();
+    return V;
+}
+
+SlicedView GatherMatrix::sliced_view(int which) const {
     SlicedView V;
     V.nrows = nrows; V.nrows_pad = sliced.nrows_pad; V.nslices = sliced.nslices; V.nrb = sliced.nrb; V.R = sliced.R;
     V.tile_ptr = sliced.tile_ptr.get(); V.cnt = sliced.cnt.get();
-    V.idx = sliced.idx.get(); V.val = use_masked ? valM.get() : sliced.val.get(); V.partial = sliced.partial.get();
+    V.idx = sliced.idx.get(); V.val = which == 1 ? valM.get() : sliced.val.get(); V.partial = sliced.partial.get();
+    if (which == 2) {
+        V.tile_ptr = compact.tile_ptr.get(); V.cnt = compact.cnt.get(); V.idx = compact.idx.get(); V.val = compact.val.get();
+    }
     V.row_long = nlong > 0 ? row_long.get() : nullptr;
-    V.masked = use_masked ? 1 : 0;
+    V.masked = which == 1 ? 1 : 0;
     return V;
 }
 
@@ -446,6 +557,114 @@ void GatherMatrix::mask_values(const double* weight, bool by_row, hipStream_t s)
         hipLaunchKernelGGL(mask_long_rows_kernel, dim3(nlong), dim3(kBlock), 0, s, view(), weight, by_row ? 1 : 0, lvalM.get());
     }
     IPXK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// compacted tiles (GatherMatrix::compact_tiles)
+// ---------------------------------------------------------------------------
+// kept entries per row of the tile and per tile; one workgroup per tile.  wkey[e] addresses the weight of
+// entry e (its row in the gather matrix, or its gathered index), rowof[e] its row.
+__global__ __launch_bounds__(kBlock) void compact_count_kernel(SlicedView M, const int* __restrict__ rowof,
+                                                               const int* __restrict__ wkey, const double* __restrict__ weight,
+                                                               unsigned char* __restrict__ cnt_out, unsigned* __restrict__ tile_kept) {
+    __shared__ int rowcnt[kSlicedRows];
+    __shared__ int wsum[kBlock / 64];
+    const int tile = blockIdx.x, rb = tile / M.nslices, tid = threadIdx.x;
+    for (int r = tid; r < M.R; r += kBlock) rowcnt[r] = 0;
+    __syncthreads();
+    const unsigned e0 = M.tile_ptr[tile], e1 = M.tile_ptr[tile + 1];
+    int mine = 0;
+    for (unsigned e = e0 + tid; e < e1; e += kBlock)
+        if (weight[wkey[e]] != 0.0) { atomicAdd(&rowcnt[rowof[e] - rb * M.R], 1); mine++; }
+    __syncthreads();
+    for (int r = tid; r < M.R; r += kBlock) cnt_out[(size_t)tile * M.R + r] = (unsigned char)rowcnt[r];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
+    if ((tid & 63) == 0) wsum[tid >> 6] = mine;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < kBlock / 64; w++) t += wsum[w]; tile_kept[tile] = (unsigned)t; }
+}
+// exclusive prefix sum of n counts by one workgroup (n = # tiles, a few thousand)
+__global__ __launch_bounds__(1024) void compact_scan_kernel(int n, const unsigned* __restrict__ in, unsigned* __restrict__ out) {
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const unsigned v = i < n ? in[i] : 0u;
+        unsigned incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        unsigned before = carry;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        if (i < n) out[i] = before + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry;
+}
+// the kept entries of a tile, in order, to their new place; one workgroup per tile
+__global__ __launch_bounds__(kBlock) void compact_fill_kernel(SlicedView M, const int* __restrict__ wkey, const double* __restrict__ weight,
+                                                              const unsigned* __restrict__ new_ptr, int* __restrict__ idx_out,
+                                                              double* __restrict__ val_out) {
+    __shared__ int wsum[kBlock / 64];
+    const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned e0 = M.tile_ptr[tile], e1 = M.tile_ptr[tile + 1];
+    unsigned base = new_ptr[tile];
+    for (unsigned c0 = e0; c0 < e1; c0 += kBlock) {
+        const unsigned e = c0 + tid;
+        const bool keep = e < e1 && weight[wkey[e]] != 0.0;
+        const unsigned long long b = __ballot(keep);
+        const int before = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(b);
+        __syncthreads();
+        int wbefore = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) { if (w < wave) wbefore += wsum[w]; total += wsum[w]; }
+        if (keep) {
+            idx_out[base + wbefore + before] = M.idx[e];
+            val_out[base + wbefore + before] = M.val[e];
+        }
+        base += (unsigned)total;
+        __syncthreads();
+    }
+}
+
+void GatherMatrix::compact_tiles(const double* weight, bool by_row, hipStream_t s) {
+    compact.valid = false;
+    if (!use_sliced || !sliced.built) return;
+    const int64_t nz = (int64_t)sliced.idx.size();
+    const SlicedView V = sliced_view(0);
+    const int ntiles = V.nrb * V.nslices;
+    if (nz == 0 || ntiles == 0) return;
+    if (rowof.size() == 0) {
+        rowof.resize((size_t)nz);
+        IPXK_HIP(hipMemsetAsync(rowof.get(), 0, (size_t)nz * sizeof(int), s));
+        hipLaunchKernelGGL(rowof_sliced_kernel, dim3(ntiles), dim3(kBlock), 0, s, V, rowof.get());
+    }
+    compact.tile_ptr.ensure((size_t)ntiles + 1);
+    compact.tile_kept.ensure((size_t)ntiles);
+    compact.cnt.ensure((size_t)ntiles * V.R);
+    compact.idx.ensure((size_t)nz);
+    compact.val.ensure((size_t)nz);
+    const int* wkey = by_row ? rowof.get() : sliced.idx.get();
+    hipLaunchKernelGGL(compact_count_kernel, dim3(ntiles), dim3(kBlock), 0, s, V, rowof.get(), wkey, weight, compact.cnt.get(),
+                       compact.tile_kept.get());
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, s, ntiles, compact.tile_kept.get(), compact.tile_ptr.get());
+    hipLaunchKernelGGL(compact_fill_kernel, dim3(ntiles), dim3(kBlock), 0, s, V, wkey, weight, compact.tile_ptr.get(),
+                       compact.idx.get(), compact.val.get());
+    IPXK_HIP(hipGetLastError());
+    if (nlong > 0) {           // long rows stay with their masked values
+        lvalM.ensure(lval.size());
+        hipLaunchKernelGGL(mask_long_rows_kernel, dim3(nlong), dim3(kBlock), 0, s, view(), weight, by_row ? 1 : 0, lvalM.get());
+        IPXK_HIP(hipGetLastError());
+    }
+    compact.valid = true;
 }
 
 // ---------------------------------------------------------------------------

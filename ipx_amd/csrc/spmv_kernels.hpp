@@ -457,10 +457,12 @@ __global__ __launch_bounds__(kBlock) void spmv_sliced_combine_kernel(SlicedView 
     }
 }
 
-template <class Epi, bool MASKED = false>
+// COMPACT: use the compacted copy of the tiles (GatherMatrix::compact_tiles) -- the plain kernels on fewer entries
+template <class Epi, bool MASKED = false, bool COMPACT = false>
 inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi& epi, double* dot_partials,
                                const int* done, hipStream_t s) {
-    const SlicedView V = M.sliced_view(MASKED);
+    static_assert(!(MASKED && COMPACT), "the compacted copy needs no mask");
+    const SlicedView V = M.sliced_view(COMPACT ? 2 : MASKED ? 1 : 0);
     const size_t lds = (size_t)(M.sliced.max_tile + M.sliced.max_tile / 32 + 1) * sizeof(double);
     const dim3 grid(V.nrb * V.nslices), block(kBlock);
     if (V.nslices == 1) {       // fused: the tile kernel is the whole product
@@ -476,7 +478,7 @@ inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi
                            dot_partials, done);
     }
     if (M.nlong > 0) {          // rows of more than kMaxRowLen entries: segment sums + ordered fix-up
-        const GatherView G = M.view(MASKED);
+        const GatherView G = M.view(MASKED || COMPACT);
         hipLaunchKernelGGL(spmv_long_kernel<Epi>, dim3(M.nseg), block, 0, s, G, x, done);
         hipLaunchKernelGGL(spmv_long_fixup_kernel<Epi>, dim3(1), block, 0, s, G, epi, dot_partials,
                            V.nslices == 1 ? M.fused_grid() : M.combine_grid(), done);
@@ -489,7 +491,8 @@ template <class Epi, bool MASKED = false>
 inline int launch_spmv(const GatherMatrix& M, const double* x, const Epi& epi, double* dot_partials,
                        const int* done, hipStream_t s) {
     if (M.use_sliced) {
-        launch_spmv_sliced<Epi, MASKED>(M, x, epi, dot_partials, done, s);
+        if (MASKED && M.compact.valid) launch_spmv_sliced<Epi, false, true>(M, x, epi, dot_partials, done, s);
+        else launch_spmv_sliced<Epi, MASKED>(M, x, epi, dot_partials, done, s);
         return dot_partials ? M.num_partials() : 0;
     }
     const GatherView V = M.view(MASKED);

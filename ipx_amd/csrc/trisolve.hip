@@ -73,6 +73,7 @@ struct LaneRec {
     int src;        // index of the right-hand side in the input vector (-1: padding)
     int len;        // entries of the row
     int sub;        // merged chunks: which of the chunk's levels the row belongs to
+    int dst2;       // second destination of the result (SweepView::dst2), -1: none
     double dg, xr;
     int j[8];       // dependency positions
     double a[8];
@@ -89,6 +90,7 @@ __device__ __forceinline__ void load_rec(LaneRec& R, const SweepView& S, const C
     // every address depends on the (scalar) descriptor only: one round trip, fully coalesced
     const int pos = d.width >= 0 ? d.pos0 + lane : d.pos0 + (lane >> 3);
     R.src = S.src[pos];
+    R.dst2 = S.dst2 ? S.dst2[pos] : -1;
     R.dg = S.diag[pos];
     const int lenword = S.len[pos];
     R.len = lenword & ((1 << kLenBits) - 1);
@@ -111,7 +113,7 @@ __device__ __forceinline__ void load_rec(LaneRec& R, const SweepView& S, const C
 // Through memory: every look at a dependency bypasses L1; results are stored write-through, or with plain
 // stores that stay in the XCD's L2 when all workgroups of the launch are known to share one XCD.
 struct HandGlobal {
-    const gu64* xo; double* xout; bool plain_store;
+    const gu64* xo; double* xout; bool plain_store; double* out2;
     __device__ __forceinline__ gu64 look(int pj) const { return load_sc1(xo + pj); }
     __device__ __forceinline__ void store(int pos, gu64 out) const {
         if (plain_store) __hip_atomic_store(reinterpret_cast<gu64*>(xout) + pos, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -153,10 +155,11 @@ __device__ __forceinline__ bool wait_polls(const LaneRec& R, const Hand& H, gu64
 }
 
 template <class Hand>
-__device__ __forceinline__ void store_result(const Hand& H, int pos, double res) {
+__device__ __forceinline__ void store_result(const Hand& H, int pos, double res, int dst2 = -1) {
     gu64 out = (gu64)__double_as_longlong(res);
     if (out == kSentinel) out = kPlainNan;     // a result must never look unfinished
     H.store(pos, out);
+    if (dst2 >= 0) H.out2[dst2] = res;         // second copy for the kernel AFTER this launch: a plain store
 }
 
 // value of lane (this lane + N) of the same 16-lane row (DPP row_shl:N); lanes whose source lies outside
@@ -228,8 +231,8 @@ __device__ __forceinline__ void solve_merged(const LaneRec& R, const ChunkDesc& 
         }
         if (R.sub == s && (ell || gl == 0)) result = R.src >= 0 ? (RUNNING ? acc : R.xr - acc) / R.dg : 0.0;
     }
-    if (ell) store_result(H, d.pos0 + lane, result);
-    else if (gl == 0) store_result(H, d.pos0 + (lane >> 3), result);
+    if (ell) store_result(H, d.pos0 + lane, result, R.dst2);
+    else if (gl == 0) store_result(H, d.pos0 + (lane >> 3), result, R.dst2);
 }
 
 // solves the chunk whose records are in R (first look at the dependencies already issued into bits);
@@ -250,7 +253,7 @@ __device__ __forceinline__ bool solve_chunk(LaneRec& R, const ChunkDesc& d, int 
                 acc = RUNNING ? acc - prod : acc + prod;
             }
         // padding positions get a value too (1 wavefront = 1 contiguous store; nobody depends on them)
-        store_result(H, d.pos0 + lane, R.src >= 0 ? (RUNNING ? acc : R.xr - acc) / R.dg : 0.0);
+        store_result(H, d.pos0 + lane, R.src >= 0 ? (RUNNING ? acc : R.xr - acc) / R.dg : 0.0, R.dst2);
         return true;
     }
     const int gl = lane & 7;
@@ -308,7 +311,7 @@ __device__ __forceinline__ bool solve_chunk(LaneRec& R, const ChunkDesc& d, int 
             if (!wait_polls(R, H, bits, abort_flag)) return false;
         }
     }
-    if (gl == 0) store_result(H, d.pos0 + (lane >> 3), R.src >= 0 ? (RUNNING ? acc : R.xr - acc) / R.dg : 0.0);
+    if (gl == 0) store_result(H, d.pos0 + (lane >> 3), R.src >= 0 ? (RUNNING ? acc : R.xr - acc) / R.dg : 0.0, R.dst2);
     return true;
 }
 
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(kBlock) void sweep_run_kernel(SweepView S, int c0, 
         plain = same_xcd != 0;
     }
     if (!active) return;
-    const HandGlobal H{xo, xout, plain};
+    const HandGlobal H{xo, xout, plain, S.out2};
     chunk_loop<RUNNING, MERGED>(S, c, c1, NW, lane, xin, H, A, d, dn, abort_flag);
 }
 
@@ -439,6 +442,11 @@ __global__ void compose_kernel(int n, const int* __restrict__ order, const int* 
         const int i = order[p];
         out[p] = i >= 0 ? (map ? map[i] : i) : -1;
     }
+}
+
+// out[map[i]] = i
+__global__ void invert_map_kernel(int n, const int* __restrict__ map, int* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[map[i]] = i;
 }
 
 // lhs = free ? 0 : lhs + rhs;  partial dot rhs'lhs       (splitted_normal_matrix.cc:112-116)
@@ -502,9 +510,11 @@ void plan_sweep(Sweep& S, bool level_launches) {
 
 // runs the sweep on the input vector xin (addressed through S.src); the result goes to S.y, which must
 // hold the sentinel in every position (fill_results)
-static void run_sweep(Context* c, const Sweep& S, bool scaled, const double* xin, const int* done) {
+static void run_sweep(Context* c, const Sweep& S, bool scaled, const double* xin, const int* done,
+                      const int* dst2 = nullptr, double* out2 = nullptr) {
     SplitOperator* sp = c->split;
-    const SweepView V = S.view(scaled);
+    SweepView V = S.view(scaled);
+    V.dst2 = dst2; V.out2 = out2;
     double* xout = S.y.get();
     // Every workgroup of a run must be resident (a wavefront may wait for a chunk that another workgroup of
     // the same launch owns): never launch more workgroups than the device holds at once.  One block per CU
@@ -641,9 +651,18 @@ static void upload_scaling(Context* c, SplitOperator* S, const ipxint* status, c
     // N N' runs on the model matrix with weights that are zero on the BASIC and fixed columns: value arrays in
     // which those columns' entries are zero let both passes skip the gathers of those entries (spmv.hip)
     S->masked_values = !(getenv("IPXK_MASKED_VALUES") && getenv("IPXK_MASKED_VALUES")[0] == '0');
+    // IPXK_COMPACT_N=0: keep streaming the whole model matrix with masked values (round-2 form)
+    const bool compact = !(getenv("IPXK_COMPACT_N") && getenv("IPXK_COMPACT_N")[0] == '0');
+    c->Acols.compact.valid = c->Arows.compact.valid = false;
     if (S->masked_values) {
-        c->Acols.mask_values(S->Wsplit.get(), true, s);      // a row of the gather matrix = a structural column
-        c->Arows.mask_values(S->Wsplit.get(), false, s);     // the gathered index = a structural column
+        // N as a matrix of its own (splitted_normal_matrix.cc:42-55): the tiles of the two gather matrices without
+        // the entries of zero-weight columns; layouts without tiles (phased) and long rows keep the masked values
+        if (compact) {
+            c->Acols.compact_tiles(S->Wsplit.get(), true, s);    // a row of the gather matrix = a structural column
+            c->Arows.compact_tiles(S->Wsplit.get(), false, s);   // the gathered index = a structural column
+        }
+        if (!c->Acols.compact.valid) c->Acols.mask_values(S->Wsplit.get(), true, s);
+        if (!c->Arows.compact.valid) c->Arows.mask_values(S->Wsplit.get(), false, s);
     }
 }
 
@@ -669,6 +688,11 @@ static void finish_prepare(Context* c, SplitOperator* S, const ipxint* status, c
         compose(S->Uf.npos, S->Uf.order.get(), S->Lf.posof.get(), S->Uf.src.get());
         S->perm_after_backward.ensure(mm);
         compose(m, S->rowperm_inv.get(), S->Lt.posof.get(), S->perm_after_backward.get());
+        // ... and its inverse, by position of the L' sweep (padding positions: -1)
+        S->row_after_backward.ensure((size_t)std::max(S->Lt.npos, 1));
+        IPXK_HIP(hipMemsetAsync(S->row_after_backward.get(), 0xff, (size_t)std::max(S->Lt.npos, 1) * sizeof(int), s));
+        if (m > 0) hipLaunchKernelGGL(invert_map_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, m, S->perm_after_backward.get(),
+                                      S->row_after_backward.get());
     }
     S->xcc_slots.resize(64);
     IPXK_HIP(hipMemsetAsync(S->xcc_slots.get(), 0, 64 * sizeof(gu64), s));
@@ -988,11 +1012,11 @@ int split_apply_dev(Context* c, const double* rhs, double* lhs, const int* done)
     time_mark(c, kTimeBt, true);
     run_sweep(c, S->Ut, true, rhs, done);
     bump_between(c, true, S->Ut.y.get(), done);
-    run_sweep(c, S->Lt, true, S->Ut.y.get(), done);
+    // (the L' sweep also leaves its result in u in the row order of A, for the N N' product)
+    run_sweep(c, S->Lt, true, S->Ut.y.get(), done, S->row_after_backward.get(), u);
     time_mark(c, kTimeBt, false);
     time_mark(c, kTimeOp, true);
-    // N N' of it: into the row order of A, A (M D^2) A'
-    hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, S->Lt.y.get(), S->perm_after_backward.get(), u, done);
+    // N N' of it: A (M D^2) A'
     EpiScale e1{{}, S->Wsplit.get(), c->tcols.get()};
     EpiNormalRows e2{{}, S->Wsplit.get() + n, u, work};
     if (S->masked_values) {

@@ -48,6 +48,11 @@ struct SweepView {
     // dependencies that become available last (the L' sweep: descending unknowns, ascending storage order), so
     // its rounds are taken from the end of the row -- all but the last round then run ahead of the chain
     int newest_first;
+    // optional second copy of the result in another order (plain stores, read after the launch): out2[dst2[k]] =
+    // value at position k for dst2[k] >= 0 -- the L' sweep of the split operator hands inverse(B~') rhs to the
+    // N N' product in the row order of A this way, without a permutation pass of its own
+    const int* dst2;
+    double* out2;
 };
 
 // A sweep is a sequence of launches, each a run of consecutive levels (= a range of chunks):
@@ -81,6 +86,7 @@ struct Sweep {
         V.val = (scaled && scale_mode) ? valS.get() : val.get();
         V.diag = (scaled && scale_mode) ? diagS.get() : diag.get();
         V.newest_first = newest_first ? 1 : 0;
+        V.dst2 = nullptr; V.out2 = nullptr;
         return V;
     }
 };
@@ -98,6 +104,7 @@ struct SplitOperator {
     int num_free = 0;
     DevBuf<double> w0, w1, w2, w3;         // m workspaces
     DevBuf<int> perm_after_backward;       // u[i] = Lt.y[perm_after_backward[i]] is inverse(B~') rhs in row order of A
+    DevBuf<int> row_after_backward;        // its inverse by position of the L' sweep: row of A of a position, -1 for padding
     DevBuf<unsigned long long> xcc_slots;  // one-XCD runs: placement consensus words
     unsigned epoch = 0;                    // launch counter of the one-XCD runs
     DevBuf<int> abort_flag;

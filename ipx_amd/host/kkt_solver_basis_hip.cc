@@ -30,12 +30,17 @@ void KKTSolverBasisHip::_Factorize(Iterate* iterate, Info* info) {
     // _Factorize is one private function, so this also runs its CPU SplittedNormalMatrix::Prepare,
     // whose result is not used here: duplicated O(nnz) host work per IPM iteration that only a change
     // inside src/kkt_solver_basis.cc could remove -- see INTEGRATION.md.)
-    const bool fresh_before = basis_.FactorizationIsFresh();
     cpu_.Factorize(iterate, info);
     if (info->errflag)
         return;
-    // same basis, same factorization as at the previous hand-off: only the scaling changed
-    const bool same_factors = prepared_once_ && fresh_before && cpu_.basis_changes() == 0;
+    // The device keeps the factors of the previous hand-off.  They are still the factors Basis holds iff no LU
+    // factorization happened since (Basis::factorizations(), src/basis.h:214, counts every one -- also a
+    // refactorization of an UNCHANGED basis after Basis::TightenLuPivotTol, which basis_changes() == 0 would
+    // miss) and no update was applied on top of them (the factorization is fresh, as _Factorize leaves it).
+    // Then only the scaling changed.
+    const bool same_factors = prepared_once_ && basis_.FactorizationIsFresh() &&
+                              basis_.factorizations() == factorizations_at_handoff_;
+    factorizations_at_handoff_ = basis_.factorizations();
 
     // Interior point column scaling after the state changes (src/iterate.cc:183-198): fixed
     // variables scale by 0, free/implied ones by infinity -- the values the reference's

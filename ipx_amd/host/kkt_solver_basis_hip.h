@@ -39,6 +39,7 @@ private:
     HipModel device_;
     bool factorized_{false};
     bool prepared_once_{false};  // the device holds the factors of an earlier hand-off
+    Int factorizations_at_handoff_{-1};   // Basis::factorizations() when those factors were handed over
     Int maxiter_{-1};
     Int iter_{0};
 };

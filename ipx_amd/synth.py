@@ -333,6 +333,34 @@ def lp_like_basis_matrix(dim, bump=64, frac_rowsing=0.2, frac_slack=0.5, offdiag
                 rowperm=rowperm.astype(i64), colperm=colperm.astype(i64), is_slack_stage=is_slack)
 
 
+def disturbed_basis_matrix(dim, num_exchanged, entries=8, seed=12345, **kw):
+    """lp_like_basis_matrix after `num_exchanged` basis exchanges: that many of its columns are replaced by random
+    columns of `entries` entries (what Maxvolume / the simplex method do to a basis).  Singleton peeling is
+    all-or-nothing along dependency chains, so a few dozen such columns leave a bump of a large part of the matrix
+     -- sparse and nearly triangular, the input of the LU's tearing phase."""
+    G = lp_like_basis_matrix(dim, seed=seed, **kw)
+    rng = np.random.default_rng(seed + 99)
+    import scipy.sparse as sp
+    B = sp.csc_matrix((G["Bx"], G["Bi"], G["Bp"]), shape=(dim, dim)).tolil()
+    cols = rng.choice(dim, num_exchanged, replace=False)
+    stage_of_col = np.empty(dim, dtype=i64)
+    stage_of_col[G["colperm"]] = np.arange(dim)
+    for j in cols:
+        # an exchange keeps the basis nonsingular (the pivot element of the update is nonzero): the entering column
+        # has an entry in the row the leaving column was paired with in the hidden pivot order
+        keep = G["rowperm"][stage_of_col[j]]
+        rows = np.unique(np.concatenate([[keep], rng.choice(dim, entries - 1, replace=False)]))
+        B[:, j] = 0
+        for r in rows:
+            B[r, j] = rng.uniform(0.5, 4.0) * rng.choice([-1.0, 1.0])
+    B = B.tocsc()
+    B.eliminate_zeros()
+    B.sort_indices()
+    out = dict(G)
+    out.update(Bp=B.indptr.astype(i64), Bi=B.indices.astype(i64), Bx=B.data.astype(f64), exchanged=np.sort(cols))
+    return out
+
+
 def lp_like_basis(m, n, seed=12345, **kw):
     """An LP [A I] (m x n structural columns) with a nearly triangular basis: lp_like_basis_matrix planted into it.
     The unit columns of B are slack columns n+i, its other columns are structural columns of A (scattered),

@@ -1388,7 +1388,16 @@ extern "C" Int orc_ipm_driver_diag(orc_kkt_diag* K, const unsigned char* state, 
 //     the rows not yet pivoted, ties: smaller row), columns in ascending index order; a column whose largest
 //     entry is below the absolute tolerance (kLuDependencyTol if strict_abs_pivottol, src/ipx_internal.h:26,
 //     else 1e-14, BASICLU's default) is dependent;
-//   * dependent columns come last, paired with the left-over rows in ascending order.
+//   * dependent columns come last, paired with the left-over rows in ascending order;
+//   * a bump of more than bump_limit rows is not factorized densely as it stands: it is TORN first.  Whenever the
+//     rounds stall, the T active columns with the most active entries (ties: smaller index) are set aside as
+//     SPIKES (T = 1, doubled up to 1024 while a tear frees fewer than 64 pivots, back to 1 otherwise) and the
+//     rounds go on without them, until no active column is left.  Spikes are never pivots of a round, so every
+//     round pivot still costs no arithmetic outside them; the spikes themselves receive the updates of the row
+//     singleton pivots in pivot order (a forward substitution with the L columns found so far), their entries in
+//     pivoted rows become entries of U, and their entries in the rows that were never pivoted form the dense block
+//     that is then factorized with partial pivoting as above (refused if it has more than bump_limit rows).
+//     This is the classical bump-and-spike ordering of LP bases (Hellerman-Rarick) restated for rounds.
 // PARITY UNPINNED against BASICLU's pivot order and values (no fixture in the reference holds them:
 // check/solver.cc asserts statuses only).  What IS pinned: the contract, through the reference's own
 // LuFactorization::Factorize / stability() (src/lu_factorization.cc:87-127) and ForrestTomlin
@@ -1424,13 +1433,17 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
     for (Int j = 0; j < dim; j++) cc[j] = Bend[j] - Bbegin[j];
     for (Int i = 0; i < dim; i++) rc[i] = rp[i + 1] - rp[i];
     Int npiv = 0, rounds = 0;
+    std::vector<char> torn(dim, 0);                  // spike columns (set aside when the rounds stall)
+    std::vector<Int> pivrow_of(dim, -1);             // pivot row of a pivoted column
+    bool tearing = false;
+    Int ntorn = 0, tear_width = 1, npiv_at_tear = 0;
     while (true) {
         Int found = 0;
         // ---- column singletons
         {
             std::vector<Int> claim(dim, -1), piv_row(dim, -1);
             for (Int j = 0; j < dim; j++) {
-                if (cstage[j] >= 0 || cc[j] != 1) continue;
+                if (cstage[j] >= 0 || torn[j] || cc[j] != 1) continue;
                 for (Int p = Bbegin[j]; p < Bend[j]; p++) {
                     const Int i = Bi[p];
                     if (rstage[i] >= 0) continue;
@@ -1444,6 +1457,7 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
                 const Int i = piv_row[j];
                 rstage[i] = cstage[j] = npiv++;
                 ckind[j] = 1;
+                pivrow_of[j] = i;
             }
             for (Int j : winners) {
                 const Int i = piv_row[j];
@@ -1461,7 +1475,7 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
                 if (rstage[i] >= 0 || rc[i] != 1) continue;
                 for (Int q = rp[i]; q < rp[i + 1]; q++) {
                     const Int j = rj[q];
-                    if (cstage[j] >= 0) continue;
+                    if (cstage[j] >= 0 || torn[j]) continue;
                     const double a = std::abs(rx[q]);
                     double colmax = 0.0;
                     for (Int p = Bbegin[j]; p < Bend[j]; p++)
@@ -1477,6 +1491,7 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
                 const Int j = piv_col[i];
                 rstage[i] = cstage[j] = npiv++;
                 ckind[j] = 2;
+                pivrow_of[j] = i;
                 for (Int q = rp[i]; q < rp[i + 1]; q++) if (rj[q] == j) pivot[j] = rx[q];
             }
             for (Int i : winners) {
@@ -1488,9 +1503,33 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
             F->info[1] += (Int)winners.size();
         }
         rounds++;
-        if (found == 0) break;
+        if (found > 0) continue;
+        // the rounds stall: done, or (a bump beyond the dense limit) tear spikes off and go on
+        Int nact = 0;
+        for (Int j = 0; j < dim; j++) nact += cstage[j] < 0 && !torn[j];
+        if (nact == 0) break;
+        if (!tearing) {
+            if (bump_limit < 0 || nact <= bump_limit) break;       // small enough: dense as it stands
+            tearing = true;
+        } else {
+            tear_width = npiv - npiv_at_tear < 64 ? std::min<Int>(2 * tear_width, 1024) : 1;
+        }
+        std::vector<std::pair<Int, Int>> cand;                     // (-active entries, index)
+        for (Int j = 0; j < dim; j++) if (cstage[j] < 0 && !torn[j]) cand.emplace_back(-cc[j], j);
+        const size_t take = std::min<size_t>((size_t)tear_width, cand.size());
+        std::partial_sort(cand.begin(), cand.begin() + take, cand.end());
+        for (size_t t = 0; t < take; t++) {
+            const Int j = cand[t].second;
+            torn[j] = 1;
+            for (Int p = Bbegin[j]; p < Bend[j]; p++)
+                if (rstage[Bi[p]] < 0) rc[Bi[p]]--;
+        }
+        ntorn += (Int)take;
+        npiv_at_tear = npiv;
+        if (ntorn > bump_limit) { F->info[2] = ntorn; return nullptr; }
     }
     F->info[3] = rounds;
+    F->info[5] = ntorn;
     // ---- bump: dense, partial pivoting
     std::vector<Int> brow, bcol, rloc(dim, -1), cloc(dim, -1);
     for (Int i = 0; i < dim; i++) if (rstage[i] < 0) { rloc[i] = (Int)brow.size(); brow.push_back(i); }
@@ -1499,9 +1538,46 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
     F->info[2] = kb;
     if (bump_limit >= 0 && kb > bump_limit) return nullptr;
     std::vector<double> D((size_t)kb * kb, 0.0);      // column-major
-    for (Int c = 0; c < kb; c++)
-        for (Int p = Bbegin[bcol[c]]; p < Bend[bcol[c]]; p++)
-            if (rloc[Bi[p]] >= 0) D[(size_t)c * kb + rloc[Bi[p]]] = Bx[p];
+    std::vector<std::vector<std::pair<Int, double>>> spikeU;       // torn: entries of a spike in pivoted rows (stage, value)
+    if (!tearing) {
+        for (Int c = 0; c < kb; c++)
+            for (Int p = Bbegin[bcol[c]]; p < Bend[bcol[c]]; p++)
+                if (rloc[Bi[p]] >= 0) D[(size_t)c * kb + rloc[Bi[p]]] = Bx[p];
+    } else {
+        // the spikes through the row singleton pivots in pivot order: x[r] -= l_rj * x[i] for every row r that was
+        // still active when (i, j) was pivoted (products rounded before they are subtracted)
+        std::vector<Int> lpiv;                                     // row singleton columns by stage
+        {
+            std::vector<std::pair<Int, Int>> o;
+            for (Int j = 0; j < dim; j++) if (ckind[j] == 2) o.emplace_back(cstage[j], j);
+            std::sort(o.begin(), o.end());
+            for (auto& e : o) lpiv.push_back(e.second);
+        }
+        spikeU.resize(kb);
+        std::vector<double> x(dim, 0.0);
+        for (Int c = 0; c < kb; c++) {
+            const Int js = bcol[c];
+            for (Int p = Bbegin[js]; p < Bend[js]; p++) x[Bi[p]] = Bx[p];
+            for (Int j : lpiv) {
+                const Int i = pivrow_of[j], k = cstage[j];
+                const double xi = x[i];
+                if (xi == 0.0) continue;
+                for (Int p = Bbegin[j]; p < Bend[j]; p++) {
+                    const Int r = Bi[p];
+                    if (r == i || (rstage[r] >= 0 && rstage[r] < k)) continue;
+                    const double l = Bx[p] / pivot[j];
+                    x[r] -= l * xi;
+                }
+            }
+            for (Int r = 0; r < dim; r++) {
+                if (x[r] != 0.0) {
+                    if (rstage[r] >= 0) spikeU[c].emplace_back(rstage[r], x[r]);
+                    else D[(size_t)c * kb + rloc[r]] = x[r];
+                }
+                x[r] = 0.0;
+            }
+        }
+    }
     std::vector<Int> brstep(kb, -1), bcstep(kb, -1);   // bump-local pivot step of a row / column
     Int bstep = 0;
     for (Int c = 0; c < kb; c++) {
@@ -1554,12 +1630,16 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
             ucol.emplace_back(k, 1.0);
         } else {
             const Int c = cloc[j];
-            for (Int p = Bbegin[j]; p < Bend[j]; p++) {
-                const Int i = Bi[p];
-                if (c >= 0 && rloc[i] >= 0) continue;                 // bump x bump: from the dense result
-                const Int s = rstage[i];
-                if (s < k) ucol.emplace_back(s, Bx[p]);
-                else if (s > k) lcol.emplace_back(s, Bx[p] / pivot[j]);
+            if (c >= 0 && tearing) {
+                for (auto& e : spikeU[c]) ucol.push_back(e);          // a spike above the dense block: its updated values
+            } else {
+                for (Int p = Bbegin[j]; p < Bend[j]; p++) {
+                    const Int i = Bi[p];
+                    if (c >= 0 && rloc[i] >= 0) continue;             // bump x bump: from the dense result
+                    const Int s = rstage[i];
+                    if (s < k) ucol.emplace_back(s, Bx[p]);
+                    else if (s > k) lcol.emplace_back(s, Bx[p] / pivot[j]);
+                }
             }
             if (c >= 0) {
                 const double* col = &D[(size_t)c * kb];

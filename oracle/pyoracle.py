@@ -167,7 +167,8 @@ class Oracle:
         self.lib.orc_lu_free(h)
         return dict(L=Csc(dim, dim, Lp, Li, Lx), U=Csc(dim, dim, Up, Ui, Ux), rowperm=rowperm, colperm=colperm,
                     dependent=dep, info=dict(col_singletons=int(info[0]), row_singletons=int(info[1]),
-                                             bump=int(info[2]), rounds=int(info[3]), dependent=int(info[4])))
+                                             bump=int(info[2]), rounds=int(info[3]), dependent=int(info[4]),
+                                             spikes=int(info[5])))
 
     def basis(self, A, basis, status, max_etas=100):
         """ipx::Basis as far as Maxvolume needs it, over [A I] (A: Csc m x n)"""

@@ -57,6 +57,34 @@ def test_lu_vs_oracle_and_contract(ctx, oracle, kw):
     assert check_contract(G, F) < 1e-12
 
 
+def test_lu_torn_bump_vs_oracle(kkt, oracle, monkeypatch):
+    """a bump beyond the dense limit: spikes torn off, carried through the row singleton pivots on the device
+    (forward substitution, 64 spikes at a time) -- the same spikes, pivot order and VALUES as the CPU restatement,
+    bit for bit; the contract; at 60000 rows the planted chain structure leaves a bump of most of the matrix"""
+    from test_lu_oracle import TORN
+    for kw in TORN:
+        kw = dict(kw)
+        limit = kw.pop("limit")
+        G = synth.disturbed_basis_matrix(seed=5, **kw)
+        dim = G["dim"]
+        monkeypatch.setenv("IPXK_LU_BUMP_MAX", str(limit))
+        c = kkt.KktContext(synth.synthetic_lp(8, 12, 2, 1))
+        F = c.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
+        Fo = oracle.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1, bump_limit=limit)
+        assert (F["col_singletons"], F["row_singletons"], F["bump"], F["num_dependent"], F["spikes"], F["rounds"]) == \
+            (Fo["info"]["col_singletons"], Fo["info"]["row_singletons"], Fo["info"]["bump"], Fo["info"]["dependent"],
+             Fo["info"]["spikes"], Fo["info"]["rounds"]), kw
+        assert F["spikes"] > 0
+        same_factors(F, Fo)
+        if dim <= 3000:
+            assert check_contract(G, F) < 1e-10
+        # a limit below the number of spikes: refused, loudly
+        monkeypatch.setenv("IPXK_LU_BUMP_MAX", str(max(1, F["spikes"] // 2)))
+        with pytest.raises(RuntimeError, match="spikes"):
+            c.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
+        c.close()
+
+
 @pytest.mark.parametrize("kw", [CASES[0], CASES[3], BIG[1]], ids=["plain", "singular", "big"])
 def test_lu_under_the_reference(ctx, ref, kw):
     G = synth.lp_like_basis_matrix(seed=5, **kw)
@@ -99,9 +127,14 @@ def test_lu_unsorted_strict_and_limits(ctx, oracle, kkt, monkeypatch):
         at = len(big_i)
     end = begin + np.diff(Bp)
     same_factors(ctx.lu_factorize(400, begin, end, np.array(big_i), np.array(big_x)), F)
-    # errors: bump over the limit, bad index, bad tolerance
+    # a bump over the limit is torn (same factors as the restatement with that limit); refused when even the
+    # spikes exceed it; bad index, bad tolerance
     monkeypatch.setenv("IPXK_LU_BUMP_MAX", "24")
-    with pytest.raises(kkt.KktError, match="bump of 25 rows"):
+    Ft = ctx.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx)
+    assert 0 < Ft["spikes"] <= 24
+    same_factors(Ft, oracle.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx, bump_limit=24))
+    monkeypatch.setenv("IPXK_LU_BUMP_MAX", "2")
+    with pytest.raises(kkt.KktError, match="spikes"):
         ctx.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx)
     monkeypatch.delenv("IPXK_LU_BUMP_MAX")
     bad = Bi.copy()

@@ -91,6 +91,45 @@ def test_oracle_lu_unsorted_columns_and_strict_tolerance(oracle, ref):
 
 
 def test_bump_limit(oracle):
+    """a bump beyond the limit is torn (spikes set aside until the rounds get through); refused only when the
+    spikes themselves exceed the limit"""
     G = synth.lp_like_basis_matrix(dim=120, bump=30, seed=2)
-    assert oracle.lu_factorize(120, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], bump_limit=29) is None
-    assert oracle.lu_factorize(120, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], bump_limit=30) is not None
+    F = oracle.lu_factorize(120, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], bump_limit=30)
+    assert F is not None and F["info"]["spikes"] == 0 and F["info"]["bump"] == 30
+    assert oracle.lu_factorize(120, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], bump_limit=3) is None
+    F = oracle.lu_factorize(120, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], bump_limit=29)   # a dense 30 x 30 bump: 29 spikes
+    assert F is not None and 0 < F["info"]["spikes"] <= 29 and check_contract(G, F) < 1e-12
+
+
+TORN = [dict(dim=300, num_exchanged=6, limit=30, bump=20), dict(dim=3000, num_exchanged=10, limit=20, bump=20),
+        dict(dim=3000, num_exchanged=25, limit=64, bump=10, offdiag=3), dict(dim=2000, num_exchanged=12, limit=40, bump=30, window=5),
+        dict(dim=60000, num_exchanged=40, limit=2048, bump=100, offdiag=3)]
+
+
+@pytest.mark.parametrize("kw", TORN, ids=[str(i) for i in range(len(TORN))])
+def test_oracle_lu_torn_bump_under_the_reference(oracle, ref, kw):
+    """bases after a number of exchanges (a few columns replaced by random ones): the singleton rounds stall on a
+    bump far beyond the dense limit; with the spikes torn off, the factorization satisfies the contract, the
+    reference's LuFactorization::Factorize calls it stable and its ForrestTomlin solves with it"""
+    kw = dict(kw)
+    limit = kw.pop("limit")
+    G = synth.disturbed_basis_matrix(seed=5, **kw)
+    dim = G["dim"]
+    plain = oracle.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], bump_limit=-1) if dim <= 3000 else None
+    F = oracle.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], bump_limit=limit)
+    assert F is not None
+    inf = F["info"]
+    assert 0 < inf["spikes"] <= limit and inf["bump"] == inf["spikes"] and inf["dependent"] == 0
+    assert inf["col_singletons"] + inf["row_singletons"] + inf["bump"] == dim
+    if plain is not None:
+        assert plain["info"]["bump"] > limit and inf["spikes"] < plain["info"]["bump"] / 3
+    R = ref.lu(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], F)
+    assert R.stability < 1e-12 and R.flag == 0
+    B = sp.csc_matrix((G["Bx"].copy(), G["Bi"].copy(), G["Bp"].copy()), shape=(dim, dim))
+    x = np.random.default_rng(0).standard_normal(dim)
+    for trans in (False, True):
+        y = R.solve_dense(x, trans)
+        r = (B.T if trans else B) @ y - x
+        assert np.abs(r).max() <= 1e-8 * (1 + np.abs(y).max())
+    if dim <= 3000:
+        assert check_contract(G, F) < 1e-10
