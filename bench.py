@@ -282,7 +282,7 @@ def main():
     # rocprofv3 --pmc runs; bench.py cannot collect counters on itself)
     layouts, tuned_us = ctx.spmv_layout()
     kernel_names = {"phased": "spmv_phased_kernel", "sliced": "spmv_sliced_tile_kernel+spmv_sliced_combine_kernel",
-                    "fused": "spmv_sliced_tile_kernel<fused>"}
+                    "fused": "spmv_sliced_tile_kernel<fused>", "sorted": "spmv_sorted_tile_kernel+spmv_sliced_combine_kernel"}
     traffic, traffic_note = pmc_traffic("pmc_traffic.json", "traffic_bytes_per_apply",
                                         "C3 m=%d n=%d nnz=%d" % (m, n, nnz) if world == 1 else None, layouts)
 

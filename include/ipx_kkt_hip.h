@@ -483,12 +483,15 @@ ipxint ipxk_normal_apply_bytes(const ipxk_context* ctx);
 /* Which device layout the two sparse products of NormalMatrix::_Apply
  * (normal_matrix.cc:45-126) use on this model: layout[0] for t = W.*(A'y),
  * layout[1] for lhs = A t; 0 = phased (time-tiled), 1 = XCD-sliced tiles,
- * 2 = fused tiles (one slice, epilogue in the tile kernel).  The sliced layout is
+ * 2 = fused tiles (one slice, epilogue in the tile kernel), 3 = sorted
+ * sub-tiles (the sliced layout's slices with the gathers of a tile issued in
+ * address order; same partial sums as 1, bit for bit).  The sliced layouts are
  * chosen by a property of the matrix (x larger than an XCD's L2 and gathers that
- * spread over the slices); otherwise a timing at ipxk_create picks the faster of
- * phased and fused, which are bit-identical (IPXK_SPMV_LAYOUT=phased|sliced|fused
- * overrides); us[6] receives the measured microseconds
- * {pass1 phased, sliced, fused, pass2 phased, sliced, fused} (0 = not timed). */
+ * spread over the slices), between 1 and 3 the faster at ipxk_create; otherwise a
+ * timing picks the faster of phased and fused, which are bit-identical
+ * (IPXK_SPMV_LAYOUT=phased|sliced|fused|sorted overrides); us[6] receives the
+ * measured microseconds {pass1 phased, sliced (or sorted, if that was kept), fused,
+ * pass2 phased, sliced (sorted), fused} (0 = not timed). */
 int ipxk_spmv_layout(const ipxk_context* ctx, int layout[2], double us[6]);
 /* plain device allocation helpers so that callers without torch can hold
  * resident vectors */

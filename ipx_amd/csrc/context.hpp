@@ -64,6 +64,8 @@ struct Context {
     GatherMatrix AdCols;                // k rows x m: computes Ad' u
     GatherMatrix AdRows;                // m rows x k: computes Ad w
     DevBuf<double> chol, chol_inv, smw_work, smw_u, Wnodense;   // chol_inv: inverted 64 x 64 diagonal blocks (k > 64)
+    DevBuf<double> schur_panel, schur_part;     // blocked Schur assembly: dense copy of the dense columns, per-slab partial S
+    DevBuf<int> schur_colptr;
     DevBuf<int> chol_info;
     DevBuf<unsigned char> dense_mask;   // n, 1 for dense columns
 

@@ -205,16 +205,19 @@ struct SlicedMatrix {
 // instructions of a CU) that fall on the same 128-byte line share a request, so a tile whose entries are sorted by
 // gathered index needs only as many requests as it touches lines: 0.63 of its entries when it holds as many
 // entries as its slice has lines (72 instead of 88 us), 0.43 at two entries per line (60 us).  Layout:
-//   * row blocks of RB = 1024 * RPT rows (8192 at C3), slices as in the sliced layout, every slice cut into `nsub`
+//   * row blocks of RB = 256 * RPT rows (8192 at C3), slices as in the sliced layout, every slice cut into `nsub`
 //     sub-slices; sub-tile (rb, s, h) holds the entries of the block in sub-slice h of slice s SORTED by gathered
 //     index, at most kSortedMaxSub of them;
 //   * an entry is one 32-bit word (slot << 18 | index - first index of the slice) + its value: slot = the place of
 //     the entry when the sub-tile's entries are listed row by row in storage order -- the product goes to that LDS
 //     slot, and after one barrier every thread adds up the products of its RPT consecutive rows from consecutive
 //     slots, continuing the running sums of the previous sub-tile: a row's sum is formed slice by slice in storage
-//     order exactly as in the sliced layout (bit-identical partial sums), one workgroup of 1024 threads per (rb, s);
+//     order exactly as in the sliced layout (bit-identical partial sums), one workgroup per (rb, s) -- few, large
+//     workgroups that stream their entries batch after batch without a barrier in between (measured: two
+//     workgroups of 1024 threads per CU that process a sub-tile in one batch between two barriers lose more to
+//     the exposed load -> gather -> stage chain than the sorted gathers win);
 //   * partial vectors and the combine kernel are the sliced layout's.
-constexpr int kSortedThreads = 1024;
+constexpr int kSortedThreads = 256;
 constexpr int kSortedMaxSub = 8192;    // entries per sub-tile: 13 bits of slot
 constexpr int kSortedOffBits = 18;     // index inside a slice of at most 2 MiB of x
 struct SortedView {

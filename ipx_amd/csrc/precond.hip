@@ -55,6 +55,75 @@ __global__ void column_scatter_kernel(int p0, int p1, const int* __restrict__ id
     }
 }
 
+// ---- blocked Schur complement ------------------------------------------------------------------
+// S = Ad' inv(E) Ad for ALL pairs of dense columns in one pass over a dense copy of Ad (m x k, column major):
+// a 64 x 64 tile of S per workgroup and slab of rows, partial tiles added in slab order afterwards (fixed order,
+// no atomics).  The reference forms S one column at a time with a scatter and k sparse dot products
+// (src/diagonal_precond.cc:68-85); every term is the same product a_ri * (a_rj / e_r), only the order of the sum
+// differs (by slabs) -- rounding-level differences, like LAPACK's blocked dpotrf that follows.
+__global__ void dense_panel_fill_kernel(int k, int64_t m, const int* __restrict__ colptr, const int* __restrict__ idx,
+                                        const double* __restrict__ val, double* __restrict__ P) {
+    const int kk = blockIdx.y;
+    for (int p = colptr[kk] + blockIdx.x * blockDim.x + threadIdx.x; p < colptr[kk + 1]; p += gridDim.x * blockDim.x)
+        P[(size_t)kk * m + idx[p]] = val[p];
+}
+constexpr int kSchurTile = 64, kSchurRows = 32;
+__global__ __launch_bounds__(kBlock) void schur_gemm_kernel(int k, int64_t m, int64_t rows_per_slab, const double* __restrict__ P,
+                                                            const double* __restrict__ diag, double* __restrict__ Spart) {
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (ti < tj) return;                                  // lower triangle of tiles
+    __shared__ double As[kSchurRows][kSchurTile + 1], Bs[kSchurRows][kSchurTile + 1];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;     // thread -> 4 x 4 outputs (rows 4*ty.., cols 4*tx..)
+    const int64_t r0 = (int64_t)blockIdx.z * rows_per_slab, r1 = std::min<int64_t>(m, r0 + rows_per_slab);
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
+    const int lr = tid & (kSchurRows - 1), lc0 = tid / kSchurRows;  // loader: row lr of the chunk, columns lc0, lc0 + 8, ...
+    for (int64_t r = r0; r < r1; r += kSchurRows) {
+        const int64_t rr = r + lr;
+        const double d = rr < r1 ? diag[rr] : 1.0;
+#pragma unroll
+        for (int c = lc0; c < kSchurTile; c += kBlock / kSchurRows) {
+            const int ci = ti * kSchurTile + c, cj = tj * kSchurTile + c;
+            As[lr][c] = (rr < r1 && ci < k) ? P[(size_t)ci * m + rr] : 0.0;
+            Bs[lr][c] = (rr < r1 && cj < k) ? P[(size_t)cj * m + rr] / d : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int q = 0; q < kSchurRows; q++) {
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { a[t] = As[q][4 * ty + t]; b[t] = Bs[q][4 * tx + t]; }
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+#pragma unroll
+                for (int y = 0; y < 4; y++) acc[x][y] += a[x] * b[y];
+        }
+        __syncthreads();
+    }
+    double* out = Spart + (size_t)blockIdx.z * k * k;
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const int i = ti * kSchurTile + 4 * ty + x, j = tj * kSchurTile + 4 * tx + y;
+            if (i < k && j < k && i >= j) out[i + (size_t)j * k] = acc[x][y];
+        }
+}
+// S[i,j] = S[j,i] = sum over the slabs, in slab order
+__global__ void schur_reduce_kernel(int k, int nslabs, const double* __restrict__ Spart, double* __restrict__ S) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)k * k; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e % k), j = (int)(e / k);
+        if (i < j) continue;
+        double sum = 0.0;
+        for (int z = 0; z < nslabs; z++) sum += Spart[(size_t)z * k * k + e];
+        S[i + (size_t)j * k] = sum;
+        S[j + (size_t)i * k] = sum;
+    }
+}
+
 // S[c,c] += 1/W[dense_col[c]]                                     (:82-83)
 __global__ void schur_add_diag_kernel(int k, const int* __restrict__ dense_col,
                                       const double* __restrict__ W, double* __restrict__ S) {
@@ -363,7 +432,31 @@ void diag_factorize_dev(Context* c, const double* W, bool precond_dense_cols, ip
         for (int kk = 0; kk < k; kk++) dc[kk] = (int)c->dense_cols[kk];
         DevBuf<int> dcols;
         dcols.upload(dc, s);
-        for (int kk = 0; kk < k; kk++) {
+        const bool blocked = (int64_t)m * k * 8 <= (int64_t(8) << 30) && !(getenv("IPXK_SCHUR_BLOCKED") && getenv("IPXK_SCHUR_BLOCKED")[0] == '0');
+        if (blocked) {
+            // all k^2 entries in one pass over a dense copy of the dense columns
+            DevBuf<double>& P = c->schur_panel;
+            P.ensure((size_t)m * k);
+            IPXK_HIP(hipMemsetAsync(P.get(), 0, (size_t)m * k * sizeof(double), s));
+            if (c->schur_colptr.size() != (size_t)k + 1) {
+                c->schur_colptr.upload(c->AdCols.h_plain_ptr, s);
+                IPXK_HIP(hipStreamSynchronize(s));
+            }
+            hipLaunchKernelGGL(dense_panel_fill_kernel, dim3(64, k), dim3(kBlock), 0, s, k, m, c->schur_colptr.get(),
+                               c->AdCols.plain_idx.get(), c->AdCols.plain_val.get(), P.get());
+            const int nt = (k + kSchurTile - 1) / kSchurTile;
+            const int64_t ntri = (int64_t)nt * (nt + 1) / 2;
+            int nslabs = (int)std::max<int64_t>(1, std::min<int64_t>(256, 2048 / ntri));
+            nslabs = (int)std::min<int64_t>(nslabs, std::max<int64_t>(1, m / 256));
+            const int64_t per = ((m + nslabs - 1) / nslabs + kSchurRows - 1) / kSchurRows * kSchurRows;
+            nslabs = (int)((m + per - 1) / per);
+            c->schur_part.ensure((size_t)nslabs * k * k);
+            hipLaunchKernelGGL(schur_gemm_kernel, dim3(nt, nt, nslabs), dim3(kBlock), 0, s, k, m, per, P.get(), c->diagonal.get(),
+                               c->schur_part.get());
+            hipLaunchKernelGGL(schur_reduce_kernel, dim3(vec_grid((int64_t)k * k)), dim3(kBlock), 0, s, k, nslabs, c->schur_part.get(),
+                               c->chol.get());
+        }
+        for (int kk = 0; kk < k && !blocked; kk++) {
             const int p0 = c->AdCols.h_plain_ptr[kk], p1 = c->AdCols.h_plain_ptr[kk + 1];
             const int g = vec_grid(p1 - p0);
             hipLaunchKernelGGL(column_scatter_kernel, dim3(g), dim3(kBlock), 0, s, p0, p1,

@@ -268,6 +268,9 @@ void GatherMatrix::build_sliced(const ipxint* hptr, const ipxint* hidx, const do
     // rows per tile: as many as fit the LDS staging buffer (a matrix whose rows concentrate in one
     // slice, e.g. a banded one, needs smaller tiles than a uniformly random one)
     int R = kSlicedRows, nrb = 0, max_tile = 0;
+    // small matrices: enough tiles to give every CU several workgroups (C2, 50k x 100k: 98 tiles of 1024 rows kept
+    // 98 of the 256 CUs busy with 8192 entries each)
+    while (R > kBlock && (nrows + R - 1) / R * (int64_t)ns < 2048) R /= 2;
     int64_t ntiles = 0;
     std::vector<unsigned> tptr;
     std::vector<unsigned char> cnt;
@@ -355,12 +358,12 @@ void GatherMatrix::build_sorted(const ipxint* hptr, const ipxint* hidx, const do
     const int64_t half = (slice / nsub + 15) / 16 * 16;
     const std::vector<unsigned char>& rlong = h_row_long;
     const bool verbose = getenv("IPXK_VERBOSE") != nullptr;
-    int RB = 8 * kSortedThreads, nrb = 0, max_sub = 0;
+    int RB = 32 * kSortedThreads, nrb = 0, max_sub = 0;
     int64_t nsubs = 0, nshort = 0;
     std::vector<unsigned> sptr;
     std::vector<unsigned char> cnt;
     for (;; RB /= 2) {
-        if (RB < kSortedThreads) {
+        if (RB < 4 * kSortedThreads) {
             if (verbose) fprintf(stderr, "ipxk: sorted layout not used for %d x %d: a sub-tile of %d rows holds %d entries\n", nrows, ncols, 2 * RB, max_sub);
             return;
         }

@@ -435,6 +435,121 @@ __global__ __launch_bounds__(kBlock) void spmv_sliced_tile_kernel(SlicedView M, 
     }
 }
 
+// ---- sorted sub-tiles (internal.hpp, SortedMatrix) ---------------------------------------------
+// One workgroup of 256 threads per (row block, slice).  For every sub-tile the workgroup streams the entries in
+// batches of 2048 (packed word + value, coalesced, non-temporal, 8 per thread in flight), gathers x at ASCENDING
+// addresses (neighbouring lanes share lines: fewer L1->L2 requests than entries) and writes each product to its LDS
+// slot (the entry's place in row order) -- batch after batch without a barrier, slots are distinct; after ONE
+// barrier every thread adds the products of its RPT consecutive rows from consecutive slots to its running sums,
+// which pass from one sub-tile to the next: a row's partial sum is formed in storage order exactly as in the sliced
+// layout.  The partial sums leave through LDS so that the store is coalesced.
+template <int RPT, class Prod, bool MASKED = false>
+__global__ __launch_bounds__(kSortedThreads, kSortedThreads / 128) void spmv_sorted_tile_kernel(SortedView M, const double* __restrict__ x, const int* done) {
+    if (done && *done) return;
+    extern __shared__ double so_prod[];
+    __shared__ int wave_sum[kSortedThreads / 64];
+    static_assert(RPT == 4 || RPT == 8 || RPT == 16 || RPT == 32, "rows per thread");
+    constexpr int U = 8;
+    constexpr int kBatch = kSortedThreads * U;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x, s = tile % M.nslices, rb = tile / M.nslices;
+    const double* __restrict__ xs = x + (size_t)s * M.slice_elems;
+    constexpr int RB = kSortedThreads * RPT;
+    double acc[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; q++) acc[q] = 0.0;
+    // Software pipeline over the batches of ALL sub-tiles of the tile: while the gathers of a batch are in flight,
+    // the stream loads of the next batch (of this or the next sub-tile) are issued, so that the load -> gather ->
+    // stage chain of a workgroup overlaps with itself (few, large workgroups: 8 waves per CU).
+    const int sub0 = tile * M.nsub;
+    unsigned pk[U];
+    double v[U];
+    auto stream = [&](int sub, int base) {         // (pk, v) of the batch starting at `base` of sub-tile `sub`
+        const unsigned e0 = M.sub_ptr[sub];
+        const int ne = (int)(M.sub_ptr[sub + 1] - e0);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = min(base + u * kSortedThreads + tid, max(ne - 1, 0));
+            pk[u] = __builtin_nontemporal_load(M.pack + e0 + i);
+            v[u] = __builtin_nontemporal_load(M.val + e0 + i);
+        }
+    };
+    stream(sub0, 0);
+    for (int h = 0; h < M.nsub; h++) {
+        const int sub = sub0 + h;
+        const int ne = (int)(M.sub_ptr[sub + 1] - M.sub_ptr[sub]);
+        // my RPT row counts: RPT bytes (16-byte loads)
+        unsigned cw[RPT / 4];
+        {
+            const unsigned* cbase = reinterpret_cast<const unsigned*>(M.cnt + (size_t)sub * RB) + (size_t)tid * (RPT / 4);
+#pragma unroll
+            for (int q = 0; q < RPT / 4; q++) cw[q] = cbase[q];
+        }
+        for (int base = 0; base < ne || base == 0; base += kBatch) {
+            double xg[U];
+            unsigned slot[U];
+            double vv[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const unsigned off = pk[u] & ((1u << kSortedOffBits) - 1u);
+                slot[u] = pk[u] >> kSortedOffBits;
+                vv[u] = v[u];
+                if (MASKED) xg[u] = v[u] != 0.0 ? xs[off] : 0.0;
+                else xg[u] = xs[off];
+            }
+            // next batch: of this sub-tile, else the first one of the next sub-tile
+            if (base + kBatch < ne) stream(sub, base + kBatch);
+            else if (h + 1 < M.nsub) stream(sub + 1, 0);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = base + u * kSortedThreads + tid;
+                if (i < ne) so_prod[lds_slot((int)slot[u])] = Prod::prod(xg[u], vv[u]);
+            }
+        }
+        // first slot of my rows: exclusive scan of the per-thread entry counts over the workgroup
+        int mine = 0;
+#pragma unroll
+        for (int q = 0; q < RPT / 4; q++) mine += (int)((cw[q] & 255u) + ((cw[q] >> 8) & 255u) + ((cw[q] >> 16) & 255u) + (cw[q] >> 24));
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int nb = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += nb;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        int p = incl - mine;
+        for (int w = 0; w < wave; w++) p += wave_sum[w];
+        // first product of every row with independent LDS reads, the rest of a row (rare) one by one
+        double first[RPT];
+        int p0[RPT];
+#pragma unroll
+        for (int q = 0; q < RPT; q++) {
+            const int cq = (int)((cw[q / 4] >> (8 * (q & 3))) & 255u);
+            p0[q] = p;
+            first[q] = cq > 0 ? so_prod[lds_slot(p)] : 0.0;
+            p += cq;
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; q++) {
+            const int cq = (int)((cw[q / 4] >> (8 * (q & 3))) & 255u);
+            if (cq > 0) acc[q] += first[q];
+            for (int kk = 1; kk < cq; kk++) acc[q] += so_prod[lds_slot(p0[q] + kk)];
+        }
+        __syncthreads();                  // the staging buffer and wave_sum are reused by the next sub-tile
+    }
+    // coalesced store of the RB partial sums: through LDS (thread t holds rows t*RPT .. t*RPT + RPT - 1)
+#pragma unroll
+    for (int q = 0; q < RPT; q++) so_prod[lds_slot(tid * RPT + q)] = acc[q];
+    __syncthreads();
+    double* dst = M.partial + (size_t)s * M.nrows_pad + (size_t)rb * RB;
+#pragma unroll
+    for (int q = 0; q < RPT; q += 2) {
+        const int r = (q / 2) * (2 * kSortedThreads) + 2 * tid;
+        reinterpret_cast<double2*>(dst + r)[0] = make_double2(so_prod[lds_slot(r)], so_prod[lds_slot(r + 1)]);
+    }
+}
+
 // out[r] = finish(init(r) (+|-) partial[0][r] (+|-) partial[1][r] ...), slices in ascending order
 template <class Epi>
 __global__ __launch_bounds__(kBlock) void spmv_sliced_combine_kernel(SlicedView M, Epi epi, double* dot_partials,
@@ -462,6 +577,28 @@ template <class Epi, bool MASKED = false, bool COMPACT = false>
 inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi& epi, double* dot_partials,
                                const int* done, hipStream_t s) {
     static_assert(!(MASKED && COMPACT), "the compacted copy needs no mask");
+    if (M.use_sorted && !MASKED && !COMPACT) {
+        // sorted sub-tiles + the sliced layout's combine on their partial vectors
+        const SortedView W = M.sorted_view();
+        const int lds_elems = std::max(M.sorted.max_sub, W.RB);          // staging of a sub-tile; of the RB partial sums at the end
+        const size_t lds = (size_t)(lds_elems + lds_elems / 32 + 1) * sizeof(double);
+        const dim3 grid(W.nrb * W.nslices), block(kSortedThreads);
+        switch (W.RB / kSortedThreads) {
+            case 32: hipLaunchKernelGGL((spmv_sorted_tile_kernel<32, Epi>), grid, block, lds, s, W, x, done); break;
+            case 16: hipLaunchKernelGGL((spmv_sorted_tile_kernel<16, Epi>), grid, block, lds, s, W, x, done); break;
+            case 8: hipLaunchKernelGGL((spmv_sorted_tile_kernel<8, Epi>), grid, block, lds, s, W, x, done); break;
+            default: hipLaunchKernelGGL((spmv_sorted_tile_kernel<4, Epi>), grid, block, lds, s, W, x, done); break;
+        }
+        SlicedView C = M.sliced_view(0);
+        C.nrows_pad = W.nrows_pad; C.partial = W.partial;
+        hipLaunchKernelGGL(spmv_sliced_combine_kernel<Epi>, dim3(M.combine_grid()), dim3(kBlock), 0, s, C, epi, dot_partials, done);
+        if (M.nlong > 0) {
+            const GatherView G = M.view(false);
+            hipLaunchKernelGGL(spmv_long_kernel<Epi>, dim3(M.nseg), dim3(kBlock), 0, s, G, x, done);
+            hipLaunchKernelGGL(spmv_long_fixup_kernel<Epi>, dim3(1), dim3(kBlock), 0, s, G, epi, dot_partials, M.combine_grid(), done);
+        }
+        return;
+    }
     const SlicedView V = M.sliced_view(COMPACT ? 2 : MASKED ? 1 : 0);
     const size_t lds = (size_t)(M.sliced.max_tile + M.sliced.max_tile / 32 + 1) * sizeof(double);
     const dim3 grid(V.nrb * V.nslices), block(kBlock);
