@@ -485,13 +485,15 @@ ipxint ipxk_normal_apply_bytes(const ipxk_context* ctx);
  * layout[1] for lhs = A t; 0 = phased (time-tiled), 1 = XCD-sliced tiles,
  * 2 = fused tiles (one slice, epilogue in the tile kernel), 3 = sorted
  * sub-tiles (the sliced layout's slices with the gathers of a tile issued in
- * address order; same partial sums as 1, bit for bit).  The sliced layouts are
+ * address order; same partial sums as 1, bit for bit), 4 = sorted fused tiles
+ * (one slice, gathers in address order, epilogue in the tile kernel: bit-identical
+ * to 0 and 2, for matrices whose gathers have locality).  The sliced layouts are
  * chosen by a property of the matrix (x larger than an XCD's L2 and gathers that
  * spread over the slices), between 1 and 3 the faster at ipxk_create; otherwise a
- * timing picks the faster of phased and fused, which are bit-identical
- * (IPXK_SPMV_LAYOUT=phased|sliced|fused|sorted overrides); us[6] receives the
- * measured microseconds {pass1 phased, sliced (or sorted, if that was kept), fused,
- * pass2 phased, sliced (sorted), fused} (0 = not timed). */
+ * timing picks the fastest of phased, fused and sorted fused, which are
+ * bit-identical (IPXK_SPMV_LAYOUT=phased|sliced|fused|sorted|sortedfused overrides);
+ * us[6] receives the measured microseconds {pass1 phased, sliced (or sorted, if
+ * that was kept), fused (or sorted fused), pass2 likewise} (0 = not timed). */
 int ipxk_spmv_layout(const ipxk_context* ctx, int layout[2], double us[6]);
 /* plain device allocation helpers so that callers without torch can hold
  * resident vectors */

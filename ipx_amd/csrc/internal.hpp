@@ -220,8 +220,15 @@ struct SlicedMatrix {
 constexpr int kSortedThreads = 256;
 constexpr int kSortedMaxSub = 8192;    // entries per sub-tile: 13 bits of slot
 constexpr int kSortedOffBits = 18;     // index inside a slice of at most 2 MiB of x
+//   * FUSED form (one slice = all of x, one sub-tile per row block; for matrices whose gathers have locality): the
+//     gathered index is stored relative to the tile's smallest index (`xmin`, the tile's window must span less
+//     than 2^18 entries), the thread starts each row from the epilogue's initial value, adds the row's products
+//     in storage order and applies the epilogue itself -- bit-identical to the phased and fused layouts; a banded
+//     tile touches a few hundred lines with thousands of entries, so almost all its gathers share requests.
 struct SortedView {
     int nrows, nrows_pad, nslices, nsub, nrb, RB, slice_elems;
+    const int* xmin;                   // FUSED: [nrb] smallest gathered index of the tile; else nullptr
+    const unsigned char* row_long;     // FUSED: rows left to the long-row kernels, or nullptr
     const unsigned* sub_ptr;           // [nrb*nslices*nsub + 1]
     const unsigned char* cnt;          // [nrb*nslices*nsub][RB] entries per row of the sub-tile
     const unsigned* pack;
@@ -234,6 +241,8 @@ struct SortedMatrix {
     DevBuf<unsigned> sub_ptr, pack;
     DevBuf<unsigned char> cnt;
     DevBuf<double> val, partial;
+    bool fused = false;                // the FUSED form
+    DevBuf<int> xmin;
 };
 
 struct GatherMatrix {
@@ -264,6 +273,11 @@ struct GatherMatrix {
     SortedMatrix sorted;
     bool use_sorted = false;           // only with use_sliced and sliced.nslices > 1
     void build_sorted(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s);
+    // the FUSED form (independent of the sliced layout); use_sorted_fused: it is the layout in use
+    void build_sorted_fused(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s);
+    bool use_sorted_fused = false;
+    float tuned_us_sorted_fused = 0.f;
+    int sorted_fused_grid() const { return std::min(sorted.nrb, kMaxPartials); }
     SortedView sorted_view() const;
     float tuned_us_phased = 0.f, tuned_us_sliced = 0.f, tuned_us_fused = 0.f, tuned_us_sorted = 0.f;
     // ns_request: 0 = as many slices as x needs (>= 2), 1 = the fused single-slice variant
@@ -295,7 +309,7 @@ struct GatherMatrix {
     void compact_tiles(const double* weight, bool by_row, hipStream_t s);
     DevBuf<int> rowof;                  // row of every stored short entry (built on first use by mask_values(by_row))
     void mask_values(const double* weight, bool by_row, hipStream_t s);
-    // # dot partials a launch produces
+    // # dot partials a launch of the phased / sliced / fused layouts produces (the sorted-fused overlay: launch_spmv)
     int num_partials() const {
         const int extra = nlong > 0 ? 1 : 0;      // the long-row fix-up kernel adds one
         if (!use_sliced) return G + extra;

@@ -173,7 +173,13 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
     if (const char* e = getenv("IPXK_SPMV_LAYOUT")) layout = e;
     if (layout == "phased") return;
     use_sorted = false;
+    use_sorted_fused = false;
     sorted = SortedMatrix();
+    if (layout == "sortedfused") {
+        build_sorted_fused(hptr, hidx, hval, s);
+        use_sorted_fused = sorted.built;
+        return;
+    }
     if (layout == "sliced" || layout == "fused" || layout == "sorted") {
         build_sliced(hptr, hidx, hval, s, layout == "fused" ? 1 : 0);
         use_sliced = sliced.built;
@@ -219,6 +225,18 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
         if (spread) sliced = std::move(slicedm);
         else if (fusedm.built && tuned_us_fused < 0.95f * tuned_us_phased) sliced = std::move(fusedm);
         use_sliced = sliced.built;
+        if (!spread && !(getenv("IPXK_SPMV_SORTED") && getenv("IPXK_SPMV_SORTED")[0] == '0')) {
+            // gathers with locality: the fused tiles with the gathers in address order (bit-identical to the phased
+            // and fused layouts, so a timing may choose); kept if it beats what the timing chose so far
+            // (an overlay: masked products -- the basis path's N N' -- keep using the layout chosen above)
+            build_sorted_fused(hptr, hidx, hval, s);
+            if (sorted.built) {
+                use_sorted_fused = true;
+                tuned_us_sorted_fused = time_current();
+                const float best = use_sliced ? tuned_us_fused : tuned_us_phased;
+                if (!(tuned_us_sorted_fused < 0.95f * best)) { use_sorted_fused = false; sorted = SortedMatrix(); }
+            }
+        }
         if (spread && !(getenv("IPXK_SPMV_SORTED") && getenv("IPXK_SPMV_SORTED")[0] == '0')) {
             // the same slices with the gathers of a tile in address order: bit-identical partial sums, so the faster
             // of the two is kept (the sliced arrays stay: the basis path compacts them)
@@ -237,7 +255,8 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
         if (getenv("IPXK_VERBOSE"))
             fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld: phased %.1f us, fused %.1f us, sliced %.1f us, sorted %.1f us (fullest-slice share %.2f) -> %s\n",
                     nrows, ncols, (long long)nnz, tuned_us_phased, tuned_us_fused, tuned_us_sliced, tuned_us_sorted, share,
-                    !use_sliced ? "phased" : sliced.nslices == 1 ? "fused" : use_sorted ? "sorted" : "sliced");
+                    use_sorted_fused ? "sorted-fused" : !use_sliced ? "phased" : sliced.nslices == 1 ? "fused" : use_sorted ? "sorted" : "sliced");
+        if (getenv("IPXK_VERBOSE") && tuned_us_sorted_fused > 0.f) fprintf(stderr, "ipxk:   sorted-fused %.1f us\n", tuned_us_sorted_fused);
     }
     IPXK_HIP(hipEventDestroy(e0));
     IPXK_HIP(hipEventDestroy(e1));
@@ -432,8 +451,78 @@ void GatherMatrix::build_sorted(const ipxint* hptr, const ipxint* hidx, const do
     sorted.built = true;
 }
 
+// FUSED sorted tiles (internal.hpp): one slice, the epilogue in the tile kernel.
+void GatherMatrix::build_sorted_fused(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s) {
+    sorted = SortedMatrix();
+    if (nrows == 0 || nnz == 0 || ncols == 0) return;
+    const std::vector<unsigned char>& rlong = h_row_long;
+    int RB = 32 * kSortedThreads, nrb = 0, max_sub = 0;
+    int64_t nshort = 0;
+    std::vector<unsigned> sptr;
+    std::vector<unsigned char> cnt;
+    for (;; RB /= 2) {
+        if (RB < kSortedThreads) return;
+        nrb = (nrows + RB - 1) / RB;
+        if (RB > kSortedThreads && nrb < 1024) continue;          // enough tiles to fill the chip
+        sptr.assign((size_t)nrb + 1, 0);
+        cnt.assign((size_t)nrb * RB, 0);
+        bool ok = true;
+        for (int r = 0; r < nrows && ok; r++) {
+            if (!rlong.empty() && rlong[r]) continue;
+            const int64_t len = hptr[r + 1] - hptr[r];
+            if (len > 255) { ok = false; break; }
+            cnt[(size_t)(r / RB) * RB + r % RB] = (unsigned char)len;
+            sptr[r / RB + 1] += (unsigned)len;
+        }
+        if (!ok) return;
+        max_sub = 0;
+        for (int t = 0; t < nrb; t++) { max_sub = std::max(max_sub, (int)sptr[t + 1]); sptr[t + 1] += sptr[t]; }
+        nshort = sptr[nrb];
+        if (max_sub <= kSortedMaxSub) break;
+    }
+    if (nshort == 0) return;
+    std::vector<int> xmin((size_t)nrb, 0);
+    std::vector<unsigned> pk((size_t)nshort);
+    std::vector<double> tv((size_t)nshort);
+    std::vector<std::pair<ipxint, std::pair<unsigned, double>>> tmp;    // (index, (slot, value))
+    for (int t = 0; t < nrb; t++) {
+        tmp.clear();
+        const int r1 = std::min(nrows, (t + 1) * RB);
+        ipxint lo = ncols, hi = -1;
+        for (int r = t * RB; r < r1; r++) {
+            if (!rlong.empty() && rlong[r]) continue;
+            for (ipxint p = hptr[r]; p < hptr[r + 1]; p++) {
+                tmp.push_back({hidx[p], {(unsigned)tmp.size(), hval[p]}});
+                lo = std::min(lo, hidx[p]); hi = std::max(hi, hidx[p]);
+            }
+        }
+        if (tmp.empty()) continue;
+        if (hi - lo >= (ipxint(1) << kSortedOffBits)) return;     // the tile's window of x is too wide: no locality to use
+        xmin[t] = (int)lo;
+        std::sort(tmp.begin(), tmp.end(), [](const std::pair<ipxint, std::pair<unsigned, double>>& a,
+                                             const std::pair<ipxint, std::pair<unsigned, double>>& b) {
+            return a.first != b.first ? a.first < b.first : a.second.first < b.second.first;
+        });
+        for (size_t e = 0; e < tmp.size(); e++) {
+            pk[sptr[t] + e] = (tmp[e].second.first << kSortedOffBits) | (unsigned)(tmp[e].first - lo);
+            tv[sptr[t] + e] = tmp[e].second.second;
+        }
+    }
+    sorted.nslices = 1; sorted.nsub = 1; sorted.nrb = nrb; sorted.RB = RB; sorted.nrows_pad = nrb * RB;
+    sorted.max_sub = max_sub; sorted.slice_elems = 0; sorted.fused = true;
+    sorted.sub_ptr.upload(sptr, s);
+    sorted.cnt.upload(cnt, s);
+    sorted.pack.upload(pk, s);
+    sorted.val.upload(tv, s);
+    sorted.xmin.upload(xmin, s);
+    IPXK_HIP(hipStreamSynchronize(s));
+    sorted.built = true;
+}
+
 SortedView GatherMatrix::sorted_view() const {
     SortedView V;
+    V.xmin = sorted.fused ? sorted.xmin.get() : nullptr;
+    V.row_long = sorted.fused && nlong > 0 ? row_long.get() : nullptr;
     V.nrows = nrows; V.nrows_pad = sorted.nrows_pad; V.nslices = sorted.nslices; V.nsub = sorted.nsub; V.nrb = sorted.nrb;
     V.RB = sorted.RB; V.slice_elems = sorted.slice_elems;
     V.sub_ptr = sorted.sub_ptr.get(); V.cnt = sorted.cnt.get(); V.pack = sorted.pack.get(); V.val = sorted.val.get();

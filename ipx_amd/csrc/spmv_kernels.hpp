@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kSortedThreads, kSortedThreads / 128) void spmv_sor
     if (done && *done) return;
     extern __shared__ double so_prod[];
     __shared__ int wave_sum[kSortedThreads / 64];
-    static_assert(RPT == 4 || RPT == 8 || RPT == 16 || RPT == 32, "rows per thread");
+    static_assert(RPT == 4 || RPT == 8 || RPT == 16 || RPT == 32, "rows per thread (sliced form)");
     constexpr int U = 8;
     constexpr int kBatch = kSortedThreads * U;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -550,6 +550,117 @@ __global__ __launch_bounds__(kSortedThreads, kSortedThreads / 128) void spmv_sor
     }
 }
 
+// The FUSED form: one slice, one sub-tile per row block, gathered indices relative to the tile's smallest one; the
+// thread starts each row from epi.init, adds the row's products in storage order (the reference's order, bit for
+// bit as in the phased and fused layouts) and applies epi.finish itself.  A workgroup walks tiles blockIdx.x,
+// blockIdx.x + gridDim.x, ...; its dot partial goes to dot_partials[blockIdx.x].
+template <class Epi, int RPT>
+__global__ __launch_bounds__(kSortedThreads, kSortedThreads / 128) void spmv_sorted_fused_kernel(SortedView M, const double* __restrict__ x, Epi epi,
+                                                                                           double* dot_partials, const int* done) {
+    if (done && *done) return;
+    extern __shared__ double so_prod[];
+    __shared__ int wave_sum[kSortedThreads / 64];
+    __shared__ double red[kSortedThreads / 64 + 1];
+    static_assert(RPT == 1 || RPT == 2 || RPT == 4 || RPT == 8 || RPT == 16 || RPT == 32, "rows per thread");
+    constexpr int U = 8;
+    constexpr int kBatch = kSortedThreads * U;
+    constexpr int RB = kSortedThreads * RPT;
+    constexpr int CW = RPT >= 4 ? RPT / 4 : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double dotpart = 0.0;
+    unsigned pk[U];
+    double v[U];
+    auto stream = [&](int tile, int base) {
+        const unsigned e0 = M.sub_ptr[tile];
+        const int ne = (int)(M.sub_ptr[tile + 1] - e0);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = min(base + u * kSortedThreads + tid, max(ne - 1, 0));
+            pk[u] = __builtin_nontemporal_load(M.pack + e0 + i);
+            v[u] = __builtin_nontemporal_load(M.val + e0 + i);
+        }
+    };
+    if ((int)blockIdx.x < M.nrb) stream(blockIdx.x, 0);
+    for (int tile = blockIdx.x; tile < M.nrb; tile += gridDim.x) {
+        const int ne = (int)(M.sub_ptr[tile + 1] - M.sub_ptr[tile]);
+        const double* __restrict__ xs = x + M.xmin[tile];
+        unsigned cw[CW];
+        {
+            const unsigned char* cbase = M.cnt + (size_t)tile * RB + (size_t)tid * RPT;
+            if (RPT >= 4) {
+#pragma unroll
+                for (int q = 0; q < CW; q++) cw[q] = reinterpret_cast<const unsigned*>(cbase)[q];
+            } else if (RPT == 2) {
+                cw[0] = (unsigned)reinterpret_cast<const unsigned short*>(cbase)[0];
+            } else {
+                cw[0] = (unsigned)cbase[0];
+            }
+        }
+        for (int base = 0; base < ne || base == 0; base += kBatch) {
+            double xg[U], vv[U];
+            unsigned slot[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const unsigned off = pk[u] & ((1u << kSortedOffBits) - 1u);
+                slot[u] = pk[u] >> kSortedOffBits;
+                vv[u] = v[u];
+                xg[u] = xs[off];
+            }
+            if (base + kBatch < ne) stream(tile, base + kBatch);
+            else if (tile + (int)gridDim.x < M.nrb) stream(tile + gridDim.x, 0);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = base + u * kSortedThreads + tid;
+                if (i < ne) so_prod[lds_slot((int)slot[u])] = Epi::prod(xg[u], vv[u]);
+            }
+        }
+        int mine = 0;
+#pragma unroll
+        for (int q = 0; q < CW; q++) mine += (int)((cw[q] & 255u) + ((cw[q] >> 8) & 255u) + ((cw[q] >> 16) & 255u) + (cw[q] >> 24));
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int nb = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += nb;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        int p = incl - mine;
+        for (int w = 0; w < wave; w++) p += wave_sum[w];
+#pragma unroll
+        for (int q = 0; q < RPT; q++) {
+            const int cq = (int)((cw[q / 4] >> (8 * (q & 3))) & 255u);
+            const int r = tile * RB + tid * RPT + q;
+            if (r < M.nrows && !(M.row_long && M.row_long[r])) {
+                double acc = epi.init(r);
+                for (int kk = 0; kk < cq; kk += 4) {           // four LDS reads in flight, added strictly in storage order
+                    double t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) t[j] = so_prod[lds_slot(p + min(kk + j, cq - 1))];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (kk + j < cq) acc = Epi::kNeg ? acc - t[j] : acc + t[j];
+                }
+                epi.finish(r, acc, dotpart);
+            }
+            p += cq;
+        }
+        __syncthreads();                  // the staging buffer and wave_sum are reused by the next tile
+    }
+    if (dot_partials) {
+        double d = dotpart;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
+        if (lane == 0) red[wave] = d;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < kSortedThreads / 64; w++) t += red[w];
+            dot_partials[blockIdx.x] = t;
+        }
+    }
+}
+
 // out[r] = finish(init(r) (+|-) partial[0][r] (+|-) partial[1][r] ...), slices in ascending order
 template <class Epi>
 __global__ __launch_bounds__(kBlock) void spmv_sliced_combine_kernel(SlicedView M, Epi epi, double* dot_partials,
@@ -627,6 +738,25 @@ inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi
 template <class Epi, bool MASKED = false>
 inline int launch_spmv(const GatherMatrix& M, const double* x, const Epi& epi, double* dot_partials,
                        const int* done, hipStream_t s) {
+    if (M.use_sorted_fused && !MASKED) {
+        const SortedView W = M.sorted_view();
+        const size_t lds = (size_t)(M.sorted.max_sub + M.sorted.max_sub / 32 + 1) * sizeof(double);
+        const dim3 grid(M.sorted_fused_grid()), block(kSortedThreads);
+        switch (W.RB / kSortedThreads) {
+            case 32: hipLaunchKernelGGL((spmv_sorted_fused_kernel<Epi, 32>), grid, block, lds, s, W, x, epi, dot_partials, done); break;
+            case 16: hipLaunchKernelGGL((spmv_sorted_fused_kernel<Epi, 16>), grid, block, lds, s, W, x, epi, dot_partials, done); break;
+            case 8: hipLaunchKernelGGL((spmv_sorted_fused_kernel<Epi, 8>), grid, block, lds, s, W, x, epi, dot_partials, done); break;
+            case 4: hipLaunchKernelGGL((spmv_sorted_fused_kernel<Epi, 4>), grid, block, lds, s, W, x, epi, dot_partials, done); break;
+            case 2: hipLaunchKernelGGL((spmv_sorted_fused_kernel<Epi, 2>), grid, block, lds, s, W, x, epi, dot_partials, done); break;
+            default: hipLaunchKernelGGL((spmv_sorted_fused_kernel<Epi, 1>), grid, block, lds, s, W, x, epi, dot_partials, done); break;
+        }
+        if (M.nlong > 0) {
+            const GatherView G = M.view(false);
+            hipLaunchKernelGGL(spmv_long_kernel<Epi>, dim3(M.nseg), dim3(kBlock), 0, s, G, x, done);
+            hipLaunchKernelGGL(spmv_long_fixup_kernel<Epi>, dim3(1), dim3(kBlock), 0, s, G, epi, dot_partials, M.sorted_fused_grid(), done);
+        }
+        return dot_partials ? M.sorted_fused_grid() + (M.nlong > 0 ? 1 : 0) : 0;
+    }
     if (M.use_sliced) {
         if (MASKED && M.compact.valid) launch_spmv_sliced<Epi, false, true>(M, x, epi, dot_partials, done, s);
         else launch_spmv_sliced<Epi, MASKED>(M, x, epi, dot_partials, done, s);

@@ -2,7 +2,18 @@
 
 #include <cassert>
 
+#include <cstdlib>
+
 #include "sparse_matrix.h"
+#include "splitted_normal_matrix.h"
+#include "timer.h"
+
+// measurement aid (IPXK_TIME_CPU_PREPARE=1): seconds the reference's own SplittedNormalMatrix::Prepare takes on
+// the bases of this run -- the work KKTSolverBasis::_Factorize does for its CPU operator and this class discards
+static double g_cpu_prepare_seconds = 0.0;
+static long g_cpu_prepare_calls = 0;
+extern "C" double ipx_hip_cpu_prepare_seconds() { return g_cpu_prepare_seconds; }
+extern "C" long ipx_hip_cpu_prepare_calls() { return g_cpu_prepare_calls; }
 
 namespace ipx {
 
@@ -53,6 +64,14 @@ void KKTSolverBasisHip::_Factorize(Iterate* iterate, Info* info) {
     }
     for (Int p = 0; p < m; p++)
         basic[p] = basis_[p];
+    static const bool time_cpu_prepare = std::getenv("IPXK_TIME_CPU_PREPARE") != nullptr;
+    if (time_cpu_prepare) {
+        SplittedNormalMatrix probe(model_);
+        Timer timer;
+        probe.Prepare(basis_, colscale.data());
+        g_cpu_prepare_seconds += timer.Elapsed();
+        g_cpu_prepare_calls++;
+    }
 
     // Hand-off of the LU factors: B[rowperm,colperm] = (L+I)*U (src/lu_update.h:43-60).
     SparseMatrix L, U;

@@ -1,6 +1,8 @@
 """Condenses rocprofv3 outputs under gpurun_out/ into the tracked summaries in profiles/.
 usage: python scripts/make_profile_summary.py <kernel_trace_dir> <pmc_fetch_dir> <pmc_write_dir> <tag>"""
-import collections, csv, glob, json, shutil, statistics, sys
+import collections, csv, glob, json, os, shutil, statistics, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench          # source_hashes(): git blob hashes of the kernel sources these counters belong to
 trace_dir, fetch_dir, write_dir, tag = sys.argv[1:5]
 one = lambda d, pat: glob.glob("%s/*/*%s" % (d, pat))[0]
 rows = list(csv.DictReader(open(one(trace_dir, "kernel_trace.csv"))))
@@ -12,7 +14,7 @@ lines = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --war
          "# for the SpMV kernels (launches that did work)",
          "kernel,calls,total_ms,avg_us_all,calls_working,avg_us_working,median_us_working"]
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-    thr = 20000 if ("spmv_phased" in k or "sliced_tile" in k) else (8000 if "sliced_combine" in k else 0)
+    thr = 20000 if ("spmv_phased" in k or "sliced_tile" in k or "sorted_tile" in k) else (8000 if "sliced_combine" in k else 0)
     w = [x for x in v if x > thr]
     lines.append('"%s",%d,%.3f,%.2f,%d,%.2f,%.2f' % (k.replace('"', "'"), len(v), sum(v) / 1e6, sum(v) / len(v) / 1e3, len(w),
                                                 (sum(w) / len(w) / 1e3 if w else 0), (statistics.median(w) / 1e3 if w else 0)))
@@ -21,7 +23,7 @@ shutil.copy(one(trace_dir, "kernel_stats.csv"), "profiles/%s_bench_kernel_stats_
 def short(k):
     return k.split("(")[0].replace("void ipxk::", "").replace("ipxk::", "")
 # the kernels of one NormalMatrix apply, whichever layout each pass uses
-apply_kernels = [k for k in dur if "spmv_" in k and ("EpiScale" in k or "EpiNormalRows" in k) and len(dur[k]) > 50]   # not the few build-time tuning launches
+apply_kernels = [k for k in dur if "spmv_" in k and ("EpiScale" in k or "EpiNormalRows" in k) and len(dur[k]) > 60]   # not the few build-time tuning launches
 apply_kernels.sort(key=lambda k: ("EpiNormalRows" in k, "combine" in k))
 def working(k, v):        # launches after CR termination return at once
     return [x for x in v if x > (8000 if "combine" in k else 20000)]
@@ -43,7 +45,8 @@ for k in apply_kernels:
     total += (2 * f + wv) * 1024
     total_us += us
     rows_txt.append("%s,%.1f,%.0f,%.1f,%.0f,%.1f" % (short(k).replace(",", ""), us, f, 2 * f * 1024 / 1e6, wv, wv * 1024 / 1e6))
-layouts = ["sliced" if any("sliced" in k and e in k for k in apply_kernels) else "phased" for e in ("EpiScale", "EpiNormalRows")]
+layouts = ["sorted" if any("sorted_tile" in k and e in k for k in apply_kernels) else
+           "sliced" if any("sliced" in k and e in k for k in apply_kernels) else "phased" for e in ("EpiScale", "EpiNormalRows")]
 txt = """# L2<->fabric traffic of the NormalMatrix apply (C3: m=1M, n=2M, nnz=16M), MI355X, %s
 # separate passes:  rocprofv3 --pmc FETCH_SIZE -- python3 bench.py ...   and   rocprofv3 --pmc WRITE_SIZE -- ...
 # units KiB as reported.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads exactly 1/2 of a coalesced
@@ -56,6 +59,7 @@ kernel,avg_us_working,FETCH_SIZE_KiB_raw,read_MB_corrected,WRITE_SIZE_KiB,write_
 """ % (tag, "\n".join(rows_txt), total_us, total / 1e6, total / 476e6)
 open("profiles/%s_pmc_traffic.txt" % tag, "w").write(txt)
 json.dump({"workload": "C3 m=1000000 n=2000000 nnz=16000000", "layouts": layouts, "traffic_bytes_per_apply": total,
+           "source_hashes": bench.source_hashes(),
            "source": "profiles/%s_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)" % tag},
           open("profiles/pmc_traffic.json", "w"), indent=1)
 print(txt)

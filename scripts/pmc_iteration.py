@@ -1,8 +1,10 @@
 """Per-operator-application HBM-side traffic of the basis CR iteration from two rocprofv3 --pmc runs (FETCH_SIZE,
 WRITE_SIZE) of scripts/gpu_basis_iter.py: sums the counter over the kernels of the CR loop and divides by the number
 of operator applications (= calls of split_finish_kernel).  usage: pmc_iteration.py <fetch dir> <write dir>"""
-import collections, csv, glob, json, sys
-KERNELS = ("sweep_run_kernel", "spmv_sliced", "spmv_phased", "spmv_long", "gather_perm_kernel", "fill_sentinel_kernel",
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+KERNELS = ("sweep_run_kernel", "spmv_sliced", "spmv_sorted", "spmv_phased", "spmv_long", "gather_perm_kernel", "fill_sentinel_kernel",
            "split_finish_kernel", "cr_direction_kernel", "cr_control_update_kernel", "snapshot_done_kernel", "unpack_result_kernel")
 def load(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
@@ -25,5 +27,6 @@ for k in sorted(ft, key=lambda k: -ft[k]):
     print("%-70s calls/apply %6.2f  read %8.1f MB  write %7.1f MB" % (k[:70], fc[k] / napply, r, w))
 print("per application: read %.1f MB + write %.1f MB = %.1f MB" % (read_mb, write_mb, read_mb + write_mb))
 json.dump({"workload": "C3 basis path, planted factors: one operator application + CR vector kernels", "traffic_bytes_per_iteration": (read_mb + write_mb) * 1e6,
-           "source": "profiles/r02_basis_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on scripts/gpu_basis_iter.py, FETCH x2 gfx950 correction)"},
+           "layouts": [a for a in sys.argv[3:5]] if len(sys.argv) > 4 else ["sorted", "sorted"], "source_hashes": bench.source_hashes(),
+           "source": "profiles/r03_basis_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on scripts/gpu_basis_iter.py, FETCH x2 gfx950 correction)"},
           open("gpurun_out/pmc_traffic_basis.json", "w"), indent=1)

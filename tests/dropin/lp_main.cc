@@ -26,6 +26,10 @@
 extern "C" long dropin_lu_factorizations();
 extern "C" long dropin_lu_max_bump();
 extern "C" double dropin_lu_seconds();
+#ifdef IPX_LP_HIP
+extern "C" double ipx_hip_cpu_prepare_seconds();
+extern "C" long ipx_hip_cpu_prepare_calls();
+#endif
 
 template <class T>
 static std::vector<T> ReadBin(const std::string& path) {
@@ -108,6 +112,10 @@ int main(int argc, char** argv) {
     f << "lu_factorizations " << dropin_lu_factorizations() << '\n';
     f << "lu_max_bump " << dropin_lu_max_bump() << '\n';
     f << "lu_device_seconds " << dropin_lu_seconds() << '\n';
+#ifdef IPX_LP_HIP
+    f << "cpu_prepare_seconds " << ipx_hip_cpu_prepare_seconds() << '\n';
+    f << "cpu_prepare_calls " << ipx_hip_cpu_prepare_calls() << '\n';
+#endif
 
     if (info.status_ipm != IPX_STATUS_not_run) {
         std::vector<double> x(num_var), xl(num_var), xu(num_var), slack(num_constr), y(num_constr), zl(num_var),

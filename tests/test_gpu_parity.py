@@ -436,6 +436,41 @@ def test_spmv_layouts_agree(kkt, po, oracle, monkeypatch):
     assert relerr(out["sliced"][2], out["phased"][2]) < 1e-8
 
 
+def test_sorted_fused_layout_on_a_banded_matrix(kkt, po, oracle, monkeypatch):
+    """gathers with locality (8 rows per column inside a 2048-row band): the fused tiles with the gathers of a tile
+    in address order -- row sums in the reference's order, bit for bit, like the phased and fused layouts; the
+    layout is refused (and the phased one used) when a tile's window of x is too wide"""
+    m, n = 120000, 250000
+    A = synth.banded_lp(m, n, 8, 2048, 5)
+    rng = np.random.default_rng(2)
+    W = 10.0 ** rng.uniform(-2, 2, n + m)
+    u = rng.standard_normal(m)
+    ref, ref_dot = oracle.normal_apply(ocsc(po, A), W, u)
+    res = {}
+    for layout in ("phased", "sortedfused", None):
+        if layout: monkeypatch.setenv("IPXK_SPMV_LAYOUT", layout)
+        else: monkeypatch.delenv("IPXK_SPMV_LAYOUT")
+        ctx = kkt.KktContext(A)
+        if layout: assert ctx.spmv_layout()[0] == (layout, layout)
+        ctx.normal_prepare(W)
+        lhs, dot = ctx.normal_apply(u)
+        assert np.array_equal(lhs, ref) and abs(dot - ref_dot) <= 1e-12 * abs(ref_dot), layout
+        st = synth.synthetic_ipm_state(m, n, 1.0, 5)
+        assert ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"]) == 0
+        x, y, it, e, _ = ctx.kkt_diag_solve(st["a"], st["b"], 0.3 * np.sqrt(st["mu"]), 500)
+        res[layout] = (x, y, it, e, ctx.spmv_layout())
+        ctx.close()
+    assert res["sortedfused"][3] == res["phased"][3] == 0 and abs(res["sortedfused"][2] - res["phased"][2]) <= 2
+    assert relerr(res["sortedfused"][1], res["phased"][1]) < 1e-8
+    print("auto choice on the banded matrix:", res[None][4])
+    # uniformly random indices: no tile has a narrow window -> not built, the phased layout serves
+    monkeypatch.setenv("IPXK_SPMV_LAYOUT", "sortedfused")
+    A2, _ = diag_problem(20000, 600000, seed=3)
+    ctx = kkt.KktContext(A2)
+    assert ctx.spmv_layout()[0][1] == "phased"
+    ctx.close()
+
+
 def test_split_prepare_rejects_bad_factors(kkt):
     """indices that violate the factor contract (src/lu_update.h:43-60) are refused before any kernel uses them"""
     m, n = 300, 700
