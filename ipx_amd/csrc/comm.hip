@@ -106,15 +106,22 @@ __device__ __forceinline__ double load_sys(const double* p) {
                                                              __HIP_MEMORY_SCOPE_SYSTEM));
 }
 // all lanes of the calling workgroup return once flags[p * stride] >= epoch for every rank p; false on timeout
+// wait budget of the exchange kernels in 100 MHz ticks (set from IPXK_COMM_TIMEOUT_S when the communicator is built)
+__device__ unsigned long long g_comm_timeout_ticks = 120ull * 100000000ull;
+
 __device__ __forceinline__ bool wait_ranks(const unsigned* flags, int stride, int nranks, unsigned epoch, int* abort_flag) {
     __shared__ int ok_shared;
     if (threadIdx.x == 0) ok_shared = 1;
     __syncthreads();
     if ((int)threadIdx.x < nranks) {
+        // bounded wait: by wall clock (s_memrealtime ticks at 100 MHz), not by a poll count whose duration depends on
+        // the load of the host-memory path; the budget comes from IPXK_COMM_TIMEOUT_S (default 120 s)
+        const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
         int spins = 0;
         while ((int)(__hip_atomic_load(flags + threadIdx.x * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1 << 24) || ((spins & 1023) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            if (((++spins & 1023) == 0 && (__builtin_amdgcn_s_memrealtime() - t_begin > g_comm_timeout_ticks ||
+                                            __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))) {
                 __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok_shared = 0;
                 break;
@@ -181,15 +188,19 @@ struct DirectComm {
 
     unsigned* ready_dev() const { return flags_dev; }                          // ready[p] at p * 16 words
     unsigned* reduced_dev() const { return flags_dev + (size_t)nranks * 16; }
-    void host_barrier() {
+    void host_barrier(int limit_s = 120) {
         const int gen = hdr->generation.load();
         if (hdr->count.fetch_add(1) + 1 == nranks) { hdr->count.store(0); hdr->generation.fetch_add(1); return; }
         const auto t0 = std::chrono::steady_clock::now();
         while (hdr->generation.load() == gen) {
             std::this_thread::sleep_for(std::chrono::microseconds(50));
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
-                throw Error(IPXK_E_HIP, "direct exchange: a rank did not reach the set-up barrier within 120 s");
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(limit_s))
+                throw Error(IPXK_E_HIP, "direct exchange: a rank did not reach the barrier in time");
         }
+    }
+    bool aborted() const {
+        int f = 0;
+        return abort_flag.size() && hipMemcpy(&f, abort_flag.get(), sizeof f, hipMemcpyDeviceToHost) == hipSuccess && f != 0;
     }
     void open(const std::string& nm, int r, int n, size_t cap) {
         IPXK_REQUIRE(n <= kMaxDirectRanks, "direct exchange supports at most 16 ranks");
@@ -263,11 +274,19 @@ struct DirectComm {
         }
         abort_flag.resize(1);
         IPXK_HIP(hipMemset(abort_flag.get(), 0, sizeof(int)));
+        {
+            double seconds = 120.0;
+            if (const char* e = getenv("IPXK_COMM_TIMEOUT_S")) if (atof(e) > 0.0) seconds = atof(e);
+            const unsigned long long ticks = (unsigned long long)(seconds * 1e8);
+            IPXK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_comm_timeout_ticks), &ticks, sizeof ticks));
+        }
         host_barrier();                                   // everybody has mapped everything
     }
     ~DirectComm() {
         for (void* p : opened) (void)hipIpcCloseMemHandle(p);
-        if (hdr) { try { host_barrier(); } catch (...) {} }   // nobody unmaps a buffer that a peer still has open
+        // nobody unmaps a buffer that a peer still has open -- unless the exchange already failed (a peer may be gone:
+        // then a short wait only)
+        if (hdr) { try { host_barrier(aborted() ? 2 : 120); } catch (...) {} }
         if (S) (void)hipFree(S);
         if (T) (void)hipFree(T);
         if (seg) { (void)hipHostUnregister(seg); munmap(seg, seg_bytes); }

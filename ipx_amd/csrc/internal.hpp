@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -256,6 +257,10 @@ struct GatherMatrix {
     DevBuf<int> seg_p0, seg_p1, lidx, long_row, long_slot;
     DevBuf<double> lval, long_partials;
     DevBuf<unsigned long long> stamps;   // allocated only when IPXK_STAMPS=1
+    // how much of the layout choice build() pays for: 2 = every layout built and timed (the model matrix: once per
+    // model), 1 = phased against fused only, 0 = the phased layout, no timing (auxiliary matrices built inside a
+    // Factorize: the dense columns' gather matrices)
+    int tune_level = 2;
     // optional copy in plain row order (ptr/idx/val) for callers that address single rows
     bool keep_plain = false;
     std::vector<int> h_plain_ptr;
@@ -277,7 +282,10 @@ struct GatherMatrix {
     void build_sorted_fused(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s);
     bool use_sorted_fused = false;
     float tuned_us_sorted_fused = 0.f;
-    int sorted_fused_grid() const { return std::min(sorted.nrb, kMaxPartials); }
+    int sorted_fused_grid() const {
+        static const int cap = [] { const char* e = getenv("IPXK_SF_GRID"); return e && atoi(e) > 0 ? std::min(atoi(e), kMaxPartials) : kMaxPartials; }();
+        return std::min(sorted.nrb, cap);
+    }
     SortedView sorted_view() const;
     float tuned_us_phased = 0.f, tuned_us_sliced = 0.f, tuned_us_fused = 0.f, tuned_us_sorted = 0.f;
     // ns_request: 0 = as many slices as x needs (>= 2), 1 = the fused single-slice variant

@@ -383,16 +383,29 @@ void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_i
         else hipLaunchKernelGGL(mv_eta_ftran_kernel, dim3(1), dim3(kEtaThreads), 0, s, K, M.eta_ptr.get(), M.eta_pos.get(),
                                 M.eta_piv.get(), M.eta_idx.get(), M.eta_val.get(), v);
     };
+    // LU pivot tolerance of this run and the reference's ladder for it (Basis::TightenLuPivotTol, src/basis.cc:490-503)
+    double pivottol = 0.1;
+    auto tighten_pivottol = [&]() {
+        if (pivottol <= 0.05) pivottol = 0.1;
+        else if (pivottol <= 0.25) pivottol = 0.3;
+        else if (pivottol <= 0.5) pivottol = 0.9;
+        else return false;
+        return true;
+    };
     auto refactorize = [&]() {                   // Basis::Factorize (src/basis.cc:116-156) + the operator of the sweeps
         ipxk_lu_info li{};
-        lu_factorize_basis(c, basis_h.data(), 0.1, false, &li);
-        if (li.num_dependent > 0) throw Error(IPXK_E_ARGUMENT, "maxvolume: the basis became singular (IPX_ERROR_basis_singular)");
+        lu_factorize_basis(c, basis_h.data(), pivottol, false, &li);
+        if (li.num_dependent > 0) {              // Basis::Factorize returns IPX_ERROR_basis_singular (:131-137)
+            I.errflag = 301;
+            return false;
+        }
         split_prepare_lu(c, status_h.data(), colscale_in);
         lu_plain_matrix(c, &Ap, &Ai, &Ax);
         K = 0;
         eta_used = 0;
         IPXK_HIP(hipMemcpyAsync(M.eta_ptr.get(), &zero, sizeof(int), hipMemcpyHostToDevice, s));
         I.factorizations++;
+        return true;
     };
     const int gm = grid_for(m), gN = grid_for(N);
     const bool verbose = getenv("IPXK_VERBOSE") != nullptr && getenv("IPXK_VERBOSE")[0] == '2';
@@ -446,9 +459,11 @@ void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_i
             // Basis::ExchangeIfStable (:286-321): the pivot from the row against the pivot from the column
             const bool stable = a.pivot_col != 0.0 && std::abs(a.pivot_col - pivot) <= 1e-8 * std::abs(a.pivot_col);
             if (!stable) {
+                // Basis::ExchangeIfStable (src/basis.cc:299-306): on fresh factors the pivot tolerance is tightened
+                // first, and only when that is no longer possible the basis is declared too ill conditioned
                 I.refused++;
-                if (K == 0) { I.errflag = 306; break; }                             // IPX_ERROR_basis_too_ill_conditioned
-                refactorize();
+                if (K == 0 && !tighten_pivottol()) { I.errflag = 306; break; }      // IPX_ERROR_basis_too_ill_conditioned
+                if (!refactorize()) break;
                 continue;                                                           // "try again" (:290-291)
             }
             // the eta of this exchange
@@ -474,7 +489,8 @@ void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_i
             basis_h[(size_t)a.pmax] = a.jn;
             status_h[(size_t)a.jn] = IPXK_BASIC;
             status_h[(size_t)a.jb] = IPXK_NONBASIC;
-            if (K >= max_etas || eta_used + m > eta_cap) refactorize();             // NeedFreshFactorization (:318-319)
+            if (K >= max_etas || eta_used + m > eta_cap)                            // NeedFreshFactorization (:318-319)
+                if (!refactorize()) break;
         }
         I.skipped += skipped;
         if (I.errflag) break;
@@ -484,7 +500,7 @@ void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_i
     // the tail of KKTSolverBasis::_Factorize (src/kkt_solver_basis.cc:56-61): a fresh factorization of the final
     // basis and the operator built from it
     // (IPXK_MAXVOL_SKIP_FINAL=1, measurements only: leaves the context with the factors of the last refactorized basis)
-    if (K > 0 && !I.errflag && !getenv("IPXK_MAXVOL_SKIP_FINAL")) refactorize();
+    if (K > 0 && !I.errflag && !getenv("IPXK_MAXVOL_SKIP_FINAL")) (void)refactorize();
     IPXK_HIP(hipStreamSynchronize(s));
     I.seconds = now_s() - t_start;
     if (basis_out) std::copy(basis_h.begin(), basis_h.end(), basis_out);

@@ -373,6 +373,8 @@ static void build_dense_structures(Context* c) {
             Tx[put] = Cx[p];
         }
     c->AdCols.keep_plain = true;
+    c->AdCols.tune_level = 0;           // k long rows: the long-row kernels do all the work in any layout
+    c->AdRows.tune_level = 1;           // m short rows gathering from k numbers: phased against fused
     c->AdCols.build(k, m, Cp.data(), Ci.data(), Cx.data(), c->stream);
     c->AdRows.build(m, k, Tp.data(), Ti.data(), Tx.data(), c->stream);
     c->chol.resize((size_t)k * k);

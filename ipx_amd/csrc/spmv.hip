@@ -211,13 +211,13 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
         return ms * 1e3f / reps;
     };
     // small matrices: a few microseconds either way, not worth two more copies of the matrix
-    if (nnz >= (1 << 16)) {
+    if (nnz >= (1 << 16) && tune_level > 0) {
         tuned_us_phased = time_current();
         SlicedMatrix fusedm, slicedm;
         build_sliced(hptr, hidx, hval, s, 1);
         if (sliced.built) { use_sliced = true; tuned_us_fused = time_current(); use_sliced = false; fusedm = std::move(sliced); }
         sliced = SlicedMatrix();
-        build_sliced(hptr, hidx, hval, s, 0);
+        if (tune_level > 1) build_sliced(hptr, hidx, hval, s, 0);
         if (sliced.built) { use_sliced = true; tuned_us_sliced = time_current(); use_sliced = false; slicedm = std::move(sliced); }
         sliced = SlicedMatrix();
         const double share = slicedm.built ? slicedm.dominant_fraction : 1.0;
@@ -225,7 +225,7 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
         if (spread) sliced = std::move(slicedm);
         else if (fusedm.built && tuned_us_fused < 0.95f * tuned_us_phased) sliced = std::move(fusedm);
         use_sliced = sliced.built;
-        if (!spread && !(getenv("IPXK_SPMV_SORTED") && getenv("IPXK_SPMV_SORTED")[0] == '0')) {
+        if (!spread && tune_level > 1 && !(getenv("IPXK_SPMV_SORTED") && getenv("IPXK_SPMV_SORTED")[0] == '0')) {
             // gathers with locality: the fused tiles with the gathers in address order (bit-identical to the phased
             // and fused layouts, so a timing may choose); kept if it beats what the timing chose so far
             // (an overlay: masked products -- the basis path's N N' -- keep using the layout chosen above)

@@ -519,18 +519,27 @@ static void run_sweep(Context* c, const Sweep& S, bool scaled, const double* xin
     // Every workgroup of a run must be resident (a wavefront may wait for a chunk that another workgroup of
     // the same launch owns): never launch more workgroups than the device holds at once.  One block per CU
     // is held back from what the occupancy query reports (it over-reports by one for some kernels).
-    static const int grid_all = [] {
+    // (per operator, i.e. per context and device; the smallest occupancy of the four instantiations counts.  Two
+    // contexts must not run basis sweeps on ONE device at the same time: their workgroups would compete for the
+    // residency each of them assumes -- a violation ends in the bounded spin's time-out error, not in a hang.)
+    if (sp->sweep_grid_all == 0) {
         const char* e = getenv("IPXK_SWEEP_GRID");
         int want = e && atoi(e) > 0 ? atoi(e) : kSweepGrid;
-        int dev = 0, per_cu = 0;
+        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sweep_run_kernel<true, true>, kBlock, 0) == hipSuccess) {
-            const int resident = prop.multiProcessorCount * std::max(1, per_cu - 1);
-            want = std::max(1, std::min(want, resident));
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            int per_cu = 1 << 30, got = 0;
+            auto ask = [&](auto kernel) {
+                int v = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kernel, kBlock, 0) == hipSuccess) { per_cu = std::min(per_cu, v); got++; }
+            };
+            ask(sweep_run_kernel<true, true>); ask(sweep_run_kernel<true, false>);
+            ask(sweep_run_kernel<false, true>); ask(sweep_run_kernel<false, false>);
+            if (got == 4) want = std::max(1, std::min(want, prop.multiProcessorCount * std::max(1, per_cu - 1)));
         }
-        return want;
-    }();
+        sp->sweep_grid_all = want;
+    }
+    const int grid_all = sp->sweep_grid_all;
     static const int wgs_xcd = [] { const char* e = getenv("IPXK_SWEEP_XCD_WGS"); return e && atoi(e) > 0 ? std::min(atoi(e), 64) : kSweepXcdWgs; }();
     for (const Sweep::Launch& L : S.plan) {
         const bool one_xcd = L.kind == Sweep::kOneXcd;

@@ -107,6 +107,7 @@ struct SplitOperator {
     DevBuf<int> row_after_backward;        // its inverse by position of the L' sweep: row of A of a position, -1 for padding
     DevBuf<unsigned long long> xcc_slots;  // one-XCD runs: placement consensus words
     unsigned epoch = 0;                    // launch counter of the one-XCD runs
+    int sweep_grid_all = 0;                // workgroups of an all-XCD run: all resident on this operator's device (0: not asked yet)
     DevBuf<int> abort_flag;
     DevBuf<double> tI;                     // m
     bool level_launches = false;           // IPXK_TRISOLVE=levels: one launch per level (debugging aid)
