@@ -323,6 +323,13 @@ def main():
         # the RCCL measurement above; never `value`.  Any failure is recorded instead of a number.
         out["config"]["direct_exchange"] = bench_direct_exchange(kkt, dist, torch, A, st, tol, args, rank, world,
                                                                  local_rank, it, tdev)
+    # what the transport itself reports about the communicator (ncclCommCount / ncclCommUserRank for RCCL): lets a
+    # SCALE record be checked against the number of ranks that really exchanged data
+    try:
+        tname, tn, tr = ctx.comm_info()
+        out["config"]["communicator"] = {"transport": tname, "nranks_reported_by_transport": tn, "rank": tr, "world_size": world}
+    except Exception as exc:            # noqa: BLE001
+        out["config"]["communicator"] = {"error": str(exc)}
     if rehearsal:
         out["config"]["transport"] = "REHEARSAL: all ranks on one GPU, direct exchange between the rank processes"
     elif world > 1:

@@ -471,6 +471,11 @@ int ipxk_comm_init(ipxk_context* ctx, const void* id128, int rank, int nranks);
  * every scalar of the CR loop is replicated, the one exchange step per
  * NormalMatrix::_Apply is the all-reduce of the m partial sums A_g t_g. */
 int ipxk_comm_init_columns(ipxk_context* ctx, const void* id128, int rank, int nranks);
+/* What the transport itself reports about the communicator of this context:
+ * transport 0 = none, 1 = RCCL (nranks / rank from ncclCommCount /
+ * ncclCommUserRank), 2 = the direct exchange (its rank table).  For the records
+ * of a multi-GPU run (bench.py writes it into its JSON line). */
+int ipxk_comm_info(const ipxk_context* ctx, int* transport, int* nranks, int* rank);
 
 /* ---- measurement helpers (bench.py, section 8d) --------------------------- */
 /* Runs `reps` NormalMatrix applies on resident device vectors and returns the

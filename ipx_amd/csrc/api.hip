@@ -18,6 +18,7 @@ Context::~Context() {
     if (prepare_host) destroy_prepare_host(prepare_host);
     if (lu) destroy_lu(lu);
     if (maxvol) destroy_maxvol(maxvol);
+    if (nmat) destroy_nmatrix(nmat);
     comm_destroy(this);
     if (h_state) (void)hipHostFree(h_state);
     if (h_cycle_done) (void)hipHostFree(h_cycle_done);

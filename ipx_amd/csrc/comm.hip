@@ -41,6 +41,8 @@ typedef int (*CommDestroyFn)(ncclComm*);
 typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, ncclComm*, hipStream_t);
 typedef int (*AllGatherFn)(const void*, void*, size_t, int, ncclComm*, hipStream_t);
 typedef const char* (*GetErrorStringFn)(int);
+typedef int (*CommCountFn)(const ncclComm*, int*);
+typedef int (*CommUserRankFn)(const ncclComm*, int*);
 
 struct Rccl {
     void* handle = nullptr;
@@ -50,6 +52,8 @@ struct Rccl {
     AllReduceFn all_reduce = nullptr;
     AllGatherFn all_gather = nullptr;
     GetErrorStringFn error_string = nullptr;
+    CommCountFn comm_count = nullptr;
+    CommUserRankFn comm_user_rank = nullptr;
 };
 
 Rccl& rccl() {
@@ -64,6 +68,8 @@ Rccl& rccl() {
         r.all_reduce = (AllReduceFn)dlsym(r.handle, "ncclAllReduce");
         r.all_gather = (AllGatherFn)dlsym(r.handle, "ncclAllGather");
         r.error_string = (GetErrorStringFn)dlsym(r.handle, "ncclGetErrorString");
+        r.comm_count = (CommCountFn)dlsym(r.handle, "ncclCommCount");
+        r.comm_user_rank = (CommUserRankFn)dlsym(r.handle, "ncclCommUserRank");
         if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_reduce || !r.all_gather)
             throw Error(IPXK_E_HIP, "librccl lacks an expected symbol");
     }
@@ -453,6 +459,27 @@ static int comm_init_impl(ipxk_context* c, const void* id128, int rank, int nran
         IPXK_HIP(hipMemcpyAsync(&total, cnt.get(), sizeof(double), hipMemcpyDeviceToHost, c->stream));
         IPXK_HIP(hipStreamSynchronize(c->stream));
         c->m_global = (int64_t)(total + 0.5);
+        return IPXK_OK;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    }
+}
+
+// what the transport itself says about the communicator (for the records of a multi-GPU run): RCCL's ncclCommCount /
+// ncclCommUserRank, or the rank table of the direct exchange
+extern "C" int ipxk_comm_info(const ipxk_context* c, int* transport, int* nranks, int* rank) {
+    try {
+        if (!c || !transport || !nranks || !rank) throw Error(IPXK_E_ARGUMENT, "ipxk_comm_info: bad argument");
+        *transport = 0; *nranks = 1; *rank = 0;
+        if (c->direct) { *transport = 2; *nranks = c->direct->nranks; *rank = c->direct->rank; }
+        else if (c->comm) {
+            *transport = 1;
+            Rccl& r = rccl();
+            if (!r.comm_count || !r.comm_user_rank) throw Error(IPXK_E_HIP, "librccl lacks ncclCommCount / ncclCommUserRank");
+            check(r.comm_count(c->comm, nranks), "ncclCommCount");
+            check(r.comm_user_rank(c->comm, rank), "ncclCommUserRank");
+        }
         return IPXK_OK;
     } catch (const Error& e) {
         set_last_error(e.what());

@@ -26,6 +26,7 @@ struct SplitOperator;   // trisolve.hip
 struct PrepareHost;     // trisolve.hip
 struct LuState;         // lu.hip
 struct MaxvolState;     // maxvolume.hip
+struct NMatrix;         // nmatrix.hip
 
 struct Context {
     int device = 0;
@@ -101,6 +102,7 @@ struct Context {
     PrepareHost* prepare_host = nullptr;   // host workspaces of split_prepare (trisolve.hip)
     LuState* lu = nullptr;                 // factors of the last ipxk_lu_factorize* (lu.hip)
     MaxvolState* maxvol = nullptr;         // workspaces of ipxk_maxvolume (maxvolume.hip)
+    NMatrix* nmat = nullptr;               // N of the split operator as a matrix of its own (nmatrix.hip)
 
     // ---- multi-GPU ----
     ncclComm* comm = nullptr;
@@ -224,6 +226,11 @@ void destroy_lu(LuState*);
 void maxvolume_dev(Context* c, const ipxint* status, const double* colscale, const ipxk_maxvolume_params* prm,
                    ipxint* basis_out, ipxint* status_out, ipxk_maxvolume_info* info, ipxint* log, ipxint log_cap);
 void destroy_maxvol(MaxvolState*);
+void destroy_nmatrix(NMatrix*);
+// N = the NONBASIC columns of A with nonzero weight as a pair of gather matrices built on the device (nmatrix.hip):
+// prepare returns false when N is not used for this model; apply: work = W_I .* u + N (W_N .* (N' u))
+bool nmatrix_prepare(Context* c, const double* W);
+void nmatrix_apply(Context* c, const double* WI, const double* u, double* work, const int* done);
 // ---- presolve.hip (stand-alone, no context) ----
 void equilibrate_device(int device, int64_t m, int64_t n, const ipxint* Ap, const ipxint* Ai, double* Ax,
                         double* colscale, double* rowscale, ipxint* rounds);

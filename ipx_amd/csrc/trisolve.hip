@@ -663,7 +663,9 @@ static void upload_scaling(Context* c, SplitOperator* S, const ipxint* status, c
     // IPXK_COMPACT_N=0: keep streaming the whole model matrix with masked values (round-2 form)
     const bool compact = !(getenv("IPXK_COMPACT_N") && getenv("IPXK_COMPACT_N")[0] == '0');
     c->Acols.compact.valid = c->Arows.compact.valid = false;
-    if (S->masked_values) {
+    // large models: N as a pair of gather matrices of its own, built on the device (nmatrix.hip); otherwise ...
+    S->real_N = S->masked_values && compact && nmatrix_prepare(c, S->Wsplit.get());
+    if (S->masked_values && !S->real_N) {
         // N as a matrix of its own (splitted_normal_matrix.cc:42-55): the tiles of the two gather matrices without
         // the entries of zero-weight columns; layouts without tiles (phased) and long rows keep the masked values
         if (compact) {
@@ -1028,7 +1030,9 @@ int split_apply_dev(Context* c, const double* rhs, double* lhs, const int* done)
     // N N' of it: A (M D^2) A'
     EpiScale e1{{}, S->Wsplit.get(), c->tcols.get()};
     EpiNormalRows e2{{}, S->Wsplit.get() + n, u, work};
-    if (S->masked_values) {
+    if (S->real_N) {
+        nmatrix_apply(c, S->Wsplit.get() + n, u, work, done);
+    } else if (S->masked_values) {
         // the entries of BASIC / fixed columns have weight zero in both passes: masked value arrays, no gathers for them
         launch_spmv<EpiScale, true>(c->Acols, u, e1, nullptr, done, s);
         launch_spmv<EpiNormalRows, true>(c->Arows, c->tcols.get(), e2, nullptr, done, s);

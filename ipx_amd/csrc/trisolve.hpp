@@ -112,6 +112,7 @@ struct SplitOperator {
     DevBuf<double> tI;                     // m
     bool level_launches = false;           // IPXK_TRISOLVE=levels: one launch per level (debugging aid)
     bool masked_values = false;            // N N' uses the gather matrices' masked value arrays (spmv.hip)
+    bool real_N = false;                   // N N' uses N built as a matrix of its own (nmatrix.hip)
     // Dense bump of the factorization (factors that came from the device LU): with the bump's block D22 =
     // (L22+I) U22 cut out of L and U,  (L+I) U = (L~+I) blockdiag(I, D22) U~,  L~ = L without L22, U~ = U with U22
     // replaced by I.  The level-scheduled sweeps run on L~ and U~ (no chain as long as the bump), and BETWEEN the

@@ -31,7 +31,7 @@ EXPORTS = [
     "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_rescale", "ipxk_split_apply", "ipxk_forward_solve",
     "ipxk_backward_solve", "ipxk_solve_dense", "ipxk_split_levels", "ipxk_cr_solve",
     "ipxk_kkt_basis_solve", "ipxk_newton_solve", "ipxk_iterate_set", "ipxk_iterate_get", "ipxk_iterate_update",
-    "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_ipm_step", "ipxk_iterate_objectives", "ipxk_ipm_driver", "ipxk_iterate_factorize_diag", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns",
+    "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_ipm_step", "ipxk_iterate_objectives", "ipxk_ipm_driver", "ipxk_iterate_factorize_diag", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns", "ipxk_comm_info",
     "ipxk_time_normal_apply", "ipxk_equilibrate", "ipxk_transpose", "ipxk_lu_factorize", "ipxk_lu_factorize_basis",
     "ipxk_lu_get_factors", "ipxk_split_prepare_lu", "ipxk_maxvolume", "ipxk_ipm_driver_basis",
     "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
@@ -237,6 +237,12 @@ class KktContext:
     @property
     def normal_apply_bytes(self):
         return int(self.lib.ipxk_normal_apply_bytes(self.h))
+
+    def comm_info(self):
+        """(transport, nranks, rank) as the transport reports them: 'none' | 'rccl' (ncclCommCount / ncclCommUserRank) | 'direct'"""
+        t, n, r = C.c_int(), C.c_int(), C.c_int()
+        self._check(self.lib.ipxk_comm_info(self.h, C.byref(t), C.byref(n), C.byref(r)))
+        return ("none", "rccl", "direct")[t.value], n.value, r.value
 
     def spmv_layout(self):
         """(layout of A'y, layout of A t) as 'phased'/'sliced', and the build-time timings in us."""

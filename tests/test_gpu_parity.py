@@ -297,6 +297,51 @@ def test_basis_path_vs_oracle(kkt, po, oracle, monkeypatch, mode, m, n, num_free
     ctx.close()
 
 
+def test_real_N_matrix_vs_oracle_and_masked_form(kkt, po, oracle, monkeypatch):
+    """N built on the device as a matrix of its own (nmatrix.hip; the slice size shrunk so that a small model
+    qualifies): the split operator against the oracle (1e-12), against the masked / compacted model-matrix form
+    (1e-13: the same products, another association across the slices of the compact vector), a rescale with other
+    weights and with another set of fixed variables (N must be rebuilt), and the KKT solve"""
+    monkeypatch.setenv("IPXK_SPMV_LAYOUT", "sliced")
+    monkeypatch.setenv("IPXK_SLICE_TEST_KB", "4")
+    m, n = 2500, 5200
+    B, st, colscale = basis_problem(m, n, seed=41, num_free=6, num_fixed=9)
+    A, L, U = B["A"], B["L"], B["U"]
+    AI = A.with_identity()
+    rhs = np.random.default_rng(4).standard_normal(m)
+    out = {}
+    for real in ("1", "0"):
+        monkeypatch.setenv("IPXK_REAL_N", real)
+        monkeypatch.setenv("IPXK_VERBOSE", "1")
+        ctx = kkt.KktContext(A)
+        assert ctx.spmv_layout()[0] == ("sliced", "sliced")
+        ctx.split_prepare(L, U, B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
+        l1, d1 = ctx.split_apply(rhs)
+        x1, yy1, it1, e1, _ = ctx.kkt_basis_solve(st["a"], st["b"], 1e-8)
+        # other weights on the same columns; then some more columns fixed (weight 0): another N
+        cs2 = colscale * np.where(np.isfinite(colscale) & (colscale > 0), 10.0 ** np.random.default_rng(8).uniform(-0.3, 0.3, n + m), 1.0)
+        ctx.split_rescale(B["status"], cs2)
+        l2, d2 = ctx.split_apply(rhs)
+        status3 = B["status"].copy()
+        nb = np.nonzero(status3[:n] == -1)[0][:40]
+        status3[nb] = -2                                          # NONBASIC_FIXED
+        cs3 = cs2.copy()
+        cs3[nb] = 0.0
+        ctx.split_rescale(status3, cs3)
+        l3, d3 = ctx.split_apply(rhs)
+        out[real] = (l1, d1, x1, yy1, it1, e1, l2, l3)
+        ctx.close()
+    S = oracle.split_prepare(ocsc(po, AI), n, ocsc(po, L), ocsc(po, U), B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
+    lo, do = S.apply(rhs)
+    a, b = out["1"], out["0"]
+    assert relerr(a[0], lo) <= 1e-12 and abs(a[1] - do) <= 1e-12 * abs(do)
+    for k in (0, 6, 7):
+        assert relerr(a[k], b[k]) <= 1e-13, k
+    assert not np.array_equal(a[0], b[0])                          # ... so N was really used (its slices are those of the compact t)
+    assert not np.array_equal(a[6], a[7])                          # the fixed columns did change the operator
+    assert a[5] == b[5] == 0 and abs(a[4] - b[4]) <= 2 and relerr(a[2], b[2]) < 1e-6 and relerr(a[3], b[3]) < 1e-6
+
+
 def test_operator_timers(kkt):
     """ipx_info::time_cr1_AAt / time_cr1_pre / time_cr2_NNt / _B / _Bt equivalents (ipxk_times)."""
     A, st = diag_problem(20000, 42000, seed=77)
