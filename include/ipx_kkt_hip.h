@@ -300,6 +300,23 @@ int ipxk_maxvolume(ipxk_context* ctx, const ipxint* status, const double* colsca
                    const ipxk_maxvolume_params* params, ipxint* basis_out,
                    ipxint* status_out, ipxk_maxvolume_info* info,
                    ipxint* exchange_log, ipxint log_cap);
+/* Maxvolume::RunSequential (src/maxvolume.cc:14-106), the variant KKTSolverBasis
+ * selects for update_heuristic == 0 (src/kkt_solver_basis.cc:47-51): passes over
+ * the NONBASIC columns in decreasing order of their scaling factor; per candidate
+ * the tableau column (SolveForUpdate) and the largest scaled entry
+ * |x_p| * invscale_basic[p] * colscale[j]; an exchange when it exceeds
+ * max(volume_tol, 1), checked like ipxk_maxvolume's (the BTRAN of the leaving
+ * variable that ExchangeIfStable computes for sys = -1 gives the pivot from the
+ * row).  maxpasses < 0: until a pass brings no update (the reference's default).
+ * Same preconditions, outputs and final refactorization + Prepare as
+ * ipxk_maxvolume; info->slices reports the number of passes.  A candidate costs
+ * two sweeps over all m unknowns on the device (the reference's solves are
+ * hypersparse): meant for moderate sizes, the heuristic is the one for 1M rows. */
+int ipxk_maxvolume_sequential(ipxk_context* ctx, const ipxint* status,
+                              const double* colscale, double volume_tol,
+                              ipxint maxpasses, ipxint max_etas, ipxint* basis_out,
+                              ipxint* status_out, ipxk_maxvolume_info* info,
+                              ipxint* exchange_log, ipxint log_cap);
 /* _Apply (src/splitted_normal_matrix.cc:90-117) */
 int ipxk_split_apply(ipxk_context* ctx, const double* rhs, double* lhs,
                      double* rhs_dot_lhs);

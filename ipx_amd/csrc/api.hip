@@ -758,6 +758,17 @@ int ipxk_maxvolume(ipxk_context* c, const ipxint* status, const double* colscale
     });
 }
 
+int ipxk_maxvolume_sequential(ipxk_context* c, const ipxint* status, const double* colscale, double volume_tol, ipxint maxpasses,
+                              ipxint max_etas, ipxint* basis_out, ipxint* status_out, ipxk_maxvolume_info* info,
+                              ipxint* exchange_log, ipxint log_cap) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && status && colscale, "NULL argument");
+        IPXK_REQUIRE(log_cap >= 0 && (exchange_log || log_cap == 0), "bad log arguments");
+        bind_device(c);
+        maxvolume_sequential_dev(c, status, colscale, volume_tol, maxpasses, max_etas, basis_out, status_out, info, exchange_log, log_cap);
+    });
+}
+
 int ipxk_cr_diagnostics(ipxk_context* c, ipxk_cr_diag* out) {
     return guarded([&] {
         IPXK_REQUIRE(c && out, "NULL argument");

@@ -225,6 +225,9 @@ void destroy_lu(LuState*);
 // ---- maxvolume.hip ----
 void maxvolume_dev(Context* c, const ipxint* status, const double* colscale, const ipxk_maxvolume_params* prm,
                    ipxint* basis_out, ipxint* status_out, ipxk_maxvolume_info* info, ipxint* log, ipxint log_cap);
+void maxvolume_sequential_dev(Context* c, const ipxint* status, const double* colscale, double volume_tol, ipxint maxpasses,
+                              ipxint max_etas, ipxint* basis_out, ipxint* status_out, ipxk_maxvolume_info* info, ipxint* log,
+                              ipxint log_cap);
 void destroy_maxvol(MaxvolState*);
 void destroy_nmatrix(NMatrix*);
 // N = the NONBASIC columns of A with nonzero weight as a pair of gather matrices built on the device (nmatrix.hip):

@@ -264,6 +264,90 @@ __global__ void mv_exchange_kernel(const Scalars* S, ipxint* basis, int* map2bas
     mask[jn] = 0.0;
     mask[jb] = 1.0;
 }
+// ---- Maxvolume::RunSequential (src/maxvolume.cc:14-106) ---------------------------------------------------------
+// the candidate chosen by the host's pass order
+__global__ void mvs_set_candidate_kernel(int j, double dj, Scalars* S) { S->jn = j; S->colscale_jn = dj; S->weight = dj; }
+// search_pivot (:61-70): first position of the largest v = |x_p| * invscale_basic[p] * d_j; # nonzeros and sum of
+// squares of the scaled column (tblnnz, frobnorm_squared)
+__global__ __launch_bounds__(kBlock) void mvs_search_pivot_kernel(int m, const Scalars* S, const double* __restrict__ lhs,
+                                                                  const double* __restrict__ invscale, Part* part) {
+    __shared__ double sv[kBlock / 64], ss[kBlock / 64];
+    __shared__ int si[kBlock / 64], sc[kBlock / 64];
+    const double dj = S->colscale_jn;
+    double best = 0.0, sum = 0.0;
+    int bi = INT_MAX, cnt = 0;
+    IPXK_GRID_STRIDE(p, m) {
+        const double v = fabs(lhs[p]) * invscale[p] * dj;
+        if (v > best || (v == best && v > 0.0 && (int)p < bi)) { best = v; bi = (int)p; }
+        sum += v * v;
+        cnt += v != 0.0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double ov = __shfl_xor(best, d, 64);
+        const int oi = __shfl_xor(bi, d, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        sum += __shfl_xor(sum, d, 64);
+        cnt += __shfl_xor(cnt, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sv[w] = best; si[w] = bi; ss[w] = sum; sc[w] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kBlock / 64; k++) {
+            if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+            sum += ss[k];
+            cnt += sc[k];
+        }
+        part[blockIdx.x] = Part{best, bi, sum, cnt};
+    }
+}
+__global__ __launch_bounds__(kRedGrid) void mvs_search_pivot_final_kernel(int nparts, const Part* part, const double* __restrict__ lhs,
+                                                                          const double* __restrict__ invscale, const ipxint* __restrict__ basis,
+                                                                          Scalars* S) {
+    __shared__ double sv[kRedGrid / 64], ss[kRedGrid / 64];
+    __shared__ int si[kRedGrid / 64], sc[kRedGrid / 64];
+    const bool have = (int)threadIdx.x < nparts;
+    double best = have ? part[threadIdx.x].v : 0.0, sum = have ? part[threadIdx.x].s : 0.0;
+    int bi = have ? part[threadIdx.x].i : INT_MAX, cnt = have ? part[threadIdx.x].c : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { sum += __shfl_xor(sum, d, 64); cnt += __shfl_xor(cnt, d, 64); }
+    if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = sum; sc[threadIdx.x >> 6] = cnt; }
+    final_argmax(best, bi, sv, si);
+    if (threadIdx.x != 0) return;
+    for (int k = 1; k < kRedGrid / 64; k++) { sum += ss[k]; cnt += sc[k]; }
+    const int pmax = bi == INT_MAX ? -1 : bi;
+    S->pmax = pmax;
+    S->vmax = best;
+    S->weight_recomp = sum;                            // sum of squares of the scaled column
+    S->eta_nnz = cnt;                                  // # nonzeros of the column (its eta has one fewer)
+    S->jb = pmax >= 0 ? (int)basis[pmax] : -1;
+    S->pivot_col = pmax >= 0 ? lhs[pmax] : 0.0;
+    S->invscale_pmax = pmax >= 0 ? invscale[pmax] : 0.0;
+    S->used_pmax = 0;
+}
+// the pivot from the row: btran' a_jn (one workgroup)
+__global__ __launch_bounds__(kBlock) void mvs_pivot_row_kernel(int n, const int* __restrict__ Ap, const int* __restrict__ Ai,
+                                                               const double* __restrict__ Ax, const double* __restrict__ btran, Scalars* S) {
+    __shared__ double red[kBlock / 64];
+    const int j = S->jn;
+    double sum = 0.0;
+    if (j >= n) { if (threadIdx.x == 0) S->pivot_row = btran[j - n]; return; }
+    // (sequential order of the column's entries for few entries; a fixed tree over the threads otherwise)
+    for (int q = Ap[j] + threadIdx.x; q < Ap[j + 1]; q += kBlock) sum += Ax[q] * btran[Ai[q]];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < kBlock / 64; k++) t += red[k]; S->pivot_row = t; }
+}
+__global__ void mvs_exchange_kernel(const Scalars* S, ipxint* basis, int* map2basis, double* invscale) {
+    const int jn = S->jn, jb = S->jb, p = S->pmax;
+    invscale[p] = 1.0 / S->colscale_jn;                 // :88
+    basis[p] = jn;                                      // Basis::ExchangeIfStable :308-313
+    map2basis[jn] = p;
+    map2basis[jb] = -1;
+}
+
 // ---- set-up -------------------------------------------------------------------------------------------------------
 __global__ void mv_init_columns_kernel(int64_t N, const ipxint* __restrict__ status, const double* __restrict__ colscale_in,
                                        double* __restrict__ colscale, double* __restrict__ mask, int* __restrict__ map2basis) {
@@ -502,6 +586,162 @@ void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_i
     // (IPXK_MAXVOL_SKIP_FINAL=1, measurements only: leaves the context with the factors of the last refactorized basis)
     if (K > 0 && !I.errflag && !getenv("IPXK_MAXVOL_SKIP_FINAL")) (void)refactorize();
     IPXK_HIP(hipStreamSynchronize(s));
+    I.seconds = now_s() - t_start;
+    if (basis_out) std::copy(basis_h.begin(), basis_h.end(), basis_out);
+    if (status_out) std::copy(status_h.begin(), status_h.end(), status_out);
+    if (info) *info = I;
+}
+
+// Maxvolume::RunSequential on the device (update_heuristic == 0, src/kkt_solver_basis.cc:47-51): every NONBASIC column in
+// decreasing order of its scaling factor gets its tableau column (the forward sweep pair + the etas), the host reads
+// one block of scalars per candidate and takes the reference's decisions.  The reference does this with hypersparse
+// solves; here a candidate costs two sweeps over all m unknowns, so the sequential variant is for moderate sizes --
+// the heuristic (maxvolume_dev) is the one built for 1M rows.
+void maxvolume_sequential_dev(Context* c, const ipxint* status_in, const double* colscale_in, double volume_tol, ipxint maxpasses,
+                              ipxint max_etas_in, ipxint* basis_out, ipxint* status_out, ipxk_maxvolume_info* info, ipxint* log,
+                              ipxint log_cap) {
+    LuView V;
+    IPXK_REQUIRE(lu_view(c, &V) && V.from_basis && V.ndep == 0, "maxvolume needs the factorization of the current basis (ipxk_lu_factorize_basis)");
+    IPXK_REQUIRE(c->split, "maxvolume needs the operator of the current basis (ipxk_split_prepare_lu)");
+    const int m = (int)c->m, n = (int)c->n;
+    const int64_t N = (int64_t)n + m;
+    IPXK_REQUIRE(m > 0, "empty model");
+    hipStream_t s = c->stream;
+    if (!c->maxvol) c->maxvol = new MaxvolState;
+    MaxvolState& M = *c->maxvol;
+    const double t_start = now_s();
+    const double volumetol = std::max(volume_tol, 1.0);
+    const int max_etas = (int)std::max<ipxint>(1, max_etas_in > 0 ? max_etas_in : 100);
+    const int64_t eta_cap = std::max<int64_t>(4 * (int64_t)m, int64_t(1) << 20);
+    for (DevBuf<double>* b : {&M.invscale, &M.rhs, &M.lhs, &M.unit, &M.btran}) b->ensure((size_t)m);
+    M.map2basis.ensure((size_t)N); M.flag.ensure((size_t)m); M.rank.ensure((size_t)m);
+    M.eta_ptr.ensure((size_t)max_etas + 1); M.eta_pos.ensure((size_t)max_etas); M.eta_piv.ensure((size_t)max_etas);
+    M.eta_idx.ensure((size_t)eta_cap + m); M.eta_val.ensure((size_t)eta_cap + m);
+    M.part.ensure(kRedGrid); M.scalars.ensure(1);
+    M.colscale.ensure((size_t)N); M.mask.ensure((size_t)N);
+    if (!M.h) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&M.h), sizeof(Scalars)));
+    std::vector<ipxint> basis_h((size_t)m), status_h(status_in, status_in + N);
+    IPXK_HIP(hipMemcpyAsync(basis_h.data(), V.basis, (size_t)m * sizeof(ipxint), hipMemcpyDeviceToHost, s));
+    DevBuf<double> colscale_dev;
+    colscale_dev.upload(colscale_in, (size_t)N, s);
+    M.status.upload(status_in, (size_t)N, s);
+    M.basis.ensure((size_t)m);
+    IPXK_HIP(hipMemcpyAsync(M.basis.get(), V.basis, (size_t)m * sizeof(ipxint), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(mv_init_columns_kernel, dim3(grid_for(N)), dim3(kBlock), 0, s, N, M.status.get(), colscale_dev.get(),
+                       M.colscale.get(), M.mask.get(), M.map2basis.get());
+    hipLaunchKernelGGL(mv_init_basis_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, M.basis.get(), M.status.get(), colscale_dev.get(),
+                       M.invscale.get(), M.map2basis.get());
+    const int zero = 0;
+    IPXK_HIP(hipMemcpyAsync(M.eta_ptr.get(), &zero, sizeof(int), hipMemcpyHostToDevice, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    for (int p = 0; p < m; p++) IPXK_REQUIRE(basis_h[p] >= 0 && basis_h[p] < N && status_h[basis_h[p]] >= 0, "status of a basic variable is not BASIC / BASIC_FREE");
+    const int *Ap = nullptr, *Ai = nullptr;
+    const double* Ax = nullptr;
+    lu_plain_matrix(c, &Ap, &Ai, &Ax);
+    int K = 0;
+    int64_t eta_used = 0;
+    ipxk_maxvolume_info I{};
+    double pivottol = 0.1;
+    auto tighten_pivottol = [&]() {                   // Basis::TightenLuPivotTol, src/basis.cc:490-503
+        if (pivottol <= 0.05) pivottol = 0.1;
+        else if (pivottol <= 0.25) pivottol = 0.3;
+        else if (pivottol <= 0.5) pivottol = 0.9;
+        else return false;
+        return true;
+    };
+    auto apply_etas = [&](bool transposed, double* v) {
+        if (K == 0) return;
+        if (transposed) hipLaunchKernelGGL(mv_eta_btran_kernel, dim3(1), dim3(kEtaThreads), 0, s, K, M.eta_ptr.get(), M.eta_pos.get(),
+                                           M.eta_piv.get(), M.eta_idx.get(), M.eta_val.get(), v);
+        else hipLaunchKernelGGL(mv_eta_ftran_kernel, dim3(1), dim3(kEtaThreads), 0, s, K, M.eta_ptr.get(), M.eta_pos.get(),
+                                M.eta_piv.get(), M.eta_idx.get(), M.eta_val.get(), v);
+    };
+    auto refactorize = [&]() {
+        ipxk_lu_info li{};
+        lu_factorize_basis(c, basis_h.data(), pivottol, false, &li);
+        if (li.num_dependent > 0) { I.errflag = 301; return false; }
+        split_prepare_lu(c, status_h.data(), colscale_in);
+        lu_plain_matrix(c, &Ap, &Ai, &Ax);
+        K = 0;
+        eta_used = 0;
+        IPXK_HIP(hipMemcpyAsync(M.eta_ptr.get(), &zero, sizeof(int), hipMemcpyHostToDevice, s));
+        I.factorizations++;
+        return true;
+    };
+    const int gm = grid_for(m);
+    ipxint passes = 0;
+    // candidates of a pass: Sortperm(n+m, colscale, false) (src/utils.cc:87-104), taken from the back
+    std::vector<std::pair<double, ipxint>> cand;
+    while ((passes < maxpasses || maxpasses < 0) && !I.errflag) {
+        ipxint updates_last = 0;
+        cand.resize((size_t)N);
+        for (int64_t j = 0; j < N; j++) cand[(size_t)j] = std::make_pair(colscale_in[j], (ipxint)j);
+        std::sort(cand.begin(), cand.end());
+        while (!cand.empty()) {
+            const ipxint j = cand.back().second;
+            const double dj = cand.back().first;
+            if (dj == 0.0) break;
+            if (status_h[(size_t)j] != IPXK_NONBASIC) { cand.pop_back(); continue; }
+            // tableau column and search_pivot
+            hipLaunchKernelGGL(mvs_set_candidate_kernel, dim3(1), dim3(1), 0, s, (int)j, dj, M.scalars.get());
+            IPXK_HIP(hipMemsetAsync(M.rhs.get(), 0, (size_t)m * sizeof(double), s));
+            hipLaunchKernelGGL(mv_scatter_column_kernel, dim3(4), dim3(kBlock), 0, s, n, M.scalars.get(), Ap, Ai, Ax, M.rhs.get());
+            solve_dense_dev(c, M.rhs.get(), M.lhs.get(), 'N');
+            apply_etas(false, M.lhs.get());
+            hipLaunchKernelGGL(mvs_search_pivot_kernel, dim3(kRedGrid), dim3(kBlock), 0, s, m, M.scalars.get(), M.lhs.get(), M.invscale.get(),
+                               M.part.get());
+            hipLaunchKernelGGL(mvs_search_pivot_final_kernel, dim3(1), dim3(kRedGrid), 0, s, kRedGrid, M.part.get(), M.lhs.get(),
+                               M.invscale.get(), M.basis.get(), M.scalars.get());
+            IPXK_HIP(hipMemcpyAsync(M.h, M.scalars.get(), sizeof(Scalars), hipMemcpyDeviceToHost, s));
+            IPXK_HIP(hipStreamSynchronize(s));
+            const Scalars a = *M.h;
+            if (a.vmax <= volumetol || a.pmax < 0) { I.skipped++; cand.pop_back(); continue; }      // :72-76
+            // the BTRAN of the leaving variable (ExchangeIfStable with sys = -1, src/basis.cc:292-293): pivot from the row
+            hipLaunchKernelGGL(mv_unit_kernel, dim3(gm), dim3(kBlock), 0, s, m, M.scalars.get(), M.unit.get());
+            apply_etas(true, M.unit.get());
+            solve_dense_dev(c, M.unit.get(), M.btran.get(), 'T');
+            hipLaunchKernelGGL(mvs_pivot_row_kernel, dim3(1), dim3(kBlock), 0, s, n, Ap, Ai, Ax, M.btran.get(), M.scalars.get());
+            IPXK_HIP(hipMemcpyAsync(M.h, M.scalars.get(), sizeof(Scalars), hipMemcpyDeviceToHost, s));
+            IPXK_HIP(hipStreamSynchronize(s));
+            const double pivot = M.h->pivot_row;
+            const bool stable = a.pivot_col != 0.0 && std::abs(a.pivot_col - pivot) <= 1e-8 * std::abs(a.pivot_col);
+            if (!stable) {
+                I.refused++;
+                if (K == 0 && !tighten_pivottol()) { I.errflag = 306; break; }
+                if (!refactorize()) break;
+                continue;                                                           // "try again" (:86-87)
+            }
+            hipLaunchKernelGGL(mv_eta_flag_kernel, dim3(gm), dim3(kBlock), 0, s, m, M.scalars.get(), M.lhs.get(), M.flag.get());
+            {
+                size_t bytes = 0;
+                IPXK_HIP(rocprim::exclusive_scan(nullptr, bytes, M.flag.get(), M.rank.get(), 0, (size_t)m, rocprim::plus<int>(), s));
+                if (M.tmp.size() < bytes) M.tmp.resize(bytes);
+                IPXK_HIP(rocprim::exclusive_scan(M.tmp.get(), bytes, M.flag.get(), M.rank.get(), 0, (size_t)m, rocprim::plus<int>(), s));
+            }
+            hipLaunchKernelGGL(mv_eta_store_kernel, dim3(gm), dim3(kBlock), 0, s, m, K, M.scalars.get(), M.lhs.get(), M.flag.get(), M.rank.get(),
+                               M.eta_ptr.get(), M.eta_pos.get(), M.eta_piv.get(), M.eta_idx.get(), M.eta_val.get(), M.scalars.get());
+            hipLaunchKernelGGL(mvs_exchange_kernel, dim3(1), dim3(1), 0, s, M.scalars.get(), M.basis.get(), M.map2basis.get(), M.invscale.get());
+            K++;
+            eta_used += a.eta_nnz;
+            if (log && I.updates + updates_last < log_cap) { log[2 * (I.updates + updates_last)] = a.jb; log[2 * (I.updates + updates_last) + 1] = j; }
+            updates_last++;
+            I.volinc += std::log2(a.vmax);                                          // :90
+            basis_h[(size_t)a.pmax] = j;
+            status_h[(size_t)j] = IPXK_BASIC;
+            status_h[(size_t)a.jb] = IPXK_NONBASIC;
+            cand.pop_back();
+            if (K >= max_etas || eta_used + m > eta_cap)
+                if (!refactorize()) break;
+        }
+        I.updates += updates_last;
+        passes++;
+        if (updates_last == 0) break;
+    }
+    IPXK_HIP(hipStreamSynchronize(s));
+    check_sweep_abort(c);
+    if (K > 0 && !I.errflag) (void)refactorize();      // the tail of KKTSolverBasis::_Factorize (src/kkt_solver_basis.cc:56-61)
+    IPXK_HIP(hipStreamSynchronize(s));
+    I.slices = passes;                                 // (the field reports the passes for this variant)
     I.seconds = now_s() - t_start;
     if (basis_out) std::copy(basis_h.begin(), basis_h.end(), basis_out);
     if (status_out) std::copy(status_h.begin(), status_h.end(), status_out);

@@ -31,7 +31,7 @@ EXPORTS = [
     "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_rescale", "ipxk_split_apply", "ipxk_forward_solve",
     "ipxk_backward_solve", "ipxk_solve_dense", "ipxk_split_levels", "ipxk_cr_solve",
     "ipxk_kkt_basis_solve", "ipxk_newton_solve", "ipxk_iterate_set", "ipxk_iterate_get", "ipxk_iterate_update",
-    "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_ipm_step", "ipxk_iterate_objectives", "ipxk_ipm_driver", "ipxk_iterate_factorize_diag", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns", "ipxk_comm_info",
+    "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_ipm_step", "ipxk_iterate_objectives", "ipxk_ipm_driver", "ipxk_iterate_factorize_diag", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns", "ipxk_comm_info", "ipxk_maxvolume_sequential",
     "ipxk_time_normal_apply", "ipxk_equilibrate", "ipxk_transpose", "ipxk_lu_factorize", "ipxk_lu_factorize_basis",
     "ipxk_lu_get_factors", "ipxk_split_prepare_lu", "ipxk_maxvolume", "ipxk_ipm_driver_basis",
     "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
@@ -541,6 +541,20 @@ class KktContext:
         self._check(self.lib.ipxk_maxvolume(self.h, _ip(status), _fp(colscale), C.byref(prm), _ip(basis_out), _ip(status_out),
                                             C.byref(info), _ip(log), c_i64(log_cap)))
         out = {name: getattr(info, name) for name, _ in MaxvolumeInfo._fields_}
+        out.update(basis=basis_out, status=status_out, exchanges=log[: 2 * min(info.updates, log_cap)].reshape(-1, 2))
+        return out
+
+    def maxvolume_sequential(self, status, colscale, volume_tol=2.0, maxpasses=-1, max_etas=100, log_cap=100000):
+        """Maxvolume::RunSequential (update_heuristic == 0) + refactorization + Prepare on the resident basis"""
+        status, colscale = _I(status), _F(colscale)
+        info = MaxvolumeInfo()
+        basis_out, status_out = np.zeros(self.m, i64), np.zeros(self.n + self.m, i64)
+        log = np.zeros(2 * max(log_cap, 1), i64)
+        self._check(self.lib.ipxk_maxvolume_sequential(self.h, _ip(status), _fp(colscale), c_f64(volume_tol), c_i64(maxpasses),
+                                                       c_i64(max_etas), _ip(basis_out), _ip(status_out), C.byref(info), _ip(log),
+                                                       c_i64(log_cap)))
+        out = {name: getattr(info, name) for name, _ in MaxvolumeInfo._fields_}
+        out["passes"] = out["slices"]
         out.update(basis=basis_out, status=status_out, exchanges=log[: 2 * min(info.updates, log_cap)].reshape(-1, 2))
         return out
 

@@ -1847,6 +1847,65 @@ extern "C" Int orc_basis_exchange_if_stable(orc_basis* B, Int jb, Int jn, double
 // (KKTSolverBasis::_Factorize passes Iterate::ScalingFactor, src/kkt_solver_basis.cc:28-29,46-50).
 // info[8] = updates, skipped, slices, volinc, # exchanges that were refused as unstable, errflag, 0, 0.
 // log (may be NULL, capacity log_cap pairs): the accepted exchanges (jb, jn) in order.
+// Maxvolume::RunSequential (src/maxvolume.cc:14-106), selected by update_heuristic == 0 (src/kkt_solver_basis.cc:47-51):
+// passes over the columns in decreasing order of their scaling factor; for every NONBASIC candidate the tableau column
+// (SolveForUpdate), the largest scaled entry v = |x_p| * invscale_basic[p] * d_j (first position on ties: the
+// reference's for_each_nonzero order is the pattern order of its IndexedVector, an LU detail -- ties are measure zero);
+// an exchange if v > max(volume_tol, 1).  ExchangeIfStable is called with sys = -1 (src/maxvolume.cc:83): the
+// reference computes the BTRAN of the leaving variable for its LU update there; here the same BTRAN yields the pivot
+// from the row, compared with the pivot from the column (exchange_if_stable above).
+// info[8] = updates, skipped, passes, volinc, refused, errflag, tblnnz of the last pass, tblmax of the last pass.
+extern "C" Int orc_maxvolume_sequential(orc_basis* B, const double* colscale, double volume_tol, Int maxpasses, double* info,
+                                        Int* log, Int log_cap) {
+    const Int m = B->m, n = B->n;
+    Vec invscale_basic(m, 0.0), ftran(m), btran(m), row(n + m);
+    for (Int p = 0; p < m; p++)
+        if (B->status_of(B->basis[p]) == ORC_BASIC) invscale_basic[p] = colscale ? 1.0 / colscale[B->basis[p]] : 1.0;
+    const double volumetol = std::max(volume_tol, 1.0);
+    Int updates = 0, skipped = 0, passes = 0, refused = 0, errflag = 0, tblnnz = 0;
+    double volinc = 0.0, tblmax = 0.0;
+    while (passes < maxpasses || maxpasses < 0) {
+        tblnnz = 0; tblmax = 0.0;
+        Int updates_last = 0;
+        std::vector<std::pair<double, Int>> cand(n + m);            // Sortperm(n+m, colscale, false), src/utils.cc:87-104
+        for (Int j = 0; j < n + m; j++) cand[j] = std::make_pair(colscale ? colscale[j] : 1.0, j);
+        std::sort(cand.begin(), cand.end());
+        while (!cand.empty()) {
+            const Int j = cand.back().second;
+            const double dj = cand.back().first;
+            if (dj == 0.0) break;
+            if (B->status_of(j) != ORC_NONBASIC) { cand.pop_back(); continue; }
+            B->solve_for_update(j, ftran.data());
+            Int pmax = -1;
+            double vmax = 0.0;
+            for (Int p = 0; p < m; p++) {
+                const double v = std::abs(ftran[p]) * invscale_basic[p] * dj;
+                if (v > vmax) { vmax = v; pmax = p; }
+                tblnnz += v != 0.0;
+            }
+            tblmax = std::max(tblmax, vmax);
+            if (vmax <= volumetol) { skipped++; cand.pop_back(); continue; }
+            const Int jb = B->basis[pmax];
+            B->tableau_row(jb, btran.data(), row.data(), false);     // (the BTRAN of the leaving variable; row[j] = pivot from the row)
+            bool exchanged = false;
+            errflag = B->exchange_if_stable(jb, j, row[j], &exchanged);
+            if (errflag) break;
+            if (!exchanged) { refused++; continue; }                 // refactorized: try the same candidate again
+            if (log && updates + updates_last < log_cap) { log[2 * (updates + updates_last)] = jb; log[2 * (updates + updates_last) + 1] = j; }
+            invscale_basic[pmax] = 1.0 / dj;
+            updates_last++;
+            volinc += std::log2(vmax);
+            cand.pop_back();
+        }
+        updates += updates_last;
+        passes++;
+        if (updates_last == 0 || errflag != 0) break;
+    }
+    info[0] = (double)updates; info[1] = (double)skipped; info[2] = (double)passes; info[3] = volinc;
+    info[4] = (double)refused; info[5] = (double)errflag; info[6] = (double)tblnnz; info[7] = tblmax;
+    return errflag;
+}
+
 extern "C" Int orc_maxvolume_heuristic(orc_basis* B, const double* colscale_in, double volume_tol, Int maxskip_updates,
                                        Int rows_per_slice, double* info, Int* log, Int log_cap) {
     const Int m = B->m, n = B->n;

@@ -249,6 +249,10 @@ void orc_basis_solve_dense(const orc_basis* B, const double* rhs, double* lhs, c
 void orc_basis_solve_for_update(orc_basis* B, orc_int j, double* lhs);
 void orc_basis_tableau_row(orc_basis* B, orc_int jb, double* btran, double* row, int ignore_fixed);
 orc_int orc_basis_exchange_if_stable(orc_basis* B, orc_int jb, orc_int jn, double tableau_entry, orc_int* exchanged);
+/* Maxvolume::RunSequential (src/maxvolume.cc:14-106); info[8] = updates, skipped, passes, volinc, refused, errflag,
+ * tblnnz and tblmax of the last pass; log: accepted exchanges (jb, jn) */
+orc_int orc_maxvolume_sequential(orc_basis* B, const double* colscale, double volume_tol, orc_int maxpasses, double* info,
+                                 orc_int* log, orc_int log_cap);
 orc_int orc_maxvolume_heuristic(orc_basis* B, const double* colscale, double volume_tol, orc_int maxskip_updates,
                                 orc_int rows_per_slice, double* info, orc_int* log, orc_int log_cap);
 

@@ -317,6 +317,7 @@ class OracleBasis:
         err = c_i64(0)
         self.lib.orc_basis_exchange_if_stable.restype = c_i64
         self.lib.orc_maxvolume_heuristic.restype = c_i64
+        self.lib.orc_maxvolume_sequential.restype = c_i64
         self.h = C.c_void_p(self.lib.orc_basis_new(c_i64(self.m), c_i64(self.n), _ip(self.keep[0]), _ip(self.keep[1]),
                                                    _fp(self.keep[2]), _ip(_I(basis)), _ip(_I(status)), c_i64(max_etas),
                                                    C.byref(err)))
@@ -355,6 +356,15 @@ class OracleBasis:
         k = int(info[0])
         return dict(errflag=int(err), updates=k, skipped=int(info[1]), slices=int(info[2]), volinc=float(info[3]),
                     refused=int(info[4]), exchanges=log[: 2 * min(k, log_cap)].reshape(-1, 2))
+
+    def maxvolume_sequential(self, colscale, volume_tol=2.0, maxpasses=-1, log_cap=100000):
+        info = np.zeros(8, f64)
+        log = np.zeros(2 * log_cap, i64)
+        err = self.lib.orc_maxvolume_sequential(self.h, _fp(_F(colscale)), c_f64(volume_tol), c_i64(maxpasses), _fp(info), _ip(log),
+                                                c_i64(log_cap))
+        k = int(info[0])
+        return dict(errflag=int(err), updates=k, skipped=int(info[1]), passes=int(info[2]), volinc=float(info[3]),
+                    refused=int(info[4]), tblnnz=int(info[6]), tblmax=float(info[7]), exchanges=log[: 2 * min(k, log_cap)].reshape(-1, 2))
 
     def close(self):
         if self.h:

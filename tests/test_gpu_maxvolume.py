@@ -77,3 +77,30 @@ def test_maxvolume_preconditions_and_no_op(kkt, po, oracle):
     if got["updates"] == 0:
         assert got["factorizations"] == 0 and np.array_equal(got["basis"], P["basis"])
     ctx.close()
+
+
+@pytest.mark.parametrize("m,n,bump,seed,free,fixed,max_etas", [(300, 700, 20, 4, 0, 0, 100), (200, 450, 15, 5, 3, 6, 4),
+                                                             (900, 2000, 40, 12, 2, 4, 25)])
+def test_maxvolume_sequential_vs_oracle(kkt, oracle, po, m, n, bump, seed, free, fixed, max_etas):
+    """Maxvolume::RunSequential (update_heuristic == 0) on the device against its CPU restatement: the same exchanges in
+    the same order, the same final basis and counters, and the operator of the new basis in the context"""
+    P, status, colscale, Ao = setup(po, m, n, bump, seed, num_free=free, num_fixed=fixed)
+    B = oracle.basis(Ao, P["basis"], status, max_etas=max_etas)
+    want = B.maxvolume_sequential(colscale, volume_tol=2.0)
+    assert want["errflag"] == 0 and want["updates"] > 5
+    ctx = kkt.KktContext(P["A"])
+    ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+    ctx.split_prepare_lu(status, colscale)
+    got = ctx.maxvolume_sequential(status, colscale, volume_tol=2.0, max_etas=max_etas)
+    assert got["errflag"] == 0
+    assert np.array_equal(got["exchanges"], want["exchanges"])
+    assert (got["updates"], got["skipped"], got["passes"], got["refused"]) == \
+        (want["updates"], want["skipped"], want["passes"], want["refused"])
+    assert got["volinc"] == pytest.approx(want["volinc"], rel=1e-9)
+    basis_o, status_o, _ = B.get()
+    assert np.array_equal(got["basis"], basis_o) and np.array_equal(got["status"], status_o)
+    Bm = basis_matrix(Ao, got["basis"])
+    rhs = np.random.default_rng(3).standard_normal(m)
+    x = ctx.solve_dense(rhs, "n")
+    assert np.abs(Bm @ x - rhs).max() <= 1e-8 * (1 + np.abs(x).max())
+    ctx.close()

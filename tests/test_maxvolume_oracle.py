@@ -93,3 +93,32 @@ def test_maxvolume_grows_the_volume(oracle, po, m, n, bump, seed, free, fixed):
         return ld / np.log(2.0)
     assert logvol(basis) - logvol(P["basis"]) == pytest.approx(r["volinc"], rel=1e-8, abs=1e-8)
     assert r["volinc"] >= r["updates"] * 1.0            # every exchange gained more than volume_tol = 2
+
+
+@pytest.mark.parametrize("m,n,bump,seed,free,fixed", [(120, 300, 8, 3, 0, 0), (200, 450, 15, 5, 3, 6)])
+def test_maxvolume_sequential_grows_the_volume(oracle, po, m, n, bump, seed, free, fixed):
+    """Maxvolume::RunSequential (src/maxvolume.cc:14-106, update_heuristic == 0): same defining properties as the
+    heuristic; after the last pass no NONBASIC column can enter with a volume gain above the tolerance"""
+    P, status, colscale, Ao = setup(po, m, n, bump, seed, num_free=free, num_fixed=fixed)
+    B = oracle.basis(Ao, P["basis"], status)
+    r = B.maxvolume_sequential(colscale, volume_tol=2.0)
+    assert r["errflag"] == 0 and r["updates"] > 0 and r["passes"] >= 2          # the last pass finds nothing
+    basis, status2, _ = B.get()
+    assert np.array_equal(np.nonzero(status2 == 1)[0], np.nonzero(status == 1)[0])
+    assert np.array_equal(np.nonzero(status2 == -2)[0], np.nonzero(status == -2)[0])
+    assert sorted(basis) == sorted(np.nonzero(status2 >= 0)[0]) and (status2 >= 0).sum() == m
+    def logvol(bs):
+        d = np.where(status[bs] == 1, 1.0, colscale[bs])
+        sign, ld = np.linalg.slogdet(basis_matrix(Ao, bs).toarray() * d)
+        assert sign != 0
+        return ld / np.log(2.0)
+    assert logvol(basis) - logvol(P["basis"]) == pytest.approx(r["volinc"], rel=1e-8, abs=1e-8)
+    assert r["volinc"] >= r["updates"] * 1.0
+    # the termination criterion, checked densely: every scaled tableau entry of a NONBASIC column is <= volume_tol
+    Bm = basis_matrix(Ao, basis).toarray()
+    AI = sp.hstack([sp.csc_matrix((Ao.x, Ao.i, Ao.p), shape=(m, n)), sp.identity(m)]).tocsc()
+    nb = np.nonzero(status2 == -1)[0]
+    T = np.linalg.solve(Bm, AI[:, nb].toarray())
+    inv = np.where(status2[basis] == 0, 1.0 / colscale[basis], 0.0)
+    V = np.abs(T) * inv[:, None] * colscale[nb][None, :]
+    assert V.max() <= 2.0 * (1 + 1e-9)
