@@ -280,7 +280,7 @@ __global__ void level_keys_kernel(int dim, int ascending, int by_length, const i
 __global__ void place_kernel(int dim, const int* __restrict__ sorted_key, const int* __restrict__ sorted_unknown,
                              const int* __restrict__ lstart, const int* __restrict__ lpos, const int* __restrict__ lsub,
                              const int* __restrict__ rp, const double* __restrict__ dgn, int* __restrict__ order,
-                             int* __restrict__ posof, double* __restrict__ diag, int* __restrict__ len) {
+                             int* __restrict__ posof, double* __restrict__ diag, int* __restrict__ len, int* bad_len) {
     IPXK_GRID_STRIDE(t, dim) {
         const int key = sorted_key[t], i = sorted_unknown[t];
         const int l = key >> kLenKeyBits;
@@ -289,7 +289,9 @@ __global__ void place_kernel(int dim, const int* __restrict__ sorted_key, const 
         order[pos] = i;
         posof[i] = pos;
         diag[pos] = dgn[i];
-        len[pos] = (rp[i + 1] - rp[i]) | (lsub[l] << kLenBits);     // lsub: the level's place inside a merged chunk
+        const int rowlen = rp[i + 1] - rp[i];
+        if (rowlen >= (1 << kLenBits)) *bad_len = 1;                // does not fit the len word: refused by the host
+        len[pos] = (rowlen & ((1 << kLenBits) - 1)) | (lsub[l] << kLenBits);     // lsub: the level's place inside a merged chunk
     }
 }
 
@@ -309,6 +311,9 @@ __global__ void chunk_size_kernel(int nchunks, ChunkDesc* __restrict__ chunks, c
     if (blockIdx.x == 0 && threadIdx.x == 0) size[nchunks] = 0;
 }
 
+__global__ void check_monotone_kernel(int n, const int* __restrict__ a, int* bad) {
+    IPXK_GRID_STRIDE(c, n) if (a[c + 1] < a[c] || a[c] < 0) *bad = 1;
+}
 __global__ void chunk_ent0_kernel(int nchunks, ChunkDesc* __restrict__ chunks, const int* __restrict__ ent0) {
     IPXK_GRID_STRIDE(c, nchunks) chunks[c].ent0 = ent0[c];
 }
@@ -566,18 +571,23 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
             W.lpos.ensure(lpos.size()); W.lsub.ensure(lsub.size());
             W.lpos.upload(lpos, s);
             W.lsub.upload(lsub, s);
+            DevBuf<int> too_long(3);                          // [0] merged long row beyond one round, [1] row beyond the len word, [2] slot count overflow
+            IPXK_HIP(hipMemsetAsync(too_long.get(), 0, 3 * sizeof(int), s));
             hipLaunchKernelGGL(place_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, W.keys2.get(), W.vals2.get(),
                                W.lstart.get(), W.lpos.get(), W.lsub.get(), W.rp.get(), W.dgn.get(), S.order.get(), S.posof.get(),
-                               S.diag.get(), S.len.get());
+                               S.diag.get(), S.len.get(), too_long.get() + 1);
             W.csize.ensure(nc1 + 1); W.cent0.ensure(nc1 + 1);
-            DevBuf<int> too_long(1);
-            IPXK_HIP(hipMemsetAsync(too_long.get(), 0, sizeof(int), s));
             hipLaunchKernelGGL(chunk_size_kernel, dim3(grid_for(nchunks)), dim3(kBlock), 0, s, nchunks, S.chunks.get(),
                                S.len.get(), W.csize.get(), too_long.get());
-            int tl = 0;
-            too_long.download(&tl, 1, s);
-            if (tl) return false;                             // a merged long row exceeds one round: lay out again without
             exclusive_scan(W, W.csize.get(), W.cent0.get(), (size_t)nchunks + 1, s);
+            // (the 32-bit running sum must not wrap: entry offsets are ints)
+            hipLaunchKernelGGL(check_monotone_kernel, dim3(grid_for(nchunks)), dim3(kBlock), 0, s, nchunks, W.cent0.get(), too_long.get() + 2);
+            int tl[3] = {0, 0, 0};
+            too_long.download(tl, 3, s);
+            if (tl[1] || tl[2])
+                throw Error(IPXK_E_UNSUPPORTED, tl[1] ? "a row of a triangular factor has 2^24 entries or more: beyond the packed sweep layout"
+                                                      : "the packed triangular factor needs 2^31 entry slots or more: beyond the packed sweep layout");
+            if (tl[0]) return false;                          // a merged long row exceeds one round: lay out again without
             hipLaunchKernelGGL(chunk_ent0_kernel, dim3(grid_for(nchunks)), dim3(kBlock), 0, s, nchunks, S.chunks.get(), W.cent0.get());
             IPXK_HIP(hipMemcpyAsync(W.h_flag, W.cent0.get() + nchunks, sizeof(int), hipMemcpyDeviceToHost, s));
             IPXK_HIP(hipStreamSynchronize(s));

@@ -27,7 +27,8 @@ constexpr int kLenKeyBits = 8;   // sort key = level << kLenKeyBits | (255 - min
 // instead of memory -- a chain of tiny levels costs ~0.15 us per level instead of one memory hand-off each.
 // The per-position sub-level is kept in the upper half of `len` (kLenBits).
 struct ChunkDesc { int pos0, ent0, width, npos, sub, pad0, pad1, pad2; };
-constexpr int kLenBits = 16;            // len word of a position: entries | sub-level << kLenBits
+constexpr int kLenBits = 24;            // len word of a position: entries | sub-level << kLenBits (a row of a factor with spikes
+                                        // can hold a large part of the dimension: 16 bits were too few)
 constexpr int kMaxSubLevels = 32;
 
 // A sweep reads its right-hand side through `src` (position -> index into the input vector, -1 for

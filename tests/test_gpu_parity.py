@@ -542,6 +542,42 @@ def test_split_prepare_rejects_bad_factors(kkt):
     ctx.close()
 
 
+def test_sweeps_with_a_spike_of_70000_entries(kkt, po, oracle):
+    """factors as a torn LU leaves them (lu.hip step 2b): columns of U that hold most of the dimension -- more than
+    65 535 entries, which the packed layout's 16-bit row length could not hold (a GPU memory fault at 1M rows before
+    the length word was widened to 24 bits) -- and the rows of U that cross them; L empty, two spikes, a sparse rest"""
+    import scipy.sparse as sp
+    from ipx_amd.synth import CscMatrix
+    m, n = 72000, 150000
+    rng = np.random.default_rng(5)
+    rows, cols = [], []
+    for j in range(1, m - 2):                                     # one random entry above the diagonal in most columns
+        if rng.random() < 0.7:
+            rows.append(rng.integers(0, j)); cols.append(j)
+    for j, cnt in ((m - 1, 70000), (m - 2, 66000)):              # the spikes
+        r = rng.choice(j, size=cnt, replace=False)
+        rows += list(r); cols += [j] * cnt
+    rows, cols = np.array(rows), np.array(cols)
+    vals = rng.uniform(0.05, 0.3, rows.size) * rng.choice([-1.0, 1.0], rows.size) / np.sqrt(1 + np.bincount(cols, minlength=m)[cols])
+    Um = (sp.coo_matrix((vals, (rows, cols)), shape=(m, m)) + sp.diags(rng.uniform(0.5, 2.0, m) * rng.choice([-1.0, 1.0], m))).tocsc()
+    Um.sum_duplicates(); Um.sort_indices()
+    U = CscMatrix(m, m, Um.indptr, Um.indices, Um.data)
+    A = synth_identity_model(m, n)
+    ctx = kkt.KktContext(A)
+    ident = np.arange(m, dtype=np.int64)
+    status = np.full(n + m, -1, dtype=np.int64); status[:m] = 0
+    colscale = np.ones(n + m)
+    ctx.split_prepare(synth_csc_empty(m), U, ident, ident, ident, status, colscale)
+    rhs = rng.standard_normal(m)
+    Lnone = po.Csc(m, m, np.zeros(m + 1, np.int64), np.zeros(0, np.int64), np.zeros(0))
+    Uo = ocsc(po, U)
+    # U' (transposed, ascending): every row in the reference's order, the 70000-entry ones included
+    assert np.array_equal(ctx.solve_dense(rhs, "T"), oracle.backward_solve(Lnone, Uo, rhs))
+    # U (forward, descending): rows crossing the spikes
+    assert np.array_equal(ctx.solve_dense(rhs, "N"), oracle.forward_solve(Lnone, Uo, rhs))
+    ctx.close()
+
+
 @pytest.mark.parametrize("mode", ["default", "allxcd", "onexcd", "nomerge"])
 def test_sweeps_with_dense_rows_and_columns(kkt, po, oracle, monkeypatch, mode):
     """factors with a few rows AND columns of 70 / 300 / 1500 entries next to short ones: rows longer than
