@@ -478,7 +478,8 @@ void GatherMatrix::build_sorted_fused(const ipxint* hptr, const ipxint* hidx, co
         max_sub = 0;
         for (int t = 0; t < nrb; t++) { max_sub = std::max(max_sub, (int)sptr[t + 1]); sptr[t + 1] += sptr[t]; }
         nshort = sptr[nrb];
-        if (max_sub <= kSortedMaxSub) break;
+        static const int cap = [] { const char* e = getenv("IPXK_SF_MAXSUB"); return e && atoi(e) >= 256 ? std::min(atoi(e), kSortedMaxSub) : kSortedMaxSub; }();
+        if (max_sub <= cap) break;
     }
     if (nshort == 0) return;
     std::vector<int> xmin((size_t)nrb, 0);

@@ -713,59 +713,6 @@ static void finish_prepare(Context* c, SplitOperator* S, const ipxint* status, c
     IPXK_HIP(hipStreamSynchronize(s));
 }
 
-void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const double* Lx,
-                        const ipxint* Up, const ipxint* Ui, const double* Ux, const ipxint* rowperm,
-                        const ipxint* colperm, const ipxint* basis, const ipxint* status,
-                        const double* colscale) {
-    const int m = (int)c->m, n = (int)c->n;
-    hipStream_t s = c->stream;
-    IPXK_REQUIRE(c->nranks == 1, "the basis path does not shard: run it as independent replicas");
-    IPXK_REQUIRE(Lp[m] < (int64_t(1) << 31) && Up[m] < (int64_t(1) << 31), "factor nnz exceeds 32 bits");
-    IPXK_REQUIRE(Lp[0] == 0 && Up[0] == 0, "column pointers must start at 0");
-    for (int k = 0; k < m; k++) {
-        IPXK_REQUIRE(Lp[k + 1] >= Lp[k] && Up[k + 1] > Up[k] && Up[k + 1] <= Up[m] && Lp[k + 1] <= Lp[m],
-                     "factor column pointers not monotone");
-        IPXK_REQUIRE(Ui[Up[k + 1] - 1] == k, "U must hold its diagonal last in each column");
-        IPXK_REQUIRE(basis[k] >= 0 && basis[k] < n + m, "basis entry out of range");
-        IPXK_REQUIRE(rowperm[k] >= 0 && rowperm[k] < m && colperm[k] >= 0 && colperm[k] < m, "permutation entry out of range");
-    }
-    {   // rowperm, colperm are permutations; basis entries distinct is the caller's contract
-        std::vector<unsigned char> seen_r(m, 0), seen_c(m, 0);
-        for (int k = 0; k < m; k++) {
-            IPXK_REQUIRE(!seen_r[rowperm[k]] && !seen_c[colperm[k]], "rowperm / colperm is not a permutation");
-            seen_r[rowperm[k]] = seen_c[colperm[k]] = 1;
-        }
-    }
-    // the operator object (and its device buffers) is reused from one Prepare to the next; while it is
-    // being rebuilt the context has no operator, and a failure leaves it that way
-    std::unique_ptr<SplitOperator> S(c->split ? c->split : new SplitOperator);
-    c->split = nullptr;
-    S->m = m;
-    if (const char* e = getenv("IPXK_TRISOLVE")) S->level_launches = std::string(e) == "levels";
-
-    const bool verbose = getenv("IPXK_VERBOSE") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double tp0 = now();
-    S->bump_start = S->bump_size = 0;          // factors from the host: no dense block is known
-    analyse_sweeps_device(c, S.get(), Lp, Li, Lx, Up, Ui, Ux);
-    const double tp1 = now();
-    // permutations (InversePerm, utils.cc:73-80) and bookkeeping for KKTSolverBasis::_Solve
-    {
-        std::vector<int> rpm(m), rpi(m), cpm(m), bs(m);
-        for (int i = 0; i < m; i++) { rpm[i] = (int)rowperm[i]; cpm[i] = (int)colperm[i]; bs[i] = (int)basis[i]; }
-        for (int i = 0; i < m; i++) rpi[rpm[i]] = i;
-        S->rowperm.upload(rpm, s);
-        S->rowperm_inv.upload(rpi, s);
-        S->colperm.upload(cpm, s);
-        S->basis.upload(bs, s);
-    }
-    finish_prepare(c, S.get(), status, colscale);
-    if (verbose)
-        fprintf(stderr, "ipxk: split_prepare: analysis and packing %.1f ms, permutations/scaling %.1f ms\n",
-                (tp1 - tp0) * 1e3, (now() - tp1) * 1e3);
-    c->split = S.release();
-}
-
 // ---------------------------------------------------------------------------
 // The dense bump of an LU from the device (SplitOperator::bump_*, trisolve.hpp)
 // ---------------------------------------------------------------------------
@@ -923,6 +870,131 @@ static void bump_between(Context* c, bool trans, double* y, const int* done) {
                             S->bump_invU.get(), S->bump_pos_fwd.get(), y, done);
 }
 
+// Cuts the trailing block [s0, s0 + kb) = [s0, m) out of the factors: D22 = (L22 + I) U22 goes to S->bumpD (dense, with
+// the inverted 64 x 64 diagonal blocks), the returned factors are L without L22 and U with U22 replaced by I (trisolve.hpp).
+// Exact for ANY trailing block; it pays when the block is (nearly) dense.
+struct CutBuffers { DevBuf<ipxint> TLp, TUp, TUi; DevBuf<double> TUx; };
+static DeviceFactors cut_dense_block(Context* c, SplitOperator* S, const DeviceFactors& in, int s0, int kb, CutBuffers& B) {
+    hipStream_t s = c->stream;
+    const int m = S->m, nblk = (kb + 63) / 64;
+    S->bumpD.ensure((size_t)kb * kb);
+    IPXK_HIP(hipMemsetAsync(S->bumpD.get(), 0, (size_t)kb * kb * sizeof(double), s));
+    hipLaunchKernelGGL(bump_extract_kernel, dim3(vec_grid(kb)), dim3(kBlock), 0, s, s0, kb, in.Lp, in.Li, in.Lx, in.Up, in.Ui,
+                       in.Ux, S->bumpD.get());
+    DevBuf<int> cnt((size_t)m), start((size_t)m);
+    hipLaunchKernelGGL(bump_ucount_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, m, s0, in.Up, in.Ui, cnt.get());
+    hipLaunchKernelGGL(bump_ustart_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, m, s0, in.Up, cnt.get(), start.get());
+    hipLaunchKernelGGL(bump_ustart_tail_kernel, dim3(1), dim3(1), 0, s, m, s0, in.Up, cnt.get(), start.get());
+    B.TLp.resize((size_t)m + 1); B.TUp.resize((size_t)m + 1);
+    B.TUi.resize((size_t)std::max<int64_t>(in.nzU, 1)); B.TUx.resize((size_t)std::max<int64_t>(in.nzU, 1));
+    hipLaunchKernelGGL(bump_ufill_kernel, dim3(vec_grid(m + 1)), dim3(kBlock), 0, s, m, s0, in.Up, in.Ui, in.Ux, start.get(), cnt.get(),
+                       B.TUp.get(), B.TUi.get(), B.TUx.get(), in.Lp, B.TLp.get());
+    ipxint ends[2] = {0, 0};
+    IPXK_HIP(hipMemcpyAsync(&ends[0], B.TLp.get() + m, sizeof(ipxint), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipMemcpyAsync(&ends[1], B.TUp.get() + m, sizeof(ipxint), hipMemcpyDeviceToHost, s));
+    S->bump_invL.ensure((size_t)nblk * 64 * 64); S->bump_invU.ensure((size_t)nblk * 64 * 64);
+    hipLaunchKernelGGL(bump_invert_blocks_kernel, dim3(nblk), dim3(64), 0, s, kb, S->bumpD.get(), S->bump_invL.get(), 0);
+    hipLaunchKernelGGL(bump_invert_blocks_kernel, dim3(nblk), dim3(64), 0, s, kb, S->bumpD.get(), S->bump_invU.get(), 1);
+    IPXK_HIP(hipStreamSynchronize(s));               // cnt / start go out of scope; ends
+    S->bump_start = s0;
+    S->bump_size = kb;
+    return DeviceFactors{B.TLp.get(), in.Li, B.TUp.get(), B.TUi.get(), in.Lx, B.TUx.get(), ends[0], ends[1]};
+}
+
+// A dense trailing block in factors that come from the host (the dense bump of an LU kernel -- lu.hip's or any other
+// -- is pivoted last): the longest suffix of columns of L that are at least half full below the diagonal.  Where
+// the device computed the factors it knows the block (LuView); factors handed over by ipx::Basis have gone through
+// the host, and without this a 2000-row bump is a chain of 2000 dependency levels (12 ms per operator application
+// against 1 ms with the block cut out: the drop-in class on the IPM's random LPs).
+static int trailing_dense_block(int m, const ipxint* Lp) {
+    int s0 = m;
+    for (int j = m - 2; j >= 0; j--) {
+        const int64_t below = m - 1 - j, have = Lp[j + 1] - Lp[j];
+        if (2 * have < below) break;
+        s0 = j;
+    }
+    return m - s0 >= 2 ? s0 : m;
+}
+
+void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const double* Lx,
+                        const ipxint* Up, const ipxint* Ui, const double* Ux, const ipxint* rowperm,
+                        const ipxint* colperm, const ipxint* basis, const ipxint* status,
+                        const double* colscale) {
+    const int m = (int)c->m, n = (int)c->n;
+    hipStream_t s = c->stream;
+    IPXK_REQUIRE(c->nranks == 1, "the basis path does not shard: run it as independent replicas");
+    IPXK_REQUIRE(Lp[m] < (int64_t(1) << 31) && Up[m] < (int64_t(1) << 31), "factor nnz exceeds 32 bits");
+    IPXK_REQUIRE(Lp[0] == 0 && Up[0] == 0, "column pointers must start at 0");
+    for (int k = 0; k < m; k++) {
+        IPXK_REQUIRE(Lp[k + 1] >= Lp[k] && Up[k + 1] > Up[k] && Up[k + 1] <= Up[m] && Lp[k + 1] <= Lp[m],
+                     "factor column pointers not monotone");
+        IPXK_REQUIRE(Ui[Up[k + 1] - 1] == k, "U must hold its diagonal last in each column");
+        IPXK_REQUIRE(basis[k] >= 0 && basis[k] < n + m, "basis entry out of range");
+        IPXK_REQUIRE(rowperm[k] >= 0 && rowperm[k] < m && colperm[k] >= 0 && colperm[k] < m, "permutation entry out of range");
+    }
+    {   // rowperm, colperm are permutations; basis entries distinct is the caller's contract
+        std::vector<unsigned char> seen_r(m, 0), seen_c(m, 0);
+        for (int k = 0; k < m; k++) {
+            IPXK_REQUIRE(!seen_r[rowperm[k]] && !seen_c[colperm[k]], "rowperm / colperm is not a permutation");
+            seen_r[rowperm[k]] = seen_c[colperm[k]] = 1;
+        }
+    }
+    // the operator object (and its device buffers) is reused from one Prepare to the next; while it is
+    // being rebuilt the context has no operator, and a failure leaves it that way
+    std::unique_ptr<SplitOperator> S(c->split ? c->split : new SplitOperator);
+    c->split = nullptr;
+    S->m = m;
+    if (const char* e = getenv("IPXK_TRISOLVE")) S->level_launches = std::string(e) == "levels";
+
+    const bool verbose = getenv("IPXK_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tp0 = now();
+    S->bump_start = S->bump_size = 0;
+    {
+        // factors as given, on the device; a dense trailing block (the bump of the LU) is cut out of the sweeps
+        DevBuf<ipxint> dLp, dLi, dUp, dUi;
+        DevBuf<double> dLx, dUx;
+        const int64_t nzL = Lp[m], nzU = Up[m];
+        dLp.upload(Lp, (size_t)m + 1, s); dUp.upload(Up, (size_t)m + 1, s);
+        dLi.upload(Li, (size_t)nzL, s);   dLx.upload(Lx, (size_t)nzL, s);
+        dUi.upload(Ui, (size_t)nzU, s);   dUx.upload(Ux, (size_t)nzU, s);
+        dLi.ensure(1); dLx.ensure(1);
+        const DeviceFactors F0{dLp.get(), dLi.get(), dUp.get(), dUi.get(), dLx.get(), dUx.get(), nzL, nzU};
+        const char* dense_env = getenv("IPXK_BUMP_DENSE");
+        const int bump_min = getenv("IPXK_BUMP_MIN") ? atoi(getenv("IPXK_BUMP_MIN")) : kBumpMin;
+        const int s0 = m > 0 ? trailing_dense_block(m, Lp) : m;
+        CutBuffers cut;
+        if (m - s0 >= bump_min && m - s0 <= 8192 && !(dense_env && dense_env[0] == '0')) {
+            const DeviceFactors F = cut_dense_block(c, S.get(), F0, s0, m - s0, cut);
+            analyse_sweeps_resident(c, S.get(), F, nullptr, nullptr, nullptr, nullptr);
+        } else {
+            analyse_sweeps_resident(c, S.get(), F0, Lp, Li, Up, Ui);
+        }
+        if (S->bump_size > 0) {
+            S->bump_pos_fwd.ensure((size_t)S->bump_size); S->bump_pos_bwd.ensure((size_t)S->bump_size);
+            hipLaunchKernelGGL(bump_positions_kernel, dim3(vec_grid(S->bump_size)), dim3(kBlock), 0, s, S->bump_start, S->bump_size,
+                               S->Lf.posof.get(), S->Ut.posof.get(), S->bump_pos_fwd.get(), S->bump_pos_bwd.get());
+        }
+        IPXK_HIP(hipStreamSynchronize(s));           // the uploaded factors go out of scope
+    }
+    const double tp1 = now();
+    // permutations (InversePerm, utils.cc:73-80) and bookkeeping for KKTSolverBasis::_Solve
+    {
+        std::vector<int> rpm(m), rpi(m), cpm(m), bs(m);
+        for (int i = 0; i < m; i++) { rpm[i] = (int)rowperm[i]; cpm[i] = (int)colperm[i]; bs[i] = (int)basis[i]; }
+        for (int i = 0; i < m; i++) rpi[rpm[i]] = i;
+        S->rowperm.upload(rpm, s);
+        S->rowperm_inv.upload(rpi, s);
+        S->colperm.upload(cpm, s);
+        S->basis.upload(bs, s);
+    }
+    finish_prepare(c, S.get(), status, colscale);
+    if (verbose)
+        fprintf(stderr, "ipxk: split_prepare: analysis and packing %.1f ms, permutations/scaling %.1f ms\n",
+                (tp1 - tp0) * 1e3, (now() - tp1) * 1e3);
+    c->split = S.release();
+}
+
 // 64-bit permutations / basis list on the device -> the operator's 32-bit copies (+ InversePerm, utils.cc:73-80)
 __global__ void perms_from_lu_kernel(int m, const ipxint* __restrict__ rowperm, const ipxint* __restrict__ colperm,
                                      const ipxint* __restrict__ basis, int* __restrict__ rpm, int* __restrict__ rpi,
@@ -954,36 +1026,12 @@ void split_prepare_lu(Context* c, const ipxint* status, const double* colscale) 
     if (const char* e = getenv("IPXK_TRISOLVE")) S->level_launches = std::string(e) == "levels";
     // the dense bump leaves the level-scheduled structure (SplitOperator::bump_*)
     DeviceFactors F = V.F;
-    DevBuf<ipxint> TLp, TUp, TUi;
-    DevBuf<double> TUx;
+    CutBuffers cut;
     S->bump_start = S->bump_size = 0;
     const char* dense_env = getenv("IPXK_BUMP_DENSE");
     const int bump_min = getenv("IPXK_BUMP_MIN") ? atoi(getenv("IPXK_BUMP_MIN")) : kBumpMin;      // (tests)
-    if (V.bump_size >= bump_min && V.bump_size > 0 && V.bump_start + V.bump_size == m && !(dense_env && dense_env[0] == '0')) {
-        const int s0 = V.bump_start, kb = V.bump_size, nblk = (kb + 63) / 64;
-        S->bumpD.ensure((size_t)kb * kb);
-        IPXK_HIP(hipMemsetAsync(S->bumpD.get(), 0, (size_t)kb * kb * sizeof(double), s));
-        hipLaunchKernelGGL(bump_extract_kernel, dim3(vec_grid(kb)), dim3(kBlock), 0, s, s0, kb, V.F.Lp, V.F.Li, V.F.Lx, V.F.Up, V.F.Ui,
-                           V.F.Ux, S->bumpD.get());
-        DevBuf<int> cnt((size_t)m), start((size_t)m);
-        hipLaunchKernelGGL(bump_ucount_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, m, s0, V.F.Up, V.F.Ui, cnt.get());
-        hipLaunchKernelGGL(bump_ustart_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, m, s0, V.F.Up, cnt.get(), start.get());
-        hipLaunchKernelGGL(bump_ustart_tail_kernel, dim3(1), dim3(1), 0, s, m, s0, V.F.Up, cnt.get(), start.get());
-        TLp.resize((size_t)m + 1); TUp.resize((size_t)m + 1);
-        TUi.resize((size_t)std::max<int64_t>(V.F.nzU, 1)); TUx.resize((size_t)std::max<int64_t>(V.F.nzU, 1));
-        hipLaunchKernelGGL(bump_ufill_kernel, dim3(vec_grid(m + 1)), dim3(kBlock), 0, s, m, s0, V.F.Up, V.F.Ui, V.F.Ux, start.get(), cnt.get(),
-                           TUp.get(), TUi.get(), TUx.get(), V.F.Lp, TLp.get());
-        ipxint ends[2] = {0, 0};
-        IPXK_HIP(hipMemcpyAsync(&ends[0], TLp.get() + m, sizeof(ipxint), hipMemcpyDeviceToHost, s));
-        IPXK_HIP(hipMemcpyAsync(&ends[1], TUp.get() + m, sizeof(ipxint), hipMemcpyDeviceToHost, s));
-        S->bump_invL.ensure((size_t)nblk * 64 * 64); S->bump_invU.ensure((size_t)nblk * 64 * 64);
-        hipLaunchKernelGGL(bump_invert_blocks_kernel, dim3(nblk), dim3(64), 0, s, kb, S->bumpD.get(), S->bump_invL.get(), 0);
-        hipLaunchKernelGGL(bump_invert_blocks_kernel, dim3(nblk), dim3(64), 0, s, kb, S->bumpD.get(), S->bump_invU.get(), 1);
-        IPXK_HIP(hipStreamSynchronize(s));               // cnt / start go out of scope; ends
-        F = DeviceFactors{TLp.get(), V.F.Li, TUp.get(), TUi.get(), V.F.Lx, TUx.get(), ends[0], ends[1]};
-        S->bump_start = s0;
-        S->bump_size = kb;
-    }
+    if (V.bump_size >= bump_min && V.bump_size > 0 && V.bump_start + V.bump_size == m && !(dense_env && dense_env[0] == '0'))
+        F = cut_dense_block(c, S.get(), V.F, V.bump_start, V.bump_size, cut);
     analyse_sweeps_resident(c, S.get(), F, nullptr, nullptr, nullptr, nullptr);
     const size_t mm = (size_t)std::max(m, 1);
     if (S->bump_size > 0) {

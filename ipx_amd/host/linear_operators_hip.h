@@ -5,8 +5,12 @@
 #ifndef IPX_LINEAR_OPERATORS_HIP_H_
 #define IPX_LINEAR_OPERATORS_HIP_H_
 
+#include <vector>
+
+#include "basis.h"
 #include "hip_device.h"
 #include "linear_operator.h"
+#include "sparse_matrix.h"
 
 namespace ipx {
 
@@ -38,10 +42,23 @@ private:
     HipModel& device_;
 };
 
-// reference src/splitted_normal_matrix.h:25-67 (prepared through ipxk_split_prepare)
+// reference src/splitted_normal_matrix.h:25-67
 class SplittedNormalMatrixHip : public LinearOperator {
 public:
     explicit SplittedNormalMatrixHip(HipModel& device) : device_(device) {}
+    // SplittedNormalMatrix::Prepare (src/splitted_normal_matrix.cc:18-66): the fresh LU factors of @basis
+    // (Basis::GetLuFactors, src/basis.cc:162-166), the basis, the variable statuses and @colscale go to the device
+    void Prepare(const Basis& basis, const double* colscale) {
+        const Model& model = basis.model();
+        const Int m = model.rows(), n = model.cols();
+        SparseMatrix L, U;
+        std::vector<Int> rowperm(m), colperm(m), status(n + m), basic(m);
+        basis.GetLuFactors(&L, &U, rowperm.data(), colperm.data());
+        for (Int j = 0; j < n + m; j++) status[j] = basis.StatusOf(j);
+        for (Int p = 0; p < m; p++) basic[p] = basis[p];
+        HipCheck(ipxk_split_prepare(device_.get(), L.colptr(), L.rowidx(), L.values(), U.colptr(), U.rowidx(), U.values(),
+                                    rowperm.data(), colperm.data(), basic.data(), status.data(), colscale));
+    }
 private:
     void _Apply(const Vector& rhs, Vector& lhs, double* rhs_dot_lhs) override {
         HipCheck(ipxk_split_apply(device_.get(), &rhs[0], &lhs[0], rhs_dot_lhs));

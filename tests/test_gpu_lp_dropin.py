@@ -259,3 +259,20 @@ def test_synthetic_lp_through_both_solvers(tmp_path, m, n, seed, params):
              hi["time_kkt_factorize"], hi["lu_device_seconds"], hi["lu_factorizations"], hi["lu_max_bump"]))
     print("the reference's CPU SplittedNormalMatrix::Prepare that KKTSolverBasis::_Factorize runs and KKTSolverBasisHip discards: "
           "%.2f ms per IPM iteration (%d calls)" % (1e3 * hi["cpu_prepare_seconds"] / max(hi["cpu_prepare_calls"], 1), hi["cpu_prepare_calls"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,seed", [(300, 700, 3), (1500, 3500, 12345)])
+def test_basis_classes_object_against_object(m, n, seed):
+    """oracle/_ref/test_basis_dropin (tests/dropin/basis_main.cc): on ONE ipx::Basis built by the reference
+    (StartingBasis, then KKTSolverBasis::Factorize with Maxvolume until it settles) the reference's
+    SplittedNormalMatrix against SplittedNormalMatrixHip (single application 1e-10; the reference's own CR loop over
+    either operator: same iteration count) and KKTSolverBasis::Solve against KKTSolverBasisHip::Solve (iteration
+    counts, x and y to 1e-6 at tol 1e-9) -- the two oracle rows a8 / a14 against the reference itself"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "test_basis_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/test_basis_dropin not built (needs the reference sources at build time)")
+    r = subprocess.run([exe, str(m), str(n), str(seed)], capture_output=True, text=True, timeout=900)
+    print(r.stdout, r.stderr[-2000:])
+    assert r.returncode == 0 and "DONE" in r.stdout, r.stdout + r.stderr[-2000:]
+    assert r.stdout.count("PASS") == 3
