@@ -121,6 +121,10 @@ struct SplitOperator {
     int bump_start = 0, bump_size = 0;     // 0: no dense block
     DevBuf<double> bumpD;                  // bump_size^2, column major: U22 on and above the diagonal, L22 below
     DevBuf<double> bump_invL, bump_invU;   // inverted 64 x 64 diagonal blocks of L22+I and of U22
+    // large blocks: inverse(D22) itself, row major, and its transpose (bump_size^2 each; empty for small blocks) --
+    // the solve between the sweeps of a pair is then ONE matrix-vector product spread over the chip
+    DevBuf<double> bump_inv, bump_invT, bump_x;
+    bool bump_explicit = false;
     DevBuf<int> bump_pos_fwd, bump_pos_bwd;   // position of bump unknown t in the result of the L sweep / of the U' sweep
 };
 

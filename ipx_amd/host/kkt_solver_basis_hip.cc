@@ -41,7 +41,11 @@ void KKTSolverBasisHip::_Factorize(Iterate* iterate, Info* info) {
     // _Factorize is one private function, so this also runs its CPU SplittedNormalMatrix::Prepare,
     // whose result is not used here: duplicated O(nnz) host work per IPM iteration that only a change
     // inside src/kkt_solver_basis.cc could remove -- see INTEGRATION.md.)
+    // (KKTSolver::Factorize, src/kkt_solver.cc:8-12, adds its elapsed time to info->time_kkt_factorize; the wrapper
+    // around THIS function adds the whole, so the inner share is taken back out)
+    const double time_kkt_factorize = info->time_kkt_factorize;
     cpu_.Factorize(iterate, info);
+    info->time_kkt_factorize = time_kkt_factorize;
     if (info->errflag)
         return;
     // The device keeps the factors of the previous hand-off.  They are still the factors Basis holds iff no LU
