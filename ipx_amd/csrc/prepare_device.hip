@@ -614,6 +614,7 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
         IPXK_REQUIRE(ok, "chunk layout failed");
     }
     if (scale_mode) { S.valS.ensure(ns1); S.diagS.ensure(np1); }
+    build_sweep_blocks(c, S, level_launches);
     plan_sweep(S, level_launches);
     IPXK_HIP(hipStreamSynchronize(s));    // host vectors uploaded above go out of scope
     if (getenv("IPXK_SWEEP_STATS")) {

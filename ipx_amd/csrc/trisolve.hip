@@ -62,7 +62,8 @@ constexpr int kSpinLimit = 1 << 22;                 // polls (>= 0.2 us each) be
 constexpr int kSweepGrid = 256;      // workgroups of an all-XCD run (one per CU: all resident)
 constexpr int kSweepXcdWgs = 32;     // participating workgroups of a one-XCD run (one per CU of an XCD)
 constexpr int kNarrowLevel = 96;     // levels of up to this many chunks may join a one-XCD run
-constexpr int kMinXcdLevels = 4;     // shorter runs of narrow levels are not worth a launch of their own
+constexpr int kMinXcdLevels = 10;    // shorter runs of narrow levels are not worth a launch of their own (4 until round 3: with the
+                                     // inverted blocks below, the 6-10 level runs left next to them cost 5-10 us more than they saved)
 
 __device__ __forceinline__ gu64 load_sc1(const gu64* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bypasses L1, served by L2 / fabric
@@ -327,6 +328,10 @@ __device__ __forceinline__ ChunkDesc scalar_desc(const ChunkDesc& v) {   // wave
 
 // the wavefront's chunks c, c + NW, ... < c1; A holds the records of chunk c (descriptor d), dn is the
 // descriptor of chunk c + NW
+// (Round 3, measured and dropped: THREE chunks in flight per wavefront -- the first look at the dependencies of chunk
+// c + NW and its right-hand side issued before chunk c waits, the records of chunk c + 2 NW behind them.  The wide
+// levels move 11 G unknowns/s = 6.5 us per chunk and wavefront, which looks like a lack of overlapped round trips;
+// but the deeper pipeline made both pairs slower, backward 272 -> 288 us, forward 300 -> 314 us.)
 template <bool RUNNING, bool MERGED, class Hand>
 __device__ __forceinline__ void chunk_loop(const SweepView& S, int c, int c1, int NW, int lane, const double* __restrict__ xin,
                                            const Hand& H, LaneRec& A, ChunkDesc d, ChunkDesc dn, int* abort_flag) {
@@ -469,6 +474,217 @@ __global__ __launch_bounds__(kBlock) void split_finish_kernel(int m, const doubl
 }
 
 // ---------------------------------------------------------------------------
+// inverted head / tail of a sweep (Sweep::Block, trisolve.hpp)
+// ---------------------------------------------------------------------------
+constexpr int kBlockInvThreads = 1024;
+// slot of entry e of a row whose first entry sits at `base` (base < 0: a row of a long chunk, -(slot + 1))
+__device__ __forceinline__ int row_slot(int base, int e) {
+    return base >= 0 ? base + e * 64 : (-base - 1) + (e >> 3) * 64 + (e & 7);
+}
+// per block row: how many of its entries look at positions in front of the block (< p0) / inside it
+__global__ void block_count_kernel(int K, int p0, const int* __restrict__ tpos, const int* __restrict__ base, const int* __restrict__ len,
+                                   const int* __restrict__ idx, int* __restrict__ hcnt, int* __restrict__ tcnt) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < K; t += gridDim.x * blockDim.x) {
+        const int L = len[tpos[t]] & ((1 << kLenBits) - 1), b = base[t];
+        int h = 0;
+        for (int e = 0; e < L; e++) h += idx[row_slot(b, e)] < p0 ? 1 : 0;
+        hcnt[t] = h;
+        tcnt[t] = L - h;
+    }
+}
+// outside entries -> their slots (row order kept); inside entries -> (block rank of the dependency, unscaled value)
+__global__ void block_fill_kernel(int K, int p0, const int* __restrict__ tpos, const int* __restrict__ base, const int* __restrict__ len,
+                                  const int* __restrict__ idx, const double* __restrict__ val, const int* __restrict__ rank_of_pos,
+                                  const int* __restrict__ hptr, const int* __restrict__ tptr, int* __restrict__ hslot,
+                                  int* __restrict__ hidx, int* __restrict__ tcol, double* __restrict__ tval) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < K; t += gridDim.x * blockDim.x) {
+        const int L = len[tpos[t]] & ((1 << kLenBits) - 1), b = base[t];
+        int h = hptr[t], q = tptr[t];
+        for (int e = 0; e < L; e++) {
+            const int slot = row_slot(b, e), j = idx[slot];
+            if (j < p0) { hslot[h] = slot; hidx[h] = j; h++; }
+            else { tcol[q] = rank_of_pos[j - p0]; tval[q] = val[slot]; q++; }
+        }
+    }
+}
+// M = inverse(T22), T22 = diag + the inside entries, lower triangular in block order.  A workgroup owns 64 columns of M
+// (lane = column) and walks the block's levels; the rows of a level are independent and shared among the wavefronts.
+// Row i of the columns j0.. needs the rows k < i of the SAME columns: written by this workgroup in earlier levels.
+__global__ __launch_bounds__(kBlockInvThreads) void block_inverse_kernel(int K, int nlev, const int* __restrict__ lev, const int* __restrict__ tptr,
+                                                                         const int* __restrict__ tcol, const double* __restrict__ tval,
+                                                                         const double* __restrict__ dg, const int* __restrict__ tpos,
+                                                                         double* M) {
+    const int j0 = blockIdx.x * 64, j = j0 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+    for (int l = 0; l < nlev; l++) {
+        const int r1 = lev[l + 1];
+        for (int i = lev[l] + wave; i < r1; i += kBlockInvThreads / 64) {
+            if (i < j0) continue;                                  // rows above the block's first column: zero (M is pre-filled)
+            double s2 = i == j ? 1.0 : 0.0;
+            for (int e = tptr[i]; e < tptr[i + 1]; e++) {
+                const int k = tcol[e];
+                if (k >= j0 && j < K) s2 -= tval[e] * M[(size_t)k * K + j];
+            }
+            if (j < K) M[(size_t)i * K + j] = s2 / dg[tpos[i]];
+        }
+        __syncthreads();                                           // (workgroup-scope release / acquire of the rows just written)
+    }
+}
+// right-hand side of block unknown l as the block's kernels read it: xin[zsrc[l]]
+__global__ void block_zsrc_kernel(int K, const int* __restrict__ tpos, const int* __restrict__ src, int* __restrict__ zsrc) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < K; t += gridDim.x * blockDim.x) zsrc[t] = src[tpos[t]];
+}
+// z[t] = (rhs of block row t minus its outside entries, all final: the launches of the earlier levels are over)
+// [/ the column scale of unknown t: scaled U' sweep], 32 lanes per row
+__global__ __launch_bounds__(kBlock) void block_gather_kernel(SweepView S, int K, const int* __restrict__ zsrc, const int* __restrict__ hptr,
+                                                              const int* __restrict__ hslot, const int* __restrict__ hidx,
+                                                              const int* __restrict__ unk, const double* __restrict__ pre_scale,
+                                                              const double* __restrict__ xin, const double* __restrict__ y,
+                                                              double* __restrict__ z, const int* done) {
+    if (done && *done) return;
+    const int g = threadIdx.x & 31;
+    for (int t = (blockIdx.x * kBlock + threadIdx.x) >> 5; t < K; t += (gridDim.x * kBlock) >> 5) {
+        const int e1 = hptr[t + 1];
+        const double b = xin[zsrc[t]];
+        double s2 = 0.0;
+        for (int e = hptr[t] + g; e < e1; e += 32) s2 += S.val[hslot[e]] * y[hidx[e]];
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) s2 += __shfl_xor(s2, d, 64);
+        if (g == 0) {
+            const double r = b - s2;
+            z[t] = pre_scale ? r / pre_scale[unk[t]] : r;
+        }
+    }
+}
+// y[pos[t]] = (row t of M) z  [/ the column scale of unknown t: scaled U sweep]; M is lower triangular: a workgroup
+// takes the rows b and K-1-b, K+1 entries together, every thread a few independent loads, fixed reduction tree.
+// INLINE_Z (a head: rows without outside entries): z[l] = xin[zsrc[l]] [/ pre_scale] is formed on the fly, no gather
+// launch in front.  Second copy of the result as SweepView::dst2 asks.
+template <bool INLINE_Z>
+__global__ __launch_bounds__(kBlock) void block_gemv_kernel(int K, const double* __restrict__ M, const double* __restrict__ z,
+                                                            const int* __restrict__ zsrc, const double* __restrict__ xin,
+                                                            const double* __restrict__ pre_scale,
+                                                            const int* __restrict__ tpos, const int* __restrict__ unk,
+                                                            const double* __restrict__ post_scale, double* __restrict__ y,
+                                                            const int* __restrict__ dst2, double* __restrict__ out2, const int* done) {
+    if (done && *done) return;
+    __shared__ double red[2][kBlock / 64];
+    const int ta = blockIdx.x, tb = K - 1 - blockIdx.x;            // ta <= tb; equal for the middle row of an odd K
+    const int na = ta + 1, total = na + (tb > ta ? tb + 1 : 0);
+    double sa = 0.0, sb = 0.0;
+    for (int q = threadIdx.x; q < total; q += kBlock) {
+        const bool first = q < na;
+        const int l = first ? q : q - na;
+        double zl;
+        if (INLINE_Z) { zl = xin[zsrc[l]]; if (pre_scale) zl /= pre_scale[unk[l]]; }
+        else zl = z[l];
+        const double p = M[(size_t)(first ? ta : tb) * K + l] * zl;
+        if (first) sa += p; else sb += p;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { sa += __shfl_xor(sa, d, 64); sb += __shfl_xor(sb, d, 64); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = sa; red[1][wave] = sb; }
+    __syncthreads();
+    if (threadIdx.x < 2 && (threadIdx.x == 0 || tb > ta)) {
+        const int t = threadIdx.x == 0 ? ta : tb;
+        double s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) s2 += red[threadIdx.x][w];
+        const double v = post_scale ? s2 / post_scale[unk[t]] : s2;
+        const int pos = tpos[t];
+        y[pos] = v;
+        if (dst2 && dst2[pos] >= 0) out2[dst2[pos]] = v;
+    }
+}
+
+// the levels [la, lb) of S as an inverted block
+static void build_block(Context* c, Sweep& S, Sweep::Block& T, int la, int lb, const char* what) {
+    hipStream_t s = c->stream;
+    const int c0 = S.level_chunk[la], c1 = S.level_chunk[lb], nc = c1 - c0;
+    int64_t K = 0;
+    for (int l = la; l < lb; l++) K += S.level_width[l];
+    std::vector<ChunkDesc> ch((size_t)nc);
+    IPXK_HIP(hipMemcpyAsync(ch.data(), S.chunks.get() + c0, (size_t)nc * sizeof(ChunkDesc), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    const int p0 = ch[0].pos0, p1 = ch.back().pos0 + (ch.back().width >= 0 ? 64 : kLongLanes), np = p1 - p0;
+    std::vector<int> order((size_t)np);
+    IPXK_HIP(hipMemcpyAsync(order.data(), S.order.get() + p0, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    std::vector<int> tpos, unk, base, rank((size_t)np, -1), lev;
+    tpos.reserve((size_t)K); unk.reserve((size_t)K); base.reserve((size_t)K);
+    // block order = position order; level boundaries from the level widths (a merged chunk holds its levels in order)
+    for (const ChunkDesc& d : ch) {
+        const int npos_c = d.width >= 0 ? 64 : kLongLanes;
+        for (int q = 0; q < npos_c; q++) {
+            const int pos = d.pos0 + q;
+            if (order[pos - p0] < 0) continue;
+            rank[pos - p0] = (int)tpos.size();
+            tpos.push_back(pos);
+            unk.push_back(order[pos - p0]);
+            base.push_back(d.width >= 0 ? d.ent0 + q : -(d.ent0 + 8 * q + 1));
+        }
+    }
+    IPXK_REQUIRE((int64_t)tpos.size() == K, "inverted block of a sweep: positions and level widths disagree");
+    lev.push_back(0);
+    for (int l = la; l < lb; l++) lev.push_back(lev.back() + S.level_width[l]);
+    const int Ki = (int)K;
+    DevBuf<int> dbase, drank, hcnt((size_t)Ki), tcnt((size_t)Ki), dlev, tptr, tcol;
+    DevBuf<double> tval;
+    T.pos.upload(tpos, s); T.unk.upload(unk, s);
+    dbase.upload(base, s); drank.upload(rank, s); dlev.upload(lev, s);
+    hipLaunchKernelGGL(block_count_kernel, dim3(vec_grid(Ki)), dim3(kBlock), 0, s, Ki, p0, T.pos.get(), dbase.get(), S.len.get(),
+                       S.idx.get(), hcnt.get(), tcnt.get());
+    std::vector<int> hc((size_t)Ki), tc((size_t)Ki), hp((size_t)Ki + 1, 0), tp((size_t)Ki + 1, 0);
+    hcnt.download(hc.data(), hc.size(), s); tcnt.download(tc.data(), tc.size(), s);
+    IPXK_HIP(hipStreamSynchronize(s));
+    for (int t = 0; t < Ki; t++) { hp[t + 1] = hp[t] + hc[t]; tp[t + 1] = tp[t] + tc[t]; }
+    T.hptr.upload(hp, s); tptr.upload(tp, s);
+    T.nh = hp[Ki];
+    T.hslot.ensure((size_t)std::max(T.nh, 1)); T.hidx.ensure((size_t)std::max(T.nh, 1)); T.zsrc.ensure((size_t)Ki); tcol.ensure((size_t)std::max(tp[Ki], 1)); tval.ensure((size_t)std::max(tp[Ki], 1));
+    hipLaunchKernelGGL(block_fill_kernel, dim3(vec_grid(Ki)), dim3(kBlock), 0, s, Ki, p0, T.pos.get(), dbase.get(), S.len.get(),
+                       S.idx.get(), S.val.get(), drank.get(), T.hptr.get(), tptr.get(), T.hslot.get(), T.hidx.get(), tcol.get(), tval.get());
+    T.M.ensure((size_t)Ki * Ki); T.z.ensure((size_t)Ki);
+    IPXK_HIP(hipMemsetAsync(T.M.get(), 0, (size_t)Ki * Ki * sizeof(double), s));
+    hipLaunchKernelGGL(block_inverse_kernel, dim3((Ki + 63) / 64), dim3(kBlockInvThreads), 0, s, Ki, lb - la, dlev.get(), tptr.get(),
+                       tcol.get(), tval.get(), S.diag.get(), T.pos.get(), T.M.get());
+    IPXK_HIP(hipStreamSynchronize(s));                             // the scratch buffers above go out of scope
+    IPXK_HIP(hipGetLastError());
+    T.K = Ki; T.la = la; T.lb = lb; T.p0 = p0; T.p1 = p1;
+    if (getenv("IPXK_VERBOSE") || getenv("IPXK_SWEEP_STATS"))
+        fprintf(stderr, "ipxk: sweep %s: levels %d..%d (%d unknowns, %d outside + %d inside entries) inverted\n", what, la, lb - 1, Ki,
+                T.nh, tp[Ki]);
+}
+
+void build_sweep_blocks(Context* c, Sweep& S, bool level_launches) {
+    S.head.K = S.tail.K = 0;
+    // IPXK_TAIL_INVERSE / IPXK_HEAD_INVERSE: unknowns at most (default 2048); 0: never.  Large factors only: below
+    // IPXK_TAIL_MIN_DIM rows (default 200 000) the whole sweep is a few launches anyway, and the small cases of the
+    // test-suite stay bit-identical to the reference's arithmetic.
+    auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    const int tail_max = env_int("IPXK_TAIL_INVERSE", 2048), head_max = env_int("IPXK_HEAD_INVERSE", 2048);
+    const int min_dim = env_int("IPXK_TAIL_MIN_DIM", 200000);
+    constexpr int kMinLevels = 8, kMinUnknowns = 256;
+    const int nlev = S.nlevels;
+    if (level_launches || nlev < kMinLevels + 1 || S.dim < min_dim) return;
+    // the longest run of final levels with at most tail_max unknowns and at most 1/64 of the sweep
+    int la = nlev;
+    int64_t K = 0;
+    for (const int64_t cap = std::min<int64_t>(tail_max, S.dim / 64); la > 1 && K + S.level_width[la - 1] <= cap;) K += S.level_width[--la];
+    const bool tail = nlev - la >= kMinLevels && K >= kMinUnknowns;
+    if (!tail) la = nlev;
+    // ... and of first levels (their rows have no entries outside the block)
+    int lb = 0;
+    K = 0;
+    for (const int64_t cap = std::min<int64_t>(head_max, S.dim / 64); lb < la - 1 && K + S.level_width[lb] <= cap;) K += S.level_width[lb++];
+    const bool head = lb >= kMinLevels && K >= kMinUnknowns;
+    if (getenv("IPXK_SWEEP_STATS"))
+        fprintf(stderr, "ipxk: sweep blocks: %d levels, tail candidate %d.. (%s), head candidate ..%d (%lld unknowns, %s)\n", nlev, la,
+                tail ? "taken" : "not taken", lb - 1, (long long)K, head ? "taken" : "not taken");
+    if (head) build_block(c, S, S.head, 0, lb, "head");
+    if (tail) build_block(c, S, S.tail, la, nlev, "tail");
+}
+
+// ---------------------------------------------------------------------------
 // launch plan and sweeps
 // ---------------------------------------------------------------------------
 // Levels of at most kNarrowLevel chunks are "narrow"; a run of at least kMinXcdLevels narrow levels becomes
@@ -478,7 +694,8 @@ __global__ __launch_bounds__(kBlock) void split_finish_kernel(int m, const doubl
 // got 70-200 us slower.)
 void plan_sweep(Sweep& S, bool level_launches) {
     S.plan.clear();
-    const int nlev = S.nlevels;
+    const int nlev = S.tail.K > 0 ? S.tail.la : S.nlevels;        // an inverted tail takes the levels from la on,
+    const int lfirst = S.head.K > 0 ? S.head.lb : 0;              // an inverted head the levels below lb
     if (nlev == 0) return;
     auto push = [&](int l0, int l1, int kind) {
         const int c0 = S.level_chunk[l0], c1 = S.level_chunk[l1];
@@ -493,14 +710,14 @@ void plan_sweep(Sweep& S, bool level_launches) {
     if (const char* e = getenv("IPXK_SWEEP_MINLEVELS")) min_levels = std::max(1, atoi(e));
     auto nchunks = [&](int lv) { return S.level_chunk[lv + 1] - S.level_chunk[lv]; };
     std::vector<unsigned char> kind(nlev, Sweep::kAllXcds);
-    for (int l = 0; l < nlev;) {
+    for (int l = lfirst; l < nlev;) {
         if (nchunks(l) > narrow_max) { l++; continue; }
         int b = l;
         while (b < nlev && nchunks(b) <= narrow_max) b++;
         if (b - l >= min_levels) for (int t = l; t < b; t++) kind[t] = Sweep::kOneXcd;
         l = b;
     }
-    for (int l = 0; l < nlev;) {
+    for (int l = lfirst; l < nlev;) {
         int b = l + 1;
         while (b < nlev && kind[b] == kind[l]) b++;
         push(l, b, kind[l]);
@@ -539,6 +756,22 @@ static void run_sweep(Context* c, const Sweep& S, bool scaled, const double* xin
         }
         sp->sweep_grid_all = want;
     }
+    // x2 = inverse(T22) (b2 - T21 x1) for the levels the plan leaves out (Sweep::Block)
+    auto run_block = [&](const Sweep::Block& T) {
+        const double* us = scaled ? sp->uscale.get() : nullptr;
+        const double *pre = S.scale_mode == 1 ? us : nullptr, *post = S.scale_mode == 2 ? us : nullptr;
+        const int wgs = (T.K + 1) / 2;
+        if (T.nh == 0) {
+            hipLaunchKernelGGL(block_gemv_kernel<true>, dim3(wgs), dim3(kBlock), 0, c->stream, T.K, T.M.get(), T.z.get(), T.zsrc.get(), xin, pre,
+                               T.pos.get(), T.unk.get(), post, xout, dst2, out2, done);
+            return;
+        }
+        hipLaunchKernelGGL(block_gather_kernel, dim3((T.K * 32 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, V, T.K, T.zsrc.get(),
+                           T.hptr.get(), T.hslot.get(), T.hidx.get(), T.unk.get(), pre, xin, xout, T.z.get(), done);
+        hipLaunchKernelGGL(block_gemv_kernel<false>, dim3(wgs), dim3(kBlock), 0, c->stream, T.K, T.M.get(), T.z.get(), T.zsrc.get(), xin, pre,
+                           T.pos.get(), T.unk.get(), post, xout, dst2, out2, done);
+    };
+    if (S.head.K > 0) run_block(S.head);
     const int grid_all = sp->sweep_grid_all;
     static const int wgs_xcd = [] { const char* e = getenv("IPXK_SWEEP_XCD_WGS"); return e && atoi(e) > 0 ? std::min(atoi(e), 64) : kSweepXcdWgs; }();
     for (const Sweep::Launch& L : S.plan) {
@@ -552,6 +785,7 @@ static void run_sweep(Context* c, const Sweep& S, bool scaled, const double* xin
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, c->stream, V, L.c0, L.c1, xin, xout, one_xcd ? 1 : 0, epoch,
                            sp->xcc_slots.get(), sp->abort_flag.get(), done);
     }
+    if (S.tail.K > 0) run_block(S.tail);
 }
 
 // sentinel into the result vectors of the given sweeps (one launch)
@@ -697,6 +931,10 @@ static void finish_prepare(Context* c, SplitOperator* S, const ipxint* status, c
         compose(S->Lt.npos, S->Lt.order.get(), S->Ut.posof.get(), S->Lt.src.get());
         compose(S->Lf.npos, S->Lf.order.get(), S->rowperm.get(), S->Lf.src.get());
         compose(S->Uf.npos, S->Uf.order.get(), S->Lf.posof.get(), S->Uf.src.get());
+        for (Sweep* W : {&S->Ut, &S->Lt, &S->Lf, &S->Uf})          // inverted blocks: where their right-hand sides sit
+            for (Sweep::Block* T : {&W->head, &W->tail})
+                if (T->K > 0)
+                    hipLaunchKernelGGL(block_zsrc_kernel, dim3(vec_grid(T->K)), dim3(kBlock), 0, s, T->K, T->pos.get(), W->src.get(), T->zsrc.get());
         S->perm_after_backward.ensure(mm);
         compose(m, S->rowperm_inv.get(), S->Lt.posof.get(), S->perm_after_backward.get());
         // ... and its inverse, by position of the L' sweep (padding positions: -1)

@@ -81,6 +81,27 @@ struct Sweep {
     struct Launch { int c0, c1; int kind; bool merged; };   // merged: the run contains merged chunks
     std::vector<int> merged_prefix;  // host, [nchunks+1] number of merged chunks before chunk c
     std::vector<Launch> plan;
+    // INVERTED BLOCKS (large factors; build_sweep_blocks, trisolve.hip).  The first levels of the transposed sweeps
+    // and the last levels of every sweep hold few unknowns each -- the planted C3 factors: 36 levels for the first
+    // 6384 unknowns of U', 37 levels for the last 1059 of L, whose rows are the longest of the matrix -- and cost one
+    // hand-off each however little work they carry.  With the unknowns of such a run of levels as block 2 of
+    // T = [T11 0; T21 T22] (block 1: the levels before it, empty for a head),  x2 = inverse(T22) (b2 - T21 x1):  one
+    // kernel that subtracts the rows' outside entries (all known: the launches of the earlier levels are over) and
+    // one dense lower-triangular matrix-vector product with M = inverse(T22), computed once per Prepare from the
+    // UNSCALED values; the column scaling of the U sweeps is applied around it (mode 1, S T: z / s; mode 2, T S: the
+    // result / s).  Same solve in exact arithmetic; the block's rows are no longer summed in the reference's order
+    // (1e-13 against the level-scheduled form, tests/test_gpu_parity.py).
+    struct Block {
+        int K = 0;                 // unknowns of the block (0: none, the plan covers these levels)
+        int la = 0, lb = 0;        // its levels [la, lb)
+        int p0 = 0, p1 = 0;        // its positions [p0, p1)
+        int nh = 0;                // outside entries of its rows
+        DevBuf<int> pos;           // [K] position of block unknown t (block order = position order)
+        DevBuf<int> unk;           // [K] its unknown
+        DevBuf<int> hptr, hslot, hidx;   // [K+1], [nh], [nh] outside entries of a row: slots of the packed entry arrays, positions
+        DevBuf<int> zsrc;          // [K] where the sweep's input vector holds the right-hand side of unknown t (Sweep::src of its position)
+        DevBuf<double> M, z;       // [K*K] row major; [K]
+    } head, tail;
     SweepView view(bool scaled) const {
         SweepView V;
         V.chunks = chunks.get(); V.src = src.get(); V.len = len.get(); V.idx = idx.get();
@@ -130,6 +151,8 @@ struct SplitOperator {
 
 // Launch plan of a sweep from its level structure (host arithmetic, O(#levels)).
 void plan_sweep(Sweep& S, bool level_launches);
+// decides whether the sweep gets an inverted head / tail and builds them from the packed rows (before plan_sweep)
+void build_sweep_blocks(Context* c, Sweep& S, bool level_launches);
 
 // Device-side analysis of the four sweeps (prepare_device.hip): uploads L and U as given, builds
 // the row lists, computes dependency levels, orders the unknowns and packs the rows on the GPU.

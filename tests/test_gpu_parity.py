@@ -342,6 +342,49 @@ def test_real_N_matrix_vs_oracle_and_masked_form(kkt, po, oracle, monkeypatch):
     assert a[5] == b[5] == 0 and abs(a[4] - b[4]) <= 2 and relerr(a[2], b[2]) < 1e-6 and relerr(a[3], b[3]) < 1e-6
 
 
+def test_inverted_head_and_tail_of_the_sweeps(kkt, po, oracle, monkeypatch, capfd):
+    """Sweep::Block (trisolve.hpp): the first levels of the transposed sweeps and the last levels of every sweep --
+    few unknowns, one hand-off each -- replaced by x2 = inverse(T22) (b2 - T21 x1).  The bound on the dimension is
+    lowered so that a 60 000-row planted basis qualifies.  Against the level-scheduled form (whose arithmetic is the
+    oracle's, bit for bit: the other tests) the solves agree to 1e-12; unscaled (Basis::SolveDense) and scaled (the
+    operator, after a rescale too: the inverse is that of the UNSCALED block, the column scaling of U is applied
+    around it)."""
+    m, n = 60000, 125000
+    B, st, colscale = basis_problem(m, n, seed=23)
+    A, L, U = B["A"], B["L"], B["U"]
+    rng = np.random.default_rng(9)
+    rhs = rng.standard_normal(m)
+    cs2 = colscale * np.where(np.isfinite(colscale) & (colscale > 0), 10.0 ** rng.uniform(-0.5, 0.5, n + m), 1.0)
+    out = {}
+    monkeypatch.setenv("IPXK_TAIL_MIN_DIM", "1000")
+    monkeypatch.setenv("IPXK_VERBOSE", "1")
+    for cap in ("900", "0"):
+        monkeypatch.setenv("IPXK_TAIL_INVERSE", cap)
+        monkeypatch.setenv("IPXK_HEAD_INVERSE", cap)
+        ctx = kkt.KktContext(A)
+        ctx.split_prepare(L, U, B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
+        err = capfd.readouterr().err
+        print(err)
+        assert (err.count("sweep tail: levels") >= 2 and err.count("sweep head: levels") == 2) == (cap != "0"), err
+        fwd = ctx.solve_dense(rhs, "N")
+        bwd = ctx.solve_dense(rhs, "T")
+        l1, d1 = ctx.split_apply(rhs)
+        ctx.split_rescale(B["status"], cs2)
+        l2, d2 = ctx.split_apply(rhs)
+        x, y, it, e, _ = ctx.kkt_basis_solve(st["a"], st["b"], 1e-8)
+        out[cap] = (fwd, bwd, l1, l2, x, y, it, e)
+        ctx.close()
+    a, b = out["900"], out["0"]
+    Bm = A.to_scipy()[:, :m]                                                      # basis[p] = p
+    for v in (a, b):
+        assert relerr(Bm @ v[0], rhs) <= 1e-10 and relerr(Bm.T @ v[1], rhs) <= 1e-10
+    for k in (0, 1, 2, 3):
+        assert relerr(a[k], b[k]) <= 1e-12, (k, relerr(a[k], b[k]))
+        assert not np.array_equal(a[k], b[k])
+    # (CR to 1e-8 takes ~255 iterations here; the count moves by a few with the rounding of the operator)
+    assert a[7] == b[7] == 0 and abs(a[6] - b[6]) <= 3 + b[6] // 50 and relerr(a[4], b[4]) < 1e-6 and relerr(a[5], b[5]) < 1e-6
+
+
 def test_operator_timers(kkt):
     """ipx_info::time_cr1_AAt / time_cr1_pre / time_cr2_NNt / _B / _Bt equivalents (ipxk_times)."""
     A, st = diag_problem(20000, 42000, seed=77)
@@ -848,9 +891,17 @@ def test_basis_path_full_size_properties(kkt, monkeypatch):
     nb = B["status"] == -1
     assert np.abs(res[nb]).max() < 1e-9 * (1 + np.abs(st["a"]).max() + np.abs(g).max())   # exact on nonbasic
     assert np.abs(res[~nb] * colscale[~nb]).max() <= tol * (1 + 1e-6)                      # tol on basic
+    # the inverted tails of the forward sweeps (Sweep::Block; on by default at this size) against the level-scheduled form
+    xN1, xT1 = ctx.solve_dense(r, "N"), ctx.solve_dense(r, "T")
+    fw1, bw1 = ctx.forward_solve(r), ctx.backward_solve(r)
+    monkeypatch.setenv("IPXK_TAIL_INVERSE", "0")
+    monkeypatch.setenv("IPXK_HEAD_INVERSE", "0")
+    ctx.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
     # the single-launch runs reproduce what one launch per level computes, bit for bit
     xN, xT = ctx.solve_dense(r, "N"), ctx.solve_dense(r, "T")
     fw, bw = ctx.forward_solve(r), ctx.backward_solve(r)
+    for v1, v0 in ((xN1, xN), (fw1, fw), (xT1, xT), (bw1, bw)):
+        assert relerr(v1, v0) <= 1e-12 and not np.array_equal(v1, v0)
     lv = ctx.split_levels()
     monkeypatch.setenv("IPXK_TRISOLVE", "levels")
     ctx.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
@@ -858,6 +909,9 @@ def test_basis_path_full_size_properties(kkt, monkeypatch):
     assert np.array_equal(ctx.solve_dense(r, "N"), xN) and np.array_equal(ctx.solve_dense(r, "T"), xT)
     assert np.array_equal(ctx.forward_solve(r), fw) and np.array_equal(ctx.backward_solve(r), bw)
     monkeypatch.delenv("IPXK_TRISOLVE")
+    monkeypatch.delenv("IPXK_TAIL_INVERSE")
+    monkeypatch.delenv("IPXK_HEAD_INVERSE")
+    ctx.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
     # same basis, new scaling factors: ipxk_split_rescale == a full Prepare (src/kkt_solver_basis.cc:59-64)
     cs2 = colscale * np.where(np.isfinite(colscale), 10.0 ** np.random.default_rng(5).uniform(-0.5, 0.5, colscale.size), 1.0)
     t0 = time.time()
