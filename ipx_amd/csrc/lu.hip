@@ -349,11 +349,13 @@ __global__ void lu_compact_kernel(int dim, const int* __restrict__ flag, const i
         if (flag[i]) list[rank[i]] = (int)i;
     }
 }
-__global__ void lu_dense_fill_kernel(int kb, const int* __restrict__ bcol, const int* __restrict__ Bp, const int* __restrict__ Bi,
-                                     const double* __restrict__ Bx, const int* __restrict__ rloc, double* __restrict__ D) {
-    IPXK_GRID_STRIDE(c, kb) {
+__global__ __launch_bounds__(kBlock) void lu_dense_fill_kernel(int kb, const int* __restrict__ bcol, const int* __restrict__ Bp,
+                                                               const int* __restrict__ Bi, const double* __restrict__ Bx,
+                                                               const int* __restrict__ rloc, double* __restrict__ D) {
+    const int lane = threadIdx.x & 63;                            // a wavefront per bump column
+    for (int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); c < kb; c += gridDim.x * (kBlock / 64)) {
         const int j = bcol[c];
-        for (int p = Bp[j]; p < Bp[j + 1]; p++) {
+        for (int p = Bp[j] + lane; p < Bp[j + 1]; p += 64) {
             const int r = rloc[Bi[p]];
             if (r >= 0) D[(size_t)c * kb + r] = Bx[p];
         }
@@ -1028,7 +1030,8 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
         hipLaunchKernelGGL(lu_fill_int_kernel, dim3(gk), dim3(kBlock), 0, s, (int64_t)kb, -1, brstep.get());
         hipLaunchKernelGGL(lu_fill_int_kernel, dim3(gk), dim3(kBlock), 0, s, (int64_t)kb, -1, bcstep.get());
         if (!tearing) {
-            hipLaunchKernelGGL(lu_dense_fill_kernel, dim3(gk), dim3(kBlock), 0, s, kb, bcol.get(), Bp, Bi, Bx, rloc.get(), D.get());
+            hipLaunchKernelGGL(lu_dense_fill_kernel, dim3((kb + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, s, kb, bcol.get(), Bp, Bi, Bx,
+                               rloc.get(), D.get());
         } else {
             // ---- 2b. the spikes through the row singleton pivots (forward substitution, 64 spikes at a time)
             DevBuf<u64> &lkey = W.lkey, &lkey2 = W.lkey2;

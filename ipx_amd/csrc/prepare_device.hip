@@ -153,6 +153,82 @@ __global__ void u_diag_kernel(int m, const ipxint* __restrict__ Up, const double
     IPXK_GRID_STRIDE(k, m) dgn[k] = Ux[Up[k + 1] - 1];
 }
 
+// ---- step 2 (round 3): levels in ONE launch ---------------------------------------------------------------
+// The processing order of a sweep (ascending / descending unknowns) is a topological order of its dependency graph,
+// so the levels can be computed the way the sweeps themselves run (trisolve.hip): level[] starts at -1 = "not known",
+// wavefront w of the W resident ones takes the 64-row chunks w, w + W, ... of the processing order, a row polls the
+// levels of its dependencies (L1-bypassing loads) until all are known and stores max + 1 -- the value is the flag.  The
+// lowest unfinished row depends only on finished ones, so the launch always makes progress, whatever the placement;
+// every workgroup must be resident (the grid is sized from the occupancy query).  Rows inside one chunk may depend on
+// each other: a lane never spins on its own, the wavefront loops over "whoever is ready now".  Rows of more than
+// kLevelLongRow entries are evaluated by the whole wavefront, lowest first.  A wait that exceeds the spin budget
+// raises `abort` and the caller falls back to the relaxation launches below.
+// (Replaces 20-60 relaxation launches per sweep: 9.1 of the 12.7 ms of kernel time of a Prepare at 1M rows.)
+constexpr int kLevelLongRow = 32;
+constexpr int kLevelSpin = 1 << 20;
+__global__ __launch_bounds__(kBlock) void level_sweep_kernel(int dim, int ascending, const int* __restrict__ rp, const int* __restrict__ ri,
+                                                             int* level, int* abort_flag) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), NW = gridDim.x * (kBlock / 64);
+    const int nchunks = (dim + 63) / 64;
+    for (int c = gw; c < nchunks; c += NW) {
+        const int t = c * 64 + lane;
+        const int i = t < dim ? (ascending ? t : dim - 1 - t) : -1;
+        const int p0 = i >= 0 ? rp[i] : 0, p1 = i >= 0 ? rp[i + 1] : 0;
+        const bool is_long = p1 - p0 > kLevelLongRow;
+        bool finished = i < 0;
+        if (i >= 0 && p1 == p0) {
+            __hip_atomic_store(level + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            finished = true;
+        }
+        for (int spins = 0;; spins++) {
+            if (!finished && !is_long) {
+                int lv = 0;
+                bool ready = true;
+                for (int p = p0; p < p1; p++) {
+                    const int l = __hip_atomic_load(level + ri[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (l < 0) { ready = false; break; }
+                    lv = l + 1 > lv ? l + 1 : lv;
+                }
+                if (ready) {
+                    __hip_atomic_store(level + i, lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    finished = true;
+                }
+            }
+            const unsigned long long lm = __ballot(!finished && is_long);
+            if (lm) {                                             // the lowest unfinished long row, by all lanes
+                const int src = __ffsll((long long)lm) - 1;
+                const int q0 = __shfl(p0, src, 64), q1 = __shfl(p1, src, 64);
+                int lv = 0;
+                bool ready = true;
+                for (int p = q0 + lane; p < q1; p += 64) {
+                    const int l = __hip_atomic_load(level + ri[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (l < 0) ready = false;
+                    else lv = l + 1 > lv ? l + 1 : lv;
+                }
+                if (__all(ready)) {
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) {
+                        const int o = __shfl_xor(lv, d, 64);
+                        lv = o > lv ? o : lv;
+                    }
+                    if (lane == src) {
+                        __hip_atomic_store(level + i, lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        finished = true;
+                    }
+                }
+            }
+            if (!__any(!finished)) break;
+            if (spins > kLevelSpin ||
+                ((spins & 255) == 255 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
 // ---- step 2: levels -----------------------------------------------------------------------
 // One pass of level[i] = max(level[dep] + 1) over the rows of at most kRelaxLong entries.  Two things let a
 // single launch settle many levels: the threads take the unknowns in PROCESSING order (descending sweeps from
@@ -407,15 +483,38 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
     S.dim = dim;
     S.running = running;
     S.scale_mode = scale_mode;
-    // 2. levels: rounds of relaxation launches, twice as many each time (one host round trip per round)
+    // 2. levels: one sync-free launch (level_sweep_kernel); should it give up, rounds of relaxation launches, twice as
+    // many each time (one host round trip per round)
     W.level.ensure(std::max(dim, 1));
-    IPXK_HIP(hipMemsetAsync(W.level.get(), 0, sizeof(int) * std::max(dim, 1), s));
     DevBuf<int> changed(1);
     if (!W.h_flag) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&W.h_flag), sizeof(int)));
+    bool have_levels = false;
+    if (dim > 0 && !(getenv("IPXK_LEVEL_SWEEP") && getenv("IPXK_LEVEL_SWEEP")[0] == '0')) {
+        static const int resident = [] {
+            int dev = 0, per_cu = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, level_sweep_kernel, kBlock, 0) != hipSuccess) return 0;
+            // one block per CU is held back from what the query reports (as for the sweeps, trisolve.hip), at most 4 are used
+            return prop.multiProcessorCount * std::max(0, std::min(per_cu - 1, 4));
+        }();
+        if (resident > 0) {
+            IPXK_HIP(hipMemsetAsync(W.level.get(), 0xff, sizeof(int) * dim, s));
+            IPXK_HIP(hipMemsetAsync(changed.get(), 0, sizeof(int), s));
+            const int grid = std::max(1, std::min(resident, (dim + kBlock - 1) / kBlock));
+            hipLaunchKernelGGL(level_sweep_kernel, dim3(grid), dim3(kBlock), 0, s, dim, ascending ? 1 : 0, W.rp.get(), W.ri.get(),
+                               W.level.get(), changed.get());
+            IPXK_HIP(hipMemcpyAsync(W.h_flag, changed.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+            IPXK_HIP(hipStreamSynchronize(s));
+            have_levels = *W.h_flag == 0;
+            if (getenv("IPXK_VERBOSE")) fprintf(stderr, "ipxk: levels by one sync-free launch%s\n", have_levels ? "" : ": gave up, relaxation instead");
+        }
+    }
+    if (!have_levels) IPXK_HIP(hipMemsetAsync(W.level.get(), 0, sizeof(int) * std::max(dim, 1), s));
     // long rows, in processing order
     int nlong = 0;
     DevBuf<int> long_rows;
-    if (dim > 0) {
+    if (dim > 0 && !have_levels) {
         W.keys.ensure((size_t)dim); W.vals.ensure((size_t)dim);
         hipLaunchKernelGGL(relax_long_flag_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, ascending ? 1 : 0, W.rp.get(), W.keys.get());
         exclusive_scan(W, W.keys.get(), W.vals.get(), (size_t)dim, s);
@@ -433,7 +532,7 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
     // a cycle = one pass over the short rows + (if any) one over the long ones, a wavefront each; every batch
     // of cycles (twice as many each time, one host round trip per batch) starts with the sequential pass over
     // the long rows, which settles a chain among them at once
-    for (int launched = 0, batch = nlong > 0 ? 4 : 8; dim > 0; batch = std::min(batch * 2, 64)) {
+    for (int launched = 0, batch = nlong > 0 ? 4 : 8; dim > 0 && !have_levels; batch = std::min(batch * 2, 64)) {
         if (launched >= kMaxRelaxLaunches) {
             std::vector<int> lv((size_t)dim, 0);
             host_levels(lv);

@@ -958,14 +958,17 @@ constexpr int kBumpMin = 32;          // smaller bumps stay in the level-schedul
 constexpr int kBumpThreads = 1024;
 
 // D22: bump column t = pivot stage s0 + t; U22 on and above the diagonal, L22 (multipliers) below
-__global__ void bump_extract_kernel(int s0, int kb, const ipxint* __restrict__ Lp, const ipxint* __restrict__ Li,
-                                    const double* __restrict__ Lx, const ipxint* __restrict__ Up, const ipxint* __restrict__ Ui,
-                                    const double* __restrict__ Ux, double* __restrict__ D) {
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < kb; t += gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(kBlock) void bump_extract_kernel(int s0, int kb, const ipxint* __restrict__ Lp, const ipxint* __restrict__ Li,
+                                                              const double* __restrict__ Lx, const ipxint* __restrict__ Up, const ipxint* __restrict__ Ui,
+                                                              const double* __restrict__ Ux, double* __restrict__ D) {
+    // a wavefront per column (a column of U holds up to s0 + kb entries, of which the last <= kb belong to the block)
+    const int lane = threadIdx.x & 63;
+    for (int t = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); t < kb; t += gridDim.x * (kBlock / 64)) {
         const int j = s0 + t;
-        for (ipxint p = Up[j]; p < Up[j + 1]; p++)
+        const ipxint u1 = Up[j + 1], u0 = max(Up[j], u1 - kb);     // indices ascend: entries with Ui >= s0 are among the last kb
+        for (ipxint p = u0 + lane; p < u1; p += 64)
             if (Ui[p] >= s0) D[(size_t)t * kb + (Ui[p] - s0)] = Ux[p];
-        for (ipxint p = Lp[j]; p < Lp[j + 1]; p++) D[(size_t)t * kb + (Li[p] - s0)] = Lx[p];
+        for (ipxint p = Lp[j] + lane; p < Lp[j + 1]; p += 64) D[(size_t)t * kb + (Li[p] - s0)] = Lx[p];
     }
 }
 // U~: columns < s0 as they are; a bump column keeps its entries above the bump (a prefix: indices ascend) and gets
@@ -1167,7 +1170,7 @@ static DeviceFactors cut_dense_block(Context* c, SplitOperator* S, const DeviceF
     const int m = S->m, nblk = (kb + 63) / 64;
     S->bumpD.ensure((size_t)kb * kb);
     IPXK_HIP(hipMemsetAsync(S->bumpD.get(), 0, (size_t)kb * kb * sizeof(double), s));
-    hipLaunchKernelGGL(bump_extract_kernel, dim3(vec_grid(kb)), dim3(kBlock), 0, s, s0, kb, in.Lp, in.Li, in.Lx, in.Up, in.Ui,
+    hipLaunchKernelGGL(bump_extract_kernel, dim3((kb + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, s, s0, kb, in.Lp, in.Li, in.Lx, in.Up, in.Ui,
                        in.Ux, S->bumpD.get());
     DevBuf<int> cnt((size_t)m), start((size_t)m);
     hipLaunchKernelGGL(bump_ucount_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, m, s0, in.Up, in.Ui, cnt.get());
