@@ -439,8 +439,10 @@ __global__ __launch_bounds__(kBlock) void rescale_kernel(SweepView S, const int*
     }
 }
 
-struct Scratch {   // reused by the four sweeps of one Prepare
+struct Scratch {   // reused by the four sweeps of a Prepare and kept from one Prepare to the next (Context::prepare_host; grow-only:
+                   // hipMalloc / hipFree of a dozen buffers cost more than the kernels that used them)
     DevBuf<int> keys, vals, keys2, vals2, colof, level, lstart, lpos, lsub, csize, cent0;
+    DevBuf<int> changed, too_long, bkeys, bad;
     DevBuf<unsigned char> tmp;
     DevBuf<int> rp, ri;
     DevBuf<double> rx, dgn;
@@ -486,7 +488,8 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
     // 2. levels: one sync-free launch (level_sweep_kernel); should it give up, rounds of relaxation launches, twice as
     // many each time (one host round trip per round)
     W.level.ensure(std::max(dim, 1));
-    DevBuf<int> changed(1);
+    DevBuf<int>& changed = W.changed;
+    changed.ensure(1);
     if (!W.h_flag) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&W.h_flag), sizeof(int)));
     bool have_levels = false;
     if (dim > 0 && !(getenv("IPXK_LEVEL_SWEEP") && getenv("IPXK_LEVEL_SWEEP")[0] == '0')) {
@@ -579,7 +582,8 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
         std::vector<int> bkeys((size_t)2 * nlev + 1);
         for (int l = 0; l < nlev; l++) { bkeys[2 * l] = l << kLenKeyBits; bkeys[2 * l + 1] = (l << kLenKeyBits) | (255 - kShortRow); }
         bkeys[2 * nlev] = nlev << kLenKeyBits;
-        DevBuf<int> dk; dk.upload(bkeys, s);
+        DevBuf<int>& dk = W.bkeys;
+        dk.upload(bkeys, s);
         W.lstart.ensure(bkeys.size());
         hipLaunchKernelGGL(lower_bound_keys_kernel, dim3(grid_for((int64_t)bkeys.size())), dim3(kBlock), 0, s, (int)bkeys.size(),
                            (int64_t)dim, W.keys2.get(), dk.get(), W.lstart.get());
@@ -670,7 +674,8 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
             W.lpos.ensure(lpos.size()); W.lsub.ensure(lsub.size());
             W.lpos.upload(lpos, s);
             W.lsub.upload(lsub, s);
-            DevBuf<int> too_long(3);                          // [0] merged long row beyond one round, [1] row beyond the len word, [2] slot count overflow
+            DevBuf<int>& too_long = W.too_long;               // [0] merged long row beyond one round, [1] row beyond the len word, [2] slot count overflow
+            too_long.ensure(3);
             IPXK_HIP(hipMemsetAsync(too_long.get(), 0, 3 * sizeof(int), s));
             hipLaunchKernelGGL(place_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, s, dim, W.keys2.get(), W.vals2.get(),
                                W.lstart.get(), W.lpos.get(), W.lsub.get(), W.rp.get(), W.dgn.get(), S.order.get(), S.posof.get(),
@@ -726,6 +731,9 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
 }
 
 }  // namespace
+
+struct PrepareHost { Scratch W; };           // workspaces of Prepare kept by the context (context.hpp)
+void destroy_prepare_host(PrepareHost* p) { delete p; }
 
 void rescale_sweeps_device(Context* c, SplitOperator* S) {
     hipStream_t s = c->stream;
@@ -802,12 +810,13 @@ void analyse_sweeps_resident(Context* c, SplitOperator* S, const DeviceFactors& 
                                                "strictly lower, U not upper with its diagonal last)");
     }
     const double t1 = now();
-    Scratch W;
+    if (!c->prepare_host) c->prepare_host = new PrepareHost;
+    Scratch& W = c->prepare_host->W;
     const size_t maxnz = (size_t)std::max<int64_t>(std::max(nzL, nzU), 1);
-    W.rp.resize((size_t)m + 1); W.ri.resize(maxnz); W.rx.resize(maxnz);
-    W.dgn.resize(std::max(m, 1));
-    W.keys.resize(std::max<size_t>(maxnz, (size_t)m + 1)); W.vals.resize(W.keys.size());
-    W.keys2.resize(W.keys.size()); W.vals2.resize(W.keys.size()); W.colof.resize(maxnz);
+    W.rp.ensure((size_t)m + 1); W.ri.ensure(maxnz); W.rx.ensure(maxnz);
+    W.dgn.ensure(std::max(m, 1));
+    const size_t nkeys = std::max<size_t>(maxnz, (size_t)m + 1);
+    W.keys.ensure(nkeys); W.vals.ensure(nkeys); W.keys2.ensure(nkeys); W.vals2.ensure(nkeys); W.colof.ensure(maxnz);
     const int g = grid_for(m);
     const int rowbits = bits_for(std::max(m, 2));
     const bool ll = S->level_launches;

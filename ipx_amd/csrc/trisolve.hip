@@ -40,8 +40,6 @@
 namespace ipxk {
 
 void destroy_split(SplitOperator* s) { delete s; }
-struct PrepareHost {};                       // (host-side analysis workspaces: none any more)
-void destroy_prepare_host(PrepareHost* p) { delete p; }
 
 static void bump_between(Context* c, bool trans, double* y, const int* done);   // dense bump of an LU from the device (below)
 
@@ -628,8 +626,9 @@ static void build_block(Context* c, Sweep& S, Sweep::Block& T, int la, int lb, c
     lev.push_back(0);
     for (int l = la; l < lb; l++) lev.push_back(lev.back() + S.level_width[l]);
     const int Ki = (int)K;
-    DevBuf<int> dbase, drank, hcnt((size_t)Ki), tcnt((size_t)Ki), dlev, tptr, tcol;
-    DevBuf<double> tval;
+    DevBuf<int> &dbase = T.w_base, &drank = T.w_rank, &hcnt = T.w_hcnt, &tcnt = T.w_tcnt, &dlev = T.w_lev, &tptr = T.w_tptr, &tcol = T.w_tcol;
+    DevBuf<double>& tval = T.w_tval;
+    hcnt.ensure((size_t)Ki); tcnt.ensure((size_t)Ki);
     T.pos.upload(tpos, s); T.unk.upload(unk, s);
     dbase.upload(base, s); drank.upload(rank, s); dlev.upload(lev, s);
     hipLaunchKernelGGL(block_count_kernel, dim3(vec_grid(Ki)), dim3(kBlock), 0, s, Ki, p0, T.pos.get(), dbase.get(), S.len.get(),
@@ -647,7 +646,7 @@ static void build_block(Context* c, Sweep& S, Sweep::Block& T, int la, int lb, c
     IPXK_HIP(hipMemsetAsync(T.M.get(), 0, (size_t)Ki * Ki * sizeof(double), s));
     hipLaunchKernelGGL(block_inverse_kernel, dim3((Ki + 63) / 64), dim3(kBlockInvThreads), 0, s, Ki, lb - la, dlev.get(), tptr.get(),
                        tcol.get(), tval.get(), S.diag.get(), T.pos.get(), T.M.get());
-    IPXK_HIP(hipStreamSynchronize(s));                             // the scratch buffers above go out of scope
+    IPXK_HIP(hipStreamSynchronize(s));                             // the host vectors uploaded above go out of scope
     IPXK_HIP(hipGetLastError());
     T.K = Ki; T.la = la; T.lb = lb; T.p0 = p0; T.p1 = p1;
     if (getenv("IPXK_VERBOSE") || getenv("IPXK_SWEEP_STATS"))
@@ -1164,7 +1163,10 @@ static void bump_between(Context* c, bool trans, double* y, const int* done) {
 // Cuts the trailing block [s0, s0 + kb) = [s0, m) out of the factors: D22 = (L22 + I) U22 goes to S->bumpD (dense, with
 // the inverted 64 x 64 diagonal blocks), the returned factors are L without L22 and U with U22 replaced by I (trisolve.hpp).
 // Exact for ANY trailing block; it pays when the block is (nearly) dense.
-struct CutBuffers { DevBuf<ipxint> TLp, TUp, TUi; DevBuf<double> TUx; };
+struct CutBuffers {                                    // (the operator's own, kept from one Prepare to the next)
+    DevBuf<ipxint> &TLp, &TUp, &TUi; DevBuf<double>& TUx;
+    explicit CutBuffers(SplitOperator* S) : TLp(S->cut_Lp), TUp(S->cut_Up), TUi(S->cut_Ui), TUx(S->cut_Ux) {}
+};
 static DeviceFactors cut_dense_block(Context* c, SplitOperator* S, const DeviceFactors& in, int s0, int kb, CutBuffers& B) {
     hipStream_t s = c->stream;
     const int m = S->m, nblk = (kb + 63) / 64;
@@ -1172,12 +1174,13 @@ static DeviceFactors cut_dense_block(Context* c, SplitOperator* S, const DeviceF
     IPXK_HIP(hipMemsetAsync(S->bumpD.get(), 0, (size_t)kb * kb * sizeof(double), s));
     hipLaunchKernelGGL(bump_extract_kernel, dim3((kb + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, s, s0, kb, in.Lp, in.Li, in.Lx, in.Up, in.Ui,
                        in.Ux, S->bumpD.get());
-    DevBuf<int> cnt((size_t)m), start((size_t)m);
+    DevBuf<int> &cnt = S->cut_cnt, &start = S->cut_start;
+    cnt.ensure((size_t)m); start.ensure((size_t)m);
     hipLaunchKernelGGL(bump_ucount_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, m, s0, in.Up, in.Ui, cnt.get());
     hipLaunchKernelGGL(bump_ustart_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, s, m, s0, in.Up, cnt.get(), start.get());
     hipLaunchKernelGGL(bump_ustart_tail_kernel, dim3(1), dim3(1), 0, s, m, s0, in.Up, cnt.get(), start.get());
-    B.TLp.resize((size_t)m + 1); B.TUp.resize((size_t)m + 1);
-    B.TUi.resize((size_t)std::max<int64_t>(in.nzU, 1)); B.TUx.resize((size_t)std::max<int64_t>(in.nzU, 1));
+    B.TLp.ensure((size_t)m + 1); B.TUp.ensure((size_t)m + 1);
+    B.TUi.ensure((size_t)std::max<int64_t>(in.nzU, 1)); B.TUx.ensure((size_t)std::max<int64_t>(in.nzU, 1));
     hipLaunchKernelGGL(bump_ufill_kernel, dim3(vec_grid(m + 1)), dim3(kBlock), 0, s, m, s0, in.Up, in.Ui, in.Ux, start.get(), cnt.get(),
                        B.TUp.get(), B.TUi.get(), B.TUx.get(), in.Lp, B.TLp.get());
     ipxint ends[2] = {0, 0};
@@ -1255,8 +1258,8 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
     S->bump_start = S->bump_size = 0;
     {
         // factors as given, on the device; a dense trailing block (the bump of the LU) is cut out of the sweeps
-        DevBuf<ipxint> dLp, dLi, dUp, dUi;
-        DevBuf<double> dLx, dUx;
+        DevBuf<ipxint> &dLp = S->in_Lp, &dLi = S->in_Li, &dUp = S->in_Up, &dUi = S->in_Ui;
+        DevBuf<double> &dLx = S->in_Lx, &dUx = S->in_Ux;
         const int64_t nzL = Lp[m], nzU = Up[m];
         dLp.upload(Lp, (size_t)m + 1, s); dUp.upload(Up, (size_t)m + 1, s);
         dLi.upload(Li, (size_t)nzL, s);   dLx.upload(Lx, (size_t)nzL, s);
@@ -1266,7 +1269,7 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
         const char* dense_env = getenv("IPXK_BUMP_DENSE");
         const int bump_min = getenv("IPXK_BUMP_MIN") ? atoi(getenv("IPXK_BUMP_MIN")) : kBumpMin;
         const int s0 = m > 0 ? trailing_dense_block(m, Lp) : m;
-        CutBuffers cut;
+        CutBuffers cut(S.get());
         if (m - s0 >= bump_min && m - s0 <= 8192 && !(dense_env && dense_env[0] == '0')) {
             const DeviceFactors F = cut_dense_block(c, S.get(), F0, s0, m - s0, cut);
             analyse_sweeps_resident(c, S.get(), F, nullptr, nullptr, nullptr, nullptr);
@@ -1329,7 +1332,7 @@ void split_prepare_lu(Context* c, const ipxint* status, const double* colscale) 
     if (const char* e = getenv("IPXK_TRISOLVE")) S->level_launches = std::string(e) == "levels";
     // the dense bump leaves the level-scheduled structure (SplitOperator::bump_*)
     DeviceFactors F = V.F;
-    CutBuffers cut;
+    CutBuffers cut(S.get());
     S->bump_start = S->bump_size = 0;
     const char* dense_env = getenv("IPXK_BUMP_DENSE");
     const int bump_min = getenv("IPXK_BUMP_MIN") ? atoi(getenv("IPXK_BUMP_MIN")) : kBumpMin;      // (tests)

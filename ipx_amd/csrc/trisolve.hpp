@@ -101,6 +101,8 @@ struct Sweep {
         DevBuf<int> hptr, hslot, hidx;   // [K+1], [nh], [nh] outside entries of a row: slots of the packed entry arrays, positions
         DevBuf<int> zsrc;          // [K] where the sweep's input vector holds the right-hand side of unknown t (Sweep::src of its position)
         DevBuf<double> M, z;       // [K*K] row major; [K]
+        DevBuf<int> w_base, w_rank, w_hcnt, w_tcnt, w_lev, w_tptr, w_tcol;   // workspaces of build_block, kept (grow-only)
+        DevBuf<double> w_tval;
     } head, tail;
     SweepView view(bool scaled) const {
         SweepView V;
@@ -147,6 +149,11 @@ struct SplitOperator {
     DevBuf<double> bump_inv, bump_invT, bump_x;
     bool bump_explicit = false;
     DevBuf<int> bump_pos_fwd, bump_pos_bwd;   // position of bump unknown t in the result of the L sweep / of the U' sweep
+    // workspaces of Prepare kept from one call to the next (grow-only): the factors as uploaded, the factors with the
+    // dense block cut out
+    DevBuf<ipxint> in_Lp, in_Li, in_Up, in_Ui, cut_Lp, cut_Up, cut_Ui;
+    DevBuf<double> in_Lx, in_Ux, cut_Ux;
+    DevBuf<int> cut_cnt, cut_start;
 };
 
 // Launch plan of a sweep from its level structure (host arithmetic, O(#levels)).
