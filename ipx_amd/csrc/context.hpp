@@ -142,6 +142,7 @@ void build_model(Context* c, const ipxint* Ap, const ipxint* Ai, const double* A
 void debug_single_pass(Context* c, int which, const double* x, double* out);
 
 // ---- precond.hip ----
+void prepare_dense_columns(Context* c);   // model-dependent part of the dense-column preconditioner (precond.hip)
 void diag_factorize_dev(Context* c, const double* W, bool precond_dense_cols, ipxint* errflag);
 // lhs = P rhs; partial dot rhs'lhs -> part(slot); returns # partials
 int diag_apply_dev(Context* c, const double* rhs, double* lhs, int slot, const int* done);

@@ -389,6 +389,23 @@ __global__ void add_vector_kernel(int len, const double* __restrict__ w, double*
         out[i] = w[i] + out[i];
 }
 
+// Everything of the dense-column machinery that depends on the model alone, built when the model is (build_model): the
+// first Factorize then costs what the others do (C5: 56 ms -> see DESIGN section 5).
+void prepare_dense_columns(Context* c) {
+    if (c->num_dense <= 0 || comm_active(c)) return;
+    const int64_t m = c->m, n = c->n;
+    const int k = (int)c->dense_cols.size();
+    hipStream_t s = c->stream;
+    build_dense_structures(c);
+    std::vector<unsigned char> mask(n, 0);
+    for (ipxint j : c->dense_cols) mask[j] = 1;
+    c->dense_mask.upload(mask, s);
+    c->Wnodense.resize(n);
+    c->diagonal.resize(m);
+    if ((int64_t)m * k * 8 <= (int64_t(8) << 30)) c->schur_panel.ensure((size_t)m * k);
+    IPXK_HIP(hipStreamSynchronize(s));
+}
+
 void diag_factorize_dev(Context* c, const double* W, bool precond_dense_cols, ipxint* errflag) {
     const int64_t m = c->m, n = c->n;
     hipStream_t s = c->stream;

@@ -822,6 +822,7 @@ void build_model(Context* c, const ipxint* Ap, const ipxint* Ai, const double* A
     c->Arows.build(m, n, c->h_ATp.data(), c->h_ATi.data(), c->h_ATx.data(), c->stream);
     find_dense_columns(c);
     c->tcols.resize(n > 0 ? n : 1);
+    prepare_dense_columns(c);
 }
 
 // ---------------------------------------------------------------------------
