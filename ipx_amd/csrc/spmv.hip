@@ -373,7 +373,11 @@ void GatherMatrix::build_sorted(const ipxint* hptr, const ipxint* hidx, const do
     const int ns = sliced.nslices;
     const int64_t slice = ((ncols + ns - 1) / ns + 15) / 16 * 16;        // as in build_sliced
     if (slice > (int64_t(1) << kSortedOffBits)) return;
-    const int nsub = 2;
+    // (sub-slices per slice: 2.  Round 3, measured at C3 with IPXK_SORTED_NSUB: 4 sub-slices let the row block double at the
+    // same staging buffer, i.e. twice the entries per line of the gathered window -- but the apply went 238 -> 276 us, 8 ->
+    // 351 us: two more barriers, a scan and a count word per row and sub-tile cost more than the shared requests save)
+    static const int nsub_env = [] { const char* e = getenv("IPXK_SORTED_NSUB"); return e && atoi(e) > 0 ? std::min(atoi(e), 16) : 2; }();
+    const int nsub = nsub_env;
     const int64_t half = (slice / nsub + 15) / 16 * 16;
     const std::vector<unsigned char>& rlong = h_row_long;
     const bool verbose = getenv("IPXK_VERBOSE") != nullptr;
