@@ -122,6 +122,10 @@ int ipxk_synchronize(ipxk_context* ctx);
  * src/normal_matrix.cc:57,125, src/diagonal_precond.cc:126,158,
  * src/splitted_normal_matrix.cc:93-110).  Off by default: ~2 extra stream markers per call. */
 int ipxk_set_profiling(ipxk_context* ctx, int on);
+/* Control::InterruptCheck for the calls that take no callback of their own: ipxk_maxvolume and
+ * ipxk_maxvolume_sequential poll it once per candidate column (src/maxvolume.cc:52,250); a nonzero
+ * value ends the run with info->errflag = that value, the exchanges made so far kept.  NULL: none. */
+int ipxk_set_interrupt(ipxk_context* ctx, ipxint (*interrupt)(void* user), void* interrupt_user);
 ipxint ipxk_num_dense_cols(const ipxk_context* ctx);
 /* Copies out the device-side row-wise matrix (for bit-exact index parity
  * tests against Transpose): ATp[m+1], ATi[nnz], ATx[nnz]; NULL skips. */

@@ -250,6 +250,14 @@ int ipxk_set_profiling(ipxk_context* c, int on) {
     });
 }
 
+int ipxk_set_interrupt(ipxk_context* c, ipxint (*interrupt)(void*), void* interrupt_user) {
+    return guarded([&] {
+        IPXK_REQUIRE(c != nullptr, "ctx is NULL");
+        c->interrupt = interrupt;
+        c->interrupt_user = interrupt_user;
+    });
+}
+
 int ipxk_synchronize(ipxk_context* c) {
     return guarded([&] {
         IPXK_REQUIRE(c != nullptr, "ctx is NULL");

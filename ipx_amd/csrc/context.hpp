@@ -36,6 +36,8 @@ struct Context {
     // optional per-operator timing (ipxk_set_profiling): HIP events around every operator /
     // preconditioner / triangular-solve application of a solve, summed into ipxk_times afterwards
     bool profile_ops = false;
+    ipxint (*interrupt)(void*) = nullptr;   // ipxk_set_interrupt: Control::InterruptCheck for calls without a callback argument
+    void* interrupt_user = nullptr;
     bool timing_active = false;
     std::vector<hipEvent_t> time_events;
     std::vector<int> time_kinds;        // per recorded event: kind (begin) or -1-kind (end)

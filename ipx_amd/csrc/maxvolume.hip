@@ -523,6 +523,7 @@ void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_i
                 fprintf(stderr, "ipxk: maxvolume slice %d: jn %d weight %.3e pmax %d jb %d vmax %.3e (etas %d, updates %lld, skipped %lld)\n", slice,
                         a.jn, a.weight, a.pmax, a.jb, a.vmax, K, (long long)I.updates, (long long)skipped);
             if (a.weight == 0.0) break;                                             // :243-244
+            if (c->interrupt && (I.errflag = c->interrupt(c->interrupt_user)) != 0) break;   // :250-251
             if (a.vmax <= volumetol) {                                              // :259-266
                 hipLaunchKernelGGL(mv_skip_kernel, dim3(1), dim3(1), 0, s, M.scalars.get(), M.colweights.get(), M.colscale.get());
                 if (++skipped > prm->maxskip_updates && prm->maxskip_updates >= 0) break;
@@ -682,6 +683,7 @@ void maxvolume_sequential_dev(Context* c, const ipxint* status_in, const double*
             const double dj = cand.back().first;
             if (dj == 0.0) break;
             if (status_h[(size_t)j] != IPXK_NONBASIC) { cand.pop_back(); continue; }
+            if (c->interrupt && (I.errflag = c->interrupt(c->interrupt_user)) != 0) break;   // :52-53
             // tableau column and search_pivot
             hipLaunchKernelGGL(mvs_set_candidate_kernel, dim3(1), dim3(1), 0, s, (int)j, dj, M.scalars.get());
             IPXK_HIP(hipMemsetAsync(M.rhs.get(), 0, (size_t)m * sizeof(double), s));

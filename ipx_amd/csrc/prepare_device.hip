@@ -446,6 +446,7 @@ struct Scratch {   // reused by the four sweeps of a Prepare and kept from one P
     DevBuf<unsigned char> tmp;
     DevBuf<int> rp, ri;
     DevBuf<double> rx, dgn;
+    int level_grid = -1;     // workgroups of level_sweep_kernel: all resident on this context's device (-1: not asked yet)
     int* h_flag = nullptr;   // pinned
     ~Scratch() { if (h_flag) (void)hipHostFree(h_flag); }
 };
@@ -493,14 +494,16 @@ void finish_sweep(Context* c, Scratch& W, Sweep& S, bool level_launches, int dim
     if (!W.h_flag) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&W.h_flag), sizeof(int)));
     bool have_levels = false;
     if (dim > 0 && !(getenv("IPXK_LEVEL_SWEEP") && getenv("IPXK_LEVEL_SWEEP")[0] == '0')) {
-        static const int resident = [] {
+        if (W.level_grid < 0) {                                   // per context, i.e. per device (as the sweeps' grid, trisolve.hip)
             int dev = 0, per_cu = 0;
             hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, level_sweep_kernel, kBlock, 0) != hipSuccess) return 0;
-            // one block per CU is held back from what the query reports (as for the sweeps, trisolve.hip), at most 4 are used
-            return prop.multiProcessorCount * std::max(0, std::min(per_cu - 1, 4));
-        }();
+            W.level_grid = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, level_sweep_kernel, kBlock, 0) == hipSuccess)
+                // one block per CU is held back from what the query reports, at most 4 are used
+                W.level_grid = prop.multiProcessorCount * std::max(0, std::min(per_cu - 1, 4));
+        }
+        const int resident = W.level_grid;
         if (resident > 0) {
             IPXK_HIP(hipMemsetAsync(W.level.get(), 0xff, sizeof(int) * dim, s));
             IPXK_HIP(hipMemsetAsync(changed.get(), 0, sizeof(int), s));

@@ -25,7 +25,7 @@ NONBASIC_FIXED, NONBASIC, BASIC, BASIC_FREE = -2, -1, 0, 1
 
 EXPORTS = [
     "ipxk_last_error", "ipxk_device_count", "ipxk_create", "ipxk_destroy", "ipxk_set_pointer_mode",
-    "ipxk_set_stream", "ipxk_synchronize", "ipxk_set_profiling", "ipxk_num_dense_cols", "ipxk_get_rowwise",
+    "ipxk_set_stream", "ipxk_synchronize", "ipxk_set_profiling", "ipxk_set_interrupt", "ipxk_num_dense_cols", "ipxk_get_rowwise",
     "ipxk_normal_prepare", "ipxk_normal_apply", "ipxk_diag_factorize", "ipxk_diag_apply",
     "ipxk_diag_get", "ipxk_pcr_solve", "ipxk_cr_diagnostics", "ipxk_kkt_diag_factorize", "ipxk_kkt_diag_solve",
     "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_rescale", "ipxk_split_apply", "ipxk_forward_solve",
@@ -223,6 +223,11 @@ class KktContext:
 
     def set_profiling(self, on):
         self._check(self.lib.ipxk_set_profiling(self.h, C.c_int(1 if on else 0)))
+
+    def set_interrupt(self, interrupt):
+        """Control::InterruptCheck for maxvolume / maxvolume_sequential (polled once per candidate); None removes it"""
+        self._interrupt_cb = INTERRUPT_FN(lambda _u: int(interrupt())) if interrupt else C.cast(None, INTERRUPT_FN)
+        self._check(self.lib.ipxk_set_interrupt(self.h, self._interrupt_cb, None))
 
     def synchronize(self):
         self._check(self.lib.ipxk_synchronize(self.h))

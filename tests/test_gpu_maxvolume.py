@@ -104,3 +104,32 @@ def test_maxvolume_sequential_vs_oracle(kkt, oracle, po, m, n, bump, seed, free,
     x = ctx.solve_dense(rhs, "n")
     assert np.abs(Bm @ x - rhs).max() <= 1e-8 * (1 + np.abs(x).max())
     ctx.close()
+
+
+def test_maxvolume_polls_the_interrupt_callback(kkt, oracle, po):
+    """Control::InterruptCheck inside Maxvolume (src/maxvolume.cc:52,250): ipxk_set_interrupt's callback is polled once per
+    candidate column; a nonzero value ends the run with that errflag, the exchanges made before it are kept and are
+    the first ones of the uninterrupted run"""
+    m, n = 300, 700
+    P, status, colscale, Ao = setup(po, m, n, 20, 4)
+    runs = {}
+    for variant in ("heuristic", "sequential"):
+        for stop_after in (None, 7):
+            ctx = kkt.KktContext(P["A"])
+            ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+            ctx.split_prepare_lu(status, colscale)
+            polls = [0]
+
+            def cb():
+                polls[0] += 1
+                return 998 if stop_after is not None and polls[0] > stop_after else 0
+            ctx.set_interrupt(cb)
+            got = ctx.maxvolume(status, colscale, volume_tol=2.0) if variant == "heuristic" else ctx.maxvolume_sequential(status, colscale, volume_tol=2.0)
+            runs[(variant, stop_after)] = (got, polls[0])
+            ctx.set_interrupt(None)
+            ctx.close()
+        full, cut = runs[(variant, None)], runs[(variant, 7)]
+        assert full[0]["errflag"] == 0 and full[1] >= full[0]["updates"] > 7
+        assert cut[0]["errflag"] == 998 and cut[1] == 8 and cut[0]["updates"] <= 7
+        k = cut[0]["updates"]
+        assert np.array_equal(np.asarray(cut[0]["exchanges"])[:k], np.asarray(full[0]["exchanges"])[:k])
