@@ -30,3 +30,5 @@ json.dump({"workload": "C3 basis path, planted factors: one operator application
            "layouts": [a for a in sys.argv[3:5]] if len(sys.argv) > 4 else ["sorted", "sorted"], "source_hashes": bench.source_hashes(),
            "source": "profiles/r03_basis_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on scripts/gpu_basis_iter.py, FETCH x2 gfx950 correction)"},
           open("gpurun_out/pmc_traffic_basis.json", "w"), indent=1)
+import shutil
+shutil.copy("gpurun_out/pmc_traffic_basis.json", "profiles/pmc_traffic_basis.json")   # a bench.py run in the same call reads it from there
