@@ -133,3 +133,20 @@ def test_maxvolume_polls_the_interrupt_callback(kkt, oracle, po):
         assert cut[0]["errflag"] == 998 and cut[1] == 8 and cut[0]["updates"] <= 7
         k = cut[0]["updates"]
         assert np.array_equal(np.asarray(cut[0]["exchanges"])[:k], np.asarray(full[0]["exchanges"])[:k])
+
+
+@pytest.mark.parametrize("args", ["2000 5000 300 12345", "3000 7000 100 7", "20000 45000 400 3", "600 1500 60 5 1", "900 2000 150 11 1"])
+def test_maxvolume_against_the_reference_itself(args):
+    """oracle/_ref/test_maxvol_dropin (tests/dropin/maxvol_main.cc): the reference's own ipx::Maxvolume (RunHeuristic; with
+    a fifth argument RunSequential) on the reference's ipx::Basis against ipxk_maxvolume / ipxk_maxvolume_sequential from
+    the same slack basis, scaling factors and parameters -- the program fails unless the final bases agree in >= 99 % of
+    their columns and the volume gained to 1e-6; measured on the MI355X: IDENTICAL final bases, update and skip counts,
+    volume to 12 digits in every case"""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "test_maxvol_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/test_maxvol_dropin not built (needs the reference sources at build time)")
+    r = subprocess.run([exe] + args.split(), capture_output=True, text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0 and "DONE" in r.stdout and "PASS" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "IDENTICAL decisions" in r.stdout, r.stdout
