@@ -258,3 +258,19 @@ def test_ipm_driver_basis_refuses_what_it_does_not_handle(kkt):
     g = ctx.ipm_driver_basis(b, c, lbs, ubs, ipm_maxiter=2)      # iteration limit of the basis phase
     assert g["status_ipm"] == 6 and g["iter"] == 2 and g["basis_updates"] > 0
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", ["2000 5000 12345", "500 1200 7", "20000 50000 3"])
+def test_ipm_driver_against_the_reference_itself(args):
+    """oracle/_ref/test_ipm_dropin (tests/dropin/ipm_main.cc): the reference's own IPM::Driver over its own KKTSolverDiag
+    against ipxk_ipm_driver, both from the starting point the reference's IPM::ComputeStartingPoint produced: mu,
+    residuals and objectives after 1, 2, 4, 8 iterations (2e-3; measured: equal in every printed digit, CR iteration
+    counts included, for the first four), and the end of the run (optimal value 1e-7, or the same switch point)"""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "test_ipm_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/test_ipm_dropin not built (needs the reference sources at build time)")
+    r = subprocess.run([exe] + args.split(), capture_output=True, text=True, timeout=900)
+    print(r.stdout)
+    assert r.returncode == 0 and "DONE" in r.stdout and r.stdout.count("PASS") == 5, (r.stdout[-3000:], r.stderr[-2000:])
