@@ -11,8 +11,13 @@
 //   rows a1-a7, a9(apply from explicit factors)-a13, a15, a16: pinned against
 //   the reference's own objects (oracle/_ref) and the committed golden vectors.
 //   rows a8 (Prepare) and a14 (KKTSolverBasis::_Solve): the reference classes
-//   need BASICLU -> not runnable here; pinned only through their building
-//   blocks and the KKT-residual property ("parity partially unpinned").
+//   need ipx::Basis, hence BASICLU -> not runnable on the CPU alone; this
+//   restatement is pinned through their building blocks and the KKT-residual
+//   property.  Round 3: with the device LU standing in for BASICLU (test harness
+//   tests/dropin/basiclu_absent.cc) the reference's own SplittedNormalMatrix /
+//   KKTSolverBasis / Maxvolume / IPM objects run on the MI355X box next to the
+//   device code that the GPU tests hold equal to this restatement
+//   (tests/dropin/basis_main.cc, maxvol_main.cc, ipm_main.cc): pinned through it.
 
 #include "ipx_oracle.h"
 
@@ -967,9 +972,10 @@ extern "C" void orc_split_free(orc_split* S) { delete S; }
 
 // ---------------------------------------------------------------------------
 // IPM::SolveNewtonSystem, src/ipm.cc:532-645.
-// PARITY UNPINNED against the reference: ipm.cc cannot be linked here (it needs
-// ipx::Basis, hence BASICLU); this is a line-by-line restatement, additionally
-// checked by the Newton equations it must satisfy (tests/).
+// ipm.cc cannot be linked on the CPU alone (it needs ipx::Basis, hence BASICLU); a
+// line-by-line restatement, checked by the Newton equations it must satisfy (tests/)
+// and, through the device code held equal to it, against the reference's own
+// IPM::Driver (tests/dropin/ipm_main.cc, GPU box).
 // state[j]: 0 fixed, 1 free, 2 barrier lb, 3 barrier ub, 4 barrier boxed
 // (Iterate::StateOf / has_barrier_lb / has_barrier_ub, src/iterate.h:99-108).
 // ---------------------------------------------------------------------------
@@ -1159,8 +1165,8 @@ extern "C" double orc_step_to_boundary(Int len, const double* x, const double* d
 
 // ---------------------------------------------------------------------------
 // One IPM step: IPM::Predictor, AddCorrector, StepSizes, MakeStep
-// (src/ipm.cc:340-530) around KKTSolverDiag.  PARITY UNPINNED (ipm.cc cannot be
-// linked here); a restatement line by line, built from the pinned pieces above.
+// (src/ipm.cc:340-530) around KKTSolverDiag.  A restatement line by line, built
+// from the pinned pieces above; pinned through the device code (tests/dropin/ipm_main.cc).
 // info: step_primal, step_dual, mu_before, mu_after, sigma, kktiter_predictor,
 //       kktiter_corrector  (7 doubles)
 // ---------------------------------------------------------------------------
@@ -1313,8 +1319,8 @@ extern "C" void orc_model_norms(Int m, Int n, const double* b, const double* c, 
 // IPM::Driver, src/ipm.cc:56-123, around KKTSolverDiag: termination test (Iterate::term_crit_reached with
 // crossover_start = 0, iterate.cc:221-249), divergence / bad-iteration test with the infeasibility
 // classification, iteration limit, Factorize, Predictor + AddCorrector + MakeStep (orc_ipm_step_diag), the
-// bad-iteration count and best complementarity of MakeStep (:520-530).  PARITY UNPINNED as a whole (ipm.cc
-// cannot be linked here); built from pinned pieces.  Returns status_ipm (IPX_STATUS_*).
+// bad-iteration count and best complementarity of MakeStep (:520-530).  Built from pinned pieces; the device driver held
+// equal to it runs against the reference's own IPM::Driver (tests/dropin/ipm_main.cc).  Returns status_ipm (IPX_STATUS_*).
 // info[10] = iter, errflag, kktiter, pobjective and dobjective after postprocessing, presidual, dresidual,
 //            complementarity, mu, last min(step_primal, step_dual)
 // ---------------------------------------------------------------------------
@@ -1691,7 +1697,9 @@ extern "C" void orc_lu_free(orc_lu* F) { delete F; }
 // the pivot from the tableau row (BTRAN) against the one from the tableau column (FTRAN), relative 1e-8
 // (the role of kFtDiagErrorTol, src/ipx_internal.h:37); on failure, and after max_etas exchanges, the basis is
 // refactorized (Basis::ExchangeIfStable :299-306, :318-319).
-// PARITY UNPINNED as a whole: Maxvolume needs a live ipx::Basis (BASICLU).
+// Maxvolume needs a live ipx::Basis (BASICLU): pinned through the device code, which takes the same exchanges as this
+// restatement (tests/test_gpu_maxvolume.py) and ends in the same basis as the reference's own ipx::Maxvolume
+// (tests/dropin/maxvol_main.cc).
 // ---------------------------------------------------------------------------
 struct orc_basis {
     Int m = 0, n = 0;

@@ -175,7 +175,7 @@ orc_int orc_kkt_basis_solve(orc_split* S, const double* a, const double* b,
                             orc_int hist_cap);
 void orc_split_free(orc_split* S);
 
-/* ---- IPM::SolveNewtonSystem (src/ipm.cc:532-645); parity unpinned, see .cc ---- */
+/* ---- IPM::SolveNewtonSystem (src/ipm.cc:532-645); pinned through the device code, see .cc ---- */
 orc_int orc_newton_solve_diag(orc_kkt_diag* K, const double* rb, const double* rc,
     const double* rl, const double* ru, const double* sl, const double* su,
     const double* xl, const double* xu, const double* zl, const double* zu,
@@ -202,7 +202,7 @@ void orc_iterate_complementarity(orc_int N, const unsigned char* state, const do
 double orc_step_to_boundary(orc_int len, const double* x, const double* dx, double alpha,
                             orc_int* blocking_index);
 
-/* IPM::Predictor + AddCorrector + StepSizes + MakeStep (src/ipm.cc:340-530); parity unpinned.
+/* IPM::Predictor + AddCorrector + StepSizes + MakeStep (src/ipm.cc:340-530); pinned through the device code (tests/dropin/ipm_main.cc).
  * The iterate is updated in place; info[7] = step_primal, step_dual, mu_before, mu_after, sigma,
  * kktiter_predictor, kktiter_corrector.  Returns the errflag of the KKT solves. */
 orc_int orc_ipm_step_diag(orc_kkt_diag* K, const unsigned char* state, const double* b,
@@ -216,7 +216,7 @@ void orc_iterate_objectives(orc_int m, orc_int n, const orc_int* Ap, const orc_i
 /* Model::ComputeNorms (src/model.cc:58-67): out2 = norm_bounds, norm_c */
 void orc_model_norms(orc_int m, orc_int n, const double* b, const double* c, const double* lb,
                      const double* ub, double* out2);
-/* IPM::Driver (src/ipm.cc:56-123) around KKTSolverDiag; parity unpinned as a whole.  Returns status_ipm;
+/* IPM::Driver (src/ipm.cc:56-123) around KKTSolverDiag; pinned through the device code (tests/dropin/ipm_main.cc).  Returns status_ipm;
  * info[10] = iter, errflag, kktiter, pobjective, dobjective (after postprocessing), presidual, dresidual,
  * complementarity, mu, last min(step_primal, step_dual). */
 orc_int orc_ipm_driver_diag(orc_kkt_diag* K, const unsigned char* state, const double* b,
