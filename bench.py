@@ -767,6 +767,28 @@ def bench_maxvolume(kkt, synth, m, n, args, entering=300):
         res["cpu_baseline"] = {"value": 1.0 / tc, "unit": "runs/s", "cores": 1, "kind": "port",
                                "sample": "1 x the same Maxvolume run by the repo's CPU restatement (%.1f s)" % tc}
         res["gpu_over_cpu"] = tc / dt
+        # the same kind of run against the reference's OWN ipx::Maxvolume on its ipx::Basis (tests/dropin/maxvol_main.cc; the
+        # program generates its model itself, same shape; the reference's Basis takes its LU from the device there)
+        exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "test_maxvol_dropin")
+        if os.path.exists(exe):
+            import re, subprocess
+            try:
+                pr = subprocess.run([exe, str(m), str(n), str(entering), "12345"], capture_output=True, text=True, timeout=600)
+                pat = r"errflag (\d+) updates (\d+) skipped (\d+) slices (\d+) volinc ([-+.\de]+) time ([.\d]+) s"
+                mr = re.search("reference: +" + pat, pr.stdout)
+                md = re.search("device: +" + pat, pr.stdout)
+                if mr and md:
+                    res["against_the_reference_itself"] = {
+                        "workload": "tests/dropin/maxvol_main.cc %d %d %d 12345: ipx::Maxvolume::RunHeuristic on the reference's ipx::Basis "
+                                    "(Forrest-Tomlin updates) next to ipxk_maxvolume, same slack basis / scaling factors / parameters" % (m, n, entering),
+                        "reference_seconds_one_core": float(mr.group(6)), "device_seconds": float(md.group(6)),
+                        "updates_reference_device": [int(mr.group(2)), int(md.group(2))],
+                        "skipped_reference_device": [int(mr.group(3)), int(md.group(3))],
+                        "volinc_reference_device": [float(mr.group(5)), float(md.group(5))],
+                        "identical_final_basis_and_counts": "IDENTICAL decisions" in pr.stdout,
+                        "device_over_reference": float(mr.group(6)) / max(float(md.group(6)), 1e-9)}
+            except Exception as exc:
+                sys.stderr.write("test_maxvol_dropin did not run (%s)\n" % exc)
     return res
 
 
