@@ -441,12 +441,26 @@ __global__ __launch_bounds__(kPanelThreads) void lu_panel_kernel(Dense A, int c0
 // The same for bumps of at most kPanelThreads rows: a thread owns one row of the panel in registers, the pivot
 // row travels through LDS; the panel is read and written once.  Same arithmetic, same order.  (The column steps
 // are instantiated one by one: v[] must be indexed by constants to stay in registers.)
+// (two copies of everything, used alternately by consecutive pivot steps: a step then needs two barriers, not four --
+// every thread combines the wavefronts' candidates itself, and no barrier has to protect the buffers for the next step)
 struct PanelShared {
-    double red_v[kPanelThreads / 64];
-    int red_r[kPanelThreads / 64];
-    double su[kPanel];
-    int s_pr;
+    double red_v[2][kPanelThreads / 64];
+    int red_r[2][kPanelThreads / 64];
+    double su[2][kPanel];
 };
+// the pivot row of a step from the wavefronts' candidates (largest |entry|, ties: smaller row); -1: none / no column
+__device__ __forceinline__ int panel_pivot_row(const PanelShared& sh, int par, bool col, double abstol, bool* dependent) {
+    double bv = 0.0;
+    int rr = INT_MAX;
+#pragma unroll
+    for (int w = 0; w < kPanelThreads / 64; w++) {
+        const double v = sh.red_v[par][w];
+        const int r = sh.red_r[par][w];
+        if (v > bv || (v == bv && r < rr)) { bv = v; rr = r; }
+    }
+    *dependent = col && (rr == INT_MAX || !(bv >= abstol) || bv == 0.0);
+    return col && !*dependent ? rr : -1;
+}
 template <int T>
 __device__ __forceinline__ void panel_small_steps(const Dense& A, PanelShared& sh, double (&v)[kPanel], int c0, int c1, int r,
                                                   bool& active, int& np, int& step) {
@@ -461,45 +475,36 @@ __device__ __forceinline__ void panel_small_steps(const Dense& A, PanelShared& s
             const int orr = __shfl_xor(br, d, 64);
             if (ov > best || (ov == best && orr < br)) { best = ov; br = orr; }
         }
-        if (lane == 0) { sh.red_v[wave] = best; sh.red_r[wave] = br; }
+        constexpr int par = T & 1;
+        if (lane == 0) { sh.red_v[par][wave] = best; sh.red_r[par][wave] = br; }
         __syncthreads();
+        bool dependent;
+        const int pr = panel_pivot_row(sh, par, col, A.abstol, &dependent);      // uniform over the workgroup
         if (tid == 0) {
-            double bv = 0.0;
-            int rr = INT_MAX;
-            for (int w = 0; w < kPanelThreads / 64; w++)
-                if (sh.red_v[w] > bv || (sh.red_v[w] == bv && sh.red_r[w] < rr)) { bv = sh.red_v[w]; rr = sh.red_r[w]; }
-            if (!col) {
-                sh.s_pr = -1;
-            } else if (rr == INT_MAX || !(bv >= A.abstol) || bv == 0.0) {
-                sh.s_pr = -1;
-                A.bcstep[c0 + T] = -1;
-            } else {
-                sh.s_pr = rr;
-                A.brstep[rr] = step;
+            if (dependent) A.bcstep[c0 + T] = -1;
+            else if (pr >= 0) {
+                A.brstep[pr] = step;
                 A.bcstep[c0 + T] = step;
-                A.prow[np] = rr;
+                A.prow[np] = pr;
                 A.pcol[np] = c0 + T;
             }
         }
-        __syncthreads();
-        const int pr = sh.s_pr;                        // uniform over the workgroup
-        if (pr >= 0) { np++; step++; }
         if (pr >= 0 && r == pr) {
             active = false;
 #pragma unroll
-            for (int t2 = 0; t2 < kPanel; t2++) sh.su[t2] = v[t2];
+            for (int t2 = 0; t2 < kPanel; t2++) sh.su[par][t2] = v[t2];
         }
         __syncthreads();
+        if (pr >= 0) { np++; step++; }
         if (pr >= 0 && active) {
-            const double l = v[T] / sh.su[T];
+            const double l = v[T] / sh.su[par][T];
             v[T] = l;
 #pragma unroll
             for (int t2 = T + 1; t2 < kPanel; t2++) {
-                const double u = sh.su[t2];
+                const double u = sh.su[par][t2];
                 if (c0 + t2 < c1 && u != 0.0) v[t2] -= l * u;
             }
         }
-        __syncthreads();                               // su and red_* are reused by the next column
         panel_small_steps<T + 1>(A, sh, v, c0, c1, r, active, np, step);
     }
 }
@@ -525,11 +530,12 @@ __global__ __launch_bounds__(kPanelThreads) void lu_panel_small_kernel(Dense A, 
 // Bumps of more than kPanelThreads rows: panels of kNarrow columns, a thread owns R rows of the panel in registers
 // (R * kPanelThreads >= rows).  Same arithmetic, same order; the two kernels that follow a panel take the number
 // of its pivots from bstep[1], so they serve both panel widths.
-constexpr int kNarrow = 8;
-template <int R, int T>
-__device__ __forceinline__ void panel_multi_steps(const Dense& A, PanelShared& sh, double (&v)[R][kNarrow], int c0, int c1,
+constexpr int kNarrow = 8;            // panel width with 4 rows per thread (bumps of 2049 .. 4096 rows)
+constexpr int kNarrowWide = 16;       // ... with 2 rows per thread (1025 .. 2048 rows): half the panels, the same registers
+template <int R, int W, int T>
+__device__ __forceinline__ void panel_multi_steps(const Dense& A, PanelShared& sh, double (&v)[R][W], int c0, int c1,
                                                   unsigned& active, int& np, int& step) {
-    if constexpr (T < kNarrow) {
+    if constexpr (T < W) {
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const bool col = c0 + T < c1;                  // uniform
         double best = 0.0;
@@ -545,29 +551,20 @@ __device__ __forceinline__ void panel_multi_steps(const Dense& A, PanelShared& s
             const int orr = __shfl_xor(br, d, 64);
             if (ov > best || (ov == best && orr < br)) { best = ov; br = orr; }
         }
-        if (lane == 0) { sh.red_v[wave] = best; sh.red_r[wave] = br; }
+        constexpr int par = T & 1;
+        if (lane == 0) { sh.red_v[par][wave] = best; sh.red_r[par][wave] = br; }
         __syncthreads();
+        bool dependent;
+        const int pr = panel_pivot_row(sh, par, col, A.abstol, &dependent);      // uniform over the workgroup
         if (tid == 0) {
-            double bv = 0.0;
-            int rr = INT_MAX;
-            for (int w = 0; w < kPanelThreads / 64; w++)
-                if (sh.red_v[w] > bv || (sh.red_v[w] == bv && sh.red_r[w] < rr)) { bv = sh.red_v[w]; rr = sh.red_r[w]; }
-            if (!col) {
-                sh.s_pr = -1;
-            } else if (rr == INT_MAX || !(bv >= A.abstol) || bv == 0.0) {
-                sh.s_pr = -1;
-                A.bcstep[c0 + T] = -1;
-            } else {
-                sh.s_pr = rr;
-                A.brstep[rr] = step;
+            if (dependent) A.bcstep[c0 + T] = -1;
+            else if (pr >= 0) {
+                A.brstep[pr] = step;
                 A.bcstep[c0 + T] = step;
-                A.prow[np] = rr;
+                A.prow[np] = pr;
                 A.pcol[np] = c0 + T;
             }
         }
-        __syncthreads();
-        const int pr = sh.s_pr;                        // uniform over the workgroup
-        if (pr >= 0) { np++; step++; }
         if (pr >= 0 && (pr % kPanelThreads) == tid) {
             const int qp = pr / kPanelThreads;
 #pragma unroll
@@ -575,49 +572,49 @@ __device__ __forceinline__ void panel_multi_steps(const Dense& A, PanelShared& s
                 if (q == qp) {
                     active &= ~(1u << q);
 #pragma unroll
-                    for (int t2 = 0; t2 < kNarrow; t2++) sh.su[t2] = v[q][t2];
+                    for (int t2 = 0; t2 < W; t2++) sh.su[par][t2] = v[q][t2];
                 }
         }
         __syncthreads();
         if (pr >= 0) {
+            np++; step++;
 #pragma unroll
             for (int q = 0; q < R; q++)
                 if ((active >> q) & 1u) {
-                    const double l = v[q][T] / sh.su[T];
+                    const double l = v[q][T] / sh.su[par][T];
                     v[q][T] = l;
 #pragma unroll
-                    for (int t2 = T + 1; t2 < kNarrow; t2++) {
-                        const double u = sh.su[t2];
+                    for (int t2 = T + 1; t2 < W; t2++) {
+                        const double u = sh.su[par][t2];
                         if (c0 + t2 < c1 && u != 0.0) v[q][t2] -= l * u;
                     }
                 }
         }
-        __syncthreads();
-        panel_multi_steps<R, T + 1>(A, sh, v, c0, c1, active, np, step);
+        panel_multi_steps<R, W, T + 1>(A, sh, v, c0, c1, active, np, step);
     }
 }
-template <int R>
+template <int R, int W>
 __global__ __launch_bounds__(kPanelThreads) void lu_panel_multi_kernel(Dense A, int c0, int c1) {
     __shared__ PanelShared sh;
     const int kb = A.kb, tid = threadIdx.x;
     unsigned active = 0, have = 0;
-    double v[R][kNarrow];
+    double v[R][W];
 #pragma unroll
     for (int q = 0; q < R; q++) {
         const int r = tid + q * kPanelThreads;
         if (r < kb) { have |= 1u << q; if (A.brstep[r] < 0) active |= 1u << q; }
 #pragma unroll
-        for (int t = 0; t < kNarrow; t++) v[q][t] = (r < kb && c0 + t < c1) ? A.D[(size_t)(c0 + t) * kb + r] : 0.0;
+        for (int t = 0; t < W; t++) v[q][t] = (r < kb && c0 + t < c1) ? A.D[(size_t)(c0 + t) * kb + r] : 0.0;
     }
     int np = 0;
     int step = A.bstep[0];
-    panel_multi_steps<R, 0>(A, sh, v, c0, c1, active, np, step);
+    panel_multi_steps<R, W, 0>(A, sh, v, c0, c1, active, np, step);
 #pragma unroll
     for (int q = 0; q < R; q++)
         if ((have >> q) & 1u) {
             const int r = tid + q * kPanelThreads;
 #pragma unroll
-            for (int t = 0; t < kNarrow; t++)
+            for (int t = 0; t < W; t++)
                 if (c0 + t < c1) A.D[(size_t)(c0 + t) * kb + r] = v[q][t];
         }
     if (tid == 0) { A.bstep[0] = step; A.bstep[1] = np; }
@@ -1091,12 +1088,12 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
             }
         }
         Dense A{kb, D.get(), brstep.get(), bcstep.get(), bstep.get(), prow.get(), pcol.get(), abstol};
-        const int width = kb <= kPanelThreads ? kPanel : kb <= 4 * kPanelThreads ? kNarrow : kPanel;
+        const int width = kb <= kPanelThreads ? kPanel : kb <= 2 * kPanelThreads ? kNarrowWide : kb <= 4 * kPanelThreads ? kNarrow : kPanel;
         for (int c0 = 0; c0 < kb; c0 += width) {
             const int c1 = std::min(kb, c0 + width);
             if (kb <= kPanelThreads) hipLaunchKernelGGL(lu_panel_small_kernel, dim3(1), dim3(kPanelThreads), 0, s, A, c0, c1);
-            else if (kb <= 2 * kPanelThreads) hipLaunchKernelGGL(lu_panel_multi_kernel<2>, dim3(1), dim3(kPanelThreads), 0, s, A, c0, c1);
-            else if (kb <= 4 * kPanelThreads) hipLaunchKernelGGL(lu_panel_multi_kernel<4>, dim3(1), dim3(kPanelThreads), 0, s, A, c0, c1);
+            else if (kb <= 2 * kPanelThreads) hipLaunchKernelGGL((lu_panel_multi_kernel<2, kNarrowWide>), dim3(1), dim3(kPanelThreads), 0, s, A, c0, c1);
+            else if (kb <= 4 * kPanelThreads) hipLaunchKernelGGL((lu_panel_multi_kernel<4, kNarrow>), dim3(1), dim3(kPanelThreads), 0, s, A, c0, c1);
             else hipLaunchKernelGGL(lu_panel_kernel, dim3(1), dim3(kPanelThreads), 0, s, A, c0, c1);
             if (c1 < kb) {
                 hipLaunchKernelGGL(lu_panel_rows_kernel, dim3(grid_for(kb - c1)), dim3(kBlock), 0, s, A, c1);
