@@ -669,12 +669,15 @@ void build_sweep_blocks(Context* c, Sweep& S, bool level_launches) {
     int la = nlev;
     int64_t K = 0;
     for (const int64_t cap = std::min<int64_t>(tail_max, S.dim / 64); la > 1 && K + S.level_width[la - 1] <= cap;) K += S.level_width[--la];
+    // (a block starts and ends with a chunk: consecutive tiny levels may share a MERGED chunk, which stays whole)
+    while (la < nlev && la > 0 && S.level_chunk[la] == S.level_chunk[la - 1]) K -= S.level_width[la++];
     const bool tail = nlev - la >= kMinLevels && K >= kMinUnknowns;
     if (!tail) la = nlev;
     // ... and of first levels (their rows have no entries outside the block)
     int lb = 0;
     K = 0;
     for (const int64_t cap = std::min<int64_t>(head_max, S.dim / 64); lb < la - 1 && K + S.level_width[lb] <= cap;) K += S.level_width[lb++];
+    while (lb > 0 && lb < nlev && S.level_chunk[lb] == S.level_chunk[lb - 1]) K -= S.level_width[--lb];
     const bool head = lb >= kMinLevels && K >= kMinUnknowns;
     if (getenv("IPXK_SWEEP_STATS"))
         fprintf(stderr, "ipxk: sweep blocks: %d levels, tail candidate %d.. (%s), head candidate ..%d (%lld unknowns, %s)\n", nlev, la,

@@ -385,6 +385,45 @@ def test_inverted_head_and_tail_of_the_sweeps(kkt, po, oracle, monkeypatch, capf
     assert a[7] == b[7] == 0 and abs(a[6] - b[6]) <= 3 + b[6] // 50 and relerr(a[4], b[4]) < 1e-6 and relerr(a[5], b[5]) < 1e-6
 
 
+def test_inverted_blocks_on_chains_of_tiny_levels(kkt, po, oracle, monkeypatch, capfd):
+    """a block must start and end with a chunk: factors whose levels hold one or two unknowns each (a bidiagonal L
+    under a banded U: long stretches of MERGED chunks) with the blocks forced on -- Prepare must not trip over a block
+    boundary inside a merged chunk, and the solves agree with the level-scheduled form"""
+    import scipy.sparse as sp
+    from ipx_amd.synth import CscMatrix
+    m, n = 40000, 80500                                                       # (a block holds at most dim / 64 unknowns and at least 256)
+    rng = np.random.default_rng(12)
+    sub = rng.uniform(0.1, 0.5, m - 1) * rng.choice([-1.0, 1.0], m - 1)
+    Lm = sp.diags(sub, -1, shape=(m, m), format="csc")                        # a pure chain: m levels of one unknown
+    Lm.sort_indices()
+    up = rng.uniform(0.1, 0.5, m - 2) * rng.choice([-1.0, 1.0], m - 2)
+    Um = (sp.diags(rng.uniform(0.5, 2.0, m) * rng.choice([-1.0, 1.0], m)) + sp.diags(up, 2, shape=(m, m))).tocsc()   # two interleaved chains
+    Um.sort_indices()
+    L = CscMatrix(m, m, Lm.indptr, Lm.indices, Lm.data)
+    U = CscMatrix(m, m, Um.indptr, Um.indices, Um.data)
+    A = synth_identity_model(m, n)
+    ident = np.arange(m, dtype=np.int64)
+    status = np.full(n + m, -1, dtype=np.int64); status[:m] = 0
+    colscale = np.ones(n + m)
+    rhs = rng.standard_normal(m)
+    out = {}
+    monkeypatch.setenv("IPXK_TAIL_MIN_DIM", "1000")
+    monkeypatch.setenv("IPXK_VERBOSE", "1")
+    for cap in ("1000", "0"):
+        monkeypatch.setenv("IPXK_TAIL_INVERSE", cap)
+        monkeypatch.setenv("IPXK_HEAD_INVERSE", cap)
+        ctx = kkt.KktContext(A)
+        ctx.split_prepare(L, U, ident, ident, ident, status, colscale)
+        err = capfd.readouterr().err
+        assert (err.count("inverted") >= 4) == (cap != "0"), err                 # heads and tails of the sweeps over L and U
+        out[cap] = (ctx.solve_dense(rhs, "N"), ctx.solve_dense(rhs, "T"))
+        ctx.close()
+    Lo, Uo = ocsc(po, L), ocsc(po, U)
+    assert np.array_equal(out["0"][0], oracle.forward_solve(Lo, Uo, rhs)) and np.array_equal(out["0"][1], oracle.backward_solve(Lo, Uo, rhs))
+    for k in (0, 1):
+        assert relerr(out["1000"][k], out["0"][k]) <= 1e-11, (k, relerr(out["1000"][k], out["0"][k]))
+
+
 def test_operator_timers(kkt):
     """ipx_info::time_cr1_AAt / time_cr1_pre / time_cr2_NNt / _B / _Bt equivalents (ipxk_times)."""
     A, st = diag_problem(20000, 42000, seed=77)
