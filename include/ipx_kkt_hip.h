@@ -231,7 +231,7 @@ int ipxk_split_rescale(ipxk_context* ctx, const ipxint* status,
  * singleton must pass |a| >= pivottol * max|active column|).  Absolute pivot
  * tolerance: kLuDependencyTol = 1e-3 (src/ipx_internal.h:26) if
  * strict_abs_pivottol, else 1e-14.  A bump of more than IPXK_LU_BUMP_MAX rows
- * (environment, default 4096) is torn first: whenever the rounds stall, the
+ * (environment, default 8192) is torn first: whenever the rounds stall, the
  * active columns with the most active entries are set aside as spikes and the
  * rounds go on; the spikes are carried through the row singleton pivots by a
  * forward substitution and end in a dense block of one row per spike

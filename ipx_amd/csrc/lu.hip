@@ -26,7 +26,7 @@
 // The rules (tolerances, tie breaks, order of the dependent columns) are restated on the CPU by the test
 // infrastructure, which the tests compare against entry by entry; the reference's own
 // LuFactorization::Factorize (stability estimate) and ForrestTomlin judge the factors there as well.
-//   2b. TEARING.  A bump of more than IPXK_LU_BUMP_MAX rows (default 4096) is not factorized densely as it stands.
+//   2b. TEARING.  A bump of more than IPXK_LU_BUMP_MAX rows (default 8192) is not factorized densely as it stands.
 //      LP bumps are sparse and nearly triangular themselves -- a few columns (the ones recent basis exchanges
 //      brought in) block the singleton rounds, and singleton peeling is all-or-nothing along dependency chains.
 //      Whenever the rounds stall, the T active columns with the most active entries (ties: smaller index) are set
@@ -920,7 +920,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
              abstol, pivottol};
     int rounds = 0;
     const int batch = 8;
-    int kb_max = 4096;
+    int kb_max = 8192;      // (4096 until round 3: the IPM's bases on random 12 000-row LPs end in bumps of 8000 rows)
     if (const char* e = getenv("IPXK_LU_BUMP_MAX")) kb_max = std::max(0, atoi(e));
     bool tearing = false;
     int ntorn = 0, tear_width = 1, npiv_at_tear = 0;

@@ -1144,6 +1144,15 @@ __global__ void bump_positions_kernel(int s0, int kb, const int* __restrict__ po
     }
 }
 // between the two sweeps of a pair: `y` is the result of the first one
+// the blocked solve keeps the kb unknowns of the block in LDS: beyond 64 KB of dynamic LDS the kernels have to be allowed
+static void allow_bump_lds(size_t bytes) {
+    static size_t allowed = 64 * 1024;
+    if (bytes <= allowed) return;
+    IPXK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bump_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    IPXK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bump_solve_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    IPXK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bump_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    allowed = bytes;
+}
 static void bump_between(Context* c, bool trans, double* y, const int* done) {
     SplitOperator* S = c->split;
     if (S->bump_size == 0) return;
@@ -1157,6 +1166,7 @@ static void bump_between(Context* c, bool trans, double* y, const int* done) {
         return;
     }
     const size_t lds = (size_t)(kb + 64) * sizeof(double);
+    allow_bump_lds(lds);
     if (trans) hipLaunchKernelGGL(bump_solve_kernel<true>, dim3(1), dim3(kBumpThreads), lds, c->stream, kb, S->bumpD.get(), S->bump_invL.get(),
                                   S->bump_invU.get(), S->bump_pos_bwd.get(), y, done);
     else hipLaunchKernelGGL(bump_solve_kernel<false>, dim3(1), dim3(kBumpThreads), lds, c->stream, kb, S->bumpD.get(), S->bump_invL.get(),
@@ -1195,10 +1205,15 @@ static DeviceFactors cut_dense_block(Context* c, SplitOperator* S, const DeviceF
     // large blocks: the inverse itself (IPXK_BUMP_INVERSE_MIN rows and more, default 512; 0 = never), so that the solve
     // between two sweeps is one matrix-vector product over the chip instead of a blocked solve by one workgroup
     // (measured with a 1316-row block: 4.3 ms -> 0.06 ms per CR iteration of the drop-in solver; the reference's CPU solver: 0.54 ms)
+    // ... up to IPXK_BUMP_INVERSE_MAX rows (default: every block the LU can produce).  The inverse costs kb workgroups a whole
+    // blocked solve each -- about 1 s at 8000 rows -- but the one-workgroup solve it replaces takes 18 ms per application there:
+    // measured on a 12 000 x 30 000 LP through the drop-in solver (24 Prepares, 1100 CR iterations): 23 + 0.7 s against 43 s
     static const int inverse_min = [] { const char* e = getenv("IPXK_BUMP_INVERSE_MIN"); return e ? atoi(e) : 512; }();
-    S->bump_explicit = inverse_min > 0 && kb >= inverse_min;
+    static const int inverse_max = [] { const char* e = getenv("IPXK_BUMP_INVERSE_MAX"); return e ? atoi(e) : 8192; }();
+    S->bump_explicit = inverse_min > 0 && kb >= inverse_min && kb <= inverse_max;
     if (S->bump_explicit) {
         S->bump_inv.ensure((size_t)kb * kb); S->bump_invT.ensure((size_t)kb * kb); S->bump_x.ensure((size_t)kb);
+        allow_bump_lds((size_t)(kb + 64) * sizeof(double));
         hipLaunchKernelGGL(bump_inverse_kernel, dim3(kb), dim3(kBumpThreads), (size_t)(kb + 64) * sizeof(double), s, kb, S->bumpD.get(),
                            S->bump_invL.get(), S->bump_invU.get(), S->bump_inv.get(), S->bump_invT.get());
     }
