@@ -103,6 +103,7 @@ struct Context {
     SplitOperator* split = nullptr;
     PrepareHost* prepare_host = nullptr;   // host workspaces of split_prepare (trisolve.hip)
     LuState* lu = nullptr;                 // factors of the last ipxk_lu_factorize* (lu.hip)
+    void* blas_handle = nullptr;           // rocBLAS handle, created when a large dense block is first inverted (dense_blas.hip)
     MaxvolState* maxvol = nullptr;         // workspaces of ipxk_maxvolume (maxvolume.hip)
     NMatrix* nmat = nullptr;               // N of the split operator as a matrix of its own (nmatrix.hip)
 
@@ -214,6 +215,9 @@ CrResult kkt_basis_solve_dev(Context* c, const double* a, const double* b, doubl
                              void* user, ipxk_times* times);
 void split_levels(const Context* c, ipxint levels[4]);
 void check_sweep_abort(Context* c);
+// inverse of a dense LU-factored block by two rocblas_dtrsm (dense_blas.hip); false: rocBLAS unavailable, nothing launched
+bool blas_lu_inverse(Context* c, int kb, const double* D, double* X, double* Xt);
+void blas_destroy(Context* c);
 void destroy_split(SplitOperator*);
 void destroy_prepare_host(PrepareHost*);
 

@@ -1213,8 +1213,13 @@ static DeviceFactors cut_dense_block(Context* c, SplitOperator* S, const DeviceF
     S->bump_explicit = inverse_min > 0 && kb >= inverse_min && kb <= inverse_max;
     if (S->bump_explicit) {
         S->bump_inv.ensure((size_t)kb * kb); S->bump_invT.ensure((size_t)kb * kb); S->bump_x.ensure((size_t)kb);
+        // blocks of 1024 rows and more through rocBLAS where it can be loaded (two dtrsm on the identity: 0.5 / 4.8 / 28 ms at
+        // 1024 / 4096 / 8000 rows against 2 / 134 / 1000 ms for the kernel below; dense_blas.hip)
+        const char* blas_env = getenv("IPXK_ROCBLAS_MIN");          // (read per Prepare: the tests switch it)
+        const int blas_min = blas_env ? atoi(blas_env) : 1024;
+        const bool by_blas = kb >= blas_min && blas_lu_inverse(c, kb, S->bumpD.get(), S->bump_invT.get(), S->bump_inv.get());
         allow_bump_lds((size_t)(kb + 64) * sizeof(double));
-        hipLaunchKernelGGL(bump_inverse_kernel, dim3(kb), dim3(kBumpThreads), (size_t)(kb + 64) * sizeof(double), s, kb, S->bumpD.get(),
+        if (!by_blas) hipLaunchKernelGGL(bump_inverse_kernel, dim3(kb), dim3(kBumpThreads), (size_t)(kb + 64) * sizeof(double), s, kb, S->bumpD.get(),
                            S->bump_invL.get(), S->bump_invU.get(), S->bump_inv.get(), S->bump_invT.get());
     }
     IPXK_HIP(hipStreamSynchronize(s));               // cnt / start go out of scope; ends

@@ -236,3 +236,28 @@ def test_lu_and_maxvolume_at_baseline_size(kkt, ref):
     x = ctx.solve_dense(rhs, "n")
     assert np.abs(Bn @ x - rhs).max() <= 1e-9 * (1 + np.abs(x).max())
     ctx.close()
+
+
+def test_dense_block_inverse_by_rocblas_against_the_own_kernel(kkt, monkeypatch, capfd):
+    """the explicit inverse of a large dense block of the factors (trisolve.hip: cut_dense_block): two rocblas_dtrsm on the
+    identity (dense_blas.hip, blocks of >= 1024 rows where librocblas can be loaded) against the library's own
+    bump_inverse_kernel on the same factors -- operator applications and dense solves agree to 1e-11"""
+    from ipx_amd import synth
+    m, n, bump = 40000, 90000, 1300
+    P = synth.lp_like_basis(m, n, seed=5, bump=bump, offdiag=3)
+    colscale = synth.synthetic_basis_state(P["status"], 1.0, 5)
+    rhs = np.random.default_rng(2).standard_normal(m)
+    out = {}
+    for blas_min in ("1024", "1000000"):
+        monkeypatch.setenv("IPXK_ROCBLAS_MIN", blas_min)
+        ctx = kkt.KktContext(P["A"])
+        F = ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+        assert F["bump"] == bump
+        ctx.split_prepare_lu(P["status"], colscale)
+        out[blas_min] = (ctx.split_apply(rhs)[0], ctx.solve_dense(rhs, "N"), ctx.solve_dense(rhs, "T"))
+        ctx.close()
+    a, b = out["1024"], out["1000000"]
+    for k in range(3):
+        err = np.abs(a[k] - b[k]).max() / np.abs(b[k]).max()
+        assert err <= 1e-11, (k, err)
+    assert not np.array_equal(a[0], b[0])          # (otherwise rocBLAS was not used: the box has no librocblas?)
