@@ -424,6 +424,61 @@ def test_inverted_blocks_on_chains_of_tiny_levels(kkt, po, oracle, monkeypatch, 
         assert relerr(out["1000"][k], out["0"][k]) <= 1e-11, (k, relerr(out["1000"][k], out["0"][k]))
 
 
+def test_level_analysis_one_launch_against_the_relaxation(kkt, monkeypatch):
+    """the dependency levels of the four sweeps from ONE sync-free launch (level_sweep_kernel, the default) and from the
+    relaxation launches it replaced (IPXK_LEVEL_SWEEP=0, kept as the fall-back): the same levels, hence the same packed
+    factors and bit-identical solves -- on planted factors, on a banded structure with thousands of levels and on factors
+    with rows and columns of hundreds of entries (the rows the wavefront evaluates together)"""
+    import scipy.sparse as sp
+    from ipx_amd.synth import CscMatrix
+    rng = np.random.default_rng(21)
+    cases = [basis_problem(30000, 62000, seed=61), basis_problem(6000, 12500, seed=47, band=12)]
+    for B, st, colscale in cases:
+        m = B["A"].nrow
+        rhs = rng.standard_normal(m)
+        out = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("IPXK_LEVEL_SWEEP", mode)
+            ctx = kkt.KktContext(B["A"])
+            ctx.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
+            out[mode] = (ctx.split_levels(), ctx.forward_solve(rhs), ctx.backward_solve(rhs), ctx.split_apply(rhs)[0])
+            ctx.close()
+        assert out["1"][0] == out["0"][0]
+        for k in (1, 2, 3):
+            assert np.array_equal(out["1"][k], out["0"][k]), k
+    # long rows: a few rows / columns of 300 entries in L and U
+    m, n = 4000, 8200
+    def tri(lower):
+        rows, cols = [], []
+        for j in range(m - 1):
+            k = rng.integers(0, 4)
+            r = np.unique(rng.integers(j + 1, m, size=k)) if lower else np.unique(rng.integers(0, j + 1, size=k))
+            rows.append(r); cols.append(np.full(r.size, j if lower else j + 1))
+        for i in (m - 1, m - 9, m // 2):
+            c = rng.choice(i, size=300, replace=False)
+            rows.append(np.full(300, i) if lower else c); cols.append(c if lower else np.full(300, i))
+        rows, cols = np.concatenate(rows), np.concatenate(cols)
+        v = rng.uniform(0.05, 0.3, rows.size) * rng.choice([-1.0, 1.0], rows.size)
+        T = sp.coo_matrix((v, (rows, cols)), shape=(m, m)).tocsc()
+        T.sum_duplicates()
+        return sp.tril(T, -1).tocsc() if lower else sp.triu(T, 1).tocsc()
+    Lm = tri(True); Lm.sort_indices()
+    Um = (tri(False) + sp.diags(rng.uniform(0.5, 2.0, m) * rng.choice([-1.0, 1.0], m))).tocsc(); Um.sort_indices()
+    L = CscMatrix(m, m, Lm.indptr, Lm.indices, Lm.data); U = CscMatrix(m, m, Um.indptr, Um.indices, Um.data)
+    A = synth_identity_model(m, n)
+    ident = np.arange(m, dtype=np.int64)
+    status = np.full(n + m, -1, dtype=np.int64); status[:m] = 0
+    rhs = rng.standard_normal(m)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("IPXK_LEVEL_SWEEP", mode)
+        ctx = kkt.KktContext(A)
+        ctx.split_prepare(L, U, ident, ident, ident, status, np.ones(n + m))
+        out[mode] = (ctx.split_levels(), ctx.solve_dense(rhs, "N"), ctx.solve_dense(rhs, "T"))
+        ctx.close()
+    assert out["1"][0] == out["0"][0] and np.array_equal(out["1"][1], out["0"][1]) and np.array_equal(out["1"][2], out["0"][2])
+
+
 def test_operator_timers(kkt):
     """ipx_info::time_cr1_AAt / time_cr1_pre / time_cr2_NNt / _B / _Bt equivalents (ipxk_times)."""
     A, st = diag_problem(20000, 42000, seed=77)
