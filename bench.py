@@ -54,6 +54,7 @@ def parse():
                     help="N > 1: skip the extra measurement of the column partition (config.column_partition)")
     ap.add_argument("--no-lu", action="store_true", help="skip the basis LU factorization on the device (config.lu_path)")
     ap.add_argument("--no-maxvolume", action="store_true", help="skip Maxvolume on the device (config.maxvolume_path)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the reference's LpSolver through both KKT solver classes (config.dropin_lp_solver)")
     ap.add_argument("--no-banded", action="store_true", help="skip the banded-matrix probe of the SpMV (extra field of roofline)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 2 and 5 (config.other_configs)")
     ap.add_argument("--no-direct-exchange", action="store_true",
@@ -349,6 +350,8 @@ def main():
         out["config"]["maxvolume_path"] = bench_maxvolume(kkt, synth, m, n, args)
     if rank == 0 and world == 1 and not args.no_newton:
         out["config"]["newton_step"] = bench_newton(kkt, synth, ctx, m, n, args)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_dropin and (m, n) == (1000000, 2000000):
+        out["config"]["dropin_lp_solver"] = bench_dropin_lp_solver(m, n)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ctx.set_pointer_mode(False)
         Wd, xg, yg, traj = parity_inputs
@@ -790,6 +793,31 @@ def bench_maxvolume(kkt, synth, m, n, args, entering=300):
             except Exception as exc:
                 sys.stderr.write("test_maxvol_dropin did not run (%s)\n" % exc)
     return res
+
+
+def bench_dropin_lp_solver(m, n):
+    """CPU-baseline leg: the reference's own LpSolver (oracle/_ref/test_lp_ref, test_lp_hip: tests/dropin/lp_main.cc) on a 1M x 2M
+    synthetic LP, three iterations of the initial IPM (stop_at_switch = 1), once with the reference's KKTSolverDiag on one host core
+    and once with KKTSolverDiagHip (host pointers at the boundary, PCIe included): Info::time_kkt_solve of both runs."""
+    import re, subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    if not os.path.exists(os.path.join(here, "oracle", "_ref", "test_lp_hip")):
+        return {"skipped": "oracle/_ref/test_lp_hip not built"}
+    try:
+        pr = subprocess.run([sys.executable, os.path.join(here, "scripts", "gpu_lp_dropin_c3.py"), str(m), str(n), "3"], capture_output=True,
+                            text=True, timeout=900)
+        mt = re.search(r"KKT solve time \(Info::time_kkt_solve\): reference ([.\d]+) s, Hip ([.\d]+) s -> ([.\d]+) x;  initial IPM \(time_ipm1\): "
+                       r"([.\d]+) / ([.\d]+) s -> [.\d]+ x; kktiter1 (\d+) / (\d+)", pr.stdout)
+        if not mt:
+            return {"error": (pr.stdout + pr.stderr)[-400:]}
+        return {"workload": "ipx::LpSolver::Solve on a %d x %d synthetic LP, 3 iterations of the initial IPM (stop_at_switch = 1), through "
+                            "ipx::KKTSolverDiag (1 host core) and through ipx::KKTSolverDiagHip (host pointers at the boundary)" % (m, n),
+                "time_kkt_solve_reference_s": float(mt.group(1)), "time_kkt_solve_hip_s": float(mt.group(2)),
+                "hip_over_reference": float(mt.group(3)), "time_ipm1_reference_s": float(mt.group(4)), "time_ipm1_hip_s": float(mt.group(5)),
+                "kktiter1_reference_hip": [int(mt.group(6)), int(mt.group(7))],
+                "note": "time_ipm1 of the Hip run contains the one-time ipxk_create of the solver object (layouts built and tuned: ~3 s)"}
+    except Exception as exc:            # noqa: BLE001
+        return {"error": str(exc)}
 
 
 def basis_cpu_baseline(ctx, B, AI, colscale, m, n, us_iter_gpu, iters=8):
