@@ -521,6 +521,26 @@ ipxint ipxk_normal_apply_bytes(const ipxk_context* ctx);
  * us[6] receives the measured microseconds {pass1 phased, sliced (or sorted, if
  * that was kept), fused (or sorted fused), pass2 likewise} (0 = not timed). */
 int ipxk_spmv_layout(const ipxk_context* ctx, int layout[2], double us[6]);
+/* Inspection of the device layouts (tests: the layouts built on the device by
+ * radix sorts, layout_device.hip, against the host builders, array by array;
+ * IPXK_LAYOUT_BUILD=host forces the host builders).  The reference's
+ * NormalMatrix copies nothing (normal_matrix.h:20-27): what replaces its
+ * "construct = store a reference" is one upload + transpose + layout build per
+ * model, timed in create_ms {upload + transpose, A' layouts, A layouts, rest}.
+ * which: 0 = the gather matrix of A'y (rows = columns of A), 1 = of A t.
+ * info: {use_sliced, use_sorted, use_sorted_fused, nlong, sliced.built, R,
+ * nslices, nrb, nrows_pad, max_tile, bits of the fullest-slice share (double),
+ * sorted.built, nslices, nsub, nrb, RB, nrows_pad, max_sub, slice_elems, fused,
+ * nnz, P, G, RT*1e6 + Q*1e3}. */
+int ipxk_layout_info(const ipxk_context* ctx, int which, ipxint info[24],
+                     double create_ms[4]);
+/* array: 0 sliced tile_ptr (u32), 1 sliced cnt (u8), 2 sliced idx (i32), 3
+ * sliced val (f64), 4 sorted sub_ptr (u32), 5 sorted cnt (u8), 6 sorted pack
+ * (u32), 7 sorted val (f64), 8 / 9 / 10 the row-wise copy of the model (Transpose,
+ * sparse_matrix.cc:120-151) as the device holds it: ptr (i32), idx (i32), val
+ * (f64).  Copies min(cap, size) bytes into out; *nbytes = the array's size. */
+int ipxk_layout_array(ipxk_context* ctx, int which, int array, void* out,
+                      ipxint cap, ipxint* nbytes);
 /* plain device allocation helpers so that callers without torch can hold
  * resident vectors */
 int ipxk_dev_alloc(ipxk_context* ctx, ipxint bytes, void** ptr);

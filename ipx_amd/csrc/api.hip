@@ -275,6 +275,8 @@ int ipxk_get_rowwise(const ipxk_context* c, ipxint* ATp, ipxint* ATi, double* AT
         IPXK_HIP(hipSetDevice(c->device));
         // the row-wise copy is produced by the library's own Transpose arithmetic (spmv.hip)
         const size_t m = (size_t)c->m, nz = (size_t)c->nnz;
+        Context* cc = const_cast<Context*>(static_cast<const Context*>(c));
+        ensure_host_model(cc, true);      // a download of the device's row-wise copy (layout_device.hip)
         if (ATp) for (size_t r = 0; r <= m; r++) ATp[r] = c->h_ATp[r];
         if (ATi) for (size_t q = 0; q < nz; q++) ATi[q] = c->h_ATi[q];
         if (ATx) for (size_t q = 0; q < nz; q++) ATx[q] = c->h_ATx[q];
@@ -932,6 +934,56 @@ int ipxk_debug_get_stamps(ipxk_context* c, int which, unsigned long long* out, i
         const size_t n = std::min<size_t>((size_t)cap, M.stamps.size());
         M.stamps.download(out, n, c->stream);
         IPXK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+// Layout inspection (tests/test_gpu_layout.py: the device builders against the host builders, array by array).
+int ipxk_layout_info(const ipxk_context* c, int which, ipxint info[24], double create_ms[4]) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && info && (which == 0 || which == 1), "bad argument");
+        const GatherMatrix& M = which == 0 ? c->Acols : c->Arows;
+        for (int i = 0; i < 24; i++) info[i] = 0;
+        info[0] = M.use_sliced; info[1] = M.use_sorted; info[2] = M.use_sorted_fused; info[3] = M.nlong;
+        info[4] = M.sliced.built; info[5] = M.sliced.R; info[6] = M.sliced.nslices; info[7] = M.sliced.nrb;
+        info[8] = M.sliced.nrows_pad; info[9] = M.sliced.max_tile;
+        { double d = M.sliced.dominant_fraction; memcpy(&info[10], &d, sizeof d); }
+        info[11] = M.sorted.built; info[12] = M.sorted.nslices; info[13] = M.sorted.nsub; info[14] = M.sorted.nrb;
+        info[15] = M.sorted.RB; info[16] = M.sorted.nrows_pad; info[17] = M.sorted.max_sub; info[18] = M.sorted.slice_elems;
+        info[19] = M.sorted.fused; info[20] = M.nnz;
+        info[21] = M.P; info[22] = M.G; info[23] = (ipxint)M.RT * 1000000 + (ipxint)M.Q * 1000 + 0;
+        if (create_ms) for (int i = 0; i < 4; i++) create_ms[i] = c->create_ms[i];
+    });
+}
+// array: 0 sliced.tile_ptr (u32) 1 sliced.cnt (u8) 2 sliced.idx (i32) 3 sliced.val (f64) 4 sorted.sub_ptr (u32)
+// 5 sorted.cnt (u8) 6 sorted.pack (u32) 7 sorted.val (f64) 8 plain row-wise ptr (i32) 9 idx (i32) 10 val (f64).
+// Copies min(cap, size) bytes to `out` (host), *nbytes = size of the array in bytes.
+int ipxk_layout_array(ipxk_context* c, int which, int array, void* out, ipxint cap, ipxint* nbytes) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && nbytes && (which == 0 || which == 1), "bad argument");
+        bind_device(c);
+        const GatherMatrix& M = which == 0 ? c->Acols : c->Arows;
+        const void* src = nullptr;
+        size_t bytes = 0;
+        const size_t ntiles = (size_t)M.sliced.nrb * M.sliced.nslices, nsubs = (size_t)M.sorted.nrb * M.sorted.nslices * M.sorted.nsub;
+        const size_t nz = (size_t)M.nnz;
+        switch (array) {
+            case 0: src = M.sliced.tile_ptr.get(); bytes = M.sliced.built ? (ntiles + 1) * 4 : 0; break;
+            case 1: src = M.sliced.cnt.get(); bytes = M.sliced.built ? ntiles * M.sliced.R : 0; break;
+            case 2: src = M.sliced.idx.get(); bytes = M.sliced.built ? nz * 4 : 0; break;
+            case 3: src = M.sliced.val.get(); bytes = M.sliced.built ? nz * 8 : 0; break;
+            case 4: src = M.sorted.sub_ptr.get(); bytes = M.sorted.built ? (nsubs + 1) * 4 : 0; break;
+            case 5: src = M.sorted.cnt.get(); bytes = M.sorted.built ? nsubs * M.sorted.RB : 0; break;
+            case 6: src = M.sorted.pack.get(); bytes = M.sorted.built ? nz * 4 : 0; break;
+            case 7: src = M.sorted.val.get(); bytes = M.sorted.built ? nz * 8 : 0; break;
+            case 8: src = c->pl_Tp.get(); bytes = ((size_t)c->m + 1) * 4; break;
+            case 9: src = c->pl_Ti.get(); bytes = (size_t)c->nnz * 4; break;
+            case 10: src = c->pl_Tx.get(); bytes = (size_t)c->nnz * 8; break;
+            default: IPXK_REQUIRE(false, "unknown array");
+        }
+        if (M.nlong > 0 && array < 8) bytes = 0;       // long rows: the tiles hold fewer entries than nnz; not inspected
+        *nbytes = (ipxint)bytes;
+        const size_t ncopy = std::min<size_t>(bytes, cap > 0 ? (size_t)cap : 0);
+        if (out && ncopy > 0) staged_d2h(out, src, ncopy, c->stream);
     });
 }
 

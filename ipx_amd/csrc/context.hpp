@@ -45,10 +45,19 @@ struct Context {
 
     // ---- model ----
     int64_t m = 0, n = 0, nnz = 0;
-    std::vector<ipxint> h_Ap, h_Ai;     // host copy of the structural CSC
+    std::vector<ipxint> h_Ap;           // column pointers (host)
+    // host copies of the entries and of the row-wise copy: filled on demand only (ensure_host_model) -- the model
+    // lives on the device, the layouts are built there (layout_device.hip)
+    std::vector<ipxint> h_Ai;
     std::vector<double> h_Ax;
-    std::vector<ipxint> h_ATp, h_ATi;   // row-wise copy (host)
+    std::vector<ipxint> h_ATp, h_ATi;
     std::vector<double> h_ATx;
+    // the model on the device in plain form, 32-bit indices: CSC and the row-wise copy (Transpose,
+    // src/sparse_matrix.cc:120-151).  Shared by the layout builders, N (nmatrix.hip) and the basis LU (lu.hip).
+    DevBuf<int> pl_Ap, pl_Ai, pl_Tp, pl_Ti;
+    DevBuf<double> pl_Ax, pl_Tx;
+    bool have_plain = false;
+    double create_ms[4] = {0, 0, 0, 0};   // ipxk_create: upload + transpose, Acols layouts, Arows layouts, the rest
     GatherMatrix Acols;                 // rows = columns of A  (computes A'y)
     GatherMatrix Arows;                 // rows = rows of A     (computes A t)
     int64_t num_dense = 0, nz_dense = 0;
@@ -127,6 +136,19 @@ struct Context {
     ~Context();
     double* part(int slot) const { return partials.get() + (size_t)slot * kPartialStride; }
 };
+
+// layout_device.hip
+struct LayoutScratch;
+LayoutScratch* new_layout_scratch();
+void free_layout_scratch(LayoutScratch* S);
+void upload_plain_model(Context* c, const ipxint* Ap, const ipxint* Ai, const double* Ax);
+void ensure_host_model(Context* c, bool rowwise);
+void fetch_columns(Context* c, const std::vector<ipxint>& cols, std::vector<ipxint>& Cp, std::vector<ipxint>& Ci, std::vector<double>& Cx);
+int device_max_row_length(LayoutScratch& S, int nrows, const int* dptr, hipStream_t s);
+bool device_build_sliced(LayoutScratch& S, SlicedMatrix& out, int nrows, int ncols, int64_t nnz, const int* dptr, const int* didx,
+                         const double* dval, hipStream_t s);
+bool device_build_sorted(LayoutScratch& S, SortedMatrix& out, const SlicedMatrix& sliced, int nrows, int ncols, int64_t nnz, const int* dptr,
+                         const int* didx, const double* dval, hipStream_t s);
 
 enum TimeKind { kTimeOp = 0, kTimePrecond = 1, kTimeB = 2, kTimeBt = 3, kNumTimeKinds = 4 };
 void time_mark(Context* c, int kind, bool begin);      // no-op unless timing is active

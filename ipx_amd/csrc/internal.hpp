@@ -246,6 +246,8 @@ struct SortedMatrix {
     DevBuf<int> xmin;
 };
 
+struct LayoutScratch;                 // layout_device.hip
+
 struct GatherMatrix {
     int nrows = 0, ncols = 0;
     int64_t nnz = 0;
@@ -270,6 +272,13 @@ struct GatherMatrix {
     // Builds from host arrays with 64-bit indices (ptr has nrows+1 entries).
     void build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, const ipxint* hidx,
                const double* hval, hipStream_t s);
+    // Builds from the plain device copy (ptr / idx 32 bits) with radix sorts on the device (layout_device.hip): the sliced
+    // and the sorted layout, every array equal to build()'s.  Returns false -- nothing built -- when the matrix is not
+    // one of those the device path covers (long rows, a gathered vector that fits an XCD's L2, gathers that do not
+    // spread over the slices): the caller then runs build() on host arrays.
+    bool build_device(LayoutScratch& S, int64_t nrows_, int64_t ncols_, int64_t nnz_, const int* dptr, const int* didx,
+                      const double* dval, hipStream_t s);
+    void set_geometry(int64_t nrows_, int64_t ncols_);      // P, G, RT, Q, RWrows of the phased layout
     // optional second layout and the choice between the two (IPXK_SPMV_LAYOUT=phased|sliced|auto;
     // auto times both once at build time on this matrix and keeps the faster one)
     SlicedMatrix sliced;

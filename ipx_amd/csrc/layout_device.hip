@@ -1,0 +1,427 @@
+// Model upload and gather-matrix layouts built ON THE DEVICE (round 4).
+//
+// The reference's NormalMatrix stores a reference to the model and copies nothing (src/normal_matrix.h:20-27), so
+// constructing a KKT solver is free; rounds 1-3 built every layout of the model matrix with single-threaded host
+// loops (transpose, bucketing, std::sort per tile: 3.2 s at 1M x 2M, per solver object).  Here the matrix is uploaded
+// once as it is (CSC, 64-bit indices), narrowed and validated, transposed, and cut into the XCD-sliced tile layout
+// and the sorted sub-tile layout (internal.hpp) by radix sorts -- the same scheme nmatrix.hip uses for N:
+//   * a STABLE sort of the entries, enumerated in storage order, by (tile, row in tile) IS the sliced layout:
+//     tile pointers by binary search in the sorted keys, per-row byte counts from the runs of equal keys, indices
+//     and values by a gather through the sorted positions;
+//   * the sorted sub-tiles need two sorts: by (sub-tile, row) -- which numbers the slots -- and then, stably, by
+//     (sub-tile, offset in the slice): ties keep the slot order, exactly the host builder's comparator.
+// Every array equals the host builder's bit for bit (tests/test_gpu_layout.py compares them all); the host builder
+// (spmv.hip) stays as that test's reference and as the path of matrices the device path does not cover
+// (long rows, gathered vectors that fit an XCD's L2, gathers with locality: phased / fused / sorted-fused layouts).
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "context.hpp"
+
+namespace ipxk {
+
+namespace {
+
+using u64 = unsigned long long;
+#define IPXK_GS(i, n) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+int gridn(int64_t n) { return (int)std::min<int64_t>(8192, std::max<int64_t>(1, (n + kBlock - 1) / kBlock)); }
+int bits_for(u64 maxval) { int b = 1; while (b < 64 && (maxval >> b) != 0) b++; return b; }
+
+__global__ void narrow_kernel(int64_t nz, const ipxint* __restrict__ in, int* __restrict__ out, int limit, int* bad) {
+    IPXK_GS(p, nz) {
+        const ipxint v = in[p];
+        if (v < 0 || v >= limit) *bad = 1;
+        out[p] = (int)v;
+    }
+}
+// column (row of the gather matrix) and position of every entry, enumerated row by row
+__global__ void rowof_kernel(int nrows, const int* __restrict__ ptr, int* __restrict__ rowof, unsigned* __restrict__ pos) {
+    IPXK_GS(r, nrows)
+        for (int p = ptr[r]; p < ptr[r + 1]; p++) { rowof[p] = (int)r; if (pos) pos[p] = (unsigned)p; }
+}
+__global__ void gather_transposed_kernel(int64_t nz, const unsigned* __restrict__ perm, const int* __restrict__ colof,
+                                         const double* __restrict__ Ax, int* __restrict__ Ti, double* __restrict__ Tx) {
+    IPXK_GS(t, nz) {
+        const unsigned p = perm[t];
+        Ti[t] = colof[p];
+        Tx[t] = Ax[p];
+    }
+}
+template <class K>
+__global__ void lower_bounds_kernel(int64_t count, int64_t nz, const K* __restrict__ sorted, u64 stride, int shift, unsigned* __restrict__ out) {
+    // out[t] = first position whose key is >= t * stride (shift: keys are compared after >> shift)
+    IPXK_GS(t, count) {
+        const u64 want = (u64)t * stride;
+        int64_t lo = 0, hi = nz;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (((u64)sorted[mid] >> shift) < want) lo = mid + 1; else hi = mid; }
+        out[t] = (unsigned)lo;
+    }
+}
+__global__ void row_pointers_kernel(int64_t m, int64_t nz, const unsigned* __restrict__ sorted_rows, int* __restrict__ Tp) {
+    IPXK_GS(i, m + 1) {
+        int64_t lo = 0, hi = nz;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted_rows[mid] < (unsigned)i) lo = mid + 1; else hi = mid; }
+        Tp[i] = (int)lo;
+    }
+}
+__global__ void max_len_kernel(int nrows, const int* __restrict__ ptr, int* out) {
+    int best = 0;
+    IPXK_GS(r, nrows) best = max(best, ptr[r + 1] - ptr[r]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) best = max(best, __shfl_xor(best, d, 64));
+    if ((threadIdx.x & 63) == 0 && best > 0) atomicMax(out, best);
+}
+// key of the sliced layout: (tile, row in tile), tile = row block * ns + slice of the gathered index
+__global__ void sliced_keys_kernel(int nrows, const int* __restrict__ ptr, const int* __restrict__ idx, int R, int ns, int slice,
+                                   unsigned* __restrict__ key, unsigned* __restrict__ pos) {
+    IPXK_GS(r, nrows) {
+        const unsigned base = (unsigned)(r / R) * (unsigned)ns, rr = (unsigned)(r % R);
+        for (int p = ptr[r]; p < ptr[r + 1]; p++) {
+            key[p] = (base + (unsigned)(idx[p] / slice)) * (unsigned)R + rr;
+            pos[p] = (unsigned)p;
+        }
+    }
+}
+// key of the sorted layout's first sort: (sub-tile, row in row block)
+__global__ void sorted_keys1_kernel(int nrows, const int* __restrict__ ptr, const int* __restrict__ idx, int RB, int ns, int nsub, int slice,
+                                    int half, unsigned* __restrict__ key, unsigned* __restrict__ pos) {
+    IPXK_GS(r, nrows) {
+        const unsigned tile0 = (unsigned)(r / RB) * (unsigned)ns, rr = (unsigned)(r % RB);
+        for (int p = ptr[r]; p < ptr[r + 1]; p++) {
+            const int sl = idx[p] / slice, off = idx[p] - sl * slice;
+            const unsigned sub = (tile0 + (unsigned)sl) * (unsigned)nsub + (unsigned)min(off / half, nsub - 1);
+            key[p] = sub * (unsigned)RB + rr;
+            pos[p] = (unsigned)p;
+        }
+    }
+}
+// second sort: (sub-tile, offset in the slice), enumerated in slot order
+__global__ void sorted_keys2_kernel(int64_t nz, const unsigned* __restrict__ key1s, const unsigned* __restrict__ perm1, const int* __restrict__ idx,
+                                    int RB, int ns, int nsub, int slice, u64* __restrict__ key2, unsigned* __restrict__ pos) {
+    IPXK_GS(e, nz) {
+        const unsigned sub = key1s[e] / (unsigned)RB;
+        const int sl = (int)((sub / (unsigned)nsub) % (unsigned)ns);
+        const int off = idx[perm1[e]] - sl * slice;
+        key2[e] = ((u64)sub << kSortedOffBits) | (u64)(unsigned)off;
+        pos[e] = (unsigned)e;
+    }
+}
+__global__ void sorted_fill_kernel(int64_t nz, const u64* __restrict__ key2s, const unsigned* __restrict__ perm2, const unsigned* __restrict__ perm1,
+                                   const unsigned* __restrict__ sub_ptr, const double* __restrict__ val, unsigned* __restrict__ pack,
+                                   double* __restrict__ out_val) {
+    IPXK_GS(f, nz) {
+        const u64 k = key2s[f];
+        const unsigned e = perm2[f], sub = (unsigned)(k >> kSortedOffBits), off = (unsigned)(k & ((1u << kSortedOffBits) - 1u));
+        pack[f] = ((e - sub_ptr[sub]) << kSortedOffBits) | off;
+        out_val[f] = val[perm1[e]];
+    }
+}
+// byte counts per key from the runs of equal keys (cnt is zero on entry); a run of more than 255 raises *overflow
+__global__ void run_counts_kernel(int64_t nz, const unsigned* __restrict__ sorted, unsigned char* __restrict__ cnt, int* overflow) {
+    IPXK_GS(e, nz) {
+        const unsigned k = sorted[e];
+        if (e > 0 && sorted[e - 1] == k) continue;
+        int len = 1;
+        while (e + len < nz && len <= 256 && sorted[e + len] == k) len++;
+        if (len > 255) *overflow = 1;
+        cnt[k] = (unsigned char)len;
+    }
+}
+__global__ void gather_entries_kernel(int64_t nz, const unsigned* __restrict__ perm, const int* __restrict__ idx, const double* __restrict__ val,
+                                      int* __restrict__ out_idx, double* __restrict__ out_val) {
+    IPXK_GS(e, nz) {
+        const unsigned p = perm[e];
+        out_idx[e] = idx[p];
+        out_val[e] = val[p];
+    }
+}
+// [0] = largest tile, [2..3] = (64 bits) sum over the row blocks of their fullest slice's entries
+__global__ void tile_stats_kernel(int nrb, int ns, const unsigned* __restrict__ tile_ptr, int* out) {
+    int best_tile = 0;
+    u64 dom = 0;
+    IPXK_GS(rb, nrb) {
+        unsigned best = 0;
+        for (int sl = 0; sl < ns; sl++) best = max(best, tile_ptr[(size_t)rb * ns + sl + 1] - tile_ptr[(size_t)rb * ns + sl]);
+        best_tile = max(best_tile, (int)best);
+        dom += best;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { best_tile = max(best_tile, __shfl_xor(best_tile, d, 64)); dom += __shfl_xor(dom, d, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(out, best_tile);
+        if (dom) atomicAdd(reinterpret_cast<u64*>(out + 2), dom);
+    }
+}
+__global__ void max_range_kernel(int64_t count, const unsigned* __restrict__ ptr, int* out) {
+    int best = 0;
+    IPXK_GS(t, count) best = max(best, (int)(ptr[t + 1] - ptr[t]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) best = max(best, __shfl_xor(best, d, 64));
+    if ((threadIdx.x & 63) == 0 && best > 0) atomicMax(out, best);
+}
+// entries of a list of columns, one after the other (dense columns: precond.hip)
+__global__ void gather_columns_kernel(int k, const int* __restrict__ cols, const int* __restrict__ off, const int* __restrict__ Ap,
+                                      const int* __restrict__ Ai, const double* __restrict__ Ax, ipxint* __restrict__ out_i, double* __restrict__ out_x) {
+    const int kk = blockIdx.x;
+    if (kk >= k) return;
+    const int j = cols[kk], p0 = Ap[j], len = Ap[j + 1] - p0, o = off[kk];
+    for (int t = threadIdx.x; t < len; t += blockDim.x) { out_i[o + t] = Ai[p0 + t]; out_x[o + t] = Ax[p0 + t]; }
+}
+__global__ void widen_kernel(int64_t nz, const int* __restrict__ in, ipxint* __restrict__ out) { IPXK_GS(p, nz) out[p] = in[p]; }
+
+struct Tmp {
+    DevBuf<unsigned char> bytes;
+    void* need(size_t n) { if (bytes.size() < n) bytes.resize(n); return bytes.get(); }
+};
+template <class K>
+void sort_pairs(Tmp& T, const K* kin, K* kout, const unsigned* vin, unsigned* vout, size_t n, int bits, hipStream_t s) {
+    size_t bytes = 0;
+    IPXK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0u, (unsigned)bits, s));
+    IPXK_HIP(rocprim::radix_sort_pairs(T.need(bytes), bytes, kin, kout, vin, vout, n, 0u, (unsigned)bits, s));
+}
+
+}  // namespace
+
+// scratch of the layout builders: kept for the two gather matrices of a model, released when the model is built
+struct LayoutScratch {
+    DevBuf<unsigned> k1, k2, v1, v2, v3, v4;
+    DevBuf<u64> q1, q2;
+    DevBuf<int> stats;
+    Tmp T;
+};
+LayoutScratch* new_layout_scratch() { return new LayoutScratch; }
+void free_layout_scratch(LayoutScratch* S) { delete S; }
+
+// ---------------------------------------------------------------------------
+// the model on the device: CSC and the row-wise copy, 32-bit indices
+// ---------------------------------------------------------------------------
+void upload_plain_model(Context* c, const ipxint* Ap, const ipxint* Ai, const double* Ax) {
+    const int64_t m = c->m, n = c->n;
+    hipStream_t s = c->stream;
+    IPXK_REQUIRE(m < (int64_t(1) << 31) - 1 && n < (int64_t(1) << 31) - 1, "dimension exceeds 32-bit device indices");
+    IPXK_REQUIRE(Ap[0] == 0, "colptr[0] must be 0");
+    const int64_t nz = Ap[n];
+    IPXK_REQUIRE(nz >= 0 && nz < (int64_t(1) << 31) - kLongSeg, "nnz exceeds 32-bit device indices");
+    c->h_Ap.assign(Ap, Ap + n + 1);
+    std::vector<int> ap32((size_t)n + 1);
+    for (int64_t j = 0; j < n; j++) {
+        IPXK_REQUIRE(Ap[j] <= Ap[j + 1], "colptr not monotone");
+        ap32[(size_t)j] = (int)Ap[j];
+    }
+    ap32[(size_t)n] = (int)nz;
+    c->nnz = nz;
+    const size_t nz1 = (size_t)std::max<int64_t>(nz, 1);
+    c->pl_Ap.upload(ap32, s);
+    c->pl_Ai.ensure(nz1); c->pl_Ax.ensure(nz1); c->pl_Tp.ensure((size_t)m + 1); c->pl_Ti.ensure(nz1); c->pl_Tx.ensure(nz1);
+    DevBuf<int> bad(1);
+    IPXK_HIP(hipMemsetAsync(bad.get(), 0, sizeof(int), s));
+    if (nz > 0) {
+        DevBuf<ipxint> ai64(nz1);
+        ai64.upload(Ai, (size_t)nz, s);
+        c->pl_Ax.upload(Ax, (size_t)nz, s);
+        hipLaunchKernelGGL(narrow_kernel, dim3(gridn(nz)), dim3(kBlock), 0, s, nz, ai64.get(), c->pl_Ai.get(), (int)m, bad.get());
+        int flag = 0;
+        IPXK_HIP(hipMemcpyAsync(&flag, bad.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));           // ai64 goes out of scope
+        IPXK_REQUIRE(flag == 0, "row index out of range");
+        // Transpose (src/sparse_matrix.cc:120-151): a stable sort by row of the entries enumerated column by column
+        // leaves every row in ascending source-column order, like the reference's counting sort
+        DevBuf<int> colof(nz1);
+        DevBuf<unsigned> pos(nz1), rows2(nz1), perm(nz1);
+        Tmp T;
+        hipLaunchKernelGGL(rowof_kernel, dim3(gridn(n)), dim3(kBlock), 0, s, (int)n, c->pl_Ap.get(), colof.get(), pos.get());
+        sort_pairs<unsigned>(T, reinterpret_cast<const unsigned*>(c->pl_Ai.get()), rows2.get(), pos.get(), perm.get(), (size_t)nz,
+                             bits_for((u64)std::max<int64_t>(m, 2) - 1), s);
+        hipLaunchKernelGGL(gather_transposed_kernel, dim3(gridn(nz)), dim3(kBlock), 0, s, nz, perm.get(), colof.get(), c->pl_Ax.get(),
+                           c->pl_Ti.get(), c->pl_Tx.get());
+        hipLaunchKernelGGL(row_pointers_kernel, dim3(gridn(m + 1)), dim3(kBlock), 0, s, m, nz, rows2.get(), c->pl_Tp.get());
+        IPXK_HIP(hipStreamSynchronize(s));           // temporaries go out of scope
+    } else {
+        IPXK_HIP(hipMemsetAsync(c->pl_Tp.get(), 0, ((size_t)m + 1) * sizeof(int), s));
+        IPXK_HIP(hipStreamSynchronize(s));
+    }
+    IPXK_HIP(hipGetLastError());
+    c->have_plain = true;
+}
+
+// host copies of the entries (64-bit indices) for the paths that still build on the host
+void ensure_host_model(Context* c, bool rowwise) {
+    hipStream_t s = c->stream;
+    const size_t nz = (size_t)c->nnz;
+    auto fetch = [&](const DevBuf<int>& ptr, size_t nptr, const DevBuf<int>& idx, const DevBuf<double>& val, std::vector<ipxint>& hp,
+                     std::vector<ipxint>& hi, std::vector<double>& hx) {
+        DevBuf<ipxint> wide(std::max(std::max(nz, nptr), (size_t)1));
+        hp.resize(nptr); hi.resize(nz); hx.resize(nz);
+        hipLaunchKernelGGL(widen_kernel, dim3(gridn((int64_t)nptr)), dim3(kBlock), 0, s, (int64_t)nptr, ptr.get(), wide.get());
+        wide.download(hp.data(), nptr, s);
+        if (nz) {
+            hipLaunchKernelGGL(widen_kernel, dim3(gridn((int64_t)nz)), dim3(kBlock), 0, s, (int64_t)nz, idx.get(), wide.get());
+            wide.download(hi.data(), nz, s);
+            val.download(hx.data(), nz, s);
+        }
+        IPXK_HIP(hipStreamSynchronize(s));
+    };
+    IPXK_REQUIRE(c->have_plain, "model not uploaded");
+    if (!rowwise && c->h_Ai.size() != nz) {
+        std::vector<ipxint> hp;
+        fetch(c->pl_Ap, (size_t)c->n + 1, c->pl_Ai, c->pl_Ax, hp, c->h_Ai, c->h_Ax);
+    }
+    if (rowwise && (c->h_ATp.size() != (size_t)c->m + 1 || c->h_ATi.size() != nz))
+        fetch(c->pl_Tp, (size_t)c->m + 1, c->pl_Ti, c->pl_Tx, c->h_ATp, c->h_ATi, c->h_ATx);
+}
+
+// the entries of `cols` (structural columns), one column after the other, on the host
+void fetch_columns(Context* c, const std::vector<ipxint>& cols, std::vector<ipxint>& Cp, std::vector<ipxint>& Ci, std::vector<double>& Cx) {
+    const int k = (int)cols.size();
+    hipStream_t s = c->stream;
+    Cp.assign((size_t)k + 1, 0);
+    std::vector<int> c32((size_t)k), off((size_t)k);
+    for (int kk = 0; kk < k; kk++) {
+        const ipxint j = cols[(size_t)kk];
+        c32[(size_t)kk] = (int)j;
+        off[(size_t)kk] = (int)Cp[(size_t)kk];
+        Cp[(size_t)kk + 1] = Cp[(size_t)kk] + (c->h_Ap[(size_t)j + 1] - c->h_Ap[(size_t)j]);
+    }
+    const size_t tot = (size_t)Cp[(size_t)k];
+    Ci.resize(tot); Cx.resize(tot);
+    if (k == 0 || tot == 0) return;
+    DevBuf<int> dc, doff;
+    DevBuf<ipxint> di(tot);
+    DevBuf<double> dx(tot);
+    dc.upload(c32, s); doff.upload(off, s);
+    hipLaunchKernelGGL(gather_columns_kernel, dim3(k), dim3(kBlock), 0, s, k, dc.get(), doff.get(), c->pl_Ap.get(), c->pl_Ai.get(), c->pl_Ax.get(),
+                       di.get(), dx.get());
+    di.download(Ci.data(), tot, s);
+    dx.download(Cx.data(), tot, s);
+    IPXK_HIP(hipStreamSynchronize(s));
+    IPXK_HIP(hipGetLastError());
+}
+
+int device_max_row_length(LayoutScratch& S, int nrows, const int* dptr, hipStream_t s) {
+    S.stats.ensure(8);
+    IPXK_HIP(hipMemsetAsync(S.stats.get(), 0, 8 * sizeof(int), s));
+    hipLaunchKernelGGL(max_len_kernel, dim3(gridn(nrows)), dim3(kBlock), 0, s, nrows, dptr, S.stats.get());
+    int h = 0;
+    IPXK_HIP(hipMemcpyAsync(&h, S.stats.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    return h;
+}
+
+// ---------------------------------------------------------------------------
+// XCD-sliced tiles (the arrays of GatherMatrix::build_sliced with ns_request = 0, bit for bit)
+// ---------------------------------------------------------------------------
+// returns false when the layout does not apply (x fits an XCD's L2, a tile does not fit LDS, > 255 entries of a row in
+// one slice): the caller then takes the host path
+bool device_build_sliced(LayoutScratch& S, SlicedMatrix& out, int nrows, int ncols, int64_t nnz, const int* dptr, const int* didx,
+                         const double* dval, hipStream_t s) {
+    out = SlicedMatrix();
+    if (nrows == 0 || nnz == 0 || ncols == 0) return false;
+    const int64_t x_bytes = (int64_t)ncols * 8;
+    int64_t slice_bytes = int64_t(2) << 20;
+    if (const char* e = getenv("IPXK_SLICE_TEST_KB"))
+        if (atoi(e) > 0) slice_bytes = (int64_t)atoi(e) << 10;
+    if (x_bytes <= 2 * slice_bytes && !(getenv("IPXK_SLICE_FORCE2") && x_bytes > slice_bytes)) return false;
+    int ns = 2;
+    while (ns < 8 && x_bytes > (int64_t)ns * slice_bytes) ns *= 2;
+    const int64_t slice = (((int64_t)ncols + ns - 1) / ns + 15) / 16 * 16;
+    int R = kSlicedRows;
+    while (R > kBlock && ((int64_t)nrows + R - 1) / R * (int64_t)ns < 2048) R /= 2;
+    const size_t nz = (size_t)nnz;
+    S.k1.ensure(nz); S.k2.ensure(nz); S.v1.ensure(nz); S.v2.ensure(nz); S.stats.ensure(8);
+    int nrb = 0, h[4] = {0, 0, 0, 0};
+    int64_t ntiles = 0;
+    for (;; R /= 2) {
+        if (R < kBlock) return false;
+        nrb = (nrows + R - 1) / R;
+        ntiles = (int64_t)nrb * ns;
+        if ((u64)ntiles * (u64)R >= (u64(1) << 32)) return false;
+        hipLaunchKernelGGL(sliced_keys_kernel, dim3(gridn(nrows)), dim3(kBlock), 0, s, nrows, dptr, didx, R, ns, (int)slice, S.k1.get(), S.v1.get());
+        sort_pairs<unsigned>(S.T, S.k1.get(), S.k2.get(), S.v1.get(), S.v2.get(), nz, bits_for((u64)ntiles * (u64)R - 1), s);
+        out.tile_ptr.ensure((size_t)ntiles + 1);
+        hipLaunchKernelGGL(lower_bounds_kernel<unsigned>, dim3(gridn(ntiles + 1)), dim3(kBlock), 0, s, ntiles + 1, nnz, S.k2.get(), (u64)R, 0,
+                           out.tile_ptr.get());
+        IPXK_HIP(hipMemsetAsync(S.stats.get(), 0, 8 * sizeof(int), s));
+        hipLaunchKernelGGL(tile_stats_kernel, dim3(gridn(nrb)), dim3(kBlock), 0, s, nrb, ns, out.tile_ptr.get(), S.stats.get());
+        IPXK_HIP(hipMemcpyAsync(h, S.stats.get(), sizeof h, hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        if (h[0] <= kSlicedMaxTile) break;
+    }
+    u64 dom = 0;
+    memcpy(&dom, h + 2, sizeof dom);
+    out.dominant_fraction = (double)(int64_t)dom / (double)nnz;
+    const size_t nslots = (size_t)ntiles * R;
+    out.cnt.ensure(nslots); out.idx.ensure(nz); out.val.ensure(nz);
+    IPXK_HIP(hipMemsetAsync(out.cnt.get(), 0, nslots, s));
+    IPXK_HIP(hipMemsetAsync(S.stats.get(), 0, 8 * sizeof(int), s));
+    hipLaunchKernelGGL(run_counts_kernel, dim3(gridn(nnz)), dim3(kBlock), 0, s, nnz, S.k2.get(), out.cnt.get(), S.stats.get());
+    hipLaunchKernelGGL(gather_entries_kernel, dim3(gridn(nnz)), dim3(kBlock), 0, s, nnz, S.v2.get(), didx, dval, out.idx.get(), out.val.get());
+    int over = 0;
+    IPXK_HIP(hipMemcpyAsync(&over, S.stats.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    IPXK_HIP(hipGetLastError());
+    if (over) { out = SlicedMatrix(); return false; }
+    out.R = R; out.nslices = ns; out.nrb = nrb; out.nrows_pad = nrb * R; out.max_tile = h[0];
+    out.partial.resize((size_t)ns * out.nrows_pad);
+    out.built = true;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// sorted sub-tiles (the arrays of GatherMatrix::build_sorted, bit for bit); needs the sliced layout's slices
+// ---------------------------------------------------------------------------
+bool device_build_sorted(LayoutScratch& S, SortedMatrix& out, const SlicedMatrix& sliced, int nrows, int ncols, int64_t nnz, const int* dptr,
+                         const int* didx, const double* dval, hipStream_t s) {
+    out = SortedMatrix();
+    if (!sliced.built || sliced.nslices < 2 || nnz == 0) return false;
+    const int ns = sliced.nslices;
+    const int64_t slice = (((int64_t)ncols + ns - 1) / ns + 15) / 16 * 16;
+    if (slice > (int64_t(1) << kSortedOffBits)) return false;
+    static const int nsub_env = [] { const char* e = getenv("IPXK_SORTED_NSUB"); return e && atoi(e) > 0 ? std::min(atoi(e), 16) : 2; }();
+    const int nsub = nsub_env;
+    const int64_t half = (slice / nsub + 15) / 16 * 16;
+    const size_t nz = (size_t)nnz;
+    S.k1.ensure(nz); S.k2.ensure(nz); S.v1.ensure(nz); S.v2.ensure(nz); S.v3.ensure(nz); S.v4.ensure(nz); S.q1.ensure(nz); S.q2.ensure(nz);
+    S.stats.ensure(8);
+    int RB = 32 * kSortedThreads, nrb = 0, max_sub = 0;
+    int64_t nsubs = 0;
+    for (;; RB /= 2) {
+        if (RB < 4 * kSortedThreads) return false;
+        nrb = (nrows + RB - 1) / RB;
+        nsubs = (int64_t)nrb * ns * nsub;
+        if ((u64)nsubs * (u64)RB >= (u64(1) << 32)) return false;
+        hipLaunchKernelGGL(sorted_keys1_kernel, dim3(gridn(nrows)), dim3(kBlock), 0, s, nrows, dptr, didx, RB, ns, nsub, (int)slice, (int)half,
+                           S.k1.get(), S.v1.get());
+        sort_pairs<unsigned>(S.T, S.k1.get(), S.k2.get(), S.v1.get(), S.v2.get(), nz, bits_for((u64)nsubs * (u64)RB - 1), s);
+        out.sub_ptr.ensure((size_t)nsubs + 1);
+        hipLaunchKernelGGL(lower_bounds_kernel<unsigned>, dim3(gridn(nsubs + 1)), dim3(kBlock), 0, s, nsubs + 1, nnz, S.k2.get(), (u64)RB, 0,
+                           out.sub_ptr.get());
+        IPXK_HIP(hipMemsetAsync(S.stats.get(), 0, 8 * sizeof(int), s));
+        hipLaunchKernelGGL(max_range_kernel, dim3(gridn(nsubs)), dim3(kBlock), 0, s, nsubs, out.sub_ptr.get(), S.stats.get());
+        IPXK_HIP(hipMemcpyAsync(&max_sub, S.stats.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        if (max_sub <= kSortedMaxSub) break;
+    }
+    const size_t nslots = (size_t)nsubs * RB;
+    out.cnt.ensure(nslots); out.pack.ensure(nz); out.val.ensure(nz);
+    IPXK_HIP(hipMemsetAsync(out.cnt.get(), 0, nslots, s));
+    IPXK_HIP(hipMemsetAsync(S.stats.get(), 0, 8 * sizeof(int), s));
+    hipLaunchKernelGGL(run_counts_kernel, dim3(gridn(nnz)), dim3(kBlock), 0, s, nnz, S.k2.get(), out.cnt.get(), S.stats.get());
+    // second sort: by (sub-tile, offset), stable on the slot order
+    hipLaunchKernelGGL(sorted_keys2_kernel, dim3(gridn(nnz)), dim3(kBlock), 0, s, nnz, S.k2.get(), S.v2.get(), didx, RB, ns, nsub, (int)slice,
+                       S.q1.get(), S.v3.get());
+    sort_pairs<u64>(S.T, S.q1.get(), S.q2.get(), S.v3.get(), S.v4.get(), nz, kSortedOffBits + bits_for((u64)nsubs - 1), s);
+    hipLaunchKernelGGL(sorted_fill_kernel, dim3(gridn(nnz)), dim3(kBlock), 0, s, nnz, S.q2.get(), S.v4.get(), S.v2.get(), out.sub_ptr.get(), dval,
+                       out.pack.get(), out.val.get());
+    int over = 0;
+    IPXK_HIP(hipMemcpyAsync(&over, S.stats.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    IPXK_HIP(hipGetLastError());
+    if (over) { out = SortedMatrix(); return false; }
+    out.nslices = ns; out.nsub = nsub; out.nrb = nrb; out.RB = RB; out.nrows_pad = nrb * RB;
+    out.max_sub = max_sub; out.slice_elems = (int)slice;
+    out.partial.resize((size_t)ns * out.nrows_pad);
+    out.built = true;
+    return true;
+}
+
+}  // namespace ipxk

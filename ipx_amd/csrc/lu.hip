@@ -1208,7 +1208,7 @@ bool lu_view(const Context* c, LuView* out) {
 void lu_plain_matrix(const Context* c, const int** Ap, const int** Ai, const double** Ax) {
     const LuState* S = c->lu;
     IPXK_REQUIRE(S && S->have_A, "no resident copy of the matrix (ipxk_lu_factorize_basis)");
-    *Ap = S->Ap.get(); *Ai = S->Ai.get(); *Ax = S->Ax.get();
+    *Ap = c->pl_Ap.get(); *Ai = c->pl_Ai.get(); *Ax = c->pl_Ax.get();
 }
 
 void lu_factorize_host(Context* c, int64_t dim64, const ipxint* Bbegin, const ipxint* Bend, const ipxint* Bi,
@@ -1252,16 +1252,8 @@ void lu_factorize_basis(Context* c, const ipxint* basis, double pivottol, bool s
     const int m = (int)c->m, n = (int)c->n;
     hipStream_t s = c->stream;
     LuState* S = lu_state(c);
-    if (!S->have_A) {
-        IPXK_REQUIRE(c->nnz < (int64_t(1) << 31), "nnz(A) exceeds 32 bits");
-        std::vector<int> ap((size_t)n + 1), ai((size_t)c->nnz);
-        for (int j = 0; j <= n; j++) ap[(size_t)j] = (int)c->h_Ap[(size_t)j];
-        for (int64_t p = 0; p < c->nnz; p++) ai[(size_t)p] = (int)c->h_Ai[(size_t)p];
-        S->Ap.upload(ap, s); S->Ai.upload(ai, s); S->Ax.upload(c->h_Ax, s);
-        S->Ai.ensure(1); S->Ax.ensure(1);
-        IPXK_HIP(hipStreamSynchronize(s));
-        S->have_A = true;
-    }
+    IPXK_REQUIRE(c->have_plain, "no resident copy of the matrix");
+    S->have_A = true;
     S->basis.upload(basis, (size_t)m, s);
     S->basis.ensure(1);
     const size_t m1 = (size_t)std::max(m, 1);
@@ -1274,7 +1266,7 @@ void lu_factorize_basis(Context* c, const ipxint* basis, double pivottol, bool s
     IPXK_HIP(hipMemsetAsync(bad.get(), 0, sizeof(int), s));
     int64_t nb = 0;
     if (m > 0) {
-        hipLaunchKernelGGL(lu_basis_count_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, n, S->basis.get(), S->Ap.get(), cnt.get(), bad.get());
+        hipLaunchKernelGGL(lu_basis_count_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, n, S->basis.get(), c->pl_Ap.get(), cnt.get(), bad.get());
         scan_exclusive(T, cnt.get(), dBp.get(), (size_t)m, s);
         int last[2] = {0, 0}, hbad = 0;
         IPXK_HIP(hipMemcpyAsync(&last[0], dBp.get() + m - 1, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1286,8 +1278,8 @@ void lu_factorize_basis(Context* c, const ipxint* basis, double pivottol, bool s
         const int nb32 = (int)nb;
         IPXK_HIP(hipMemcpyAsync(dBp.get() + m, &nb32, sizeof(int), hipMemcpyHostToDevice, s));
         dBi.ensure((size_t)std::max<int64_t>(nb, 1)); dBx.ensure((size_t)std::max<int64_t>(nb, 1));
-        hipLaunchKernelGGL(lu_basis_fill_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, n, S->basis.get(), S->Ap.get(), S->Ai.get(),
-                           S->Ax.get(), dBp.get(), dBi.get(), dBx.get());
+        hipLaunchKernelGGL(lu_basis_fill_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, n, S->basis.get(), c->pl_Ap.get(), c->pl_Ai.get(),
+                           c->pl_Ax.get(), dBp.get(), dBi.get(), dBx.get());
         IPXK_HIP(hipStreamSynchronize(s));               // nb32
     } else {
         IPXK_HIP(hipMemsetAsync(dBp.get(), 0, sizeof(int), s));

@@ -150,10 +150,6 @@ struct NMatrix {
     DevBuf<int> keep, len, newidx, off, colof, cnt32, counters;
     DevBuf<u64> keys, keys2, hash;
     DevBuf<double> wN, tN;
-    // plain copies of A on the device: by column and by row (32-bit indices)
-    DevBuf<int> Ap, Ai, Tp, Ti;
-    DevBuf<double> Ax, Tx;
-    bool have_plain = false;
     Tmp T;
 };
 void destroy_nmatrix(NMatrix* N) { delete N; }
@@ -211,19 +207,10 @@ bool nmatrix_prepare(Context* c, const double* W) {
     hipStream_t s = c->stream;
     if (!c->nmat) c->nmat = new NMatrix;
     NMatrix& N = *c->nmat;
-    if (!N.have_plain) {
-        std::vector<int> ap((size_t)n + 1), ai((size_t)c->nnz), tp((size_t)m + 1), ti((size_t)c->nnz);
-        for (int j = 0; j <= n; j++) ap[(size_t)j] = (int)c->h_Ap[(size_t)j];
-        for (int i = 0; i <= m; i++) tp[(size_t)i] = (int)c->h_ATp[(size_t)i];
-        for (int64_t p = 0; p < c->nnz; p++) { ai[(size_t)p] = (int)c->h_Ai[(size_t)p]; ti[(size_t)p] = (int)c->h_ATi[(size_t)p]; }
-        N.Ap.upload(ap, s); N.Ai.upload(ai, s); N.Ax.upload(c->h_Ax, s);
-        N.Tp.upload(tp, s); N.Ti.upload(ti, s); N.Tx.upload(c->h_ATx, s);
-        IPXK_HIP(hipStreamSynchronize(s));
-        N.have_plain = true;
-    }
+    IPXK_REQUIRE(c->have_plain, "no resident copy of the matrix");
     N.keep.ensure((size_t)n); N.len.ensure((size_t)n); N.newidx.ensure((size_t)n); N.off.ensure((size_t)n);
     N.counters.ensure(4); N.hash.ensure(1);
-    hipLaunchKernelGGL(nm_keep_kernel, dim3(gridn(n)), dim3(kBlock), 0, s, n, W, N.Ap.get(), N.keep.get(), N.len.get());
+    hipLaunchKernelGGL(nm_keep_kernel, dim3(gridn(n)), dim3(kBlock), 0, s, n, W, c->pl_Ap.get(), N.keep.get(), N.len.get());
     IPXK_HIP(hipMemsetAsync(N.hash.get(), 0, sizeof(u64), s));
     hipLaunchKernelGGL(nm_hash_kernel, dim3(gridn(n)), dim3(kBlock), 0, s, n, N.keep.get(), N.hash.get());
     u64 hsh = 0;
@@ -254,18 +241,18 @@ bool nmatrix_prepare(Context* c, const double* W) {
         N.P1 = SlicedMatrix(); N.P2 = SlicedMatrix();
         bool ok = false;
         for (int R = kSlicedRows; R >= kBlock && !ok; R /= 2) {
-            hipLaunchKernelGGL(nm_keys_p1_kernel, dim3(gridn(n)), dim3(kBlock), 0, s, n, N.Ap.get(), N.Ai.get(), N.newidx.get(), N.off.get(), R,
+            hipLaunchKernelGGL(nm_keys_p1_kernel, dim3(gridn(n)), dim3(kBlock), 0, s, n, c->pl_Ap.get(), c->pl_Ai.get(), N.newidx.get(), N.off.get(), R,
                                ns1, (int)slice1, N.keys.get());
             sort_u64(N.T, N.keys.get(), N.keys2.get(), (size_t)nzN, s);
-            ok = finish_layout(N, N.P1, nN, R, ns1, nzN, N.keys2.get(), N.Ai.get(), N.Ax.get(), nullptr, s);
+            ok = finish_layout(N, N.P1, nN, R, ns1, nzN, N.keys2.get(), c->pl_Ai.get(), c->pl_Ax.get(), nullptr, s);
         }
         if (!ok) return false;
         ok = false;
         for (int R = kSlicedRows; R >= kBlock && !ok; R /= 2) {
-            hipLaunchKernelGGL(nm_keys_p2_kernel, dim3(gridn(m)), dim3(kBlock), 0, s, m, N.Tp.get(), N.Ti.get(), N.newidx.get(), R, ns2, (int)slice2,
+            hipLaunchKernelGGL(nm_keys_p2_kernel, dim3(gridn(m)), dim3(kBlock), 0, s, m, c->pl_Tp.get(), c->pl_Ti.get(), N.newidx.get(), R, ns2, (int)slice2,
                                N.keys.get());
             sort_u64(N.T, N.keys.get(), N.keys2.get(), (size_t)c->nnz, s);      // the entries of dropped columns sort to the end
-            ok = finish_layout(N, N.P2, m, R, ns2, nzN, N.keys2.get(), N.Ti.get(), N.Tx.get(), N.newidx.get(), s);
+            ok = finish_layout(N, N.P2, m, R, ns2, nzN, N.keys2.get(), c->pl_Ti.get(), c->pl_Tx.get(), N.newidx.get(), s);
         }
         if (!ok) return false;
         N.wN.ensure((size_t)nN); N.tN.ensure((size_t)nN);

@@ -350,16 +350,9 @@ static void build_dense_structures(Context* c) {
     // (src/diagonal_precond.cc:59-65), both host-built once per model.
     const int64_t k = (int64_t)c->dense_cols.size(), m = c->m;
     if (c->AdCols.nrows == k && c->AdRows.nrows == m && k > 0) return;
-    std::vector<ipxint> Cp(k + 1, 0), Ci;
+    std::vector<ipxint> Cp, Ci;
     std::vector<double> Cx;
-    for (int64_t kk = 0; kk < k; kk++) {
-        const ipxint j = c->dense_cols[kk];
-        for (ipxint p = c->h_Ap[j]; p < c->h_Ap[j + 1]; p++) {
-            Ci.push_back(c->h_Ai[p]);
-            Cx.push_back(c->h_Ax[p]);
-        }
-        Cp[kk + 1] = (ipxint)Ci.size();
-    }
+    fetch_columns(c, c->dense_cols, Cp, Ci, Cx);     // from the device's plain copy of the model
     // transpose (counting sort, ascending dense-column position within a row)
     std::vector<ipxint> Tp(m + 1, 0), Ti(Ci.size());
     std::vector<double> Tx(Ci.size());

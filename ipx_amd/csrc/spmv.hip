@@ -3,6 +3,7 @@
 // as two row-gather SpMVs:  t = Ws .* (A' rhs);  lhs = W_I .* rhs + A t  with the
 // dot product rhs'lhs fused into the second pass (src/normal_matrix.cc:123-124).
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 
 #include <cstdio>
@@ -26,23 +27,17 @@ int slice_elems() {
     return cached;
 }
 
-void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, const ipxint* hidx,
-                         const double* hval, hipStream_t s) {
-    IPXK_REQUIRE(nrows_ >= 0 && ncols_ >= 0, "negative dimension");
-    IPXK_REQUIRE(nrows_ < (int64_t(1) << 31) - 1 && ncols_ < (int64_t(1) << 31) - 1,
-                 "dimension exceeds 32-bit device indices");
-    const int64_t nz = hptr[nrows_];
-    IPXK_REQUIRE(nz < (int64_t(1) << 31) - kLongSeg, "nnz exceeds 32-bit device indices");
-    nrows = (int)nrows_;
-    ncols = (int)ncols_;
-    nnz = nz;
-
-    // geometry
-    // phases of ~1 MiB of x; at most kMaxPhases of them (the per-(row,phase) count table grows
-    // with P), so very long vectors get proportionally larger slices
+// elements of the gathered vector per phase of the phased layout: ~1 MiB of x; at most kMaxPhases phases (the
+// per-(row,phase) count table grows with P), so very long vectors get proportionally larger slices
+static int64_t phase_slice(int64_t ncols_) {
     constexpr int kMaxPhases = 64;
     int64_t slice = slice_elems();
     if ((ncols_ + slice - 1) / slice > kMaxPhases) slice = (ncols_ + kMaxPhases - 1) / kMaxPhases;
+    return slice;
+}
+
+void GatherMatrix::set_geometry(int64_t nrows_, int64_t ncols_) {
+    const int64_t slice = phase_slice(ncols_);
     P = (int)std::max<int64_t>(1, (ncols_ + slice - 1) / slice);
     int maxwg = kMaxWorkgroups;
     if (const char* e = getenv("IPXK_MAX_WG")) maxwg = atoi(e) > 0 ? atoi(e) : maxwg;
@@ -59,6 +54,22 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
     }
     G = (int)std::max<int64_t>(1, std::min<int64_t>(maxwg, (nrows_ + RWrows - 1) / RWrows));
     Q = (int)std::max<int64_t>(1, (nrows_ + (int64_t)G * RWrows - 1) / ((int64_t)G * RWrows));
+}
+
+void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, const ipxint* hidx,
+                         const double* hval, hipStream_t s) {
+    IPXK_REQUIRE(nrows_ >= 0 && ncols_ >= 0, "negative dimension");
+    IPXK_REQUIRE(nrows_ < (int64_t(1) << 31) - 1 && ncols_ < (int64_t(1) << 31) - 1,
+                 "dimension exceeds 32-bit device indices");
+    const int64_t nz = hptr[nrows_];
+    IPXK_REQUIRE(nz < (int64_t(1) << 31) - kLongSeg, "nnz exceeds 32-bit device indices");
+    nrows = (int)nrows_;
+    ncols = (int)ncols_;
+    nnz = nz;
+
+    set_geometry(nrows_, ncols_);
+    const int64_t slice = phase_slice(ncols_);
+    const int64_t RW = (int64_t)kBlock * RT;     // count slots per step
     const int64_t nsteps = (int64_t)Q * P * G;
     IPXK_REQUIRE(nsteps * RW < (int64_t(1) << 40), "matrix too large for the phased layout");
 
@@ -260,6 +271,64 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
     }
     IPXK_HIP(hipEventDestroy(e0));
     IPXK_HIP(hipEventDestroy(e1));
+}
+
+// The device path (layout_device.hip): sliced + sorted layouts by radix sorts, for matrices whose gathered vector needs
+// slicing and whose gathers spread over the slices -- the same decision build() takes from the same property of the
+// matrix, so a model gets the same layouts whichever path builds them.
+bool GatherMatrix::build_device(LayoutScratch& S, int64_t nrows_, int64_t ncols_, int64_t nnz_, const int* dptr, const int* didx,
+                                const double* dval, hipStream_t s) {
+    if (const char* e = getenv("IPXK_LAYOUT_BUILD")) if (e[0] == 'h') return false;           // host: the test reference
+    if (const char* e = getenv("IPXK_SPMV_LAYOUT")) if (std::string(e) != "auto") return false;
+    if (const char* e = getenv("IPXK_SPMV_SORTED")) if (e[0] == '0') return false;
+    if (tune_level < 2 || keep_plain || nnz_ < (1 << 16) || getenv("IPXK_STAMPS")) return false;
+    if (nrows_ >= (int64_t(1) << 31) - 1 || ncols_ >= (int64_t(1) << 31) - 1 || nnz_ >= (int64_t(1) << 31) - kLongSeg) return false;
+    if (device_max_row_length(S, (int)nrows_, dptr, s) > kMaxRowLen) return false;      // long rows: host path
+    SlicedMatrix sl;
+    if (!device_build_sliced(S, sl, (int)nrows_, (int)ncols_, nnz_, dptr, didx, dval, s)) return false;
+    if (!(sl.dominant_fraction <= 1.5 / sl.nslices)) return false;                     // gathers with locality: host path
+    nrows = (int)nrows_; ncols = (int)ncols_; nnz = nnz_;
+    set_geometry(nrows_, ncols_);
+    nlong = 0; nseg = 0;
+    h_row_long.clear();
+    long_partials.resize(1);
+    sliced = std::move(sl);
+    use_sliced = true;
+    use_sorted = false; use_sorted_fused = false;
+    sorted = SortedMatrix();
+    SortedMatrix so;
+    if (device_build_sorted(S, so, sliced, nrows, ncols, nnz_, dptr, didx, dval, s)) sorted = std::move(so);
+    // sliced against sorted: bit-identical partial sums, the faster one is kept (as in build())
+    DevBuf<double> tx((size_t)std::max(ncols, 1)), tout((size_t)std::max(nrows, 1));
+    IPXK_HIP(hipMemsetAsync(tx.get(), 0, tx.size() * sizeof(double), s));
+    hipEvent_t e0, e1;
+    IPXK_HIP(hipEventCreate(&e0));
+    IPXK_HIP(hipEventCreate(&e1));
+    EpiScale epi{{}, nullptr, tout.get()};
+    auto time_current = [&]() {
+        const int reps = 5;
+        for (int w = 0; w < 2; w++) launch_spmv(*this, tx.get(), epi, nullptr, nullptr, s);
+        IPXK_HIP(hipEventRecord(e0, s));
+        for (int r = 0; r < reps; r++) launch_spmv(*this, tx.get(), epi, nullptr, nullptr, s);
+        IPXK_HIP(hipEventRecord(e1, s));
+        IPXK_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        IPXK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        return ms * 1e3f / reps;
+    };
+    tuned_us_sliced = time_current();
+    if (sorted.built) {
+        use_sorted = true;
+        tuned_us_sorted = time_current();
+        use_sorted = tuned_us_sorted < tuned_us_sliced || (getenv("IPXK_SPMV_SORTED") && getenv("IPXK_SPMV_SORTED")[0] == '1');
+        if (!use_sorted) sorted = SortedMatrix();
+    }
+    IPXK_HIP(hipEventDestroy(e0));
+    IPXK_HIP(hipEventDestroy(e1));
+    if (getenv("IPXK_VERBOSE"))
+        fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld built on the device: sliced %.1f us, sorted %.1f us (fullest-slice share %.2f) -> %s\n",
+                nrows, ncols, (long long)nnz, tuned_us_sliced, tuned_us_sorted, sliced.dominant_fraction, use_sorted ? "sorted" : "sliced");
+    return true;
 }
 
 // Sliced layout (internal.hpp).  Eligible when x does not fit an XCD's L2, no row is "long" and
@@ -767,66 +836,74 @@ void GatherMatrix::compact_tiles(const double* weight, bool by_row, hipStream_t 
 // ---------------------------------------------------------------------------
 // model upload
 // ---------------------------------------------------------------------------
-// Row-wise copy by counting sort, entries of a row in ascending source-column
-// order -- the index arithmetic of Transpose (src/sparse_matrix.cc:120-151).
-static void transpose_host(int64_t nrow, int64_t ncol, const ipxint* Ap, const ipxint* Ai,
-                           const double* Ax, std::vector<ipxint>& Tp, std::vector<ipxint>& Ti,
-                           std::vector<double>& Tx) {
-    const int64_t nz = Ap[ncol];
-    Tp.assign(nrow + 1, 0);
-    Ti.resize(nz);
-    Tx.resize(nz);
-    for (int64_t p = 0; p < nz; p++) Tp[Ai[p] + 1]++;
-    for (int64_t i = 0; i < nrow; i++) Tp[i + 1] += Tp[i];
-    std::vector<ipxint> next(Tp.begin(), Tp.end() - 1);
-    for (int64_t j = 0; j < ncol; j++)
-        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
-            const int64_t put = next[Ai[p]]++;
-            Ti[put] = j;
-            Tx[put] = Ax[p];
-        }
-}
-
-// Dense-column classification of Model::FindDenseColumns (src/model.cc:34-56).
+// Dense-column classification of Model::FindDenseColumns (src/model.cc:34-56): with the column counts in ascending
+// order, the first count that exceeds max(40, 10 * its predecessor) is the threshold.  Equal neighbours never
+// satisfy that, so it is enough to walk the DISTINCT counts in ascending order (a histogram instead of a sort).
 static void find_dense_columns(Context* c) {
     const int64_t n = c->n, m = c->m;
     c->num_dense = 0;
     c->nz_dense = m + 1;
-    std::vector<ipxint> cnt(n);
-    for (int64_t j = 0; j < n; j++) cnt[j] = c->h_Ap[j + 1] - c->h_Ap[j];
-    std::sort(cnt.begin(), cnt.end());
-    for (int64_t j = 1; j < n; j++) {
-        if (cnt[j] > std::max<ipxint>(40, 10 * cnt[j - 1])) {
-            c->num_dense = n - j;
-            c->nz_dense = cnt[j];
+    c->dense_cols.clear();
+    if (n < 2) return;
+    ipxint maxcnt = 0;
+    for (int64_t j = 0; j < n; j++) maxcnt = std::max(maxcnt, c->h_Ap[j + 1] - c->h_Ap[j]);
+    std::vector<int64_t> hist((size_t)maxcnt + 1, 0);
+    for (int64_t j = 0; j < n; j++) hist[(size_t)(c->h_Ap[j + 1] - c->h_Ap[j])]++;
+    ipxint prev = -1;
+    int64_t below = 0;                  // # columns with a smaller count
+    for (ipxint v = 0; v <= maxcnt; v++) {
+        if (hist[(size_t)v] == 0) continue;
+        if (prev >= 0 && v > std::max<ipxint>(40, 10 * prev)) {
+            c->num_dense = n - below;
+            c->nz_dense = v;
             break;
         }
+        prev = v;
+        below += hist[(size_t)v];
     }
     if (c->num_dense > 1000) {
         c->num_dense = 0;
         c->nz_dense = m + 1;
     }
-    c->dense_cols.clear();
     for (int64_t j = 0; j < n; j++)
         if (c->h_Ap[j + 1] - c->h_Ap[j] >= c->nz_dense) c->dense_cols.push_back(j);
 }
 
+static double ms_since(std::chrono::steady_clock::time_point& t0) {
+    const auto t1 = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    t0 = t1;
+    return ms;
+}
+
+// The model goes to the device as it is (one staged copy of the caller's arrays); validation, the narrowing to 32-bit
+// indices, Transpose and the layouts of both gather matrices happen there (layout_device.hip).  Matrices the device
+// builders do not cover take the host builders on host copies of the entries -- of the caller's arrays for the CSC, a
+// download of the device's row-wise copy for the other gather matrix.
 void build_model(Context* c, const ipxint* Ap, const ipxint* Ai, const double* Ax) {
     const int64_t m = c->m, n = c->n;
-    IPXK_REQUIRE(Ap[0] == 0, "colptr[0] must be 0");
-    const int64_t nz = Ap[n];
-    for (int64_t j = 0; j < n; j++) IPXK_REQUIRE(Ap[j] <= Ap[j + 1], "colptr not monotone");
-    for (int64_t p = 0; p < nz; p++) IPXK_REQUIRE(Ai[p] >= 0 && Ai[p] < m, "row index out of range");
-    c->nnz = nz;
-    c->h_Ap.assign(Ap, Ap + n + 1);
-    c->h_Ai.assign(Ai, Ai + nz);
-    c->h_Ax.assign(Ax, Ax + nz);
-    transpose_host(m, n, Ap, Ai, Ax, c->h_ATp, c->h_ATi, c->h_ATx);
-    c->Acols.build(n, m, c->h_Ap.data(), c->h_Ai.data(), c->h_Ax.data(), c->stream);
-    c->Arows.build(m, n, c->h_ATp.data(), c->h_ATi.data(), c->h_ATx.data(), c->stream);
+    auto t0 = std::chrono::steady_clock::now();
+    upload_plain_model(c, Ap, Ai, Ax);
+    const int64_t nz = c->nnz;
+    c->create_ms[0] = ms_since(t0);
+    std::unique_ptr<LayoutScratch, void (*)(LayoutScratch*)> S(new_layout_scratch(), free_layout_scratch);
+    if (!c->Acols.build_device(*S, n, m, nz, c->pl_Ap.get(), c->pl_Ai.get(), c->pl_Ax.get(), c->stream))
+        c->Acols.build(n, m, Ap, Ai, Ax, c->stream);
+    c->create_ms[1] = ms_since(t0);
+    if (!c->Arows.build_device(*S, m, n, nz, c->pl_Tp.get(), c->pl_Ti.get(), c->pl_Tx.get(), c->stream)) {
+        ensure_host_model(c, true);
+        c->Arows.build(m, n, c->h_ATp.data(), c->h_ATi.data(), c->h_ATx.data(), c->stream);
+        c->h_ATp = std::vector<ipxint>(); c->h_ATi = std::vector<ipxint>(); c->h_ATx = std::vector<double>();
+    }
+    c->create_ms[2] = ms_since(t0);
+    S.reset();
     find_dense_columns(c);
     c->tcols.resize(n > 0 ? n : 1);
     prepare_dense_columns(c);
+    c->create_ms[3] = ms_since(t0);
+    if (getenv("IPXK_VERBOSE"))
+        fprintf(stderr, "ipxk: model %lld x %lld nnz %lld on the device: upload + transpose %.1f ms, A' layouts %.1f ms, A layouts %.1f ms, rest %.1f ms\n",
+                (long long)m, (long long)n, (long long)nz, c->create_ms[0], c->create_ms[1], c->create_ms[2], c->create_ms[3]);
 }
 
 // ---------------------------------------------------------------------------

@@ -34,7 +34,7 @@ EXPORTS = [
     "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_ipm_step", "ipxk_iterate_objectives", "ipxk_ipm_driver", "ipxk_iterate_factorize_diag", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns", "ipxk_comm_info", "ipxk_maxvolume_sequential",
     "ipxk_time_normal_apply", "ipxk_equilibrate", "ipxk_transpose", "ipxk_lu_factorize", "ipxk_lu_factorize_basis",
     "ipxk_lu_get_factors", "ipxk_split_prepare_lu", "ipxk_maxvolume", "ipxk_ipm_driver_basis",
-    "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
+    "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_layout_info", "ipxk_layout_array", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
     "ipxk_dev_download",
 ]
 
@@ -256,6 +256,29 @@ class KktContext:
         self._check(self.lib.ipxk_spmv_layout(self.h, lay, us))
         names = ("phased", "sliced", "fused", "sorted", "sortedfused")
         return (names[lay[0]], names[lay[1]]), [float(v) for v in us]
+
+    def layout_info(self, which):
+        """Scalars of the device layouts of gather matrix `which` (0: A'y, 1: A t) and the create timings (ms)."""
+        info = (C.c_int64 * 24)()
+        ms = (C.c_double * 4)()
+        self._check(self.lib.ipxk_layout_info(self.h, which, info, ms))
+        keys = ("use_sliced", "use_sorted", "use_sorted_fused", "nlong", "sliced_built", "R", "nslices", "nrb", "nrows_pad",
+                "max_tile", "dominant_bits", "sorted_built", "so_nslices", "so_nsub", "so_nrb", "so_RB", "so_nrows_pad",
+                "so_max_sub", "so_slice_elems", "so_fused", "nnz", "P", "G", "RTQ")
+        d = {k: int(v) for k, v in zip(keys, info)}
+        d["dominant_fraction"] = float(np.array([d.pop("dominant_bits")], dtype=np.int64).view(np.float64)[0])
+        return d, [float(v) for v in ms]
+
+    def layout_array(self, which, array):
+        """One array of the device layouts as numpy (see ipxk_layout_array)."""
+        dt = (np.uint32, np.uint8, np.int32, np.float64, np.uint32, np.uint8, np.uint32, np.float64, np.int32, np.int32, np.float64)[array]
+        nb = C.c_int64(0)
+        self._check(self.lib.ipxk_layout_array(self.h, which, array, None, 0, C.byref(nb)))
+        out = np.zeros(nb.value // np.dtype(dt).itemsize, dtype=dt)
+        if nb.value:
+            self._check(self.lib.ipxk_layout_array(self.h, which, array, out.ctypes.data_as(C.c_void_p), nb.value, C.byref(nb)))
+            self._check(self.lib.ipxk_synchronize(self.h))
+        return out
 
     def get_rowwise(self):
         nnz = int(self._keep[0][-1])

@@ -27,6 +27,7 @@ extern "C" long dropin_lu_factorizations();
 extern "C" long dropin_lu_max_bump();
 extern "C" double dropin_lu_seconds();
 #ifdef IPX_LP_HIP
+#include "hip_device.h"
 extern "C" double ipx_hip_cpu_prepare_seconds();
 extern "C" long ipx_hip_cpu_prepare_calls();
 #endif
@@ -115,6 +116,9 @@ int main(int argc, char** argv) {
 #ifdef IPX_LP_HIP
     f << "cpu_prepare_seconds " << ipx_hip_cpu_prepare_seconds() << '\n';
     f << "cpu_prepare_calls " << ipx_hip_cpu_prepare_calls() << '\n';
+    // one device model per Model: the three solver objects of LpSolver::Solve share one context (hip_device.h)
+    f << "hip_model_creations " << ipx::HipModel::creations() << '\n';
+    f << "hip_model_hits " << ipx::HipModel::hits() << '\n';
 #endif
 
     if (info.status_ipm != IPX_STATUS_not_run) {
