@@ -513,7 +513,11 @@ ipxint ipxk_normal_apply_bytes(const ipxk_context* ctx);
  * sub-tiles (the sliced layout's slices with the gathers of a tile issued in
  * address order; same partial sums as 1, bit for bit), 4 = sorted fused tiles
  * (one slice, gathers in address order, epilogue in the tile kernel: bit-identical
- * to 0 and 2, for matrices whose gathers have locality).  The sliced layouts are
+ * to 0 and 2, for matrices whose gathers have locality), 5 = accumulated tiles
+ * (the sliced layout's slices, a row block's sums kept in LDS, the entries of a
+ * tile in address order and in batches that hold one entry per row; same partial
+ * sums as 1 for rows stored with ascending indices; used whenever the sliced
+ * layout is and IPXK_SPMV_ACC is not 0).  The sliced layouts are
  * chosen by a property of the matrix (x larger than an XCD's L2 and gathers that
  * spread over the slices), between 1 and 3 the faster at ipxk_create; otherwise a
  * timing picks the fastest of phased, fused and sorted fused, which are
@@ -531,14 +535,16 @@ int ipxk_spmv_layout(const ipxk_context* ctx, int layout[2], double us[6]);
  * info: {use_sliced, use_sorted, use_sorted_fused, nlong, sliced.built, R,
  * nslices, nrb, nrows_pad, max_tile, bits of the fullest-slice share (double),
  * sorted.built, nslices, nsub, nrb, RB, nrows_pad, max_sub, slice_elems, fused,
- * nnz, P, G, RT*1e6 + Q*1e3}. */
-int ipxk_layout_info(const ipxk_context* ctx, int which, ipxint info[24],
+ * nnz, P, G, RT*1e6 + Q*1e3, use_acc, acc.built, nslices, nrb, RB, nrows_pad,
+ * slice_elems, # batches, # entries that waited for a later batch}. */
+int ipxk_layout_info(const ipxk_context* ctx, int which, ipxint info[40],
                      double create_ms[4]);
 /* array: 0 sliced tile_ptr (u32), 1 sliced cnt (u8), 2 sliced idx (i32), 3
  * sliced val (f64), 4 sorted sub_ptr (u32), 5 sorted cnt (u8), 6 sorted pack
  * (u32), 7 sorted val (f64), 8 / 9 / 10 the row-wise copy of the model (Transpose,
  * sparse_matrix.cc:120-151) as the device holds it: ptr (i32), idx (i32), val
- * (f64).  Copies min(cap, size) bytes into out; *nbytes = the array's size. */
+ * (f64); 11 acc tile_batch (u32), 12 acc bptr (u32), 13 acc pack (u32), 14 acc
+ * val (f64).  Copies min(cap, size) bytes into out; *nbytes = the array's size. */
 int ipxk_layout_array(ipxk_context* ctx, int which, int array, void* out,
                       ipxint cap, ipxint* nbytes);
 /* plain device allocation helpers so that callers without torch can hold

@@ -938,11 +938,11 @@ int ipxk_debug_get_stamps(ipxk_context* c, int which, unsigned long long* out, i
 }
 
 // Layout inspection (tests/test_gpu_layout.py: the device builders against the host builders, array by array).
-int ipxk_layout_info(const ipxk_context* c, int which, ipxint info[24], double create_ms[4]) {
+int ipxk_layout_info(const ipxk_context* c, int which, ipxint info[40], double create_ms[4]) {
     return guarded([&] {
         IPXK_REQUIRE(c && info && (which == 0 || which == 1), "bad argument");
         const GatherMatrix& M = which == 0 ? c->Acols : c->Arows;
-        for (int i = 0; i < 24; i++) info[i] = 0;
+        for (int i = 0; i < 40; i++) info[i] = 0;
         info[0] = M.use_sliced; info[1] = M.use_sorted; info[2] = M.use_sorted_fused; info[3] = M.nlong;
         info[4] = M.sliced.built; info[5] = M.sliced.R; info[6] = M.sliced.nslices; info[7] = M.sliced.nrb;
         info[8] = M.sliced.nrows_pad; info[9] = M.sliced.max_tile;
@@ -951,6 +951,8 @@ int ipxk_layout_info(const ipxk_context* c, int which, ipxint info[24], double c
         info[15] = M.sorted.RB; info[16] = M.sorted.nrows_pad; info[17] = M.sorted.max_sub; info[18] = M.sorted.slice_elems;
         info[19] = M.sorted.fused; info[20] = M.nnz;
         info[21] = M.P; info[22] = M.G; info[23] = (ipxint)M.RT * 1000000 + (ipxint)M.Q * 1000 + 0;
+        info[24] = M.use_acc; info[25] = M.acc.built; info[26] = M.acc.nslices; info[27] = M.acc.nrb; info[28] = M.acc.RB;
+        info[29] = M.acc.nrows_pad; info[30] = M.acc.slice_elems; info[31] = M.acc.nbatches; info[32] = M.acc.deferred;
         if (create_ms) for (int i = 0; i < 4; i++) create_ms[i] = c->create_ms[i];
     });
 }
@@ -978,9 +980,13 @@ int ipxk_layout_array(ipxk_context* c, int which, int array, void* out, ipxint c
             case 8: src = c->pl_Tp.get(); bytes = ((size_t)c->m + 1) * 4; break;
             case 9: src = c->pl_Ti.get(); bytes = (size_t)c->nnz * 4; break;
             case 10: src = c->pl_Tx.get(); bytes = (size_t)c->nnz * 8; break;
+            case 11: src = M.acc.tile_batch.get(); bytes = M.acc.built ? ((size_t)M.acc.nrb * M.acc.nslices + 1) * 4 : 0; break;
+            case 12: src = M.acc.bptr.get(); bytes = M.acc.built ? ((size_t)M.acc.nbatches + 1) * 4 : 0; break;
+            case 13: src = M.acc.pack.get(); bytes = M.acc.built ? nz * 4 : 0; break;
+            case 14: src = M.acc.val.get(); bytes = M.acc.built ? nz * 8 : 0; break;
             default: IPXK_REQUIRE(false, "unknown array");
         }
-        if (M.nlong > 0 && array < 8) bytes = 0;       // long rows: the tiles hold fewer entries than nnz; not inspected
+        if (M.nlong > 0 && (array < 8 || array > 10)) bytes = 0;       // long rows: the tiles hold fewer entries than nnz; not inspected
         *nbytes = (ipxint)bytes;
         const size_t ncopy = std::min<size_t>(bytes, cap > 0 ? (size_t)cap : 0);
         if (out && ncopy > 0) staged_d2h(out, src, ncopy, c->stream);
@@ -996,13 +1002,13 @@ ipxint ipxk_normal_apply_bytes(const ipxk_context* c) {
 int ipxk_spmv_layout(const ipxk_context* c, int layout[2], double us[6]) {
     return guarded([&] {
         IPXK_REQUIRE(c && layout, "bad argument");
-        auto code = [](const GatherMatrix& M) { return M.use_sorted_fused ? 4 : !M.use_sliced ? 0 : M.sliced.nslices == 1 ? 2 : M.use_sorted ? 3 : 1; };
+        auto code = [](const GatherMatrix& M) { return M.use_acc ? 5 : M.use_sorted_fused ? 4 : !M.use_sliced ? 0 : M.sliced.nslices == 1 ? 2 : M.use_sorted ? 3 : 1; };
         layout[0] = code(c->Acols);
         layout[1] = code(c->Arows);
         if (us) {
-            us[0] = c->Acols.tuned_us_phased; us[1] = c->Acols.use_sorted ? c->Acols.tuned_us_sorted : c->Acols.tuned_us_sliced;
+            us[0] = c->Acols.tuned_us_phased; us[1] = c->Acols.use_acc ? c->Acols.tuned_us_acc : c->Acols.use_sorted ? c->Acols.tuned_us_sorted : c->Acols.tuned_us_sliced;
             us[2] = c->Acols.use_sorted_fused ? c->Acols.tuned_us_sorted_fused : c->Acols.tuned_us_fused;
-            us[3] = c->Arows.tuned_us_phased; us[4] = c->Arows.use_sorted ? c->Arows.tuned_us_sorted : c->Arows.tuned_us_sliced;
+            us[3] = c->Arows.tuned_us_phased; us[4] = c->Arows.use_acc ? c->Arows.tuned_us_acc : c->Arows.use_sorted ? c->Arows.tuned_us_sorted : c->Arows.tuned_us_sliced;
             us[5] = c->Arows.use_sorted_fused ? c->Arows.tuned_us_sorted_fused : c->Arows.tuned_us_fused;
         }
     });

@@ -150,6 +150,10 @@ bool device_build_sliced(LayoutScratch& S, SlicedMatrix& out, int nrows, int nco
 bool device_build_sorted(LayoutScratch& S, SortedMatrix& out, const SlicedMatrix& sliced, int nrows, int ncols, int64_t nnz, const int* dptr,
                          const int* didx, const double* dval, hipStream_t s);
 
+int acc_rows_per_block(int nrows, int ns);
+bool device_build_acc(LayoutScratch& S, AccMatrix& out, const SlicedMatrix& sliced, int nrows, int ncols, int64_t nnz, const int* dptr,
+                      const int* didx, const double* dval, hipStream_t s);
+
 enum TimeKind { kTimeOp = 0, kTimePrecond = 1, kTimeB = 2, kTimeBt = 3, kNumTimeKinds = 4 };
 void time_mark(Context* c, int kind, bool begin);      // no-op unless timing is active
 void time_start(Context* c, ipxk_times* times);        // called by a solve before it enqueues work

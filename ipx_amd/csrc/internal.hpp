@@ -246,6 +246,44 @@ struct SortedMatrix {
     DevBuf<int> xmin;
 };
 
+// Accumulated tiles (round 4; the headline's layout): the sliced layout's slices with the ROW SUMS of a row block kept
+// in LDS.  Measured first (scripts/bench_ldsacc.hip, profiles/r04_ldsacc_microbench.txt): what the sorted sub-tiles pay
+// for staging every product in an LDS slot (a byte count per row and sub-tile, a scan, a row-by-row sum phase, running
+// sums in registers that cap the row block at 8192 rows) costs more than the gathers; with nothing but RB doubles of
+// LDS per workgroup the row block grows to 16384 rows, a tile holds two entries per 128-byte line of its slice, and
+// the sum phase disappears:
+//   * tile (rb, s) = the entries of RB rows whose gathered index lies in slice s, in ascending order of the gathered
+//     ADDRESS over the whole slice (ties in storage order), cut into BATCHES of at most kAccBatch entries;
+//   * a batch holds at most ONE entry of a row: walking the entries in address order, an entry whose row already has
+//     one in the current batch waits for the next batch (it goes first there), and a batch is closed when it is full
+//     or nothing else is left -- so the ds_add_f64 of a batch hit distinct addresses, one workgroup barrier separates
+//     two batches, and a row's products are added in ascending address order whatever the thread timing:
+//     deterministic, and equal to the storage order (hence to the sliced layout's partial sums, bit for bit) when the
+//     rows are stored with ascending indices, as the reference's Transpose and its sorted CSC give them;
+//   * an entry is one 32-bit word (row in block << 18 | index - first index of the slice) + its value; batch q of
+//     tile t is entries [bptr[tb[t] + q], bptr[tb[t] + q + 1]);
+//   * partial vectors and the combine kernel are the sliced layout's (folding the partials into the last workgroup of
+//     a row block to finish measured SLOWER than the combine launch: 109-145 against 95-101 us per pass).
+constexpr int kAccThreads = 512;
+constexpr int kAccPerThread = 4;
+constexpr int kAccBatch = kAccThreads * kAccPerThread;     // 2048 entries between two barriers
+constexpr int kAccMaxRows = 16384;                         // 128 KB of row sums; 14 bits of row in the entry word
+struct AccView {
+    int nrows, nrows_pad, nslices, nrb, RB, slice_elems;
+    const unsigned* tile_batch;        // [nrb*nslices + 1] first batch of each tile
+    const unsigned* bptr;              // [# batches + 1] first entry of each batch
+    const unsigned* pack;
+    const double* val;
+    double* partial;                   // [nslices][nrows_pad]
+};
+struct AccMatrix {
+    bool built = false;
+    int nslices = 0, nrb = 0, RB = 0, nrows_pad = 0, slice_elems = 0;
+    int64_t nbatches = 0, deferred = 0;
+    DevBuf<unsigned> tile_batch, bptr, pack;
+    DevBuf<double> val, partial;
+};
+
 struct LayoutScratch;                 // layout_device.hip
 
 struct GatherMatrix {
@@ -287,6 +325,12 @@ struct GatherMatrix {
     SortedMatrix sorted;
     bool use_sorted = false;           // only with use_sliced and sliced.nslices > 1
     void build_sorted(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s);
+    // accumulated tiles (the sliced layout's slices, row sums in LDS); use_acc: the layout in use for unmasked products
+    AccMatrix acc;
+    bool use_acc = false;
+    float tuned_us_acc = 0.f;
+    void build_acc(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s);     // host builder (test reference)
+    AccView acc_view() const;
     // the FUSED form (independent of the sliced layout); use_sorted_fused: it is the layout in use
     void build_sorted_fused(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s);
     bool use_sorted_fused = false;

@@ -169,6 +169,131 @@ __global__ void gather_columns_kernel(int k, const int* __restrict__ cols, const
 }
 __global__ void widen_kernel(int64_t nz, const int* __restrict__ in, ipxint* __restrict__ out) { IPXK_GS(p, nz) out[p] = in[p]; }
 
+// ---- accumulated tiles -----------------------------------------------------------------------
+// key = (tile << 18 | offset in the slice), enumerated in storage order (a stable sort keeps that order among ties)
+__global__ void acc_keys_kernel(int nrows, const int* __restrict__ ptr, const int* __restrict__ idx, int RB, int ns, int slice,
+                                u64* __restrict__ key, unsigned* __restrict__ pos, int* __restrict__ rowof) {
+    IPXK_GS(r, nrows) {
+        const u64 tile0 = (u64)(r / RB) * (u64)ns;
+        for (int p = ptr[r]; p < ptr[r + 1]; p++) {
+            const int sl = idx[p] / slice, off = idx[p] - sl * slice;
+            key[p] = ((tile0 + (u64)sl) << kSortedOffBits) | (u64)(unsigned)off;
+            pos[p] = (unsigned)p;
+            rowof[p] = (int)r;
+        }
+    }
+}
+// the entry words in sorted order: row in block << 18 | offset
+__global__ void acc_words_kernel(int64_t nz, const u64* __restrict__ keys, const unsigned* __restrict__ perm, const int* __restrict__ rowof, int RB,
+                                 unsigned* __restrict__ word) {
+    IPXK_GS(e, nz) word[e] = ((unsigned)(rowof[perm[e]] % RB) << kSortedOffBits) | (unsigned)(keys[e] & ((1u << kSortedOffBits) - 1u));
+}
+// The batches of one tile, by ONE wavefront: the tile's entries are walked in address order, 64 candidates at a time
+// (the entries that waited from the previous batch first, then the stream); a candidate is taken unless its row
+// already has an entry in the current batch (stamp) or an earlier candidate of the same group has the same row
+// (claim: the lowest lane wins) or the batch is full; whoever is not taken waits for the next batch, in order.
+// Sequential by nature (a greedy list schedule), but only ~ne/64 steps per tile and all tiles in parallel.
+__global__ __launch_bounds__(64) void acc_batch_kernel(int RB, const unsigned* __restrict__ tile_ptr, const unsigned* __restrict__ word,
+                                                        unsigned* __restrict__ dst, unsigned* pendA, unsigned* pendB, unsigned* __restrict__ bstart,
+                                                        unsigned* __restrict__ nbatch, u64* deferred_total) {
+    extern __shared__ unsigned ab_lds[];
+    unsigned* stamp = ab_lds;
+    unsigned* claim = ab_lds + RB;
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const unsigned e0 = tile_ptr[tile];
+    const int ne = (int)(tile_ptr[tile + 1] - e0);
+    for (int r = lane; r < RB; r += 64) { stamp[r] = 0u; claim[r] = 0xffffffffu; }
+    __syncthreads();
+    unsigned cur = 1;
+    int fill = 0, out = 0, nb = 0, cursor = 0, na = 0, ia = 0, nbp = 0;
+    u64 ndef = 0;
+    unsigned *pa = pendA + e0, *pb = pendB + e0;
+    if (ne > 0) { if (lane == 0) bstart[e0] = e0; nb = 1; }
+    const u64 lt = (1ull << lane) - 1ull;
+    while (out < ne) {
+        int n = 0, c = 0;
+        if (ia < na) {
+            n = min(64, na - ia);
+            if (lane < n) c = (int)__hip_atomic_load(pa + ia + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written by this wave: read it past L1
+            ia += n;
+        } else if (fill < kAccBatch && cursor < ne) {
+            n = min(64, ne - cursor);
+            c = cursor + lane;
+            cursor += n;
+        } else {                                   // close the batch
+            if (lane == 0) bstart[e0 + nb] = e0 + (unsigned)out;
+            nb++; cur++; fill = 0;
+            unsigned* t = pa; pa = pb; pb = t;
+            na = nbp; ia = 0; nbp = 0;
+            __syncthreads();                       // the waiting list written by this wave is read back below
+            continue;
+        }
+        const bool live = lane < n;
+        const unsigned row = live ? (word[e0 + c] >> kSortedOffBits) : 0u;
+        const bool ok = live && stamp[row] != cur;
+        if (ok) atomicMin(&claim[row], (unsigned)lane);
+        __syncthreads();
+        const bool win = ok && claim[row] == (unsigned)lane;
+        __syncthreads();
+        if (win) { claim[row] = 0xffffffffu; stamp[row] = cur; }
+        const u64 wmask = __ballot(win);
+        const int prefix = __popcll(wmask & lt);
+        const bool take = win && prefix < kAccBatch - fill;
+        if (take) dst[e0 + c] = e0 + (unsigned)(out + prefix);
+        const int nt = __popcll(__ballot(take));
+        const bool def = live && !take;
+        const u64 dmask = __ballot(def);
+        if (def) pb[nbp + __popcll(dmask & lt)] = (unsigned)c;
+        const int nd = __popcll(dmask);
+        nbp += nd; ndef += (u64)nd; out += nt; fill += nt;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        nbatch[tile] = (unsigned)nb;
+        if (ndef) atomicAdd(deferred_total, ndef);
+    }
+}
+__global__ void acc_scatter_kernel(int64_t nz, const unsigned* __restrict__ dst, const unsigned* __restrict__ word, const unsigned* __restrict__ perm,
+                                   const double* __restrict__ val, unsigned* __restrict__ pack, double* __restrict__ out_val) {
+    IPXK_GS(e, nz) {
+        const unsigned d = dst[e];
+        pack[d] = word[e];
+        out_val[d] = val[perm[e]];
+    }
+}
+// exclusive scan of the tiles' batch counts by one workgroup (a few thousand tiles)
+__global__ __launch_bounds__(1024) void scan_u32_kernel(int n, const unsigned* __restrict__ in, unsigned* __restrict__ out) {
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const unsigned v = i < n ? in[i] : 0u;
+        unsigned incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        unsigned before = carry;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        if (i < n) out[i] = before + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry;
+}
+__global__ void acc_bptr_kernel(int ntiles, const unsigned* __restrict__ tile_ptr, const unsigned* __restrict__ tile_batch,
+                                const unsigned* __restrict__ bstart, unsigned nz, unsigned* __restrict__ bptr) {
+    const int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const unsigned e0 = tile_ptr[tile], b0 = tile_batch[tile], nb = tile_batch[tile + 1] - b0;
+    for (unsigned q = threadIdx.x; q < nb; q += blockDim.x) bptr[b0 + q] = bstart[e0 + q];
+    if (tile == ntiles - 1 && threadIdx.x == 0) bptr[tile_batch[ntiles]] = nz;
+}
+
 struct Tmp {
     DevBuf<unsigned char> bytes;
     void* need(size_t n) { if (bytes.size() < n) bytes.resize(n); return bytes.get(); }
@@ -419,6 +544,64 @@ bool device_build_sorted(LayoutScratch& S, SortedMatrix& out, const SlicedMatrix
     if (over) { out = SortedMatrix(); return false; }
     out.nslices = ns; out.nsub = nsub; out.nrb = nrb; out.RB = RB; out.nrows_pad = nrb * RB;
     out.max_sub = max_sub; out.slice_elems = (int)slice;
+    out.partial.resize((size_t)ns * out.nrows_pad);
+    out.built = true;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// accumulated tiles (the arrays of GatherMatrix::build_acc, bit for bit); needs the sliced layout's slices
+// ---------------------------------------------------------------------------
+int acc_rows_per_block(int nrows, int ns) {
+    static const int cap = [] { const char* e = getenv("IPXK_ACC_ROWS"); return e && atoi(e) >= 1024 ? std::min(atoi(e), kAccMaxRows) : kAccMaxRows; }();
+    int RB = cap;
+    while (RB > 1024 && ((int64_t)nrows + RB - 1) / RB * (int64_t)ns < 512) RB /= 2;
+    return RB;
+}
+
+bool device_build_acc(LayoutScratch& S, AccMatrix& out, const SlicedMatrix& sliced, int nrows, int ncols, int64_t nnz, const int* dptr,
+                      const int* didx, const double* dval, hipStream_t s) {
+    out = AccMatrix();
+    if (!sliced.built || sliced.nslices < 2 || nnz == 0) return false;
+    const int ns = sliced.nslices;
+    const int64_t slice = (((int64_t)ncols + ns - 1) / ns + 15) / 16 * 16;
+    if (slice > (int64_t(1) << kSortedOffBits)) return false;
+    const int RB = acc_rows_per_block(nrows, ns);
+    const int nrb = (nrows + RB - 1) / RB;
+    const int64_t ntiles = (int64_t)nrb * ns;
+    const size_t nz = (size_t)nnz;
+    S.q1.ensure(nz); S.q2.ensure(nz); S.v1.ensure(nz); S.v2.ensure(nz); S.v3.ensure(nz); S.v4.ensure(nz); S.k1.ensure(nz); S.k2.ensure(nz);
+    S.stats.ensure(8);
+    DevBuf<int> rowof(nz);
+    DevBuf<unsigned> tile_ptr((size_t)ntiles + 1), nbatch((size_t)ntiles + 1), bstart(nz);
+    hipLaunchKernelGGL(acc_keys_kernel, dim3(gridn(nrows)), dim3(kBlock), 0, s, nrows, dptr, didx, RB, ns, (int)slice, S.q1.get(), S.v1.get(), rowof.get());
+    sort_pairs<u64>(S.T, S.q1.get(), S.q2.get(), S.v1.get(), S.v2.get(), nz, kSortedOffBits + bits_for((u64)std::max<int64_t>(ntiles, 2) - 1), s);
+    hipLaunchKernelGGL(lower_bounds_kernel<u64>, dim3(gridn(ntiles + 1)), dim3(kBlock), 0, s, ntiles + 1, nnz, S.q2.get(), (u64)1, kSortedOffBits,
+                       tile_ptr.get());
+    unsigned* word = S.k1.get();
+    hipLaunchKernelGGL(acc_words_kernel, dim3(gridn(nnz)), dim3(kBlock), 0, s, nnz, S.q2.get(), S.v2.get(), rowof.get(), RB, word);
+    IPXK_HIP(hipMemsetAsync(S.stats.get(), 0, 8 * sizeof(int), s));
+    const size_t lds = (size_t)RB * 2 * sizeof(unsigned);
+    IPXK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(acc_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(kAccMaxRows * 2 * sizeof(unsigned))));
+    hipLaunchKernelGGL(acc_batch_kernel, dim3((unsigned)ntiles), dim3(64), lds, s, RB, tile_ptr.get(), word, S.k2.get(), S.v3.get(), S.v4.get(),
+                       bstart.get(), nbatch.get(), reinterpret_cast<u64*>(S.stats.get()));
+    out.tile_batch.ensure((size_t)ntiles + 1);
+    hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(1024), 0, s, (int)ntiles, nbatch.get(), out.tile_batch.get());
+    unsigned nb_total = 0;
+    u64 ndef = 0;
+    IPXK_HIP(hipMemcpyAsync(&nb_total, out.tile_batch.get() + ntiles, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipMemcpyAsync(&ndef, S.stats.get(), sizeof(u64), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    out.bptr.ensure((size_t)nb_total + 1); out.pack.ensure(nz); out.val.ensure(nz);
+    hipLaunchKernelGGL(acc_bptr_kernel, dim3((unsigned)ntiles), dim3(64), 0, s, (int)ntiles, tile_ptr.get(), out.tile_batch.get(), bstart.get(),
+                       (unsigned)nnz, out.bptr.get());
+    hipLaunchKernelGGL(acc_scatter_kernel, dim3(gridn(nnz)), dim3(kBlock), 0, s, nnz, S.k2.get(), word, S.v2.get(), dval, out.pack.get(),
+                       out.val.get());
+    IPXK_HIP(hipStreamSynchronize(s));       // the temporaries go out of scope
+    IPXK_HIP(hipGetLastError());
+    out.nslices = ns; out.nrb = nrb; out.RB = RB; out.nrows_pad = nrb * RB; out.slice_elems = (int)slice;
+    out.nbatches = nb_total; out.deferred = (int64_t)ndef;
     out.partial.resize((size_t)ns * out.nrows_pad);
     out.built = true;
     return true;

@@ -186,6 +186,15 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
     use_sorted = false;
     use_sorted_fused = false;
     sorted = SortedMatrix();
+    use_acc = false;
+    acc = AccMatrix();
+    if (layout == "acc") {
+        build_sliced(hptr, hidx, hval, s, 0);
+        use_sliced = sliced.built;
+        build_acc(hptr, hidx, hval, s);
+        use_acc = acc.built;
+        return;
+    }
     if (layout == "sortedfused") {
         build_sorted_fused(hptr, hidx, hval, s);
         use_sorted_fused = sorted.built;
@@ -256,7 +265,16 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
                 use_sorted = true;
                 tuned_us_sorted = time_current();
                 use_sorted = tuned_us_sorted < tuned_us_sliced || (getenv("IPXK_SPMV_SORTED") && getenv("IPXK_SPMV_SORTED")[0] == '1');
-                if (!use_sorted) sorted = SortedMatrix();
+                if (!use_sorted && !getenv("IPXK_BUILD_ALL_LAYOUTS")) sorted = SortedMatrix();
+            }
+        }
+        if (spread && !(getenv("IPXK_SPMV_ACC") && getenv("IPXK_SPMV_ACC")[0] == '0')) {
+            // accumulated tiles: used whenever they can be built (never a timing decision: see build_device)
+            build_acc(hptr, hidx, hval, s);
+            if (acc.built) {
+                use_acc = true;
+                tuned_us_acc = time_current();
+                if (!getenv("IPXK_BUILD_ALL_LAYOUTS")) { use_sorted = false; sorted = SortedMatrix(); }
             }
         }
         if (use_sliced) {        // the phased copy of the entries is not needed any more
@@ -296,8 +314,13 @@ bool GatherMatrix::build_device(LayoutScratch& S, int64_t nrows_, int64_t ncols_
     use_sliced = true;
     use_sorted = false; use_sorted_fused = false;
     sorted = SortedMatrix();
+    acc = AccMatrix(); use_acc = false;
+    const bool want_acc = !(getenv("IPXK_SPMV_ACC") && getenv("IPXK_SPMV_ACC")[0] == '0');
+    AccMatrix ac;
+    if (want_acc && device_build_acc(S, ac, sliced, nrows, ncols, nnz_, dptr, didx, dval, s)) acc = std::move(ac);
     SortedMatrix so;
-    if (device_build_sorted(S, so, sliced, nrows, ncols, nnz_, dptr, didx, dval, s)) sorted = std::move(so);
+    // (the sorted sub-tiles are the fall-back of the accumulated tiles; both are built only when asked for)
+    if ((!acc.built || getenv("IPXK_BUILD_ALL_LAYOUTS")) && device_build_sorted(S, so, sliced, nrows, ncols, nnz_, dptr, didx, dval, s)) sorted = std::move(so);
     // sliced against sorted: bit-identical partial sums, the faster one is kept (as in build())
     DevBuf<double> tx((size_t)std::max(ncols, 1)), tout((size_t)std::max(nrows, 1));
     IPXK_HIP(hipMemsetAsync(tx.get(), 0, tx.size() * sizeof(double), s));
@@ -321,13 +344,21 @@ bool GatherMatrix::build_device(LayoutScratch& S, int64_t nrows_, int64_t ncols_
         use_sorted = true;
         tuned_us_sorted = time_current();
         use_sorted = tuned_us_sorted < tuned_us_sliced || (getenv("IPXK_SPMV_SORTED") && getenv("IPXK_SPMV_SORTED")[0] == '1');
-        if (!use_sorted) sorted = SortedMatrix();
+        if (!use_sorted && !getenv("IPXK_BUILD_ALL_LAYOUTS")) sorted = SortedMatrix();
+    }
+    if (acc.built) {
+        // used whenever it was built: its row sums equal the sliced layout's bit for bit only for rows stored with
+        // ascending indices, so the choice is a property of the matrix and the environment, never of a timing
+        use_acc = true;
+        tuned_us_acc = time_current();
     }
     IPXK_HIP(hipEventDestroy(e0));
     IPXK_HIP(hipEventDestroy(e1));
     if (getenv("IPXK_VERBOSE"))
-        fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld built on the device: sliced %.1f us, sorted %.1f us (fullest-slice share %.2f) -> %s\n",
-                nrows, ncols, (long long)nnz, tuned_us_sliced, tuned_us_sorted, sliced.dominant_fraction, use_sorted ? "sorted" : "sliced");
+        fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld built on the device: sliced %.1f us, sorted %.1f us, accumulated %.1f us (%lld batches, %.1f%% of the entries waited) (fullest-slice share %.2f) -> %s\n",
+                nrows, ncols, (long long)nnz, tuned_us_sliced, tuned_us_sorted, tuned_us_acc, (long long)acc.nbatches,
+                acc.built ? 100.0 * (double)acc.deferred / (double)nnz : 0.0, sliced.dominant_fraction,
+                use_acc ? "accumulated" : use_sorted ? "sorted" : "sliced");
     return true;
 }
 
@@ -522,6 +553,79 @@ void GatherMatrix::build_sorted(const ipxint* hptr, const ipxint* hidx, const do
     sorted.partial.resize((size_t)ns * sorted.nrows_pad);
     IPXK_HIP(hipStreamSynchronize(s));
     sorted.built = true;
+}
+
+// Accumulated tiles (internal.hpp), host builder: the reference the device builder (layout_device.hip) is tested against.
+void GatherMatrix::build_acc(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s) {
+    acc = AccMatrix();
+    if (!sliced.built || sliced.nslices < 2 || nlong > 0 || nnz == 0) return;
+    const int ns = sliced.nslices;
+    const int64_t slice = ((ncols + ns - 1) / ns + 15) / 16 * 16;        // as in build_sliced
+    if (slice > (int64_t(1) << kSortedOffBits)) return;
+    const int RB = acc_rows_per_block(nrows, ns);
+    const int nrb = (nrows + RB - 1) / RB;
+    const int64_t ntiles = (int64_t)nrb * ns;
+    struct E { unsigned off, row; double v; };
+    std::vector<unsigned> tptr((size_t)ntiles + 1, 0);
+    for (int r = 0; r < nrows; r++)
+        for (ipxint p = hptr[r]; p < hptr[r + 1]; p++) tptr[(size_t)(r / RB) * ns + hidx[p] / slice + 1]++;
+    for (int64_t t = 0; t < ntiles; t++) tptr[t + 1] += tptr[t];
+    std::vector<E> all((size_t)nnz);
+    {
+        std::vector<unsigned> cursor(tptr.begin(), tptr.end() - 1);
+        for (int r = 0; r < nrows; r++)
+            for (ipxint p = hptr[r]; p < hptr[r + 1]; p++) {
+                const int64_t sl = hidx[p] / slice;
+                all[cursor[(size_t)(r / RB) * ns + sl]++] = E{(unsigned)(hidx[p] - sl * slice), (unsigned)(r % RB), hval[p]};
+            }
+    }
+    std::vector<unsigned> pk((size_t)nnz), bp, tb((size_t)ntiles + 1, 0);
+    std::vector<double> tv((size_t)nnz);
+    std::vector<int> stamp((size_t)RB), pend, newpend;
+    int64_t deferred = 0;
+    for (int64_t t = 0; t < ntiles; t++) {
+        E* a = all.data() + tptr[t];
+        const int ne = (int)(tptr[t + 1] - tptr[t]);
+        tb[t] = (unsigned)bp.size();
+        std::stable_sort(a, a + ne, [](const E& x, const E& y) { return x.off < y.off; });
+        std::fill(stamp.begin(), stamp.end(), -1);
+        pend.clear();
+        int cursor = 0, put = 0, batch = 0;
+        while (put < ne) {
+            bp.push_back(tptr[t] + (unsigned)put);
+            newpend.clear();
+            int fill = 0;
+            auto offer = [&](int i) {
+                if (stamp[a[i].row] == batch || fill == kAccBatch) { newpend.push_back(i); deferred++; return; }
+                stamp[a[i].row] = batch;
+                pk[tptr[t] + put] = (a[i].row << kSortedOffBits) | a[i].off;
+                tv[tptr[t] + put] = a[i].v;
+                put++; fill++;
+            };
+            for (int i : pend) offer(i);                                   // whoever waited goes first, in order
+            while (fill < kAccBatch && cursor < ne) offer(cursor++);      // then the stream
+            pend.swap(newpend);
+            batch++;
+        }
+    }
+    tb[ntiles] = (unsigned)bp.size();
+    bp.push_back((unsigned)nnz);
+    acc.nslices = ns; acc.nrb = nrb; acc.RB = RB; acc.nrows_pad = nrb * RB; acc.slice_elems = (int)slice;
+    acc.nbatches = (int64_t)bp.size() - 1; acc.deferred = deferred;
+    acc.tile_batch.upload(tb, s);
+    acc.bptr.upload(bp, s);
+    acc.pack.upload(pk, s);
+    acc.val.upload(tv, s);
+    acc.partial.resize((size_t)ns * acc.nrows_pad);
+    IPXK_HIP(hipStreamSynchronize(s));
+    acc.built = true;
+}
+
+AccView GatherMatrix::acc_view() const {
+    AccView V;
+    V.nrows = nrows; V.nrows_pad = acc.nrows_pad; V.nslices = acc.nslices; V.nrb = acc.nrb; V.RB = acc.RB; V.slice_elems = acc.slice_elems;
+    V.tile_batch = acc.tile_batch.get(); V.bptr = acc.bptr.get(); V.pack = acc.pack.get(); V.val = acc.val.get(); V.partial = acc.partial.get();
+    return V;
 }
 
 // FUSED sorted tiles (internal.hpp): one slice, the epilogue in the tile kernel.

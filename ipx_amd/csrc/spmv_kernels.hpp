@@ -661,6 +661,66 @@ __global__ __launch_bounds__(kSortedThreads, kSortedThreads / 128) void spmv_sor
     }
 }
 
+// ---- accumulated tiles (internal.hpp, AccMatrix) -----------------------------------------------
+// One workgroup of 512 threads per (row block, slice); the RB row sums live in LDS.  Batch after batch (at most 2048
+// entries, 4 per thread): packed word + value streamed non-temporally, x gathered at ascending addresses (neighbouring
+// lanes share lines), one barrier, one ds_add_f64 per entry -- the layout guarantees that a batch holds at most one
+// entry of a row, so the adds of a batch hit distinct addresses and a row is summed in batch order.  The stream loads
+// of batch k+1 are in flight while the gathers of batch k return.  The row sums leave as one partial vector per slice.
+template <class Prod>
+__global__ __launch_bounds__(kAccThreads) void spmv_acc_tile_kernel(AccView M, const double* __restrict__ x, const int* done) {
+    if (done && *done) return;
+    extern __shared__ double ac_sum[];
+    constexpr int U = kAccPerThread, T = kAccThreads;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, s = tile % M.nslices, rb = tile / M.nslices;
+    const double* __restrict__ xs = x + (size_t)s * M.slice_elems;
+    const unsigned b0 = M.tile_batch[tile], b1 = M.tile_batch[tile + 1];
+    unsigned pk[U];
+    double v[U];
+    auto stream = [&](unsigned e0, int ne) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = min(u * T + tid, ne - 1);
+            pk[u] = __builtin_nontemporal_load(M.pack + e0 + i);
+            v[u] = __builtin_nontemporal_load(M.val + e0 + i);
+        }
+    };
+    unsigned e_cur = 0, e_next = 0;
+    if (b0 < b1) {
+        e_cur = M.bptr[b0];
+        e_next = M.bptr[b0 + 1];
+        stream(e_cur, (int)(e_next - e_cur));
+    }
+    for (int r = tid; r < M.RB; r += T) ac_sum[r] = 0.0;
+    for (unsigned b = b0; b < b1; b++) {
+        const int ne = (int)(e_next - e_cur);
+        double xg[U], vv[U];
+        unsigned row[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            row[u] = pk[u] >> kSortedOffBits;
+            vv[u] = v[u];
+            xg[u] = xs[pk[u] & ((1u << kSortedOffBits) - 1u)];
+        }
+        unsigned e_nn = e_next;
+        if (b + 1 < b1) {
+            e_nn = M.bptr[b + 2];
+            stream(e_next, (int)(e_nn - e_next));
+        }
+        __syncthreads();                  // the adds of the previous batch (first batch: the zeroing) are done
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (u * T + tid < ne)
+                __hip_atomic_fetch_add(ac_sum + row[u], Prod::prod(xg[u], vv[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        e_cur = e_next;
+        e_next = e_nn;
+    }
+    __syncthreads();
+    double* dst = M.partial + (size_t)s * M.nrows_pad + (size_t)rb * M.RB;
+    for (int r = 2 * tid; r < M.RB; r += 2 * T) reinterpret_cast<double2*>(dst + r)[0] = make_double2(ac_sum[r], ac_sum[r + 1]);
+}
+
 // out[r] = finish(init(r) (+|-) partial[0][r] (+|-) partial[1][r] ...), slices in ascending order
 template <class Epi>
 __global__ __launch_bounds__(kBlock) void spmv_sliced_combine_kernel(SlicedView M, Epi epi, double* dot_partials,
@@ -688,6 +748,27 @@ template <class Epi, bool MASKED = false, bool COMPACT = false>
 inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi& epi, double* dot_partials,
                                const int* done, hipStream_t s) {
     static_assert(!(MASKED && COMPACT), "the compacted copy needs no mask");
+    if (M.use_acc && !MASKED && !COMPACT) {
+        // accumulated tiles + the sliced layout's combine on their partial vectors
+        const AccView W = M.acc_view();
+        const size_t lds = (size_t)W.RB * sizeof(double);
+        static bool lds_attr_set = false;       // per instantiation: dynamic LDS beyond 64 KB has to be allowed once
+        if (!lds_attr_set) {
+            IPXK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spmv_acc_tile_kernel<Epi>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(kAccMaxRows * sizeof(double))));
+            lds_attr_set = true;
+        }
+        hipLaunchKernelGGL((spmv_acc_tile_kernel<Epi>), dim3(W.nrb * W.nslices), dim3(kAccThreads), lds, s, W, x, done);
+        SlicedView C = M.sliced_view(0);
+        C.nrows_pad = W.nrows_pad; C.partial = W.partial;
+        hipLaunchKernelGGL(spmv_sliced_combine_kernel<Epi>, dim3(M.combine_grid()), dim3(kBlock), 0, s, C, epi, dot_partials, done);
+        if (M.nlong > 0) {
+            const GatherView G = M.view(false);
+            hipLaunchKernelGGL(spmv_long_kernel<Epi>, dim3(M.nseg), dim3(kBlock), 0, s, G, x, done);
+            hipLaunchKernelGGL(spmv_long_fixup_kernel<Epi>, dim3(1), dim3(kBlock), 0, s, G, epi, dot_partials, M.combine_grid(), done);
+        }
+        return;
+    }
     if (M.use_sorted && !MASKED && !COMPACT) {
         // sorted sub-tiles + the sliced layout's combine on their partial vectors
         const SortedView W = M.sorted_view();

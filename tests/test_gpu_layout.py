@@ -16,13 +16,14 @@ from ipx_amd import kkt, synth
 
 pytestmark = pytest.mark.gpu
 
-ARRAYS = ("sliced.tile_ptr", "sliced.cnt", "sliced.idx", "sliced.val", "sorted.sub_ptr", "sorted.cnt", "sorted.pack", "sorted.val")
+ARRAYS = {0: "sliced.tile_ptr", 1: "sliced.cnt", 2: "sliced.idx", 3: "sliced.val", 4: "sorted.sub_ptr", 5: "sorted.cnt", 6: "sorted.pack",
+          7: "sorted.val", 11: "acc.tile_batch", 12: "acc.bptr", 13: "acc.pack", 14: "acc.val"}
 
 
 def _ctx(A, build, env):
-    old = {k: os.environ.get(k) for k in list(env) + ["IPXK_LAYOUT_BUILD"]}
+    env = dict(env, IPXK_LAYOUT_BUILD=build, IPXK_BUILD_ALL_LAYOUTS="1")       # also the sorted sub-tiles, which the accumulated tiles replace
+    old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
-    os.environ["IPXK_LAYOUT_BUILD"] = build
     try:
         return kkt.KktContext(A, device=0)
     finally:
@@ -40,17 +41,17 @@ def _compare(A, env, want_sorted=True):
         for which in (0, 1):
             ih, _ = host.layout_info(which)
             idv, ms = dev.layout_info(which)
-            assert idv["use_sliced"] == 1 and idv["sliced_built"] == 1, idv
+            assert idv["use_sliced"] == 1 and idv["sliced_built"] == 1 and idv["use_acc"] == 1 and idv["acc_built"] == 1, idv
             if want_sorted:
                 assert idv["sorted_built"] == 1 or ih["sorted_built"] == 0
             # which of the two bit-identical layouts is in use is a timing decision; everything else must agree
             skip = {"use_sorted", "sorted_built", "so_nslices", "so_nsub", "so_nrb", "so_RB", "so_nrows_pad", "so_max_sub",
-                    "so_slice_elems"} if ih["sorted_built"] != idv["sorted_built"] else {"use_sorted"}
+                    "so_slice_elems", "acc_deferred"} if ih["sorted_built"] != idv["sorted_built"] else {"use_sorted", "acc_deferred"}   # acc_deferred: a statistic (waiting events), counted differently by the two builders
             for k in ih:
                 if k not in skip:
                     assert ih[k] == idv[k], (which, k, ih[k], idv[k])
-            for a, name in enumerate(ARRAYS):
-                if a >= 4 and not (ih["sorted_built"] and idv["sorted_built"]):
+            for a, name in ARRAYS.items():
+                if 4 <= a <= 7 and not (ih["sorted_built"] and idv["sorted_built"]):
                     continue
                 x, y = host.layout_array(which, a), dev.layout_array(which, a)
                 assert x.shape == y.shape and x.size > 0, (which, name, x.shape, y.shape)
@@ -68,10 +69,12 @@ def _compare(A, env, want_sorted=True):
         dev.normal_prepare(W)
         l1, d1 = host.normal_apply(y)
         l2, d2 = dev.normal_apply(y)
-        if host.spmv_layout()[0] == dev.spmv_layout()[0]:
-            assert np.array_equal(l1, l2) and d1 == d2
-        else:
-            assert np.abs(l1 - l2).max() <= 1e-13 * np.abs(l1).max()
+        assert host.spmv_layout()[0] == dev.spmv_layout()[0] == ("acc", "acc")
+        assert np.array_equal(l1, l2) and d1 == d2
+        # the accumulated tiles against scipy (the oracle's order differs in association across slices only)
+        S0 = A.to_scipy()
+        ref = W[A.ncol:] * y + S0 @ (W[:A.ncol] * (S0.T @ y))
+        assert np.abs(l2 - ref).max() <= 1e-12 * np.abs(ref).max()
         return dev.layout_info(0)[1]
     finally:
         host.close()
@@ -103,7 +106,11 @@ def test_device_layouts_equal_host_layouts_unsorted_columns_and_duplicates_of_ro
 def test_device_layouts_equal_host_layouts_benchmark_size():
     # C3: 1M x 2M, 16M entries -- the size the create time is quoted on
     A = synth.synthetic_lp(1 << 20, 2 << 20, 8, 12345)
-    ms = _compare(A, {})
+    _compare(A, {})
+    c = kkt.KktContext(A, device=0)                  # default environment: what a solver object pays
+    ms = c.layout_info(0)[1]
+    assert c.spmv_layout()[0] == ("acc", "acc")
+    c.close()
     total = sum(ms)
     print("ipxk_create at 1M x 2M: upload + transpose %.1f ms, A' layouts %.1f ms, A layouts %.1f ms, rest %.1f ms" % tuple(ms))
     assert total < 400.0, ms          # 3.2 s with the host builders (round 3); target 100 ms

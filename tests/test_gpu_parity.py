@@ -595,7 +595,7 @@ def test_spmv_layouts_agree(kkt, po, oracle, monkeypatch):
     u = rng.standard_normal(m)
     ref, ref_dot = oracle.normal_apply(ocsc(po, A), W, u)
     out = {}
-    for layout in ("phased", "sliced", "fused", "sorted"):
+    for layout in ("phased", "sliced", "fused", "sorted", "acc"):
         monkeypatch.setenv("IPXK_SPMV_LAYOUT", layout)
         ctx = kkt.KktContext(A)
         assert ctx.spmv_layout()[0][1] == layout
@@ -614,6 +614,9 @@ def test_spmv_layouts_agree(kkt, po, oracle, monkeypatch):
     # sorted sub-tiles: the sliced layout's partial sums in the same order, bit for bit
     assert np.array_equal(out["sorted"][0], out["sliced"][0]) and out["sorted"][3] == out["sliced"][3]
     assert np.array_equal(out["sorted"][2], out["sliced"][2])
+    # accumulated tiles: a row is summed in ascending address order = the storage order of these (sorted) rows
+    assert np.array_equal(out["acc"][0], out["sliced"][0]) and out["acc"][3] == out["sliced"][3]
+    assert np.array_equal(out["acc"][2], out["sliced"][2])
     assert out["sliced"][4] == out["phased"][4] == 0 and abs(out["sliced"][3] - out["phased"][3]) <= 2
     assert relerr(out["sliced"][2], out["phased"][2]) < 1e-8
 
