@@ -53,7 +53,8 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 }
 
 // MODE 0: partial vectors (plain stores); 1: fold by the last arriver (8-byte sc1 stores); 2: like 0 without the per-batch
-// barrier (upper bound); 3: fold with 16-byte sc1 stores
+// barrier (upper bound); 3: fold with 16-byte sc1 stores; ablations of mode 0: 4 = no gather (x = 1), 5 = no LDS add (register sum),
+// 6 = no partial store, 7 = next batch's stream issued AFTER the adds (no overlap)
 template <int T, int MODE, bool PASS2, int U = 8>
 __global__ __launch_bounds__(T) void tile_kernel(View M, const double* __restrict__ x) {
     extern __shared__ double acc[];
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(T) void tile_kernel(View M, const double* __restric
     const int ntiles = M.nrb * M.ns;
     unsigned pk[U];
     double v[U];
+    double regsum = 0.0;
     auto stream = [&](int tile, int base) {
         const unsigned e0 = M.tile_ptr[tile];
         const int ne = (int)(M.tile_ptr[tile + 1] - e0);
@@ -88,20 +90,29 @@ __global__ __launch_bounds__(T) void tile_kernel(View M, const double* __restric
             for (int u = 0; u < U; u++) {
                 row[u] = pk[u] >> kOffBits;
                 vv[u] = v[u];
-                xg[u] = xs[pk[u] & ((1u << kOffBits) - 1u)];
+                xg[u] = MODE == 4 ? 1.0 : xs[pk[u] & ((1u << kOffBits) - 1u)];
             }
-            if (base + B < ne) stream(tile, base + B);
-            else if (tile + (int)gridDim.x < ntiles) stream(tile + gridDim.x, 0);
+            if (MODE != 7) {
+                if (base + B < ne) stream(tile, base + B);
+                else if (tile + (int)gridDim.x < ntiles) stream(tile + gridDim.x, 0);
+            }
             if (MODE != 2 || base == 0) __syncthreads();          // the adds of the previous batch (or the zeroing) are done
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int i = base + u * T + tid;
-                if (i < ne) lds_add(acc + row[u], xg[u] * vv[u]);
+                if (MODE == 5) { if (i < ne) regsum += xg[u] * vv[u] + (double)row[u]; }
+                else if (i < ne) lds_add(acc + row[u], xg[u] * vv[u]);
+            }
+            if (MODE == 7) {
+                if (base + B < ne) stream(tile, base + B);
+                else if (tile + (int)gridDim.x < ntiles) stream(tile + gridDim.x, 0);
             }
         }
         __syncthreads();
         double* mine = M.partial + (size_t)s * M.nrows_pad + (size_t)rb * M.RB;
-        if (MODE != 1 && MODE != 3) {
+        if (MODE == 5 && regsum == 12345.678) mine[tid] = regsum;
+        if (MODE == 6) { if (acc[tid] == 12345.678) mine[tid] = acc[tid]; }
+        else if (MODE != 1 && MODE != 3) {
             for (int r = tid; r < M.RB; r += T) mine[r] = acc[r];
         } else {
             if (MODE == 1) for (int r = tid; r < M.RB; r += T) store_sc1(mine + r, acc[r]);
@@ -291,7 +302,7 @@ static void run(Pass& P, const char* name) {
         printf("      check: max err %.2e (rel %.1e)%s", err, err / nrm, PASS2 ? "" : "\n");
         if (PASS2) printf(", dot rel err %.1e\n", fabs(dot - refdot) / fabs(refdot));
     };
-    for (int mode : {0, 1, 3}) for (int grid : {ntiles, 256}) {
+    for (int mode : {0}) for (int grid : {ntiles}) {
         if (grid > ntiles) continue;
         if (grid != ntiles && grid % (8 * P.ns) != 0 && (8 % P.ns != 0 || grid % 8 != 0)) continue;
         CHECK(hipMemset(M.out, 0, (size_t)nrows_pad * 8));
@@ -313,15 +324,30 @@ static void run(Pass& P, const char* name) {
         check(mode == 1 || mode == 3 ? P.nrb : 1024);
         fflush(stdout);
     }
-    // tile kernel alone (mode 0 without the combine)
-    {
-        for (int wu = 0; wu < 3; wu++) hipLaunchKernelGGL((tile_kernel<T, 0, PASS2, U>), dim3(ntiles), dim3(T), lds, 0, M, dx);
+    // tile kernel alone: mode 0 and its ablations
+    auto time_mode = [&](int mode) {
+        auto launch = [&]() {
+            switch (mode) {
+                case 0: hipLaunchKernelGGL((tile_kernel<T, 0, PASS2, U>), dim3(ntiles), dim3(T), lds, 0, M, dx); break;
+                case 4: hipLaunchKernelGGL((tile_kernel<T, 4, PASS2, U>), dim3(ntiles), dim3(T), lds, 0, M, dx); break;
+                case 5: hipLaunchKernelGGL((tile_kernel<T, 5, PASS2, U>), dim3(ntiles), dim3(T), lds, 0, M, dx); break;
+                case 6: hipLaunchKernelGGL((tile_kernel<T, 6, PASS2, U>), dim3(ntiles), dim3(T), lds, 0, M, dx); break;
+                default: hipLaunchKernelGGL((tile_kernel<T, 7, PASS2, U>), dim3(ntiles), dim3(T), lds, 0, M, dx); break;
+            }
+        };
+        for (int wu = 0; wu < 3; wu++) launch();
         CHECK(hipEventRecord(e0));
-        for (int r = 0; r < 20; r++) hipLaunchKernelGGL((tile_kernel<T, 0, PASS2, U>), dim3(ntiles), dim3(T), lds, 0, M, dx);
+        for (int r = 0; r < 20; r++) launch();
         CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-        printf("  %s RB=%5d T=%4d U=%2d tile kernel alone: %6.1f us\n", name, P.RB, T, U, ms / 20 * 1e3);
-    }
+        return ms / 20 * 1e3;
+    };
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<T, 4, PASS2, U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<T, 5, PASS2, U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<T, 6, PASS2, U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<T, 7, PASS2, U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    printf("  %s RB=%5d T=%4d U=%2d tile kernel alone: full %6.1f us | no gather %6.1f | no LDS add %6.1f | no partial store %6.1f | stream not overlapped %6.1f\n",
+           name, P.RB, T, U, time_mode(0), time_mode(4), time_mode(5), time_mode(6), time_mode(7));
     hipFree((void*)M.tile_ptr); hipFree((void*)M.pack); hipFree((void*)M.val); hipFree((void*)M.w); hipFree((void*)M.y);
     hipFree(dx); hipFree(M.partial); hipFree(M.counter); hipFree(M.out); hipFree(M.dot_partials);
 }
@@ -331,7 +357,7 @@ int main(int argc, char** argv) {
     std::mt19937_64 rng(12345);
     const int m = (1 << 20) / scale, n = (2 << 20) / scale;
     struct Cfg { int RB, T, U; };
-    for (Cfg c : {Cfg{16384, 512, 8}, Cfg{16384, 512, 4}, Cfg{16384, 1024, 4}, Cfg{16384, 256, 16}, Cfg{16384, 1024, 8}}) {
+    for (Cfg c : {Cfg{16384, 512, 4}, Cfg{16384, 1024, 4}, Cfg{16384, 512, 8}}) {
         Pass P1{n, m, 8, 4, c.RB, c.T, c.U}, P2{m, n, 16, 8, c.RB, c.T, c.U};
         build(P1, rng);
         build(P2, rng);

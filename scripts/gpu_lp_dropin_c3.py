@@ -19,5 +19,6 @@ for exe in (T.HIP_BIN, T.REF_BIN):
     res[exe] = info
     print(os.path.basename(exe), "wall %.1f s" % (time.time() - t0), {k: info.get(k) for k in keys}, flush=True)
 a, b = res[T.HIP_BIN], res[T.REF_BIN]
+print("device models: %d ipxk_create for %d solver objects (HipModel registry: one context per Model)" % (a.get("hip_model_creations", -1), a.get("hip_model_creations", 0) + a.get("hip_model_hits", 0)))
 print("KKT solve time (Info::time_kkt_solve): reference %.2f s, Hip %.2f s -> %.1f x;  initial IPM (time_ipm1): %.2f / %.2f s -> %.1f x; kktiter1 %d / %d"
       % (b["time_kkt_solve"], a["time_kkt_solve"], b["time_kkt_solve"] / a["time_kkt_solve"], b["time_ipm1"], a["time_ipm1"], b["time_ipm1"] / a["time_ipm1"], b["kktiter1"], a["kktiter1"]))
