@@ -525,6 +525,19 @@ ipxint ipxk_normal_apply_bytes(const ipxk_context* ctx);
  * us[6] receives the measured microseconds {pass1 phased, sliced (or sorted, if
  * that was kept), fused (or sorted fused), pass2 likewise} (0 = not timed). */
 int ipxk_spmv_layout(const ipxk_context* ctx, int layout[2], double us[6]);
+/* The guard of the explicit inverses of SplittedNormalMatrix::Prepare's device
+ * form (ipxk_split_prepare*): narrow first / last levels of a sweep and large
+ * dense blocks of the factors are applied as inverse(T) * b; substitution is
+ * backward stable whatever the condition of T, a product with a computed inverse
+ * is not, and IPX's late bases are ill conditioned by construction (that is what
+ * the stability loop of src/basis.cc:130-152 and the residual test of
+ * src/lu_factorization.cc:87-127 are for).  Every inverse is therefore probed at
+ * Prepare with two fixed vectors, || T (M z) - z ||_inf <= 1e-10 (IPXK_INVERSE_TOL),
+ * and a block that fails keeps its level-scheduled / blocked solve.  Returns the
+ * number of probes, of rejected inverses and the worst residual seen since
+ * ipxk_create. */
+int ipxk_split_inverse_stats(const ipxk_context* ctx, ipxint* probes,
+                             ipxint* rejected, double* worst_residual);
 /* Inspection of the device layouts (tests: the layouts built on the device by
  * radix sorts, layout_device.hip, against the host builders, array by array;
  * IPXK_LAYOUT_BUILD=host forces the host builders).  The reference's

@@ -937,6 +937,15 @@ int ipxk_debug_get_stamps(ipxk_context* c, int which, unsigned long long* out, i
     });
 }
 
+int ipxk_split_inverse_stats(const ipxk_context* c, ipxint* probes, ipxint* rejected, double* worst_residual) {
+    return guarded([&] {
+        IPXK_REQUIRE(c != nullptr, "ctx is NULL");
+        if (probes) *probes = c->split_stats.inverse_probes;
+        if (rejected) *rejected = c->split_stats.inverse_rejected;
+        if (worst_residual) *worst_residual = c->split_stats.worst_probe;
+    });
+}
+
 // Layout inspection (tests/test_gpu_layout.py: the device builders against the host builders, array by array).
 int ipxk_layout_info(const ipxk_context* c, int which, ipxint info[40], double create_ms[4]) {
     return guarded([&] {

@@ -109,6 +109,8 @@ struct Context {
     DevBuf<double> ipm[12];            // residuals, complementarity targets and the step of ipxk_ipm_step
 
     // ---- basis path ----
+    // guard of the explicit inverses (trisolve.hip): # probes and # inverses rejected since the context was created, worst residual
+    struct { long inverse_probes = 0, inverse_rejected = 0; double worst_probe = 0.0; } split_stats;
     SplitOperator* split = nullptr;
     PrepareHost* prepare_host = nullptr;   // host workspaces of split_prepare (trisolve.hip)
     LuState* lu = nullptr;                 // factors of the last ipxk_lu_factorize* (lu.hip)

@@ -595,6 +595,79 @@ __global__ __launch_bounds__(kBlock) void block_gemv_kernel(int K, const double*
     }
 }
 
+// ---------------------------------------------------------------------------
+// guard of every explicit inverse (round 4)
+// ---------------------------------------------------------------------------
+// IPX's late bases are ill conditioned by construction (that is why src/basis.cc:130-152 has a stability loop and
+// src/lu_factorization.cc:87-127 a residual test): substitution with a triangular factor is backward stable whatever
+// its condition, a product with its computed INVERSE is not (error ~ cond * eps).  So every inverse computed at
+// Prepare is probed with two fixed vectors z:  || T (M z) - z ||_inf / || z ||_inf  must not exceed kInverseTol
+// (IPXK_INVERSE_TOL, default 1e-10); a block that fails keeps its level-scheduled / blocked solve.
+static double inverse_tol() {
+    static const double tol = [] { const char* e = getenv("IPXK_INVERSE_TOL"); return e ? atof(e) : 1e-10; }();
+    return tol;
+}
+__device__ __forceinline__ double probe_z(int q, int l) {       // entries in [0.5, 1.5], two unrelated sign patterns
+    const unsigned h = (unsigned)l * 2654435761u + (unsigned)q * 40503u;
+    const double mag = 0.5 + (double)((h >> 9) & 1023u) / 1024.0;
+    return ((h >> 20) ^ (unsigned)(q * l)) & 1u ? -mag : mag;
+}
+__device__ __forceinline__ void probe_max(double* slot, double v) {   // maximum of non-negative doubles through their bit patterns
+    if (!(v == v)) v = __builtin_huge_val();                           // a NaN residual fails the test
+    atomicMax(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double_as_longlong(v));
+}
+// w_q = M z_q for the lower-triangular M of an inverted head / tail (row major, K x K): one wavefront per row
+__global__ __launch_bounds__(kBlock) void block_probe_mz_kernel(int K, const double* __restrict__ M, double* __restrict__ w) {
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); i < K; i += gridDim.x * (kBlock / 64)) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int l = lane; l <= i; l += 64) { const double a = M[(size_t)i * K + l]; s0 += a * probe_z(0, l); s1 += a * probe_z(1, l); }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { s0 += __shfl_xor(s0, d, 64); s1 += __shfl_xor(s1, d, 64); }
+        if (lane == 0) { w[i] = s0; w[K + i] = s1; }
+    }
+}
+// res[q] = max_i | (T22 w_q)_i - z_q(i) |,  T22 = diagonal + the block's inside entries (unscaled)
+__global__ void block_probe_res_kernel(int K, const int* __restrict__ tptr, const int* __restrict__ tcol, const double* __restrict__ tval,
+                                       const double* __restrict__ dg, const int* __restrict__ tpos, const double* __restrict__ w, double* res) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K; i += gridDim.x * blockDim.x) {
+        const double d = dg[tpos[i]];
+        double r0 = d * w[i], r1 = d * w[K + i];
+        for (int e = tptr[i]; e < tptr[i + 1]; e++) { const int k = tcol[e]; r0 += tval[e] * w[k]; r1 += tval[e] * w[K + k]; }
+        probe_max(res + 0, fabs(r0 - probe_z(0, i)));
+        probe_max(res + 1, fabs(r1 - probe_z(1, i)));
+    }
+}
+// dense block D22 = (L22 + I) U22 (column major in D: L22 below, U22 on and above the diagonal), inv row major:
+// w_q = inv z_q (one wavefront per row), t_q = U22 w_q, r_q = (L22 + I) t_q - z_q (one thread per row: lanes read a column's
+// consecutive rows)
+__global__ __launch_bounds__(kBlock) void bump_probe_mz_kernel(int kb, const double* __restrict__ inv, double* __restrict__ w) {
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); i < kb; i += gridDim.x * (kBlock / 64)) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int l = lane; l < kb; l += 64) { const double a = inv[(size_t)i * kb + l]; s0 += a * probe_z(0, l); s1 += a * probe_z(1, l); }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { s0 += __shfl_xor(s0, d, 64); s1 += __shfl_xor(s1, d, 64); }
+        if (lane == 0) { w[i] = s0; w[kb + i] = s1; }
+    }
+}
+__global__ void bump_probe_u_kernel(int kb, const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ t) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kb; i += gridDim.x * blockDim.x) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int l = i; l < kb; l++) { const double a = D[(size_t)l * kb + i]; s0 += a * w[l]; s1 += a * w[kb + l]; }
+        t[i] = s0; t[kb + i] = s1;
+    }
+}
+__global__ void bump_probe_l_kernel(int kb, const double* __restrict__ D, const double* __restrict__ t, double* res) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kb; i += gridDim.x * blockDim.x) {
+        double s0 = t[i], s1 = t[kb + i];
+        for (int l = 0; l < i; l++) { const double a = D[(size_t)l * kb + i]; s0 += a * t[l]; s1 += a * t[kb + l]; }
+        probe_max(res + 0, fabs(s0 - probe_z(0, i)));
+        probe_max(res + 1, fabs(s1 - probe_z(1, i)));
+    }
+}
+// (z has entries of magnitude in [0.5, 1.5]: || z ||_inf is between 1 and 1.5 for any block of a few rows, the residuals are taken as they are)
+
 // the levels [la, lb) of S as an inverted block
 static void build_block(Context* c, Sweep& S, Sweep::Block& T, int la, int lb, const char* what) {
     hipStream_t s = c->stream;
@@ -646,12 +719,27 @@ static void build_block(Context* c, Sweep& S, Sweep::Block& T, int la, int lb, c
     IPXK_HIP(hipMemsetAsync(T.M.get(), 0, (size_t)Ki * Ki * sizeof(double), s));
     hipLaunchKernelGGL(block_inverse_kernel, dim3((Ki + 63) / 64), dim3(kBlockInvThreads), 0, s, Ki, lb - la, dlev.get(), tptr.get(),
                        tcol.get(), tval.get(), S.diag.get(), T.pos.get(), T.M.get());
-    IPXK_HIP(hipStreamSynchronize(s));                             // the host vectors uploaded above go out of scope
+    // the guard: T22 (M z) against z for two fixed vectors
+    T.w_probe.ensure((size_t)2 * Ki + 2);
+    DevBuf<double>& pw = T.w_probe;
+    IPXK_HIP(hipMemsetAsync(pw.get() + 2 * (size_t)Ki, 0, 2 * sizeof(double), s));
+    hipLaunchKernelGGL(block_probe_mz_kernel, dim3((Ki + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, s, Ki, T.M.get(), pw.get());
+    hipLaunchKernelGGL(block_probe_res_kernel, dim3(vec_grid(Ki)), dim3(kBlock), 0, s, Ki, tptr.get(), tcol.get(), tval.get(), S.diag.get(),
+                       T.pos.get(), pw.get(), pw.get() + 2 * (size_t)Ki);
+    double h[2] = {0.0, 0.0};
+    IPXK_HIP(hipMemcpyAsync(h, pw.get() + 2 * (size_t)Ki, sizeof h, hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipStreamSynchronize(s));                             // also: the host vectors uploaded above go out of scope
     IPXK_HIP(hipGetLastError());
-    T.K = Ki; T.la = la; T.lb = lb; T.p0 = p0; T.p1 = p1;
+    const double resid = std::max(h[0], h[1]);
+    const bool good = resid <= inverse_tol();
+    c->split_stats.inverse_probes++;
+    c->split_stats.worst_probe = std::max(c->split_stats.worst_probe, resid);
+    if (!good) c->split_stats.inverse_rejected++;
     if (getenv("IPXK_VERBOSE") || getenv("IPXK_SWEEP_STATS"))
-        fprintf(stderr, "ipxk: sweep %s: levels %d..%d (%d unknowns, %d outside + %d inside entries) inverted\n", what, la, lb - 1, Ki,
-                T.nh, tp[Ki]);
+        fprintf(stderr, "ipxk: sweep %s: levels %d..%d (%d unknowns, %d outside + %d inside entries) inverted; probe |T M z - z| = %.2e%s\n", what, la,
+                lb - 1, Ki, T.nh, tp[Ki], resid, good ? "" : " -> REJECTED, these levels stay in the level-scheduled sweep");
+    if (!good) { T.K = 0; return; }
+    T.K = Ki; T.la = la; T.lb = lb; T.p0 = p0; T.p1 = p1;
 }
 
 void build_sweep_blocks(Context* c, Sweep& S, bool level_launches) {
@@ -1221,6 +1309,23 @@ static DeviceFactors cut_dense_block(Context* c, SplitOperator* S, const DeviceF
         allow_bump_lds((size_t)(kb + 64) * sizeof(double));
         if (!by_blas) hipLaunchKernelGGL(bump_inverse_kernel, dim3(kb), dim3(kBumpThreads), (size_t)(kb + 64) * sizeof(double), s, kb, S->bumpD.get(),
                            S->bump_invL.get(), S->bump_invU.get(), S->bump_inv.get(), S->bump_invT.get());
+        // the guard (whoever computed the inverse): D22 (inverse z) against z; a block that fails keeps the blocked solve
+        S->bump_probe.ensure((size_t)4 * kb + 2);
+        double* pw = S->bump_probe.get();
+        IPXK_HIP(hipMemsetAsync(pw + 4 * (size_t)kb, 0, 2 * sizeof(double), s));
+        hipLaunchKernelGGL(bump_probe_mz_kernel, dim3((kb + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, s, kb, S->bump_inv.get(), pw);
+        hipLaunchKernelGGL(bump_probe_u_kernel, dim3((kb + 63) / 64), dim3(64), 0, s, kb, S->bumpD.get(), pw, pw + 2 * (size_t)kb);
+        hipLaunchKernelGGL(bump_probe_l_kernel, dim3((kb + 63) / 64), dim3(64), 0, s, kb, S->bumpD.get(), pw + 2 * (size_t)kb, pw + 4 * (size_t)kb);
+        double h[2] = {0.0, 0.0};
+        IPXK_HIP(hipMemcpyAsync(h, pw + 4 * (size_t)kb, sizeof h, hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        const double resid = std::max(h[0], h[1]);
+        c->split_stats.inverse_probes++;
+        c->split_stats.worst_probe = std::max(c->split_stats.worst_probe, resid);
+        if (!(resid <= inverse_tol())) { S->bump_explicit = false; c->split_stats.inverse_rejected++; }
+        if (getenv("IPXK_VERBOSE") || getenv("IPXK_SWEEP_STATS"))
+            fprintf(stderr, "ipxk: dense block of %d rows inverted (%s); probe |D (inverse z) - z| = %.2e%s\n", kb, by_blas ? "rocBLAS dtrsm" : "own kernel",
+                    resid, S->bump_explicit ? "" : " -> REJECTED, the blocked solve stays");
     }
     IPXK_HIP(hipStreamSynchronize(s));               // cnt / start go out of scope; ends
     S->bump_start = s0;

@@ -102,7 +102,7 @@ struct Sweep {
         DevBuf<int> zsrc;          // [K] where the sweep's input vector holds the right-hand side of unknown t (Sweep::src of its position)
         DevBuf<double> M, z;       // [K*K] row major; [K]
         DevBuf<int> w_base, w_rank, w_hcnt, w_tcnt, w_lev, w_tptr, w_tcol;   // workspaces of build_block, kept (grow-only)
-        DevBuf<double> w_tval;
+        DevBuf<double> w_tval, w_probe;
     } head, tail;
     SweepView view(bool scaled) const {
         SweepView V;
@@ -148,6 +148,7 @@ struct SplitOperator {
     // the solve between the sweeps of a pair is then ONE matrix-vector product spread over the chip
     DevBuf<double> bump_inv, bump_invT, bump_x;
     bool bump_explicit = false;
+    DevBuf<double> bump_probe;             // workspace of the guard of the explicit inverse
     DevBuf<int> bump_pos_fwd, bump_pos_bwd;   // position of bump unknown t in the result of the L sweep / of the U' sweep
     // workspaces of Prepare kept from one call to the next (grow-only): the factors as uploaded, the factors with the
     // dense block cut out

@@ -4,7 +4,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ipx_amd import kkt, synth
-m, n = 1 << 20, 2 << 20
+m, n = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1 << 20, 2 << 20)
 A = synth.synthetic_lp(m, n, 8, 12345)
 t0 = time.perf_counter()
 c = kkt.KktContext(A, device=0)
@@ -22,4 +22,6 @@ c.set_pointer_mode(True)
 rhs = c.vector(m, y); lhs = c.vector(m)
 c.time_normal_apply(rhs, lhs, 5)
 print("apply %.1f us" % (c.time_normal_apply(rhs, lhs, 50) / 50 * 1e3))
+c.time_normal_apply(rhs, lhs, 3000)          # half a second of sustained load
+print("apply after 3000 more: %.1f us" % (c.time_normal_apply(rhs, lhs, 50) / 50 * 1e3))
 c.close()
