@@ -123,7 +123,7 @@ def lp_vectors(m, n):
                 constr_type="<" * m)
 
 
-def planted_lu_basis(A, offdiag=3, seed=12345, band=None, num_free=0, num_fixed=0):
+def planted_lu_basis(A, offdiag=3, seed=12345, band=None, num_free=0, num_fixed=0, big_rows=0.0, big=1.0):
     """Plants a basis with known LU factors into [A I] (BASICLU is not available
     offline).  Generates sparse unit-lower L0 (strictly lower part
     returned) and upper U0 with `offdiag` off-diagonal entries per column (uniform
@@ -152,6 +152,9 @@ def planted_lu_basis(A, offdiag=3, seed=12345, band=None, num_free=0, num_fixed=
             ok = span > 0
         rows, cols = rows[ok], cols[ok]
         vals = rng.uniform(0.1, 0.6, rows.size) * rng.choice([-1.0, 1.0], rows.size)
+        if lower and big_rows > 0:
+            hot = rows >= int((1.0 - big_rows) * m)
+            vals[hot] = rng.uniform(big, 1.2 * big, int(hot.sum())) * rng.choice([-1.0, 1.0], int(hot.sum()))
         T = sp.coo_matrix((vals, (rows, cols)), shape=(m, m)).tocsc()
         T.sum_duplicates()
         T.sort_indices()

@@ -261,3 +261,29 @@ def test_dense_block_inverse_by_rocblas_against_the_own_kernel(kkt, monkeypatch,
         err = np.abs(a[k] - b[k]).max() / np.abs(b[k]).max()
         assert err <= 1e-11, (k, err)
     assert not np.array_equal(a[0], b[0])          # (otherwise rocBLAS was not used: the box has no librocblas?)
+
+
+def test_dense_block_inverse_is_guarded(kkt, monkeypatch):
+    """the explicit inverse of a dense block of the factors is probed like the inverted levels of the sweeps
+    (|D (inverse z) - z| <= 1e-10 at Prepare); a block that fails keeps the blocked in-place solve.  A well conditioned
+    block passes (residual ~ 1e-13); with IPXK_INVERSE_TOL=0 it is rejected and the operator falls back: same results
+    to 1e-11 (the blocked solve and the product with the inverse round differently)."""
+    from ipx_amd import synth
+    m, n, bump = 40000, 90000, 1300
+    P = synth.lp_like_basis(m, n, seed=5, bump=bump, offdiag=3)
+    colscale = synth.synthetic_basis_state(P["status"], 1.0, 5)
+    rhs = np.random.default_rng(2).standard_normal(m)
+    out = {}
+    for tol in ("1e-10", "0"):
+        monkeypatch.setenv("IPXK_INVERSE_TOL", tol)
+        ctx = kkt.KktContext(P["A"])
+        ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+        ctx.split_prepare_lu(P["status"], colscale)
+        probes, rejected, worst = ctx.split_inverse_stats()
+        assert probes >= 1 and worst < 1e-10 and (rejected >= 1) == (tol == "0"), (probes, rejected, worst)
+        out[tol] = (ctx.split_apply(rhs)[0], ctx.solve_dense(rhs, "N"), ctx.solve_dense(rhs, "T"))
+        ctx.close()
+    for k in range(3):
+        err = np.abs(out["0"][k] - out["1e-10"][k]).max() / np.abs(out["1e-10"][k]).max()
+        assert err <= 1e-11, (k, err)
+    assert not np.array_equal(out["0"][0], out["1e-10"][0])

@@ -385,6 +385,65 @@ def test_inverted_head_and_tail_of_the_sweeps(kkt, po, oracle, monkeypatch, capf
     assert a[7] == b[7] == 0 and abs(a[6] - b[6]) <= 3 + b[6] // 50 and relerr(a[4], b[4]) < 1e-6 and relerr(a[5], b[5]) < 1e-6
 
 
+def test_ill_conditioned_block_is_not_inverted(kkt, monkeypatch, capfd):
+    """The guard of the explicit inverses (trisolve.hip; IPX's bases get ill conditioned late in a solve: that is what
+    the stability loop of src/basis.cc:130-152 and the residual test of src/lu_factorization.cc:87-127 are for).  A
+    planted basis whose L has entries of magnitude 3 in its last rows: along the dependency chains of those rows the
+    inverse of the tail block grows like 3^depth (probe residual |T M z - z| ~ 1e2, i.e. cond * eps with cond ~ 1e18).
+    Substitution with that block is backward stable, a product with its computed inverse is not.  With the guard the
+    block keeps its level-scheduled solve and B x = r is solved to 1e-9 for a right-hand side with a moderate solution;
+    with the guard switched off (IPXK_INVERSE_TOL=1e300) the same solve is wrong by orders of magnitude, which shows
+    that the planted block does what it is meant to."""
+    from ipx_amd import synth
+    m, n = 60000, 130000
+    B = synth.planted_lu_basis(synth.synthetic_lp(m, n, 8, 3), seed=3, big_rows=0.03, big=3.0)
+    cs = synth.synthetic_basis_state(B["status"], 1.0, 3)
+    Bm = B["A"].to_scipy()[:, :m].tocsr()
+    xt = np.random.default_rng(1).standard_normal(m)
+    monkeypatch.setenv("IPXK_TAIL_MIN_DIM", "1000")
+    monkeypatch.setenv("IPXK_VERBOSE", "1")
+    res = {}
+    for tol in ("1e-10", "1e300"):
+        monkeypatch.setenv("IPXK_INVERSE_TOL", tol)
+        ctx = kkt.KktContext(B["A"])
+        ctx.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], cs)
+        probes, rejected, worst = ctx.split_inverse_stats()
+        err = capfd.readouterr().err
+        assert probes >= 3 and worst >= 1e-4, (probes, worst)              # cond * eps >= 1e-4: cond >= 1e12
+        assert (rejected >= 1) == (tol == "1e-10") and ("REJECTED" in err) == (tol == "1e-10"), (rejected, err)
+        out = []
+        for trans, M in (("N", Bm), ("T", Bm.T)):
+            r = M @ xt
+            x = ctx.solve_dense(r, trans)
+            out.append(float(np.abs(M @ x - r).max() / np.abs(r).max()))
+        res[tol] = out
+        ctx.close()
+    assert max(res["1e-10"]) <= 1e-9, res
+    assert max(res["1e300"]) >= 1e-6, res          # the unguarded inverse really is that bad on this block
+
+
+def test_guard_that_rejects_everything_equals_no_blocks(kkt, monkeypatch):
+    """IPXK_INVERSE_TOL=0 rejects every inverted block: the operator must then be, bit for bit, the one built with
+    the blocks switched off (IPXK_TAIL_INVERSE=0, IPXK_HEAD_INVERSE=0) -- the fall-back leaves nothing behind."""
+    m, n = 60000, 125000
+    B, st, colscale = basis_problem(m, n, seed=23)
+    rhs = np.random.default_rng(9).standard_normal(m)
+    monkeypatch.setenv("IPXK_TAIL_MIN_DIM", "1000")
+    out = []
+    for env in ({"IPXK_INVERSE_TOL": "0"}, {"IPXK_TAIL_INVERSE": "0", "IPXK_HEAD_INVERSE": "0"}):
+        for k in ("IPXK_INVERSE_TOL", "IPXK_TAIL_INVERSE", "IPXK_HEAD_INVERSE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = kkt.KktContext(B["A"])
+        ctx.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
+        out.append((ctx.solve_dense(rhs, "N"), ctx.solve_dense(rhs, "T"), ctx.split_apply(rhs)[0], ctx.split_inverse_stats()))
+        ctx.close()
+    assert out[0][3][1] == out[0][3][0] >= 3 and out[1][3][0] == 0          # all probed blocks rejected / no block built
+    for k in range(3):
+        assert np.array_equal(out[0][k], out[1][k]), k
+
+
 def test_inverted_blocks_on_chains_of_tiny_levels(kkt, po, oracle, monkeypatch, capfd):
     """a block must start and end with a chunk: factors whose levels hold one or two unknowns each (a bidiagonal L
     under a banded U: long stretches of MERGED chunks) with the blocks forced on -- Prepare must not trip over a block
