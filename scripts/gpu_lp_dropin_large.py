@@ -12,4 +12,4 @@ for exe in (T.HIP_BIN, T.REF_BIN):
     t0 = time.time()
     info, _, out = T.run(exe, d + "/in", d + "/out_" + os.path.basename(exe), timeout=1100)
     print(out.strip().splitlines()[0] if out.strip() else "")
-    print(os.path.basename(exe), "wall %.1f s" % (time.time() - t0), {k: info[k] for k in ("status_ipm", "iter", "kktiter1", "kktiter2", "updates_ipm", "pobjval", "time_ipm1", "time_ipm2", "time_starting_basis", "time_kkt_factorize", "time_kkt_solve", "time_maxvol", "time_cr2", "lu_factorizations", "lu_max_bump", "lu_device_seconds")}, flush=True)
+    print(os.path.basename(exe), "wall %.1f s" % (time.time() - t0), {k: info[k] for k in ("status_ipm", "iter", "kktiter1", "kktiter2", "updates_ipm", "pobjval", "time_ipm1", "time_ipm2", "time_starting_basis", "time_kkt_factorize", "time_kkt_solve", "time_maxvol", "time_cr2", "lu_factorizations", "lu_max_bump", "lu_device_seconds") + (("device_maxvolume_calls", "cpu_maxvolume_calls") if "device_maxvolume_calls" in info else ())}, flush=True)

@@ -30,6 +30,8 @@ extern "C" double dropin_lu_seconds();
 #include "hip_device.h"
 extern "C" double ipx_hip_cpu_prepare_seconds();
 extern "C" long ipx_hip_cpu_prepare_calls();
+extern "C" long ipx_hip_device_maxvolume_calls();
+extern "C" long ipx_hip_cpu_maxvolume_calls();
 #endif
 
 template <class T>
@@ -117,6 +119,8 @@ int main(int argc, char** argv) {
     f << "cpu_prepare_seconds " << ipx_hip_cpu_prepare_seconds() << '\n';
     f << "cpu_prepare_calls " << ipx_hip_cpu_prepare_calls() << '\n';
     // one device model per Model: the three solver objects of LpSolver::Solve share one context (hip_device.h)
+    f << "device_maxvolume_calls " << ipx_hip_device_maxvolume_calls() << '\n';
+    f << "cpu_maxvolume_calls " << ipx_hip_cpu_maxvolume_calls() << '\n';
     f << "hip_model_creations " << ipx::HipModel::creations() << '\n';
     f << "hip_model_hits " << ipx::HipModel::hits() << '\n';
 #endif

@@ -1,7 +1,9 @@
 """GPU: the device LU factorization (ipxk_lu_factorize*) through the C ABI
   * against the CPU restatement: permutations, patterns and dependent columns bit-exact, values bit-exact
     (the singleton part divides original entries by pivots; the dense bump applies its updates one pivot at a
-    time in the restatement's order);
+    time in the restatement's order) -- for bumps of more than 1024 rows with IPXK_LU_MFMA_MIN=0: by default their
+    trailing updates run on the matrix cores (v_mfma_f64_16x16x4_f64, fused accumulation), and the factors are
+    held to the contract, the same pivots and 1e-11 against the restatement's values instead;
   * against the contract B[rowperm,colperm] = (L+I)U (src/lu_factorization.h:21-58);
   * under the reference's own objects: LuFactorization::Factorize's stability estimate and ForrestTomlin
     (oracle/_ref, where built);
@@ -45,16 +47,31 @@ BIG = [dict(dim=20000, bump=600, offdiag=3), dict(dim=5000, bump=97, window=4, f
 
 
 @pytest.mark.parametrize("kw", CASES + BIG, ids=[str(i) for i in range(len(CASES) + len(BIG))])
-def test_lu_vs_oracle_and_contract(ctx, oracle, kw):
+def test_lu_vs_oracle_and_contract(ctx, oracle, kw, monkeypatch):
     G = synth.lp_like_basis_matrix(seed=3, **kw)
     dim = G["dim"]
-    F = ctx.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
     Fo = oracle.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
-    assert (F["col_singletons"], F["row_singletons"], F["bump"], F["num_dependent"]) == \
-        (Fo["info"]["col_singletons"], Fo["info"]["row_singletons"], Fo["info"]["bump"], Fo["info"]["dependent"])
-    assert F["bump"] == kw["bump"]
-    same_factors(F, Fo)
-    assert check_contract(G, F) < 1e-12
+    mfma = kw["bump"] > 1024           # the trailing updates of such a bump run on the matrix cores by default
+    for mfma_min in (("0", None) if mfma else (None,)):
+        if mfma_min is None:
+            monkeypatch.delenv("IPXK_LU_MFMA_MIN", raising=False)
+        else:
+            monkeypatch.setenv("IPXK_LU_MFMA_MIN", mfma_min)
+        F = ctx.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
+        assert (F["col_singletons"], F["row_singletons"], F["bump"], F["num_dependent"]) == \
+            (Fo["info"]["col_singletons"], Fo["info"]["row_singletons"], Fo["info"]["bump"], Fo["info"]["dependent"])
+        assert F["bump"] == kw["bump"]
+        if mfma and mfma_min is None:
+            # fused accumulation: same pivots, values to rounding (entries that cancel exactly in one arithmetic need not in the other)
+            for key in ("rowperm", "colperm", "dependent"):
+                assert np.array_equal(F[key], Fo[key]), key
+            for key in ("L", "U"):
+                a = sp.csc_matrix((F[key].x, F[key].i, F[key].p), shape=(dim, dim))
+                b = sp.csc_matrix((Fo[key].x, Fo[key].i, Fo[key].p), shape=(dim, dim))
+                assert abs(a - b).max() <= 1e-11 * max(1.0, abs(b).max()), key
+        else:
+            same_factors(F, Fo)
+        assert check_contract(G, F) < 1e-12
 
 
 def test_lu_torn_bump_vs_oracle(kkt, oracle, monkeypatch):
