@@ -19,7 +19,6 @@ Context::~Context() {
     if (lu) destroy_lu(lu);
     if (maxvol) destroy_maxvol(maxvol);
     if (nmat) destroy_nmatrix(nmat);
-    blas_destroy(this);
     comm_destroy(this);
     if (h_state) (void)hipHostFree(h_state);
     if (h_cycle_done) (void)hipHostFree(h_cycle_done);

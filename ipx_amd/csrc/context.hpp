@@ -114,7 +114,7 @@ struct Context {
     SplitOperator* split = nullptr;
     PrepareHost* prepare_host = nullptr;   // host workspaces of split_prepare (trisolve.hip)
     LuState* lu = nullptr;                 // factors of the last ipxk_lu_factorize* (lu.hip)
-    void* blas_handle = nullptr;           // rocBLAS handle, created when a large dense block is first inverted (dense_blas.hip)
+    DevBuf<double> dense_work;             // workspace of the dense block inverse (dense_inverse.hip), grow-only
     MaxvolState* maxvol = nullptr;         // workspaces of ipxk_maxvolume (maxvolume.hip)
     NMatrix* nmat = nullptr;               // N of the split operator as a matrix of its own (nmatrix.hip)
 
@@ -155,6 +155,9 @@ bool device_build_sorted(LayoutScratch& S, SortedMatrix& out, const SlicedMatrix
 int acc_rows_per_block(int nrows, int ns);
 bool device_build_acc(LayoutScratch& S, AccMatrix& out, const SlicedMatrix& sliced, int nrows, int ncols, int64_t nnz, const int* dptr,
                       const int* didx, const double* dval, hipStream_t s);
+
+// dense_inverse.hip
+void dense_lu_inverse(Context* c, int kb, const double* D, const double* invL, const double* invU, double* X, double* Xt);
 
 enum TimeKind { kTimeOp = 0, kTimePrecond = 1, kTimeB = 2, kTimeBt = 3, kNumTimeKinds = 4 };
 void time_mark(Context* c, int kind, bool begin);      // no-op unless timing is active
@@ -243,9 +246,6 @@ CrResult kkt_basis_solve_dev(Context* c, const double* a, const double* b, doubl
                              void* user, ipxk_times* times);
 void split_levels(const Context* c, ipxint levels[4]);
 void check_sweep_abort(Context* c);
-// inverse of a dense LU-factored block by two rocblas_dtrsm (dense_blas.hip); false: rocBLAS unavailable, nothing launched
-bool blas_lu_inverse(Context* c, int kb, const double* D, double* X, double* Xt);
-void blas_destroy(Context* c);
 void destroy_split(SplitOperator*);
 void destroy_prepare_host(PrepareHost*);
 

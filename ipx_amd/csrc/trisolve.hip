@@ -601,11 +601,17 @@ __global__ __launch_bounds__(kBlock) void block_gemv_kernel(int K, const double*
 // IPX's late bases are ill conditioned by construction (that is why src/basis.cc:130-152 has a stability loop and
 // src/lu_factorization.cc:87-127 a residual test): substitution with a triangular factor is backward stable whatever
 // its condition, a product with its computed INVERSE is not (error ~ cond * eps).  So every inverse computed at
-// Prepare is probed with two fixed vectors z:  || T (M z) - z ||_inf / || z ||_inf  must not exceed kInverseTol
-// (IPXK_INVERSE_TOL, default 1e-10); a block that fails keeps its level-scheduled / blocked solve.
-static double inverse_tol() {           // (read per Prepare: the tests switch it)
+// Prepare is probed with two fixed vectors z:  || T (M z) - z ||_inf / || z ||_inf  must not exceed the tolerance
+// (IPXK_INVERSE_TOL; default 1e-10 for the inverted levels of a sweep, 1e-8 for a dense block); a block that fails keeps its
+// level-scheduled / blocked solve.
+// Dense blocks of the factors (hundreds to thousands of rows of a dense LU) get 1e-8: || D X - I || of a computed inverse is
+// ~ cond(D) * eps whoever computes it -- measured on well conditioned 1024 / 2048 / 4096 / 8000-row blocks: 9e-12 / 2e-10 /
+// 8e-10 / 2e-9 by recursive doubling on the matrix cores, 3e-12 / 8e-11 / 1e-10 by one substitution per column (what a
+// dtrsm does) -- and an inverse that good perturbs the solves far below every tolerance the IPM asks of a KKT solve
+// (0.3 * sqrt(mu), src/ipm.cc:572); the catastrophes the guard is there for are orders of magnitude above it.
+static double inverse_tol(bool dense_block = false) {           // (read per Prepare: the tests switch it)
     const char* e = getenv("IPXK_INVERSE_TOL");
-    return e ? atof(e) : 1e-10;
+    return e ? atof(e) : dense_block ? 1e-8 : 1e-10;
 }
 __device__ __forceinline__ double probe_z(int q, int l) {       // entries in [0.5, 1.5], two unrelated sign patterns
     const unsigned h = (unsigned)l * 2654435761u + (unsigned)q * 40503u;
@@ -1301,11 +1307,13 @@ static DeviceFactors cut_dense_block(Context* c, SplitOperator* S, const DeviceF
     S->bump_explicit = inverse_min > 0 && kb >= inverse_min && kb <= inverse_max;
     if (S->bump_explicit) {
         S->bump_inv.ensure((size_t)kb * kb); S->bump_invT.ensure((size_t)kb * kb); S->bump_x.ensure((size_t)kb);
-        // blocks of 1024 rows and more through rocBLAS where it can be loaded (two dtrsm on the identity: 0.5 / 4.8 / 28 ms at
-        // 1024 / 4096 / 8000 rows against 2 / 134 / 1000 ms for the kernel below; dense_blas.hip)
-        const char* blas_env = getenv("IPXK_ROCBLAS_MIN");          // (read per Prepare: the tests switch it)
-        const int blas_min = blas_env ? atoi(blas_env) : 1024;
-        const bool by_blas = kb >= blas_min && blas_lu_inverse(c, kb, S->bumpD.get(), S->bump_invT.get(), S->bump_inv.get());
+        // blocks of IPXK_DENSE_INVERSE_MIN rows and more (default: all of them) on the matrix cores (dense_inverse.hip: triangular
+        // inverses by recursive doubling + one product, v_mfma_f64_16x16x4_f64); below, or with IPXK_DENSE_INVERSE_MIN=0, the
+        // older kernel: one blocked solve per column of the identity
+        const char* di_env = getenv("IPXK_DENSE_INVERSE_MIN");          // (read per Prepare: the tests switch it)
+        const int di_min = di_env ? atoi(di_env) : 1;
+        const bool by_blas = di_min > 0 && kb >= di_min;
+        if (by_blas) dense_lu_inverse(c, kb, S->bumpD.get(), S->bump_invL.get(), S->bump_invU.get(), S->bump_invT.get(), S->bump_inv.get());
         allow_bump_lds((size_t)(kb + 64) * sizeof(double));
         if (!by_blas) hipLaunchKernelGGL(bump_inverse_kernel, dim3(kb), dim3(kBumpThreads), (size_t)(kb + 64) * sizeof(double), s, kb, S->bumpD.get(),
                            S->bump_invL.get(), S->bump_invU.get(), S->bump_inv.get(), S->bump_invT.get());
@@ -1322,9 +1330,9 @@ static DeviceFactors cut_dense_block(Context* c, SplitOperator* S, const DeviceF
         const double resid = std::max(h[0], h[1]);
         c->split_stats.inverse_probes++;
         c->split_stats.worst_probe = std::max(c->split_stats.worst_probe, resid);
-        if (!(resid <= inverse_tol())) { S->bump_explicit = false; c->split_stats.inverse_rejected++; }
+        if (!(resid <= inverse_tol(true))) { S->bump_explicit = false; c->split_stats.inverse_rejected++; }
         if (getenv("IPXK_VERBOSE") || getenv("IPXK_SWEEP_STATS"))
-            fprintf(stderr, "ipxk: dense block of %d rows inverted (%s); probe |D (inverse z) - z| = %.2e%s\n", kb, by_blas ? "rocBLAS dtrsm" : "own kernel",
+            fprintf(stderr, "ipxk: dense block of %d rows inverted (%s); probe |D (inverse z) - z| = %.2e%s\n", kb, by_blas ? "recursive doubling on the matrix cores" : "one blocked solve per column",
                     resid, S->bump_explicit ? "" : " -> REJECTED, the blocked solve stays");
     }
     IPXK_HIP(hipStreamSynchronize(s));               // cnt / start go out of scope; ends
