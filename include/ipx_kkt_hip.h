@@ -201,7 +201,11 @@ int ipxk_kkt_diag_get(const ipxk_context* ctx, double* W, double* resscale);
  * Basis::GetLuFactors (src/basis.cc:162-166) is explicit: L (strictly lower,
  * no diagonal), U (upper, diagonal last in each column), rowperm, colperm with
  * B[rowperm,colperm] = (L+I)*U (src/lu_update.h:43-60); basis[p] = variable at
- * position p; status[n+m] in IPXK_*; colscale[n+m]. */
+ * position p; status[n+m] in IPXK_*; colscale[n+m].  Row indices inside a column
+ * may come in any order as long as U's diagonal is last; a dense trailing block of
+ * the factors is cut out of the sweeps (and applied as a blocked solve or an
+ * explicit inverse) only when the columns of U that cross it are sorted, as
+ * GetLuFactors returns them. */
 int ipxk_split_prepare(ipxk_context* ctx, const ipxint* Lp, const ipxint* Li,
                        const double* Lx, const ipxint* Up, const ipxint* Ui,
                        const double* Ux, const ipxint* rowperm,

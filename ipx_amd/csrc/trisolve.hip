@@ -1406,7 +1406,15 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
         const int bump_min = getenv("IPXK_BUMP_MIN") ? atoi(getenv("IPXK_BUMP_MIN")) : kBumpMin;
         const int s0 = m > 0 ? trailing_dense_block(m, Lp) : m;
         CutBuffers cut(S.get());
-        if (m - s0 >= bump_min && m - s0 <= 8192 && !(dense_env && dense_env[0] == '0')) {
+        // the cut takes the entries of a U column above the block as a PREFIX of the column and the block's own as its last
+        // entries: that needs ascending row indices inside the columns from s0 on.  The contract of ipxk_split_prepare asks
+        // for the diagonal last only (the reference's GetLuFactors does return sorted columns); unsorted ones keep the whole
+        // factors in the sweeps.
+        bool sorted_U = true;
+        for (int j = s0; j < m && sorted_U; j++)
+            for (ipxint p = Up[j] + 1; p < Up[j + 1]; p++)
+                if (Ui[p] <= Ui[p - 1]) { sorted_U = false; break; }
+        if (sorted_U && m - s0 >= bump_min && m - s0 <= 8192 && !(dense_env && dense_env[0] == '0')) {
             const DeviceFactors F = cut_dense_block(c, S.get(), F0, s0, m - s0, cut);
             analyse_sweeps_resident(c, S.get(), F, nullptr, nullptr, nullptr, nullptr);
         } else {
