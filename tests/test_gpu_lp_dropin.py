@@ -8,8 +8,8 @@ drives ipx::KKTSolverDiagHip and ipx::KKTSolverBasisHip on the MI355X.  In both 
 ipx::Basis is computed by ipx::LuKernelHip (BASICLU is not in the image; tests/dropin/basiclu_absent.cc), so the
 two runs differ in the KKT solver classes only.
 
-What is compared: status_ipm / status_crossover, the number of IPM iterations, kktiter2 (CR iterations of the main
-phase) within 2 %, the objectives, the number of basis updates.  The small cases restate the models and the
+What is compared: status_ipm / status_crossover, the objectives, the number of IPM iterations (within one), kktiter2
+(CR iterations of the main phase, within 8 %), the number of basis updates (within 2 %): compare_runs.  The small cases restate the models and the
 expected statuses of the reference's own end-to-end tests (check/solver.cc:153-251: 0-, 1- and 2-row models,
 switchiter = 0 straight into the basis phase, with and without dualization) -- data and expectations, not code.
 """
@@ -78,24 +78,24 @@ def close(a, b, rel):
     return abs(a - b) <= rel * (1.0 + max(abs(a), abs(b)))
 
 
-def compare_runs(ref, hip, obj_tol=1e-8, kkt_rel=0.15, upd_rel=0.05):
-    """The two runs take the same path through the reference's IPM: identical statuses, IPM iteration counts within
-    max(2, 10 %) (equal in three of the four synthetic cases; in the update_heuristic = 0 case the count hinges on
-    rounding: reference 22, Hip 22 with the bump left in the sweeps, 21 with the bump solved between the sweeps,
-    24 with its explicit inverse -- same optimal value to 12 digits every time), objectives to 1e-8.  The CR iteration counts and the number of basis updates are NOT expected to be
-    equal: every KKT solve stops at the reference's tolerance 0.3 sqrt(mu) (src/ipm.cc:572), the two
-    implementations' solutions differ at that level, so from the second IPM iteration on the iterates differ in
-    the 6th-9th digit and Maxvolume's threshold decisions flip for borderline columns (measured on the MI355X:
-    kktiter2 583 / 595, 2023 / 2032, 676 / 663, 821 / 772; updates_ipm 419 / 410, 1893 / 1962, 1170 / 1174,
-    1480 / 1485; with the dense blocks inverted by rocBLAS the dualized case takes 736 against 821).  Bounds: 15 % on
-    kktiter2, 5 % on the updates."""
+def compare_runs(ref, hip, obj_tol=1e-8, kkt_rel=0.08, upd_rel=0.02):
+    """The two runs take the same path through the reference's IPM: identical statuses, objectives to 1e-8, IPM
+    iteration counts within ONE, CR iterations of the main phase (kktiter2) within 8 %, basis updates within 2 %.
+    Why not equal: every KKT solve stops at the reference's tolerance 0.3 sqrt(mu) (src/ipm.cc:572) and the two
+    implementations' solutions differ at that level, so from the second IPM iteration on the iterates differ in the
+    6th-9th digit, Maxvolume's threshold decisions flip for borderline columns, and the termination test
+    (src/iterate.cc:221-249) is met one iteration earlier or later.  Measured on the MI355X in round 4 (Maxvolume on
+    the device, dense blocks inverted on the matrix cores -- nothing in a run depends on an optional library any
+    more), reference / Hip: IPM iterations 22 / 21, 24 / 23, 22 / 23, 20 / 20; kktiter2 589 / 573 (2.7 %), 2072 / 1992
+    (3.9 %), 679 / 653 (3.8 %), 808 / 753 (6.8 %: the dualized case, whose bases carry 1485-row dense blocks);
+    updates_ipm 418 / 420, 1882 / 1892, 1172 / 1165, 1495 / 1478 (1.1 %).  (Round 3 allowed 15 % / 10 % / 5 %.)"""
     ri, ra, rout = ref
     hi, ha, hout = hip
     msg = "\nREF: " + rout + "\nHIP: " + hout
     for k in ("status", "status_ipm", "status_crossover", "errflag", "dualized", "dependent_rows", "dependent_cols",
               "rows_inconsistent", "cols_inconsistent"):
         assert ri[k] == hi[k], (k, ri[k], hi[k], msg)
-    assert abs(ri["iter"] - hi["iter"]) <= max(2.0, 0.1 * ri["iter"]), msg
+    assert abs(ri["iter"] - hi["iter"]) <= 1, msg
     per_iter = ri["kktiter2"] / max(ri["iter"], 1.0)            # the extra / missing IPM iterations carry their own solves
     assert abs(ri["kktiter2"] - hi["kktiter2"]) <= max(2.0 * max(ri["iter"], 1), kkt_rel * ri["kktiter2"]) \
         + 2.0 * per_iter * abs(ri["iter"] - hi["iter"]), msg
@@ -250,20 +250,24 @@ def test_afiro_through_both_solvers(tmp_path):
 ])
 def test_synthetic_lp_through_both_solvers(tmp_path, m, n, seed, params):
     """IPM::Driver over KKTSolverBasisHip (and the initial phase over KKTSolverDiagHip) against the same driver over
-    the reference's classes: same statuses and IPM iteration count, kktiter2 within 2 %, objectives 1e-8, the same
-    number of basis updates (Maxvolume, DropPrimal / DropDual take the same decisions)"""
+    the reference's classes: same statuses, objectives 1e-8, IPM iteration counts within one, kktiter2 within 8 %, basis
+    updates within 2 % (compare_runs says why they are not equal).  KKTSolverBasisHip::_Factorize runs DropPrimal /
+    DropDual on the reference's Basis and Maxvolume on the device (every Factorize of these runs: device_maxvolume_calls
+    > 0, cpu_maxvolume_calls == 0), and the three solver objects of the run share one device model."""
     _need_bins()
     ref, hip = both(tmp_path, "lp", *general_lp(m, n, seed), crossover=1, **params)
     compare_runs(ref, hip)
     hi = hip[0]
     assert hi["status_ipm"] == IPX_STATUS_optimal, hip[2]
     assert hi["kktiter2"] > 0 and hi["lu_factorizations"] > 0
+    assert hi["device_maxvolume_calls"] > 0 and hi["cpu_maxvolume_calls"] == 0, hi
+    assert hi["hip_model_creations"] == 1 and hi["hip_model_hits"] >= 1, hi        # one device model per Model (hip_device.h)
     print("ref:", ref[2], "hip:", hip[2])
     print("time_ipm2 ref %.3f hip %.3f; cr2 ref %.3f hip %.3f; factorize ref %.3f hip %.3f; LU on device %.3f s in %d calls, largest bump %d"
           % (ref[0]["time_ipm2"], hi["time_ipm2"], ref[0]["time_cr2"], hi["time_cr2"], ref[0]["time_kkt_factorize"],
              hi["time_kkt_factorize"], hi["lu_device_seconds"], hi["lu_factorizations"], hi["lu_max_bump"]))
-    print("the reference's CPU SplittedNormalMatrix::Prepare that KKTSolverBasis::_Factorize runs and KKTSolverBasisHip discards: "
-          "%.2f ms per IPM iteration (%d calls)" % (1e3 * hi["cpu_prepare_seconds"] / max(hi["cpu_prepare_calls"], 1), hi["cpu_prepare_calls"]))
+    print("Maxvolume: %d Factorize calls on the device, %d on the reference's Basis; device models created %d, reused %d"
+          % (hi["device_maxvolume_calls"], hi["cpu_maxvolume_calls"], hi["hip_model_creations"], hi["hip_model_hits"]))
 
 
 @pytest.mark.gpu
