@@ -51,6 +51,14 @@ __global__ void nm_colof_kernel(int n, const int* __restrict__ keep, const int* 
         newidx_or_minus[j] = keep[j] ? newidx[j] : -1;
     }
 }
+// # columns whose kept flag differs from the previous build's (the exact test behind the fingerprint)
+__global__ void nm_diff_kernel(int n, const int* __restrict__ keep, const int* __restrict__ keep_prev, int* out) {
+    int d = 0;
+    IPXK_GS(j, n) d += keep[j] != keep_prev[j] ? 1 : 0;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) d += __shfl_xor(d, s, 64);
+    if ((threadIdx.x & 63) == 0 && d) atomicAdd(out, d);
+}
 // a 64-bit fingerprint of the kept set (order-independent sum of a hash of the kept indices)
 __global__ void nm_hash_kernel(int n, const int* __restrict__ keep, u64* out) {
     u64 h = 0;
@@ -147,7 +155,7 @@ struct NMatrix {
     int nN = 0;
     u64 kept_hash = 0;
     SlicedMatrix P1, P2;
-    DevBuf<int> keep, len, newidx, off, colof, cnt32, counters;
+    DevBuf<int> keep, keep_built, len, newidx, off, colof, cnt32, counters;     // keep_built: the kept flags N was built for
     DevBuf<u64> keys, keys2, hash;
     DevBuf<double> wN, tN;
     Tmp T;
@@ -216,7 +224,18 @@ bool nmatrix_prepare(Context* c, const double* W) {
     u64 hsh = 0;
     IPXK_HIP(hipMemcpyAsync(&hsh, N.hash.get(), sizeof hsh, hipMemcpyDeviceToHost, s));
     IPXK_HIP(hipStreamSynchronize(s));
-    if (!(N.valid && hsh == N.kept_hash)) {
+    // the structure is reused only for EXACTLY the same set of columns: the fingerprint is a fast reject, the flags
+    // of the build decide (a colliding fingerprint must not bring back the N of another basis)
+    bool same = N.valid && hsh == N.kept_hash && N.keep_built.size() >= (size_t)n;
+    if (same) {
+        IPXK_HIP(hipMemsetAsync(N.counters.get(), 0, sizeof(int), s));
+        hipLaunchKernelGGL(nm_diff_kernel, dim3(gridn(n)), dim3(kBlock), 0, s, n, N.keep.get(), N.keep_built.get(), N.counters.get());
+        int diff = 1;
+        IPXK_HIP(hipMemcpyAsync(&diff, N.counters.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        same = diff == 0;
+    }
+    if (!same) {
         N.valid = false;
         // numbering of the kept columns and their entry offsets
         scan_int(N.T, N.keep.get(), N.newidx.get(), (size_t)n, s);
@@ -257,6 +276,8 @@ bool nmatrix_prepare(Context* c, const double* W) {
         if (!ok) return false;
         N.wN.ensure((size_t)nN); N.tN.ensure((size_t)nN);
         N.kept_hash = hsh;
+        N.keep_built.ensure((size_t)n);
+        IPXK_HIP(hipMemcpyAsync(N.keep_built.get(), N.keep.get(), (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, s));
         N.valid = true;
         if (getenv("IPXK_VERBOSE"))
             fprintf(stderr, "ipxk: N built on the device: %d of %d structural columns, %lld entries; N'u tiles %d x %d (rows %d), N t tiles %d x %d (rows %d)\n",

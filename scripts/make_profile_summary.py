@@ -9,12 +9,12 @@ rows = list(csv.DictReader(open(one(trace_dir, "kernel_trace.csv"))))
 dur = collections.defaultdict(list)
 for r in rows:
     dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-lines = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-banded --no-basis --no-newton   (MI355X)",
+lines = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-banded --no-basis --no-newton --no-other-configs --no-lu --no-maxvolume --no-dropin   (MI355X)",
          "# avg over ALL calls includes the early-exit no-op launches after CR termination; 'working' = duration > 20 us",
          "# for the SpMV kernels (launches that did work)",
          "kernel,calls,total_ms,avg_us_all,calls_working,avg_us_working,median_us_working"]
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-    thr = 20000 if ("spmv_phased" in k or "sliced_tile" in k or "sorted_tile" in k) else (8000 if "sliced_combine" in k else 0)
+    thr = 20000 if ("spmv_phased" in k or "sliced_tile" in k or "sorted_tile" in k or "acc_tile" in k) else (8000 if "sliced_combine" in k else 0)
     w = [x for x in v if x > thr]
     lines.append('"%s",%d,%.3f,%.2f,%d,%.2f,%.2f' % (k.replace('"', "'"), len(v), sum(v) / 1e6, sum(v) / len(v) / 1e3, len(w),
                                                 (sum(w) / len(w) / 1e3 if w else 0), (statistics.median(w) / 1e3 if w else 0)))
@@ -45,7 +45,8 @@ for k in apply_kernels:
     total += (2 * f + wv) * 1024
     total_us += us
     rows_txt.append("%s,%.1f,%.0f,%.1f,%.0f,%.1f" % (short(k).replace(",", ""), us, f, 2 * f * 1024 / 1e6, wv, wv * 1024 / 1e6))
-layouts = ["sorted" if any("sorted_tile" in k and e in k for k in apply_kernels) else
+layouts = ["acc" if any("acc_tile" in k and e in k for k in apply_kernels) else
+           "sorted" if any("sorted_tile" in k and e in k for k in apply_kernels) else
            "sliced" if any("sliced" in k and e in k for k in apply_kernels) else "phased" for e in ("EpiScale", "EpiNormalRows")]
 txt = """# L2<->fabric traffic of the NormalMatrix apply (C3: m=1M, n=2M, nnz=16M), MI355X, %s
 # separate passes:  rocprofv3 --pmc FETCH_SIZE -- python3 bench.py ...   and   rocprofv3 --pmc WRITE_SIZE -- ...
