@@ -132,6 +132,38 @@ __global__ void nm_weights_kernel(int nN, const int* __restrict__ colof, const d
     IPXK_GS(c, nN) wN[c] = W[colof[c]];
 }
 
+// ---- N in plain compact form (for the accumulated-tiles layout, layout_device.hip) ----
+// N' by row (= kept column c of A): ptr1[c] = off[colof[c]], entries copied in storage order
+__global__ void nm_csr1_kernel(int nN, int64_t nzN, const int* __restrict__ colof, const int* __restrict__ off, const int* __restrict__ Ap,
+                               const int* __restrict__ Ai, const double* __restrict__ Ax, int* __restrict__ ptr, int* __restrict__ idx,
+                               double* __restrict__ val) {
+    IPXK_GS(c, nN) {
+        const int j = colof[c], o = off[j];
+        ptr[c] = o;
+        for (int p = Ap[j], q = o; p < Ap[j + 1]; p++, q++) { idx[q] = Ai[p]; val[q] = Ax[p]; }
+        if (c == nN - 1) ptr[nN] = (int)nzN;
+    }
+}
+// N by row of A: the entries whose column is kept, compact column index
+__global__ void nm_csr2_count_kernel(int m, const int* __restrict__ Tp, const int* __restrict__ Ti, const int* __restrict__ newidx, int* __restrict__ cnt) {
+    IPXK_GS(i, m) {
+        int k = 0;
+        for (int q = Tp[i]; q < Tp[i + 1]; q++) k += newidx[Ti[q]] >= 0 ? 1 : 0;
+        cnt[i] = k;
+    }
+}
+__global__ void nm_csr2_fill_kernel(int m, int64_t nzN, const int* __restrict__ Tp, const int* __restrict__ Ti, const double* __restrict__ Tx,
+                                    const int* __restrict__ newidx, int* __restrict__ ptr, int* __restrict__ idx, double* __restrict__ val) {
+    IPXK_GS(i, m) {
+        int o = ptr[i];
+        for (int q = Tp[i]; q < Tp[i + 1]; q++) {
+            const int c = newidx[Ti[q]];
+            if (c >= 0) { idx[o] = c; val[o] = Tx[q]; o++; }
+        }
+        if (i == m - 1) ptr[m] = (int)nzN;
+    }
+}
+
 struct Tmp {
     DevBuf<unsigned char> bytes;
     void* need(size_t n) { if (bytes.size() < n) bytes.resize(n); return bytes.get(); }
@@ -155,6 +187,9 @@ struct NMatrix {
     int nN = 0;
     u64 kept_hash = 0;
     SlicedMatrix P1, P2;
+    AccMatrix A1, A2;                  // the same two gather matrices as accumulated tiles (used when built)
+    DevBuf<int> cptr, cidx;            // scratch: N in plain compact form
+    DevBuf<double> cval;
     DevBuf<int> keep, keep_built, len, newidx, off, colof, cnt32, counters;     // keep_built: the kept flags N was built for
     DevBuf<u64> keys, keys2, hash;
     DevBuf<double> wN, tN;
@@ -274,6 +309,24 @@ bool nmatrix_prepare(Context* c, const double* W) {
             ok = finish_layout(N, N.P2, m, R, ns2, nzN, N.keys2.get(), c->pl_Ti.get(), c->pl_Tx.get(), N.newidx.get(), s);
         }
         if (!ok) return false;
+        // the accumulated-tiles form of both (IPXK_SPMV_ACC=0: the sliced tiles stay)
+        N.A1 = AccMatrix(); N.A2 = AccMatrix();
+        if (!(getenv("IPXK_SPMV_ACC") && getenv("IPXK_SPMV_ACC")[0] == '0') && ns1 > 1 && ns2 > 1) {
+            std::unique_ptr<LayoutScratch, void (*)(LayoutScratch*)> LS(new_layout_scratch(), free_layout_scratch);
+            const size_t nzn = (size_t)nzN;
+            N.cptr.ensure((size_t)std::max(nN, m) + 1); N.cidx.ensure(nzn); N.cval.ensure(nzn);
+            hipLaunchKernelGGL(nm_csr1_kernel, dim3(gridn(nN)), dim3(kBlock), 0, s, nN, nzN, N.colof.get(), N.off.get(), c->pl_Ap.get(), c->pl_Ai.get(),
+                               c->pl_Ax.get(), N.cptr.get(), N.cidx.get(), N.cval.get());
+            AccMatrix a1, a2;
+            const bool ok1 = device_build_acc(*LS, a1, N.P1, nN, m, nzN, N.cptr.get(), N.cidx.get(), N.cval.get(), s);
+            N.cnt32.ensure((size_t)m + 1);
+            hipLaunchKernelGGL(nm_csr2_count_kernel, dim3(gridn(m)), dim3(kBlock), 0, s, m, c->pl_Tp.get(), c->pl_Ti.get(), N.newidx.get(), N.cnt32.get());
+            scan_int(N.T, N.cnt32.get(), N.cptr.get(), (size_t)m, s);
+            hipLaunchKernelGGL(nm_csr2_fill_kernel, dim3(gridn(m)), dim3(kBlock), 0, s, m, nzN, c->pl_Tp.get(), c->pl_Ti.get(), c->pl_Tx.get(),
+                               N.newidx.get(), N.cptr.get(), N.cidx.get(), N.cval.get());
+            const bool ok2 = device_build_acc(*LS, a2, N.P2, m, nN, nzN, N.cptr.get(), N.cidx.get(), N.cval.get(), s);
+            if (ok1 && ok2) { N.A1 = std::move(a1); N.A2 = std::move(a2); }
+        }
         N.wN.ensure((size_t)nN); N.tN.ensure((size_t)nN);
         N.kept_hash = hsh;
         N.keep_built.ensure((size_t)n);
@@ -309,13 +362,36 @@ static void launch_tiles(const SlicedMatrix& P, int nrows, const double* x, cons
     hipLaunchKernelGGL(spmv_sliced_combine_kernel<Epi>, dim3(cg), dim3(kBlock), 0, s, V, epi, (double*)nullptr, done);
 }
 
+template <class Epi>
+static void launch_acc(const AccMatrix& A, const SlicedMatrix& P, int nrows, const double* x, const Epi& epi, const int* done, hipStream_t s) {
+    AccView W;
+    W.nrows = nrows; W.nrows_pad = A.nrows_pad; W.nslices = A.nslices; W.nrb = A.nrb; W.RB = A.RB; W.slice_elems = A.slice_elems;
+    W.tile_batch = A.tile_batch.get(); W.bptr = A.bptr.get(); W.pack = A.pack.get(); W.val = A.val.get(); W.partial = A.partial.get();
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {
+        IPXK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spmv_acc_tile_kernel<Epi>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(kAccMaxRows * sizeof(double))));
+        lds_attr_set = true;
+    }
+    hipLaunchKernelGGL((spmv_acc_tile_kernel<Epi>), dim3(W.nrb * W.nslices), dim3(kAccThreads), (size_t)W.RB * sizeof(double), s, W, x, done);
+    SlicedView V = view_of(P, nrows);
+    V.nrows_pad = A.nrows_pad; V.partial = A.partial.get();
+    const int cg = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ((int64_t)nrows + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(spmv_sliced_combine_kernel<Epi>, dim3(cg), dim3(kBlock), 0, s, V, epi, (double*)nullptr, done);
+}
+
 // work = W_I .* u + N (W_N .* (N' u))        (AddNormalProduct on N, plus the slack columns of N: the identity part)
 void nmatrix_apply(Context* c, const double* WI, const double* u, double* work, const int* done) {
     NMatrix& N = *c->nmat;
     hipStream_t s = c->stream;
     EpiScale e1{{}, N.wN.get(), N.tN.get()};
-    launch_tiles(N.P1, N.nN, u, e1, done, s);
     EpiNormalRows e2{{}, WI, u, work};
+    if (N.A1.built && N.A2.built) {
+        launch_acc(N.A1, N.P1, N.nN, u, e1, done, s);
+        launch_acc(N.A2, N.P2, (int)c->m, N.tN.get(), e2, done, s);
+        return;
+    }
+    launch_tiles(N.P1, N.nN, u, e1, done, s);
     launch_tiles(N.P2, (int)c->m, N.tN.get(), e2, done, s);
 }
 

@@ -657,19 +657,40 @@ __global__ __launch_bounds__(kBlock) void bump_probe_mz_kernel(int kb, const dou
         if (lane == 0) { w[i] = s0; w[kb + i] = s1; }
     }
 }
-__global__ void bump_probe_u_kernel(int kb, const double* __restrict__ D, const double* __restrict__ w, double* __restrict__ t) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kb; i += gridDim.x * blockDim.x) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int l = i; l < kb; l++) { const double a = D[(size_t)l * kb + i]; s0 += a * w[l]; s1 += a * w[kb + l]; }
-        t[i] = s0; t[kb + i] = s1;
+// t = U22 w (upper part of D with the diagonal) and r = (L22 + I) t - z, D column major: a workgroup takes 64 rows and a
+// chunk of 256 columns (lanes along the rows: every load is a 512-byte segment of a column of D, 4 column groups per
+// workgroup), the chunks' partial sums are added in chunk order by the second kernel of each stage
+constexpr int kProbeChunk = 256;
+__global__ __launch_bounds__(kBlock) void bump_probe_partial_kernel(int kb, const double* __restrict__ D, const double* __restrict__ w, int upper,
+                                                                    double* __restrict__ part) {
+    __shared__ double red[2][4][64];
+    const int r = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int l0 = blockIdx.y * kProbeChunk, l1 = min(kb, l0 + kProbeChunk);
+    double s0 = 0.0, s1 = 0.0;
+    if (r < kb)
+        for (int l = l0 + g; l < l1; l += 4) {
+            const bool in = upper ? l >= r : l < r;            // U22: columns from the diagonal on; L22: strictly below it
+            if (in) { const double a = D[(size_t)l * kb + r]; s0 += a * w[l]; s1 += a * w[kb + l]; }
+        }
+    red[0][g][threadIdx.x & 63] = s0; red[1][g][threadIdx.x & 63] = s1;
+    __syncthreads();
+    if (g == 0 && r < kb) {
+        const int x = threadIdx.x;
+        part[((size_t)blockIdx.y * 2 + 0) * kb + r] = ((red[0][0][x] + red[0][1][x]) + red[0][2][x]) + red[0][3][x];
+        part[((size_t)blockIdx.y * 2 + 1) * kb + r] = ((red[1][0][x] + red[1][1][x]) + red[1][2][x]) + red[1][3][x];
     }
 }
-__global__ void bump_probe_l_kernel(int kb, const double* __restrict__ D, const double* __restrict__ t, double* res) {
+// stage 1 (res == nullptr): t = sum of the chunks;  stage 2: r = t + sum of the chunks - z, res[q] = max |r_q|
+__global__ void bump_probe_finish_kernel(int kb, int nchunks, const double* __restrict__ part, const double* __restrict__ tin,
+                                         double* __restrict__ tout, double* res) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kb; i += gridDim.x * blockDim.x) {
-        double s0 = t[i], s1 = t[kb + i];
-        for (int l = 0; l < i; l++) { const double a = D[(size_t)l * kb + i]; s0 += a * t[l]; s1 += a * t[kb + l]; }
-        probe_max(res + 0, fabs(s0 - probe_z(0, i)));
-        probe_max(res + 1, fabs(s1 - probe_z(1, i)));
+        double s0 = tin ? tin[i] : 0.0, s1 = tin ? tin[kb + i] : 0.0;
+        for (int c = 0; c < nchunks; c++) { s0 += part[((size_t)c * 2 + 0) * kb + i]; s1 += part[((size_t)c * 2 + 1) * kb + i]; }
+        if (tout) { tout[i] = s0; tout[kb + i] = s1; }
+        if (res) {
+            probe_max(res + 0, fabs(s0 - probe_z(0, i)));
+            probe_max(res + 1, fabs(s1 - probe_z(1, i)));
+        }
     }
 }
 // (z has entries of magnitude in [0.5, 1.5]: || z ||_inf is between 1 and 1.5 for any block of a few rows, the residuals are taken as they are)
@@ -1318,12 +1339,19 @@ static DeviceFactors cut_dense_block(Context* c, SplitOperator* S, const DeviceF
         if (!by_blas) hipLaunchKernelGGL(bump_inverse_kernel, dim3(kb), dim3(kBumpThreads), (size_t)(kb + 64) * sizeof(double), s, kb, S->bumpD.get(),
                            S->bump_invL.get(), S->bump_invU.get(), S->bump_inv.get(), S->bump_invT.get());
         // the guard (whoever computed the inverse): D22 (inverse z) against z; a block that fails keeps the blocked solve
-        S->bump_probe.ensure((size_t)4 * kb + 2);
+        const int nchunks = (kb + kProbeChunk - 1) / kProbeChunk;
+        S->bump_probe.ensure((size_t)4 * kb + 2 + (size_t)2 * nchunks * kb);
         double* pw = S->bump_probe.get();
+        double* part = pw + 4 * (size_t)kb + 2;
         IPXK_HIP(hipMemsetAsync(pw + 4 * (size_t)kb, 0, 2 * sizeof(double), s));
         hipLaunchKernelGGL(bump_probe_mz_kernel, dim3((kb + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, s, kb, S->bump_inv.get(), pw);
-        hipLaunchKernelGGL(bump_probe_u_kernel, dim3((kb + 63) / 64), dim3(64), 0, s, kb, S->bumpD.get(), pw, pw + 2 * (size_t)kb);
-        hipLaunchKernelGGL(bump_probe_l_kernel, dim3((kb + 63) / 64), dim3(64), 0, s, kb, S->bumpD.get(), pw + 2 * (size_t)kb, pw + 4 * (size_t)kb);
+        const dim3 pgrid((kb + 63) / 64, nchunks);
+        hipLaunchKernelGGL(bump_probe_partial_kernel, pgrid, dim3(kBlock), 0, s, kb, S->bumpD.get(), pw, 1, part);
+        hipLaunchKernelGGL(bump_probe_finish_kernel, dim3(vec_grid(kb)), dim3(kBlock), 0, s, kb, nchunks, part, (const double*)nullptr, pw + 2 * (size_t)kb,
+                           (double*)nullptr);
+        hipLaunchKernelGGL(bump_probe_partial_kernel, pgrid, dim3(kBlock), 0, s, kb, S->bumpD.get(), pw + 2 * (size_t)kb, 0, part);
+        hipLaunchKernelGGL(bump_probe_finish_kernel, dim3(vec_grid(kb)), dim3(kBlock), 0, s, kb, nchunks, part, pw + 2 * (size_t)kb, (double*)nullptr,
+                           pw + 4 * (size_t)kb);
         double h[2] = {0.0, 0.0};
         IPXK_HIP(hipMemcpyAsync(h, pw + 4 * (size_t)kb, sizeof h, hipMemcpyDeviceToHost, s));
         IPXK_HIP(hipStreamSynchronize(s));
