@@ -331,6 +331,14 @@ struct GatherMatrix {
     float tuned_us_acc = 0.f;
     void build_acc(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s);     // host builder (test reference)
     AccView acc_view() const;
+    // plain rows (small matrices): the device's plain copy of the matrix itself, 8 lanes per row (spmv_rowgroup_kernel); an
+    // overlay for the unmasked launches like the sorted fused tiles; set by the caller of build() (the model matrices)
+    const int* csr_ptr = nullptr;
+    const int* csr_idx = nullptr;
+    const double* csr_val = nullptr;
+    bool use_plain = false;
+    float tuned_us_plain = 0.f;
+    int plain_grid() const { return (int)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, ((int64_t)nrows * 8 + kBlock - 1) / kBlock)); }
     // the FUSED form (independent of the sliced layout); use_sorted_fused: it is the layout in use
     void build_sorted_fused(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s);
     bool use_sorted_fused = false;

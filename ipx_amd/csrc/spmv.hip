@@ -188,6 +188,8 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
     sorted = SortedMatrix();
     use_acc = false;
     acc = AccMatrix();
+    use_plain = false;
+    if (layout == "plain") { use_plain = csr_ptr != nullptr; return; }
     if (layout == "acc") {
         build_sliced(hptr, hidx, hval, s, 0);
         use_sliced = sliced.built;
@@ -268,6 +270,13 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
                 if (!use_sorted && !getenv("IPXK_BUILD_ALL_LAYOUTS")) sorted = SortedMatrix();
             }
         }
+        if (!spread && csr_ptr && nnz <= (int64_t(4) << 20) && !(getenv("IPXK_SPMV_PLAIN") && getenv("IPXK_SPMV_PLAIN")[0] == '0')) {
+            // small matrices: the plain rows, 8 lanes each (bit-identical to the three layouts timed above); kept if it beats them
+            use_plain = true;
+            tuned_us_plain = time_current();
+            const float best = use_sorted_fused ? tuned_us_sorted_fused : use_sliced ? tuned_us_fused : tuned_us_phased;
+            if (!(tuned_us_plain < 0.95f * best)) use_plain = false;
+        }
         if (spread && !(getenv("IPXK_SPMV_ACC") && getenv("IPXK_SPMV_ACC")[0] == '0')) {
             // accumulated tiles: used whenever they can be built (never a timing decision: see build_device)
             build_acc(hptr, hidx, hval, s);
@@ -282,9 +291,9 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
             wg_chunk_ptr.release(); chunk_start.release(); chunk_info.release(); chunk_step.release();
         }
         if (getenv("IPXK_VERBOSE"))
-            fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld: phased %.1f us, fused %.1f us, sliced %.1f us, sorted %.1f us (fullest-slice share %.2f) -> %s\n",
-                    nrows, ncols, (long long)nnz, tuned_us_phased, tuned_us_fused, tuned_us_sliced, tuned_us_sorted, share,
-                    use_sorted_fused ? "sorted-fused" : !use_sliced ? "phased" : sliced.nslices == 1 ? "fused" : use_sorted ? "sorted" : "sliced");
+            fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld: phased %.1f us, fused %.1f us, sliced %.1f us, sorted %.1f us, plain rows %.1f us (fullest-slice share %.2f) -> %s\n",
+                    nrows, ncols, (long long)nnz, tuned_us_phased, tuned_us_fused, tuned_us_sliced, tuned_us_sorted, tuned_us_plain, share,
+                    use_plain ? "plain rows" : use_sorted_fused ? "sorted-fused" : !use_sliced ? "phased" : sliced.nslices == 1 ? "fused" : use_sorted ? "sorted" : "sliced");
         if (getenv("IPXK_VERBOSE") && tuned_us_sorted_fused > 0.f) fprintf(stderr, "ipxk:   sorted-fused %.1f us\n", tuned_us_sorted_fused);
     }
     IPXK_HIP(hipEventDestroy(e0));
@@ -991,6 +1000,8 @@ void build_model(Context* c, const ipxint* Ap, const ipxint* Ai, const double* A
     const int64_t nz = c->nnz;
     c->create_ms[0] = ms_since(t0);
     std::unique_ptr<LayoutScratch, void (*)(LayoutScratch*)> S(new_layout_scratch(), free_layout_scratch);
+    c->Acols.csr_ptr = c->pl_Ap.get(); c->Acols.csr_idx = c->pl_Ai.get(); c->Acols.csr_val = c->pl_Ax.get();
+    c->Arows.csr_ptr = c->pl_Tp.get(); c->Arows.csr_idx = c->pl_Ti.get(); c->Arows.csr_val = c->pl_Tx.get();
     if (!c->Acols.build_device(*S, n, m, nz, c->pl_Ap.get(), c->pl_Ai.get(), c->pl_Ax.get(), c->stream))
         c->Acols.build(n, m, Ap, Ai, Ax, c->stream);
     c->create_ms[1] = ms_since(t0);

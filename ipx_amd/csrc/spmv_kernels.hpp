@@ -738,6 +738,42 @@ __global__ __launch_bounds__(kAccThreads) void spmv_acc_tile_kernel(AccView M, c
     for (int r = 2 * tid; r < M.RB; r += 2 * T) reinterpret_cast<double2*>(dst + r)[0] = make_double2(ac_sum[r], ac_sum[r + 1]);
 }
 
+// ---- plain rows (small matrices) --------------------------------------------------------------
+// The matrix as it is (the device's plain copy, layout_device.hip): 8 lanes per row, lane k takes entries k, k + 8, ...
+// (coalesced: a wavefront reads 64 consecutive entries), the first lane of the group adds the products in storage
+// order (the reference's order, bit for bit as in the phased and fused layouts).  No LDS, no barrier, no tile
+// tables: a pass is three dependent round trips (row pointers -> entries -> gathers).  For matrices of a few hundred
+// thousand entries, where a pass of the tiled layouts is 10 us of latency chains for 10 MB (C2: 50k x 100k).
+template <class Epi>
+__global__ __launch_bounds__(kBlock) void spmv_rowgroup_kernel(int nrows, const int* __restrict__ ptr, const int* __restrict__ idx,
+                                                               const double* __restrict__ val, const unsigned char* __restrict__ row_long,
+                                                               const double* __restrict__ x, Epi epi, double* dot_partials, const int* done) {
+    if (done && *done) return;
+    __shared__ double red[kBlock / 64 + 1];
+    const int lane8 = threadIdx.x & 7, lane = threadIdx.x & 63, g0 = lane & ~7;
+    double dotpart = 0.0;
+    const int ngroups = (gridDim.x * kBlock) >> 3;
+    for (int r = (blockIdx.x * kBlock + threadIdx.x) >> 3; r < nrows; r += ngroups) {
+        const bool live = !(row_long && row_long[r]);
+        const int p0 = ptr[r], p1 = live ? ptr[r + 1] : p0;
+        double acc = lane8 == 0 ? epi.init(r) : 0.0;
+        for (int p = p0; p < p1; p += 8) {
+            const int q = p + lane8;
+            const double prod = q < p1 ? Epi::prod(x[idx[q]], val[q]) : 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const double t = __shfl(prod, g0 + k, 64);
+                if (p + k < p1) acc = Epi::kNeg ? acc - t : acc + t;
+            }
+        }
+        if (live && lane8 == 0) epi.finish(r, acc, dotpart);
+    }
+    if (dot_partials) {
+        const double d = block_reduce<SumOp>(dotpart, red);
+        if (threadIdx.x == 0) dot_partials[blockIdx.x] = d;
+    }
+}
+
 // out[r] = finish(init(r) (+|-) partial[0][r] (+|-) partial[1][r] ...), slices in ascending order
 template <class Epi>
 __global__ __launch_bounds__(kBlock) void spmv_sliced_combine_kernel(SlicedView M, Epi epi, double* dot_partials,
@@ -814,6 +850,17 @@ inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi
 template <class Epi, bool MASKED = false>
 inline int launch_spmv(const GatherMatrix& M, const double* x, const Epi& epi, double* dot_partials,
                        const int* done, hipStream_t s) {
+    if (M.use_plain && !MASKED) {
+        const int grid = M.plain_grid();
+        hipLaunchKernelGGL(spmv_rowgroup_kernel<Epi>, dim3(grid), dim3(kBlock), 0, s, M.nrows, M.csr_ptr, M.csr_idx, M.csr_val,
+                           M.nlong > 0 ? M.row_long.get() : nullptr, x, epi, dot_partials, done);
+        if (M.nlong > 0) {
+            const GatherView G = M.view(false);
+            hipLaunchKernelGGL(spmv_long_kernel<Epi>, dim3(M.nseg), dim3(kBlock), 0, s, G, x, done);
+            hipLaunchKernelGGL(spmv_long_fixup_kernel<Epi>, dim3(1), dim3(kBlock), 0, s, G, epi, dot_partials, grid, done);
+        }
+        return dot_partials ? grid + (M.nlong > 0 ? 1 : 0) : 0;
+    }
     if (M.use_sorted_fused && !MASKED) {
         const SortedView W = M.sorted_view();
         const size_t lds = (size_t)(M.sorted.max_sub + M.sorted.max_sub / 32 + 1) * sizeof(double);
