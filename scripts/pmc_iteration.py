@@ -28,7 +28,7 @@ for k in sorted(ft, key=lambda k: -ft[k]):
 print("per application: read %.1f MB + write %.1f MB = %.1f MB" % (read_mb, write_mb, read_mb + write_mb))
 json.dump({"workload": "C3 basis path, planted factors: one operator application + CR vector kernels", "traffic_bytes_per_iteration": (read_mb + write_mb) * 1e6,
            "layouts": [a for a in sys.argv[3:5]] if len(sys.argv) > 4 else ["sorted", "sorted"], "source_hashes": bench.source_hashes(),
-           "source": "profiles/r03_basis_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on scripts/gpu_basis_iter.py, FETCH x2 gfx950 correction)"},
+           "source": "profiles/r04_basis_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on scripts/gpu_basis_iter.py, FETCH x2 gfx950 correction)"},
           open("gpurun_out/pmc_traffic_basis.json", "w"), indent=1)
 import shutil
 shutil.copy("gpurun_out/pmc_traffic_basis.json", "profiles/pmc_traffic_basis.json")   # a bench.py run in the same call reads it from there

@@ -11,7 +11,7 @@ python3 scripts/trace_summary.py gpurun_out/r04_basis_trace > gpurun_out/r04_bas
 python3 scripts/trace_iteration.py gpurun_out/r04_basis_trace > gpurun_out/r04_basis_iteration.txt &&
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r04_basis_fetch -- python3 scripts/gpu_basis_iter.py > gpurun_out/r04_basis_fetch.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/r04_basis_write -- python3 scripts/gpu_basis_iter.py > gpurun_out/r04_basis_write.log 2>&1 &&
-python3 scripts/pmc_iteration.py gpurun_out/r04_basis_fetch gpurun_out/r04_basis_write > gpurun_out/r04_basis_pmc_traffic.txt &&
+python3 scripts/pmc_iteration.py gpurun_out/r04_basis_fetch gpurun_out/r04_basis_write acc acc > gpurun_out/r04_basis_pmc_traffic.txt &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r04_c2_trace -- python3 scripts/gpu_probe_c2.py > gpurun_out/r04_c2_trace.log 2>&1 &&
 python3 scripts/trace_c2_iteration.py gpurun_out/r04_c2_trace > gpurun_out/r04_c2_iteration.txt &&
 python3 scripts/trace_summary.py gpurun_out/r04_c2_trace > gpurun_out/r04_c2_kernel_summary.txt &&
