@@ -287,7 +287,7 @@ def main():
     kernel_names = {"phased": "spmv_phased_kernel", "sliced": "spmv_sliced_tile_kernel+spmv_sliced_combine_kernel",
                     "fused": "spmv_sliced_tile_kernel<fused>", "sorted": "spmv_sorted_tile_kernel+spmv_sliced_combine_kernel",
                     "sortedfused": "spmv_sorted_fused_kernel", "acc": "spmv_acc_tile_kernel+spmv_sliced_combine_kernel",
-                    "plain": "spmv_rowgroup_kernel"}
+                    "plain": "spmv_rowgroup_kernel", "accfused": "spmv_acc_fused_kernel"}
     traffic, traffic_note = pmc_traffic("pmc_traffic.json", "traffic_bytes_per_apply",
                                         "C3 m=%d n=%d nnz=%d" % (m, n, nnz) if world == 1 else None, layouts)
 

@@ -523,7 +523,9 @@ ipxint ipxk_normal_apply_bytes(const ipxk_context* ctx);
  * sums as 1 for rows stored with ascending indices; used whenever the sliced
  * layout is and IPXK_SPMV_ACC is not 0), 6 = plain rows (the matrix as it is, 8
  * lanes per row, sums in storage order: bit-identical to 0, 2 and 4; a candidate of
- * the timing for matrices of at most 4M entries).  The sliced layouts are
+ * the timing for matrices of at most 4M entries), 7 = fused accumulated tiles (5
+ * with one slice and the epilogue in the tile kernel, for matrices whose gathers have
+ * locality and whose rows are stored sorted: bit-identical to 0, 2, 4, 6).  The sliced layouts are
  * chosen by a property of the matrix (x larger than an XCD's L2 and gathers that
  * spread over the slices), between 1 and 3 the faster at ipxk_create; otherwise a
  * timing picks the fastest of phased, fused and sorted fused, which are

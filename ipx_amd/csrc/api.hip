@@ -1010,14 +1010,14 @@ ipxint ipxk_normal_apply_bytes(const ipxk_context* c) {
 int ipxk_spmv_layout(const ipxk_context* c, int layout[2], double us[6]) {
     return guarded([&] {
         IPXK_REQUIRE(c && layout, "bad argument");
-        auto code = [](const GatherMatrix& M) { return M.use_plain ? 6 : M.use_acc ? 5 : M.use_sorted_fused ? 4 : !M.use_sliced ? 0 : M.sliced.nslices == 1 ? 2 : M.use_sorted ? 3 : 1; };
+        auto code = [](const GatherMatrix& M) { return M.use_acc_fused ? 7 : M.use_plain ? 6 : M.use_acc ? 5 : M.use_sorted_fused ? 4 : !M.use_sliced ? 0 : M.sliced.nslices == 1 ? 2 : M.use_sorted ? 3 : 1; };
         layout[0] = code(c->Acols);
         layout[1] = code(c->Arows);
         if (us) {
             us[0] = c->Acols.tuned_us_phased; us[1] = c->Acols.use_acc ? c->Acols.tuned_us_acc : c->Acols.use_sorted ? c->Acols.tuned_us_sorted : c->Acols.tuned_us_sliced;
-            us[2] = c->Acols.use_plain ? c->Acols.tuned_us_plain : c->Acols.use_sorted_fused ? c->Acols.tuned_us_sorted_fused : c->Acols.tuned_us_fused;
+            us[2] = c->Acols.use_acc_fused ? c->Acols.tuned_us_acc_fused : c->Acols.use_plain ? c->Acols.tuned_us_plain : c->Acols.use_sorted_fused ? c->Acols.tuned_us_sorted_fused : c->Acols.tuned_us_fused;
             us[3] = c->Arows.tuned_us_phased; us[4] = c->Arows.use_acc ? c->Arows.tuned_us_acc : c->Arows.use_sorted ? c->Arows.tuned_us_sorted : c->Arows.tuned_us_sliced;
-            us[5] = c->Arows.use_plain ? c->Arows.tuned_us_plain : c->Arows.use_sorted_fused ? c->Arows.tuned_us_sorted_fused : c->Arows.tuned_us_fused;
+            us[5] = c->Arows.use_acc_fused ? c->Arows.tuned_us_acc_fused : c->Arows.use_plain ? c->Arows.tuned_us_plain : c->Arows.use_sorted_fused ? c->Arows.tuned_us_sorted_fused : c->Arows.tuned_us_fused;
         }
     });
 }

@@ -268,8 +268,15 @@ constexpr int kAccThreads = 512;
 constexpr int kAccPerThread = 4;
 constexpr int kAccBatch = kAccThreads * kAccPerThread;     // 2048 entries between two barriers
 constexpr int kAccMaxRows = 16384;                         // 128 KB of row sums; 14 bits of row in the entry word
+//   * FUSED form (one slice = all of x, for matrices whose gathers have locality; round 4): a tile is a row block of RB rows
+//     (as many as give every CU two tiles), the gathered index is stored relative to the tile's smallest one (`xmin`; the
+//     tile's window of x must span less than 2^18 entries), the row sums start from the epilogue's initial value and the
+//     tile kernel applies the epilogue itself: no partial vectors, no combine launch.  Rows must be stored with ascending
+//     indices (then a row is summed in storage order: bit-identical to the phased, fused and sorted fused layouts, so the
+//     timing at ipxk_create may choose among them).
 struct AccView {
     int nrows, nrows_pad, nslices, nrb, RB, slice_elems;
+    const int* xmin;                   // FUSED: [nrb] smallest gathered index of the tile; else nullptr
     const unsigned* tile_batch;        // [nrb*nslices + 1] first batch of each tile
     const unsigned* bptr;              // [# batches + 1] first entry of each batch
     const unsigned* pack;
@@ -282,6 +289,8 @@ struct AccMatrix {
     int64_t nbatches = 0, deferred = 0;
     DevBuf<unsigned> tile_batch, bptr, pack;
     DevBuf<double> val, partial;
+    bool fused = false;                // the FUSED form
+    DevBuf<int> xmin;
 };
 
 struct LayoutScratch;                 // layout_device.hip
@@ -330,6 +339,11 @@ struct GatherMatrix {
     bool use_acc = false;
     float tuned_us_acc = 0.f;
     void build_acc(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s);     // host builder (test reference)
+    void build_acc_fused(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s);
+    AccMatrix accf;                    // the FUSED form (an overlay for the unmasked launches, like the sorted fused tiles)
+    bool use_acc_fused = false;
+    float tuned_us_acc_fused = 0.f;
+    AccView acc_fused_view() const;
     AccView acc_view() const;
     // plain rows (small matrices): the device's plain copy of the matrix itself, 8 lanes per row (spmv_rowgroup_kernel); an
     // overlay for the unmasked launches like the sorted fused tiles; set by the caller of build() (the model matrices)

@@ -189,7 +189,10 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
     use_acc = false;
     acc = AccMatrix();
     use_plain = false;
+    use_acc_fused = false;
+    accf = AccMatrix();
     if (layout == "plain") { use_plain = csr_ptr != nullptr; return; }
+    if (layout == "accfused") { build_acc_fused(hptr, hidx, hval, s); use_acc_fused = accf.built; return; }
     if (layout == "acc") {
         build_sliced(hptr, hidx, hval, s, 0);
         use_sliced = sliced.built;
@@ -270,7 +273,19 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
                 if (!use_sorted && !getenv("IPXK_BUILD_ALL_LAYOUTS")) sorted = SortedMatrix();
             }
         }
-        if (!spread && csr_ptr && nnz <= (int64_t(4) << 20) && !(getenv("IPXK_SPMV_PLAIN") && getenv("IPXK_SPMV_PLAIN")[0] == '0')) {
+        if (!spread && tune_level > 1 && !(getenv("IPXK_SPMV_ACC") && getenv("IPXK_SPMV_ACC")[0] == '0')) {
+            // gathers with locality, second candidate: the fused accumulated tiles (bit-identical to the layouts timed above for
+            // rows stored with ascending indices -- build_acc_fused checks that); kept if it beats what was chosen so far
+            build_acc_fused(hptr, hidx, hval, s);
+            if (accf.built) {
+                use_acc_fused = true;
+                tuned_us_acc_fused = time_current();
+                const float best = use_sorted_fused ? tuned_us_sorted_fused : use_sliced ? tuned_us_fused : tuned_us_phased;
+                if (!(tuned_us_acc_fused < 0.95f * best)) { use_acc_fused = false; accf = AccMatrix(); }
+                else if (use_sorted_fused) { use_sorted_fused = false; sorted = SortedMatrix(); }
+            }
+        }
+        if (!spread && !use_acc_fused && csr_ptr && nnz <= (int64_t(4) << 20) && !(getenv("IPXK_SPMV_PLAIN") && getenv("IPXK_SPMV_PLAIN")[0] == '0')) {
             // small matrices: the plain rows, 8 lanes each (bit-identical to the three layouts timed above); kept if it beats them
             use_plain = true;
             tuned_us_plain = time_current();
@@ -293,8 +308,11 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
         if (getenv("IPXK_VERBOSE"))
             fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld: phased %.1f us, fused %.1f us, sliced %.1f us, sorted %.1f us, plain rows %.1f us (fullest-slice share %.2f) -> %s\n",
                     nrows, ncols, (long long)nnz, tuned_us_phased, tuned_us_fused, tuned_us_sliced, tuned_us_sorted, tuned_us_plain, share,
-                    use_plain ? "plain rows" : use_sorted_fused ? "sorted-fused" : !use_sliced ? "phased" : sliced.nslices == 1 ? "fused" : use_sorted ? "sorted" : "sliced");
+                    use_acc_fused ? "accumulated-fused" : use_plain ? "plain rows" : use_sorted_fused ? "sorted-fused" : !use_sliced ? "phased" : sliced.nslices == 1 ? "fused" : use_sorted ? "sorted" : "sliced");
         if (getenv("IPXK_VERBOSE") && tuned_us_sorted_fused > 0.f) fprintf(stderr, "ipxk:   sorted-fused %.1f us\n", tuned_us_sorted_fused);
+        if (getenv("IPXK_VERBOSE") && tuned_us_acc_fused > 0.f)
+            fprintf(stderr, "ipxk:   accumulated-fused %.1f us (%d rows per tile, %lld batches, %.1f%% of the entries waited)\n", tuned_us_acc_fused, accf.RB,
+                    (long long)accf.nbatches, accf.built ? 100.0 * (double)accf.deferred / (double)nnz : 0.0);
     }
     IPXK_HIP(hipEventDestroy(e0));
     IPXK_HIP(hipEventDestroy(e1));
@@ -633,7 +651,87 @@ void GatherMatrix::build_acc(const ipxint* hptr, const ipxint* hidx, const doubl
 AccView GatherMatrix::acc_view() const {
     AccView V;
     V.nrows = nrows; V.nrows_pad = acc.nrows_pad; V.nslices = acc.nslices; V.nrb = acc.nrb; V.RB = acc.RB; V.slice_elems = acc.slice_elems;
+    V.xmin = nullptr;
     V.tile_batch = acc.tile_batch.get(); V.bptr = acc.bptr.get(); V.pack = acc.pack.get(); V.val = acc.val.get(); V.partial = acc.partial.get();
+    return V;
+}
+
+// FUSED accumulated tiles (internal.hpp): one slice, the epilogue in the tile kernel.  Only for matrices without long rows whose
+// rows are stored with ascending indices and whose row blocks gather from windows of less than 2^18 entries.
+void GatherMatrix::build_acc_fused(const ipxint* hptr, const ipxint* hidx, const double* hval, hipStream_t s) {
+    accf = AccMatrix();
+    if (nrows == 0 || nnz == 0 || ncols == 0 || nlong > 0) return;
+    for (int r = 0; r < nrows; r++)
+        for (ipxint p = hptr[r] + 1; p < hptr[r + 1]; p++)
+            if (hidx[p] <= hidx[p - 1]) return;                    // unsorted row: the sum would not be in storage order
+    // rows per tile: as many as a batch has entries (a batch takes one entry per row: with fewer rows its batches could not fill,
+    // with more the greedy leaves more tail batches), doubled until there are at most kMaxPartials tiles.  Measured on the banded
+    // probe, 8-entry rows: 2048 rows 43.9 us per pass (7816 batches for 16 M entries), 4096 rows 46.0 (9998); 16-entry rows: 1024
+    // rows 112, 2048 rows 83 -- those keep the sorted fused tiles (58.6), the timing decides.
+    int RB = kAccBatch;
+    while (((int64_t)nrows + RB - 1) / RB > kMaxPartials) RB *= 2;
+    if (RB > kAccMaxRows) return;
+    const int nrb = (nrows + RB - 1) / RB;
+    struct E { unsigned off, row; double v; };
+    std::vector<E> a;
+    std::vector<unsigned> pk((size_t)nnz), bp, tb((size_t)nrb + 1, 0);
+    std::vector<double> tv((size_t)nnz);
+    std::vector<int> xmin((size_t)nrb, 0), stamp((size_t)RB), pend, newpend;
+    int64_t deferred = 0;
+    unsigned base = 0;
+    for (int t = 0; t < nrb; t++) {
+        const int r1 = std::min(nrows, (t + 1) * RB);
+        ipxint lo = ncols, hi = -1;
+        for (int r = t * RB; r < r1; r++)
+            for (ipxint p = hptr[r]; p < hptr[r + 1]; p++) { lo = std::min(lo, hidx[p]); hi = std::max(hi, hidx[p]); }
+        tb[t] = (unsigned)bp.size();
+        if (hi < 0) continue;
+        if (hi - lo >= (ipxint(1) << kSortedOffBits)) return;          // the tile's window of x is too wide: no locality to use
+        xmin[t] = (int)lo;
+        a.clear();
+        for (int r = t * RB; r < r1; r++)
+            for (ipxint p = hptr[r]; p < hptr[r + 1]; p++) a.push_back(E{(unsigned)(hidx[p] - lo), (unsigned)(r - t * RB), hval[p]});
+        const int ne = (int)a.size();
+        std::stable_sort(a.begin(), a.end(), [](const E& x, const E& y) { return x.off < y.off; });
+        std::fill(stamp.begin(), stamp.end(), -1);
+        pend.clear();
+        int cursor = 0, put = 0, batch = 0;
+        while (put < ne) {
+            bp.push_back(base + (unsigned)put);
+            newpend.clear();
+            int fill = 0;
+            auto offer = [&](int i) {
+                if (stamp[a[i].row] == batch || fill == kAccBatch) { newpend.push_back(i); deferred++; return; }
+                stamp[a[i].row] = batch;
+                pk[base + put] = (a[i].row << kSortedOffBits) | a[i].off;
+                tv[base + put] = a[i].v;
+                put++; fill++;
+            };
+            for (int i : pend) offer(i);
+            while (fill < kAccBatch && cursor < ne) offer(cursor++);
+            pend.swap(newpend);
+            batch++;
+        }
+        base += (unsigned)ne;
+    }
+    tb[nrb] = (unsigned)bp.size();
+    bp.push_back((unsigned)nnz);
+    accf.nslices = 1; accf.nrb = nrb; accf.RB = RB; accf.nrows_pad = nrb * RB; accf.slice_elems = 0; accf.fused = true;
+    accf.nbatches = (int64_t)bp.size() - 1; accf.deferred = deferred;
+    accf.tile_batch.upload(tb, s);
+    accf.bptr.upload(bp, s);
+    accf.pack.upload(pk, s);
+    accf.val.upload(tv, s);
+    accf.xmin.upload(xmin, s);
+    IPXK_HIP(hipStreamSynchronize(s));
+    accf.built = true;
+}
+
+AccView GatherMatrix::acc_fused_view() const {
+    AccView V;
+    V.nrows = nrows; V.nrows_pad = accf.nrows_pad; V.nslices = 1; V.nrb = accf.nrb; V.RB = accf.RB; V.slice_elems = 0;
+    V.xmin = accf.xmin.get();
+    V.tile_batch = accf.tile_batch.get(); V.bptr = accf.bptr.get(); V.pack = accf.pack.get(); V.val = accf.val.get(); V.partial = nullptr;
     return V;
 }
 

@@ -774,6 +774,91 @@ __global__ __launch_bounds__(kBlock) void spmv_rowgroup_kernel(int nrows, const 
     }
 }
 
+// The FUSED form: one slice, a tile per row block, gathered indices relative to the tile's smallest one; the row sums
+// start from epi.init, the products are added batch by batch (ascending address = storage order of sorted rows) and the
+// kernel applies epi.finish itself; the tile's dot partial goes to dot_partials[tile].  The pipeline is the sliced
+// form's: adds of batch k, gathers of k + 1, stream loads of k + 2 and k + 3 in flight.
+template <class Epi>
+__global__ __launch_bounds__(kAccThreads) void spmv_acc_fused_kernel(AccView M, const double* __restrict__ x, Epi epi, double* dot_partials,
+                                                                     const int* done) {
+    if (done && *done) return;
+    extern __shared__ double ac_sum[];
+    __shared__ double red[kAccThreads / 64];
+    constexpr int U = kAccPerThread, T = kAccThreads;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const double* __restrict__ xs = x + M.xmin[tile];
+    const unsigned b0 = M.tile_batch[tile];
+    const int nb = (int)(M.tile_batch[tile + 1] - b0);
+    auto first = [&](int k) -> unsigned { return M.bptr[b0 + min(k, nb)]; };
+    constexpr int NE = 6;
+    unsigned e[NE];
+#pragma unroll
+    for (int i = 0; i < NE; i++) e[i] = first(i);
+    unsigned pk[3][U];
+    double v[3][U], xg[2][U];
+    auto stream = [&](unsigned (&pkb)[U], double (&vb)[U], unsigned e0, unsigned e1) {
+        const int ne = (int)(e1 - e0);
+        if (ne <= 0) return;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = min(u * T + tid, ne - 1);
+            pkb[u] = __builtin_nontemporal_load(M.pack + e0 + i);
+            vb[u] = __builtin_nontemporal_load(M.val + e0 + i);
+        }
+    };
+    auto gather = [&](double (&xgb)[U], const unsigned (&pkb)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) xgb[u] = xs[pkb[u] & ((1u << kSortedOffBits) - 1u)];
+    };
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+#pragma unroll
+        for (int u = 0; u < U; u++) { pk[d][u] = 0u; v[d][u] = 0.0; }
+        stream(pk[d], v[d], e[d], e[d + 1]);
+    }
+    const int r0 = tile * M.RB;
+    for (int r = tid; r < M.RB; r += T) ac_sum[r] = r0 + r < M.nrows ? epi.init(r0 + r) : 0.0;
+    if (nb > 0) gather(xg[0], pk[0]);
+    for (int k0 = 0; k0 < nb; k0 += 6) {
+#pragma unroll
+        for (int d = 0; d < 6; d++) {
+            const int k = k0 + d;
+            if (k < nb) {
+                const int ne = (int)(e[1] - e[0]);
+                if (k + 1 < nb) gather(xg[(d + 1) & 1], pk[(d + 1) % 3]);
+                const unsigned enew = first(k + NE);
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (u * T + tid < ne) {
+                        const double p = Epi::prod(xg[d & 1][u], v[d % 3][u]);
+                        __hip_atomic_fetch_add(ac_sum + (pk[d % 3][u] >> kSortedOffBits), Epi::kNeg ? -p : p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                stream(pk[d % 3], v[d % 3], e[3], e[4]);
+#pragma unroll
+                for (int i = 0; i + 1 < NE; i++) e[i] = e[i + 1];
+                e[NE - 1] = enew;
+            }
+        }
+    }
+    __syncthreads();
+    double dotpart = 0.0;
+    for (int r = tid; r < M.RB; r += T)
+        if (r0 + r < M.nrows) epi.finish(r0 + r, ac_sum[r], dotpart);
+    if (dot_partials) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dotpart += __shfl_down(dotpart, o, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = dotpart;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < T / 64; w++) t += red[w];
+            dot_partials[tile] = t;
+        }
+    }
+}
+
 // out[r] = finish(init(r) (+|-) partial[0][r] (+|-) partial[1][r] ...), slices in ascending order
 template <class Epi>
 __global__ __launch_bounds__(kBlock) void spmv_sliced_combine_kernel(SlicedView M, Epi epi, double* dot_partials,
@@ -850,6 +935,17 @@ inline void launch_spmv_sliced(const GatherMatrix& M, const double* x, const Epi
 template <class Epi, bool MASKED = false>
 inline int launch_spmv(const GatherMatrix& M, const double* x, const Epi& epi, double* dot_partials,
                        const int* done, hipStream_t s) {
+    if (M.use_acc_fused && !MASKED) {
+        const AccView W = M.acc_fused_view();
+        static bool lds_attr_set = false;
+        if (!lds_attr_set) {
+            IPXK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spmv_acc_fused_kernel<Epi>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(kAccMaxRows * sizeof(double))));
+            lds_attr_set = true;
+        }
+        hipLaunchKernelGGL((spmv_acc_fused_kernel<Epi>), dim3(W.nrb), dim3(kAccThreads), (size_t)W.RB * sizeof(double), s, W, x, epi, dot_partials, done);
+        return dot_partials ? W.nrb : 0;
+    }
     if (M.use_plain && !MASKED) {
         const int grid = M.plain_grid();
         hipLaunchKernelGGL(spmv_rowgroup_kernel<Epi>, dim3(grid), dim3(kBlock), 0, s, M.nrows, M.csr_ptr, M.csr_idx, M.csr_val,

@@ -254,7 +254,7 @@ class KktContext:
         lay = (C.c_int * 2)()
         us = (C.c_double * 6)()
         self._check(self.lib.ipxk_spmv_layout(self.h, lay, us))
-        names = ("phased", "sliced", "fused", "sorted", "sortedfused", "acc", "plain")
+        names = ("phased", "sliced", "fused", "sorted", "sortedfused", "acc", "plain", "accfused")
         return (names[lay[0]], names[lay[1]]), [float(v) for v in us]
 
     def split_inverse_stats(self):

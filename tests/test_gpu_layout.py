@@ -120,7 +120,7 @@ def test_matrices_outside_the_device_path_take_the_host_builders():
     # x fits an XCD's L2 (no slicing), and a model with dense columns (long rows): both still build and solve
     A = synth.synthetic_lp(20000, 45000, 8, 4)
     c = kkt.KktContext(A, device=0)
-    assert c.spmv_layout()[0][0] in ("phased", "fused", "sortedfused")
+    assert c.spmv_layout()[0][0] in ("phased", "fused", "sortedfused", "plain", "accfused")
     c.close()
     A = synth.synthetic_lp(30000, 70000, 8, 5, num_dense=4)
     c = kkt.KktContext(A, device=0)

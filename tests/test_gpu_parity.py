@@ -691,7 +691,7 @@ def test_sorted_fused_layout_on_a_banded_matrix(kkt, po, oracle, monkeypatch):
     u = rng.standard_normal(m)
     ref, ref_dot = oracle.normal_apply(ocsc(po, A), W, u)
     res = {}
-    for layout in ("phased", "sortedfused", None):
+    for layout in ("phased", "sortedfused", "accfused", None):       # accfused: the fused accumulated tiles (round 4), same bits
         if layout: monkeypatch.setenv("IPXK_SPMV_LAYOUT", layout)
         else: monkeypatch.delenv("IPXK_SPMV_LAYOUT")
         ctx = kkt.KktContext(A)
@@ -706,6 +706,7 @@ def test_sorted_fused_layout_on_a_banded_matrix(kkt, po, oracle, monkeypatch):
         ctx.close()
     assert res["sortedfused"][3] == res["phased"][3] == 0 and abs(res["sortedfused"][2] - res["phased"][2]) <= 2
     assert relerr(res["sortedfused"][1], res["phased"][1]) < 1e-8
+    assert res["accfused"][3] == 0 and abs(res["accfused"][2] - res["phased"][2]) <= 2 and relerr(res["accfused"][1], res["phased"][1]) < 1e-8
     print("auto choice on the banded matrix:", res[None][4])
     # uniformly random indices: no tile has a narrow window -> not built, the phased layout serves
     monkeypatch.setenv("IPXK_SPMV_LAYOUT", "sortedfused")
