@@ -557,7 +557,8 @@ int ipxk_split_inverse_stats(const ipxk_context* ctx, ipxint* probes,
  * nslices, nrb, nrows_pad, max_tile, bits of the fullest-slice share (double),
  * sorted.built, nslices, nsub, nrb, RB, nrows_pad, max_sub, slice_elems, fused,
  * nnz, P, G, RT*1e6 + Q*1e3, use_acc, acc.built, nslices, nrb, RB, nrows_pad,
- * slice_elems, # batches, # entries that waited for a later batch}. */
+ * slice_elems, # batches, # entries that waited for a later batch, use_acc_fused,
+ * accf.built, nrb, RB, # batches, use_plain}. */
 int ipxk_layout_info(const ipxk_context* ctx, int which, ipxint info[40],
                      double create_ms[4]);
 /* array: 0 sliced tile_ptr (u32), 1 sliced cnt (u8), 2 sliced idx (i32), 3
@@ -565,7 +566,9 @@ int ipxk_layout_info(const ipxk_context* ctx, int which, ipxint info[40],
  * (u32), 7 sorted val (f64), 8 / 9 / 10 the row-wise copy of the model (Transpose,
  * sparse_matrix.cc:120-151) as the device holds it: ptr (i32), idx (i32), val
  * (f64); 11 acc tile_batch (u32), 12 acc bptr (u32), 13 acc pack (u32), 14 acc
- * val (f64).  Copies min(cap, size) bytes into out; *nbytes = the array's size. */
+ * val (f64); 15-19 the fused accumulated tiles: tile_batch, bptr, pack (u32), val
+ * (f64), xmin (i32); 20 xmin of the fused sorted tiles (i32).  Copies min(cap, size)
+ * bytes into out; *nbytes = the array's size. */
 int ipxk_layout_array(ipxk_context* ctx, int which, int array, void* out,
                       ipxint cap, ipxint* nbytes);
 /* plain device allocation helpers so that callers without torch can hold

@@ -961,6 +961,8 @@ int ipxk_layout_info(const ipxk_context* c, int which, ipxint info[40], double c
         info[21] = M.P; info[22] = M.G; info[23] = (ipxint)M.RT * 1000000 + (ipxint)M.Q * 1000 + 0;
         info[24] = M.use_acc; info[25] = M.acc.built; info[26] = M.acc.nslices; info[27] = M.acc.nrb; info[28] = M.acc.RB;
         info[29] = M.acc.nrows_pad; info[30] = M.acc.slice_elems; info[31] = M.acc.nbatches; info[32] = M.acc.deferred;
+        info[33] = M.use_acc_fused; info[34] = M.accf.built; info[35] = M.accf.nrb; info[36] = M.accf.RB; info[37] = M.accf.nbatches;
+        info[38] = M.use_plain;
         if (create_ms) for (int i = 0; i < 4; i++) create_ms[i] = c->create_ms[i];
     });
 }
@@ -974,7 +976,7 @@ int ipxk_layout_array(ipxk_context* c, int which, int array, void* out, ipxint c
         const GatherMatrix& M = which == 0 ? c->Acols : c->Arows;
         const void* src = nullptr;
         size_t bytes = 0;
-        const size_t ntiles = (size_t)M.sliced.nrb * M.sliced.nslices, nsubs = (size_t)M.sorted.nrb * M.sorted.nslices * M.sorted.nsub;
+        const size_t ntiles = (size_t)M.sliced.nrb * M.sliced.nslices, nsubs = (size_t)M.sorted.nrb * std::max(M.sorted.nslices, 1) * std::max(M.sorted.nsub, 1);
         const size_t nz = (size_t)M.nnz;
         switch (array) {
             case 0: src = M.sliced.tile_ptr.get(); bytes = M.sliced.built ? (ntiles + 1) * 4 : 0; break;
@@ -992,6 +994,12 @@ int ipxk_layout_array(ipxk_context* c, int which, int array, void* out, ipxint c
             case 12: src = M.acc.bptr.get(); bytes = M.acc.built ? ((size_t)M.acc.nbatches + 1) * 4 : 0; break;
             case 13: src = M.acc.pack.get(); bytes = M.acc.built ? nz * 4 : 0; break;
             case 14: src = M.acc.val.get(); bytes = M.acc.built ? nz * 8 : 0; break;
+            case 15: src = M.accf.tile_batch.get(); bytes = M.accf.built ? ((size_t)M.accf.nrb + 1) * 4 : 0; break;
+            case 16: src = M.accf.bptr.get(); bytes = M.accf.built ? ((size_t)M.accf.nbatches + 1) * 4 : 0; break;
+            case 17: src = M.accf.pack.get(); bytes = M.accf.built ? nz * 4 : 0; break;
+            case 18: src = M.accf.val.get(); bytes = M.accf.built ? nz * 8 : 0; break;
+            case 19: src = M.accf.xmin.get(); bytes = M.accf.built ? (size_t)M.accf.nrb * 4 : 0; break;
+            case 20: src = M.sorted.xmin.get(); bytes = M.sorted.built && M.sorted.fused ? (size_t)M.sorted.nrb * 4 : 0; break;
             default: IPXK_REQUIRE(false, "unknown array");
         }
         if (M.nlong > 0 && (array < 8 || array > 10)) bytes = 0;       // long rows: the tiles hold fewer entries than nnz; not inspected

@@ -148,7 +148,11 @@ void ensure_host_model(Context* c, bool rowwise);
 void fetch_columns(Context* c, const std::vector<ipxint>& cols, std::vector<ipxint>& Cp, std::vector<ipxint>& Ci, std::vector<double>& Cx);
 int device_max_row_length(LayoutScratch& S, int nrows, const int* dptr, hipStream_t s);
 bool device_build_sliced(LayoutScratch& S, SlicedMatrix& out, int nrows, int ncols, int64_t nnz, const int* dptr, const int* didx,
-                         const double* dval, hipStream_t s);
+                         const double* dval, hipStream_t s, int ns_request = 0);
+bool device_build_sorted_fused(LayoutScratch& S, SortedMatrix& out, int nrows, int ncols, int64_t nnz, const int* dptr, const int* didx,
+                               const double* dval, hipStream_t s);
+bool device_build_acc_fused(LayoutScratch& S, AccMatrix& out, int nrows, int ncols, int64_t nnz, const int* dptr, const int* didx,
+                            const double* dval, hipStream_t s);
 bool device_build_sorted(LayoutScratch& S, SortedMatrix& out, const SlicedMatrix& sliced, int nrows, int ncols, int64_t nnz, const int* dptr,
                          const int* didx, const double* dval, hipStream_t s);
 

@@ -325,6 +325,8 @@ struct GatherMatrix {
     // spread over the slices): the caller then runs build() on host arrays.
     bool build_device(LayoutScratch& S, int64_t nrows_, int64_t ncols_, int64_t nnz_, const int* dptr, const int* didx,
                       const double* dval, hipStream_t s);
+    bool build_device_local(LayoutScratch& S, int64_t nrows_, int64_t ncols_, int64_t nnz_, const int* dptr, const int* didx,
+                            const double* dval, double share, hipStream_t s);
     void set_geometry(int64_t nrows_, int64_t ncols_);      // P, G, RT, Q, RWrows of the phased layout
     // optional second layout and the choice between the two (IPXK_SPMV_LAYOUT=phased|sliced|auto;
     // auto times both once at build time on this matrix and keeps the faster one)

@@ -294,6 +294,62 @@ __global__ void acc_bptr_kernel(int ntiles, const unsigned* __restrict__ tile_pt
     if (tile == ntiles - 1 && threadIdx.x == 0) bptr[tile_batch[ntiles]] = nz;
 }
 
+// ---- one-slice (FUSED) forms: a tile is a row block, offsets are relative to the tile's smallest gathered index ----
+// smallest / largest gathered index per tile, the rows' count bytes (optional), a flag for rows with descending / repeated indices
+__global__ void tile_window_kernel(int nrows, const int* __restrict__ ptr, const int* __restrict__ idx, int RB, int* __restrict__ lo,
+                                   int* __restrict__ hi, unsigned char* __restrict__ cnt, int* flags) {
+    IPXK_GS(r, nrows) {
+        const int p0 = ptr[r], p1 = ptr[r + 1];
+        if (cnt) { if (p1 - p0 > 255) flags[0] = 1; cnt[r] = (unsigned char)(p1 - p0); }
+        if (p1 == p0) continue;
+        int a = idx[p0], b = a;
+        for (int p = p0 + 1; p < p1; p++) {
+            const int v = idx[p];
+            if (v <= idx[p - 1]) flags[1] = 1;                   // not ascending
+            a = min(a, v); b = max(b, v);
+        }
+        atomicMin(lo + r / RB, a);
+        atomicMax(hi + r / RB, b);
+    }
+}
+// [0] widest window (hi - lo) of a tile, [1] most entries of a tile; empty tiles get lo = 0
+__global__ void tile_window_stats_kernel(int nrb, int nrows, int RB, const int* __restrict__ ptr, int* __restrict__ lo, const int* __restrict__ hi,
+                                         int* out) {
+    IPXK_GS(t, nrb) {
+        const int r0 = (int)t * RB, r1 = min(nrows, r0 + RB);
+        const int ne = ptr[r1] - ptr[r0];
+        if (ne == 0) { lo[t] = 0; continue; }
+        atomicMax(out + 0, hi[t] - lo[t]);
+        atomicMax(out + 1, ne);
+    }
+}
+// key = tile << 18 | (index - the tile's smallest index), enumerated in storage order
+__global__ void fused_keys_kernel(int nrows, const int* __restrict__ ptr, const int* __restrict__ idx, int RB, const int* __restrict__ lo,
+                                  u64* __restrict__ key, unsigned* __restrict__ pos, int* __restrict__ rowof) {
+    IPXK_GS(r, nrows) {
+        const u64 t = (u64)(r / RB);
+        const int base = lo[r / RB];
+        for (int p = ptr[r]; p < ptr[r + 1]; p++) {
+            key[p] = (t << kSortedOffBits) | (u64)(unsigned)(idx[p] - base);
+            pos[p] = (unsigned)p;
+            if (rowof) rowof[p] = (int)r;
+        }
+    }
+}
+// sorted fused tiles: slot = place of the entry in the tile's row-major (= storage) order
+__global__ void sorted_fused_fill_kernel(int64_t nz, const u64* __restrict__ keys, const unsigned* __restrict__ perm, const int* __restrict__ ptr, int RB,
+                                         const double* __restrict__ val, unsigned* __restrict__ pack, double* __restrict__ out_val) {
+    IPXK_GS(f, nz) {
+        const u64 k = keys[f];
+        const unsigned p = perm[f], t = (unsigned)(k >> kSortedOffBits);
+        pack[f] = ((p - (unsigned)ptr[(size_t)t * RB]) << kSortedOffBits) | (unsigned)(k & ((1u << kSortedOffBits) - 1u));
+        out_val[f] = val[p];
+    }
+}
+__global__ void tile_ptr_from_rows_kernel(int nrb, int nrows, int RB, const int* __restrict__ ptr, unsigned* __restrict__ out) {
+    IPXK_GS(t, (int64_t)nrb + 1) out[t] = (unsigned)ptr[min((int64_t)nrows, t * RB)];
+}
+
 struct Tmp {
     DevBuf<unsigned char> bytes;
     void* need(size_t n) { if (bytes.size() < n) bytes.resize(n); return bytes.get(); }
@@ -438,16 +494,19 @@ int device_max_row_length(LayoutScratch& S, int nrows, const int* dptr, hipStrea
 // returns false when the layout does not apply (x fits an XCD's L2, a tile does not fit LDS, > 255 entries of a row in
 // one slice): the caller then takes the host path
 bool device_build_sliced(LayoutScratch& S, SlicedMatrix& out, int nrows, int ncols, int64_t nnz, const int* dptr, const int* didx,
-                         const double* dval, hipStream_t s) {
+                         const double* dval, hipStream_t s, int ns_request) {
     out = SlicedMatrix();
     if (nrows == 0 || nnz == 0 || ncols == 0) return false;
-    const int64_t x_bytes = (int64_t)ncols * 8;
-    int64_t slice_bytes = int64_t(2) << 20;
-    if (const char* e = getenv("IPXK_SLICE_TEST_KB"))
-        if (atoi(e) > 0) slice_bytes = (int64_t)atoi(e) << 10;
-    if (x_bytes <= 2 * slice_bytes && !(getenv("IPXK_SLICE_FORCE2") && x_bytes > slice_bytes)) return false;
-    int ns = 2;
-    while (ns < 8 && x_bytes > (int64_t)ns * slice_bytes) ns *= 2;
+    int ns = 1;                                   // ns_request == 1: the fused tiles (one slice)
+    if (ns_request != 1) {
+        const int64_t x_bytes = (int64_t)ncols * 8;
+        int64_t slice_bytes = int64_t(2) << 20;
+        if (const char* e = getenv("IPXK_SLICE_TEST_KB"))
+            if (atoi(e) > 0) slice_bytes = (int64_t)atoi(e) << 10;
+        if (x_bytes <= 2 * slice_bytes && !(getenv("IPXK_SLICE_FORCE2") && x_bytes > slice_bytes)) return false;
+        ns = 2;
+        while (ns < 8 && x_bytes > (int64_t)ns * slice_bytes) ns *= 2;
+    }
     const int64_t slice = (((int64_t)ncols + ns - 1) / ns + 15) / 16 * 16;
     int R = kSlicedRows;
     while (R > kBlock && ((int64_t)nrows + R - 1) / R * (int64_t)ns < 2048) R /= 2;
@@ -486,7 +545,7 @@ bool device_build_sliced(LayoutScratch& S, SlicedMatrix& out, int nrows, int nco
     IPXK_HIP(hipGetLastError());
     if (over) { out = SlicedMatrix(); return false; }
     out.R = R; out.nslices = ns; out.nrb = nrb; out.nrows_pad = nrb * R; out.max_tile = h[0];
-    out.partial.resize((size_t)ns * out.nrows_pad);
+    out.partial.resize(ns > 1 ? (size_t)ns * out.nrows_pad : 1);
     out.built = true;
     return true;
 }
@@ -605,6 +664,106 @@ bool device_build_acc(LayoutScratch& S, AccMatrix& out, const SlicedMatrix& slic
     out.nslices = ns; out.nrb = nrb; out.RB = RB; out.nrows_pad = nrb * RB; out.slice_elems = (int)slice;
     out.nbatches = nb_total; out.deferred = (int64_t)ndef;
     out.partial.resize((size_t)ns * out.nrows_pad);
+    out.built = true;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// FUSED sorted tiles (the arrays of GatherMatrix::build_sorted_fused, bit for bit)
+// ---------------------------------------------------------------------------
+bool device_build_sorted_fused(LayoutScratch& S, SortedMatrix& out, int nrows, int ncols, int64_t nnz, const int* dptr, const int* didx,
+                               const double* dval, hipStream_t s) {
+    out = SortedMatrix();
+    if (nrows == 0 || nnz == 0 || ncols == 0) return false;
+    static const int cap = [] { const char* e = getenv("IPXK_SF_MAXSUB"); return e && atoi(e) >= 256 ? std::min(atoi(e), kSortedMaxSub) : kSortedMaxSub; }();
+    const size_t nz = (size_t)nnz;
+    S.q1.ensure(nz); S.q2.ensure(nz); S.v1.ensure(nz); S.v2.ensure(nz); S.stats.ensure(8);
+    DevBuf<int> lo, hi;
+    int RB = 32 * kSortedThreads, nrb = 0, h[4] = {0, 0, 0, 0};
+    for (;; RB /= 2) {
+        if (RB < kSortedThreads) return false;
+        nrb = (nrows + RB - 1) / RB;
+        if (RB > kSortedThreads && nrb < 1024) continue;          // enough tiles to fill the chip
+        lo.ensure((size_t)nrb); hi.ensure((size_t)nrb);
+        out.cnt.ensure((size_t)nrb * RB);
+        IPXK_HIP(hipMemsetAsync(lo.get(), 0x7f, (size_t)nrb * sizeof(int), s));
+        IPXK_HIP(hipMemsetAsync(hi.get(), 0xff, (size_t)nrb * sizeof(int), s));
+        IPXK_HIP(hipMemsetAsync(out.cnt.get(), 0, (size_t)nrb * RB, s));
+        IPXK_HIP(hipMemsetAsync(S.stats.get(), 0, 8 * sizeof(int), s));
+        hipLaunchKernelGGL(tile_window_kernel, dim3(gridn(nrows)), dim3(kBlock), 0, s, nrows, dptr, didx, RB, lo.get(), hi.get(), out.cnt.get(), S.stats.get() + 2);
+        hipLaunchKernelGGL(tile_window_stats_kernel, dim3(gridn(nrb)), dim3(kBlock), 0, s, nrb, nrows, RB, dptr, lo.get(), hi.get(), S.stats.get());
+        IPXK_HIP(hipMemcpyAsync(h, S.stats.get(), sizeof h, hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        if (h[2]) { out = SortedMatrix(); return false; }          // a row of more than 255 entries
+        if (h[1] <= cap) break;
+    }
+    if (h[0] >= (1 << kSortedOffBits)) { out = SortedMatrix(); return false; }     // a tile's window of x is too wide: no locality to use
+    hipLaunchKernelGGL(fused_keys_kernel, dim3(gridn(nrows)), dim3(kBlock), 0, s, nrows, dptr, didx, RB, lo.get(), S.q1.get(), S.v1.get(), (int*)nullptr);
+    sort_pairs<u64>(S.T, S.q1.get(), S.q2.get(), S.v1.get(), S.v2.get(), nz, kSortedOffBits + bits_for((u64)std::max(nrb, 2) - 1), s);
+    out.sub_ptr.ensure((size_t)nrb + 1); out.pack.ensure(nz); out.val.ensure(nz); out.xmin.ensure((size_t)nrb);
+    hipLaunchKernelGGL(tile_ptr_from_rows_kernel, dim3(gridn(nrb + 1)), dim3(kBlock), 0, s, nrb, nrows, RB, dptr, out.sub_ptr.get());
+    hipLaunchKernelGGL(sorted_fused_fill_kernel, dim3(gridn(nnz)), dim3(kBlock), 0, s, nnz, S.q2.get(), S.v2.get(), dptr, RB, dval, out.pack.get(), out.val.get());
+    IPXK_HIP(hipMemcpyAsync(out.xmin.get(), lo.get(), (size_t)nrb * sizeof(int), hipMemcpyDeviceToDevice, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    IPXK_HIP(hipGetLastError());
+    out.nslices = 1; out.nsub = 1; out.nrb = nrb; out.RB = RB; out.nrows_pad = nrb * RB; out.max_sub = h[1]; out.slice_elems = 0; out.fused = true;
+    out.built = true;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// FUSED accumulated tiles (the arrays of GatherMatrix::build_acc_fused, bit for bit)
+// ---------------------------------------------------------------------------
+bool device_build_acc_fused(LayoutScratch& S, AccMatrix& out, int nrows, int ncols, int64_t nnz, const int* dptr, const int* didx,
+                            const double* dval, hipStream_t s) {
+    out = AccMatrix();
+    if (nrows == 0 || nnz == 0 || ncols == 0) return false;
+    int RB = kAccBatch;
+    while (((int64_t)nrows + RB - 1) / RB > kMaxPartials) RB *= 2;
+    if (RB > kAccMaxRows) return false;
+    const int nrb = (nrows + RB - 1) / RB;
+    const size_t nz = (size_t)nnz;
+    S.q1.ensure(nz); S.q2.ensure(nz); S.v1.ensure(nz); S.v2.ensure(nz); S.v3.ensure(nz); S.v4.ensure(nz); S.k1.ensure(nz); S.k2.ensure(nz);
+    S.stats.ensure(8);
+    DevBuf<int> lo((size_t)nrb), hi((size_t)nrb), rowof(nz);
+    DevBuf<unsigned> tile_ptr((size_t)nrb + 1), nbatch((size_t)nrb + 1), bstart(nz);
+    IPXK_HIP(hipMemsetAsync(lo.get(), 0x7f, (size_t)nrb * sizeof(int), s));
+    IPXK_HIP(hipMemsetAsync(hi.get(), 0xff, (size_t)nrb * sizeof(int), s));
+    IPXK_HIP(hipMemsetAsync(S.stats.get(), 0, 8 * sizeof(int), s));
+    hipLaunchKernelGGL(tile_window_kernel, dim3(gridn(nrows)), dim3(kBlock), 0, s, nrows, dptr, didx, RB, lo.get(), hi.get(), (unsigned char*)nullptr,
+                       S.stats.get() + 2);
+    hipLaunchKernelGGL(tile_window_stats_kernel, dim3(gridn(nrb)), dim3(kBlock), 0, s, nrb, nrows, RB, dptr, lo.get(), hi.get(), S.stats.get());
+    int h[4] = {0, 0, 0, 0};
+    IPXK_HIP(hipMemcpyAsync(h, S.stats.get(), sizeof h, hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    if (h[3]) return false;                                        // a row with descending indices: the sum would not be in storage order
+    if (h[0] >= (1 << kSortedOffBits)) return false;               // a tile's window of x is too wide
+    hipLaunchKernelGGL(fused_keys_kernel, dim3(gridn(nrows)), dim3(kBlock), 0, s, nrows, dptr, didx, RB, lo.get(), S.q1.get(), S.v1.get(), rowof.get());
+    sort_pairs<u64>(S.T, S.q1.get(), S.q2.get(), S.v1.get(), S.v2.get(), nz, kSortedOffBits + bits_for((u64)std::max(nrb, 2) - 1), s);
+    hipLaunchKernelGGL(tile_ptr_from_rows_kernel, dim3(gridn(nrb + 1)), dim3(kBlock), 0, s, nrb, nrows, RB, dptr, tile_ptr.get());
+    unsigned* word = S.k1.get();
+    hipLaunchKernelGGL(acc_words_kernel, dim3(gridn(nnz)), dim3(kBlock), 0, s, nnz, S.q2.get(), S.v2.get(), rowof.get(), RB, word);
+    IPXK_HIP(hipMemsetAsync(S.stats.get(), 0, 8 * sizeof(int), s));
+    IPXK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(acc_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(kAccMaxRows * 2 * sizeof(unsigned))));
+    hipLaunchKernelGGL(acc_batch_kernel, dim3((unsigned)nrb), dim3(64), (size_t)RB * 2 * sizeof(unsigned), s, RB, tile_ptr.get(), word, S.k2.get(),
+                       S.v3.get(), S.v4.get(), bstart.get(), nbatch.get(), reinterpret_cast<u64*>(S.stats.get()));
+    out.tile_batch.ensure((size_t)nrb + 1);
+    hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(1024), 0, s, nrb, nbatch.get(), out.tile_batch.get());
+    unsigned nb_total = 0;
+    u64 ndef = 0;
+    IPXK_HIP(hipMemcpyAsync(&nb_total, out.tile_batch.get() + nrb, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipMemcpyAsync(&ndef, S.stats.get(), sizeof(u64), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    out.bptr.ensure((size_t)nb_total + 1); out.pack.ensure(nz); out.val.ensure(nz); out.xmin.ensure((size_t)nrb);
+    hipLaunchKernelGGL(acc_bptr_kernel, dim3((unsigned)nrb), dim3(64), 0, s, nrb, tile_ptr.get(), out.tile_batch.get(), bstart.get(), (unsigned)nnz,
+                       out.bptr.get());
+    hipLaunchKernelGGL(acc_scatter_kernel, dim3(gridn(nnz)), dim3(kBlock), 0, s, nnz, S.k2.get(), word, S.v2.get(), dval, out.pack.get(), out.val.get());
+    IPXK_HIP(hipMemcpyAsync(out.xmin.get(), lo.get(), (size_t)nrb * sizeof(int), hipMemcpyDeviceToDevice, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    IPXK_HIP(hipGetLastError());
+    out.nslices = 1; out.nrb = nrb; out.RB = RB; out.nrows_pad = nrb * RB; out.slice_elems = 0; out.fused = true;
+    out.nbatches = nb_total; out.deferred = (int64_t)ndef;
     out.built = true;
     return true;
 }

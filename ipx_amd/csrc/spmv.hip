@@ -318,6 +318,79 @@ void GatherMatrix::build(int64_t nrows_, int64_t ncols_, const ipxint* hptr, con
     IPXK_HIP(hipEventDestroy(e1));
 }
 
+// The device path for matrices whose gathers have locality, or whose gathered vector fits an XCD's L2 (round 4): the fused tiles
+// (one slice; also what the masked products of the basis path use), the fused sorted tiles and the fused accumulated tiles, all
+// built on the device and all bit-identical to the phased layout (the accumulated ones for sorted rows only: device_build_acc_fused
+// checks), so a timing chooses among them; the plain rows join for small matrices.  The phased layout is not built on this path.
+bool GatherMatrix::build_device_local(LayoutScratch& S, int64_t nrows_, int64_t ncols_, int64_t nnz_, const int* dptr, const int* didx,
+                                      const double* dval, double share, hipStream_t s) {
+    if (getenv("IPXK_LAYOUT_LOCAL") && getenv("IPXK_LAYOUT_LOCAL")[0] == 'h') return false;      // host builders for these matrices
+    SlicedMatrix fu;
+    if (!device_build_sliced(S, fu, (int)nrows_, (int)ncols_, nnz_, dptr, didx, dval, s, 1)) return false;
+    nrows = (int)nrows_; ncols = (int)ncols_; nnz = nnz_;
+    set_geometry(nrows_, ncols_);
+    nlong = 0; nseg = 0;
+    h_row_long.clear();
+    long_partials.resize(1);
+    sliced = std::move(fu);
+    sliced.dominant_fraction = share;
+    use_sliced = true;
+    use_sorted = false; use_sorted_fused = false; use_acc = false; use_acc_fused = false; use_plain = false;
+    sorted = SortedMatrix(); acc = AccMatrix(); accf = AccMatrix();
+    DevBuf<double> tx((size_t)std::max(ncols, 1)), tout((size_t)std::max(nrows, 1));
+    IPXK_HIP(hipMemsetAsync(tx.get(), 0, tx.size() * sizeof(double), s));
+    hipEvent_t e0, e1;
+    IPXK_HIP(hipEventCreate(&e0));
+    IPXK_HIP(hipEventCreate(&e1));
+    EpiScale epi{{}, nullptr, tout.get()};
+    auto time_current = [&]() {
+        const int reps = 5;
+        for (int w = 0; w < 2; w++) launch_spmv(*this, tx.get(), epi, nullptr, nullptr, s);
+        IPXK_HIP(hipEventRecord(e0, s));
+        for (int r = 0; r < reps; r++) launch_spmv(*this, tx.get(), epi, nullptr, nullptr, s);
+        IPXK_HIP(hipEventRecord(e1, s));
+        IPXK_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        IPXK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        return ms * 1e3f / reps;
+    };
+    const bool keep_all = getenv("IPXK_BUILD_ALL_LAYOUTS") != nullptr;          // (tests: the layouts the timing discards stay built)
+    tuned_us_fused = time_current();
+    float best = tuned_us_fused;
+    SortedMatrix so;
+    if (device_build_sorted_fused(S, so, nrows, ncols, nnz_, dptr, didx, dval, s)) {
+        sorted = std::move(so);
+        use_sorted_fused = true;
+        tuned_us_sorted_fused = time_current();
+        if (tuned_us_sorted_fused < 0.95f * best) best = tuned_us_sorted_fused;
+        else { use_sorted_fused = false; if (!keep_all) sorted = SortedMatrix(); }
+    }
+    AccMatrix af;
+    if (!(getenv("IPXK_SPMV_ACC") && getenv("IPXK_SPMV_ACC")[0] == '0') && device_build_acc_fused(S, af, nrows, ncols, nnz_, dptr, didx, dval, s)) {
+        accf = std::move(af);
+        use_acc_fused = true;
+        tuned_us_acc_fused = time_current();
+        if (tuned_us_acc_fused < 0.95f * best) { best = tuned_us_acc_fused; use_sorted_fused = false; if (!keep_all) sorted = SortedMatrix(); }
+        else { use_acc_fused = false; if (!keep_all) accf = AccMatrix(); }
+    }
+    if (!use_acc_fused && csr_ptr && nnz <= (int64_t(4) << 20) && !(getenv("IPXK_SPMV_PLAIN") && getenv("IPXK_SPMV_PLAIN")[0] == '0')) {
+        const bool sf = use_sorted_fused;
+        use_sorted_fused = false;
+        use_plain = true;
+        tuned_us_plain = time_current();
+        if (tuned_us_plain < 0.95f * best) { best = tuned_us_plain; if (!keep_all) sorted = SortedMatrix(); }
+        else { use_plain = false; use_sorted_fused = sf; }
+    }
+    IPXK_HIP(hipEventDestroy(e0));
+    IPXK_HIP(hipEventDestroy(e1));
+    if (getenv("IPXK_VERBOSE"))
+        fprintf(stderr, "ipxk: gather matrix %d x %d nnz %lld built on the device (gathers with locality): fused %.1f us, sorted-fused %.1f us, accumulated-fused %.1f us, "
+                        "plain rows %.1f us (fullest-slice share %.2f) -> %s\n", nrows, ncols, (long long)nnz, tuned_us_fused, tuned_us_sorted_fused,
+                tuned_us_acc_fused, tuned_us_plain, share,
+                use_acc_fused ? "accumulated-fused" : use_plain ? "plain rows" : use_sorted_fused ? "sorted-fused" : "fused");
+    return true;
+}
+
 // The device path (layout_device.hip): sliced + sorted layouts by radix sorts, for matrices whose gathered vector needs
 // slicing and whose gathers spread over the slices -- the same decision build() takes from the same property of the
 // matrix, so a model gets the same layouts whichever path builds them.
@@ -330,8 +403,9 @@ bool GatherMatrix::build_device(LayoutScratch& S, int64_t nrows_, int64_t ncols_
     if (nrows_ >= (int64_t(1) << 31) - 1 || ncols_ >= (int64_t(1) << 31) - 1 || nnz_ >= (int64_t(1) << 31) - kLongSeg) return false;
     if (device_max_row_length(S, (int)nrows_, dptr, s) > kMaxRowLen) return false;      // long rows: host path
     SlicedMatrix sl;
-    if (!device_build_sliced(S, sl, (int)nrows_, (int)ncols_, nnz_, dptr, didx, dval, s)) return false;
-    if (!(sl.dominant_fraction <= 1.5 / sl.nslices)) return false;                     // gathers with locality: host path
+    const bool slices = device_build_sliced(S, sl, (int)nrows_, (int)ncols_, nnz_, dptr, didx, dval, s);
+    if (!slices || !(sl.dominant_fraction <= 1.5 / sl.nslices))
+        return build_device_local(S, nrows_, ncols_, nnz_, dptr, didx, dval, slices ? sl.dominant_fraction : 1.0, s);
     nrows = (int)nrows_; ncols = (int)ncols_; nnz = nnz_;
     set_geometry(nrows_, ncols_);
     nlong = 0; nseg = 0;

@@ -271,7 +271,8 @@ class KktContext:
         keys = ("use_sliced", "use_sorted", "use_sorted_fused", "nlong", "sliced_built", "R", "nslices", "nrb", "nrows_pad",
                 "max_tile", "dominant_bits", "sorted_built", "so_nslices", "so_nsub", "so_nrb", "so_RB", "so_nrows_pad",
                 "so_max_sub", "so_slice_elems", "so_fused", "nnz", "P", "G", "RTQ", "use_acc", "acc_built", "acc_nslices", "acc_nrb",
-                "acc_RB", "acc_nrows_pad", "acc_slice_elems", "acc_nbatches", "acc_deferred")
+                "acc_RB", "acc_nrows_pad", "acc_slice_elems", "acc_nbatches", "acc_deferred", "use_acc_fused", "accf_built", "accf_nrb", "accf_RB",
+                "accf_nbatches", "use_plain")
         d = {k: int(v) for k, v in zip(keys, info)}
         d["dominant_fraction"] = float(np.array([d.pop("dominant_bits")], dtype=np.int64).view(np.float64)[0])
         return d, [float(v) for v in ms]
@@ -279,7 +280,7 @@ class KktContext:
     def layout_array(self, which, array):
         """One array of the device layouts as numpy (see ipxk_layout_array)."""
         dt = (np.uint32, np.uint8, np.int32, np.float64, np.uint32, np.uint8, np.uint32, np.float64, np.int32, np.int32, np.float64,
-              np.uint32, np.uint32, np.uint32, np.float64)[array]
+              np.uint32, np.uint32, np.uint32, np.float64, np.uint32, np.uint32, np.uint32, np.float64, np.int32, np.int32)[array]
         nb = C.c_int64(0)
         self._check(self.lib.ipxk_layout_array(self.h, which, array, None, 0, C.byref(nb)))
         out = np.zeros(nb.value // np.dtype(dt).itemsize, dtype=dt)

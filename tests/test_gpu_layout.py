@@ -126,3 +126,42 @@ def test_matrices_outside_the_device_path_take_the_host_builders():
     c = kkt.KktContext(A, device=0)
     assert c.num_dense_cols == 4
     c.close()
+
+
+def test_device_layouts_of_matrices_with_locality_equal_host_layouts():
+    """matrices whose gathers have locality (banded) or whose gathered vector fits an XCD's L2: the fused tiles, the fused sorted
+    tiles and the fused accumulated tiles built on the device against the host builders (forced one by one with
+    IPXK_SPMV_LAYOUT), array by array; and the products of either context against the phased layout's, bit for bit"""
+    cases = [synth.banded_lp(30000, 70000, 8, 2048, 7), synth.banded_lp(200000, 450000, 8, 4096, 8), synth.synthetic_lp(20000, 45000, 8, 4)]
+    rng = np.random.default_rng(3)
+    for A in cases:
+        dev = _ctx(A, "device", {})
+        W = rng.uniform(0.1, 10.0, A.nrow + A.ncol)
+        y = rng.standard_normal(A.nrow)
+        dev.normal_prepare(W)
+        ld, dd = dev.normal_apply(y)
+        try:
+            for which in (0, 1):
+                idv, _ = dev.layout_info(which)
+                assert idv["use_sliced"] == 1 and idv["sliced_built"] == 1 and idv["nslices"] == 1, idv
+            for layout, ids in (("fused", (0, 1, 2, 3)), ("sortedfused", (4, 5, 6, 7, 20)), ("accfused", (15, 16, 17, 18, 19)), ("phased", ())):
+                host = _ctx(A, "host", {"IPXK_SPMV_LAYOUT": layout})
+                try:
+                    for which in (0, 1):
+                        ih, _ = host.layout_info(which)
+                        idv, _ = dev.layout_info(which)
+                        built = {"fused": ih["sliced_built"], "sortedfused": ih["sorted_built"], "accfused": ih["accf_built"], "phased": 1}[layout]
+                        dbuilt = {"fused": idv["sliced_built"], "sortedfused": idv["sorted_built"], "accfused": idv["accf_built"], "phased": 1}[layout]
+                        assert built == dbuilt, (layout, which, ih, idv)
+                        if not built:
+                            continue
+                        for a in ids:
+                            x, z = host.layout_array(which, a), dev.layout_array(which, a)
+                            assert x.shape == z.shape and x.size > 0 and np.array_equal(x, z), (layout, which, a, x.shape, z.shape)
+                    host.normal_prepare(W)
+                    lh, dh = host.normal_apply(y)
+                    assert np.array_equal(lh, ld), layout            # every one of these layouts sums a row in storage order
+                finally:
+                    host.close()
+        finally:
+            dev.close()
