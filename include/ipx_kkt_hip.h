@@ -252,6 +252,8 @@ typedef struct {
   double seconds_singletons, seconds_bump, seconds_assemble;
   ipxint spikes;            /* columns torn off a bump beyond the dense limit (0: the bump
                                was factorized as it stood); then bump == spikes */
+  ipxint sparse_pivots, sparse_rounds; /* pivots and rounds of the sparse elimination of a bump
+                               beyond the dense limit (0: none) */
 } ipxk_lu_info;
 int ipxk_lu_factorize(ipxk_context* ctx, ipxint dim, const ipxint* Bbegin,
                       const ipxint* Bend, const ipxint* Bi, const double* Bx,

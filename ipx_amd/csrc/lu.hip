@@ -767,6 +767,241 @@ __global__ __launch_bounds__(kBlock) void lu_trailing_kernel(Dense A, int c1, in
     }
 }
 
+// ---- elimination rounds ---------------------------------------------------------------------------
+// (2c in the header comment.)  The CURRENT matrix of a round is a compact problem of its own: rows and columns renumbered to the
+// active ones in ascending order (grow / gcol: their indices in B), every entry active, CSC plus a row-wise index.
+struct Sparse {
+    int dim;
+    const int *Bp, *Bi, *colof;
+    const double* Bx;
+    const int *Rp, *Rj, *Rpos;
+    const int *rc, *cc;
+    int *candrow, *cost;
+    u64 *key, *rowbest;
+    int* stats;           // [0] cheapest cost, [1] # candidates, [2] cost limit, [3] # winners, [8 + b] # candidates of cost < 2^b
+    double abstol, pivottol;
+};
+constexpr int kSpStats = 48;
+// one candidate per column: among its entries that pass the absolute and the relative threshold, the one in the shortest row
+// (ties: larger |entry|, then smaller row); cost = (row count - 1)(column count - 1)
+__global__ __launch_bounds__(kBlock) void sp_cand_kernel(Sparse S) {
+    __shared__ int s_hist[33], s_min, s_n;
+    if (threadIdx.x < 33) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_min = INT_MAX; s_n = 0; }
+    __syncthreads();
+    IPXK_GRID_STRIDE(j, S.dim) {
+        const int p0 = S.Bp[j], p1 = S.Bp[j + 1];
+        double colmax = 0.0;
+        for (int p = p0; p < p1; p++) colmax = fmax(colmax, fabs(S.Bx[p]));
+        int bi = -1, brc = 0;
+        double ba = 0.0;
+        const double rel = S.pivottol * colmax;
+        for (int p = p0; p < p1; p++) {
+            const double a = fabs(S.Bx[p]);
+            if (!(a >= S.abstol && a >= rel)) continue;
+            const int i = S.Bi[p], r = S.rc[i];
+            if (bi < 0 || r < brc || (r == brc && (a > ba || (a == ba && i < bi)))) { bi = i; brc = r; ba = a; }
+        }
+        S.candrow[j] = bi;
+        S.key[j] = kNoKey;
+        if (bi < 0) continue;
+        const long long c64 = (long long)(brc - 1) * (long long)(p1 - p0 - 1);
+        const int c = (int)(c64 < 0x7fffffffLL ? c64 : 0x7fffffffLL);
+        S.cost[j] = c;
+        atomicMin(&s_min, c);
+        atomicAdd(&s_hist[c == 0 ? 0 : 32 - __clz(c)], 1);
+        atomicAdd(&s_n, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 33 && s_hist[threadIdx.x]) atomicAdd(S.stats + 8 + threadIdx.x, s_hist[threadIdx.x]);
+    if (threadIdx.x == 0 && s_n) { atomicMin(S.stats + 0, s_min); atomicAdd(S.stats + 1, s_n); }
+}
+// the candidates that cost at most max(4, twice the cheapest) compete, and at least a quarter of all candidates (the smallest
+// power of two that admits so many)
+__global__ void sp_limit_kernel(int* stats) {
+    if (blockIdx.x || threadIdx.x) return;
+    const long long ncand = stats[1];
+    long long limit = -1;
+    if (ncand > 0) {
+        limit = 2LL * stats[0] > 4 ? 2LL * stats[0] : 4;
+        long long cum = 0;
+        for (int b = 0; b <= 32; b++) {
+            cum += stats[8 + b];
+            if (cum * 4 >= ncand) { const long long q = (1LL << b) - 1; if (q > limit) limit = q; break; }
+        }
+        if (limit > 0x7fffffffLL) limit = 0x7fffffffLL;
+    }
+    stats[2] = (int)limit;
+}
+// a row keeps its best candidate (cost, then column index)
+__global__ void sp_key_kernel(Sparse S) {
+    const int limit = S.stats[2];
+    IPXK_GRID_STRIDE(j, S.dim) {
+        if (S.candrow[j] < 0 || S.cost[j] > limit) continue;
+        const u64 k = ((u64)(unsigned)S.cost[j] << 32) | (unsigned)j;
+        S.key[j] = k;
+        atomicMin(S.rowbest + S.candrow[j], k);
+    }
+}
+// a contender (the best of its row) wins unless a better contender has an entry in its pivot row or its pivot row in this
+// column: the winners' pivots form a diagonal block.  nupd: the products a winner sends out (pivot row x pivot column, all pairs).
+__global__ void sp_win_kernel(Sparse S, int* __restrict__ winner, int* __restrict__ nupd, int* bad) {
+    IPXK_GRID_STRIDE(j, S.dim) {
+        const u64 k = S.key[j];
+        bool win = false;
+        int i = -1;
+        if (k != kNoKey && S.rowbest[S.candrow[j]] == k) {
+            win = true;
+            i = S.candrow[j];
+            for (int q = S.Rp[i]; q < S.Rp[i + 1] && win; q++) {
+                const int j2 = S.Rj[q];
+                if (j2 == (int)j) continue;
+                const u64 k2 = S.key[j2];
+                if (k2 < k && S.rowbest[S.candrow[j2]] == k2) win = false;       // (k2 < k implies k2 is a key)
+            }
+            for (int p = S.Bp[j]; p < S.Bp[j + 1] && win; p++)
+                if (S.Bi[p] != i && S.rowbest[S.Bi[p]] < k) win = false;
+        }
+        winner[j] = win ? 1 : 0;
+        int n = 0;
+        if (win) {
+            const long long n64 = (long long)S.rc[i] * S.cc[j];
+            if (n64 > (1LL << 28)) *bad = 1; else n = (int)n64;
+            atomicAdd(S.stats + 3, 1);
+        }
+        nupd[j] = n;
+    }
+}
+struct SparseGlobal {     // where a round's pivots are recorded: the arrays of the singleton rounds, indexed as B is
+    int *rstage, *cstage, *pivrow;
+    double* pivot;
+    unsigned char* ckind;
+};
+__global__ void sp_commit_kernel(Sparse S, const int* __restrict__ winner, const int* __restrict__ grow, const int* __restrict__ gcol,
+                                 int tag, SparseGlobal G, int* __restrict__ rstL, int* __restrict__ cstL, double* __restrict__ pivl) {
+    IPXK_GRID_STRIDE(j, S.dim) {
+        if (!winner[j]) continue;
+        const int i = S.candrow[j];
+        double piv = 0.0;
+        for (int p = S.Bp[j]; p < S.Bp[j + 1]; p++)
+            if (S.Bi[p] == i) piv = S.Bx[p];
+        pivl[j] = piv;
+        rstL[i] = tag;
+        cstL[j] = tag;
+        const int gi = grow[i], gj = gcol[j];
+        G.rstage[gi] = tag;
+        G.cstage[gj] = tag;
+        G.pivrow[gj] = gi;
+        G.pivot[gj] = piv;
+        G.ckind[gj] = 5;
+    }
+}
+// the indices in B of the rows (columns) that stay
+__global__ void sp_map_kernel(int n, const int* __restrict__ list, const int* __restrict__ gold, int* __restrict__ gnew) {
+    IPXK_GRID_STRIDE(r, n) gnew[r] = gold ? gold[list[r]] : list[r];
+}
+// the entries of the current matrix: those whose row and column stay are keyed (new column | new row) for the next matrix, the
+// others join the list of finished entries with their indices in B and their present values
+__global__ void sp_entries_kernel(int64_t nnz, const int* __restrict__ Bi, const int* __restrict__ colof, const double* __restrict__ Bx,
+                                  const int* __restrict__ newrow, const int* __restrict__ newcol, const int* __restrict__ grow,
+                                  const int* __restrict__ gcol, u64* __restrict__ key, double* __restrict__ val, int* cursor,
+                                  int* __restrict__ Erow, int* __restrict__ Ecol, double* __restrict__ Eval) {
+    IPXK_GRID_STRIDE(p, nnz) {
+        const int i = Bi[p], j = colof[p];
+        const int nr = newrow[i], nc = newcol[j];
+        if (nr >= 0 && nc >= 0) {
+            key[p] = ((u64)(unsigned)nc << 32) | (unsigned)nr;
+            val[p] = Bx[p];
+        } else {
+            key[p] = kNoKey;
+            val[p] = 0.0;
+            const int at = atomicAdd(cursor, 1);              // (the order is irrelevant: the assembly sorts by key)
+            Erow[at] = grow ? grow[i] : i;
+            Ecol[at] = gcol ? gcol[j] : j;
+            Eval[at] = Bx[p];
+        }
+    }
+}
+// the updates -(a_i'j / pivot) * a_ij' of the winners, behind the entries, winner after winner in ascending order of the column
+// (the sort is stable: equal positions are then summed in that order); one wavefront per winner
+__global__ __launch_bounds__(kBlock) void sp_updates_kernel(Sparse S, const int* __restrict__ winner, const int* __restrict__ uoff,
+                                                            const double* __restrict__ pivl, const int* __restrict__ newrow,
+                                                            const int* __restrict__ newcol, int64_t base, u64* __restrict__ key,
+                                                            double* __restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t j = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); j < S.dim; j += (int64_t)gridDim.x * (kBlock / 64)) {
+        if (!winner[j]) continue;
+        const int i = S.candrow[j], p0 = S.Bp[j], q0 = S.Rp[i], np = S.Bp[j + 1] - p0, nq = S.Rp[i + 1] - q0;
+        const double piv = pivl[j];
+        const int64_t at = base + uoff[j];
+        for (int t = lane; t < np * nq; t += 64) {
+            const int pi = t / nq, qi = t - pi * nq;
+            const int p = p0 + pi, q = q0 + qi;
+            const int i2 = S.Bi[p], j2 = S.Rj[q];
+            if (i2 == i || j2 == (int)j) { key[at + t] = kNoKey; val[at + t] = 0.0; continue; }
+            const double l = S.Bx[p] / piv;
+            const double prod = l * S.Bx[S.Rpos[q]];
+            key[at + t] = ((u64)(unsigned)newcol[j2] << 32) | (unsigned)newrow[i2];
+            val[at + t] = -prod;
+        }
+    }
+}
+// equal keys are summed in order; a sum that is exactly zero leaves the pattern
+__global__ void sp_combine_kernel(int64_t n, const u64* __restrict__ key, const double* __restrict__ val, int* __restrict__ flag,
+                                  double* __restrict__ sum) {
+    IPXK_GRID_STRIDE(e, n + 1) {
+        int keep = 0;
+        if (e < n) {
+            const u64 k = key[e];
+            if (k != kNoKey && (e == 0 || key[e - 1] != k)) {
+                double acc = val[e];
+                for (int64_t f = e + 1; f < n && key[f] == k; f++) acc = acc + val[f];
+                sum[e] = acc;
+                keep = acc != 0.0;
+            }
+        }
+        flag[e] = keep;
+    }
+}
+__global__ void sp_compact_kernel(int64_t n, const u64* __restrict__ key, const int* __restrict__ flag, const int* __restrict__ pos,
+                                  const double* __restrict__ sum, int* __restrict__ Bi, int* __restrict__ colof, double* __restrict__ Bx) {
+    IPXK_GRID_STRIDE(e, n) {
+        if (!flag[e]) continue;
+        const int at = pos[e];
+        Bi[at] = (int)(key[e] & 0xffffffffull);
+        colof[at] = (int)(key[e] >> 32);
+        Bx[at] = sum[e];
+    }
+}
+// column pointers from the (sorted) columns of the entries
+__global__ void sp_colptr_kernel(int dim, int nnz, const int* __restrict__ colof, int* __restrict__ Bp) {
+    IPXK_GRID_STRIDE(j, (int64_t)dim + 1) {
+        int lo = 0, hi = nnz;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (colof[mid] < (int)j) lo = mid + 1; else hi = mid;
+        }
+        Bp[j] = lo;
+    }
+}
+// the dense block's columns in ascending order of their number of entries (ties: index)
+__global__ void sp_colorder_keys_kernel(int kb, const int* __restrict__ cc, u64* __restrict__ keys) {
+    IPXK_GRID_STRIDE(c, kb) keys[c] = ((u64)(unsigned)cc[c] << 32) | (unsigned)c;
+}
+__global__ void sp_colorder_apply_kernel(int kb, const u64* __restrict__ sorted, const int* __restrict__ gcol, int* __restrict__ bcol,
+                                         int* __restrict__ cloc, int* __restrict__ cposl) {
+    IPXK_GRID_STRIDE(t, kb) {
+        const int c = (int)(sorted[t] & 0xffffffffull);
+        bcol[t] = gcol[c];
+        cloc[gcol[c]] = (int)t;
+        cposl[c] = (int)t;
+    }
+}
+__global__ void sp_dense_fill_kernel(int64_t nnz, int kb, const int* __restrict__ Bi, const int* __restrict__ colof, const double* __restrict__ Bx,
+                                     const int* __restrict__ cposl, double* __restrict__ D) {
+    IPXK_GRID_STRIDE(p, nnz) D[(size_t)cposl[colof[p]] * kb + Bi[p]] = Bx[p];
+}
+
 // stages of the bump's pivots; dependent columns and left-over rows are flagged for the ranking that follows
 __global__ void lu_bump_stage_kernel(int kb, int base, const int* __restrict__ step, const int* __restrict__ list,
                                      int* __restrict__ stage, int* __restrict__ flag, unsigned char* kind) {
@@ -915,6 +1150,18 @@ struct LuWork {
     DevBuf<double> X, spk_v;
     DevBuf<int> Bp, Bi, cnt;          // B = AI[:, basis] (ipxk_lu_factorize_basis)
     DevBuf<double> Bx;
+    // elimination rounds: the current matrix (two copies, used alternately), its row-wise index, the round's scratch, and the
+    // list E of the entries that have left the current matrix (indices in B, value at that time)
+    struct Sp {
+        DevBuf<int> Bp[2], Bi[2], colof[2], grow[2], gcol[2];
+        DevBuf<double> Bx[2];
+        DevBuf<int> Rp, Rj, Rpos, rc, cc, k32a, k32b, pos;
+        DevBuf<int> candrow, cost, winner, nupd, uoff, rstL, cstL, flag, rank, newrow, newcol, listr, listc, stats, cflag, cpos, cposl, ecur;
+        DevBuf<u64> key, rowbest, skey, skey2, okey, okey2;
+        DevBuf<double> pivl, sval, sval2, csum;
+        DevBuf<int> Erow, Ecol;
+        DevBuf<double> Eval;
+    } sp;
     Tmp T;
     int* h = nullptr;                 // pinned: counters read back per batch of rounds
     ~LuWork() { if (h) (void)hipHostFree(h); }
@@ -942,10 +1189,162 @@ static LuState* lu_state(Context* c) {
     return c->lu;
 }
 
+namespace {
+__global__ void sp_stats_init_kernel(int* stats) {
+    if (blockIdx.x == 0 && threadIdx.x < kSpStats) stats[threadIdx.x] = threadIdx.x == 0 ? INT_MAX : 0;
+}
+struct SparseOut {
+    int kb = 0, cur = 0, pivots = 0, rounds = 0;
+    int64_t nnz = 0, ne = 0;
+};
+// sorted (key, value) pairs -> the next current matrix in copy `dst`: equal keys summed in order, exact zeros dropped, column
+// pointers, row-wise index, counts.  Reads back the number of entries (and the length of E).
+void sp_finish_matrix(hipStream_t s, LuWork& W, int64_t n, int dimL, int dst, int* h, int64_t* nnz_out, int64_t* ne_out) {
+    LuWork::Sp& P = W.sp;
+    Tmp& T = W.T;
+    P.cflag.ensure((size_t)n + 1); P.cpos.ensure((size_t)n + 1); P.csum.ensure((size_t)std::max<int64_t>(n, 1));
+    if (n > 0) sort_keys(T, P.skey.get(), P.skey2.get(), P.sval.get(), P.sval2.get(), (size_t)n, 32 + bits_for(std::max(dimL, 2)), s);
+    hipLaunchKernelGGL(sp_combine_kernel, dim3(grid_for(n + 1)), dim3(kBlock), 0, s, n, P.skey2.get(), P.sval2.get(), P.cflag.get(), P.csum.get());
+    scan_exclusive(T, P.cflag.get(), P.cpos.get(), (size_t)n + 1, s);
+    IPXK_HIP(hipMemcpyAsync(h, P.cpos.get() + n, sizeof(int), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipMemcpyAsync(h + 1, P.ecur.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    const int64_t nnz = h[0];
+    *nnz_out = nnz;
+    *ne_out = h[1];
+    const size_t z1 = (size_t)std::max<int64_t>(nnz, 1), d1 = (size_t)std::max(dimL, 1);
+    P.Bi[dst].ensure(z1); P.colof[dst].ensure(z1); P.Bx[dst].ensure(z1); P.Bp[dst].ensure(d1 + 1);
+    if (n > 0)
+        hipLaunchKernelGGL(sp_compact_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, n, P.skey2.get(), P.cflag.get(), P.cpos.get(), P.csum.get(),
+                           P.Bi[dst].get(), P.colof[dst].get(), P.Bx[dst].get());
+    hipLaunchKernelGGL(sp_colptr_kernel, dim3(grid_for(dimL + 1)), dim3(kBlock), 0, s, dimL, (int)nnz, P.colof[dst].get(), P.Bp[dst].get());
+    // rows
+    P.rc.ensure(d1 + 1); P.cc.ensure(d1); P.Rp.ensure(d1 + 1);
+    for (DevBuf<int>* b : {&P.k32a, &P.k32b, &P.pos, &P.Rpos, &P.Rj}) b->ensure(z1);
+    IPXK_HIP(hipMemsetAsync(P.rc.get(), 0, (d1 + 1) * sizeof(int), s));
+    if (dimL > 0)
+        hipLaunchKernelGGL(lu_expand_kernel, dim3(grid_for(dimL)), dim3(kBlock), 0, s, dimL, P.Bp[dst].get(), P.Bi[dst].get(), P.colof[dst].get(),
+                           P.k32a.get(), P.pos.get(), P.rc.get(), P.cc.get(), P.stats.get() + 41);
+    if (nnz > 0) {
+        size_t bytes = 0;
+        const unsigned bits = (unsigned)bits_for(std::max(dimL, 2));
+        IPXK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, P.k32a.get(), P.k32b.get(), P.pos.get(), P.Rpos.get(), (size_t)nnz, 0u, bits, s));
+        IPXK_HIP(rocprim::radix_sort_pairs(T.need(bytes), bytes, P.k32a.get(), P.k32b.get(), P.pos.get(), P.Rpos.get(), (size_t)nnz, 0u, bits, s));
+        hipLaunchKernelGGL(lu_rows_kernel, dim3(grid_for(nnz)), dim3(kBlock), 0, s, nnz, P.Rpos.get(), P.colof[dst].get(), P.Rj.get());
+    }
+    scan_exclusive(T, P.rc.get(), P.Rp.get(), d1 + 1, s);
+}
+
+// 2c. ELIMINATION ROUNDS.  The singleton rounds have stalled with `nact` active rows and columns of B (rstage / cstage < 0).
+// Until at most sparse_min are left (or no column has an acceptable pivot), a round picks pivots of low Markowitz cost that
+// form a diagonal block, eliminates them at once and builds the next current matrix (see the kernels).  On return the current
+// matrix (copy out.cur: out.kb rows, out.nnz entries, local indices = rank among the rows / columns of B that are still
+// active) is what the dense code takes over, and W.sp.E* (out.ne entries) replaces B in the assembly.
+SparseOut sparse_rounds(hipStream_t s, LuWork& W, int dim, int64_t nb, const int* Bi, const int* colof, const double* Bx, SparseGlobal G,
+                        int nact, int sparse_min, int* rounds, double abstol, double pivottol, int* h) {
+    LuWork::Sp& P = W.sp;
+    Tmp& T = W.T;
+    SparseOut out;
+    const int g = grid_for(dim);
+    const size_t d1 = (size_t)std::max(dim, 1);
+    const bool verbose = getenv("IPXK_VERBOSE") && atoi(getenv("IPXK_VERBOSE")) >= 2;
+    P.stats.ensure(kSpStats); P.ecur.ensure(1);
+    IPXK_HIP(hipMemsetAsync(P.ecur.get(), 0, sizeof(int), s));
+    IPXK_HIP(hipMemsetAsync(P.stats.get(), 0, kSpStats * sizeof(int), s));
+    // the active submatrix of B, renumbered; everything else of B is finished
+    W.rloc.ensure(d1); W.cloc.ensure(d1); W.flag.ensure(d1); W.rank.ensure(d1);
+    int dimL = nact, cur = 0;
+    P.grow[0].ensure((size_t)std::max(dimL, 1)); P.gcol[0].ensure((size_t)std::max(dimL, 1));
+    hipLaunchKernelGGL(lu_active_flag_kernel, dim3(g), dim3(kBlock), 0, s, dim, G.rstage, W.flag.get());
+    scan_exclusive(T, W.flag.get(), W.rank.get(), (size_t)dim, s);
+    hipLaunchKernelGGL(lu_compact_kernel, dim3(g), dim3(kBlock), 0, s, dim, W.flag.get(), W.rank.get(), W.rloc.get(), P.grow[0].get());
+    hipLaunchKernelGGL(lu_active_flag_kernel, dim3(g), dim3(kBlock), 0, s, dim, G.cstage, W.flag.get());
+    scan_exclusive(T, W.flag.get(), W.rank.get(), (size_t)dim, s);
+    hipLaunchKernelGGL(lu_compact_kernel, dim3(g), dim3(kBlock), 0, s, dim, W.flag.get(), W.rank.get(), W.cloc.get(), P.gcol[0].get());
+    const size_t nz1 = (size_t)std::max<int64_t>(nb, 1);
+    for (DevBuf<u64>* b : {&P.skey, &P.skey2}) b->ensure(nz1);
+    for (DevBuf<double>* b : {&P.sval, &P.sval2}) b->ensure(nz1);
+    P.Erow.ensure(nz1); P.Ecol.ensure(nz1); P.Eval.ensure(nz1);
+    hipLaunchKernelGGL(sp_entries_kernel, dim3(grid_for(nb)), dim3(kBlock), 0, s, nb, Bi, colof, Bx, W.rloc.get(), W.cloc.get(), (const int*)nullptr,
+                       (const int*)nullptr, P.skey.get(), P.sval.get(), P.ecur.get(), P.Erow.get(), P.Ecol.get(), P.Eval.get());
+    int64_t nnz = 0, ne = 0;
+    sp_finish_matrix(s, W, nb, dimL, cur, h, &nnz, &ne);
+    while (dimL > sparse_min) {
+        const size_t l1 = (size_t)dimL;
+        for (DevBuf<int>* b : {&P.candrow, &P.cost, &P.winner, &P.rstL, &P.cstL, &P.flag, &P.rank, &P.newrow, &P.newcol, &P.listr, &P.listc}) b->ensure(l1);
+        P.nupd.ensure(l1 + 1); P.uoff.ensure(l1 + 1); P.key.ensure(l1); P.rowbest.ensure(l1); P.pivl.ensure(l1);
+        Sparse S{dimL, P.Bp[cur].get(), P.Bi[cur].get(), P.colof[cur].get(), P.Bx[cur].get(), P.Rp.get(), P.Rj.get(), P.Rpos.get(), P.rc.get(),
+                 P.cc.get(), P.candrow.get(), P.cost.get(), P.key.get(), P.rowbest.get(), P.stats.get(), abstol, pivottol};
+        const int gl = grid_for(dimL);
+        hipLaunchKernelGGL(sp_stats_init_kernel, dim3(1), dim3(64), 0, s, P.stats.get());
+        hipLaunchKernelGGL(lu_fill_u64_kernel, dim3(gl), dim3(kBlock), 0, s, (int64_t)dimL, kNoKey, P.rowbest.get());
+        hipLaunchKernelGGL(lu_fill_int_kernel, dim3(gl), dim3(kBlock), 0, s, (int64_t)dimL, -1, P.rstL.get());
+        hipLaunchKernelGGL(lu_fill_int_kernel, dim3(gl), dim3(kBlock), 0, s, (int64_t)dimL, -1, P.cstL.get());
+        IPXK_HIP(hipMemsetAsync(P.nupd.get(), 0, (l1 + 1) * sizeof(int), s));
+        hipLaunchKernelGGL(sp_cand_kernel, dim3(gl), dim3(kBlock), 0, s, S);
+        hipLaunchKernelGGL(sp_limit_kernel, dim3(1), dim3(64), 0, s, P.stats.get());
+        hipLaunchKernelGGL(sp_key_kernel, dim3(gl), dim3(kBlock), 0, s, S);
+        hipLaunchKernelGGL(sp_win_kernel, dim3(gl), dim3(kBlock), 0, s, S, P.winner.get(), P.nupd.get(), P.stats.get() + 40);
+        scan_exclusive(T, P.nupd.get(), P.uoff.get(), l1 + 1, s);
+        IPXK_HIP(hipMemcpyAsync(h, P.stats.get(), kSpStats * sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipMemcpyAsync(h + kSpStats, P.uoff.get() + dimL, sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        const int nwin = h[3];
+        const int64_t nupd = h[kSpStats];
+        if (h[40]) throw Error(IPXK_E_UNSUPPORTED, "LU: a pivot of an elimination round would send out more than 2^28 updates");
+        if (verbose)
+            fprintf(stderr, "ipxk: elimination round %d: active %d nnz %lld cheapest %d limit %d candidates %d winners %d updates %lld\n", out.rounds + 1, dimL,
+                    (long long)nnz, h[0], h[2], h[1], nwin, (long long)nupd);
+        if (nwin == 0) break;                      // no column has an acceptable pivot: what is left goes to the dense block
+        const int tag = 2 * (*rounds);
+        (*rounds)++;
+        out.rounds++;
+        out.pivots += nwin;
+        hipLaunchKernelGGL(sp_commit_kernel, dim3(gl), dim3(kBlock), 0, s, S, P.winner.get(), P.grow[cur].get(), P.gcol[cur].get(), tag, G, P.rstL.get(),
+                           P.cstL.get(), P.pivl.get());
+        // the rows and columns that stay, renumbered in order
+        const int dimN = dimL - nwin, nxt = 1 - cur;
+        P.grow[nxt].ensure((size_t)std::max(dimN, 1)); P.gcol[nxt].ensure((size_t)std::max(dimN, 1));
+        hipLaunchKernelGGL(lu_active_flag_kernel, dim3(gl), dim3(kBlock), 0, s, dimL, P.rstL.get(), P.flag.get());
+        scan_exclusive(T, P.flag.get(), P.rank.get(), l1, s);
+        hipLaunchKernelGGL(lu_compact_kernel, dim3(gl), dim3(kBlock), 0, s, dimL, P.flag.get(), P.rank.get(), P.newrow.get(), P.listr.get());
+        hipLaunchKernelGGL(lu_active_flag_kernel, dim3(gl), dim3(kBlock), 0, s, dimL, P.cstL.get(), P.flag.get());
+        scan_exclusive(T, P.flag.get(), P.rank.get(), l1, s);
+        hipLaunchKernelGGL(lu_compact_kernel, dim3(gl), dim3(kBlock), 0, s, dimL, P.flag.get(), P.rank.get(), P.newcol.get(), P.listc.get());
+        if (dimN > 0) {
+            hipLaunchKernelGGL(sp_map_kernel, dim3(grid_for(dimN)), dim3(kBlock), 0, s, dimN, P.listr.get(), P.grow[cur].get(), P.grow[nxt].get());
+            hipLaunchKernelGGL(sp_map_kernel, dim3(grid_for(dimN)), dim3(kBlock), 0, s, dimN, P.listc.get(), P.gcol[cur].get(), P.gcol[nxt].get());
+        }
+        const int64_t n = nnz + nupd;
+        IPXK_REQUIRE(n < (int64_t(1) << 31), "LU: the current matrix of an elimination round exceeds 32-bit positions");
+        for (DevBuf<u64>* b : {&P.skey, &P.skey2}) b->ensure((size_t)std::max<int64_t>(n, 1));
+        for (DevBuf<double>* b : {&P.sval, &P.sval2}) b->ensure((size_t)std::max<int64_t>(n, 1));
+        grow_keep(P.Erow, (size_t)ne, (size_t)(ne + nnz), s);
+        grow_keep(P.Ecol, (size_t)ne, (size_t)(ne + nnz), s);
+        grow_keep(P.Eval, (size_t)ne, (size_t)(ne + nnz), s);
+        if (nnz > 0)
+            hipLaunchKernelGGL(sp_entries_kernel, dim3(grid_for(nnz)), dim3(kBlock), 0, s, nnz, P.Bi[cur].get(), P.colof[cur].get(), P.Bx[cur].get(),
+                               P.newrow.get(), P.newcol.get(), P.grow[cur].get(), P.gcol[cur].get(), P.skey.get(), P.sval.get(), P.ecur.get(),
+                               P.Erow.get(), P.Ecol.get(), P.Eval.get());
+        if (nupd > 0) {
+            const int wgs = (int)std::min<int64_t>(4096, ((int64_t)dimL + kBlock / 64 - 1) / (kBlock / 64));
+            hipLaunchKernelGGL(sp_updates_kernel, dim3(wgs), dim3(kBlock), 0, s, S, P.winner.get(), P.uoff.get(), P.pivl.get(), P.newrow.get(),
+                               P.newcol.get(), nnz, P.skey.get(), P.sval.get());
+        }
+        sp_finish_matrix(s, W, n, dimN, nxt, h, &nnz, &ne);
+        cur = nxt;
+        dimL = dimN;
+    }
+    out.kb = dimL; out.cur = cur; out.nnz = nnz; out.ne = ne;
+    return out;
+}
+}  // namespace
+
 // B as compact 32-bit CSC on the device -> factors in S
-static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, const int* Bp, const int* Bi,
+static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, const int* Bp, const int* Bi,
                                 const double* Bx, double pivottol, bool strict, ipxk_lu_info* info) {
     hipStream_t s = c->stream;
+    int64_t nb = nb_in;
     S->valid = false;
     S->dim = dim;
     ipxk_lu_info I{};
@@ -964,7 +1363,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
     for (DevBuf<int>* b : {&rstage, &cstage, &rc, &cc, &cand, &flag, &rank, &claim, &pivrow}) b->ensure(d1);
     Rp.ensure(d1 + 1); counters.ensure(32);
     cand_bits.ensure(d1); claim_abs.ensure(d1); pivot.ensure(d1); ckind.ensure(d1);
-    if (!W.h) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&W.h), 32 * sizeof(int)));
+    if (!W.h) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&W.h), 64 * sizeof(int)));
     int* h = W.h;
     IPXK_HIP(hipMemsetAsync(rc.get(), 0, d1 * sizeof(int), s));
     IPXK_HIP(hipMemsetAsync(counters.get(), 0, 32 * sizeof(int), s));
@@ -1001,6 +1400,12 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
     if (const char* e = getenv("IPXK_LU_BUMP_MAX")) kb_max = std::max(0, atoi(e));
     bool tearing = false;
     int ntorn = 0, tear_width = 1, npiv_at_tear = 0;
+    // a bump beyond the dense limit: elimination rounds (default) or tearing (IPXK_LU_SPARSE=0)
+    const bool sparse_mode = !(getenv("IPXK_LU_SPARSE") && getenv("IPXK_LU_SPARSE")[0] == '0');
+    int sparse_min = 2048;
+    if (const char* e = getenv("IPXK_LU_SPARSE_MIN")) sparse_min = std::max(0, atoi(e));
+    SparseOut sp;
+    bool sparse_done = false;
     while (dim > 0) {
         IPXK_HIP(hipMemsetAsync(counters.get() + 8, 0, batch * sizeof(int), s));
         for (int b = 0; b < batch; b++) {
@@ -1025,6 +1430,12 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
         IPXK_HIP(hipStreamSynchronize(s));
         const int npiv = h[1] + h[2], nact = dim - npiv - ntorn;
         if (nact == 0) break;
+        if (!tearing && nact > kb_max && sparse_mode) {                 // 2c. elimination rounds down to sparse_min rows
+            SparseGlobal G{rstage.get(), cstage.get(), pivrow.get(), pivot.get(), ckind.get()};
+            sp = sparse_rounds(s, W, dim, nb, Bi, colof.get(), Bx, G, nact, std::min(sparse_min, kb_max), &rounds, abstol, pivottol, h);
+            sparse_done = true;
+            break;
+        }
         if (!tearing) {
             if (nact <= kb_max) break;                                  // small enough: dense as it stands
             tearing = true;
@@ -1057,7 +1468,9 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
     }
     I.col_singletons = dim > 0 ? h[1] : 0;
     I.row_singletons = dim > 0 ? h[2] : 0;
-    const int npiv_sing = (int)(I.col_singletons + I.row_singletons);
+    I.sparse_pivots = sp.pivots;
+    I.sparse_rounds = sp.rounds;
+    const int npiv_sing = (int)(I.col_singletons + I.row_singletons) + sp.pivots;       // all pivots before the dense block
     I.rounds = rounds;
     if (npiv_sing > 0) {           // dense stages: rounds in order, inside a round by index
         DevBuf<u64>& k1 = W.skey; DevBuf<u64>& k2 = W.skey2;
@@ -1103,7 +1516,21 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
         const int gk = grid_for(kb);
         hipLaunchKernelGGL(lu_fill_int_kernel, dim3(gk), dim3(kBlock), 0, s, (int64_t)kb, -1, brstep.get());
         hipLaunchKernelGGL(lu_fill_int_kernel, dim3(gk), dim3(kBlock), 0, s, (int64_t)kb, -1, bcstep.get());
-        if (!tearing) {
+        if (sparse_done) {
+            // the block's columns in ascending order of their number of entries (ties: index): fewer nonzeros in its factors
+            LuWork::Sp& P = W.sp;
+            IPXK_REQUIRE(sp.kb == kb, "LU: the elimination rounds and the stages disagree about what is left");
+            P.okey.ensure((size_t)kb); P.okey2.ensure((size_t)kb); P.cposl.ensure((size_t)kb);
+            hipLaunchKernelGGL(sp_colorder_keys_kernel, dim3(gk), dim3(kBlock), 0, s, kb, P.cc.get(), P.okey.get());
+            size_t bytes = 0;
+            IPXK_HIP(rocprim::radix_sort_keys(nullptr, bytes, P.okey.get(), P.okey2.get(), (size_t)kb, 0u, 64u, s));
+            IPXK_HIP(rocprim::radix_sort_keys(T.need(bytes), bytes, P.okey.get(), P.okey2.get(), (size_t)kb, 0u, 64u, s));
+            hipLaunchKernelGGL(sp_colorder_apply_kernel, dim3(gk), dim3(kBlock), 0, s, kb, P.okey2.get(), P.gcol[sp.cur].get(), bcol.get(), cloc.get(),
+                               P.cposl.get());
+            if (sp.nnz > 0)
+                hipLaunchKernelGGL(sp_dense_fill_kernel, dim3(grid_for(sp.nnz)), dim3(kBlock), 0, s, sp.nnz, kb, P.Bi[sp.cur].get(), P.colof[sp.cur].get(),
+                                   P.Bx[sp.cur].get(), P.cposl.get(), D.get());
+        } else if (!tearing) {
             hipLaunchKernelGGL(lu_dense_fill_kernel, dim3((kb + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, s, kb, bcol.get(), Bp, Bi, Bx,
                                rloc.get(), D.get());
         } else {
@@ -1244,6 +1671,13 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
     S->rowperm.ensure(d1); S->colperm.ensure(d1);
     S->Lp.ensure(d1 + 1); S->Up.ensure(d1 + 1);
     const int64_t kbsq = (int64_t)kb * kb;
+    // the entries outside the dense block: B itself, or (after elimination rounds) the list of the entries that left the
+    // current matrix, with the values they had then
+    const int64_t nbB = nb;
+    if (sparse_done) nb = sp.ne;
+    const int* asm_row = sparse_done ? W.sp.Erow.get() : Bi;
+    const int* asm_col = sparse_done ? W.sp.Ecol.get() : colof.get();
+    const double* asm_val = sparse_done ? W.sp.Eval.get() : Bx;
     const int64_t nl = nb + kbsq, nu = nb + kbsq + dim + nspk;
     int64_t lnz = 0, unz = 0;
     if (dim > 0) {
@@ -1255,7 +1689,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
         for (DevBuf<double>* b : {&uval, &uval2}) b->ensure((size_t)nu);
         if (nl > 0) hipLaunchKernelGGL(lu_fill_u64_kernel, dim3(grid_for(nl)), dim3(kBlock), 0, s, nl, kNoKey, lkey.get());
         hipLaunchKernelGGL(lu_fill_u64_kernel, dim3(grid_for(nu)), dim3(kBlock), 0, s, nu, kNoKey, ukey.get());
-        Assemble A{dim, kb, Bp, Bi, colof.get(), Bx, rstage.get(), cstage.get(), rloc.get(), cloc.get(), brow.get(), bcol.get(),
+        Assemble A{dim, kb, Bp, asm_row, asm_col, asm_val, rstage.get(), cstage.get(), rloc.get(), cloc.get(), brow.get(), bcol.get(),
                    bcstep.get(), pivot.get(), D.get(), ckind.get(), lkey.get(), ukey.get(), lval.get(), uval.get(), tearing ? 1 : 0};
         if (nb > 0) hipLaunchKernelGGL(lu_keys_sparse_kernel, dim3(grid_for(nb)), dim3(kBlock), 0, s, A, nb);
         if (kb > 0) hipLaunchKernelGGL(lu_keys_dense_kernel, dim3(grid_for(kbsq)), dim3(kBlock), 0, s, A, nb);
@@ -1300,7 +1734,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb, con
     if (info) *info = I;
     if (getenv("IPXK_VERBOSE"))
         fprintf(stderr, "ipxk: LU dim %d nnz %lld: %lld column + %lld row singletons in %d rounds (%.2f ms), bump %d (%.2f ms, %d dependent), "
-                "assembly %.2f ms; nnz(L) %lld nnz(U) %lld\n", dim, (long long)nb, (long long)I.col_singletons, (long long)I.row_singletons,
+                "assembly %.2f ms; nnz(L) %lld nnz(U) %lld\n", dim, (long long)nbB, (long long)I.col_singletons, (long long)I.row_singletons,
                 rounds, I.seconds_singletons * 1e3, kb, I.seconds_bump * 1e3, ndep, I.seconds_assemble * 1e3, (long long)lnz, (long long)unz);
 }
 

@@ -54,7 +54,8 @@ class CrDiag(C.Structure):
 class LuInfo(C.Structure):
     _fields_ = [("lnz", c_i64), ("unz", c_i64), ("num_dependent", c_i64), ("col_singletons", c_i64),
                 ("row_singletons", c_i64), ("bump", c_i64), ("rounds", c_i64), ("seconds_singletons", c_f64),
-                ("seconds_bump", c_f64), ("seconds_assemble", c_f64), ("spikes", c_i64)]
+                ("seconds_bump", c_f64), ("seconds_assemble", c_f64), ("spikes", c_i64), ("sparse_pivots", c_i64),
+                ("sparse_rounds", c_i64)]
 
 
 class MaxvolumeParams(C.Structure):

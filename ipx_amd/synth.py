@@ -410,6 +410,48 @@ def synthetic_maxvolume_state(status, spread=1.0, seed=12345):
     return d
 
 
+def basis_matrix_of(A, basis):
+    """B = [A I][:, basis] as dict(dim, Bp, Bi, Bx) (columns in storage order)"""
+    m, n = A.nrow, A.ncol
+    basis = np.asarray(basis, dtype=np.int64)
+    struct = basis < n
+    lens = np.where(struct, A.p[np.minimum(basis, n - 1) + 1] - A.p[np.minimum(basis, n - 1)], 1)
+    Bp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    Bi = np.empty(Bp[-1], dtype=np.int64)
+    Bx = np.empty(Bp[-1], dtype=np.float64)
+    # slack columns
+    sl = np.nonzero(~struct)[0]
+    Bi[Bp[sl]] = basis[sl] - n
+    Bx[Bp[sl]] = 1.0
+    st = np.nonzero(struct)[0]
+    if st.size:
+        src0 = A.p[basis[st]]
+        ln = lens[st]
+        off = np.arange(ln.sum()) - np.repeat(np.cumsum(ln) - ln, ln)
+        src = np.repeat(src0, ln) + off
+        dst = np.repeat(Bp[st], ln) + off
+        Bi[dst] = A.i[src]
+        Bx[dst] = A.x[src]
+    return dict(dim=m, Bp=Bp, Bi=Bi, Bx=Bx)
+
+
+def misplaced_basis(m, num_misplaced, seed=12345, **kw):
+    """lp_like_basis(m, 2m) after `num_misplaced` basis exchanges at random positions (a random nonbasic structural column
+    each): what a crossover-free IPM's basis looks like after Maxvolume has moved it -- the singleton rounds stall on a
+    nucleus of tens of thousands of columns.  Returns dict(A, basis, G) with G = the basis matrix."""
+    kw.setdefault("offdiag", 3)
+    P = lp_like_basis(m, 2 * m, seed=seed, **kw)
+    A, basis, status = P["A"], P["basis"].copy(), P["status"]
+    rng = np.random.default_rng(seed + 5)
+    enter = rng.choice(np.nonzero(status[:2 * m] == -1)[0], num_misplaced, replace=False)
+    basis[rng.choice(m, num_misplaced, replace=False)] = enter
+    return dict(A=A, basis=basis, G=basis_matrix_of(A, basis))
+
+
+def misplaced_basis_matrix(m, num_misplaced, seed=12345, **kw):
+    return misplaced_basis(m, num_misplaced, seed, **kw)["G"]
+
+
 def synthetic_misplaced_state(status, num_misplaced, spread=1.0, seed=12345):
     """Scaling factors of an IPM iterate whose basis is nearly the maximum volume one: synthetic_basis_state (basic
     variables large, nonbasic ones small), except that `num_misplaced` nonbasic variables have grown large and as

@@ -23,6 +23,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -1416,28 +1418,41 @@ struct orc_lu {
     Int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // col singletons, row singletons, bump size, rounds, dependent
 };
 
-extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend, const Int* Bi, const double* Bx,
-                                    double pivottol, int strict_abs_pivottol, Int bump_limit) {
+static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, const Int* Bi_in, const double* Bx_in,
+                                 double pivottol, int strict_abs_pivottol, Int bump_limit, int sparse_rounds, Int sparse_min) {
     const double abstol = strict_abs_pivottol ? 1e-3 : 1e-14;
     std::unique_ptr<orc_lu> F(new orc_lu);
     F->dim = dim;
-    // row-wise copy: entries of row i in ascending column order
-    std::vector<Int> rp(dim + 1, 0);
-    for (Int j = 0; j < dim; j++)
-        for (Int p = Bbegin[j]; p < Bend[j]; p++) rp[Bi[p] + 1]++;
-    for (Int i = 0; i < dim; i++) rp[i + 1] += rp[i];
-    std::vector<Int> rj(rp[dim]);
-    std::vector<double> rx(rp[dim]);
-    {
+    // the CURRENT matrix: B at first; with sparse rounds, the active submatrix after every elimination round
+    std::vector<Int> cp(dim + 1, 0), ci;
+    std::vector<double> cx;
+    for (Int j = 0; j < dim; j++) {
+        for (Int p = Bbegin[j]; p < Bend[j]; p++) { ci.push_back(Bi_in[p]); cx.push_back(Bx_in[p]); }
+        cp[j + 1] = (Int)ci.size();
+    }
+    // the entries that have left the current matrix because their row or column was pivoted, with the value they had then
+    std::vector<Int> Ei, Ej;
+    std::vector<double> Ex;
+    // row-wise copy: entries of row i in ascending column order; counts of the entries
+    std::vector<Int> rp, rj, rc(dim), cc(dim);
+    std::vector<double> rx;
+    auto rebuild_rows = [&]() {
+        rp.assign(dim + 1, 0);
+        for (Int j = 0; j < dim; j++)
+            for (Int p = cp[j]; p < cp[j + 1]; p++) rp[ci[p] + 1]++;
+        for (Int i = 0; i < dim; i++) rp[i + 1] += rp[i];
+        rj.assign(rp[dim], 0);
+        rx.assign(rp[dim], 0.0);
         std::vector<Int> cur(rp.begin(), rp.end() - 1);
         for (Int j = 0; j < dim; j++)
-            for (Int p = Bbegin[j]; p < Bend[j]; p++) { rj[cur[Bi[p]]] = j; rx[cur[Bi[p]]++] = Bx[p]; }
-    }
-    std::vector<Int> rstage(dim, -1), cstage(dim, -1), rc(dim), cc(dim);
+            for (Int p = cp[j]; p < cp[j + 1]; p++) { rj[cur[ci[p]]] = j; rx[cur[ci[p]]++] = cx[p]; }
+        for (Int j = 0; j < dim; j++) cc[j] = cp[j + 1] - cp[j];
+        for (Int i = 0; i < dim; i++) rc[i] = rp[i + 1] - rp[i];
+    };
+    rebuild_rows();
+    std::vector<Int> rstage(dim, -1), cstage(dim, -1);
     std::vector<double> pivot(dim, 0.0);             // by column
-    std::vector<char> ckind(dim, 0);                 // 1 column singleton, 2 row singleton, 3 bump, 4 dependent
-    for (Int j = 0; j < dim; j++) cc[j] = Bend[j] - Bbegin[j];
-    for (Int i = 0; i < dim; i++) rc[i] = rp[i + 1] - rp[i];
+    std::vector<char> ckind(dim, 0);                 // 1 column singleton, 2 row singleton, 3 bump, 4 dependent, 5 pivot of an elimination round
     Int npiv = 0, rounds = 0;
     std::vector<char> torn(dim, 0);                  // spike columns (set aside when the rounds stall)
     std::vector<Int> pivrow_of(dim, -1);             // pivot row of a pivoted column
@@ -1450,10 +1465,10 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
             std::vector<Int> claim(dim, -1), piv_row(dim, -1);
             for (Int j = 0; j < dim; j++) {
                 if (cstage[j] >= 0 || torn[j] || cc[j] != 1) continue;
-                for (Int p = Bbegin[j]; p < Bend[j]; p++) {
-                    const Int i = Bi[p];
+                for (Int p = cp[j]; p < cp[j + 1]; p++) {
+                    const Int i = ci[p];
                     if (rstage[i] >= 0) continue;
-                    if (std::abs(Bx[p]) >= abstol && claim[i] < 0) { claim[i] = j; piv_row[j] = i; pivot[j] = Bx[p]; }
+                    if (std::abs(cx[p]) >= abstol && claim[i] < 0) { claim[i] = j; piv_row[j] = i; pivot[j] = cx[p]; }
                     break;
                 }
             }
@@ -1484,8 +1499,8 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
                     if (cstage[j] >= 0 || torn[j]) continue;
                     const double a = std::abs(rx[q]);
                     double colmax = 0.0;
-                    for (Int p = Bbegin[j]; p < Bend[j]; p++)
-                        if (rstage[Bi[p]] < 0) colmax = std::max(colmax, std::abs(Bx[p]));
+                    for (Int p = cp[j]; p < cp[j + 1]; p++)
+                        if (rstage[ci[p]] < 0) colmax = std::max(colmax, std::abs(cx[p]));
                     if (a >= abstol && a >= pivottol * colmax && a > best_abs[j]) { best_abs[j] = a; best_row[j] = i; }
                     break;
                 }
@@ -1502,8 +1517,8 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
             }
             for (Int i : winners) {
                 const Int j = piv_col[i];
-                for (Int p = Bbegin[j]; p < Bend[j]; p++)
-                    if (rstage[Bi[p]] < 0) rc[Bi[p]]--;
+                for (Int p = cp[j]; p < cp[j + 1]; p++)
+                    if (rstage[ci[p]] < 0) rc[ci[p]]--;
             }
             found += (Int)winners.size();
             F->info[1] += (Int)winners.size();
@@ -1514,6 +1529,134 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
         Int nact = 0;
         for (Int j = 0; j < dim; j++) nact += cstage[j] < 0 && !torn[j];
         if (nact == 0) break;
+        if (sparse_rounds) {
+            // ---- ELIMINATION ROUNDS on the stalled matrix (every active row and column has two entries or more).  From here on
+            // the singleton rounds are not run any more: a singleton is a pivot of cost 0 of the next elimination round.
+            const uint64_t kNone = ~uint64_t(0);
+            std::vector<Int> candrow, winners;
+            // the new current matrix: the entries whose row and column stay active, followed by the updates
+            // -(a_i'j / pivot) * a_ij' in the order of the winners; equal positions are summed in that order, and an entry
+            // that cancels exactly leaves the pattern (so do explicit zeros of B).  The other entries join the list E.
+            auto rebuild = [&]() {
+                std::vector<std::pair<uint64_t, double>> ent;
+                for (Int j = 0; j < dim; j++)
+                    for (Int p = cp[j]; p < cp[j + 1]; p++) {
+                        const Int i = ci[p];
+                        if (rstage[i] < 0 && cstage[j] < 0) ent.emplace_back(((uint64_t)j << 32) | (uint64_t)i, cx[p]);
+                        else { Ei.push_back(i); Ej.push_back(j); Ex.push_back(cx[p]); }
+                    }
+                for (Int j : winners) {
+                    const Int i = candrow[j];
+                    for (Int p = cp[j]; p < cp[j + 1]; p++) {
+                        const Int i2 = ci[p];
+                        if (rstage[i2] >= 0) continue;                  // the pivot row itself (rows pivoted earlier are not in the matrix)
+                        const double l = cx[p] / pivot[j];
+                        for (Int q = rp[i]; q < rp[i + 1]; q++) {
+                            const Int j2 = rj[q];
+                            if (cstage[j2] >= 0) continue;
+                            const double prod = l * rx[q];
+                            ent.emplace_back(((uint64_t)j2 << 32) | (uint64_t)i2, -prod);
+                        }
+                    }
+                }
+                std::stable_sort(ent.begin(), ent.end(), [](const std::pair<uint64_t, double>& a, const std::pair<uint64_t, double>& b) { return a.first < b.first; });
+                ci.clear(); cx.clear();
+                std::fill(cp.begin(), cp.end(), 0);
+                for (size_t e = 0; e < ent.size();) {
+                    size_t f = e + 1;
+                    double acc = ent[e].second;
+                    while (f < ent.size() && ent[f].first == ent[e].first) acc = acc + ent[f++].second;
+                    if (acc != 0.0) {
+                        ci.push_back((Int)(ent[e].first & 0xffffffffu));
+                        cx.push_back(acc);
+                        cp[(ent[e].first >> 32) + 1]++;
+                    }
+                    e = f;
+                }
+                for (Int j = 0; j < dim; j++) cp[j + 1] += cp[j];
+                rebuild_rows();
+            };
+            if (bump_limit < 0 || nact <= bump_limit) break;       // small enough: dense as it stands
+            rebuild();                                             // the active submatrix
+            while (nact > sparse_min) {
+                // 1. one candidate per column: among its entries that pass the absolute and the relative threshold, the one in
+                //    the shortest row (ties: larger |entry|, then smaller row); cost = (row count - 1)(column count - 1)
+                candrow.assign(dim, -1);
+                std::vector<uint64_t> key(dim, kNone), rowbest(dim, kNone);
+                std::vector<int64_t> cost(dim, 0);
+                int64_t mincost = INT64_MAX, hist[33] = {0}, ncand = 0;
+                for (Int j = 0; j < dim; j++) {
+                    if (cstage[j] >= 0) continue;
+                    double colmax = 0.0;
+                    for (Int p = cp[j]; p < cp[j + 1]; p++) colmax = std::max(colmax, std::abs(cx[p]));
+                    Int bi = -1, brc = 0;
+                    double ba = 0.0;
+                    for (Int p = cp[j]; p < cp[j + 1]; p++) {
+                        const Int i = ci[p];
+                        const double a = std::abs(cx[p]);
+                        if (!(a >= abstol && a >= pivottol * colmax)) continue;
+                        if (bi < 0 || rc[i] < brc || (rc[i] == brc && (a > ba || (a == ba && i < bi)))) { bi = i; brc = rc[i]; ba = a; }
+                    }
+                    if (bi < 0) continue;
+                    candrow[j] = bi;
+                    cost[j] = std::min<int64_t>((int64_t)(brc - 1) * (cc[j] - 1), 0x7fffffff);
+                    mincost = std::min(mincost, cost[j]);
+                    int b = 0;
+                    while (b < 32 && (int64_t(1) << b) <= cost[j]) b++;          // bucket b: cost < 2^b
+                    hist[b]++;
+                    ncand++;
+                }
+                if (ncand == 0) break;                              // no column has an acceptable pivot: what is left goes to the dense block
+                // 2. the candidates that cost at most max(4, twice the cheapest) compete, and at least a quarter of all candidates
+                //    (the smallest power of two that admits so many); a row keeps its best one (cost, then column index)
+                int64_t limit = std::max<int64_t>(4, 2 * mincost);
+                {
+                    int64_t cum = 0;
+                    for (int b = 0; b <= 32; b++) {
+                        cum += hist[b];
+                        if (cum * 4 >= ncand) { limit = std::max<int64_t>(limit, (int64_t(1) << b) - 1); break; }
+                    }
+                }
+                for (Int j = 0; j < dim; j++)
+                    if (candrow[j] >= 0 && cost[j] <= limit) {
+                        key[j] = ((uint64_t)cost[j] << 32) | (uint64_t)j;
+                        rowbest[candrow[j]] = std::min(rowbest[candrow[j]], key[j]);
+                    }
+                // 3. a contender (the best of its row) wins unless a better contender has an entry in its pivot row or its pivot row
+                //    in this column: the winners' pivots form a diagonal block, so they can be eliminated together
+                auto contender = [&](Int j) { return key[j] != kNone && rowbest[candrow[j]] == key[j]; };
+                winners.clear();
+                for (Int j = 0; j < dim; j++) {
+                    if (!contender(j)) continue;
+                    const Int i = candrow[j];
+                    bool win = true;
+                    for (Int q = rp[i]; q < rp[i + 1] && win; q++) {
+                        const Int j2 = rj[q];
+                        if (j2 != j && contender(j2) && key[j2] < key[j]) win = false;
+                    }
+                    for (Int p = cp[j]; p < cp[j + 1] && win; p++)
+                        if (ci[p] != i && rowbest[ci[p]] < key[j]) win = false;
+                    if (win) winners.push_back(j);
+                }
+                // 4. pivots in ascending order of the column
+                for (Int j : winners) {
+                    const Int i = candrow[j];
+                    rstage[i] = cstage[j] = npiv++;
+                    ckind[j] = 5;
+                    pivrow_of[j] = i;
+                    for (Int p = cp[j]; p < cp[j + 1]; p++) if (ci[p] == i) pivot[j] = cx[p];
+                }
+                F->info[6] += (Int)winners.size();
+                F->info[7] += 1;
+                rounds++;
+                if (getenv("ORC_LU_DEBUG"))
+                    fprintf(stderr, "elim round %lld: active %lld nnz %lld mincost %lld limit %lld candidates %lld winners %zu\n", (long long)F->info[7],
+                            (long long)nact, (long long)cp[dim], (long long)mincost, (long long)limit, (long long)ncand, winners.size());
+                rebuild();
+                nact -= (Int)winners.size();
+            }
+            break;
+        }
         if (!tearing) {
             if (bump_limit < 0 || nact <= bump_limit) break;       // small enough: dense as it stands
             tearing = true;
@@ -1527,8 +1670,8 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
         for (size_t t = 0; t < take; t++) {
             const Int j = cand[t].second;
             torn[j] = 1;
-            for (Int p = Bbegin[j]; p < Bend[j]; p++)
-                if (rstage[Bi[p]] < 0) rc[Bi[p]]--;
+            for (Int p = cp[j]; p < cp[j + 1]; p++)
+                if (rstage[ci[p]] < 0) rc[ci[p]]--;
         }
         ntorn += (Int)take;
         npiv_at_tear = npiv;
@@ -1540,6 +1683,11 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
     std::vector<Int> brow, bcol, rloc(dim, -1), cloc(dim, -1);
     for (Int i = 0; i < dim; i++) if (rstage[i] < 0) { rloc[i] = (Int)brow.size(); brow.push_back(i); }
     for (Int j = 0; j < dim; j++) if (cstage[j] < 0) { cloc[j] = (Int)bcol.size(); bcol.push_back(j); }
+    if (sparse_rounds && !getenv("ORC_NO_COLORDER")) {
+        // the dense block's columns in ascending order of their number of entries (ties: index): fewer nonzeros in its factors
+        std::stable_sort(bcol.begin(), bcol.end(), [&](Int a, Int b) { return cc[a] < cc[b]; });
+        for (size_t c = 0; c < bcol.size(); c++) cloc[bcol[c]] = (Int)c;
+    }
     const Int kb = (Int)bcol.size();
     F->info[2] = kb;
     if (bump_limit >= 0 && kb > bump_limit) return nullptr;
@@ -1547,8 +1695,8 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
     std::vector<std::vector<std::pair<Int, double>>> spikeU;       // torn: entries of a spike in pivoted rows (stage, value)
     if (!tearing) {
         for (Int c = 0; c < kb; c++)
-            for (Int p = Bbegin[bcol[c]]; p < Bend[bcol[c]]; p++)
-                if (rloc[Bi[p]] >= 0) D[(size_t)c * kb + rloc[Bi[p]]] = Bx[p];
+            for (Int p = cp[bcol[c]]; p < cp[bcol[c] + 1]; p++)
+                if (rloc[ci[p]] >= 0) D[(size_t)c * kb + rloc[ci[p]]] = cx[p];
     } else {
         // the spikes through the row singleton pivots in pivot order: x[r] -= l_rj * x[i] for every row r that was
         // still active when (i, j) was pivoted (products rounded before they are subtracted)
@@ -1563,15 +1711,15 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
         std::vector<double> x(dim, 0.0);
         for (Int c = 0; c < kb; c++) {
             const Int js = bcol[c];
-            for (Int p = Bbegin[js]; p < Bend[js]; p++) x[Bi[p]] = Bx[p];
+            for (Int p = cp[js]; p < cp[js + 1]; p++) x[ci[p]] = cx[p];
             for (Int j : lpiv) {
                 const Int i = pivrow_of[j], k = cstage[j];
                 const double xi = x[i];
                 if (xi == 0.0) continue;
-                for (Int p = Bbegin[j]; p < Bend[j]; p++) {
-                    const Int r = Bi[p];
+                for (Int p = cp[j]; p < cp[j + 1]; p++) {
+                    const Int r = ci[p];
                     if (r == i || (rstage[r] >= 0 && rstage[r] < k)) continue;
-                    const double l = Bx[p] / pivot[j];
+                    const double l = cx[p] / pivot[j];
                     x[r] -= l * xi;
                 }
             }
@@ -1626,7 +1774,19 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
     F->rowperm.assign(dim, 0); F->colperm.assign(dim, 0);
     for (Int i = 0; i < dim; i++) F->rowperm[rstage[i]] = i;
     for (Int j = 0; j < dim; j++) F->colperm[cstage[j]] = j;
-    // ---- assemble: column k of L and U, indices ascending
+    // ---- assemble: column k of L and U, indices ascending.  With elimination rounds the entries come from the list of the
+    // entries that left the current matrix (plus what is in it now); without, that list is B itself.
+    if (sparse_rounds) {
+        for (Int j = 0; j < dim; j++)
+            for (Int p = cp[j]; p < cp[j + 1]; p++) { Ei.push_back(ci[p]); Ej.push_back(j); Ex.push_back(cx[p]); }
+        std::vector<Int> ep(dim + 1, 0);
+        for (Int j : Ej) ep[j + 1]++;
+        for (Int j = 0; j < dim; j++) ep[j + 1] += ep[j];
+        std::vector<Int> cur(ep.begin(), ep.end() - 1), ei(Ei.size());
+        std::vector<double> ex(Ei.size());
+        for (size_t e = 0; e < Ei.size(); e++) { ei[cur[Ej[e]]] = Ei[e]; ex[cur[Ej[e]]++] = Ex[e]; }
+        cp.swap(ep); ci.swap(ei); cx.swap(ex);
+    }
     F->Lp.assign(1, 0); F->Up.assign(1, 0);
     std::vector<std::pair<Int, double>> lcol, ucol;
     for (Int k = 0; k < dim; k++) {
@@ -1639,12 +1799,12 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
             if (c >= 0 && tearing) {
                 for (auto& e : spikeU[c]) ucol.push_back(e);          // a spike above the dense block: its updated values
             } else {
-                for (Int p = Bbegin[j]; p < Bend[j]; p++) {
-                    const Int i = Bi[p];
+                for (Int p = cp[j]; p < cp[j + 1]; p++) {
+                    const Int i = ci[p];
                     if (c >= 0 && rloc[i] >= 0) continue;             // bump x bump: from the dense result
                     const Int s = rstage[i];
-                    if (s < k) ucol.emplace_back(s, Bx[p]);
-                    else if (s > k) lcol.emplace_back(s, Bx[p] / pivot[j]);
+                    if (s < k) ucol.emplace_back(s, cx[p]);
+                    else if (s > k) lcol.emplace_back(s, cx[p] / pivot[j]);
                 }
             }
             if (c >= 0) {
@@ -1666,6 +1826,19 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
         F->Up.push_back((Int)F->Ui.size());
     }
     return F.release();
+}
+
+extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend, const Int* Bi, const double* Bx,
+                                    double pivottol, int strict_abs_pivottol, Int bump_limit) {
+    return lu_factorize_impl(dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol, bump_limit, 0, 0);
+}
+// ... with ELIMINATION ROUNDS instead of tearing: when the singleton rounds stall with more than bump_limit active columns, sets
+// of pivots with low Markowitz cost that form a diagonal block are eliminated at once (the fill-in enters the current matrix)
+// until at most sparse_min columns are active; what is left (at most bump_limit rows, else refused) is factorized densely,
+// its columns in ascending order of their number of entries.
+extern "C" orc_lu* orc_lu_factorize_sparse(Int dim, const Int* Bbegin, const Int* Bend, const Int* Bi, const double* Bx,
+                                           double pivottol, int strict_abs_pivottol, Int bump_limit, Int sparse_min) {
+    return lu_factorize_impl(dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol, bump_limit, 1, sparse_min);
 }
 
 extern "C" void orc_lu_sizes(const orc_lu* F, Int* lnz, Int* unz, Int* ndep, Int* info) {

@@ -90,7 +90,7 @@ class Oracle:
                      "orc_kkt_diag_solve", "orc_trisolve", "orc_split_get_sizes",
                      "orc_kkt_basis_solve", "orc_newton_solve_diag", "orc_newton_solve_basis", "orc_ipm_step_diag"):
             getattr(L, name).restype = c_i64
-        for name in ("orc_diag_factorize", "orc_kkt_diag_new", "orc_split_prepare", "orc_lu_factorize", "orc_basis_new"):
+        for name in ("orc_diag_factorize", "orc_kkt_diag_new", "orc_split_prepare", "orc_lu_factorize", "orc_lu_factorize_sparse", "orc_basis_new"):
             getattr(L, name).restype = C.c_void_p
 
     # ---- Iterate / StepToBoundary ---------------------------------------------
@@ -147,12 +147,17 @@ class Oracle:
                                _ip(ATp), _ip(ATi), _fp(ATx))
         return Csc(A.ncol, A.nrow, ATp, ATi, ATx)
 
-    def lu_factorize(self, dim, Bbegin, Bend, Bi, Bx, pivottol=0.1, strict=False, bump_limit=-1):
+    def lu_factorize(self, dim, Bbegin, Bend, Bi, Bx, pivottol=0.1, strict=False, bump_limit=-1, sparse_min=None):
         """LuFactorization contract (src/lu_factorization.h:21-58): returns dict(L, U, rowperm, colperm, dependent,
-        info) with L, U as Csc, or None when the bump exceeds bump_limit."""
+        info) with L, U as Csc, or None when the bump exceeds bump_limit.  sparse_min: elimination rounds (not tearing)
+        while more than that many columns are active."""
         Bbegin, Bend, Bi, Bx = _I(Bbegin), _I(Bend), _I(Bi), _F(Bx)
-        h = self.lib.orc_lu_factorize(c_i64(dim), _ip(Bbegin), _ip(Bend), _ip(Bi), _fp(Bx), c_f64(pivottol),
-                                      C.c_int(1 if strict else 0), c_i64(bump_limit))
+        if sparse_min is None:
+            h = self.lib.orc_lu_factorize(c_i64(dim), _ip(Bbegin), _ip(Bend), _ip(Bi), _fp(Bx), c_f64(pivottol),
+                                          C.c_int(1 if strict else 0), c_i64(bump_limit))
+        else:
+            h = self.lib.orc_lu_factorize_sparse(c_i64(dim), _ip(Bbegin), _ip(Bend), _ip(Bi), _fp(Bx), c_f64(pivottol),
+                                                 C.c_int(1 if strict else 0), c_i64(bump_limit), c_i64(sparse_min))
         if not h:
             return None
         h = C.c_void_p(h)
@@ -168,7 +173,7 @@ class Oracle:
         return dict(L=Csc(dim, dim, Lp, Li, Lx), U=Csc(dim, dim, Up, Ui, Ux), rowperm=rowperm, colperm=colperm,
                     dependent=dep, info=dict(col_singletons=int(info[0]), row_singletons=int(info[1]),
                                              bump=int(info[2]), rounds=int(info[3]), dependent=int(info[4]),
-                                             spikes=int(info[5])))
+                                             spikes=int(info[5]), sparse_pivots=int(info[6]), sparse_rounds=int(info[7])))
 
     def basis(self, A, basis, status, max_etas=100):
         """ipx::Basis as far as Maxvolume needs it, over [A I] (A: Csc m x n)"""
