@@ -39,6 +39,7 @@
 //      entries in pivoted rows become entries of U, their entries in the never-pivoted rows form the dense block
 //      of step 2.  Only if THAT block exceeds the limit is the basis refused (IPXK_E_UNSUPPORTED).
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_merge.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -783,28 +784,38 @@ struct Sparse {
 };
 constexpr int kSpStats = 48;
 // one candidate per column: among its entries that pass the absolute and the relative threshold, the one in the shortest row
-// (ties: larger |entry|, then smaller row); cost = (row count - 1)(column count - 1)
+// (ties: larger |entry|, then smaller row); cost = (row count - 1)(column count - 1).  One wavefront per column.
 __global__ __launch_bounds__(kBlock) void sp_cand_kernel(Sparse S) {
     __shared__ int s_hist[33], s_min, s_n;
     if (threadIdx.x < 33) s_hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_min = INT_MAX; s_n = 0; }
     __syncthreads();
-    IPXK_GRID_STRIDE(j, S.dim) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t j = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); j < S.dim; j += (int64_t)gridDim.x * (kBlock / 64)) {
         const int p0 = S.Bp[j], p1 = S.Bp[j + 1];
         double colmax = 0.0;
-        for (int p = p0; p < p1; p++) colmax = fmax(colmax, fabs(S.Bx[p]));
-        int bi = -1, brc = 0;
+        for (int p = p0 + lane; p < p1; p += 64) colmax = fmax(colmax, fabs(S.Bx[p]));
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) colmax = fmax(colmax, __shfl_xor(colmax, d, 64));
+        int bi = INT_MAX, brc = INT_MAX;
         double ba = 0.0;
         const double rel = S.pivottol * colmax;
-        for (int p = p0; p < p1; p++) {
+        for (int p = p0 + lane; p < p1; p += 64) {
             const double a = fabs(S.Bx[p]);
             if (!(a >= S.abstol && a >= rel)) continue;
             const int i = S.Bi[p], r = S.rc[i];
-            if (bi < 0 || r < brc || (r == brc && (a > ba || (a == ba && i < bi)))) { bi = i; brc = r; ba = a; }
+            if (r < brc || (r == brc && (a > ba || (a == ba && i < bi)))) { bi = i; brc = r; ba = a; }
         }
-        S.candrow[j] = bi;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int oi = __shfl_xor(bi, d, 64), orc = __shfl_xor(brc, d, 64);
+            const double oa = __shfl_xor(ba, d, 64);
+            if (oi != INT_MAX && (orc < brc || (orc == brc && (oa > ba || (oa == ba && oi < bi))))) { bi = oi; brc = orc; ba = oa; }
+        }
+        if (lane) continue;
+        S.candrow[j] = bi == INT_MAX ? -1 : bi;
         S.key[j] = kNoKey;
-        if (bi < 0) continue;
+        if (bi == INT_MAX) continue;
         const long long c64 = (long long)(brc - 1) * (long long)(p1 - p0 - 1);
         const int c = (int)(c64 < 0x7fffffffLL ? c64 : 0x7fffffffLL);
         S.cost[j] = c;
@@ -845,31 +856,55 @@ __global__ void sp_key_kernel(Sparse S) {
 }
 // a contender (the best of its row) wins unless a better contender has an entry in its pivot row or its pivot row in this
 // column: the winners' pivots form a diagonal block.  nupd: the products a winner sends out (pivot row x pivot column, all pairs).
-__global__ void sp_win_kernel(Sparse S, int* __restrict__ winner, int* __restrict__ nupd, int* bad) {
-    IPXK_GRID_STRIDE(j, S.dim) {
+// One wavefront per column.
+__global__ __launch_bounds__(kBlock) void sp_win_kernel(Sparse S, int* __restrict__ winner, int* __restrict__ nupd, int* bad) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t j = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); j < S.dim; j += (int64_t)gridDim.x * (kBlock / 64)) {
         const u64 k = S.key[j];
         bool win = false;
         int i = -1;
-        if (k != kNoKey && S.rowbest[S.candrow[j]] == k) {
-            win = true;
+        if (k != kNoKey && S.rowbest[S.candrow[j]] == k) {           // (uniform over the wavefront)
             i = S.candrow[j];
-            for (int q = S.Rp[i]; q < S.Rp[i + 1] && win; q++) {
+            bool lose = false;
+            for (int q = S.Rp[i] + lane; q < S.Rp[i + 1]; q += 64) {
                 const int j2 = S.Rj[q];
                 if (j2 == (int)j) continue;
                 const u64 k2 = S.key[j2];
-                if (k2 < k && S.rowbest[S.candrow[j2]] == k2) win = false;       // (k2 < k implies k2 is a key)
+                if (k2 < k && S.rowbest[S.candrow[j2]] == k2) lose = true;       // (k2 < k implies k2 is a key)
             }
-            for (int p = S.Bp[j]; p < S.Bp[j + 1] && win; p++)
-                if (S.Bi[p] != i && S.rowbest[S.Bi[p]] < k) win = false;
+            for (int p = S.Bp[j] + lane; p < S.Bp[j + 1]; p += 64)
+                if (S.Bi[p] != i && S.rowbest[S.Bi[p]] < k) lose = true;
+            win = __ballot(lose) == 0;
         }
+        if (lane) continue;
         winner[j] = win ? 1 : 0;
         int n = 0;
         if (win) {
             const long long n64 = (long long)S.rc[i] * S.cc[j];
             if (n64 > (1LL << 28)) *bad = 1; else n = (int)n64;
             atomicAdd(S.stats + 3, 1);
+            atomicAdd(S.stats + 4, S.rc[i] + S.cc[j] - 1);       // the entries of the pivot row and column leave the matrix
         }
         nupd[j] = n;
+    }
+}
+constexpr int kSpRowsBySort = 1 << 18;
+__global__ void sp_rowkeys_kernel(int64_t nnz, const int* __restrict__ Bi, int* __restrict__ keys, int* __restrict__ pos) {
+    IPXK_GRID_STRIDE(p, nnz) { keys[p] = Bi[p]; pos[p] = (int)p; }
+}
+// the row-wise index of the current matrix.  The order of a row's entries is left to the atomics: nothing depends on it (the
+// winners' test is a conjunction over the row, and a winner's updates have distinct positions, so the stable sort puts them in
+// the same places whatever the order in which they were written).
+__global__ void sp_rowcount_kernel(int64_t nnz, const int* __restrict__ Bi, int* __restrict__ rc) {
+    IPXK_GRID_STRIDE(p, nnz) atomicAdd(rc + Bi[p], 1);
+}
+__global__ void sp_rowfill_kernel(int64_t nnz, const int* __restrict__ Bi, const int* __restrict__ colof, const int* __restrict__ Rp,
+                                  int* __restrict__ cursor, int* __restrict__ Rj, int* __restrict__ Rpos) {
+    IPXK_GRID_STRIDE(p, nnz) {
+        const int i = Bi[p];
+        const int at = Rp[i] + atomicAdd(cursor + i, 1);
+        Rj[at] = colof[p];
+        Rpos[at] = (int)p;
     }
 }
 struct SparseGlobal {     // where a round's pivots are recorded: the arrays of the singleton rounds, indexed as B is
@@ -904,46 +939,60 @@ __global__ void sp_map_kernel(int n, const int* __restrict__ list, const int* __
 // others join the list of finished entries with their indices in B and their present values
 __global__ void sp_entries_kernel(int64_t nnz, const int* __restrict__ Bi, const int* __restrict__ colof, const double* __restrict__ Bx,
                                   const int* __restrict__ newrow, const int* __restrict__ newcol, const int* __restrict__ grow,
-                                  const int* __restrict__ gcol, u64* __restrict__ key, double* __restrict__ val, int* cursor,
-                                  int* __restrict__ Erow, int* __restrict__ Ecol, double* __restrict__ Eval) {
+                                  const int* __restrict__ gcol, u64* __restrict__ key, double* __restrict__ val, int* __restrict__ keep,
+                                  int* cursor, int* __restrict__ Erow, int* __restrict__ Ecol, double* __restrict__ Eval) {
     IPXK_GRID_STRIDE(p, nnz) {
         const int i = Bi[p], j = colof[p];
         const int nr = newrow[i], nc = newcol[j];
-        if (nr >= 0 && nc >= 0) {
+        const bool stays = nr >= 0 && nc >= 0;
+        if (keep) keep[p] = stays ? 1 : 0;
+        const u64 leaving = __ballot(!stays);                 // one atomic per wavefront (the order in E is irrelevant: the assembly sorts by key)
+        if (stays) {
             key[p] = ((u64)(unsigned)nc << 32) | (unsigned)nr;
             val[p] = Bx[p];
         } else {
             key[p] = kNoKey;
             val[p] = 0.0;
-            const int at = atomicAdd(cursor, 1);              // (the order is irrelevant: the assembly sorts by key)
+            const int lane = threadIdx.x & 63, leader = __ffsll((long long)leaving) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(cursor, __popcll(leaving));
+            base = __shfl(base, leader, 64);
+            const int at = base + __popcll(leaving & ((1ull << lane) - 1));
             Erow[at] = grow ? grow[i] : i;
             Ecol[at] = gcol ? gcol[j] : j;
             Eval[at] = Bx[p];
         }
     }
 }
+__global__ void sp_carry_kernel(int64_t nnz, const int* __restrict__ keep, const int* __restrict__ pos, const u64* __restrict__ key,
+                                const double* __restrict__ val, u64* __restrict__ okey, double* __restrict__ oval) {
+    IPXK_GRID_STRIDE(p, nnz) {
+        if (!keep[p]) continue;
+        okey[pos[p]] = key[p];
+        oval[pos[p]] = val[p];
+    }
+}
 // the updates -(a_i'j / pivot) * a_ij' of the winners, behind the entries, winner after winner in ascending order of the column
-// (the sort is stable: equal positions are then summed in that order); one wavefront per winner
-__global__ __launch_bounds__(kBlock) void sp_updates_kernel(Sparse S, const int* __restrict__ winner, const int* __restrict__ uoff,
-                                                            const double* __restrict__ pivl, const int* __restrict__ newrow,
-                                                            const int* __restrict__ newcol, int64_t base, u64* __restrict__ key,
-                                                            double* __restrict__ val) {
-    const int lane = threadIdx.x & 63;
-    for (int64_t j = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); j < S.dim; j += (int64_t)gridDim.x * (kBlock / 64)) {
-        if (!winner[j]) continue;
-        const int i = S.candrow[j], p0 = S.Bp[j], q0 = S.Rp[i], np = S.Bp[j + 1] - p0, nq = S.Rp[i + 1] - q0;
-        const double piv = pivl[j];
-        const int64_t at = base + uoff[j];
-        for (int t = lane; t < np * nq; t += 64) {
-            const int pi = t / nq, qi = t - pi * nq;
-            const int p = p0 + pi, q = q0 + qi;
-            const int i2 = S.Bi[p], j2 = S.Rj[q];
-            if (i2 == i || j2 == (int)j) { key[at + t] = kNoKey; val[at + t] = 0.0; continue; }
-            const double l = S.Bx[p] / piv;
-            const double prod = l * S.Bx[S.Rpos[q]];
-            key[at + t] = ((u64)(unsigned)newcol[j2] << 32) | (unsigned)newrow[i2];
-            val[at + t] = -prod;
+// (the sort is stable: equal positions are then summed in that order); one thread per product, its winner found in the offsets
+__global__ __launch_bounds__(kBlock) void sp_updates_kernel(Sparse S, const int* __restrict__ uoff, int64_t nupd, const double* __restrict__ pivl,
+                                                            const int* __restrict__ newrow, const int* __restrict__ newcol, int64_t base,
+                                                            u64* __restrict__ key, double* __restrict__ val) {
+    IPXK_GRID_STRIDE(t, nupd) {
+        int lo = 0, hi = S.dim;                       // the last column j with uoff[j] <= t (it has products: uoff[j + 1] > t)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (uoff[mid] <= (int)t) lo = mid; else hi = mid;
         }
+        const int j = lo, i = S.candrow[j], p0 = S.Bp[j], q0 = S.Rp[i], nq = S.Rp[i + 1] - q0;
+        const int u = (int)t - uoff[j];
+        const int pi = u / nq, qi = u - pi * nq;
+        const int p = p0 + pi, q = q0 + qi;
+        const int i2 = S.Bi[p], j2 = S.Rj[q];
+        if (i2 == i || j2 == j) { key[base + t] = kNoKey; val[base + t] = 0.0; continue; }
+        const double l = S.Bx[p] / pivl[j];
+        const double prod = l * S.Bx[S.Rpos[q]];
+        key[base + t] = ((u64)(unsigned)newcol[j2] << 32) | (unsigned)newrow[i2];
+        val[base + t] = -prod;
     }
 }
 // equal keys are summed in order; a sum that is exactly zero leaves the pattern
@@ -983,6 +1032,9 @@ __global__ void sp_colptr_kernel(int dim, int nnz, const int* __restrict__ colof
         }
         Bp[j] = lo;
     }
+}
+__global__ void sp_colcount_kernel(int dim, const int* __restrict__ Bp, int* __restrict__ cc) {
+    IPXK_GRID_STRIDE(j, dim) cc[j] = Bp[j + 1] - Bp[j];
 }
 // the dense block's columns in ascending order of their number of entries (ties: index)
 __global__ void sp_colorder_keys_kernel(int kb, const int* __restrict__ cc, u64* __restrict__ keys) {
@@ -1157,8 +1209,8 @@ struct LuWork {
         DevBuf<double> Bx[2];
         DevBuf<int> Rp, Rj, Rpos, rc, cc, k32a, k32b, pos;
         DevBuf<int> candrow, cost, winner, nupd, uoff, rstL, cstL, flag, rank, newrow, newcol, listr, listc, stats, cflag, cpos, cposl, ecur;
-        DevBuf<u64> key, rowbest, skey, skey2, okey, okey2;
-        DevBuf<double> pivl, sval, sval2, csum;
+        DevBuf<u64> key, rowbest, skey, skey2, ukey, ukey2, okey, okey2;
+        DevBuf<double> pivl, sval, sval2, uval, uval2, csum;
         DevBuf<int> Erow, Ecol;
         DevBuf<double> Eval;
     } sp;
@@ -1199,12 +1251,12 @@ struct SparseOut {
 };
 // sorted (key, value) pairs -> the next current matrix in copy `dst`: equal keys summed in order, exact zeros dropped, column
 // pointers, row-wise index, counts.  Reads back the number of entries (and the length of E).
-void sp_finish_matrix(hipStream_t s, LuWork& W, int64_t n, int dimL, int dst, int* h, int64_t* nnz_out, int64_t* ne_out) {
+void sp_finish_matrix(hipStream_t s, LuWork& W, const u64* skeys, const double* svals, int64_t n, int dimL, int dst, int* h, int64_t* nnz_out,
+                      int64_t* ne_out) {
     LuWork::Sp& P = W.sp;
     Tmp& T = W.T;
     P.cflag.ensure((size_t)n + 1); P.cpos.ensure((size_t)n + 1); P.csum.ensure((size_t)std::max<int64_t>(n, 1));
-    if (n > 0) sort_keys(T, P.skey.get(), P.skey2.get(), P.sval.get(), P.sval2.get(), (size_t)n, 32 + bits_for(std::max(dimL, 2)), s);
-    hipLaunchKernelGGL(sp_combine_kernel, dim3(grid_for(n + 1)), dim3(kBlock), 0, s, n, P.skey2.get(), P.sval2.get(), P.cflag.get(), P.csum.get());
+    hipLaunchKernelGGL(sp_combine_kernel, dim3(grid_for(n + 1)), dim3(kBlock), 0, s, n, skeys, svals, P.cflag.get(), P.csum.get());
     scan_exclusive(T, P.cflag.get(), P.cpos.get(), (size_t)n + 1, s);
     IPXK_HIP(hipMemcpyAsync(h, P.cpos.get() + n, sizeof(int), hipMemcpyDeviceToHost, s));
     IPXK_HIP(hipMemcpyAsync(h + 1, P.ecur.get(), sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1215,24 +1267,37 @@ void sp_finish_matrix(hipStream_t s, LuWork& W, int64_t n, int dimL, int dst, in
     const size_t z1 = (size_t)std::max<int64_t>(nnz, 1), d1 = (size_t)std::max(dimL, 1);
     P.Bi[dst].ensure(z1); P.colof[dst].ensure(z1); P.Bx[dst].ensure(z1); P.Bp[dst].ensure(d1 + 1);
     if (n > 0)
-        hipLaunchKernelGGL(sp_compact_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, n, P.skey2.get(), P.cflag.get(), P.cpos.get(), P.csum.get(),
+        hipLaunchKernelGGL(sp_compact_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, n, skeys, P.cflag.get(), P.cpos.get(), P.csum.get(),
                            P.Bi[dst].get(), P.colof[dst].get(), P.Bx[dst].get());
     hipLaunchKernelGGL(sp_colptr_kernel, dim3(grid_for(dimL + 1)), dim3(kBlock), 0, s, dimL, (int)nnz, P.colof[dst].get(), P.Bp[dst].get());
     // rows
     P.rc.ensure(d1 + 1); P.cc.ensure(d1); P.Rp.ensure(d1 + 1);
-    for (DevBuf<int>* b : {&P.k32a, &P.k32b, &P.pos, &P.Rpos, &P.Rj}) b->ensure(z1);
+    for (DevBuf<int>* b : {&P.Rpos, &P.Rj}) b->ensure(z1);
     IPXK_HIP(hipMemsetAsync(P.rc.get(), 0, (d1 + 1) * sizeof(int), s));
-    if (dimL > 0)
-        hipLaunchKernelGGL(lu_expand_kernel, dim3(grid_for(dimL)), dim3(kBlock), 0, s, dimL, P.Bp[dst].get(), P.Bi[dst].get(), P.colof[dst].get(),
-                           P.k32a.get(), P.pos.get(), P.rc.get(), P.cc.get(), P.stats.get() + 41);
-    if (nnz > 0) {
+    if (dimL > 0) hipLaunchKernelGGL(sp_colcount_kernel, dim3(grid_for(dimL)), dim3(kBlock), 0, s, dimL, P.Bp[dst].get(), P.cc.get());
+    // the row-wise index: by atomics for small matrices, by a sort for large ones (a row with thousands of entries serializes
+    // its atomics).  Nothing depends on the order of a row's entries.
+    const bool rows_by_sort = nnz >= (int64_t)kSpRowsBySort;
+    if (rows_by_sort) {
+        for (DevBuf<int>* b : {&P.k32a, &P.k32b, &P.pos}) b->ensure(z1);
+        hipLaunchKernelGGL(sp_rowkeys_kernel, dim3(grid_for(nnz)), dim3(kBlock), 0, s, nnz, P.Bi[dst].get(), P.k32a.get(), P.pos.get());
         size_t bytes = 0;
         const unsigned bits = (unsigned)bits_for(std::max(dimL, 2));
         IPXK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, P.k32a.get(), P.k32b.get(), P.pos.get(), P.Rpos.get(), (size_t)nnz, 0u, bits, s));
         IPXK_HIP(rocprim::radix_sort_pairs(T.need(bytes), bytes, P.k32a.get(), P.k32b.get(), P.pos.get(), P.Rpos.get(), (size_t)nnz, 0u, bits, s));
         hipLaunchKernelGGL(lu_rows_kernel, dim3(grid_for(nnz)), dim3(kBlock), 0, s, nnz, P.Rpos.get(), P.colof[dst].get(), P.Rj.get());
+        hipLaunchKernelGGL(sp_colptr_kernel, dim3(grid_for(dimL + 1)), dim3(kBlock), 0, s, dimL, (int)nnz, P.k32b.get(), P.Rp.get());
+        hipLaunchKernelGGL(sp_colcount_kernel, dim3(grid_for(dimL)), dim3(kBlock), 0, s, dimL, P.Rp.get(), P.rc.get());
+        return;
     }
+    if (nnz > 0) hipLaunchKernelGGL(sp_rowcount_kernel, dim3(grid_for(nnz)), dim3(kBlock), 0, s, nnz, P.Bi[dst].get(), P.rc.get());
     scan_exclusive(T, P.rc.get(), P.Rp.get(), d1 + 1, s);
+    if (nnz > 0) {
+        P.k32a.ensure(d1);
+        IPXK_HIP(hipMemsetAsync(P.k32a.get(), 0, d1 * sizeof(int), s));
+        hipLaunchKernelGGL(sp_rowfill_kernel, dim3(grid_for(nnz)), dim3(kBlock), 0, s, nnz, P.Bi[dst].get(), P.colof[dst].get(), P.Rp.get(), P.k32a.get(),
+                           P.Rj.get(), P.Rpos.get());
+    }
 }
 
 // 2c. ELIMINATION ROUNDS.  The singleton rounds have stalled with `nact` active rows and columns of B (rstage / cstage < 0).
@@ -1241,7 +1306,7 @@ void sp_finish_matrix(hipStream_t s, LuWork& W, int64_t n, int dimL, int dst, in
 // matrix (copy out.cur: out.kb rows, out.nnz entries, local indices = rank among the rows / columns of B that are still
 // active) is what the dense code takes over, and W.sp.E* (out.ne entries) replaces B in the assembly.
 SparseOut sparse_rounds(hipStream_t s, LuWork& W, int dim, int64_t nb, const int* Bi, const int* colof, const double* Bx, SparseGlobal G,
-                        int nact, int sparse_min, int* rounds, double abstol, double pivottol, int* h) {
+                        int nact, int sparse_min, int kb_max, int slow_den, int* rounds, double abstol, double pivottol, int* h) {
     LuWork::Sp& P = W.sp;
     Tmp& T = W.T;
     SparseOut out;
@@ -1266,10 +1331,15 @@ SparseOut sparse_rounds(hipStream_t s, LuWork& W, int dim, int64_t nb, const int
     for (DevBuf<double>* b : {&P.sval, &P.sval2}) b->ensure(nz1);
     P.Erow.ensure(nz1); P.Ecol.ensure(nz1); P.Eval.ensure(nz1);
     hipLaunchKernelGGL(sp_entries_kernel, dim3(grid_for(nb)), dim3(kBlock), 0, s, nb, Bi, colof, Bx, W.rloc.get(), W.cloc.get(), (const int*)nullptr,
-                       (const int*)nullptr, P.skey.get(), P.sval.get(), P.ecur.get(), P.Erow.get(), P.Ecol.get(), P.Eval.get());
+                       (const int*)nullptr, P.skey.get(), P.sval.get(), (int*)nullptr, P.ecur.get(), P.Erow.get(), P.Ecol.get(), P.Eval.get());
     int64_t nnz = 0, ne = 0;
-    sp_finish_matrix(s, W, nb, dimL, cur, h, &nnz, &ne);
+    if (nb > 0) sort_keys(T, P.skey.get(), P.skey2.get(), P.sval.get(), P.sval2.get(), (size_t)nb, 32 + bits_for(std::max(dimL, 2)), s);
+    sp_finish_matrix(s, W, P.skey2.get(), P.sval2.get(), nb, dimL, cur, h, &nnz, &ne);
+    int slow = 0;
     while (dimL > sparse_min) {
+        // (the rounds stop early once the current matrix fits the dense code and two rounds in a row have each eliminated fewer
+        // than 1 / slow_den of the columns: what is left has no large sets of independent pivots any more)
+        if (slow_den > 0 && dimL <= kb_max && slow >= 2) break;
         const size_t l1 = (size_t)dimL;
         for (DevBuf<int>* b : {&P.candrow, &P.cost, &P.winner, &P.rstL, &P.cstL, &P.flag, &P.rank, &P.newrow, &P.newcol, &P.listr, &P.listc}) b->ensure(l1);
         P.nupd.ensure(l1 + 1); P.uoff.ensure(l1 + 1); P.key.ensure(l1); P.rowbest.ensure(l1); P.pivl.ensure(l1);
@@ -1281,10 +1351,11 @@ SparseOut sparse_rounds(hipStream_t s, LuWork& W, int dim, int64_t nb, const int
         hipLaunchKernelGGL(lu_fill_int_kernel, dim3(gl), dim3(kBlock), 0, s, (int64_t)dimL, -1, P.rstL.get());
         hipLaunchKernelGGL(lu_fill_int_kernel, dim3(gl), dim3(kBlock), 0, s, (int64_t)dimL, -1, P.cstL.get());
         IPXK_HIP(hipMemsetAsync(P.nupd.get(), 0, (l1 + 1) * sizeof(int), s));
-        hipLaunchKernelGGL(sp_cand_kernel, dim3(gl), dim3(kBlock), 0, s, S);
+        const int gw = (int)std::min<int64_t>(4096, ((int64_t)dimL + kBlock / 64 - 1) / (kBlock / 64));     // a wavefront per column
+        hipLaunchKernelGGL(sp_cand_kernel, dim3(gw), dim3(kBlock), 0, s, S);
         hipLaunchKernelGGL(sp_limit_kernel, dim3(1), dim3(64), 0, s, P.stats.get());
         hipLaunchKernelGGL(sp_key_kernel, dim3(gl), dim3(kBlock), 0, s, S);
-        hipLaunchKernelGGL(sp_win_kernel, dim3(gl), dim3(kBlock), 0, s, S, P.winner.get(), P.nupd.get(), P.stats.get() + 40);
+        hipLaunchKernelGGL(sp_win_kernel, dim3(gw), dim3(kBlock), 0, s, S, P.winner.get(), P.nupd.get(), P.stats.get() + 40);
         scan_exclusive(T, P.nupd.get(), P.uoff.get(), l1 + 1, s);
         IPXK_HIP(hipMemcpyAsync(h, P.stats.get(), kSpStats * sizeof(int), hipMemcpyDeviceToHost, s));
         IPXK_HIP(hipMemcpyAsync(h + kSpStats, P.uoff.get() + dimL, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1315,23 +1386,43 @@ SparseOut sparse_rounds(hipStream_t s, LuWork& W, int dim, int64_t nb, const int
             hipLaunchKernelGGL(sp_map_kernel, dim3(grid_for(dimN)), dim3(kBlock), 0, s, dimN, P.listr.get(), P.grow[cur].get(), P.grow[nxt].get());
             hipLaunchKernelGGL(sp_map_kernel, dim3(grid_for(dimN)), dim3(kBlock), 0, s, dimN, P.listc.get(), P.gcol[cur].get(), P.gcol[nxt].get());
         }
-        const int64_t n = nnz + nupd;
-        IPXK_REQUIRE(n < (int64_t(1) << 31), "LU: the current matrix of an elimination round exceeds 32-bit positions");
-        for (DevBuf<u64>* b : {&P.skey, &P.skey2}) b->ensure((size_t)std::max<int64_t>(n, 1));
-        for (DevBuf<double>* b : {&P.sval, &P.sval2}) b->ensure((size_t)std::max<int64_t>(n, 1));
+        // the entries that stay keep their order (the renumbering is monotone): compacted, then merged with the sorted updates
+        // (the merge is stable: at equal positions the entry comes first, then the updates in the order of the winners)
+        const int64_t ncarry = nnz - h[4], n = ncarry + nupd;
+        IPXK_REQUIRE(ncarry >= 0 && n < (int64_t(1) << 31), "LU: the current matrix of an elimination round exceeds 32-bit positions");
+        const size_t nz1 = (size_t)std::max<int64_t>(std::max(n, nnz), 1), nu1 = (size_t)std::max<int64_t>(nupd, 1);
+        for (DevBuf<u64>* b : {&P.skey, &P.skey2}) b->ensure(nz1);
+        for (DevBuf<double>* b : {&P.sval, &P.sval2}) b->ensure(nz1);
+        for (DevBuf<u64>* b : {&P.ukey, &P.ukey2}) b->ensure(nu1);
+        for (DevBuf<double>* b : {&P.uval, &P.uval2}) b->ensure(nu1);
+        P.cflag.ensure((size_t)nnz + 1); P.cpos.ensure((size_t)nnz + 1);
         grow_keep(P.Erow, (size_t)ne, (size_t)(ne + nnz), s);
         grow_keep(P.Ecol, (size_t)ne, (size_t)(ne + nnz), s);
         grow_keep(P.Eval, (size_t)ne, (size_t)(ne + nnz), s);
-        if (nnz > 0)
+        if (nnz > 0) {
             hipLaunchKernelGGL(sp_entries_kernel, dim3(grid_for(nnz)), dim3(kBlock), 0, s, nnz, P.Bi[cur].get(), P.colof[cur].get(), P.Bx[cur].get(),
-                               P.newrow.get(), P.newcol.get(), P.grow[cur].get(), P.gcol[cur].get(), P.skey.get(), P.sval.get(), P.ecur.get(),
-                               P.Erow.get(), P.Ecol.get(), P.Eval.get());
-        if (nupd > 0) {
-            const int wgs = (int)std::min<int64_t>(4096, ((int64_t)dimL + kBlock / 64 - 1) / (kBlock / 64));
-            hipLaunchKernelGGL(sp_updates_kernel, dim3(wgs), dim3(kBlock), 0, s, S, P.winner.get(), P.uoff.get(), P.pivl.get(), P.newrow.get(),
-                               P.newcol.get(), nnz, P.skey.get(), P.sval.get());
+                               P.newrow.get(), P.newcol.get(), P.grow[cur].get(), P.gcol[cur].get(), P.skey.get(), P.sval.get(), P.cflag.get(),
+                               P.ecur.get(), P.Erow.get(), P.Ecol.get(), P.Eval.get());
+            scan_exclusive(T, P.cflag.get(), P.cpos.get(), (size_t)nnz, s);
+            hipLaunchKernelGGL(sp_carry_kernel, dim3(grid_for(nnz)), dim3(kBlock), 0, s, nnz, P.cflag.get(), P.cpos.get(), P.skey.get(), P.sval.get(),
+                               P.skey2.get(), P.sval2.get());
         }
-        sp_finish_matrix(s, W, n, dimN, nxt, h, &nnz, &ne);
+        const u64* mkeys = P.skey2.get();
+        const double* mvals = P.sval2.get();
+        if (nupd > 0) {
+            hipLaunchKernelGGL(sp_updates_kernel, dim3(grid_for(nupd)), dim3(kBlock), 0, s, S, P.uoff.get(), nupd, P.pivl.get(), P.newrow.get(),
+                               P.newcol.get(), (int64_t)0, P.ukey.get(), P.uval.get());
+            sort_keys(T, P.ukey.get(), P.ukey2.get(), P.uval.get(), P.uval2.get(), (size_t)nupd, 32 + bits_for(std::max(dimN, 2)), s);
+            size_t bytes = 0;
+            IPXK_HIP(rocprim::merge(nullptr, bytes, P.skey2.get(), P.ukey2.get(), P.skey.get(), P.sval2.get(), P.uval2.get(), P.sval.get(), (size_t)ncarry,
+                                    (size_t)nupd, rocprim::less<u64>(), s));
+            IPXK_HIP(rocprim::merge(T.need(bytes), bytes, P.skey2.get(), P.ukey2.get(), P.skey.get(), P.sval2.get(), P.uval2.get(), P.sval.get(),
+                                    (size_t)ncarry, (size_t)nupd, rocprim::less<u64>(), s));
+            mkeys = P.skey.get();
+            mvals = P.sval.get();
+        }
+        sp_finish_matrix(s, W, mkeys, mvals, n, dimN, nxt, h, &nnz, &ne);
+        slow = (int64_t)nwin * slow_den < (int64_t)dimL ? slow + 1 : 0;
         cur = nxt;
         dimL = dimN;
     }
@@ -1342,7 +1433,7 @@ SparseOut sparse_rounds(hipStream_t s, LuWork& W, int dim, int64_t nb, const int
 
 // B as compact 32-bit CSC on the device -> factors in S
 static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, const int* Bp, const int* Bi,
-                                const double* Bx, double pivottol, bool strict, ipxk_lu_info* info) {
+                                const double* Bx, double pivottol, bool strict, ipxk_lu_info* info, bool after_failed_tear = false) {
     hipStream_t s = c->stream;
     int64_t nb = nb_in;
     S->valid = false;
@@ -1400,10 +1491,16 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
     if (const char* e = getenv("IPXK_LU_BUMP_MAX")) kb_max = std::max(0, atoi(e));
     bool tearing = false;
     int ntorn = 0, tear_width = 1, npiv_at_tear = 0;
-    // a bump beyond the dense limit: elimination rounds (default) or tearing (IPXK_LU_SPARSE=0)
-    const bool sparse_mode = !(getenv("IPXK_LU_SPARSE") && getenv("IPXK_LU_SPARSE")[0] == '0');
-    int sparse_min = 2048;
+    // a bump beyond the dense limit: tearing first (fast when a few hundred columns block the rounds); if that would need more
+    // spikes than the dense code takes, the factorization starts again with elimination rounds instead of being refused.
+    // IPXK_LU_SPARSE=1: elimination rounds at once; =0: tearing only (refused beyond the limit, as in round 3).
+    const char* sparse_env = getenv("IPXK_LU_SPARSE");
+    const bool sparse_allowed = !(sparse_env && sparse_env[0] == '0');
+    const bool sparse_mode = after_failed_tear || (sparse_env && sparse_env[0] == '1');
+    int sparse_min = 512;
     if (const char* e = getenv("IPXK_LU_SPARSE_MIN")) sparse_min = std::max(0, atoi(e));
+    int slow_den = 64;              // ... or it fits the dense code and two rounds in a row each eliminate fewer than 1 / 64 of the columns
+    if (const char* e = getenv("IPXK_LU_SPARSE_SLOW_DEN")) slow_den = std::max(0, atoi(e));
     SparseOut sp;
     bool sparse_done = false;
     while (dim > 0) {
@@ -1432,7 +1529,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
         if (nact == 0) break;
         if (!tearing && nact > kb_max && sparse_mode) {                 // 2c. elimination rounds down to sparse_min rows
             SparseGlobal G{rstage.get(), cstage.get(), pivrow.get(), pivot.get(), ckind.get()};
-            sp = sparse_rounds(s, W, dim, nb, Bi, colof.get(), Bx, G, nact, std::min(sparse_min, kb_max), &rounds, abstol, pivottol, h);
+            sp = sparse_rounds(s, W, dim, nb, Bi, colof.get(), Bx, G, nact, std::min(sparse_min, kb_max), kb_max, slow_den, &rounds, abstol, pivottol, h);
             sparse_done = true;
             break;
         }
@@ -1453,6 +1550,13 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
         hipLaunchKernelGGL(lu_tear_apply_kernel, dim3(grid_for(take)), dim3(kBlock), 0, s, R, W.tkey2.get(), take);
         ntorn += take;
         npiv_at_tear = npiv;
+        if (ntorn > kb_max && sparse_allowed) {
+            if (getenv("IPXK_VERBOSE"))
+                fprintf(stderr, "ipxk: LU dim %d: %d spikes torn off and %d columns still active: starting again with elimination rounds\n", dim, ntorn,
+                        nact - take);
+            lu_factorize_device(c, S, dim, nb_in, Bp, Bi, Bx, pivottol, strict, info, true);
+            return;
+        }
         if (ntorn > kb_max) {
             char msg[200];
             snprintf(msg, sizeof msg, "LU: %d spikes torn off the bump and %d columns still active: the dense block would exceed %d rows "

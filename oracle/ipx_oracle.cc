@@ -1419,7 +1419,7 @@ struct orc_lu {
 };
 
 static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, const Int* Bi_in, const double* Bx_in,
-                                 double pivottol, int strict_abs_pivottol, Int bump_limit, int sparse_rounds, Int sparse_min) {
+                                 double pivottol, int strict_abs_pivottol, Int bump_limit, int sparse_rounds, Int sparse_min, Int slow_den) {
     const double abstol = strict_abs_pivottol ? 1e-3 : 1e-14;
     std::unique_ptr<orc_lu> F(new orc_lu);
     F->dim = dim;
@@ -1578,7 +1578,11 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
             };
             if (bump_limit < 0 || nact <= bump_limit) break;       // small enough: dense as it stands
             rebuild();                                             // the active submatrix
+            int slow = 0;
             while (nact > sparse_min) {
+                // (the rounds stop early once the current matrix fits the dense code and two rounds in a row have each eliminated
+                // fewer than 1 / slow_den of the columns: what is left has no large sets of independent pivots any more)
+                if (slow_den > 0 && (bump_limit < 0 || nact <= bump_limit) && slow >= 2) break;
                 // 1. one candidate per column: among its entries that pass the absolute and the relative threshold, the one in
                 //    the shortest row (ties: larger |entry|, then smaller row); cost = (row count - 1)(column count - 1)
                 candrow.assign(dim, -1);
@@ -1653,6 +1657,7 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
                     fprintf(stderr, "elim round %lld: active %lld nnz %lld mincost %lld limit %lld candidates %lld winners %zu\n", (long long)F->info[7],
                             (long long)nact, (long long)cp[dim], (long long)mincost, (long long)limit, (long long)ncand, winners.size());
                 rebuild();
+                slow = (int64_t)winners.size() * slow_den < (int64_t)nact ? slow + 1 : 0;
                 nact -= (Int)winners.size();
             }
             break;
@@ -1830,15 +1835,16 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
 
 extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend, const Int* Bi, const double* Bx,
                                     double pivottol, int strict_abs_pivottol, Int bump_limit) {
-    return lu_factorize_impl(dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol, bump_limit, 0, 0);
+    return lu_factorize_impl(dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol, bump_limit, 0, 0, 0);
 }
 // ... with ELIMINATION ROUNDS instead of tearing: when the singleton rounds stall with more than bump_limit active columns, sets
 // of pivots with low Markowitz cost that form a diagonal block are eliminated at once (the fill-in enters the current matrix)
-// until at most sparse_min columns are active; what is left (at most bump_limit rows, else refused) is factorized densely,
-// its columns in ascending order of their number of entries.
+// until at most sparse_min columns are active, or at most bump_limit and two rounds in a row have each eliminated fewer than
+// 1 / slow_den of the columns (slow_den 0: never); what is left (at most bump_limit rows, else refused) is factorized densely, its columns in ascending
+// order of their number of entries.
 extern "C" orc_lu* orc_lu_factorize_sparse(Int dim, const Int* Bbegin, const Int* Bend, const Int* Bi, const double* Bx,
-                                           double pivottol, int strict_abs_pivottol, Int bump_limit, Int sparse_min) {
-    return lu_factorize_impl(dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol, bump_limit, 1, sparse_min);
+                                           double pivottol, int strict_abs_pivottol, Int bump_limit, Int sparse_min, Int slow_den) {
+    return lu_factorize_impl(dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol, bump_limit, 1, sparse_min, slow_den);
 }
 
 extern "C" void orc_lu_sizes(const orc_lu* F, Int* lnz, Int* unz, Int* ndep, Int* info) {

@@ -95,11 +95,72 @@ def test_lu_torn_bump_vs_oracle(kkt, oracle, monkeypatch):
         same_factors(F, Fo)
         if dim <= 3000:
             assert check_contract(G, F) < 1e-10
-        # a limit below the number of spikes: refused, loudly
-        monkeypatch.setenv("IPXK_LU_BUMP_MAX", str(max(1, F["spikes"] // 2)))
+        # a limit below the number of spikes: tearing alone refuses, loudly; by default the factorization then starts again with
+        # elimination rounds and equals the restatement's (same pivots, same values)
+        low = max(1, F["spikes"] // 2)
+        monkeypatch.setenv("IPXK_LU_BUMP_MAX", str(low))
+        monkeypatch.setenv("IPXK_LU_SPARSE", "0")
         with pytest.raises(RuntimeError, match="spikes"):
             c.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
+        monkeypatch.delenv("IPXK_LU_SPARSE")
+        if dim <= 3000:
+            Fs = c.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
+            Fo = oracle.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1, bump_limit=low, sparse_min=min(512, low))
+            assert Fs["sparse_rounds"] == Fo["info"]["sparse_rounds"] > 0 and Fs["spikes"] == 0
+            same_factors(Fs, Fo)
+            assert check_contract(G, Fs) < 1e-10
         c.close()
+
+
+def test_lu_elimination_rounds_vs_oracle(kkt, oracle, ref, monkeypatch):
+    """IPXK_LU_SPARSE=1: a bump beyond the dense limit goes through elimination rounds (ipx_amd/csrc/lu.hip 2c) -- the same
+    pivots in the same rounds, the same fill-in and the same VALUES as the CPU restatement, bit for bit (nonsingular bases
+    after exchanges, and singular ones with misplaced columns); the contract; the reference's LuFactorization::Factorize
+    calls the factors stable"""
+    from test_lu_oracle import TORN
+    monkeypatch.setenv("IPXK_LU_SPARSE", "1")
+    monkeypatch.setenv("IPXK_LU_MFMA_MIN", "0")        # (a dense block of more than 1024 rows: the elimination's own arithmetic, not the matrix cores')
+    c = kkt.KktContext(synth.synthetic_lp(8, 12, 2, 1))
+    cases = [(synth.disturbed_basis_matrix(seed=5, **{k: v for k, v in kw.items() if k != "limit"}), kw["limit"], max(8, kw["limit"] // 4)) for kw in TORN]
+    cases += [(synth.misplaced_basis_matrix(5000, 30, seed=3, bump=50), 200, 64), (synth.misplaced_basis_matrix(40000, 80, seed=4, bump=300), 1000, 256)]
+    for G, limit, smin in cases:
+        dim = G["dim"]
+        monkeypatch.setenv("IPXK_LU_BUMP_MAX", str(limit))
+        monkeypatch.setenv("IPXK_LU_SPARSE_MIN", str(smin))
+        F = c.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
+        Fo = oracle.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1, bump_limit=limit, sparse_min=smin)
+        assert (F["col_singletons"], F["row_singletons"], F["bump"], F["num_dependent"], F["sparse_pivots"], F["sparse_rounds"], F["rounds"]) == \
+            (Fo["info"]["col_singletons"], Fo["info"]["row_singletons"], Fo["info"]["bump"], Fo["info"]["dependent"],
+             Fo["info"]["sparse_pivots"], Fo["info"]["sparse_rounds"], Fo["info"]["rounds"]), (dim, limit)
+        assert F["sparse_rounds"] > 0 and F["spikes"] == 0
+        same_factors(F, Fo)
+        if dim <= 5000:
+            assert check_contract(G, F) < 1e-10
+        if F["num_dependent"] == 0:
+            R = ref.lu(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], F)
+            assert R.stability < 1e-12 and R.flag == 0
+    c.close()
+
+
+def test_lu_elimination_rounds_bound_the_fill(kkt, ref, monkeypatch):
+    """a 60000-row basis after 40 exchanges, default limits (dense block up to 8192 rows): tearing (the default, faster) and
+    the elimination rounds both factorize it; the rounds keep nnz(L) + nnz(U) under 3.5 x nnz(B), and the reference calls
+    both factorizations stable"""
+    G = synth.disturbed_basis_matrix(seed=5, dim=60000, num_exchanged=40, bump=100, offdiag=3)
+    dim, nb = G["dim"], len(G["Bi"])
+    monkeypatch.setenv("IPXK_LU_BUMP_MAX", "2048")
+    c = kkt.KktContext(synth.synthetic_lp(8, 12, 2, 1))
+    fills = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("IPXK_LU_SPARSE", mode)
+        F = c.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
+        assert F["num_dependent"] == 0 and (F["spikes"] > 0) == (mode == "0") and (F["sparse_rounds"] > 0) == (mode == "1")
+        fills[mode] = (F["lnz"] + F["unz"]) / nb
+        R = ref.lu(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], F)
+        assert R.stability < 1e-12 and R.flag == 0
+    c.close()
+    print("fill: torn %.2f, elimination rounds %.2f" % (fills["0"], fills["1"]))
+    assert fills["1"] <= 3.5
 
 
 @pytest.mark.parametrize("kw", [CASES[0], CASES[3], BIG[1]], ids=["plain", "singular", "big"])

@@ -133,3 +133,46 @@ def test_oracle_lu_torn_bump_under_the_reference(oracle, ref, kw):
         assert np.abs(r).max() <= 1e-8 * (1 + np.abs(y).max())
     if dim <= 3000:
         assert check_contract(G, F) < 1e-10
+
+
+@pytest.mark.parametrize("kw", TORN, ids=[str(i) for i in range(len(TORN))])
+def test_oracle_lu_elimination_rounds_under_the_reference(oracle, ref, kw):
+    """the same bases with ELIMINATION ROUNDS in place of tearing (sets of low-Markowitz-cost pivots that form a diagonal
+    block, eliminated together; the fill-in enters the current matrix): the contract, no dependent columns, every pivot
+    accounted for; the reference's LuFactorization::Factorize calls the factors stable and its ForrestTomlin solves with
+    them; and the factors hold no more entries than the torn ones do"""
+    kw = dict(kw)
+    limit = kw.pop("limit")
+    G = synth.disturbed_basis_matrix(seed=5, **kw)
+    dim = G["dim"]
+    torn = oracle.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], bump_limit=limit)
+    F = oracle.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], bump_limit=limit, sparse_min=max(8, limit // 4))
+    assert F is not None
+    inf = F["info"]
+    assert inf["sparse_rounds"] > 0 and inf["sparse_pivots"] >= inf["sparse_rounds"] and inf["spikes"] == 0 and inf["dependent"] == 0
+    assert inf["col_singletons"] + inf["row_singletons"] + inf["sparse_pivots"] + inf["bump"] == dim
+    assert inf["bump"] <= limit
+    assert F["L"].nnz + F["U"].nnz <= 1.05 * (torn["L"].nnz + torn["U"].nnz)
+    R = ref.lu(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], F)
+    assert R.stability < 1e-12 and R.flag == 0
+    B = sp.csc_matrix((G["Bx"].copy(), G["Bi"].copy(), G["Bp"].copy()), shape=(dim, dim))
+    x = np.random.default_rng(0).standard_normal(dim)
+    for trans in (False, True):
+        y = R.solve_dense(x, trans)
+        r = (B.T if trans else B) @ y - x
+        assert np.abs(r).max() <= 1e-8 * (1 + np.abs(y).max())
+    if dim <= 3000:
+        assert check_contract(G, F) < 1e-10
+
+
+def test_oracle_lu_elimination_rounds_find_the_rank(oracle):
+    """bases with misplaced columns at random positions are singular: the elimination rounds end with exactly as many
+    dependent columns as the matrix lacks in rank (numpy), and the contract holds with the unit columns in place"""
+    for seed in (1, 2, 3):
+        G = synth.misplaced_basis_matrix(1500, 25, seed=seed, bump=40)
+        dim = G["dim"]
+        B = sp.csc_matrix((G["Bx"].copy(), G["Bi"].copy(), G["Bp"].copy()), shape=(dim, dim)).toarray()
+        F = oracle.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], bump_limit=64, sparse_min=16)
+        assert F["info"]["sparse_rounds"] > 0
+        assert len(F["dependent"]) == dim - np.linalg.matrix_rank(B)
+        assert check_contract(G, F) < 1e-10
