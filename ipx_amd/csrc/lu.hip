@@ -37,7 +37,28 @@
 //      found so far, run for 64 spikes at a time as a dense dim x 64 block (one wavefront per row, one lane per
 //      spike, rows of one half-round in one launch, every row's products subtracted in pivot order).  Their
 //      entries in pivoted rows become entries of U, their entries in the never-pivoted rows form the dense block
-//      of step 2.  Only if THAT block exceeds the limit is the basis refused (IPXK_E_UNSUPPORTED).
+//      of step 2.
+//   2c. ELIMINATION ROUNDS (round 4).  If the spikes themselves would exceed the limit, the basis is no longer refused: the
+//      factorization starts again and, when the singleton rounds stall, eliminates the bump SPARSELY.  The active submatrix
+//      becomes a compact problem of its own (rows / columns renumbered in order, CSC + a row-wise index).  A round
+//        * picks one candidate per column: among the entries that pass the absolute and the relative pivot threshold, the one in
+//          the shortest row; its Markowitz cost is (row count - 1)(column count - 1);
+//        * lets the candidates of cost <= max(4, 2 x the cheapest, the quartile of all costs rounded up to 2^b - 1) compete: a row
+//          keeps its best (cost, then column index), and a contender wins unless a better one has an entry in its pivot row or
+//          its pivot row in this column -- the winners' pivots form a DIAGONAL block, so eliminating them together is exact
+//          (Schur complement = A22 - sum over winners of column x row / pivot), and a singleton is simply a winner of cost 0;
+//        * writes the updates -(a_i'j / pivot) a_ij' behind the surviving entries (which keep their order: the renumbering is
+//          monotone), sorts the updates, merges the two sorted lists (stable: entry first, then the updates in ascending order of
+//          the winner's column), sums equal positions in that order with the product rounded before it is subtracted, drops
+//          sums that are exactly zero, and rebuilds pointers, row index and counts.  Entries whose row or column was pivoted
+//          leave the matrix for the list E (indices in B, value at that time): E replaces B in the assembly of step 3.
+//      The rounds end at IPXK_LU_SPARSE_MIN columns (512), or -- once the rest fits the dense code -- after two rounds in a row
+//      that each eliminated fewer than 1 / 64 of the columns (what is left has no large independent pivot sets any more), or
+//      when no column has an acceptable pivot; they are GIVEN UP (IPXK_E_UNSUPPORTED) when the current matrix grows beyond
+//      IPXK_LU_SPARSE_FILL_MAX (8) x nnz(B) + 2^20 entries -- bounded work.  The rest is factorized densely as in step 2, its columns in ascending order
+//      of their number of entries (fewer nonzeros in the dense factors).  Only if THAT rest exceeds the limit is the basis
+//      refused (IPXK_E_UNSUPPORTED).  IPXK_LU_SPARSE=1: elimination rounds instead of tearing from the start; =0: never.
+//      Every rule is restated in oracle/ipx_oracle.cc (orc_lu_factorize_sparse); the factors are bit-identical to it.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_merge.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -1306,7 +1327,7 @@ void sp_finish_matrix(hipStream_t s, LuWork& W, const u64* skeys, const double* 
 // matrix (copy out.cur: out.kb rows, out.nnz entries, local indices = rank among the rows / columns of B that are still
 // active) is what the dense code takes over, and W.sp.E* (out.ne entries) replaces B in the assembly.
 SparseOut sparse_rounds(hipStream_t s, LuWork& W, int dim, int64_t nb, const int* Bi, const int* colof, const double* Bx, SparseGlobal G,
-                        int nact, int sparse_min, int kb_max, int slow_den, int* rounds, double abstol, double pivottol, int* h) {
+                        int nact, int sparse_min, int kb_max, int slow_den, int fill_max, int* rounds, double abstol, double pivottol, int* h) {
     LuWork::Sp& P = W.sp;
     Tmp& T = W.T;
     SparseOut out;
@@ -1425,6 +1446,15 @@ SparseOut sparse_rounds(hipStream_t s, LuWork& W, int dim, int64_t nb, const int
         slow = (int64_t)nwin * slow_den < (int64_t)dimL ? slow + 1 : 0;
         cur = nxt;
         dimL = dimN;
+        // bounded work: a bump whose elimination fills in beyond fill_max x nnz(B) (+ 2^20) is refused, and the caller's CPU
+        // kernel takes over (measured: such bases take minutes here -- the 1M-row basis of scripts/gpu_maxvol_bench.py with a
+        // tightened pivot tolerance: 14 941 rounds, 291 s, 103 x fill)
+        if (fill_max > 0 && nnz > (int64_t)fill_max * nb + (1 << 20)) {
+            char msg[200];
+            snprintf(msg, sizeof msg, "LU: after %d elimination rounds the bump holds %lld entries, more than %d x nnz(B) "
+                     "(IPXK_LU_SPARSE_FILL_MAX)", out.rounds, (long long)nnz, fill_max);
+            throw Error(IPXK_E_UNSUPPORTED, msg);
+        }
     }
     out.kb = dimL; out.cur = cur; out.nnz = nnz; out.ne = ne;
     return out;
@@ -1501,6 +1531,8 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
     if (const char* e = getenv("IPXK_LU_SPARSE_MIN")) sparse_min = std::max(0, atoi(e));
     int slow_den = 64;              // ... or it fits the dense code and two rounds in a row each eliminate fewer than 1 / 64 of the columns
     if (const char* e = getenv("IPXK_LU_SPARSE_SLOW_DEN")) slow_den = std::max(0, atoi(e));
+    int fill_max = 8;               // ... and are given up (IPXK_E_UNSUPPORTED) when the bump fills in beyond 8 x nnz(B) + 2^20 entries
+    if (const char* e = getenv("IPXK_LU_SPARSE_FILL_MAX")) fill_max = std::max(0, atoi(e));
     SparseOut sp;
     bool sparse_done = false;
     while (dim > 0) {
@@ -1529,7 +1561,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
         if (nact == 0) break;
         if (!tearing && nact > kb_max && sparse_mode) {                 // 2c. elimination rounds down to sparse_min rows
             SparseGlobal G{rstage.get(), cstage.get(), pivrow.get(), pivot.get(), ckind.get()};
-            sp = sparse_rounds(s, W, dim, nb, Bi, colof.get(), Bx, G, nact, std::min(sparse_min, kb_max), kb_max, slow_den, &rounds, abstol, pivottol, h);
+            sp = sparse_rounds(s, W, dim, nb, Bi, colof.get(), Bx, G, nact, std::min(sparse_min, kb_max), kb_max, slow_den, fill_max, &rounds, abstol, pivottol, h);
             sparse_done = true;
             break;
         }

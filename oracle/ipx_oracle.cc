@@ -1419,7 +1419,7 @@ struct orc_lu {
 };
 
 static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, const Int* Bi_in, const double* Bx_in,
-                                 double pivottol, int strict_abs_pivottol, Int bump_limit, int sparse_rounds, Int sparse_min, Int slow_den) {
+                                 double pivottol, int strict_abs_pivottol, Int bump_limit, int sparse_rounds, Int sparse_min, Int slow_den, Int fill_max) {
     const double abstol = strict_abs_pivottol ? 1e-3 : 1e-14;
     std::unique_ptr<orc_lu> F(new orc_lu);
     F->dim = dim;
@@ -1430,6 +1430,7 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
         for (Int p = Bbegin[j]; p < Bend[j]; p++) { ci.push_back(Bi_in[p]); cx.push_back(Bx_in[p]); }
         cp[j + 1] = (Int)ci.size();
     }
+    const int64_t nnz_B = cp[dim];
     // the entries that have left the current matrix because their row or column was pivoted, with the value they had then
     std::vector<Int> Ei, Ej;
     std::vector<double> Ex;
@@ -1659,6 +1660,7 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
                 rebuild();
                 slow = (int64_t)winners.size() * slow_den < (int64_t)nact ? slow + 1 : 0;
                 nact -= (Int)winners.size();
+                if (fill_max > 0 && (int64_t)cp[dim] > (int64_t)fill_max * nnz_B + (1 << 20)) return nullptr;   // bounded work: given up
             }
             break;
         }
@@ -1835,16 +1837,17 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
 
 extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend, const Int* Bi, const double* Bx,
                                     double pivottol, int strict_abs_pivottol, Int bump_limit) {
-    return lu_factorize_impl(dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol, bump_limit, 0, 0, 0);
+    return lu_factorize_impl(dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol, bump_limit, 0, 0, 0, 0);
 }
 // ... with ELIMINATION ROUNDS instead of tearing: when the singleton rounds stall with more than bump_limit active columns, sets
 // of pivots with low Markowitz cost that form a diagonal block are eliminated at once (the fill-in enters the current matrix)
 // until at most sparse_min columns are active, or at most bump_limit and two rounds in a row have each eliminated fewer than
-// 1 / slow_den of the columns (slow_den 0: never); what is left (at most bump_limit rows, else refused) is factorized densely, its columns in ascending
+// 1 / slow_den of the columns (slow_den 0: never); given up (NULL) when the current matrix exceeds fill_max x nnz(B) + 2^20 entries
+// (0: never); what is left (at most bump_limit rows, else refused) is factorized densely, its columns in ascending
 // order of their number of entries.
 extern "C" orc_lu* orc_lu_factorize_sparse(Int dim, const Int* Bbegin, const Int* Bend, const Int* Bi, const double* Bx,
-                                           double pivottol, int strict_abs_pivottol, Int bump_limit, Int sparse_min, Int slow_den) {
-    return lu_factorize_impl(dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol, bump_limit, 1, sparse_min, slow_den);
+                                           double pivottol, int strict_abs_pivottol, Int bump_limit, Int sparse_min, Int slow_den, Int fill_max) {
+    return lu_factorize_impl(dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol, bump_limit, 1, sparse_min, slow_den, fill_max);
 }
 
 extern "C" void orc_lu_sizes(const orc_lu* F, Int* lnz, Int* unz, Int* ndep, Int* info) {

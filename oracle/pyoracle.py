@@ -147,7 +147,7 @@ class Oracle:
                                _ip(ATp), _ip(ATi), _fp(ATx))
         return Csc(A.ncol, A.nrow, ATp, ATi, ATx)
 
-    def lu_factorize(self, dim, Bbegin, Bend, Bi, Bx, pivottol=0.1, strict=False, bump_limit=-1, sparse_min=None, slow_den=64):
+    def lu_factorize(self, dim, Bbegin, Bend, Bi, Bx, pivottol=0.1, strict=False, bump_limit=-1, sparse_min=None, slow_den=64, fill_max=8):
         """LuFactorization contract (src/lu_factorization.h:21-58): returns dict(L, U, rowperm, colperm, dependent,
         info) with L, U as Csc, or None when the bump exceeds bump_limit.  sparse_min: elimination rounds (not tearing)
         while more than that many columns are active."""
@@ -157,7 +157,7 @@ class Oracle:
                                           C.c_int(1 if strict else 0), c_i64(bump_limit))
         else:
             h = self.lib.orc_lu_factorize_sparse(c_i64(dim), _ip(Bbegin), _ip(Bend), _ip(Bi), _fp(Bx), c_f64(pivottol),
-                                                 C.c_int(1 if strict else 0), c_i64(bump_limit), c_i64(sparse_min), c_i64(slow_den))
+                                                 C.c_int(1 if strict else 0), c_i64(bump_limit), c_i64(sparse_min), c_i64(slow_den), c_i64(fill_max))
         if not h:
             return None
         h = C.c_void_p(h)
