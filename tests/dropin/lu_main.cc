@@ -138,7 +138,8 @@ int main(int argc, char** argv) {
         rep->calls = &calls;
         direct.Factorize(dim, Bp.data(), Bp.data() + 1, Bi.data(), Bx.data(), 0.1, false, &rep->L, &rep->U, &rep->rowperm,
                          &rep->colperm, &rep->dependent);
-        setenv("IPXK_LU_BUMP_MAX", "1", 1);               // now every bump is "too large" for the device
+        setenv("IPXK_LU_BUMP_MAX", "1", 1);               // now every bump is "too large" for the device ...
+        setenv("IPXK_LU_SPARSE", "0", 1);                 // ... and the sparse elimination rounds may not take it either
         ipx::LuKernelHip with_fallback(ctx, std::unique_ptr<ipx::LuFactorization>(rep));
         ipx::SparseMatrix L2, U2;
         std::vector<Int> rp2, cp2, dep2;
@@ -149,6 +150,7 @@ int main(int argc, char** argv) {
             none.Factorize(dim, Bp.data(), Bp.data() + 1, Bi.data(), Bx.data(), 0.1, false, &L2, &U2, &rp2, &cp2, &dep2);
         } catch (const std::exception& e) { threw = true; }
         unsetenv("IPXK_LU_BUMP_MAX");
+        unsetenv("IPXK_LU_SPARSE");
         const bool ok = calls == 1 && with_fallback.fallbacks() == 1 && with_fallback.stability() < 1e-12 && threw &&
                         direct.info().bump > 1;
         std::printf("fallback: calls %d, counted %ld, stability %.2e, without a fallback it throws: %d\n", calls,

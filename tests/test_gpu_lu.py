@@ -212,8 +212,13 @@ def test_lu_unsorted_strict_and_limits(ctx, oracle, kkt, monkeypatch):
     assert 0 < Ft["spikes"] <= 24
     same_factors(Ft, oracle.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx, bump_limit=24))
     monkeypatch.setenv("IPXK_LU_BUMP_MAX", "2")
+    monkeypatch.setenv("IPXK_LU_SPARSE", "0")
     with pytest.raises(kkt.KktError, match="spikes"):
         ctx.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx)
+    monkeypatch.delenv("IPXK_LU_SPARSE")             # by default the elimination rounds take over where tearing refuses
+    Fs = ctx.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx)
+    assert Fs["sparse_rounds"] > 0 and Fs["bump"] <= 2
+    same_factors(Fs, oracle.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx, bump_limit=2, sparse_min=2))
     monkeypatch.delenv("IPXK_LU_BUMP_MAX")
     bad = Bi.copy()
     bad[7] = 400
