@@ -765,6 +765,29 @@ def bench_lu(kkt, synth, m, n, args, bump=1000):
            "col_singletons": F["col_singletons"], "row_singletons": F["row_singletons"], "bump": F["bump"], "rounds": F["rounds"],
            "nnz_L": F["lnz"], "nnz_U": F["unz"], "fill_factor": (F["lnz"] + F["unz"]) / nb, "levels_Ut_Lt_L_U": ctx.split_levels(),
            "parity": {"solve_dense_residual": resid}}
+    # a bump beyond the dense limit (a timing of the torn path at >= 1M rows): the same basis after 200 exchanges at
+    # random positions; tearing (the default) and the sparse elimination rounds (IPXK_LU_SPARSE=1), second call each
+    try:
+        rng = np.random.default_rng(12350)
+        basis2 = P["basis"].copy()
+        basis2[rng.choice(m, 200, replace=False)] = rng.choice(np.nonzero(P["status"][:n] == -1)[0], 200, replace=False)
+        hard = {"workload": "the same basis after 200 exchanges at random positions (singular: the dependent columns are replaced by unit columns)"}
+        old_env = os.environ.get("IPXK_LU_SPARSE")
+        for mode, label in (("0", "tearing"), ("1", "elimination_rounds")):
+            os.environ["IPXK_LU_SPARSE"] = mode
+            for _ in range(2):
+                t0 = time.perf_counter()
+                Fh = ctx.lu_factorize_basis(basis2, 0.1, download=False)
+                dt = time.perf_counter() - t0
+            hard[label] = {"factorize_ms": dt * 1e3, "fill_factor": (Fh["lnz"] + Fh["unz"]) / nb, "spikes": Fh["spikes"], "sparse_pivots": Fh["sparse_pivots"],
+                           "sparse_rounds": Fh["sparse_rounds"], "dense_block": Fh["bump"], "rounds": Fh["rounds"], "dependent": Fh["num_dependent"]}
+        if old_env is None:
+            os.environ.pop("IPXK_LU_SPARSE", None)
+        else:
+            os.environ["IPXK_LU_SPARSE"] = old_env
+        res["beyond_the_dense_limit"] = hard
+    except Exception as e:            # noqa: BLE001 -- an auxiliary measurement must not take the bench line down
+        res["beyond_the_dense_limit"] = {"error": str(e)[:200]}
     if not args.no_cpu_baseline:
         from oracle import pyoracle
         Fd = ctx.lu_factorize_basis(P["basis"], 0.1, download=True)

@@ -10,6 +10,7 @@ m, K, bmax, smin = (int(a) for a in sys.argv[1:5]) if len(sys.argv) > 4 else (20
 bump = int(sys.argv[5]) if len(sys.argv) > 5 else 100
 G = synth.misplaced_basis_matrix(m, K, seed=12345, bump=bump)
 os.environ["IPXK_LU_BUMP_MAX"] = str(bmax)
+os.environ.setdefault("IPXK_LU_SPARSE", "1")
 os.environ["IPXK_LU_SPARSE_MIN"] = str(smin)
 ctx = kkt.KktContext(synth.synthetic_lp(8, 12, 2, 1))
 for rep in range(2):

@@ -18,4 +18,7 @@ python3 scripts/trace_summary.py gpurun_out/r04_c2_trace > gpurun_out/r04_c2_ker
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r04_lu_trace -- python3 scripts/gpu_lu_bench.py 100000 220000 8000 > gpurun_out/r04_lu_trace.log 2>&1 &&
 python3 scripts/trace_summary.py gpurun_out/r04_lu_trace > gpurun_out/r04_lu_bump8000_kernel_summary.txt &&
 python3 scripts/gpu_dense_inverse_bench.py > gpurun_out/r04_dense_inverse.txt 2>&1 &&
+IPXK_LU_SPARSE=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/r04_splu -o splu -- python3 scripts/gpu_sparse_lu_quick.py 200000 200 8192 512 1000 > gpurun_out/r04_lu_elimination_rounds.log 2>&1 &&
+python3 scripts/rocprof_top.py $(find /tmp/r04_splu -name "*.db" | head -1) 24 > gpurun_out/r04_lu_elimination_rounds_kernel_summary.txt &&
+python3 scripts/gpu_lu_hard_cases.py > gpurun_out/r04_lu_hard_cases.txt 2>&1 &&
 tail -3 gpurun_out/r04_basis_trace.log && tail -12 gpurun_out/r04_c2_iteration.txt && tail -4 gpurun_out/r04_basis_pmc_traffic.txt && head -12 gpurun_out/r04_lu_bump8000_kernel_summary.txt && cat gpurun_out/r04_dense_inverse.txt
