@@ -555,6 +555,7 @@ __global__ __launch_bounds__(kPanelThreads) void lu_panel_small_kernel(Dense A, 
 constexpr int kNarrow = 8;            // panel width with 4 rows per thread (bumps of 2049 .. 4096 rows)
 constexpr int kNarrowWide = 16;       // ... with 2 rows per thread (1025 .. 2048 rows): half the panels, the same registers
 constexpr int kNarrowDeep = 4;        // ... with 8 rows per thread (4097 .. 8192 rows)
+constexpr int kNarrowWideMax = 16;    // the widest sub-panel
 template <int R, int W, int T>
 __device__ __forceinline__ void panel_multi_steps(const Dense& A, PanelShared& sh, double (&v)[R][W], int c0, int c1,
                                                   unsigned& active, int& np, int& step) {
@@ -623,11 +624,22 @@ __device__ __forceinline__ void panel_multi_steps(const Dense& A, PanelShared& s
 // order, one rounded product at a time: every entry still receives exactly the arithmetic of the column-by-column
 // elimination).  Before: a full-matrix update per 8- or 16-column panel, and bumps of more than 4096 rows went
 // through lu_panel_kernel (one workgroup, the panel in L2: 1.2 ms per panel, 0.3 s for a 6000-row bump).
+// (usub / c1o: the previous sub-panel's rows of U in the rest of the outer panel, columns [c0, c1o), which lu_subpanel_update_kernel
+// left in a side buffer -- every one of its workgroups needs the rows as they were -- are written to their places here first.)
 template <int R, int W>
-__global__ __launch_bounds__(kPanelThreads) void lu_panel_multi_kernel(Dense A, int c0, int c1, int first_inner) {
+__global__ __launch_bounds__(kPanelThreads) void lu_panel_multi_kernel(Dense A, int c0, int c1, int first_inner, const double* __restrict__ usub = nullptr,
+                                                                       int c1o = 0) {
     __shared__ PanelShared sh;
     const int kb = A.kb, tid = threadIdx.x;
     const int base = first_inner ? 0 : A.bstep[3] + A.bstep[1];
+    if (usub && !first_inner) {
+        const int pf = A.bstep[3], pn = A.bstep[1], nc = c1o - c0;
+        for (int e = tid; e < pn * nc; e += kPanelThreads) {
+            const int t = e / nc, x = e - t * nc;
+            if (t > 0) A.D[(size_t)(c0 + x) * kb + A.prow[pf + t]] = usub[t * kPanel + x];      // (the first pivot's row is unchanged)
+        }
+        __syncthreads();
+    }
     A.prow += base; A.pcol += base;
     unsigned active = 0, have = 0;
     double v[R][W];
@@ -786,6 +798,60 @@ __global__ __launch_bounds__(kBlock) void lu_trailing_kernel(Dense A, int c1, in
             }
             *d = acc;
         }
+    }
+}
+
+// The update of the rest of the outer panel, columns [c1, cend), by the pivots of the last SUB-panel, in one launch (before:
+// lu_panel_rows_kernel mode 1 + lu_trailing_kernel mode 1).  Every workgroup (64 rows) forms the sub-panel's rows of U for those
+// columns itself in LDS -- np <= 16 pivots x <= 28 columns, the arithmetic of lu_panel_rows_kernel -- and updates its rows with
+// them; workgroup 0 leaves the rows of U in `usub` ([t][x], kPanel apart), and the next lu_panel_multi_kernel writes them to
+// their places: written here, they would race with the other workgroups' reads of the rows as they were.
+__global__ __launch_bounds__(kBlock) void lu_subpanel_update_kernel(Dense A, int c1, int cend, double* __restrict__ usub) {
+    __shared__ double l11[kNarrowWideMax][kNarrowWideMax];
+    __shared__ double Us[kNarrowWideMax][kPanel];
+    __shared__ double Ls[kNarrowWideMax][64];
+    __shared__ int prow[kNarrowWideMax];
+    __shared__ int live[64];
+    const int first = A.bstep[3], np = A.bstep[1], kb = A.kb, nc = cend - c1, tid = threadIdx.x;
+    if (np == 0 || nc <= 0) return;
+    A.prow += first; A.pcol += first;
+    const int r0 = blockIdx.x * 64;
+    for (int e = tid; e < np * np; e += kBlock) {
+        const int t2 = e / np, t = e - t2 * np;
+        l11[t2][t] = t < t2 ? A.D[(size_t)A.pcol[t] * kb + A.prow[t2]] : 0.0;
+    }
+    for (int e = tid; e < np * nc; e += kBlock) {
+        const int t = e / nc, x = e - t * nc;
+        Us[t][x] = A.D[(size_t)(c1 + x) * kb + A.prow[t]];
+    }
+    for (int e = tid; e < np * 64; e += kBlock) {
+        const int t = e / 64, x = e & 63;
+        Ls[t][x] = r0 + x < kb ? A.D[(size_t)A.pcol[t] * kb + r0 + x] : 0.0;
+    }
+    if (tid < np) prow[tid] = A.prow[tid];
+    if (tid < 64) live[tid] = (r0 + tid < kb && A.brstep[r0 + tid] < 0) ? 1 : 0;
+    __syncthreads();
+    if (tid < nc) {                       // the rows of U of column c1 + tid, pivot after pivot
+        for (int t = 0; t < np; t++) {
+            const double u = Us[t][tid];
+            if (u != 0.0)
+                for (int t2 = t + 1; t2 < np; t2++) Us[t2][tid] -= l11[t2][t] * u;
+        }
+        if (blockIdx.x == 0)
+            for (int t = 0; t < np; t++) usub[t * kPanel + tid] = Us[t][tid];
+    }
+    __syncthreads();
+    // 64 rows x nc columns: a thread takes a row and every fourth column
+    const int xr = tid & 63;
+    if (!live[xr]) return;
+    for (int xc = tid >> 6; xc < nc; xc += kBlock / 64) {
+        double* d = A.D + (size_t)(c1 + xc) * kb + r0 + xr;
+        double acc = *d;
+        for (int t = 0; t < np; t++) {
+            const double u = Us[t][xc];
+            if (u != 0.0) acc -= Ls[t][xr] * u;
+        }
+        *d = acc;
     }
 }
 
@@ -1214,6 +1280,7 @@ struct LuWork {
     DevBuf<int> colof, keys, pos, keys2, Rpos, Rj, Rp, rstage, cstage, rc, cc, cand, flag, rank, claim, pivrow, counters;
     DevBuf<int> rloc, cloc, brow, bcol, brstep, bcstep, bstep, prow, pcol;
     DevBuf<double> ubuf;               // [kPanel][kb] the outer panel's rows of U, contiguous (MFMA trailing update)
+    DevBuf<double> usub;               // [sub-panel pivot][kPanel] a sub-panel's rows of U in the rest of the outer panel
     DevBuf<u64> cand_bits, claim_abs, skey, skey2, lkey, lkey2, ukey, ukey2;
     DevBuf<double> pivot, D, lval, lval2, uval, uval2;
     DevBuf<unsigned char> ckind;
@@ -1751,6 +1818,9 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
             const bool use_mfma = mfma_min > 0 && kb >= mfma_min;
             LuWork& W_ = S->work;
             if (use_mfma) W_.ubuf.ensure((size_t)kPanel * kb);
+            // the sub-panel's rows of U and its update of the rest of the outer panel in one launch (IPXK_LU_FUSED_SUB=0: two)
+            const bool fused_sub = !(getenv("IPXK_LU_FUSED_SUB") && getenv("IPXK_LU_FUSED_SUB")[0] == '0');
+            W_.usub.ensure((size_t)kNarrowWideMax * kPanel);
             for (int c0 = 0; c0 < kb; c0 += kPanel) {
                 const int c1o = std::min(kb, c0 + kPanel);
                 // (measured and dropped: the whole outer panel in ONE launch, the sub-panels' updates of the rest of the outer
@@ -1758,12 +1828,17 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
                 // 228 ms at 8000 rows against 130 with the three launches per sub-panel below)
                 for (int ci = c0; ci < c1o; ci += W) {
                     const int ce = std::min(c1o, ci + W), first = ci == c0 ? 1 : 0;
-                    if (W == kNarrowWide) hipLaunchKernelGGL((lu_panel_multi_kernel<2, kNarrowWide>), dim3(1), dim3(kPanelThreads), 0, s, A, ci, ce, first);
-                    else if (W == kNarrow) hipLaunchKernelGGL((lu_panel_multi_kernel<4, kNarrow>), dim3(1), dim3(kPanelThreads), 0, s, A, ci, ce, first);
-                    else hipLaunchKernelGGL((lu_panel_multi_kernel<8, kNarrowDeep>), dim3(1), dim3(kPanelThreads), 0, s, A, ci, ce, first);
+                    const double* us = fused_sub ? W_.usub.get() : nullptr;
+                    if (W == kNarrowWide) hipLaunchKernelGGL((lu_panel_multi_kernel<2, kNarrowWide>), dim3(1), dim3(kPanelThreads), 0, s, A, ci, ce, first, us, c1o);
+                    else if (W == kNarrow) hipLaunchKernelGGL((lu_panel_multi_kernel<4, kNarrow>), dim3(1), dim3(kPanelThreads), 0, s, A, ci, ce, first, us, c1o);
+                    else hipLaunchKernelGGL((lu_panel_multi_kernel<8, kNarrowDeep>), dim3(1), dim3(kPanelThreads), 0, s, A, ci, ce, first, us, c1o);
                     if (ce < c1o) {         // the rest of the outer panel
-                        hipLaunchKernelGGL(lu_panel_rows_kernel, dim3(1), dim3(kBlock), 0, s, A, ce, c1o, 1);
-                        hipLaunchKernelGGL(lu_trailing_kernel, dim3((kb + 63) / 64, 1), dim3(kBlock), 0, s, A, ce, c1o, 1);
+                        if (fused_sub) {
+                            hipLaunchKernelGGL(lu_subpanel_update_kernel, dim3((kb + 63) / 64), dim3(kBlock), 0, s, A, ce, c1o, W_.usub.get());
+                        } else {
+                            hipLaunchKernelGGL(lu_panel_rows_kernel, dim3(1), dim3(kBlock), 0, s, A, ce, c1o, 1);
+                            hipLaunchKernelGGL(lu_trailing_kernel, dim3((kb + 63) / 64, 1), dim3(kBlock), 0, s, A, ce, c1o, 1);
+                        }
                     }
                 }
                 if (c1o < kb) {
