@@ -53,7 +53,7 @@
 //          sums that are exactly zero, and rebuilds pointers, row index and counts.  Entries whose row or column was pivoted
 //          leave the matrix for the list E (indices in B, value at that time): E replaces B in the assembly of step 3.
 //      The rounds end at IPXK_LU_SPARSE_MIN columns (512), or -- once the rest fits the dense code -- after two rounds in a row
-//      that each eliminated fewer than 1 / 64 of the columns (what is left has no large independent pivot sets any more), or
+//      that each eliminated fewer than 1 / 256 of the columns (what is left has no large independent pivot sets any more), or
 //      when no column has an acceptable pivot; they are GIVEN UP (IPXK_E_UNSUPPORTED) when the current matrix grows beyond
 //      IPXK_LU_SPARSE_FILL_MAX (8) x nnz(B) + 2^20 entries -- bounded work.  The rest is factorized densely as in step 2, its columns in ascending order
 //      of their number of entries (fewer nonzeros in the dense factors).  Only if THAT rest exceeds the limit is the basis
@@ -1596,7 +1596,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
     const bool sparse_mode = after_failed_tear || (sparse_env && sparse_env[0] == '1');
     int sparse_min = 512;
     if (const char* e = getenv("IPXK_LU_SPARSE_MIN")) sparse_min = std::max(0, atoi(e));
-    int slow_den = 64;              // ... or it fits the dense code and two rounds in a row each eliminate fewer than 1 / 64 of the columns
+    int slow_den = 256;             // ... or it fits the dense code and two rounds in a row each eliminate fewer than 1 / 256 of the columns
     if (const char* e = getenv("IPXK_LU_SPARSE_SLOW_DEN")) slow_den = std::max(0, atoi(e));
     int fill_max = 8;               // ... and are given up (IPXK_E_UNSUPPORTED) when the bump fills in beyond 8 x nnz(B) + 2^20 entries
     if (const char* e = getenv("IPXK_LU_SPARSE_FILL_MAX")) fill_max = std::max(0, atoi(e));

@@ -147,7 +147,7 @@ class Oracle:
                                _ip(ATp), _ip(ATi), _fp(ATx))
         return Csc(A.ncol, A.nrow, ATp, ATi, ATx)
 
-    def lu_factorize(self, dim, Bbegin, Bend, Bi, Bx, pivottol=0.1, strict=False, bump_limit=-1, sparse_min=None, slow_den=64, fill_max=8):
+    def lu_factorize(self, dim, Bbegin, Bend, Bi, Bx, pivottol=0.1, strict=False, bump_limit=-1, sparse_min=None, slow_den=256, fill_max=8):
         """LuFactorization contract (src/lu_factorization.h:21-58): returns dict(L, U, rowperm, colperm, dependent,
         info) with L, U as Csc, or None when the bump exceeds bump_limit.  sparse_min: elimination rounds (not tearing)
         while more than that many columns are active."""

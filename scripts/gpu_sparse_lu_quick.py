@@ -23,7 +23,7 @@ for rep in range(2):
     print("fill %.2f" % ((info["lnz"] + info["unz"]) / len(G["Bi"])), flush=True)
 if "--cpu" in sys.argv:
     t0 = time.perf_counter()
-    Fo = po.Oracle().lu_factorize(m, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1, bump_limit=bmax, sparse_min=smin, slow_den=int(os.environ.get("IPXK_LU_SPARSE_SLOW_DEN", "64")))
+    Fo = po.Oracle().lu_factorize(m, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1, bump_limit=bmax, sparse_min=smin, slow_den=int(os.environ.get("IPXK_LU_SPARSE_SLOW_DEN", "256")))
     print("CPU restatement %.2f s" % (time.perf_counter() - t0), Fo["info"], flush=True)
     for key in ("rowperm", "colperm", "dependent"):
         print(key, "equal:", np.array_equal(F[key], Fo[key]))
