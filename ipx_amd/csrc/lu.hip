@@ -389,6 +389,7 @@ struct Dense {
     double* D;             // column-major kb x kb
     int *brstep, *bcstep;  // pivot step of a bump row / column, -1 while unpivoted / for a dependent column
     int* bstep;            // [0] # pivots so far; [1] # pivots of the current (sub-)panel; [3] # pivots of the outer panel before it
+                           // (look-ahead: two sets of bstep / prow / pcol, used by the outer panels alternately)
     int *prow, *pcol;      // rows / columns of the current panel's pivots
     double abstol;
 };
@@ -628,7 +629,7 @@ __device__ __forceinline__ void panel_multi_steps(const Dense& A, PanelShared& s
 // left in a side buffer -- every one of its workgroups needs the rows as they were -- are written to their places here first.)
 template <int R, int W>
 __global__ __launch_bounds__(kPanelThreads) void lu_panel_multi_kernel(Dense A, int c0, int c1, int first_inner, const double* __restrict__ usub = nullptr,
-                                                                       int c1o = 0) {
+                                                                       int c1o = 0, const int* __restrict__ step_src = nullptr) {
     __shared__ PanelShared sh;
     const int kb = A.kb, tid = threadIdx.x;
     const int base = first_inner ? 0 : A.bstep[3] + A.bstep[1];
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(kPanelThreads) void lu_panel_multi_kernel(Dense A, 
         for (int t = 0; t < W; t++) v[q][t] = (r < kb && c0 + t < c1) ? A.D[(size_t)(c0 + t) * kb + r] : 0.0;
     }
     int np = 0;
-    int step = A.bstep[0];
+    int step = (first_inner && step_src) ? step_src[0] : A.bstep[0];       // (look-ahead: the count so far is in the other set)
     panel_multi_steps<R, W, 0>(A, sh, v, c0, c1, active, np, step);
 #pragma unroll
     for (int q = 0; q < R; q++)
@@ -719,14 +720,17 @@ __global__ __launch_bounds__(kBlock) void lu_panel_rows_kernel(Dense A, int c1, 
 // (fused, k ascending): no longer the one-rounded-product-at-a-time arithmetic of the restatement -- the factors are
 // judged by the stability estimate (src/lu_factorization.cc:87-127) and agree with the restatement's to ~1e-13.
 typedef double lu_d4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(kBlock) void lu_trailing_mfma_kernel(Dense A, const double* __restrict__ ubuf, int ldu, int c1, int cend) {
+// (look-ahead: the update of columns [c1, cend) may run while the next outer panel is being factorized; a row that panel pivots
+// meanwhile carries a step >= this panel's count bstep[0] and is still live for THIS update.  ubuf's columns start at cu.)
+__global__ __launch_bounds__(kBlock) void lu_trailing_mfma_kernel(Dense A, const double* __restrict__ ubuf, int ldu, int c1, int cend, int cu) {
     const int np = A.bstep[3] + A.bstep[1], kb = A.kb;
     if (np == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int r = blockIdx.x * 64 + wave * 16 + li;               // this lane's row of D (B operand / result column)
     const int rc = min(r, kb - 1);
-    const bool live = r < kb && A.brstep[rc] < 0;
+    const int rs = A.brstep[rc];
+    const bool live = r < kb && (rs < 0 || rs >= A.bstep[0]);
     // all rows of the wavefront's 16 pivoted already: nothing to do
     if (__ballot(live) == 0ull) return;
     double lf[8];                                                 // L[r][t = 4 ks + lk]
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(kBlock) void lu_trailing_mfma_kernel(Dense A, const
     for (int ct = 0; ct < 4; ct++) {
         const int c0 = cb + ct * 16;
         if (c0 >= cend) break;
-        const int ca = min(c0 + li, cend - 1) - c1;               // A operand: column c0 + li of the trailing part
+        const int ca = min(c0 + li, cend - 1) - cu;               // A operand: column c0 + li of the trailing part
         lu_d4 acc;
 #pragma unroll
         for (int q = 0; q < 4; q++) {                             // result q: column c0 + lk + 4 q, row r
@@ -1304,7 +1308,14 @@ struct LuWork {
     } sp;
     Tmp T;
     int* h = nullptr;                 // pinned: counters read back per batch of rounds
-    ~LuWork() { if (h) (void)hipHostFree(h); }
+    // look-ahead of the dense LU: the trailing update beyond the next outer panel runs on a second stream
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_trail[2] = {nullptr, nullptr};
+    ~LuWork() {
+        if (h) (void)hipHostFree(h);
+        for (hipEvent_t e : {ev_rows[0], ev_rows[1], ev_trail[0], ev_trail[1]}) if (e) (void)hipEventDestroy(e);
+        if (s2) (void)hipStreamDestroy(s2);
+    }
 };
 
 struct LuState {
@@ -1690,7 +1701,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
     DevBuf<int> &rloc = W.rloc, &cloc = W.cloc, &brow = W.brow, &bcol = W.bcol, &brstep = W.brstep, &bcstep = W.bcstep,
                 &bstep = W.bstep, &prow = W.prow, &pcol = W.pcol;
     DevBuf<double>& D = W.D;
-    rloc.ensure(d1); cloc.ensure(d1); bstep.ensure(4); prow.ensure(kPanel); pcol.ensure(kPanel);
+    rloc.ensure(d1); cloc.ensure(d1); bstep.ensure(8); prow.ensure(2 * kPanel); pcol.ensure(2 * kPanel);
     int kb = 0;
     if (dim > 0) {
         hipLaunchKernelGGL(lu_active_flag_kernel, dim3(g), dim3(kBlock), 0, s, dim, rstage.get(), flag.get());
@@ -1715,7 +1726,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
     if (kb > 0) {
         D.ensure((size_t)kb * kb);
         IPXK_HIP(hipMemsetAsync(D.get(), 0, (size_t)kb * kb * sizeof(double), s));
-        IPXK_HIP(hipMemsetAsync(bstep.get(), 0, 4 * sizeof(int), s));
+        IPXK_HIP(hipMemsetAsync(bstep.get(), 0, 8 * sizeof(int), s));
         const int gk = grid_for(kb);
         hipLaunchKernelGGL(lu_fill_int_kernel, dim3(gk), dim3(kBlock), 0, s, (int64_t)kb, -1, brstep.get());
         hipLaunchKernelGGL(lu_fill_int_kernel, dim3(gk), dim3(kBlock), 0, s, (int64_t)kb, -1, bcstep.get());
@@ -1821,37 +1832,87 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
             // the sub-panel's rows of U and its update of the rest of the outer panel in one launch (IPXK_LU_FUSED_SUB=0: two)
             const bool fused_sub = !(getenv("IPXK_LU_FUSED_SUB") && getenv("IPXK_LU_FUSED_SUB")[0] == '0');
             W_.usub.ensure((size_t)kNarrowWideMax * kPanel);
-            for (int c0 = 0; c0 < kb; c0 += kPanel) {
+            // LOOK-AHEAD (with the matrix cores; IPXK_LU_LOOKAHEAD=0: off): an outer panel's update of the NEXT outer panel's columns
+            // runs first, on this stream; its update of everything beyond runs on a second stream while the next outer panel is
+            // factorized here.  The outer panels use two sets of pivot lists / counters alternately (the late update still reads
+            // its own), a row the next panel pivots meanwhile stays live for the late update (step >= that panel's count), and the
+            // next panel's rows of U beyond its columns wait for the late update.  Every entry still receives each panel's update
+            // exactly once, panels in order: the same factors bit for bit.
+            // Measured (scripts/gpu_lu_fused_check.py): 107.7 -> 96.2 ms at 8000 rows with 32 compute units kept free for the panel
+            // kernels (16: no gain; the same 32 spread over the mask's words: slower), nothing at 5000 rows -- so from 6144 rows on
+            // (IPXK_LU_LOOKAHEAD=1: always with the matrix cores, =0: never).
+            const char* look_env = getenv("IPXK_LU_LOOKAHEAD");
+            const bool lookahead = use_mfma && (look_env ? look_env[0] != '0' : kb >= 6144);
+            Dense Ap[2] = {A, A};
+            Ap[1].bstep = bstep.get() + 4; Ap[1].prow = prow.get() + kPanel; Ap[1].pcol = pcol.get() + kPanel;
+            if (lookahead && !W_.s2) {
+                // the late update leaves some compute units to the panel kernels of the first stream (a one-workgroup kernel of 1024
+                // threads does not get a slot on a chip that a 15 000-workgroup kernel keeps full): IPXK_LU_LOOKAHEAD_FREE_CUS
+                int free_cus = 32;
+                if (const char* e = getenv("IPXK_LU_LOOKAHEAD_FREE_CUS")) free_cus = std::max(0, std::min(128, atoi(e)));
+                uint32_t mask[8];
+                for (int w = 0; w < 8; w++) mask[w] = 0xffffffffu;
+                const bool spread = getenv("IPXK_LU_LOOKAHEAD_SPREAD") != nullptr;       // (measurement: the free units taken from all eight words of the mask)
+                for (int b = 0; b < free_cus; b++) {
+                    const int bit = spread ? (b % 8) * 32 + b / 8 : b;
+                    mask[bit / 32] &= ~(1u << (bit % 32));
+                }
+                if (free_cus > 0) IPXK_HIP(hipExtStreamCreateWithCUMask(&W_.s2, 8, mask));
+                else IPXK_HIP(hipStreamCreateWithFlags(&W_.s2, hipStreamNonBlocking));
+                for (hipEvent_t* e : {&W_.ev_rows[0], &W_.ev_rows[1], &W_.ev_trail[0], &W_.ev_trail[1]})
+                    IPXK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+            }
+            int k = 0, last_late = -1;                  // outer panel index; the last outer panel with a late update in flight
+            for (int c0 = 0; c0 < kb; c0 += kPanel, k++) {
                 const int c1o = std::min(kb, c0 + kPanel);
+                const Dense& P = lookahead ? Ap[k & 1] : A;
+                const int* step_src = (lookahead && k > 0) ? Ap[(k - 1) & 1].bstep : nullptr;
                 // (measured and dropped: the whole outer panel in ONE launch, the sub-panels' updates of the rest of the outer
                 // panel by that one workgroup too -- bit-identical, but one CU moves those kb x 28 columns at 50-100 GB/s:
                 // 228 ms at 8000 rows against 130 with the three launches per sub-panel below)
                 for (int ci = c0; ci < c1o; ci += W) {
                     const int ce = std::min(c1o, ci + W), first = ci == c0 ? 1 : 0;
                     const double* us = fused_sub ? W_.usub.get() : nullptr;
-                    if (W == kNarrowWide) hipLaunchKernelGGL((lu_panel_multi_kernel<2, kNarrowWide>), dim3(1), dim3(kPanelThreads), 0, s, A, ci, ce, first, us, c1o);
-                    else if (W == kNarrow) hipLaunchKernelGGL((lu_panel_multi_kernel<4, kNarrow>), dim3(1), dim3(kPanelThreads), 0, s, A, ci, ce, first, us, c1o);
-                    else hipLaunchKernelGGL((lu_panel_multi_kernel<8, kNarrowDeep>), dim3(1), dim3(kPanelThreads), 0, s, A, ci, ce, first, us, c1o);
+                    if (W == kNarrowWide) hipLaunchKernelGGL((lu_panel_multi_kernel<2, kNarrowWide>), dim3(1), dim3(kPanelThreads), 0, s, P, ci, ce, first, us, c1o, step_src);
+                    else if (W == kNarrow) hipLaunchKernelGGL((lu_panel_multi_kernel<4, kNarrow>), dim3(1), dim3(kPanelThreads), 0, s, P, ci, ce, first, us, c1o, step_src);
+                    else hipLaunchKernelGGL((lu_panel_multi_kernel<8, kNarrowDeep>), dim3(1), dim3(kPanelThreads), 0, s, P, ci, ce, first, us, c1o, step_src);
                     if (ce < c1o) {         // the rest of the outer panel
                         if (fused_sub) {
-                            hipLaunchKernelGGL(lu_subpanel_update_kernel, dim3((kb + 63) / 64), dim3(kBlock), 0, s, A, ce, c1o, W_.usub.get());
+                            hipLaunchKernelGGL(lu_subpanel_update_kernel, dim3((kb + 63) / 64), dim3(kBlock), 0, s, P, ce, c1o, W_.usub.get());
                         } else {
-                            hipLaunchKernelGGL(lu_panel_rows_kernel, dim3(1), dim3(kBlock), 0, s, A, ce, c1o, 1);
-                            hipLaunchKernelGGL(lu_trailing_kernel, dim3((kb + 63) / 64, 1), dim3(kBlock), 0, s, A, ce, c1o, 1);
+                            hipLaunchKernelGGL(lu_panel_rows_kernel, dim3(1), dim3(kBlock), 0, s, P, ce, c1o, 1);
+                            hipLaunchKernelGGL(lu_trailing_kernel, dim3((kb + 63) / 64, 1), dim3(kBlock), 0, s, P, ce, c1o, 1);
                         }
                     }
                 }
                 if (c1o < kb) {
-                    if (use_mfma) {
-                        hipLaunchKernelGGL(lu_panel_rows_kernel, dim3(grid_for(kb - c1o)), dim3(kBlock), 0, s, A, c1o, kb, 2, W_.ubuf.get(), kb);
-                        hipLaunchKernelGGL(lu_trailing_mfma_kernel, dim3((kb + 63) / 64, (kb - c1o + 63) / 64), dim3(kBlock), 0, s, A, W_.ubuf.get(), kb,
-                                           c1o, kb);
+                    if (lookahead) {
+                        if (last_late >= 0) IPXK_HIP(hipStreamWaitEvent(s, W_.ev_trail[last_late & 1], 0));      // the columns beyond are up to date
+                        hipLaunchKernelGGL(lu_panel_rows_kernel, dim3(grid_for(kb - c1o)), dim3(kBlock), 0, s, P, c1o, kb, 2, W_.ubuf.get(), kb);
+                        IPXK_HIP(hipEventRecord(W_.ev_rows[k & 1], s));
+                        const int cl = std::min(kb, c1o + kPanel);
+                        hipLaunchKernelGGL(lu_trailing_mfma_kernel, dim3((kb + 63) / 64, 1), dim3(kBlock), 0, s, P, W_.ubuf.get(), kb, c1o, cl, c1o);
+                        last_late = -1;
+                        if (cl < kb) {
+                            IPXK_HIP(hipStreamWaitEvent(W_.s2, W_.ev_rows[k & 1], 0));
+                            hipLaunchKernelGGL(lu_trailing_mfma_kernel, dim3((kb + 63) / 64, (kb - cl + 63) / 64), dim3(kBlock), 0, W_.s2, P, W_.ubuf.get(), kb,
+                                               cl, kb, c1o);
+                            IPXK_HIP(hipEventRecord(W_.ev_trail[k & 1], W_.s2));
+                            last_late = k;
+                        }
+                    } else if (use_mfma) {
+                        hipLaunchKernelGGL(lu_panel_rows_kernel, dim3(grid_for(kb - c1o)), dim3(kBlock), 0, s, P, c1o, kb, 2, W_.ubuf.get(), kb);
+                        hipLaunchKernelGGL(lu_trailing_mfma_kernel, dim3((kb + 63) / 64, (kb - c1o + 63) / 64), dim3(kBlock), 0, s, P, W_.ubuf.get(), kb,
+                                           c1o, kb, c1o);
                     } else {
-                        hipLaunchKernelGGL(lu_panel_rows_kernel, dim3(grid_for(kb - c1o)), dim3(kBlock), 0, s, A, c1o, kb, 2);
-                        hipLaunchKernelGGL(lu_trailing_kernel, dim3((kb + 63) / 64, (kb - c1o + 63) / 64), dim3(kBlock), 0, s, A, c1o, kb, 2);
+                        hipLaunchKernelGGL(lu_panel_rows_kernel, dim3(grid_for(kb - c1o)), dim3(kBlock), 0, s, P, c1o, kb, 2);
+                        hipLaunchKernelGGL(lu_trailing_kernel, dim3((kb + 63) / 64, (kb - c1o + 63) / 64), dim3(kBlock), 0, s, P, c1o, kb, 2);
                     }
                 }
             }
+            if (last_late >= 0) IPXK_HIP(hipStreamWaitEvent(s, W_.ev_trail[last_late & 1], 0));
+            if (lookahead && k > 0 && ((k - 1) & 1))        // the counters of the last outer panel to where they are read
+                IPXK_HIP(hipMemcpyAsync(bstep.get(), bstep.get() + 4, 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
         }
         IPXK_HIP(hipMemcpyAsync(h, bstep.get(), 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         IPXK_HIP(hipStreamSynchronize(s));
