@@ -785,24 +785,38 @@ __global__ __launch_bounds__(kBlock) void lu_trailing_kernel(Dense A, int c1, in
     }
     if (tid < 64) live[tid] = (r0 + tid < kb && A.brstep[r0 + tid] < 0) ? 1 : 0;
     __syncthreads();
+    // a thread's 4 x 4 entries in registers, the pivots in the outer loop: sixteen independent chains instead of one (each entry
+    // still receives its products one at a time in pivot order, and none for a zero of U)
     const int tx = tid & 15, ty = tid >> 4;
+    double acc[4][4];
+    bool on[4][4];
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const int xc = ty + 16 * b, c2 = cb + xc;
-        if (c2 >= cend) continue;
+    for (int b = 0; b < 4; b++)
 #pragma unroll
         for (int a = 0; a < 4; a++) {
-            const int xr = tx + 16 * a;
-            if (!live[xr]) continue;
-            double* d = A.D + (size_t)c2 * kb + r0 + xr;
-            double acc = *d;
-            for (int t = 0; t < np; t++) {
-                const double u = Us[t][xc];
-                if (u != 0.0) acc -= Ls[t][xr] * u;
-            }
-            *d = acc;
+            const int xc = ty + 16 * b, xr = tx + 16 * a;
+            on[a][b] = cb + xc < cend && live[xr];
+            acc[a][b] = on[a][b] ? A.D[(size_t)(cb + xc) * kb + r0 + xr] : 0.0;
         }
+    for (int t = 0; t < np; t++) {
+        double l[4], u[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) l[a] = Ls[t][tx + 16 * a];
+#pragma unroll
+        for (int b = 0; b < 4; b++) u[b] = Us[t][ty + 16 * b];
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const double next = acc[a][b] - l[a] * u[b];
+                acc[a][b] = u[b] != 0.0 ? next : acc[a][b];
+            }
     }
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+            if (on[a][b]) A.D[(size_t)(cb + ty + 16 * b) * kb + r0 + tx + 16 * a] = acc[a][b];
 }
 
 // The update of the rest of the outer panel, columns [c1, cend), by the pivots of the last SUB-panel, in one launch (before:
