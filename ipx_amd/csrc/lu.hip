@@ -700,6 +700,9 @@ __global__ __launch_bounds__(kBlock) void lu_panel_rows_kernel(Dense A, int c1, 
                 for (int t2 = t + 1; t2 < kPanel; t2++)
                     if (t2 < np) v[t2] -= l11[t2][t] * u;
             }
+            // (keeps the LDS reads of the later pivots from being hoisted up here: all 496 at once need 256 registers and 684
+            // bytes of scratch per lane -- the kernel took 38-54 us; with the fence 40 registers)
+            asm volatile("" ::: "memory");
         }
 #pragma unroll
         for (int t = 1; t < kPanel; t++)
