@@ -473,13 +473,17 @@ struct PanelShared {
 };
 // the pivot row of a step from the wavefronts' candidates (largest |entry|, ties: smaller row); -1: none / no column
 __device__ __forceinline__ int panel_pivot_row(const PanelShared& sh, int par, bool col, double abstol, bool* dependent) {
-    double bv = 0.0;
-    int rr = INT_MAX;
+    // (every lane reads one wavefront's candidate and the sixteen are combined by shuffles: the same selection -- a total order --
+    // as a scan of all sixteen by every thread, at a third of the LDS traffic: the scan was 1 us of a 4.5 us pivot step)
+    static_assert(kPanelThreads / 64 == 16, "sixteen wavefronts");
+    double bv = sh.red_v[par][threadIdx.x & 15];
+    int rr = sh.red_r[par][threadIdx.x & 15];
+    if (!(bv > 0.0)) { bv = 0.0; rr = INT_MAX; }          // (no candidate, or not a number: never a pivot)
 #pragma unroll
-    for (int w = 0; w < kPanelThreads / 64; w++) {
-        const double v = sh.red_v[par][w];
-        const int r = sh.red_r[par][w];
-        if (v > bv || (v == bv && r < rr)) { bv = v; rr = r; }
+    for (int d = 8; d >= 1; d >>= 1) {
+        const double ov = __shfl_xor(bv, d, 64);
+        const int orr = __shfl_xor(rr, d, 64);
+        if (ov > bv || (ov == bv && orr < rr)) { bv = ov; rr = orr; }
     }
     *dependent = col && (rr == INT_MAX || !(bv >= abstol) || bv == 0.0);
     return col && !*dependent ? rr : -1;
