@@ -160,19 +160,22 @@ def bench_diag_config(kkt, synth, label, m, n, num_dense, args, reps_cpu):
         it, errflag, tm = ctx.kkt_diag_solve_resident(a, b, x, y, tol, args.maxiter)
     ctx.synchronize()
     K = 10
-    t0 = time.perf_counter()
-    for _ in range(K):
+    each = []                        # (auxiliary configs: every solve timed on its own and the MEDIAN reported -- a 2 ms solve of 280
+    for _ in range(K):               # launches is at the mercy of one host hiccup; the headline keeps the contract's K-step total)
+        t0 = time.perf_counter()
         it, errflag, tm = ctx.kkt_diag_solve_resident(a, b, x, y, tol, args.maxiter)
-    ctx.synchronize()
-    dt = (time.perf_counter() - t0) / K
+        ctx.synchronize()
+        each.append(time.perf_counter() - t0)
+    dt = float(np.median(each))
+    dt_mean = float(np.mean(each))
     rhs_d, lhs_d = ctx.vector(m, np.random.default_rng(0).standard_normal(m)), ctx.vector(m)
     ctx.time_normal_apply(rhs_d, lhs_d, 5)
     apply_ms = ctx.time_normal_apply(rhs_d, lhs_d, 50) / 50
     nbytes = ctx.normal_apply_bytes
     layouts = ctx.spmv_layout()[0]
     ctx.set_pointer_mode(False)
-    res = {"workload": label, "solves_per_sec": 1.0 / dt, "ms_per_solve": dt * 1e3, "cr_iterations": it, "errflag": errflag,
-           "factorize_ms": t_fact * 1e3, "first_factorize_ms": t_fact_first * 1e3, "num_dense_cols": ctx.num_dense_cols,
+    res = {"workload": label, "solves_per_sec": 1.0 / dt, "ms_per_solve": dt * 1e3, "ms_per_solve_mean_of_%d" % K: dt_mean * 1e3,
+           "cr_iterations": it, "errflag": errflag, "factorize_ms": t_fact * 1e3, "first_factorize_ms": t_fact_first * 1e3, "num_dense_cols": ctx.num_dense_cols,
            "roofline": {"bound": "hbm", "us_per_apply": apply_ms * 1e3, "algorithmic_bytes": nbytes,
                         "achieved": nbytes / (apply_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": nbytes / (apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "layouts": list(layouts)},

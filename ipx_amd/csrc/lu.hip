@@ -1200,6 +1200,7 @@ struct Assemble {
     u64 *lkey, *ukey;
     double *lval, *uval;
     int tearing;           // the bump's columns are spikes: their entries above the dense block come from the substitution
+    int shift;             // keys are (stage of the column << shift) | stage of the row, 2^shift > dim: the sorts run over 2 * shift bits
 };
 __global__ void lu_keys_sparse_kernel(Assemble A, int64_t nb) {
     IPXK_GRID_STRIDE(p, nb) {
@@ -1207,7 +1208,7 @@ __global__ void lu_keys_sparse_kernel(Assemble A, int64_t nb) {
         if (A.ckind[j] == 4) continue;                          // replaced by a unit column
         if (A.cloc[j] >= 0 && (A.tearing || A.rloc[i] >= 0)) continue;   // bump x bump: from the dense result; a spike: lu_keys_spike_kernel
         const int k = A.cstage[j], s = A.rstage[i];
-        const u64 key = ((u64)(unsigned)k << 32) | (unsigned)s;
+        const u64 key = ((u64)(unsigned)k << A.shift) | (unsigned)s;
         if (s <= k) { A.ukey[p] = key; A.uval[p] = A.Bx[p]; }
         else { A.lkey[p] = key; A.lval[p] = A.Bx[p] / A.pivot[j]; }
     }
@@ -1219,7 +1220,7 @@ __global__ void lu_keys_dense_kernel(Assemble A, int64_t nb) {
         if (A.bcstep[c] < 0) continue;
         const int k = A.cstage[A.bcol[c]], s = A.rstage[A.brow[r]];
         const double v = A.D[e];
-        const u64 key = ((u64)(unsigned)k << 32) | (unsigned)s;
+        const u64 key = ((u64)(unsigned)k << A.shift) | (unsigned)s;
         if (s == k) { A.ukey[nb + e] = key; A.uval[nb + e] = v; }
         else if (v != 0.0) {
             if (s < k) { A.ukey[nb + e] = key; A.uval[nb + e] = v; }
@@ -1233,7 +1234,7 @@ __global__ void lu_keys_spike_kernel(Assemble A, int64_t off, int nspk, const in
         const int c = spk_c[e];
         if (A.bcstep[c] < 0) continue;                          // a dependent spike is replaced by a unit column
         const int k = A.cstage[A.bcol[c]];
-        A.ukey[off + e] = ((u64)(unsigned)k << 32) | (unsigned)spk_s[e];
+        A.ukey[off + e] = ((u64)(unsigned)k << A.shift) | (unsigned)spk_s[e];
         A.uval[off + e] = spk_v[e];
     }
 }
@@ -1241,14 +1242,14 @@ __global__ void lu_keys_unit_kernel(Assemble A, int64_t off) {
     IPXK_GRID_STRIDE(j, A.dim) {
         if (A.ckind[j] != 4) continue;
         const int k = A.cstage[j];
-        A.ukey[off + j] = ((u64)(unsigned)k << 32) | (unsigned)k;
+        A.ukey[off + j] = ((u64)(unsigned)k << A.shift) | (unsigned)k;
         A.uval[off + j] = 1.0;
     }
 }
-// column pointers of a factor from its sorted keys: ptr[k] = first key >= (k << 32), k = 0..dim
-__global__ void lu_colptr_kernel(int dim, int64_t n, const u64* __restrict__ keys, ipxint* __restrict__ ptr) {
+// column pointers of a factor from its sorted keys: ptr[k] = first key >= (k << shift), k = 0..dim
+__global__ void lu_colptr_kernel(int dim, int64_t n, const u64* __restrict__ keys, ipxint* __restrict__ ptr, int shift = 32) {
     IPXK_GRID_STRIDE(k, (int64_t)dim + 1) {
-        const u64 want = (u64)k << 32;
+        const u64 want = (u64)k << shift;
         int64_t lo = 0, hi = n;
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
@@ -1257,8 +1258,8 @@ __global__ void lu_colptr_kernel(int dim, int64_t n, const u64* __restrict__ key
         ptr[k] = lo;
     }
 }
-__global__ void lu_rowidx_kernel(int64_t nz, const u64* __restrict__ keys, ipxint* __restrict__ idx) {
-    IPXK_GRID_STRIDE(q, nz) idx[q] = (ipxint)(keys[q] & 0xffffffffull);
+__global__ void lu_rowidx_kernel(int64_t nz, const u64* __restrict__ keys, ipxint* __restrict__ idx, int shift = 32) {
+    IPXK_GRID_STRIDE(q, nz) idx[q] = (ipxint)(keys[q] & ((1ull << shift) - 1));
 }
 __global__ void lu_perm_kernel(int dim, const int* __restrict__ stage, ipxint* __restrict__ perm, int* bad) {
     IPXK_GRID_STRIDE(i, dim) {
@@ -1982,18 +1983,21 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
         for (DevBuf<double>* b : {&uval, &uval2}) b->ensure((size_t)nu);
         if (nl > 0) hipLaunchKernelGGL(lu_fill_u64_kernel, dim3(grid_for(nl)), dim3(kBlock), 0, s, nl, kNoKey, lkey.get());
         hipLaunchKernelGGL(lu_fill_u64_kernel, dim3(grid_for(nu)), dim3(kBlock), 0, s, nu, kNoKey, ukey.get());
+        const int kshift = bits_for((int64_t)dim + 1);            // 2^kshift > dim
         Assemble A{dim, kb, Bp, asm_row, asm_col, asm_val, rstage.get(), cstage.get(), rloc.get(), cloc.get(), brow.get(), bcol.get(),
-                   bcstep.get(), pivot.get(), D.get(), ckind.get(), lkey.get(), ukey.get(), lval.get(), uval.get(), tearing ? 1 : 0};
+                   bcstep.get(), pivot.get(), D.get(), ckind.get(), lkey.get(), ukey.get(), lval.get(), uval.get(), tearing ? 1 : 0, kshift};
         if (nb > 0) hipLaunchKernelGGL(lu_keys_sparse_kernel, dim3(grid_for(nb)), dim3(kBlock), 0, s, A, nb);
         if (kb > 0) hipLaunchKernelGGL(lu_keys_dense_kernel, dim3(grid_for(kbsq)), dim3(kBlock), 0, s, A, nb);
         hipLaunchKernelGGL(lu_keys_unit_kernel, dim3(g), dim3(kBlock), 0, s, A, nb + kbsq);
         if (nspk > 0)
             hipLaunchKernelGGL(lu_keys_spike_kernel, dim3(grid_for(nspk)), dim3(kBlock), 0, s, A, nb + kbsq + dim, (int)nspk,
                                W.spk_c.get(), W.spk_s.get(), W.spk_v.get());
-        if (nl > 0) sort_keys(T, lkey.get(), lkey2.get(), lval.get(), lval2.get(), (size_t)nl, 64, s);
-        sort_keys(T, ukey.get(), ukey2.get(), uval.get(), uval2.get(), (size_t)nu, 64, s);
-        hipLaunchKernelGGL(lu_colptr_kernel, dim3(grid_for(dim + 1)), dim3(kBlock), 0, s, dim, nl, lkey2.get(), S->Lp.get());
-        hipLaunchKernelGGL(lu_colptr_kernel, dim3(grid_for(dim + 1)), dim3(kBlock), 0, s, dim, nu, ukey2.get(), S->Up.get());
+        // (2 * kshift key bits instead of 64: five radix passes instead of eight at 1M rows; the unused slots hold all ones and
+        // sort behind every key)
+        if (nl > 0) sort_keys(T, lkey.get(), lkey2.get(), lval.get(), lval2.get(), (size_t)nl, 2 * kshift, s);
+        sort_keys(T, ukey.get(), ukey2.get(), uval.get(), uval2.get(), (size_t)nu, 2 * kshift, s);
+        hipLaunchKernelGGL(lu_colptr_kernel, dim3(grid_for(dim + 1)), dim3(kBlock), 0, s, dim, nl, lkey2.get(), S->Lp.get(), kshift);
+        hipLaunchKernelGGL(lu_colptr_kernel, dim3(grid_for(dim + 1)), dim3(kBlock), 0, s, dim, nu, ukey2.get(), S->Up.get(), kshift);
         ipxint ends[2] = {0, 0};
         IPXK_HIP(hipMemcpyAsync(&ends[0], S->Lp.get() + dim, sizeof(ipxint), hipMemcpyDeviceToHost, s));
         IPXK_HIP(hipMemcpyAsync(&ends[1], S->Up.get() + dim, sizeof(ipxint), hipMemcpyDeviceToHost, s));
@@ -2002,10 +2006,10 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
         S->Li.ensure((size_t)std::max<int64_t>(lnz, 1)); S->Lx.ensure((size_t)std::max<int64_t>(lnz, 1));
         S->Ui.ensure((size_t)std::max<int64_t>(unz, 1)); S->Ux.ensure((size_t)std::max<int64_t>(unz, 1));
         if (lnz > 0) {
-            hipLaunchKernelGGL(lu_rowidx_kernel, dim3(grid_for(lnz)), dim3(kBlock), 0, s, lnz, lkey2.get(), S->Li.get());
+            hipLaunchKernelGGL(lu_rowidx_kernel, dim3(grid_for(lnz)), dim3(kBlock), 0, s, lnz, lkey2.get(), S->Li.get(), kshift);
             IPXK_HIP(hipMemcpyAsync(S->Lx.get(), lval2.get(), (size_t)lnz * sizeof(double), hipMemcpyDeviceToDevice, s));
         }
-        hipLaunchKernelGGL(lu_rowidx_kernel, dim3(grid_for(unz)), dim3(kBlock), 0, s, unz, ukey2.get(), S->Ui.get());
+        hipLaunchKernelGGL(lu_rowidx_kernel, dim3(grid_for(unz)), dim3(kBlock), 0, s, unz, ukey2.get(), S->Ui.get(), kshift);
         IPXK_HIP(hipMemcpyAsync(S->Ux.get(), uval2.get(), (size_t)unz * sizeof(double), hipMemcpyDeviceToDevice, s));
         IPXK_HIP(hipMemsetAsync(counters.get() + 6, 0, sizeof(int), s));
         hipLaunchKernelGGL(lu_perm_kernel, dim3(g), dim3(kBlock), 0, s, dim, rstage.get(), S->rowperm.get(), counters.get() + 6);
