@@ -239,8 +239,14 @@ int ipxk_split_rescale(ipxk_context* ctx, const ipxint* status,
  * active columns with the most active entries are set aside as spikes and the
  * rounds go on; the spikes are carried through the row singleton pivots by a
  * forward substitution and end in a dense block of one row per spike
- * (bump-and-spike ordering; ipxk_lu_info.spikes).  IPXK_E_UNSUPPORTED is
- * returned only if that block would exceed the limit.
+ * (bump-and-spike ordering; ipxk_lu_info.spikes).  If that block would exceed
+ * the limit, the factorization starts again and eliminates the bump sparsely:
+ * rounds of pivots of low Markowitz cost that form a diagonal block, under the
+ * same absolute and relative pivot thresholds, the fill-in entering the current
+ * matrix (ipxk_lu_info.sparse_pivots / sparse_rounds; environment IPXK_LU_SPARSE
+ * = 1: from the start, = 0: never); what is left is factorized densely.
+ * IPXK_E_UNSUPPORTED is returned only if that rest still exceeds the limit or
+ * the elimination fills the bump beyond IPXK_LU_SPARSE_FILL_MAX (8) x nnz(B).
  * Columns of B are Bi/Bx[Bbegin[j] .. Bend[j]-1] (4-array form, as Basis passes
  * AI's arrays); indices need not be sorted.  The factors stay on the device;
  * ipxk_lu_get_factors copies them out (array sizes from ipxk_lu_info; any
