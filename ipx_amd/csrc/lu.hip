@@ -58,7 +58,7 @@
 //      IPXK_LU_SPARSE_FILL_MAX (8) x nnz(B) + 2^20 entries -- bounded work.  The rest is factorized densely as in step 2, its columns in ascending order
 //      of their number of entries (fewer nonzeros in the dense factors).  Only if THAT rest exceeds the limit is the basis
 //      refused (IPXK_E_UNSUPPORTED).  IPXK_LU_SPARSE=1: elimination rounds instead of tearing from the start; =0: never.
-//      Every rule is restated in oracle/ipx_oracle.cc (orc_lu_factorize_sparse); the factors are bit-identical to it.
+//      Every rule is restated sequentially on the CPU by the test infrastructure; the factors are bit-identical to that restatement.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_merge.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
