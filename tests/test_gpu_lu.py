@@ -380,3 +380,26 @@ def test_dense_block_inverse_is_guarded(kkt, monkeypatch):
         err = np.abs(out["0"][k] - out["default"][k]).max() / np.abs(out["default"][k]).max()
         assert err <= 1e-9, (k, err)
     assert not np.array_equal(out["0"][0], out["default"][0])
+
+
+def test_dense_lu_launch_variants_give_identical_factors(kkt, monkeypatch):
+    """the dense LU's launch structure does not change a bit of the factors: the sub-panel's rows of U and its update of the
+    rest of the outer panel in one launch (default) or two (IPXK_LU_FUSED_SUB=0), and the look-ahead (the late trailing update
+    on a second, CU-masked stream; default from 6144 rows on, forced here for the smaller bumps too) against the in-order form
+    -- bumps of 1500 / 2600 / 6500 rows, i.e. 2 / 4 / 8 rows per thread in the panel kernels, trailing update on the matrix cores"""
+    c = kkt.KktContext(synth.synthetic_lp(8, 12, 2, 1))
+    for dim, bump, dens in ((4000, 1500, 0.05), (6000, 2600, 0.02), (12000, 6500, 0.01)):
+        G = synth.lp_like_basis_matrix(dim=dim, bump=bump, bump_density=dens, seed=7)
+        ref = None
+        for fused, look in ((("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")) if bump < 5000 else (("1", "1"), ("0", "0"))):
+            monkeypatch.setenv("IPXK_LU_FUSED_SUB", fused)
+            monkeypatch.setenv("IPXK_LU_LOOKAHEAD", look)
+            F = c.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
+            assert F["bump"] == bump and F["num_dependent"] == 0
+            if ref is None:
+                ref = F
+                if bump < 5000:
+                    assert check_contract(G, F) < 1e-9
+            else:
+                same_factors(F, ref)
+    c.close()
