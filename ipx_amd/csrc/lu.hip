@@ -1879,8 +1879,11 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
                     const int bit = spread ? (b % 8) * 32 + b / 8 : b;
                     mask[bit / 32] &= ~(1u << (bit % 32));
                 }
-                if (free_cus > 0) IPXK_HIP(hipExtStreamCreateWithCUMask(&W_.s2, 8, mask));
-                else IPXK_HIP(hipStreamCreateWithFlags(&W_.s2, hipStreamNonBlocking));
+                if (free_cus > 0 && hipExtStreamCreateWithCUMask(&W_.s2, 8, mask) != hipSuccess) {
+                    (void)hipGetLastError();               // (a device the mask does not fit: a plain stream -- correct, no overlap to speak of)
+                    W_.s2 = nullptr;
+                }
+                if (!W_.s2) IPXK_HIP(hipStreamCreateWithFlags(&W_.s2, hipStreamNonBlocking));
                 for (hipEvent_t* e : {&W_.ev_rows[0], &W_.ev_rows[1], &W_.ev_trail[0], &W_.ev_trail[1]})
                     IPXK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
             }
