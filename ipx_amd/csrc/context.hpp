@@ -110,7 +110,7 @@ struct Context {
 
     // ---- basis path ----
     // guard of the explicit inverses (trisolve.hip): # probes and # inverses rejected since the context was created, worst residual
-    struct { long inverse_probes = 0, inverse_rejected = 0; double worst_probe = 0.0; } split_stats;
+    struct { long inverse_probes = 0, inverse_rejected = 0, inverse_refined = 0; double worst_probe = 0.0; } split_stats;
     SplitOperator* split = nullptr;
     PrepareHost* prepare_host = nullptr;   // host workspaces of split_prepare (trisolve.hip)
     LuState* lu = nullptr;                 // factors of the last ipxk_lu_factorize* (lu.hip)
@@ -161,7 +161,7 @@ bool device_build_acc(LayoutScratch& S, AccMatrix& out, const SlicedMatrix& slic
                       const int* didx, const double* dval, hipStream_t s);
 
 // dense_inverse.hip
-void dense_lu_inverse(Context* c, int kb, const double* D, const double* invL, const double* invU, double* X, double* Xt);
+void dense_lu_inverse(Context* c, int kb, const double* D, const double* invL, const double* invU, double* X, double* Xt, int refine = 0);
 
 enum TimeKind { kTimeOp = 0, kTimePrecond = 1, kTimeB = 2, kTimeBt = 3, kNumTimeKinds = 4 };
 void time_mark(Context* c, int kind, bool begin);      // no-op unless timing is active
