@@ -382,6 +382,36 @@ def test_dense_block_inverse_is_guarded(kkt, monkeypatch):
     assert not np.array_equal(out["0"][0], out["default"][0])
 
 
+def test_dense_block_inverse_is_refined_before_it_is_rejected(kkt, monkeypatch):
+    """an explicit inverse that fails the probe gets up to two refinement steps X += X (I - D X) on the matrix cores, and one
+    that still misses the tolerance is held against the blocked solve's own residual on the same vectors (within four times
+    that it stays: neither can do better on that block).  Forced here with a tolerance below the plain inverse's probe
+    (1.3e-10 on this well conditioned block): three probes, the refined residual a fraction of the plain one, nothing rejected,
+    the same solves to 1e-9.  (On the ill conditioned bases of an IPM -- scripts/gpu_lp_dropin_large.py 12000 30000 -- the plain
+    probe is 1e-7 ... 3e-5 and one step brings it under 1e-8: without it every block fell back to the one-workgroup solve.)"""
+    from ipx_amd import synth
+    m, n, bump = 40000, 90000, 1300
+    P = synth.lp_like_basis(m, n, seed=5, bump=bump, offdiag=3)
+    colscale = synth.synthetic_basis_state(P["status"], 1.0, 5)
+    rhs = np.random.default_rng(2).standard_normal(m)
+    out = {}
+    for tol in ("default", "1e-12"):
+        if tol == "default":
+            monkeypatch.delenv("IPXK_INVERSE_TOL", raising=False)
+        else:
+            monkeypatch.setenv("IPXK_INVERSE_TOL", tol)
+        ctx = kkt.KktContext(P["A"])
+        ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+        ctx.split_prepare_lu(P["status"], colscale)
+        out[tol] = (ctx.split_inverse_stats(), ctx.solve_dense(rhs, "N"), ctx.solve_dense(rhs, "T"))
+        ctx.close()
+    (p0, r0, w0), (p1, r1, w1) = out["default"][0], out["1e-12"][0]
+    assert (p0, r0) == (1, 0) and 1e-12 < w0 < 1e-8
+    assert p1 == 3 and r1 == 0 and w1 < 0.5 * w0, (p1, r1, w1, w0)
+    for k in (1, 2):
+        assert np.abs(out["1e-12"][k] - out["default"][k]).max() <= 1e-9 * np.abs(out["default"][k]).max()
+
+
 def test_dense_lu_launch_variants_give_identical_factors(kkt, monkeypatch):
     """the dense LU's launch structure does not change a bit of the factors: the sub-panel's rows of U and its update of the
     rest of the outer panel in one launch (default) or two (IPXK_LU_FUSED_SUB=0), and the look-ahead (the late trailing update
