@@ -1457,7 +1457,7 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
     Int npiv = 0, rounds = 0;
     std::vector<char> torn(dim, 0);                  // spike columns (set aside when the rounds stall)
     std::vector<Int> pivrow_of(dim, -1);             // pivot row of a pivoted column
-    bool tearing = false;
+    bool tearing = false, sparse_entered = false;
     Int ntorn = 0, tear_width = 1, npiv_at_tear = 0;
     while (true) {
         Int found = 0;
@@ -1578,6 +1578,7 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
                 rebuild_rows();
             };
             if (bump_limit < 0 || nact <= bump_limit) break;       // small enough: dense as it stands
+            sparse_entered = true;
             rebuild();                                             // the active submatrix
             int slow = 0;
             while (nact > sparse_min) {
@@ -1690,7 +1691,7 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
     std::vector<Int> brow, bcol, rloc(dim, -1), cloc(dim, -1);
     for (Int i = 0; i < dim; i++) if (rstage[i] < 0) { rloc[i] = (Int)brow.size(); brow.push_back(i); }
     for (Int j = 0; j < dim; j++) if (cstage[j] < 0) { cloc[j] = (Int)bcol.size(); bcol.push_back(j); }
-    if (sparse_rounds && !getenv("ORC_NO_COLORDER")) {
+    if (sparse_entered && !getenv("ORC_NO_COLORDER")) {
         // the dense block's columns in ascending order of their number of entries (ties: index): fewer nonzeros in its factors
         std::stable_sort(bcol.begin(), bcol.end(), [&](Int a, Int b) { return cc[a] < cc[b]; });
         for (size_t c = 0; c < bcol.size(); c++) cloc[bcol[c]] = (Int)c;
@@ -1783,7 +1784,7 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
     for (Int j = 0; j < dim; j++) F->colperm[cstage[j]] = j;
     // ---- assemble: column k of L and U, indices ascending.  With elimination rounds the entries come from the list of the
     // entries that left the current matrix (plus what is in it now); without, that list is B itself.
-    if (sparse_rounds) {
+    if (sparse_entered) {
         for (Int j = 0; j < dim; j++)
             for (Int p = cp[j]; p < cp[j + 1]; p++) { Ei.push_back(ci[p]); Ej.push_back(j); Ex.push_back(cx[p]); }
         std::vector<Int> ep(dim + 1, 0);
