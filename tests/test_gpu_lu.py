@@ -142,6 +142,37 @@ def test_lu_elimination_rounds_vs_oracle(kkt, oracle, ref, monkeypatch):
     c.close()
 
 
+def test_lu_elimination_rounds_random_bases(kkt, oracle, monkeypatch):
+    """random sizes, kinds of bases (misplaced columns: singular; exchanged columns; a planted sparse bump), dense limits, end-of-rounds
+    rules and seeds: the device's factors equal the restatement's bit for bit, also where the limit is never exceeded (no
+    rounds: the dense code as it stands) -- the short form of scripts/gpu_sparse_lu_stress.py"""
+    monkeypatch.setenv("IPXK_LU_SPARSE", "1")
+    monkeypatch.setenv("IPXK_LU_MFMA_MIN", "0")
+    c = kkt.KktContext(synth.synthetic_lp(8, 12, 2, 1))
+    rng = np.random.default_rng(77)
+    with_rounds = 0
+    for case in range(12):
+        dim, seed = int(rng.integers(1500, 9000)), int(rng.integers(1, 10**6))
+        if case % 3 == 0:
+            G = synth.misplaced_basis_matrix(dim, int(rng.integers(5, 40)), seed=seed, bump=int(rng.integers(10, 120)))
+        elif case % 3 == 1:
+            G = synth.disturbed_basis_matrix(seed=seed, dim=dim, num_exchanged=int(rng.integers(4, 25)), bump=int(rng.integers(10, 80)), offdiag=int(rng.integers(2, 4)))
+        else:
+            G = synth.lp_like_basis_matrix(dim=dim, bump=int(rng.integers(200, 700)), bump_density=float(rng.uniform(0.01, 0.05)), seed=seed)
+        limit = int(rng.integers(16, 300))
+        smin, slow = int(rng.integers(2, max(3, limit // 2))), int(rng.choice([0, 16, 256]))
+        monkeypatch.setenv("IPXK_LU_BUMP_MAX", str(limit))
+        monkeypatch.setenv("IPXK_LU_SPARSE_MIN", str(smin))
+        monkeypatch.setenv("IPXK_LU_SPARSE_SLOW_DEN", str(slow))
+        F = c.lu_factorize(G["dim"], G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
+        Fo = oracle.lu_factorize(G["dim"], G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1, bump_limit=limit, sparse_min=smin, slow_den=slow)
+        assert Fo is not None and F["sparse_rounds"] == Fo["info"]["sparse_rounds"], (case, dim, limit)
+        same_factors(F, Fo)
+        with_rounds += F["sparse_rounds"] > 0
+    assert with_rounds >= 6
+    c.close()
+
+
 def test_lu_elimination_rounds_bound_the_fill(kkt, ref, monkeypatch):
     """a 60000-row basis after 40 exchanges, default limits (dense block up to 8192 rows): tearing (the default, faster) and
     the elimination rounds both factorize it; the rounds keep nnz(L) + nnz(U) under 3.5 x nnz(B), and the reference calls
