@@ -24,3 +24,6 @@ for l in sw[:8]: print(l[:190])
 lv = [l for l in r.stderr.splitlines() if "sweep blocks:" in l]
 print(len(lv), "sweep plans; the last eight:")
 for l in lv[-8:]: print(l[:190])
+lu = [l for l in r.stderr.splitlines() if l.startswith("ipxk: LU dim")]
+print(len(lu), "device factorizations; every fourth:")
+for l in lu[::4]: print(l[:230])
