@@ -303,11 +303,15 @@ __global__ void lu_tagwork_kernel(int ntags, const ipxint* __restrict__ tagptr, 
 }
 constexpr int kSpikeBatch = 64;      // spikes per dense block: one lane each
 // X[stage of row][lane] = entries of the batch's spikes (X zero before)
-__global__ void lu_spike_scatter_kernel(int nlanes, int c0, const int* __restrict__ bcol, const int* __restrict__ Bp,
+// (all spike kernels: blockIdx.y = the batch of 64 spikes within a group of batches that travel together -- they are independent --,
+// its block of X `xs` doubles behind the previous one's; kb = # spikes in all)
+__global__ void lu_spike_scatter_kernel(int kb, int c0, size_t xs, const int* __restrict__ bcol, const int* __restrict__ Bp,
                                         const int* __restrict__ Bi, const double* __restrict__ Bx, const int* __restrict__ rstage,
                                         const int* __restrict__ rloc, int npiv, double* __restrict__ X) {
     const int l = blockIdx.x;
-    if (l >= nlanes) return;
+    c0 += kSpikeBatch * blockIdx.y;
+    X += xs * blockIdx.y;
+    if (c0 + l >= kb) return;
     const int j = bcol[c0 + l];
     for (int p = Bp[j] + threadIdx.x; p < Bp[j + 1]; p += blockDim.x) {
         const int r = Bi[p];
@@ -317,9 +321,10 @@ __global__ void lu_spike_scatter_kernel(int nlanes, int c0, const int* __restric
 }
 // rows [s0, s1) of the substitution: x[r] -= l_rj * x[stage of j] for the row's entries of L in pivot order, products
 // rounded before they are subtracted (the elimination's own arithmetic); one wavefront per row, one lane per spike
-__global__ __launch_bounds__(kBlock) void lu_spike_round_kernel(int s0, int s1, const ipxint* __restrict__ lrp, const u64* __restrict__ lkey,
+__global__ __launch_bounds__(kBlock) void lu_spike_round_kernel(int s0, int s1, size_t xs, const ipxint* __restrict__ lrp, const u64* __restrict__ lkey,
                                                                 const double* __restrict__ lval, double* __restrict__ X) {
     const int lane = threadIdx.x & 63;
+    X += xs * blockIdx.y;
     for (int64_t r = (int64_t)s0 + (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); r < s1; r += (int64_t)gridDim.x * (kBlock / 64)) {
         const ipxint e0 = lrp[r], e1 = lrp[r + 1];
         if (e0 == e1) continue;
@@ -337,9 +342,11 @@ __global__ __launch_bounds__(kBlock) void lu_spike_round_kernel(int s0, int s1, 
 // a handful of rows (a 12 000 x 30 000 LP through the drop-in solver: 2.2 million launches of the kernel above, 37 % of all
 // kernel time and more in launch latency).  A row's arithmetic is the same: its entries in pivot order, products rounded first.
 constexpr int kSpikeRunThreads = 1024;
-__global__ __launch_bounds__(kSpikeRunThreads) void lu_spike_run_kernel(int t0, int t1, const ipxint* __restrict__ tagptr, const ipxint* __restrict__ lrp,
-                                                                        const u64* __restrict__ lkey, const double* __restrict__ lval, double* X) {
+__global__ __launch_bounds__(kSpikeRunThreads) void lu_spike_run_kernel(int t0, int t1, size_t xs, const ipxint* __restrict__ tagptr,
+                                                                        const ipxint* __restrict__ lrp, const u64* __restrict__ lkey,
+                                                                        const double* __restrict__ lval, double* X) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    X += xs * blockIdx.y;
     for (int t = t0; t < t1; t++) {
         const int64_t s0 = tagptr[t], s1 = tagptr[t + 1];
         for (int64_t r = s0 + wave; r < s1; r += kSpikeRunThreads / 64) {
@@ -357,22 +364,31 @@ __global__ __launch_bounds__(kSpikeRunThreads) void lu_spike_run_kernel(int t0, 
     }
 }
 // the batch's part of the dense block: rows that were never pivoted
-__global__ void lu_spike_dense_kernel(int kb, int nlanes, int c0, int npiv, const double* __restrict__ X, double* __restrict__ D) {
+__global__ void lu_spike_dense_kernel(int kb, int c0, size_t xs, int npiv, const double* __restrict__ X, double* __restrict__ D) {
+    c0 += kSpikeBatch * blockIdx.y;
+    X += xs * blockIdx.y;
+    const int nlanes = min(kSpikeBatch, kb - c0);
     IPXK_GRID_STRIDE(e, (int64_t)kb * nlanes) {
         const int l = (int)(e % nlanes), t = (int)(e / nlanes);
         D[(size_t)(c0 + l) * kb + t] = X[(size_t)(npiv + t) * kSpikeBatch + l];
     }
 }
 // the batch's entries in pivoted rows (future entries of U): counted, then appended as (bump column, stage, value)
-__global__ void lu_spike_count_kernel(int npiv, int nlanes, const double* __restrict__ X, int* count) {
+__global__ void lu_spike_count_kernel(int kb, int c0, size_t xs, int npiv, const double* __restrict__ X, int* count) {
+    c0 += kSpikeBatch * blockIdx.y;
+    X += xs * blockIdx.y;
+    const int nlanes = min(kSpikeBatch, kb - c0);
     int mine = 0;
     IPXK_GRID_STRIDE(e, (int64_t)npiv * kSpikeBatch) mine += (int)(e % kSpikeBatch) < nlanes && X[e] != 0.0;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);
 }
-__global__ void lu_spike_append_kernel(int npiv, int nlanes, int c0, const double* __restrict__ X, int* cursor,
+__global__ void lu_spike_append_kernel(int kb, int c0, size_t xs, int npiv, const double* __restrict__ X, int* cursor,
                                        int* __restrict__ spk_c, int* __restrict__ spk_s, double* __restrict__ spk_v) {
+    c0 += kSpikeBatch * blockIdx.y;
+    X += xs * blockIdx.y;
+    const int nlanes = min(kSpikeBatch, kb - c0);
     IPXK_GRID_STRIDE(e, (int64_t)npiv * kSpikeBatch) {
         const int l = (int)(e % kSpikeBatch);
         const double v = X[e];
@@ -1814,21 +1830,29 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
             IPXK_HIP(hipMemcpyAsync(tagptr.data(), W.tagptr.get(), tagptr.size() * sizeof(ipxint), hipMemcpyDeviceToHost, s));
             IPXK_HIP(hipMemcpyAsync(tagwork.data(), W.tagwork.get(), tagwork.size() * sizeof(int), hipMemcpyDeviceToHost, s));
             IPXK_HIP(hipStreamSynchronize(s));
-            W.X.ensure((size_t)dim * kSpikeBatch);
+            // the batches of 64 spikes are independent: a GROUP of them travels together (one launch per half-round / run for the
+            // whole group), as many as IPXK_LU_SPIKE_MEM_MB (4096) of dim x 64 blocks allow
+            const int nbatches = (kb + kSpikeBatch - 1) / kSpikeBatch;
+            const size_t xs = (size_t)dim * kSpikeBatch;
+            size_t mem_mb = 4096;
+            if (const char* e = getenv("IPXK_LU_SPIKE_MEM_MB")) mem_mb = (size_t)std::max(1, atoi(e));
+            const int gmax = (int)std::max<size_t>(1, std::min<size_t>(256, (mem_mb << 20) / (xs * sizeof(double))));
+            const int gsize = std::min(nbatches, gmax);
+            W.X.ensure(xs * gsize);
             nspk = 0;
-            for (int c0 = 0; c0 < kb; c0 += kSpikeBatch) {
-                const int nl = std::min(kSpikeBatch, kb - c0);
-                IPXK_HIP(hipMemsetAsync(W.X.get(), 0, (size_t)dim * kSpikeBatch * sizeof(double), s));
-                hipLaunchKernelGGL(lu_spike_scatter_kernel, dim3(nl), dim3(kBlock), 0, s, nl, c0, bcol.get(), Bp, Bi, Bx, rstage.get(),
+            for (int b0 = 0; b0 < nbatches; b0 += gsize) {
+                const int G = std::min(gsize, nbatches - b0), c0 = b0 * kSpikeBatch;
+                IPXK_HIP(hipMemsetAsync(W.X.get(), 0, xs * G * sizeof(double), s));
+                hipLaunchKernelGGL(lu_spike_scatter_kernel, dim3(kSpikeBatch, G), dim3(kBlock), 0, s, kb, c0, xs, bcol.get(), Bp, Bi, Bx, rstage.get(),
                                    rloc.get(), npiv_sing, W.X.get());
                 auto rows = [&](int64_t s0, int64_t s1) {
                     if (s1 <= s0) return;
                     const int64_t wgs = std::min<int64_t>(2048, (s1 - s0 + kBlock / 64 - 1) / (kBlock / 64));
-                    hipLaunchKernelGGL(lu_spike_round_kernel, dim3((unsigned)wgs), dim3(kBlock), 0, s, (int)s0, (int)s1, W.lrp.get(),
+                    hipLaunchKernelGGL(lu_spike_round_kernel, dim3((unsigned)wgs, G), dim3(kBlock), 0, s, (int)s0, (int)s1, xs, W.lrp.get(),
                                        lkey2.get(), lval2.get(), W.X.get());
                 };
-                // half-rounds of many rows: a launch over the chip each; runs of small ones: one workgroup per run (IPXK_LU_SPIKE_RUNS=0: a
-                // launch per half-round with work, as before)
+                // half-rounds of many rows: a launch over the chip each; runs of small ones: one workgroup per batch and run
+                // (IPXK_LU_SPIKE_RUNS=0: a launch per half-round with work, as before)
                 static const bool runs = !(getenv("IPXK_LU_SPIKE_RUNS") && getenv("IPXK_LU_SPIKE_RUNS")[0] == '0');
                 constexpr int kSmallRows = 4 * (kSpikeRunThreads / 64);      // up to four rows per wavefront
                 for (int t = 0; t < ntags;) {
@@ -1843,16 +1867,16 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
                     if (work == 1) {                                     // (a lone half-round with work: the plain launch)
                         for (int q = t; q < t1; q++) if (tagwork[q] > 0) rows(tagptr[q], tagptr[q + 1]);
                     } else if (work > 1) {
-                        hipLaunchKernelGGL(lu_spike_run_kernel, dim3(1), dim3(kSpikeRunThreads), 0, s, t, t1, W.tagptr.get(), W.lrp.get(), lkey2.get(),
-                                           lval2.get(), W.X.get());
+                        hipLaunchKernelGGL(lu_spike_run_kernel, dim3(1, G), dim3(kSpikeRunThreads), 0, s, t, t1, xs, W.tagptr.get(), W.lrp.get(),
+                                           lkey2.get(), lval2.get(), W.X.get());
                     }
                     t = t1;
                 }
                 rows(npiv_sing, dim);                                   // the rows that were never pivoted
-                hipLaunchKernelGGL(lu_spike_dense_kernel, dim3(grid_for((int64_t)kb * nl)), dim3(kBlock), 0, s, kb, nl, c0, npiv_sing,
+                hipLaunchKernelGGL(lu_spike_dense_kernel, dim3(grid_for((int64_t)kb * kSpikeBatch), G), dim3(kBlock), 0, s, kb, c0, xs, npiv_sing,
                                    W.X.get(), D.get());
                 IPXK_HIP(hipMemsetAsync(counters.get() + 3, 0, sizeof(int), s));
-                hipLaunchKernelGGL(lu_spike_count_kernel, dim3(grid_for((int64_t)npiv_sing * kSpikeBatch)), dim3(kBlock), 0, s, npiv_sing, nl,
+                hipLaunchKernelGGL(lu_spike_count_kernel, dim3(grid_for((int64_t)npiv_sing * kSpikeBatch), G), dim3(kBlock), 0, s, kb, c0, xs, npiv_sing,
                                    W.X.get(), counters.get() + 3);
                 IPXK_HIP(hipMemcpyAsync(h, counters.get(), 8 * sizeof(int), hipMemcpyDeviceToHost, s));
                 IPXK_HIP(hipStreamSynchronize(s));
@@ -1863,8 +1887,8 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
                     grow_keep(W.spk_v, (size_t)nspk, (size_t)nspk + add, s);
                     const int cur = (int)nspk;
                     IPXK_HIP(hipMemcpyAsync(counters.get() + 3, &cur, sizeof(int), hipMemcpyHostToDevice, s));
-                    hipLaunchKernelGGL(lu_spike_append_kernel, dim3(grid_for((int64_t)npiv_sing * kSpikeBatch)), dim3(kBlock), 0, s, npiv_sing,
-                                       nl, c0, W.X.get(), counters.get() + 3, W.spk_c.get(), W.spk_s.get(), W.spk_v.get());
+                    hipLaunchKernelGGL(lu_spike_append_kernel, dim3(grid_for((int64_t)npiv_sing * kSpikeBatch), G), dim3(kBlock), 0, s, kb, c0, xs, npiv_sing,
+                                       W.X.get(), counters.get() + 3, W.spk_c.get(), W.spk_s.get(), W.spk_v.get());
                     IPXK_HIP(hipStreamSynchronize(s));                  // `cur` is a stack variable
                     nspk += add;
                 }
