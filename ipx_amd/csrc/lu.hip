@@ -600,6 +600,8 @@ __global__ __launch_bounds__(kPanelThreads) void lu_panel_small_kernel(Dense A, 
 constexpr int kNarrow = 8;            // panel width with 4 rows per thread (bumps of 2049 .. 4096 rows)
 constexpr int kNarrowWide = 16;       // ... with 2 rows per thread (1025 .. 2048 rows): half the panels, the same registers
 constexpr int kNarrowDeep = 4;        // ... with 8 rows per thread (4097 .. 8192 rows)
+constexpr int kNarrowHuge = 2;        // ... with 16 rows per thread (8193 .. 16384 rows: the dense fall-back of a bump that tearing cannot cut down)
+constexpr int kDenseHardMax = 16 * 1024;
 constexpr int kNarrowWideMax = 16;    // the widest sub-panel
 template <int R, int W, int T>
 __device__ __forceinline__ void panel_multi_steps(const Dense& A, PanelShared& sh, double (&v)[R][W], int c0, int c1,
@@ -1603,7 +1605,7 @@ SparseOut sparse_rounds(hipStream_t s, LuWork& W, int dim, int64_t nb, const int
 
 // B as compact 32-bit CSC on the device -> factors in S
 static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, const int* Bp, const int* Bi,
-                                const double* Bx, double pivottol, bool strict, ipxk_lu_info* info, bool after_failed_tear = false) {
+                                const double* Bx, double pivottol, bool strict, ipxk_lu_info* info, int after_failed_tear = 0) {
     hipStream_t s = c->stream;
     int64_t nb = nb_in;
     S->valid = false;
@@ -1666,7 +1668,11 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
     // IPXK_LU_SPARSE=1: elimination rounds at once; =0: tearing only (refused beyond the limit, as in round 3).
     const char* sparse_env = getenv("IPXK_LU_SPARSE");
     const bool sparse_allowed = !(sparse_env && sparse_env[0] == '0');
-    const bool sparse_mode = after_failed_tear || (sparse_env && sparse_env[0] == '1');
+    const bool sparse_mode = after_failed_tear == 1 || (sparse_env && sparse_env[0] == '1');
+    // after_failed_tear == 2: the bump had at most kDenseHardMax rows when the rounds first stalled and tearing could not bring
+    // it under the limit (its columns are spikes nearly all): factorized densely as it stands, 16 rows per thread in the panels
+    const bool dense_as_it_stands = after_failed_tear == 2;
+    int nact_first = -1;
     int sparse_min = 512;
     if (const char* e = getenv("IPXK_LU_SPARSE_MIN")) sparse_min = std::max(0, atoi(e));
     int slow_den = 256;             // ... or it fits the dense code and two rounds in a row each eliminate fewer than 1 / 256 of the columns
@@ -1699,6 +1705,8 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
         IPXK_HIP(hipStreamSynchronize(s));
         const int npiv = h[1] + h[2], nact = dim - npiv - ntorn;
         if (nact == 0) break;
+        if (nact_first < 0) nact_first = nact;
+        if (dense_as_it_stands) break;
         if (!tearing && nact > kb_max && sparse_mode) {                 // 2c. elimination rounds down to sparse_min rows
             SparseGlobal G{rstage.get(), cstage.get(), pivrow.get(), pivot.get(), ckind.get()};
             sp = sparse_rounds(s, W, dim, nb, Bi, colof.get(), Bx, G, nact, std::min(sparse_min, kb_max), kb_max, slow_den, fill_max, &rounds, abstol, pivottol, h);
@@ -1723,10 +1731,11 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
         ntorn += take;
         npiv_at_tear = npiv;
         if (ntorn > kb_max && sparse_allowed) {
+            const int again = (nact_first <= kDenseHardMax && kb_max >= 4 * kPanelThreads + 1) ? 2 : 1;    // (a small test limit: always the rounds)
             if (getenv("IPXK_VERBOSE"))
-                fprintf(stderr, "ipxk: LU dim %d: %d spikes torn off and %d columns still active: starting again with elimination rounds\n", dim, ntorn,
-                        nact - take);
-            lu_factorize_device(c, S, dim, nb_in, Bp, Bi, Bx, pivottol, strict, info, true);
+                fprintf(stderr, "ipxk: LU dim %d: %d spikes torn off and %d columns still active: starting again %s\n", dim, ntorn, nact - take,
+                        again == 2 ? "with the bump as a dense block as it stood" : "with elimination rounds");
+            lu_factorize_device(c, S, dim, nb_in, Bp, Bi, Bx, pivottol, strict, info, again);
             return;
         }
         if (ntorn > kb_max) {
@@ -1777,7 +1786,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
     }
     I.bump = kb;
     I.spikes = tearing ? ntorn : 0;
-    if (kb > kb_max) {
+    if (kb > (dense_as_it_stands ? kDenseHardMax : kb_max)) {
         char msg[160];
         snprintf(msg, sizeof msg, "LU: after the singletons a bump of %d rows remains (limit %d, IPXK_LU_BUMP_MAX)", kb, kb_max);
         throw Error(IPXK_E_UNSUPPORTED, msg);
@@ -1911,7 +1920,11 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
             }
         } else {
             // two-level panels: sub-panels in registers (R rows per thread), the trailing matrix once per kPanel columns
-            const int W = kb <= 2 * kPanelThreads ? kNarrowWide : kb <= 4 * kPanelThreads ? kNarrow : kNarrowDeep;
+            int W = kb <= 2 * kPanelThreads ? kNarrowWide : kb <= 4 * kPanelThreads ? kNarrow : kb <= 8 * kPanelThreads ? kNarrowDeep : kNarrowHuge;
+            if (const char* e = getenv("IPXK_LU_PANEL_W")) {               // (tests: a narrower sub-panel than the bump needs -- more rows per thread)
+                const int w = atoi(e);
+                if ((w == 2 || w == 4 || w == 8 || w == 16) && w <= W) W = w;
+            }
             // the matrix cores for the trailing update of large bumps (IPXK_LU_MFMA_MIN rows and more, default 1025; 0: never)
             const char* mfma_env = getenv("IPXK_LU_MFMA_MIN");                 // (read per factorization: the tests switch it)
             const int mfma_min = mfma_env ? atoi(mfma_env) : kPanelThreads + 1;
@@ -1967,7 +1980,8 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
                     const double* us = fused_sub ? W_.usub.get() : nullptr;
                     if (W == kNarrowWide) hipLaunchKernelGGL((lu_panel_multi_kernel<2, kNarrowWide>), dim3(1), dim3(kPanelThreads), 0, s, P, ci, ce, first, us, c1o, step_src);
                     else if (W == kNarrow) hipLaunchKernelGGL((lu_panel_multi_kernel<4, kNarrow>), dim3(1), dim3(kPanelThreads), 0, s, P, ci, ce, first, us, c1o, step_src);
-                    else hipLaunchKernelGGL((lu_panel_multi_kernel<8, kNarrowDeep>), dim3(1), dim3(kPanelThreads), 0, s, P, ci, ce, first, us, c1o, step_src);
+                    else if (W == kNarrowDeep) hipLaunchKernelGGL((lu_panel_multi_kernel<8, kNarrowDeep>), dim3(1), dim3(kPanelThreads), 0, s, P, ci, ce, first, us, c1o, step_src);
+                    else hipLaunchKernelGGL((lu_panel_multi_kernel<16, kNarrowHuge>), dim3(1), dim3(kPanelThreads), 0, s, P, ci, ce, first, us, c1o, step_src);
                     if (ce < c1o) {         // the rest of the outer panel
                         if (fused_sub) {
                             hipLaunchKernelGGL(lu_subpanel_update_kernel, dim3((kb + 63) / 64), dim3(kBlock), 0, s, P, ce, c1o, W_.usub.get());

@@ -447,12 +447,18 @@ def test_dense_lu_launch_variants_give_identical_factors(kkt, monkeypatch):
     """the dense LU's launch structure does not change a bit of the factors: the sub-panel's rows of U and its update of the
     rest of the outer panel in one launch (default) or two (IPXK_LU_FUSED_SUB=0), and the look-ahead (the late trailing update
     on a second, CU-masked stream; default from 6144 rows on, forced here for the smaller bumps too) against the in-order form
-    -- bumps of 1500 / 2600 / 6500 rows, i.e. 2 / 4 / 8 rows per thread in the panel kernels, trailing update on the matrix cores"""
+    -- bumps of 1500 / 2600 / 6500 rows, i.e. 2 / 4 / 8 rows per thread in the panel kernels (and 16, forced, on the two smaller
+    ones), trailing update on the matrix cores"""
     c = kkt.KktContext(synth.synthetic_lp(8, 12, 2, 1))
     for dim, bump, dens in ((4000, 1500, 0.05), (6000, 2600, 0.02), (12000, 6500, 0.01)):
         G = synth.lp_like_basis_matrix(dim=dim, bump=bump, bump_density=dens, seed=7)
         ref = None
-        for fused, look in ((("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")) if bump < 5000 else (("1", "1"), ("0", "0"))):
+        for fused, look in ((("1", "1"), ("0", "0"), ("1", "0"), ("0", "1"), ("w2", "1")) if bump < 5000 else (("1", "1"), ("0", "0"))):
+            if fused == "w2":                 # sub-panels of 2 columns, 16 rows per thread: the panels of bumps beyond 8192 rows
+                monkeypatch.setenv("IPXK_LU_PANEL_W", "2")
+                fused = "1"
+            else:
+                monkeypatch.delenv("IPXK_LU_PANEL_W", raising=False)
             monkeypatch.setenv("IPXK_LU_FUSED_SUB", fused)
             monkeypatch.setenv("IPXK_LU_LOOKAHEAD", look)
             F = c.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
@@ -464,3 +470,31 @@ def test_dense_lu_launch_variants_give_identical_factors(kkt, monkeypatch):
             else:
                 same_factors(F, ref)
     c.close()
+
+
+def test_lu_bump_beyond_the_dense_limit_that_tearing_cannot_cut_down(kkt, monkeypatch):
+    """a 14 000-row basis with a planted sparse bump of 9500 rows: the singleton rounds stall on it, tearing sets 9215 columns aside
+    (more than the 8192 the dense code takes by default), and the factorization starts again with the bump as a dense block as it
+    stood (up to 16 384 rows: 16 rows per thread in the panel kernels) instead of being refused; Prepare inverts the block (refined
+    if the probe asks for it) and B x = r, B' x = r are solved to 1e-9"""
+    import scipy.sparse as sp
+    m, n, bump = 14000, 32000, 9500
+    P = synth.lp_like_basis(m, n, seed=5, bump=bump, offdiag=3, bump_density=0.01)
+    colscale = synth.synthetic_basis_state(P["status"], 1.0, 5)
+    ctx = kkt.KktContext(P["A"])
+    F = ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+    assert F["bump"] == bump and F["spikes"] == 0 and F["sparse_rounds"] == 0 and F["num_dependent"] == 0
+    ctx.split_prepare_lu(P["status"], colscale)
+    probes, rejected, worst = ctx.split_inverse_stats()
+    assert probes >= 1 and rejected == 0 and worst < 1e-8
+    G = P["G"]
+    B = sp.csc_matrix((G["Bx"].copy(), G["Bi"].copy(), G["Bp"].copy()), shape=(m, m))
+    rhs = np.random.default_rng(1).standard_normal(m)
+    for tr in ("N", "T"):
+        x = ctx.solve_dense(rhs, tr)
+        r = (B if tr == "N" else B.T) @ x - rhs
+        assert np.abs(r).max() <= 1e-9 * (1 + np.abs(x).max()), tr
+    monkeypatch.setenv("IPXK_LU_SPARSE", "0")          # tearing only: refused as in round 3
+    with pytest.raises(kkt.KktError, match="spikes"):
+        ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+    ctx.close()
