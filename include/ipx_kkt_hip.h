@@ -239,9 +239,9 @@ int ipxk_split_rescale(ipxk_context* ctx, const ipxint* status,
  * active columns with the most active entries are set aside as spikes and the
  * rounds go on; the spikes are carried through the row singleton pivots by a
  * forward substitution and end in a dense block of one row per spike
- * (bump-and-spike ordering; ipxk_lu_info.spikes).  If that block would exceed
- * the limit, the factorization starts again: with the bump as a dense block as
- * it stood when it had at most 16384 rows, else it eliminates the bump sparsely:
+ * (bump-and-spike ordering; ipxk_lu_info.spikes; the spikes may number up to
+ * 16384, the largest dense block the panel kernels take).  If that block would
+ * exceed 16384 rows, the factorization starts again and eliminates the bump sparsely:
  * rounds of pivots of low Markowitz cost that form a diagonal block, under the
  * same absolute and relative pivot thresholds, the fill-in entering the current
  * matrix (ipxk_lu_info.sparse_pivots / sparse_rounds; environment IPXK_LU_SPARSE

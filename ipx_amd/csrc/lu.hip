@@ -1669,10 +1669,10 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
     const char* sparse_env = getenv("IPXK_LU_SPARSE");
     const bool sparse_allowed = !(sparse_env && sparse_env[0] == '0');
     const bool sparse_mode = after_failed_tear == 1 || (sparse_env && sparse_env[0] == '1');
-    // after_failed_tear == 2: the bump had at most kDenseHardMax rows when the rounds first stalled and tearing could not bring
-    // it under the limit (its columns are spikes nearly all): factorized densely as it stands, 16 rows per thread in the panels
-    const bool dense_as_it_stands = after_failed_tear == 2;
-    int nact_first = -1;
+    // The limit decides WHETHER a bump is torn; the spikes themselves may fill the largest dense block the panel kernels take
+    // (16 rows per thread: 16384 rows) before tearing gives up -- on the IPM bases of random LPs of 12 000 ... 24 000 rows tearing
+    // ends with 8000 ... 11 000 spikes.  (A small limit set for tests binds the spikes too.)
+    const int spike_max = kb_max > 4 * kPanelThreads ? std::max(kb_max, kDenseHardMax) : kb_max;
     int sparse_min = 512;
     if (const char* e = getenv("IPXK_LU_SPARSE_MIN")) sparse_min = std::max(0, atoi(e));
     int slow_den = 256;             // ... or it fits the dense code and two rounds in a row each eliminate fewer than 1 / 256 of the columns
@@ -1705,8 +1705,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
         IPXK_HIP(hipStreamSynchronize(s));
         const int npiv = h[1] + h[2], nact = dim - npiv - ntorn;
         if (nact == 0) break;
-        if (nact_first < 0) nact_first = nact;
-        if (dense_as_it_stands) break;
+
         if (!tearing && nact > kb_max && sparse_mode) {                 // 2c. elimination rounds down to sparse_min rows
             SparseGlobal G{rstage.get(), cstage.get(), pivrow.get(), pivot.get(), ckind.get()};
             sp = sparse_rounds(s, W, dim, nb, Bi, colof.get(), Bx, G, nact, std::min(sparse_min, kb_max), kb_max, slow_den, fill_max, &rounds, abstol, pivottol, h);
@@ -1730,18 +1729,17 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
         hipLaunchKernelGGL(lu_tear_apply_kernel, dim3(grid_for(take)), dim3(kBlock), 0, s, R, W.tkey2.get(), take);
         ntorn += take;
         npiv_at_tear = npiv;
-        if (ntorn > kb_max && sparse_allowed) {
-            const int again = (nact_first <= kDenseHardMax && kb_max >= 4 * kPanelThreads + 1) ? 2 : 1;    // (a small test limit: always the rounds)
+        if (ntorn > spike_max && sparse_allowed) {
             if (getenv("IPXK_VERBOSE"))
-                fprintf(stderr, "ipxk: LU dim %d: %d spikes torn off and %d columns still active: starting again %s\n", dim, ntorn, nact - take,
-                        again == 2 ? "with the bump as a dense block as it stood" : "with elimination rounds");
-            lu_factorize_device(c, S, dim, nb_in, Bp, Bi, Bx, pivottol, strict, info, again);
+                fprintf(stderr, "ipxk: LU dim %d: %d spikes torn off and %d columns still active: starting again with elimination rounds\n", dim, ntorn,
+                        nact - take);
+            lu_factorize_device(c, S, dim, nb_in, Bp, Bi, Bx, pivottol, strict, info, 1);
             return;
         }
-        if (ntorn > kb_max) {
+        if (ntorn > spike_max) {
             char msg[200];
             snprintf(msg, sizeof msg, "LU: %d spikes torn off the bump and %d columns still active: the dense block would exceed %d rows "
-                     "(IPXK_LU_BUMP_MAX)", ntorn, nact - take, kb_max);
+                     "(IPXK_LU_BUMP_MAX)", ntorn, nact - take, spike_max);
             throw Error(IPXK_E_UNSUPPORTED, msg);
         }
     }
@@ -1786,7 +1784,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
     }
     I.bump = kb;
     I.spikes = tearing ? ntorn : 0;
-    if (kb > (dense_as_it_stands ? kDenseHardMax : kb_max)) {
+    if (kb > (tearing ? spike_max : kb_max)) {
         char msg[160];
         snprintf(msg, sizeof msg, "LU: after the singletons a bump of %d rows remains (limit %d, IPXK_LU_BUMP_MAX)", kb, kb_max);
         throw Error(IPXK_E_UNSUPPORTED, msg);

@@ -1457,6 +1457,9 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
     Int npiv = 0, rounds = 0;
     std::vector<char> torn(dim, 0);                  // spike columns (set aside when the rounds stall)
     std::vector<Int> pivrow_of(dim, -1);             // pivot row of a pivoted column
+    // (the limit decides whether a bump is torn; the spikes may fill the largest dense block the device's panel kernels take,
+    // 16384 rows, unless a small limit -- tests -- binds them too)
+    const Int spike_limit = bump_limit > 4096 ? std::max<Int>(bump_limit, 16384) : bump_limit;
     bool tearing = false, sparse_entered = false;
     Int ntorn = 0, tear_width = 1, npiv_at_tear = 0;
     while (true) {
@@ -1683,7 +1686,7 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
         }
         ntorn += (Int)take;
         npiv_at_tear = npiv;
-        if (ntorn > bump_limit) { F->info[2] = ntorn; return nullptr; }
+        if (ntorn > spike_limit) { F->info[2] = ntorn; return nullptr; }
     }
     F->info[3] = rounds;
     F->info[5] = ntorn;
@@ -1698,7 +1701,7 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
     }
     const Int kb = (Int)bcol.size();
     F->info[2] = kb;
-    if (bump_limit >= 0 && kb > bump_limit) return nullptr;
+    if (bump_limit >= 0 && kb > (tearing ? spike_limit : bump_limit)) return nullptr;
     std::vector<double> D((size_t)kb * kb, 0.0);      // column-major
     std::vector<std::vector<std::pair<Int, double>>> spikeU;       // torn: entries of a spike in pivoted rows (stage, value)
     if (!tearing) {
