@@ -126,6 +126,13 @@ int ipxk_set_profiling(ipxk_context* ctx, int on);
  * ipxk_maxvolume_sequential poll it once per candidate column (src/maxvolume.cc:52,250); a nonzero
  * value ends the run with info->errflag = that value, the exchanges made so far kept.  NULL: none. */
 int ipxk_set_interrupt(ipxk_context* ctx, ipxint (*interrupt)(void* user), void* interrupt_user);
+/* A context handed from one solver object to the next (ipx_amd/host/hip_device.h keeps one per Model, as the
+ * reference's solver objects share one Model, src/lp_solver.cc:375,386,457) starts like a new one: NormalMatrix /
+ * DiagonalPrecond / KKTSolverDiag unprepared, no iterate, no operator of a basis, no LU factors, no interrupt
+ * callback, host pointer mode, own stream; the pivot tolerance of Maxvolume's refactorizations -- tightened for good
+ * after an unstable exchange, like Basis::TightenLuPivotTol (src/basis.cc:490-503) -- is set to lu_pivottol
+ * (Control::lu_pivottol(), src/basis.cc:30; <= 0: 0.1).  The model and its layouts stay; workspaces stay allocated. */
+int ipxk_reset_solver_state(ipxk_context* ctx, double lu_pivottol);
 ipxint ipxk_num_dense_cols(const ipxk_context* ctx);
 /* Copies out the device-side row-wise matrix (for bit-exact index parity
  * tests against Transpose): ATp[m+1], ATi[nnz], ATx[nnz]; NULL skips. */

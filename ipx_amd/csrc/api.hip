@@ -15,6 +15,7 @@ void set_last_error(const std::string& msg) { g_last_error = msg; }
 
 Context::~Context() {
     if (split) destroy_split(split);
+    if (split_spare) destroy_split(split_spare);
     if (prepare_host) destroy_prepare_host(prepare_host);
     if (lu) destroy_lu(lu);
     if (maxvol) destroy_maxvol(maxvol);
@@ -255,6 +256,33 @@ int ipxk_set_interrupt(ipxk_context* c, ipxint (*interrupt)(void*), void* interr
         IPXK_REQUIRE(c != nullptr, "ctx is NULL");
         c->interrupt = interrupt;
         c->interrupt_user = interrupt_user;
+    });
+}
+
+int ipxk_reset_solver_state(ipxk_context* c, double lu_pivottol) {
+    return guarded([&] {
+        IPXK_REQUIRE(c != nullptr, "ctx is NULL");
+        IPXK_REQUIRE(lu_pivottol <= 1.0, "lu_pivottol must lie in (0,1] (or <= 0 for the default)");
+        bind_device(c);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+        // what a solver object computed: W / the diagonal preconditioner / resscale, the iterate, the operator of a basis and its
+        // factors, N, the tightened pivot tolerance.  The buffers stay (grow-only workspaces); nothing of their content is used again.
+        c->W = nullptr;
+        c->normal_prepared = c->diag_factorized = c->kkt_diag_factorized = c->it_set = false;
+        c->kdense = 0;
+        if (c->split) {
+            if (c->split_spare) destroy_split(c->split_spare);
+            c->split_spare = c->split;
+            c->split = nullptr;
+        }
+        lu_invalidate(c);
+        nmatrix_invalidate(c);
+        c->maxvol_pivottol = lu_pivottol > 0.0 ? lu_pivottol : 0.1;
+        c->interrupt = nullptr;
+        c->interrupt_user = nullptr;
+        c->profile_ops = false;
+        c->pointer_mode = IPXK_POINTER_HOST;
+        c->stream = c->own_stream;
     });
 }
 

@@ -112,6 +112,11 @@ struct Context {
     // guard of the explicit inverses (trisolve.hip): # probes and # inverses rejected since the context was created, worst residual
     struct { long inverse_probes = 0, inverse_rejected = 0, inverse_refined = 0; double worst_probe = 0.0; } split_stats;
     SplitOperator* split = nullptr;
+    SplitOperator* split_spare = nullptr;  // the operator's buffers after ipxk_reset_solver_state: reused by the next Prepare, never applied
+    // LU pivot tolerance of Maxvolume's refactorizations: tightened after an unstable exchange and kept for the later calls of the SAME
+    // solver object, like Basis::TightenLuPivotTol changes lu_->pivottol() for good (src/basis.cc:490-503); ipxk_reset_solver_state
+    // sets it again (src/basis.cc:30: every Basis starts from control.lu_pivottol())
+    double maxvol_pivottol = 0.1;
     PrepareHost* prepare_host = nullptr;   // host workspaces of split_prepare (trisolve.hip)
     LuState* lu = nullptr;                 // factors of the last ipxk_lu_factorize* (lu.hip)
     DevBuf<double> dense_work;             // workspace of the dense block inverse (dense_inverse.hip), grow-only
@@ -261,6 +266,7 @@ void lu_get_factors(Context* c, ipxint* Lp, ipxint* Li, double* Lx, ipxint* Up, 
                     ipxint* rowperm, ipxint* colperm, ipxint* dependent);
 void split_prepare_lu(Context* c, const ipxint* status, const double* colscale);
 void destroy_lu(LuState*);
+void lu_invalidate(Context* c);          // the factors of an earlier factorization are no longer handed out
 // ---- maxvolume.hip ----
 void maxvolume_dev(Context* c, const ipxint* status, const double* colscale, const ipxk_maxvolume_params* prm,
                    ipxint* basis_out, ipxint* status_out, ipxk_maxvolume_info* info, ipxint* log, ipxint log_cap);
@@ -269,6 +275,7 @@ void maxvolume_sequential_dev(Context* c, const ipxint* status, const double* co
                               ipxint log_cap);
 void destroy_maxvol(MaxvolState*);
 void destroy_nmatrix(NMatrix*);
+void nmatrix_invalidate(Context* c);
 // N = the NONBASIC columns of A with nonzero weight as a pair of gather matrices built on the device (nmatrix.hip):
 // prepare returns false when N is not used for this model; apply: work = W_I .* u + N (W_N .* (N' u))
 bool nmatrix_prepare(Context* c, const double* W);

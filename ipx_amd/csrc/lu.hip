@@ -601,7 +601,8 @@ constexpr int kNarrow = 8;            // panel width with 4 rows per thread (bum
 constexpr int kNarrowWide = 16;       // ... with 2 rows per thread (1025 .. 2048 rows): half the panels, the same registers
 constexpr int kNarrowDeep = 4;        // ... with 8 rows per thread (4097 .. 8192 rows)
 constexpr int kNarrowHuge = 2;        // ... with 16 rows per thread (8193 .. 16384 rows: the dense fall-back of a bump that tearing cannot cut down)
-constexpr int kDenseHardMax = 16 * 1024;
+constexpr int kNarrowGiant = 1;       // ... with 32 rows per thread (16385 .. 32768 rows: what the elimination rounds leave of the bump of an IPM basis of 50 000 rows and more)
+constexpr int kDenseHardMax = 32 * 1024;
 constexpr int kNarrowWideMax = 16;    // the widest sub-panel
 template <int R, int W, int T>
 __device__ __forceinline__ void panel_multi_steps(const Dense& A, PanelShared& sh, double (&v)[R][W], int c0, int c1,
@@ -1469,7 +1470,8 @@ void sp_finish_matrix(hipStream_t s, LuWork& W, const u64* skeys, const double* 
 // matrix (copy out.cur: out.kb rows, out.nnz entries, local indices = rank among the rows / columns of B that are still
 // active) is what the dense code takes over, and W.sp.E* (out.ne entries) replaces B in the assembly.
 SparseOut sparse_rounds(hipStream_t s, LuWork& W, int dim, int64_t nb, const int* Bi, const int* colof, const double* Bx, SparseGlobal G,
-                        int nact, int sparse_min, int kb_max, int slow_den, int fill_max, int* rounds, double abstol, double pivottol, int* h) {
+                        int nact, int sparse_min, int kb_max, int slow_den, int fill_max, double dense_at, bool fill_to_dense, int* rounds, double abstol,
+                        double pivottol, int* h) {
     LuWork::Sp& P = W.sp;
     Tmp& T = W.T;
     SparseOut out;
@@ -1503,6 +1505,8 @@ SparseOut sparse_rounds(hipStream_t s, LuWork& W, int dim, int64_t nb, const int
         // (the rounds stop early once the current matrix fits the dense code and two rounds in a row have each eliminated fewer
         // than 1 / slow_den of the columns: what is left has no large sets of independent pivots any more)
         if (slow_den > 0 && dimL <= kb_max && slow >= 2) break;
+        // ... or once it fits the dense code and holds more than dense_at x dimL^2 entries: a dense matrix in sparse storage
+        if (dense_at > 0.0 && dimL <= kb_max && (double)nnz > dense_at * (double)dimL * (double)dimL) break;
         const size_t l1 = (size_t)dimL;
         for (DevBuf<int>* b : {&P.candrow, &P.cost, &P.winner, &P.rstL, &P.cstL, &P.flag, &P.rank, &P.newrow, &P.newcol, &P.listr, &P.listc}) b->ensure(l1);
         P.nupd.ensure(l1 + 1); P.uoff.ensure(l1 + 1); P.key.ensure(l1); P.rowbest.ensure(l1); P.pivl.ensure(l1);
@@ -1591,10 +1595,13 @@ SparseOut sparse_rounds(hipStream_t s, LuWork& W, int dim, int64_t nb, const int
         // bounded work: a bump whose elimination fills in beyond fill_max x nnz(B) (+ 2^20) is refused, and the caller's CPU
         // kernel takes over (measured: such bases take minutes here -- the 1M-row basis of scripts/gpu_maxvol_bench.py with a
         // tightened pivot tolerance: 14 941 rounds, 291 s, 103 x fill)
-        if (fill_max > 0 && nnz > (int64_t)fill_max * nb + (1 << 20)) {
+        // (round 5's policy: room for a current matrix the density rule will end -- dense_at x kb_max^2 entries -- whatever nnz(B) is)
+        const int64_t fill_bound = std::max<int64_t>((int64_t)fill_max * nb + (1 << 20), fill_to_dense ? (int64_t)(dense_at * (double)kb_max * (double)kb_max) : 0);
+        if (fill_max > 0 && nnz > fill_bound) {
+            if (fill_to_dense && dimL <= kb_max) break;             // (round 5: the dense code takes what is left if it can)
             char msg[200];
-            snprintf(msg, sizeof msg, "LU: after %d elimination rounds the bump holds %lld entries, more than %d x nnz(B) "
-                     "(IPXK_LU_SPARSE_FILL_MAX)", out.rounds, (long long)nnz, fill_max);
+            snprintf(msg, sizeof msg, "LU: after %d elimination rounds the bump holds %lld entries in %d columns, beyond the bound of the rounds "
+                     "(IPXK_LU_SPARSE_FILL_MAX)", out.rounds, (long long)nnz, dimL);
             throw Error(IPXK_E_UNSUPPORTED, msg);
         }
     }
@@ -1612,6 +1619,25 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
     S->dim = dim;
     ipxk_lu_info I{};
     const double abstol = strict ? 1e-3 : 1e-14;      // kLuDependencyTol (src/ipx_internal.h:26) / BASICLU's default
+    if (const char* dir = getenv("IPXK_LU_DUMP")) {   // study aid: the bases of a run as flat files (dim, nnz, Bp, Bi, Bx), every IPXK_LU_DUMP_EVERY-th
+        static int calls = 0, written = 0;
+        const int every = getenv("IPXK_LU_DUMP_EVERY") ? std::max(1, atoi(getenv("IPXK_LU_DUMP_EVERY"))) : 1;
+        if (!after_failed_tear && nb > dim && calls++ % every == 0 && written < 64) {
+            std::vector<int> hp((size_t)dim + 1), hi((size_t)nb);
+            std::vector<double> hx((size_t)nb);
+            IPXK_HIP(hipMemcpy(hp.data(), Bp, hp.size() * sizeof(int), hipMemcpyDeviceToHost));
+            IPXK_HIP(hipMemcpy(hi.data(), Bi, hi.size() * sizeof(int), hipMemcpyDeviceToHost));
+            IPXK_HIP(hipMemcpy(hx.data(), Bx, hx.size() * sizeof(double), hipMemcpyDeviceToHost));
+            char path[512];
+            snprintf(path, sizeof path, "%s/basis_%03d.bin", dir, written++);
+            if (FILE* f = fopen(path, "wb")) {
+                const int64_t head[2] = {dim, nb};
+                fwrite(head, sizeof(int64_t), 2, f);
+                fwrite(hp.data(), sizeof(int), hp.size(), f); fwrite(hi.data(), sizeof(int), hi.size(), f); fwrite(hx.data(), sizeof(double), hx.size(), f);
+                fclose(f);
+            }
+        }
+    }
     const double t0 = now_s();
     LuWork& W = S->work;
     Tmp& T = W.T;
@@ -1663,22 +1689,39 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
     if (const char* e = getenv("IPXK_LU_BUMP_MAX")) kb_max = std::max(0, atoi(e));
     bool tearing = false;
     int ntorn = 0, tear_width = 1, npiv_at_tear = 0;
-    // a bump beyond the dense limit: tearing first (fast when a few hundred columns block the rounds); if that would need more
-    // spikes than the dense code takes, the factorization starts again with elimination rounds instead of being refused.
-    // IPXK_LU_SPARSE=1: elimination rounds at once; =0: tearing only (refused beyond the limit, as in round 3).
+    // WHICH way a bump goes (round 5).  A bump of at most sparse_from rows (1024) is factorized densely as it stands.  A larger one
+    // is eliminated SPARSELY in rounds (2c) as long as that pays, and only the rest -- a matrix that has become dense, typically a
+    // third to a half of an IPM basis' bump -- goes to the dense code: on the bases of the IPM (random LPs, 16 000 rows, bump of
+    // 10 700) that is nnz(L+U) 24.6 M and 60 ms where the dense bump as it stands gave 95 M and 330 ms; the sequential minimum-
+    // Markowitz elimination of the same bases ends in 22.2 M, so there is no better order to be had.  The
+    // rounds end at sparse_min columns; or, once at most rest_max columns are left (what the dense code takes), when the current
+    // matrix holds more than dense_at x columns^2 entries, after two slow rounds, or when it has grown beyond fill_max x nnz(B) + 2^20
+    // entries.  A bump of more than sparse_first_max rows (131 072: the chains of a 1M-row basis, where a round costs 1 ms and
+    // frees a handful of pivots) is TORN first (2b) as until round 4, with the rounds as the fall-back; rounds that give up with
+    // more than rest_max columns left start again with tearing.  Only a basis neither way can take is refused.
+    //   IPXK_LU_SPARSE=t: tearing first for every bump beyond IPXK_LU_BUMP_MAX, rounds as the fall-back (the policy of round 4);
+    //   =1: rounds instead of tearing for those bumps, round 4's end rules; =0: tearing only.
     const char* sparse_env = getenv("IPXK_LU_SPARSE");
     const bool sparse_allowed = !(sparse_env && sparse_env[0] == '0');
-    const bool sparse_mode = after_failed_tear == 1 || (sparse_env && sparse_env[0] == '1');
+    const bool legacy_rounds = sparse_env && sparse_env[0] == '1';
+    const bool legacy = sparse_env && (sparse_env[0] == '0' || sparse_env[0] == '1' || sparse_env[0] == 't');
     // The limit decides WHETHER a bump is torn; the spikes themselves may fill the largest dense block the panel kernels take
     // (16 rows per thread: 16384 rows) before tearing gives up -- on the IPM bases of random LPs of 12 000 ... 24 000 rows tearing
     // ends with 8000 ... 11 000 spikes.  (A small limit set for tests binds the spikes too.)
     const int spike_max = kb_max > 4 * kPanelThreads ? std::max(kb_max, kDenseHardMax) : kb_max;
+    const int rest_max = legacy ? kb_max : spike_max;
     int sparse_min = 512;
     if (const char* e = getenv("IPXK_LU_SPARSE_MIN")) sparse_min = std::max(0, atoi(e));
-    int slow_den = 256;             // ... or it fits the dense code and two rounds in a row each eliminate fewer than 1 / 256 of the columns
+    int slow_den = legacy ? 256 : 2048;   // ... or it fits the dense code and two rounds in a row each eliminate fewer than 1 / 256 (2048) of the columns
     if (const char* e = getenv("IPXK_LU_SPARSE_SLOW_DEN")) slow_den = std::max(0, atoi(e));
-    int fill_max = 8;               // ... and are given up (IPXK_E_UNSUPPORTED) when the bump fills in beyond 8 x nnz(B) + 2^20 entries
+    int fill_max = 8;               // ... or the bump has filled in beyond 8 x nnz(B) + 2^20 entries
     if (const char* e = getenv("IPXK_LU_SPARSE_FILL_MAX")) fill_max = std::max(0, atoi(e));
+    int sparse_from = legacy ? kb_max : std::min(kb_max, 1024);
+    if (const char* e = getenv("IPXK_LU_SPARSE_FROM")) sparse_from = std::max(0, atoi(e));
+    int sparse_first_max = 131072;
+    if (const char* e = getenv("IPXK_LU_SPARSE_FIRST_MAX")) sparse_first_max = std::max(0, atoi(e));
+    double dense_at = legacy ? 0.0 : 0.2;
+    if (const char* e = getenv("IPXK_LU_SPARSE_DENSITY")) dense_at = atof(e);
     SparseOut sp;
     bool sparse_done = false;
     while (dim > 0) {
@@ -1706,14 +1749,24 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
         const int npiv = h[1] + h[2], nact = dim - npiv - ntorn;
         if (nact == 0) break;
 
-        if (!tearing && nact > kb_max && sparse_mode) {                 // 2c. elimination rounds down to sparse_min rows
+        const bool rounds_now = !tearing && sparse_allowed && nact > sparse_from &&
+                                (after_failed_tear == 1 || legacy_rounds || (!legacy && after_failed_tear != 2 && nact <= sparse_first_max));
+        if (rounds_now) {                                               // 2c. elimination rounds down to sparse_min rows
             SparseGlobal G{rstage.get(), cstage.get(), pivrow.get(), pivot.get(), ckind.get()};
-            sp = sparse_rounds(s, W, dim, nb, Bi, colof.get(), Bx, G, nact, std::min(sparse_min, kb_max), kb_max, slow_den, fill_max, &rounds, abstol, pivottol, h);
+            try {
+                sp = sparse_rounds(s, W, dim, nb, Bi, colof.get(), Bx, G, nact, std::min(sparse_min, kb_max), rest_max, slow_den, fill_max, dense_at, !legacy,
+                                   &rounds, abstol, pivottol, h);
+            } catch (const Error& e) {
+                if (legacy || after_failed_tear != 0 || e.code != IPXK_E_UNSUPPORTED) throw;
+                if (getenv("IPXK_VERBOSE")) fprintf(stderr, "ipxk: LU dim %d: %s: starting again with tearing\n", dim, e.what());
+                lu_factorize_device(c, S, dim, nb_in, Bp, Bi, Bx, pivottol, strict, info, 2);
+                return;
+            }
             sparse_done = true;
             break;
         }
         if (!tearing) {
-            if (nact <= kb_max) break;                                  // small enough: dense as it stands
+            if (nact <= (legacy ? kb_max : std::max(kb_max, sparse_from))) break;      // small enough: dense as it stands
             tearing = true;
         } else {
             tear_width = npiv - npiv_at_tear < 64 ? std::min(2 * tear_width, 1024) : 1;
@@ -1729,7 +1782,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
         hipLaunchKernelGGL(lu_tear_apply_kernel, dim3(grid_for(take)), dim3(kBlock), 0, s, R, W.tkey2.get(), take);
         ntorn += take;
         npiv_at_tear = npiv;
-        if (ntorn > spike_max && sparse_allowed) {
+        if (ntorn > spike_max && sparse_allowed && after_failed_tear != 2) {
             if (getenv("IPXK_VERBOSE"))
                 fprintf(stderr, "ipxk: LU dim %d: %d spikes torn off and %d columns still active: starting again with elimination rounds\n", dim, ntorn,
                         nact - take);
@@ -1784,7 +1837,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
     }
     I.bump = kb;
     I.spikes = tearing ? ntorn : 0;
-    if (kb > (tearing ? spike_max : kb_max)) {
+    if (kb > (tearing ? spike_max : sparse_done ? rest_max : kb_max)) {
         char msg[160];
         snprintf(msg, sizeof msg, "LU: after the singletons a bump of %d rows remains (limit %d, IPXK_LU_BUMP_MAX)", kb, kb_max);
         throw Error(IPXK_E_UNSUPPORTED, msg);
@@ -1918,10 +1971,11 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
             }
         } else {
             // two-level panels: sub-panels in registers (R rows per thread), the trailing matrix once per kPanel columns
-            int W = kb <= 2 * kPanelThreads ? kNarrowWide : kb <= 4 * kPanelThreads ? kNarrow : kb <= 8 * kPanelThreads ? kNarrowDeep : kNarrowHuge;
+            int W = kb <= 2 * kPanelThreads ? kNarrowWide : kb <= 4 * kPanelThreads ? kNarrow : kb <= 8 * kPanelThreads ? kNarrowDeep :
+                    kb <= 16 * kPanelThreads ? kNarrowHuge : kNarrowGiant;
             if (const char* e = getenv("IPXK_LU_PANEL_W")) {               // (tests: a narrower sub-panel than the bump needs -- more rows per thread)
                 const int w = atoi(e);
-                if ((w == 2 || w == 4 || w == 8 || w == 16) && w <= W) W = w;
+                if ((w == 1 || w == 2 || w == 4 || w == 8 || w == 16) && w <= W) W = w;
             }
             // the matrix cores for the trailing update of large bumps (IPXK_LU_MFMA_MIN rows and more, default 1025; 0: never)
             const char* mfma_env = getenv("IPXK_LU_MFMA_MIN");                 // (read per factorization: the tests switch it)
@@ -1979,7 +2033,8 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
                     if (W == kNarrowWide) hipLaunchKernelGGL((lu_panel_multi_kernel<2, kNarrowWide>), dim3(1), dim3(kPanelThreads), 0, s, P, ci, ce, first, us, c1o, step_src);
                     else if (W == kNarrow) hipLaunchKernelGGL((lu_panel_multi_kernel<4, kNarrow>), dim3(1), dim3(kPanelThreads), 0, s, P, ci, ce, first, us, c1o, step_src);
                     else if (W == kNarrowDeep) hipLaunchKernelGGL((lu_panel_multi_kernel<8, kNarrowDeep>), dim3(1), dim3(kPanelThreads), 0, s, P, ci, ce, first, us, c1o, step_src);
-                    else hipLaunchKernelGGL((lu_panel_multi_kernel<16, kNarrowHuge>), dim3(1), dim3(kPanelThreads), 0, s, P, ci, ce, first, us, c1o, step_src);
+                    else if (W == kNarrowHuge) hipLaunchKernelGGL((lu_panel_multi_kernel<16, kNarrowHuge>), dim3(1), dim3(kPanelThreads), 0, s, P, ci, ce, first, us, c1o, step_src);
+                    else hipLaunchKernelGGL((lu_panel_multi_kernel<32, kNarrowGiant>), dim3(1), dim3(kPanelThreads), 0, s, P, ci, ce, first, us, c1o, step_src);
                     if (ce < c1o) {         // the rest of the outer panel
                         if (fused_sub) {
                             hipLaunchKernelGGL(lu_subpanel_update_kernel, dim3((kb + 63) / 64), dim3(kBlock), 0, s, P, ce, c1o, W_.usub.get());
@@ -2113,9 +2168,12 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
     if (info) *info = I;
     if (getenv("IPXK_VERBOSE"))
         fprintf(stderr, "ipxk: LU dim %d nnz %lld: %lld column + %lld row singletons in %d rounds (%.2f ms), bump %d (%.2f ms, %d dependent), "
-                "assembly %.2f ms; nnz(L) %lld nnz(U) %lld\n", dim, (long long)nbB, (long long)I.col_singletons, (long long)I.row_singletons,
-                rounds, I.seconds_singletons * 1e3, kb, I.seconds_bump * 1e3, ndep, I.seconds_assemble * 1e3, (long long)lnz, (long long)unz);
+                "assembly %.2f ms; nnz(L) %lld nnz(U) %lld; %d sparse pivots in %d elimination rounds, %d spikes\n", dim, (long long)nbB, (long long)I.col_singletons, (long long)I.row_singletons,
+                rounds, I.seconds_singletons * 1e3, kb, I.seconds_bump * 1e3, ndep, I.seconds_assemble * 1e3, (long long)lnz, (long long)unz,
+                (int)I.sparse_pivots, (int)I.sparse_rounds, (int)I.spikes);
 }
+
+void lu_invalidate(Context* c) { if (c->lu) c->lu->valid = false; }
 
 bool lu_view(const Context* c, LuView* out) {
     const LuState* S = c->lu;

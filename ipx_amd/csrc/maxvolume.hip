@@ -388,9 +388,6 @@ struct MaxvolState {
     DevBuf<Scalars> scalars;
     DevBuf<unsigned char> tmp;
     Scalars* h = nullptr;      // pinned
-    // LU pivot tolerance of this context's refactorizations: tightened after an unstable exchange and KEPT for every later
-    // call, like Basis::TightenLuPivotTol changes lu_->pivottol() for good (src/basis.cc:490-503)
-    double pivottol = 0.1;
     ~MaxvolState() { if (h) (void)hipHostFree(h); }
 };
 void destroy_maxvol(MaxvolState* M) { delete M; }
@@ -471,7 +468,7 @@ void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_i
                                 M.eta_piv.get(), M.eta_idx.get(), M.eta_val.get(), v);
     };
     // the reference's ladder for the LU pivot tolerance (Basis::TightenLuPivotTol, src/basis.cc:490-503); the value is the context's
-    double& pivottol = M.pivottol;
+    double& pivottol = c->maxvol_pivottol;
     auto tighten_pivottol = [&]() {
         if (pivottol <= 0.05) pivottol = 0.1;
         else if (pivottol <= 0.25) pivottol = 0.3;
@@ -645,7 +642,7 @@ void maxvolume_sequential_dev(Context* c, const ipxint* status_in, const double*
     int K = 0;
     int64_t eta_used = 0;
     ipxk_maxvolume_info I{};
-    double& pivottol = M.pivottol;
+    double& pivottol = c->maxvol_pivottol;
     auto tighten_pivottol = [&]() {                   // Basis::TightenLuPivotTol, src/basis.cc:490-503
         if (pivottol <= 0.05) pivottol = 0.1;
         else if (pivottol <= 0.25) pivottol = 0.3;

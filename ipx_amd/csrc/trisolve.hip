@@ -1338,7 +1338,7 @@ static DeviceFactors cut_dense_block(Context* c, SplitOperator* S, const DeviceF
     // blocked solve each -- about 1 s at 8000 rows -- but the one-workgroup solve it replaces takes 18 ms per application there:
     // measured on a 12 000 x 30 000 LP through the drop-in solver (24 Prepares, 1100 CR iterations): 23 + 0.7 s against 43 s
     static const int inverse_min = [] { const char* e = getenv("IPXK_BUMP_INVERSE_MIN"); return e ? atoi(e) : 512; }();
-    static const int inverse_max = [] { const char* e = getenv("IPXK_BUMP_INVERSE_MAX"); return e ? atoi(e) : 16384; }();
+    static const int inverse_max = [] { const char* e = getenv("IPXK_BUMP_INVERSE_MAX"); return e ? atoi(e) : 32768; }();
     S->bump_explicit = inverse_min > 0 && kb >= inverse_min && kb <= inverse_max;
     if (S->bump_explicit) {
         S->bump_inv.ensure((size_t)kb * kb); S->bump_invT.ensure((size_t)kb * kb); S->bump_x.ensure((size_t)kb);
@@ -1427,10 +1427,10 @@ static DeviceFactors cut_dense_block(Context* c, SplitOperator* S, const DeviceF
 // the host, and without this a 2000-row bump is a chain of 2000 dependency levels (12 ms per operator application
 // against 1 ms with the block cut out: the drop-in class on the IPM's random LPs).
 static int trailing_dense_block(int m, const ipxint* Lp) {
-    // the largest trailing block (up to 16384 columns: the largest dense block the LU produces) whose part of L is at least 30 % full: a dense LU of a sparse bump
+    // the largest trailing block (up to 32768 columns: the largest dense block the LU produces) whose part of L is at least 30 % full: a dense LU of a sparse bump
     // starts with sparse columns and fills up, so single columns say little; the block as a whole does
     int s0 = m;
-    const int lo = std::max(0, m - 16384);
+    const int lo = std::max(0, m - 32768);
     for (int j = m - 2; j >= lo; j--) {
         const double kb = (double)(m - j), have = (double)(Lp[m] - Lp[j]);
         if (have >= 0.3 * (kb * (kb - 1.0) / 2.0)) s0 = j;
@@ -1463,7 +1463,8 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
     }
     // the operator object (and its device buffers) is reused from one Prepare to the next; while it is
     // being rebuilt the context has no operator, and a failure leaves it that way
-    std::unique_ptr<SplitOperator> S(c->split ? c->split : new SplitOperator);
+    std::unique_ptr<SplitOperator> S(c->split ? c->split : c->split_spare ? c->split_spare : new SplitOperator);
+    if (!c->split) c->split_spare = nullptr;
     c->split = nullptr;
     S->m = m;
     if (const char* e = getenv("IPXK_TRISOLVE")) S->level_launches = std::string(e) == "levels";
@@ -1494,7 +1495,7 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
         for (int j = s0; j < m && sorted_U; j++)
             for (ipxint p = Up[j] + 1; p < Up[j + 1]; p++)
                 if (Ui[p] <= Ui[p - 1]) { sorted_U = false; break; }
-        if (sorted_U && m - s0 >= bump_min && m - s0 <= 16384 && !(dense_env && dense_env[0] == '0')) {
+        if (sorted_U && m - s0 >= bump_min && m - s0 <= 32768 && !(dense_env && dense_env[0] == '0')) {
             const DeviceFactors F = cut_dense_block(c, S.get(), F0, s0, m - s0, cut);
             analyse_sweeps_resident(c, S.get(), F, nullptr, nullptr, nullptr, nullptr);
         } else {
@@ -1550,7 +1551,8 @@ void split_prepare_lu(Context* c, const ipxint* status, const double* colscale) 
     IPXK_REQUIRE(V.dim == m, "dimension mismatch");
     IPXK_REQUIRE(c->nranks == 1, "the basis path does not shard: run it as independent replicas");
     hipStream_t s = c->stream;
-    std::unique_ptr<SplitOperator> S(c->split ? c->split : new SplitOperator);
+    std::unique_ptr<SplitOperator> S(c->split ? c->split : c->split_spare ? c->split_spare : new SplitOperator);
+    if (!c->split) c->split_spare = nullptr;
     c->split = nullptr;
     S->m = m;
     if (const char* e = getenv("IPXK_TRISOLVE")) S->level_launches = std::string(e) == "levels";

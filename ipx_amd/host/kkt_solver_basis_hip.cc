@@ -5,7 +5,6 @@
 #include <cmath>
 #include <cstdlib>
 
-#include "indexed_vector.h"
 #include "maxvolume.h"
 #include "sparse_matrix.h"
 #include "splitted_normal_matrix.h"
@@ -21,6 +20,11 @@ extern "C" long ipx_hip_cpu_prepare_calls() { return g_cpu_prepare_calls; }
 static long g_device_maxvolume_calls = 0, g_cpu_maxvolume_calls = 0;
 extern "C" long ipx_hip_device_maxvolume_calls() { return g_device_maxvolume_calls; }
 extern "C" long ipx_hip_cpu_maxvolume_calls() { return g_cpu_maxvolume_calls; }
+// where KKTSolverBasisHip::Factorize spends its time, over all solver objects of the process (seconds): the reference's
+// DropPrimal / DropDual, the device LU + Prepare of the current basis, Maxvolume on the device, Basis::Load / Factorize of
+// the reference's Basis afterwards, the CPU path (Maxvolume on Basis + hand-off)
+static double g_phase_seconds[5] = {0, 0, 0, 0, 0};
+extern "C" double ipx_hip_factorize_phase_seconds(int phase) { return phase >= 0 && phase < 5 ? g_phase_seconds[phase] : 0.0; }
 
 namespace ipx {
 
@@ -31,10 +35,10 @@ ipxint PollInterrupt(void* control) {
 }  // namespace
 
 KKTSolverBasisHip::KKTSolverBasisHip(const Control& control, Basis& basis)
-    : control_(control), model_(basis.model()), basis_(basis), device_(basis.model()) {
-    const Int m = model_.rows();
-    const Int n = model_.cols();
-    colscale_.resize(n+m);
+    : control_(control), model_(basis.model()), basis_(basis), device_(basis.model()), reference_(control, basis) {
+    // the context may have served another solver object before (HipModel): it starts like a new one, and Maxvolume's
+    // refactorizations start from this run's pivot tolerance, as every Basis does (src/basis.cc:30)
+    HipCheck(ipxk_reset_solver_state(device_.get(), control_.lu_pivottol()));
     // time_cr2_NNt / _B / _Bt are only printed at debug level >= 2 (src/lp_solver.cc:107)
     HipCheck(ipxk_set_profiling(device_.get(), control_.Debug(2) ? 1 : 0));
     HipCheck(ipxk_set_interrupt(device_.get(), PollInterrupt, const_cast<Control*>(&control_)));
@@ -45,35 +49,42 @@ KKTSolverBasisHip::~KKTSolverBasisHip() {
     ipxk_set_interrupt(device_.get(), nullptr, nullptr);
 }
 
-// src/kkt_solver_basis.cc:20-67
+Int KKTSolverBasisHip::_basis_changes() const { return reference_.basis_changes_; }
+
+// The reference's two procedures for degenerate variables, run by the reference's own object on the Basis both share
+// (src/kkt_solver_basis.cc:30-43 decides when; :196-387 are the procedures).  They pivot on the reference's Basis
+// (TableauRow / SolveForUpdate / ExchangeIfStable), change variable states in *iterate, overwrite entries of
+// reference_.colscale_ (INFINITY for implied, 0 for fixed variables) and count their exchanges in
+// reference_.basis_changes_ and info->updates_ipm.
+void KKTSolverBasisHip::DropDegenerateVariables(Iterate* iterate, Info* info) {
+    if (iterate->pobjective() < iterate->dobjective())
+        return;                      // possibly infeasible / unbounded: the reference removes nothing then (:30-35)
+    reference_.DropPrimal(iterate, info);
+    if (!info->errflag)
+        reference_.DropDual(iterate, info);
+}
+
+// src/kkt_solver_basis.cc:20-67 with the Maxvolume / refactorize / Prepare tail (:45-64) on the device
 void KKTSolverBasisHip::_Factorize(Iterate* iterate, Info* info) {
-    const Int m = model_.rows();
-    const Int n = model_.cols();
-    info->errflag = 0;
+    static const bool on_device = !(std::getenv("IPXK_DEVICE_MAXVOLUME") && std::getenv("IPXK_DEVICE_MAXVOLUME")[0] == '0');
+    Vector& colscale = reference_.colscale_;
     factorized_ = false;
     iter_ = 0;
-    basis_changes_ = 0;
-
-    for (Int j = 0; j < n+m; j++)
-        colscale_[j] = iterate->ScalingFactor(j);
-
-    // Remove degenerate variables unless the primal objective is smaller than the dual objective (:30-43).
-    if (iterate->pobjective() >= iterate->dobjective()) {
-        DropPrimal(iterate, info);
-        if (info->errflag)
-            return;
-        DropDual(iterate, info);
-        if (info->errflag)
-            return;
-    }
-
-    // Maxvolume (:45-55), refactorization and the preconditioned normal matrix (:57-64)
-    static const bool on_device = !(std::getenv("IPXK_DEVICE_MAXVOLUME") && std::getenv("IPXK_DEVICE_MAXVOLUME")[0] == '0');
-    if (!(on_device && MaxvolumeOnDevice(info)))
-        MaxvolumeOnBasis(info);
+    reference_.basis_changes_ = 0;
+    info->errflag = 0;
+    for (Int j = 0; j < (Int)colscale.size(); j++)
+        colscale[j] = iterate->ScalingFactor(j);
+    Timer timer;
+    DropDegenerateVariables(iterate, info);
+    g_phase_seconds[0] += timer.Elapsed();
     if (info->errflag)
         return;
-    factorized_ = true;
+    if (!(on_device && MaxvolumeOnDevice(info))) {
+        timer.Reset();
+        MaxvolumeOnBasis(info);
+        g_phase_seconds[4] += timer.Elapsed();
+    }
+    factorized_ = info->errflag == 0;
 }
 
 bool KKTSolverBasisHip::MaxvolumeOnDevice(Info* info) {
@@ -84,7 +95,7 @@ bool KKTSolverBasisHip::MaxvolumeOnDevice(Info* info) {
     std::vector<double> colscale(n+m);
     bool same_basis = device_lu_valid_ && (Int)device_member_.size() == n+m;
     for (Int j = 0; j < n+m; j++) {
-        colscale[j] = colscale_[j];
+        colscale[j] = reference_.colscale_[j];
         status[j] = basis_.StatusOf(j);
         const bool member = status[j] == Basis::BASIC || status[j] == Basis::BASIC_FREE;
         if (same_basis && member != (device_member_[j] != 0))
@@ -108,6 +119,8 @@ bool KKTSolverBasisHip::MaxvolumeOnDevice(Info* info) {
             return false;                       // the reference repairs the basis (Basis::Factorize): its path
         HipCheck(ipxk_split_prepare_lu(ctx, status.data(), colscale.data()));
     }
+    g_phase_seconds[1] += timer.Elapsed();
+    Timer timer_maxvol;
     std::vector<Int> basis_out(m), status_out(n+m);
     ipxk_maxvolume_info mv;
     int rc;
@@ -127,11 +140,12 @@ bool KKTSolverBasisHip::MaxvolumeOnDevice(Info* info) {
         return false;
     }
     HipCheck(rc);
+    g_phase_seconds[2] += timer_maxvol.Elapsed();
     device_maxvolume_calls_++;
     g_device_maxvolume_calls++;
     info->updates_ipm += mv.updates;
     info->time_maxvol += timer.Elapsed();
-    basis_changes_ += mv.updates;
+    reference_.basis_changes_ += mv.updates;
     info->errflag = mv.errflag;
     if (info->errflag)
         return true;
@@ -144,6 +158,8 @@ bool KKTSolverBasisHip::MaxvolumeOnDevice(Info* info) {
         device_member_[basis_out[p]] = 1;
     device_lu_valid_ = true;
     prepared_once_ = false;                   // (the factors of an earlier GetLuFactors hand-off are gone)
+    Timer timer_load;
+    struct AddOnExit { Timer& t; ~AddOnExit() { g_phase_seconds[3] += t.Elapsed(); } } add_on_exit{timer_load};
     if (mv.updates > 0) {
         // the reference's Basis learns the final basis: loads and factorizes (src/basis.cc:81-114), as :57-61 would
         std::vector<int> basic_status(n+m);
@@ -165,13 +181,13 @@ void KKTSolverBasisHip::MaxvolumeOnBasis(Info* info) {
     device_lu_valid_ = false;
     Maxvolume maxvol(control_);
     if (control_.update_heuristic() == 0) {
-        info->errflag = maxvol.RunSequential(&colscale_[0], basis_);
+        info->errflag = maxvol.RunSequential(&reference_.colscale_[0], basis_);
     } else {
-        info->errflag = maxvol.RunHeuristic(&colscale_[0], basis_);
+        info->errflag = maxvol.RunHeuristic(&reference_.colscale_[0], basis_);
     }
     info->updates_ipm += maxvol.updates();
     info->time_maxvol += maxvol.time();
-    basis_changes_ += maxvol.updates();
+    reference_.basis_changes_ += maxvol.updates();
     if (info->errflag)
         return;
     if (!basis_.FactorizationIsFresh()) {
@@ -189,7 +205,7 @@ void KKTSolverBasisHip::MaxvolumeOnBasis(Info* info) {
     std::vector<double> colscale(n + m);
     std::vector<Int> status(n + m), basic(m);
     for (Int j = 0; j < n + m; j++) {
-        colscale[j] = colscale_[j];
+        colscale[j] = reference_.colscale_[j];
         status[j] = basis_.StatusOf(j);
     }
     for (Int p = 0; p < m; p++)
@@ -212,160 +228,6 @@ void KKTSolverBasisHip::MaxvolumeOnBasis(Info* info) {
                                   status.data(), colscale.data()};
     ipx_hip::HandOffBasis(device_.get(), h, same_factors);
     prepared_once_ = true;
-}
-
-// src/kkt_solver_basis.cc:196-290
-void KKTSolverBasisHip::DropPrimal(Iterate* iterate, Info* info) {
-    const Int m = model_.rows();
-    const Int n = model_.cols();
-    const Vector& xl = iterate->xl();
-    const Vector& xu = iterate->xu();
-    const Vector& zl = iterate->zl();
-    const Vector& zu = iterate->zu();
-    const double drop_primal = control_.ipm_drop_primal();
-    const double volume_tol = 2.0;
-    info->errflag = 0;
-
-    std::vector<Int> candidates;
-    for (Int p = 0; p < m; p++) {
-        const Int jb = basis_[p];
-        if (basis_.StatusOf(jb) != Basis::BASIC)     // free variables stay
-            continue;
-        const bool lower = xl[jb] <= xu[jb];         // the nearer bound
-        const double xj = lower ? xl[jb] : xu[jb];
-        const double zj = lower ? zl[jb] : zu[jb];
-        if (xj < 0.01*zj && xj <= drop_primal)
-            candidates.push_back(jb);
-    }
-    if (candidates.empty())
-        return;
-
-    IndexedVector btran(m), row(n+m);
-    Vector invscale_basic(m);
-    for (Int p = 0; p < m; p++)
-        invscale_basic[p] = 1.0 / colscale_[basis_[p]];
-
-    while (!candidates.empty()) {
-        const Int jb = candidates.back();
-        const Int p = basis_.PositionOf(jb);
-        assert(p >= 0);
-        const double s = invscale_basic[p];
-        basis_.TableauRow(jb, btran, row, true);
-        Int jmax = -1;
-        double vmax = volume_tol;
-        auto search_pivot = [&](Int j, double pivot) {
-            pivot = std::abs(pivot);
-            if (pivot > kPivotZeroTol) {
-                const double v = pivot * colscale_[j] * s;
-                if (v > vmax) {
-                    vmax = v;
-                    jmax = j;
-                }
-            }
-        };
-        for_each_nonzero(row, search_pivot);
-        if (jmax >= 0) {
-            const double pivot = row[jmax];
-            if (std::abs(pivot) < 1e-3)
-                control_.Debug(3)
-                    << " |pivot| = " << sci2(std::abs(pivot))
-                    << " (primal basic variable close to bound)\n";
-            bool exchanged;
-            info->errflag = basis_.ExchangeIfStable(jb, jmax, pivot, 1, &exchanged);
-            if (info->errflag)
-                return;
-            if (!exchanged)      // the factorization was unstable and has been redone: same candidate again
-                continue;
-            invscale_basic[p] = 1.0 / colscale_[jmax];
-            info->updates_ipm++;
-            basis_changes_++;
-        } else {
-            // the variable becomes "implied" at a bound
-            if (zl[jb]/xl[jb] > zu[jb]/xu[jb])
-                iterate->make_implied_lb(jb);
-            else
-                iterate->make_implied_ub(jb);
-            basis_.FreeBasicVariable(jb);
-            invscale_basic[p] = 0.0;
-            colscale_[jb] = INFINITY;
-            info->primal_dropped++;
-        }
-        candidates.pop_back();
-    }
-}
-
-// src/kkt_solver_basis.cc:292-387
-void KKTSolverBasisHip::DropDual(Iterate* iterate, Info* info) {
-    const Int m = model_.rows();
-    const Int n = model_.cols();
-    const Vector& xl = iterate->xl();
-    const Vector& xu = iterate->xu();
-    const Vector& zl = iterate->zl();
-    const Vector& zu = iterate->zu();
-    const double drop_dual = control_.ipm_drop_dual();
-    const double volume_tol = 2.0;
-    info->errflag = 0;
-
-    std::vector<Int> candidates;
-    for (Int jn = 0; jn < n+m; jn++) {
-        if (basis_.StatusOf(jn) != Basis::NONBASIC)
-            continue;
-        const bool lower = zl[jn] >= zu[jn];         // the larger dual variable
-        const double xj = lower ? xl[jn] : xu[jn];
-        const double zj = lower ? zl[jn] : zu[jn];
-        if (zj < 0.01*xj && zj <= drop_dual)
-            candidates.push_back(jn);
-    }
-    if (candidates.empty())
-        return;
-
-    IndexedVector ftran(m);
-    Vector invscale_basic(m);
-    for (Int p = 0; p < m; p++)
-        invscale_basic[p] = 1.0 / colscale_[basis_[p]];
-
-    while (!candidates.empty()) {
-        const Int jn = candidates.back();
-        const double s = colscale_[jn];
-        basis_.SolveForUpdate(jn, ftran);
-        Int pmax = -1;
-        double vmax = volume_tol;
-        auto search_pivot = [&](Int p, double pivot) {
-            pivot = std::abs(pivot);
-            if (pivot > kPivotZeroTol) {
-                const double v = pivot * invscale_basic[p] * s;
-                if (v > vmax) {
-                    vmax = v;
-                    pmax = p;
-                }
-            }
-        };
-        for_each_nonzero(ftran, search_pivot);
-        if (pmax >= 0) {
-            const double pivot = ftran[pmax];
-            if (std::abs(pivot) < 1e-3)
-                control_.Debug(3)
-                    << " |pivot| = " << sci2(std::abs(pivot))
-                    << " (dual nonbasic variable close to zero)\n";
-            const Int jb = basis_[pmax];
-            bool exchanged;
-            info->errflag = basis_.ExchangeIfStable(jb, jn, pivot, -1, &exchanged);
-            if (info->errflag)
-                return;
-            if (!exchanged)
-                continue;
-            invscale_basic[pmax] = 1.0 / colscale_[jn];
-            info->updates_ipm++;
-            basis_changes_++;
-        } else {
-            // the variable becomes "fixed" at its current value
-            iterate->make_fixed(jn);
-            basis_.FixNonbasicVariable(jn);
-            colscale_[jn] = 0.0;
-            info->dual_dropped++;
-        }
-        candidates.pop_back();
-    }
 }
 
 void KKTSolverBasisHip::_Solve(const Vector& a, const Vector& b, double tol,

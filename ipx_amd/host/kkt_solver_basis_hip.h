@@ -1,7 +1,10 @@
 // KKTSolverBasisHip: drop-in for ipx::KKTSolverBasis (reference src/kkt_solver_basis.h:21-66).
-// _Factorize restates the reference's (src/kkt_solver_basis.cc:20-67) on the public members of Basis / Iterate:
-// the scaling factors, DropPrimal / DropDual (:196-387; a handful of hypersparse solves on the reference's own
-// Basis, CPU), then Maxvolume ON THE DEVICE (ipxk_maxvolume / ipxk_maxvolume_sequential: the identical decisions as
+// _Factorize follows the reference's (src/kkt_solver_basis.cc:20-67): the scaling factors, then the reference's OWN
+// DropPrimal / DropDual (:196-387; a handful of hypersparse solves on the reference's Basis, CPU) -- this class holds
+// a KKTSolverBasis object and calls its two private members, for which src/kkt_solver_basis.h gains ONE line,
+//     friend class KKTSolverBasisHip;
+// (the test harness applies it with sed on the way into the compiler, oracle/Makefile) -- nothing
+// of those functions is restated here.  Then Maxvolume ON THE DEVICE (ipxk_maxvolume / ipxk_maxvolume_sequential: the identical decisions as
 // ipx::Maxvolume, pinned against it up to 1M rows) from a device factorization of the current basis, which ends with
 // the fresh factorization and the split operator of the final basis; the final basis goes back into the reference's
 // Basis with Basis::Load (src/basis.h:86-94: loads and factorizes -- the factorization the reference performs at
@@ -18,6 +21,7 @@
 #include "control.h"
 #include "hip_device.h"
 #include "kkt_solver.h"
+#include "kkt_solver_basis.h"
 #include "model.h"
 
 namespace ipx {
@@ -39,23 +43,22 @@ private:
     void _Solve(const Vector& a, const Vector& b, double tol,
                 Vector& x, Vector& y, Info* info) override;
     Int _iter() const override { return iter_; }
-    Int _basis_changes() const override { return basis_changes_; }
+    Int _basis_changes() const override;
     const Basis* _basis() const override { return &basis_; }
 
-    // src/kkt_solver_basis.cc:196-387 on the public interface of Basis / Iterate
-    void DropPrimal(Iterate* iterate, Info* info);
-    void DropDual(Iterate* iterate, Info* info);
+    // the reference's DropPrimal / DropDual (src/kkt_solver_basis.cc:196-387) on reference_'s colscale_ / basis_changes_
+    void DropDegenerateVariables(Iterate* iterate, Info* info);
     // Maxvolume + fresh factorization + operator on the device; false: declined (nothing changed, take the CPU path)
     bool MaxvolumeOnDevice(Info* info);
     void MaxvolumeOnBasis(Info* info);
-
-    static constexpr double kPivotZeroTol = 1e-7;      // src/kkt_solver_basis.h:33
 
     const Control& control_;
     const Model& model_;
     Basis& basis_;
     HipModel device_;
-    Vector colscale_;            // interior point column scaling factors (src/kkt_solver_basis.h:60)
+    // The reference's solver object on the same Basis: owner of the scaling factors (colscale_) and of the basis change
+    // counter, which its DropPrimal / DropDual read and update.  Its _Factorize / _Solve are never called.
+    KKTSolverBasis reference_;
     bool factorized_{false};
     bool prepared_once_{false};  // the device holds the factors of an earlier hand-off from Basis::GetLuFactors
     Int factorizations_at_handoff_{-1};   // Basis::factorizations() when those factors were handed over
@@ -63,7 +66,6 @@ private:
     bool device_lu_valid_{false};
     Int maxiter_{-1};
     Int iter_{0};
-    Int basis_changes_{0};
     Int device_maxvolume_calls_{0}, cpu_maxvolume_calls_{0};
 };
 

@@ -25,7 +25,7 @@ NONBASIC_FIXED, NONBASIC, BASIC, BASIC_FREE = -2, -1, 0, 1
 
 EXPORTS = [
     "ipxk_last_error", "ipxk_device_count", "ipxk_create", "ipxk_destroy", "ipxk_set_pointer_mode",
-    "ipxk_set_stream", "ipxk_synchronize", "ipxk_set_profiling", "ipxk_set_interrupt", "ipxk_num_dense_cols", "ipxk_get_rowwise",
+    "ipxk_set_stream", "ipxk_synchronize", "ipxk_set_profiling", "ipxk_set_interrupt", "ipxk_reset_solver_state", "ipxk_num_dense_cols", "ipxk_get_rowwise",
     "ipxk_normal_prepare", "ipxk_normal_apply", "ipxk_diag_factorize", "ipxk_diag_apply",
     "ipxk_diag_get", "ipxk_pcr_solve", "ipxk_cr_diagnostics", "ipxk_kkt_diag_factorize", "ipxk_kkt_diag_solve",
     "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_rescale", "ipxk_split_apply", "ipxk_forward_solve",
@@ -232,6 +232,11 @@ class KktContext:
 
     def synchronize(self):
         self._check(self.lib.ipxk_synchronize(self.h))
+
+    def reset_solver_state(self, lu_pivottol=0.0):
+        """the context as a new solver object finds it (HipModel hands a cached context out through this): nothing prepared /
+        factorized, Maxvolume's refactorizations start from lu_pivottol (<= 0: 0.1)"""
+        self._check(self.lib.ipxk_reset_solver_state(self.h, c_f64(lu_pivottol)))
 
     def vector(self, n, host=None):
         return DeviceVector(self, n, host)

@@ -1419,7 +1419,9 @@ struct orc_lu {
 };
 
 static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, const Int* Bi_in, const double* Bx_in,
-                                 double pivottol, int strict_abs_pivottol, Int bump_limit, int sparse_rounds, Int sparse_min, Int slow_den, Int fill_max) {
+                                 double pivottol, int strict_abs_pivottol, Int bump_limit, int sparse_rounds, Int sparse_min, Int slow_den, Int fill_max,
+                                 Int sparse_from = -2, double dense_at = 0.0, int fill_to_dense = 0) {
+    if (sparse_from == -2) sparse_from = bump_limit;       // (rounds for bumps of more than sparse_from rows; until round 4: the dense limit)
     const double abstol = strict_abs_pivottol ? 1e-3 : 1e-14;
     std::unique_ptr<orc_lu> F(new orc_lu);
     F->dim = dim;
@@ -1458,8 +1460,8 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
     std::vector<char> torn(dim, 0);                  // spike columns (set aside when the rounds stall)
     std::vector<Int> pivrow_of(dim, -1);             // pivot row of a pivoted column
     // (the limit decides whether a bump is torn; the spikes may fill the largest dense block the device's panel kernels take,
-    // 16384 rows, unless a small limit -- tests -- binds them too)
-    const Int spike_limit = bump_limit > 4096 ? std::max<Int>(bump_limit, 16384) : bump_limit;
+    // 32768 rows, unless a small limit -- tests -- binds them too)
+    const Int spike_limit = bump_limit > 4096 ? std::max<Int>(bump_limit, 32768) : bump_limit;
     bool tearing = false, sparse_entered = false;
     Int ntorn = 0, tear_width = 1, npiv_at_tear = 0;
     while (true) {
@@ -1580,7 +1582,7 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
                 for (Int j = 0; j < dim; j++) cp[j + 1] += cp[j];
                 rebuild_rows();
             };
-            if (bump_limit < 0 || nact <= bump_limit) break;       // small enough: dense as it stands
+            if (sparse_from < 0 || nact <= sparse_from) break;     // small enough: dense as it stands
             sparse_entered = true;
             rebuild();                                             // the active submatrix
             int slow = 0;
@@ -1588,6 +1590,8 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
                 // (the rounds stop early once the current matrix fits the dense code and two rounds in a row have each eliminated
                 // fewer than 1 / slow_den of the columns: what is left has no large sets of independent pivots any more)
                 if (slow_den > 0 && (bump_limit < 0 || nact <= bump_limit) && slow >= 2) break;
+                // ... or once it fits the dense code and holds more than dense_at x nact^2 entries: a dense matrix in sparse storage
+                if (dense_at > 0.0 && (bump_limit < 0 || nact <= bump_limit) && (double)cp[dim] > dense_at * (double)nact * (double)nact) break;
                 // 1. one candidate per column: among its entries that pass the absolute and the relative threshold, the one in
                 //    the shortest row (ties: larger |entry|, then smaller row); cost = (row count - 1)(column count - 1)
                 candrow.assign(dim, -1);
@@ -1664,7 +1668,12 @@ static orc_lu* lu_factorize_impl(Int dim, const Int* Bbegin, const Int* Bend, co
                 rebuild();
                 slow = (int64_t)winners.size() * slow_den < (int64_t)nact ? slow + 1 : 0;
                 nact -= (Int)winners.size();
-                if (fill_max > 0 && (int64_t)cp[dim] > (int64_t)fill_max * nnz_B + (1 << 20)) return nullptr;   // bounded work: given up
+                const int64_t fill_bound = std::max<int64_t>((int64_t)fill_max * nnz_B + (1 << 20),
+                                                             fill_to_dense ? (int64_t)(dense_at * (double)bump_limit * (double)bump_limit) : 0);
+                if (fill_max > 0 && (int64_t)cp[dim] > fill_bound) {   // bounded work: given up
+                    if (fill_to_dense && (bump_limit < 0 || nact <= bump_limit)) break;             // (round 5: the dense code takes what is left if it can)
+                    return nullptr;
+                }
             }
             break;
         }
@@ -1852,6 +1861,17 @@ extern "C" orc_lu* orc_lu_factorize(Int dim, const Int* Bbegin, const Int* Bend,
 extern "C" orc_lu* orc_lu_factorize_sparse(Int dim, const Int* Bbegin, const Int* Bend, const Int* Bi, const double* Bx,
                                            double pivottol, int strict_abs_pivottol, Int bump_limit, Int sparse_min, Int slow_den, Int fill_max) {
     return lu_factorize_impl(dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol, bump_limit, 1, sparse_min, slow_den, fill_max);
+}
+
+// ... with the policy of round 5 (ipx_amd/csrc/lu.hip, default): elimination rounds for every bump of more than sparse_from rows; they
+// end at sparse_min columns, or -- once at most rest_limit columns are left, what the dense code takes -- after two slow rounds (as above),
+// or when the current matrix holds more than dense_at x (columns left)^2 entries, or when it exceeds fill_max x nnz(B) + 2^20 entries;
+// NULL only if more than rest_limit columns are left at that point.
+extern "C" orc_lu* orc_lu_factorize_policy(Int dim, const Int* Bbegin, const Int* Bend, const Int* Bi, const double* Bx,
+                                           double pivottol, int strict_abs_pivottol, Int sparse_from, Int rest_limit, Int sparse_min,
+                                           Int slow_den, Int fill_max, double dense_at) {
+    return lu_factorize_impl(dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol, rest_limit, 1, sparse_min, slow_den, fill_max,
+                             sparse_from, dense_at, 1);
 }
 
 extern "C" void orc_lu_sizes(const orc_lu* F, Int* lnz, Int* unz, Int* ndep, Int* info) {

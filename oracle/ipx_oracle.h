@@ -236,6 +236,11 @@ orc_lu* orc_lu_factorize(orc_int dim, const orc_int* Bbegin, const orc_int* Bend
  * most sparse_min columns are active (or at most bump_limit and two rounds in a row have each eliminated fewer than 1 / slow_den of the columns; 0: never); NULL as well when the current matrix exceeds fill_max x nnz(B) + 2^20 entries (0: never).  info[6] = pivots of the elimination rounds, info[7] = # elimination rounds. */
 orc_lu* orc_lu_factorize_sparse(orc_int dim, const orc_int* Bbegin, const orc_int* Bend, const orc_int* Bi, const double* Bx,
                                 double pivottol, int strict_abs_pivottol, orc_int bump_limit, orc_int sparse_min, orc_int slow_den, orc_int fill_max);
+/* the policy of round 5 (the device's default): rounds for bumps of more than sparse_from rows, ended by density / fill / slowness once
+ * at most rest_limit columns are left (see ipx_oracle.cc) */
+orc_lu* orc_lu_factorize_policy(orc_int dim, const orc_int* Bbegin, const orc_int* Bend, const orc_int* Bi, const double* Bx,
+                                double pivottol, int strict_abs_pivottol, orc_int sparse_from, orc_int rest_limit, orc_int sparse_min,
+                                orc_int slow_den, orc_int fill_max, double dense_at);
 void orc_lu_sizes(const orc_lu* F, orc_int* lnz, orc_int* unz, orc_int* ndep, orc_int* info);
 void orc_lu_get(const orc_lu* F, orc_int* Lp, orc_int* Li, double* Lx, orc_int* Up, orc_int* Ui, double* Ux,
                 orc_int* rowperm, orc_int* colperm, orc_int* dependent);

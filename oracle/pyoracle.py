@@ -90,7 +90,7 @@ class Oracle:
                      "orc_kkt_diag_solve", "orc_trisolve", "orc_split_get_sizes",
                      "orc_kkt_basis_solve", "orc_newton_solve_diag", "orc_newton_solve_basis", "orc_ipm_step_diag"):
             getattr(L, name).restype = c_i64
-        for name in ("orc_diag_factorize", "orc_kkt_diag_new", "orc_split_prepare", "orc_lu_factorize", "orc_lu_factorize_sparse", "orc_basis_new"):
+        for name in ("orc_diag_factorize", "orc_kkt_diag_new", "orc_split_prepare", "orc_lu_factorize", "orc_lu_factorize_sparse", "orc_lu_factorize_policy", "orc_basis_new"):
             getattr(L, name).restype = C.c_void_p
 
     # ---- Iterate / StepToBoundary ---------------------------------------------
@@ -147,12 +147,20 @@ class Oracle:
                                _ip(ATp), _ip(ATi), _fp(ATx))
         return Csc(A.ncol, A.nrow, ATp, ATi, ATx)
 
-    def lu_factorize(self, dim, Bbegin, Bend, Bi, Bx, pivottol=0.1, strict=False, bump_limit=-1, sparse_min=None, slow_den=256, fill_max=8):
+    def lu_factorize(self, dim, Bbegin, Bend, Bi, Bx, pivottol=0.1, strict=False, bump_limit=-1, sparse_min=None, slow_den=256, fill_max=8,
+                     policy=None):
         """LuFactorization contract (src/lu_factorization.h:21-58): returns dict(L, U, rowperm, colperm, dependent,
         info) with L, U as Csc, or None when the bump exceeds bump_limit.  sparse_min: elimination rounds (not tearing)
-        while more than that many columns are active."""
+        while more than that many columns are active.  policy = dict(sparse_from, rest_limit, sparse_min, slow_den, fill_max,
+        dense_at): the device's default policy since round 5 (orc_lu_factorize_policy)."""
         Bbegin, Bend, Bi, Bx = _I(Bbegin), _I(Bend), _I(Bi), _F(Bx)
-        if sparse_min is None:
+        if policy is not None:
+            q = dict(sparse_from=1024, rest_limit=32768, sparse_min=512, slow_den=2048, fill_max=8, dense_at=0.2)
+            q.update(policy)
+            h = self.lib.orc_lu_factorize_policy(c_i64(dim), _ip(Bbegin), _ip(Bend), _ip(Bi), _fp(Bx), c_f64(pivottol), C.c_int(1 if strict else 0),
+                                                 c_i64(q["sparse_from"]), c_i64(q["rest_limit"]), c_i64(q["sparse_min"]), c_i64(q["slow_den"]),
+                                                 c_i64(q["fill_max"]), c_f64(q["dense_at"]))
+        elif sparse_min is None:
             h = self.lib.orc_lu_factorize(c_i64(dim), _ip(Bbegin), _ip(Bend), _ip(Bi), _fp(Bx), c_f64(pivottol),
                                           C.c_int(1 if strict else 0), c_i64(bump_limit))
         else:

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "default_policy: LU tests that run under the default policy (tests/test_gpu_lu.py)")
 
 
 @pytest.fixture(scope="session")

@@ -152,5 +152,53 @@ int main(int argc, char** argv) {
                (long)cr_hip.errflag(), RelErr(y2, y1), ok_apply && ok_cr ? "PASS" : "FAIL");
         failures += !(ok_apply && ok_cr);
     }
+    // ---- two DIFFERENT models with equal dimensions, equal nnz and equal colptr back to back (the registry of
+    //      hip_device.h must not hand the first model's device matrix to the second): model B = the model above with
+    //      ONE value changed, model C = with ONE row index changed.  Each is solved by a fresh KKTSolverDiagHip and
+    //      by the reference's KKTSolverDiag; a cached context of the first model is idle at that time.
+    {
+        const long creations_before = ipx::HipModel::creations(), hits_before = ipx::HipModel::hits();
+        { ipx::KKTSolverDiagHip again(control, model); }              // the same model once more: served from the cache
+        const bool hit = ipx::HipModel::hits() == hits_before + 1 && ipx::HipModel::creations() == creations_before;
+        bool ok_models = hit;
+        for (int variant = 0; variant < 2; variant++) {
+            std::vector<Int> Ai2 = Ai;
+            std::vector<double> Ax2 = Ax;
+            const Int j = n / 2, p = Ap[j];
+            if (variant == 0) Ax2[p] = -Ax2[p] * 1.5;
+            else {                                                     // another row for the column's first entry
+                Int r = (Ai2[p] + 1) % m;
+                for (bool clash = true; clash; ) {
+                    clash = false;
+                    for (Int q = Ap[j]; q < Ap[j + 1]; q++) if (q != p && Ai2[q] == r) { clash = true; r = (r + 1) % m; }
+                }
+                Ai2[p] = r;
+            }
+            ipx::UserModel um2;
+            ipx::Model model2;
+            if (um2.Load(control, m, n, Ap.data(), Ai2.data(), Ax2.data(), rhs.data(), ct.data(), obj.data(), lb.data(),
+                         ub.data()) != 0) return 2;
+            ipx::Presolver pre2(um2, model2);
+            if (pre2.PresolveModel(control) != 0 || model2.rows() != m || model2.cols() != n) return 2;
+            ipx::Iterate it2(model2);
+            it2.Initialize(x0, xl, xu, y0, zl, zu);
+            const long c0 = ipx::HipModel::creations();
+            ipx::KKTSolverDiag cpu(control, model2);
+            ipx::KKTSolverDiagHip gpu(control, model2);
+            cpu.maxiter(500);
+            gpu.maxiter(500);
+            Result rc = Run(cpu, &it2, a, b, tol, n, m);
+            Result rg = Run(gpu, &it2, a, b, tol, n, m);
+            const bool fresh = ipx::HipModel::creations() == c0 + 1;       // not the first model's context
+            const bool same = rc.errflag == rg.errflag && std::labs((long)(rc.iter - rg.iter)) <= 2 &&
+                              RelErr(rg.y, rc.y) < 1e-6 && RelErr(rg.x, rc.x) < 1e-5;
+            printf("model %c (one %s changed): own device model %s, y relerr %.2e x relerr %.2e\n", 'B' + variant,
+                   variant == 0 ? "value" : "row index", fresh ? "yes" : "NO", RelErr(rg.y, rc.y), RelErr(rg.x, rc.x));
+            ok_models = ok_models && fresh && same;
+        }
+        printf("equal dimensions / nnz / colptr, different content: cache hit for the same model %s -> %s\n", hit ? "yes" : "NO",
+               ok_models ? "PASS" : "FAIL");
+        failures += !ok_models;
+    }
     return failures ? 1 : 0;
 }

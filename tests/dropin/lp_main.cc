@@ -32,6 +32,7 @@ extern "C" double ipx_hip_cpu_prepare_seconds();
 extern "C" long ipx_hip_cpu_prepare_calls();
 extern "C" long ipx_hip_device_maxvolume_calls();
 extern "C" long ipx_hip_cpu_maxvolume_calls();
+extern "C" double ipx_hip_factorize_phase_seconds(int phase);
 #endif
 
 template <class T>
@@ -121,6 +122,11 @@ int main(int argc, char** argv) {
     // one device model per Model: the three solver objects of LpSolver::Solve share one context (hip_device.h)
     f << "device_maxvolume_calls " << ipx_hip_device_maxvolume_calls() << '\n';
     f << "cpu_maxvolume_calls " << ipx_hip_cpu_maxvolume_calls() << '\n';
+    {
+        const char* names[5] = {"factorize_drop_seconds", "factorize_device_lu_prepare_seconds", "factorize_device_maxvolume_seconds",
+                                "factorize_basis_load_seconds", "factorize_cpu_path_seconds"};
+        for (int p = 0; p < 5; p++) f << names[p] << ' ' << ipx_hip_factorize_phase_seconds(p) << '\n';
+    }
     f << "hip_model_creations " << ipx::HipModel::creations() << '\n';
     f << "hip_model_hits " << ipx::HipModel::hits() << '\n';
 #endif

@@ -60,6 +60,22 @@ def test_product_does_not_touch_oracle():
         assert "oracle" not in needed and "ipx_ref" not in needed
 
 
+def test_no_tracked_binaries():
+    """history stays source-only: no tracked file is an ELF object / executable / shared library"""
+    import subprocess
+    r = subprocess.run(["git", "ls-files"], cwd=ROOT, capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("not a git checkout")
+    elf = []
+    for f in r.stdout.split():
+        path = os.path.join(ROOT, f)
+        if os.path.isfile(path):
+            with open(path, "rb") as fh:
+                if fh.read(4) == b"\x7fELF":
+                    elf.append(f)
+    assert not elf, elf
+
+
 def test_struct_layout():
     from ipx_amd import kkt
     assert ctypes.sizeof(kkt.Times) == 5 * 8

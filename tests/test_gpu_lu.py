@@ -26,6 +26,17 @@ def kkt():
     return k
 
 
+@pytest.fixture(autouse=True)
+def policy_of_round_4(monkeypatch, request):
+    """the tests written for round 4's policy (tearing first for a bump beyond IPXK_LU_BUMP_MAX, dense as it stands below) keep it:
+    IPXK_LU_SPARSE=t.  Tests of the default policy (elimination rounds for every bump of more than 1024 rows) carry the marker
+    `default_policy`."""
+    if "default_policy" in request.keywords:
+        monkeypatch.delenv("IPXK_LU_SPARSE", raising=False)
+    else:
+        monkeypatch.setenv("IPXK_LU_SPARSE", "t")
+
+
 @pytest.fixture(scope="module")
 def ctx(kkt):
     c = kkt.KktContext(synth.synthetic_lp(8, 12, 2, 1))     # the stand-alone entry point only needs a device
@@ -102,7 +113,7 @@ def test_lu_torn_bump_vs_oracle(kkt, oracle, monkeypatch):
         monkeypatch.setenv("IPXK_LU_SPARSE", "0")
         with pytest.raises(RuntimeError, match="spikes"):
             c.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
-        monkeypatch.delenv("IPXK_LU_SPARSE")
+        monkeypatch.setenv("IPXK_LU_SPARSE", "t")
         if dim <= 3000:
             Fs = c.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
             Fo = oracle.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1, bump_limit=low, sparse_min=min(512, low))
@@ -246,7 +257,7 @@ def test_lu_unsorted_strict_and_limits(ctx, oracle, kkt, monkeypatch):
     monkeypatch.setenv("IPXK_LU_SPARSE", "0")
     with pytest.raises(kkt.KktError, match="spikes"):
         ctx.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx)
-    monkeypatch.delenv("IPXK_LU_SPARSE")             # by default the elimination rounds take over where tearing refuses
+    monkeypatch.setenv("IPXK_LU_SPARSE", "t")             # by default the elimination rounds take over where tearing refuses
     Fs = ctx.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx)
     assert Fs["sparse_rounds"] > 0 and Fs["bump"] <= 2
     same_factors(Fs, oracle.lu_factorize(400, Bp[:-1], Bp[1:], Bi, Bx, bump_limit=2, sparse_min=2))
@@ -483,10 +494,132 @@ def test_lu_bump_beyond_the_dense_limit_that_tearing_cannot_cut_down(kkt, monkey
     colscale = synth.synthetic_basis_state(P["status"], 1.0, 5)
     ctx = kkt.KktContext(P["A"])
     F = ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
-    assert 8192 < F["spikes"] == F["bump"] <= bump and F["sparse_rounds"] == 0 and F["num_dependent"] == 0
+    assert 8192 < F["spikes"] == F["bump"] <= bump and F["sparse_rounds"] == 0 and F["num_dependent"] == 0       # (round 4's policy, see the fixture)
     ctx.split_prepare_lu(P["status"], colscale)
     probes, rejected, worst = ctx.split_inverse_stats()
     assert probes >= 1 and rejected == 0 and worst < 1e-8
+    G = P["G"]
+    B = sp.csc_matrix((G["Bx"].copy(), G["Bi"].copy(), G["Bp"].copy()), shape=(m, m))
+    rhs = np.random.default_rng(1).standard_normal(m)
+    for tr in ("N", "T"):
+        x = ctx.solve_dense(rhs, tr)
+        r = (B if tr == "N" else B.T) @ x - rhs
+        assert np.abs(r).max() <= 1e-9 * (1 + np.abs(x).max()), tr
+    ctx.close()
+
+
+# ---- the default policy since round 5: elimination rounds for every bump of more than 1024 rows ------------------------------------
+def ipm_basis_16000():
+    """tests/golden/ipm_basis_16000.npz: a basis B = AI[:, basis] the reference's IPM (IPM::Driver over KKTSolverBasisHip, Maxvolume on
+    the device) held in its 20th iteration on the 16000 x 40000 LP of tests/test_gpu_lp_dropin.general_lp(16000, 40000, 31); dumped on the
+    MI355X with IPXK_LU_DUMP (scripts/gpu_lu_study.py).  11 400 structural columns of 8 entries + 4 600 slack columns, 95 905 entries."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ipm_basis_16000.npz"))
+    return dict(dim=int(g["dim"]), Bp=g["Bp"].astype(np.int64), Bi=g["Bi"].astype(np.int64), Bx=g["Bx"])
+
+
+@pytest.mark.default_policy
+def test_lu_default_policy_vs_oracle(kkt, oracle, ref, monkeypatch):
+    """the default policy against its CPU restatement (orc_lu_factorize_policy), bit for bit: which bumps go through the rounds, where
+    the rounds end (density, slow rounds, sparse_min), the dense rest; the contract; the reference's stability estimate"""
+    monkeypatch.setenv("IPXK_LU_MFMA_MIN", "0")        # (a dense rest of more than 1024 rows: the elimination's own arithmetic, not the matrix cores')
+    c = kkt.KktContext(synth.synthetic_lp(8, 12, 2, 1))
+    cases = [("exchanged", synth.disturbed_basis_matrix(seed=5, dim=6000, num_exchanged=40, bump=100, offdiag=3), {}),
+             ("sparse bump 2300", synth.lp_like_basis_matrix(seed=3, dim=4000, bump=2300, bump_density=0.01), {}),
+             ("denser bump 1100", synth.lp_like_basis_matrix(seed=3, dim=3000, bump=1100, bump_density=0.05), {}),
+             ("small bump: dense as it stands", synth.lp_like_basis_matrix(seed=3, dim=5000, bump=600, offdiag=3), {}),
+             ("misplaced (singular)", synth.disturbed_basis_matrix(seed=7, dim=5000, num_exchanged=60, bump=64, offdiag=2), {})]
+    for name, G, pol in cases:
+        dim, nb = G["dim"], len(G["Bi"])
+        F = c.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
+        Fo = oracle.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1, policy=pol)
+        assert Fo is not None, name
+        assert (F["col_singletons"], F["row_singletons"], F["bump"], F["num_dependent"], F["sparse_pivots"], F["sparse_rounds"], F["rounds"]) == \
+            (Fo["info"]["col_singletons"], Fo["info"]["row_singletons"], Fo["info"]["bump"], Fo["info"]["dependent"],
+             Fo["info"]["sparse_pivots"], Fo["info"]["sparse_rounds"], Fo["info"]["rounds"]), name
+        assert F["spikes"] == 0, name
+        same_factors(F, Fo)
+        assert check_contract(G, F) < 1e-10, name
+        if ref is not None and F["num_dependent"] == 0:
+            R = ref.lu(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], F)
+            assert R.stability < 1e-12 and R.flag == 0, name
+        print("%-32s dim %5d nnz(B) %6d: %5d sparse pivots in %3d rounds, dense rest %4d, fill %.2f" %
+              (name, dim, nb, F["sparse_pivots"], F["sparse_rounds"], F["bump"], (F["lnz"] + F["unz"]) / nb))
+    c.close()
+
+
+@pytest.mark.default_policy
+def test_lu_fill_on_an_ipm_basis(kkt, ref, monkeypatch):
+    """a basis of the IPM on a random 16000 x 40000 LP (fixture): the default policy eliminates two thirds of the bump sparsely and
+    leaves a dense rest of about 5000 rows -- nnz(L) + nnz(U) within 1.25 x what the SEQUENTIAL minimum-Markowitz elimination of
+    the same pattern ends with (22.19 M entries = 231 x nnz(B), profiles/r05_lu_fill_study.txt; SuperLU / COLAMD on bases of this
+    kind: 600 x) and well below what tearing leaves (round 4's policy, checked here too: 49 M on this basis, 95 M on others of the same run); both
+    factorizations pass the reference's stability test and solve with the matrix to 1e-9"""
+    G = ipm_basis_16000()
+    dim, nb = G["dim"], len(G["Bi"])
+    B = sp.csc_matrix((G["Bx"], G["Bi"], G["Bp"]), shape=(dim, dim))
+    c = kkt.KktContext(synth.synthetic_lp(8, 12, 2, 1))
+    out = {}
+    for mode in (None, "t"):
+        if mode is None:
+            monkeypatch.delenv("IPXK_LU_SPARSE", raising=False)
+        else:
+            monkeypatch.setenv("IPXK_LU_SPARSE", mode)
+        F = c.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1, download=(mode is None))
+        out[mode] = F
+        print("policy %s: bump %d, %d sparse pivots in %d rounds, %d spikes, nnz(L)+nnz(U) %d = %.0f x nnz(B)" %
+              (mode or "default", F["bump"], F["sparse_pivots"], F["sparse_rounds"], F["spikes"], F["lnz"] + F["unz"], (F["lnz"] + F["unz"]) / nb))
+    F = out[None]
+    assert F["num_dependent"] == 0 and F["sparse_rounds"] > 0 and F["spikes"] == 0
+    assert F["lnz"] + F["unz"] <= 1.25 * 22186887
+    assert F["bump"] <= 5400
+    assert out["t"]["lnz"] + out["t"]["unz"] >= 1.5 * (F["lnz"] + F["unz"])
+    if ref is not None:
+        R = ref.lu(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], F)
+        assert R.stability < 1e-12 and R.flag == 0
+        x = np.random.default_rng(0).standard_normal(dim)
+        for trans in (False, True):
+            y = R.solve_dense(x, trans)
+            assert np.abs((B.T if trans else B) @ y - x).max() <= 1e-9 * (1 + np.abs(y).max())
+    c.close()
+
+
+@pytest.mark.default_policy
+def test_lu_bump_of_20000_rows_returns_factors(kkt, monkeypatch):
+    """a 26 000-row basis with a planted sparse bump of 20 000 rows -- beyond the 16 384 rows of the largest dense block: round 4
+    refused it (and LuKernelHip threw); the default policy eliminates it in rounds and the dense rest fits.  B x = r and B'x = r
+    through Prepare + solve_dense to 1e-9."""
+    m, n, bump = 26000, 60000, 20000
+    P = synth.lp_like_basis(m, n, seed=6, bump=bump, offdiag=3, bump_density=0.0004)
+    colscale = synth.synthetic_basis_state(P["status"], 1.0, 6)
+    ctx = kkt.KktContext(P["A"])
+    F = ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+    nb = len(P["G"]["Bi"])
+    print("bump %d -> %d sparse pivots in %d rounds, dense rest %d, fill %.1f" % (bump, F["sparse_pivots"], F["sparse_rounds"], F["bump"], (F["lnz"] + F["unz"]) / nb))
+    assert F["sparse_rounds"] > 0 and F["spikes"] == 0 and F["bump"] <= 32768 and F["num_dependent"] == 0
+    ctx.split_prepare_lu(P["status"], colscale)
+    G = P["G"]
+    B = sp.csc_matrix((G["Bx"].copy(), G["Bi"].copy(), G["Bp"].copy()), shape=(m, m))
+    rhs = np.random.default_rng(1).standard_normal(m)
+    for tr in ("N", "T"):
+        x = ctx.solve_dense(rhs, tr)
+        r = (B if tr == "N" else B.T) @ x - rhs
+        assert np.abs(r).max() <= 1e-9 * (1 + np.abs(x).max()), tr
+    ctx.close()
+
+
+def test_lu_dense_block_beyond_16384_rows(kkt, monkeypatch):
+    """a dense block of 16 385 ... 32 768 rows (32 rows per thread, sub-panels of one column): a sparse planted bump of 16 600 rows
+    sent to the dense code as it stands (round 4's policy with the limit raised); Prepare inverts the block on the matrix cores and
+    B x = r, B' x = r are solved to 1e-9"""
+    monkeypatch.setenv("IPXK_LU_BUMP_MAX", "20000")
+    m, n, bump = 18000, 40000, 16600
+    P = synth.lp_like_basis(m, n, seed=4, bump=bump, offdiag=3, bump_density=0.002)
+    colscale = synth.synthetic_basis_state(P["status"], 1.0, 4)
+    ctx = kkt.KktContext(P["A"])
+    F = ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+    assert 16384 < F["bump"] <= bump and F["sparse_rounds"] == 0 and F["spikes"] == 0 and F["num_dependent"] == 0
+    ctx.split_prepare_lu(P["status"], colscale)
     G = P["G"]
     B = sp.csc_matrix((G["Bx"].copy(), G["Bi"].copy(), G["Bp"].copy()), shape=(m, m))
     rhs = np.random.default_rng(1).standard_normal(m)

@@ -592,6 +592,40 @@ def test_edge_cases(kkt, po, oracle):
         kkt.KktContext(bad)
 
 
+def test_reset_solver_state(kkt):
+    """ipxk_reset_solver_state (what HipModel calls when it hands a cached context to the next solver object): nothing the
+    previous object prepared can be used any more, the model stays, and a new factorization gives the same answer as before"""
+    A, st = diag_problem(3000, 7000, seed=77)
+    B = basis_problem(600, 1300, seed=78)
+    ctx = kkt.KktContext(A)
+    assert ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"]) == 0
+    tol = 0.3 * np.sqrt(st["mu"])
+    x1, y1, it1, e1, _ = ctx.kkt_diag_solve(st["a"], st["b"], tol, 500)
+    ctx.reset_solver_state(0.0625)
+    with pytest.raises(kkt.KktError):
+        ctx.kkt_diag_solve(st["a"], st["b"], tol, 500)
+    with pytest.raises(kkt.KktError):
+        ctx.normal_apply(st["b"])
+    assert ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"]) == 0
+    x2, y2, it2, e2, _ = ctx.kkt_diag_solve(st["a"], st["b"], tol, 500)
+    assert (it1, e1) == (it2, e2) and np.array_equal(x1, x2) and np.array_equal(y1, y2)
+    ctx.close()
+    # basis path: operator and factors are gone after the reset; Prepare again reproduces the solve bit for bit
+    Bp, st2, cs = B
+    ctx = kkt.KktContext(Bp["A"])
+    ctx.split_prepare(Bp["L"], Bp["U"], Bp["rowperm"], Bp["colperm"], Bp["basis"], Bp["status"], cs)
+    xb, yb, itb, eb, _ = ctx.kkt_basis_solve(st2["a"], st2["b"], 1e-8)
+    ctx.reset_solver_state()
+    with pytest.raises(kkt.KktError):
+        ctx.kkt_basis_solve(st2["a"], st2["b"], 1e-8)
+    with pytest.raises(kkt.KktError):
+        ctx.split_apply(st2["b"])
+    ctx.split_prepare(Bp["L"], Bp["U"], Bp["rowperm"], Bp["colperm"], Bp["basis"], Bp["status"], cs)
+    xb2, yb2, itb2, eb2, _ = ctx.kkt_basis_solve(st2["a"], st2["b"], 1e-8)
+    assert (itb, eb) == (itb2, eb2) and np.array_equal(xb, xb2) and np.array_equal(yb, yb2)
+    ctx.close()
+
+
 # --------------------------------------------------------------------------------------
 # BASELINE sizes: size-independent properties (the oracle would take minutes here)
 # --------------------------------------------------------------------------------------

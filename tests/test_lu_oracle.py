@@ -176,3 +176,29 @@ def test_oracle_lu_elimination_rounds_find_the_rank(oracle):
         assert F["info"]["sparse_rounds"] > 0
         assert len(F["dependent"]) == dim - np.linalg.matrix_rank(B)
         assert check_contract(G, F) < 1e-10
+
+
+def test_oracle_lu_default_policy_under_the_reference(oracle, ref):
+    """the policy of round 5 (orc_lu_factorize_policy: elimination rounds for every bump of more than sparse_from rows, ended by the
+    density of what is left / slow rounds / sparse_min, the rest dense): the contract, the reference's stability estimate and
+    ForrestTomlin's solves -- with the defaults and with limits small enough that every end rule fires on these sizes"""
+    G = synth.lp_like_basis_matrix(seed=3, dim=3000, bump=1400, bump_density=0.01)
+    dim = G["dim"]
+    B = sp.csc_matrix((G["Bx"].copy(), G["Bi"].copy(), G["Bp"].copy()), shape=(dim, dim))
+    seen = set()
+    for pol in ({}, dict(sparse_from=64, sparse_min=16, dense_at=0.05), dict(sparse_from=64, sparse_min=16, dense_at=0.0, slow_den=8),
+                dict(sparse_from=64, sparse_min=1000, dense_at=0.0, slow_den=0), dict(sparse_from=64, sparse_min=16, fill_max=1, dense_at=0.6, slow_den=0, rest_limit=1200)):
+        F = oracle.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], policy=pol)
+        assert F is not None, pol
+        inf = F["info"]
+        assert inf["sparse_rounds"] > 0 and inf["spikes"] == 0 and inf["dependent"] == 0
+        assert inf["col_singletons"] + inf["row_singletons"] + inf["sparse_pivots"] + inf["bump"] == dim
+        seen.add(inf["bump"])
+        R = ref.lu(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], F)
+        assert R.stability < 1e-12 and R.flag == 0
+        x = np.random.default_rng(0).standard_normal(dim)
+        for trans in (False, True):
+            y = R.solve_dense(x, trans)
+            assert np.abs((B.T if trans else B) @ y - x).max() <= 1e-8 * (1 + np.abs(y).max())
+        assert check_contract(G, F) < 1e-10
+    assert len(seen) >= 4          # the end rules end the rounds at different points
