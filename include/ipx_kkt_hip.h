@@ -268,11 +268,19 @@ typedef struct {
                                was factorized as it stood); then bump == spikes */
   ipxint sparse_pivots, sparse_rounds; /* pivots and rounds of the sparse elimination of a bump
                                beyond the dense limit (0: none) */
+  ipxint reused;            /* 1: nothing was computed -- the context already held the factors of exactly
+                               this matrix (the basis ipxk_lu_factorize_basis / ipxk_maxvolume factorized
+                               last, columns in any order, same tolerances: Basis::Load after Maxvolume
+                               on the device, src/basis.cc:81-114) and hands them out again */
 } ipxk_lu_info;
 int ipxk_lu_factorize(ipxk_context* ctx, ipxint dim, const ipxint* Bbegin,
                       const ipxint* Bend, const ipxint* Bi, const double* Bx,
                       double pivottol, int strict_abs_pivottol,
                       ipxk_lu_info* info);
+/* Number of LU factorizations this context has COMPUTED so far (a reused one does not count): a caller that
+ * keeps track of which basis the resident factors belong to (KKTSolverBasisHip) sees with it whether
+ * another factorization went through the context in between. */
+ipxint ipxk_lu_generation(const ipxk_context* ctx);
 int ipxk_lu_get_factors(ipxk_context* ctx, ipxint* Lp, ipxint* Li, double* Lx,
                         ipxint* Up, ipxint* Ui, double* Ux, ipxint* rowperm,
                         ipxint* colperm, ipxint* dependent_cols);

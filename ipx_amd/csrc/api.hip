@@ -769,6 +769,8 @@ int ipxk_lu_factorize_basis(ipxk_context* c, const ipxint* basis, double pivotto
     });
 }
 
+ipxint ipxk_lu_generation(const ipxk_context* c) { return c ? (ipxint)lu_generation(c) : 0; }
+
 int ipxk_lu_get_factors(ipxk_context* c, ipxint* Lp, ipxint* Li, double* Lx, ipxint* Up, ipxint* Ui, double* Ux,
                         ipxint* rowperm, ipxint* colperm, ipxint* dependent_cols) {
     return guarded([&] {

@@ -266,6 +266,7 @@ void lu_get_factors(Context* c, ipxint* Lp, ipxint* Li, double* Lx, ipxint* Up, 
                     ipxint* rowperm, ipxint* colperm, ipxint* dependent);
 void split_prepare_lu(Context* c, const ipxint* status, const double* colscale);
 void destroy_lu(LuState*);
+long lu_generation(const Context* c);
 void lu_invalidate(Context* c);          // the factors of an earlier factorization are no longer handed out
 // ---- maxvolume.hip ----
 void maxvolume_dev(Context* c, const ipxint* status, const double* colscale, const ipxk_maxvolume_params* prm,

@@ -1396,6 +1396,15 @@ struct LuState {
     DevBuf<int> Ap, Ai;
     DevBuf<double> Ax;
     bool have_A = false;
+    // what the resident factorization was computed with, and its statistics: ipxk_lu_factorize hands the factors of EXACTLY the
+    // matrix it is given out again instead of computing them a second time (lu_reuse_resident)
+    double pivottol_used = 0.0;
+    bool strict_used = false;
+    ipxk_lu_info last_info{};
+    bool view = false;                  // ipxk_lu_get_factors returns colperm_view (the caller's column order) instead of colperm
+    DevBuf<ipxint> colperm_view;
+    DevBuf<int> reuse_cand, reuse_mark, reuse_sigma, reuse_flag;
+    long generation = 0;                // counts the factorizations actually computed in this context
 };
 
 void destroy_lu(LuState* S) { delete S; }
@@ -1616,6 +1625,7 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
     hipStream_t s = c->stream;
     int64_t nb = nb_in;
     S->valid = false;
+    S->view = false;
     S->dim = dim;
     ipxk_lu_info I{};
     const double abstol = strict ? 1e-3 : 1e-14;      // kLuDependencyTol (src/ipx_internal.h:26) / BASICLU's default
@@ -2165,6 +2175,10 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
     I.seconds_bump = t2 - t1;
     I.seconds_assemble = now_s() - t2;
     S->valid = true;
+    S->pivottol_used = pivottol;
+    S->strict_used = strict;
+    S->last_info = I;
+    S->generation++;
     if (info) *info = I;
     if (getenv("IPXK_VERBOSE"))
         fprintf(stderr, "ipxk: LU dim %d nnz %lld: %lld column + %lld row singletons in %d rounds (%.2f ms), bump %d (%.2f ms, %d dependent), "
@@ -2172,6 +2186,90 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
                 rounds, I.seconds_singletons * 1e3, kb, I.seconds_bump * 1e3, ndep, I.seconds_assemble * 1e3, (long long)lnz, (long long)unz,
                 (int)I.sparse_pivots, (int)I.sparse_rounds, (int)I.spikes);
 }
+
+namespace {
+// column j of the packed matrix against column cand[j] of [A I] as the context holds it: same length, same rows in the same
+// order, same values (bit patterns); every candidate at most once
+__global__ void lu_reuse_compare_kernel(int m, int n, const int* __restrict__ cand, const int* __restrict__ Bp, const int* __restrict__ Bi,
+                                        const double* __restrict__ Bx, const int* __restrict__ Ap, const int* __restrict__ Ai,
+                                        const double* __restrict__ Ax, int* __restrict__ mark, int* __restrict__ flag) {
+    IPXK_GRID_STRIDE(j, m) {
+        const int col = cand[j];
+        const int b = Bp[j], len = Bp[j + 1] - b;
+        bool same;
+        if (col >= n) {
+            same = len == 1 && Bi[b] == col - n && Bx[b] == 1.0;
+        } else {
+            const int a = Ap[col];
+            same = len == Ap[col + 1] - a;
+            for (int t = 0; same && t < len; t++)
+                same = Bi[b + t] == Ai[a + t] && __double_as_longlong(Bx[b + t]) == __double_as_longlong(Ax[a + t]);
+        }
+        if (atomicExch(&mark[col], (int)j + 1) != 0) same = false;
+        if (!same) *flag = 1;
+    }
+}
+// position k of the resident basis -> the caller's column that holds the same variable
+__global__ void lu_reuse_sigma_kernel(int m, const ipxint* __restrict__ basis, const int* __restrict__ mark, int* __restrict__ sigma, int* __restrict__ flag) {
+    IPXK_GRID_STRIDE(k, m) {
+        const int q = mark[basis[k]];
+        if (q == 0) *flag = 1;
+        sigma[k] = q - 1;
+    }
+}
+__global__ void lu_reuse_colperm_kernel(int m, const ipxint* __restrict__ colperm, const int* __restrict__ sigma, ipxint* __restrict__ out) {
+    IPXK_GRID_STRIDE(t, m) out[t] = sigma[colperm[t]];
+}
+}  // namespace
+
+// Basis::Load / Basis::Factorize (src/basis.cc:81-156) of the reference's Basis right after Maxvolume on the device ask for the
+// factorization of the basis whose factors this context ALREADY holds (ipxk_lu_factorize_basis at the end of ipxk_maxvolume), its
+// columns in another order.  If the matrix handed in is exactly that basis -- every column compared entry by entry on the device
+// with the column of [A I] its offsets name, the set of columns equal to the resident basis -- and the tolerances are the ones the
+// resident factors were computed with, nothing is computed: the factors stay, and ipxk_lu_get_factors returns the column
+// permutation in the caller's numbering.  IPXK_LU_REUSE=0 switches this off.
+static bool lu_reuse_resident(Context* c, LuState* S, int dim, const ipxint* Bbegin, const ipxint* Bend, const int* dBp, const int* dBi,
+                              const double* dBx, double pivottol, bool strict) {
+    static const bool off = getenv("IPXK_LU_REUSE") && getenv("IPXK_LU_REUSE")[0] == '0';
+    const int64_t m = c->m, n = c->n;
+    if (off || !S->valid || !S->from_basis || S->ndep != 0 || dim == 0 || dim != (int)m || S->dim != dim || !c->have_plain) return false;
+    if (pivottol != S->pivottol_used || strict != S->strict_used) return false;
+    if ((int64_t)c->h_Ap.size() != n + 1) return false;
+    const std::vector<ipxint>& Ap = c->h_Ap;
+    std::vector<int> cand((size_t)dim);
+    for (int j = 0; j < dim; j++) {
+        const ipxint b = Bbegin[j], e = Bend[j];
+        if (b >= Ap[(size_t)n]) {                        // a slack column of [A I]: one entry, stored behind the structural ones
+            const ipxint i = b - Ap[(size_t)n];
+            if (i >= m || e != b + 1) return false;
+            cand[(size_t)j] = (int)(n + i);
+        } else {
+            const int64_t col = (std::upper_bound(Ap.begin(), Ap.end(), b) - Ap.begin()) - 1;
+            if (col < 0 || col >= n || Ap[(size_t)col] != b || Ap[(size_t)col + 1] != e) return false;
+            cand[(size_t)j] = (int)col;
+        }
+    }
+    hipStream_t s = c->stream;
+    S->reuse_cand.upload(cand, s);
+    S->reuse_mark.ensure((size_t)(n + m)); S->reuse_sigma.ensure((size_t)dim); S->reuse_flag.ensure(1); S->colperm_view.ensure((size_t)dim);
+    IPXK_HIP(hipMemsetAsync(S->reuse_mark.get(), 0, (size_t)(n + m) * sizeof(int), s));
+    IPXK_HIP(hipMemsetAsync(S->reuse_flag.get(), 0, sizeof(int), s));
+    const int g = grid_for(dim);
+    hipLaunchKernelGGL(lu_reuse_compare_kernel, dim3(g), dim3(kBlock), 0, s, dim, (int)n, S->reuse_cand.get(), dBp, dBi, dBx, c->pl_Ap.get(),
+                       c->pl_Ai.get(), c->pl_Ax.get(), S->reuse_mark.get(), S->reuse_flag.get());
+    hipLaunchKernelGGL(lu_reuse_sigma_kernel, dim3(g), dim3(kBlock), 0, s, dim, S->basis.get(), S->reuse_mark.get(), S->reuse_sigma.get(),
+                       S->reuse_flag.get());
+    int flag = 0;
+    IPXK_HIP(hipMemcpyAsync(&flag, S->reuse_flag.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    if (flag) return false;
+    hipLaunchKernelGGL(lu_reuse_colperm_kernel, dim3(g), dim3(kBlock), 0, s, dim, S->colperm.get(), S->reuse_sigma.get(), S->colperm_view.get());
+    S->view = true;
+    if (getenv("IPXK_VERBOSE")) fprintf(stderr, "ipxk: LU dim %d: the resident factors of this basis handed out again\n", dim);
+    return true;
+}
+
+long lu_generation(const Context* c) { return c->lu ? c->lu->generation : 0; }
 
 void lu_invalidate(Context* c) { if (c->lu) c->lu->valid = false; }
 
@@ -2204,7 +2302,6 @@ void lu_factorize_host(Context* c, int64_t dim64, const ipxint* Bbegin, const ip
     const int dim = (int)dim64;
     hipStream_t s = c->stream;
     LuState* S = lu_state(c);
-    S->from_basis = false;
     // pack the columns (they are ranges of a larger array on the caller's side, src/basis.cc:122-128)
     std::vector<int> bp((size_t)dim + 1, 0), bi;
     std::vector<double> bx;
@@ -2229,6 +2326,15 @@ void lu_factorize_host(Context* c, int64_t dim64, const ipxint* Bbegin, const ip
     dBp.upload(bp, s); dBi.upload(bi, s); dBx.upload(bx, s);
     dBi.ensure(1); dBx.ensure(1);
     IPXK_HIP(hipStreamSynchronize(s));
+    if (lu_reuse_resident(c, S, dim, Bbegin, Bend, dBp.get(), dBi.get(), dBx.get(), pivottol, strict)) {
+        if (info) {
+            *info = S->last_info;
+            info->seconds_singletons = info->seconds_bump = info->seconds_assemble = 0.0;
+            info->reused = 1;
+        }
+        return;
+    }
+    S->from_basis = false;
     lu_factorize_device(c, S, dim, nb, dBp.get(), dBi.get(), dBx.get(), pivottol, strict, info);
 }
 
@@ -2288,7 +2394,7 @@ void lu_get_factors(Context* c, ipxint* Lp, ipxint* Li, double* Lx, ipxint* Up, 
     if (Ui) S->Ui.download(Ui, (size_t)S->unz, s);
     if (Ux) S->Ux.download(Ux, (size_t)S->unz, s);
     if (rowperm) S->rowperm.download(rowperm, dim, s);
-    if (colperm) S->colperm.download(colperm, dim, s);
+    if (colperm) (S->view ? S->colperm_view : S->colperm).download(colperm, dim, s);
     if (dependent) S->dependent.download(dependent, (size_t)S->ndep, s);
     IPXK_HIP(hipStreamSynchronize(s));
 }

@@ -55,6 +55,9 @@ public:
                     std::equal(e.colptr.begin(), e.colptr.end(), AI.colptr())) {
                     e.in_use = true;
                     e.last_use = ++R.tick;
+                    e.rowidx = AI.rowidx();
+                    e.values = AI.values();
+                    e.owner = std::this_thread::get_id();
                     ctx_ = e.ctx;
                     R.hits++;
                     break;
@@ -69,7 +72,8 @@ public:
         std::lock_guard<std::mutex> lock(R.mutex);
         R.creations++;
         ctx_ = ctx;
-        if (cache) R.entries.push_back(Entry{m, n, nz, device, {fp[0], fp[1]}, std::vector<Int>(AI.colptr(), AI.colptr() + n + 1), ctx, true, ++R.tick});
+        if (cache) R.entries.push_back(Entry{m, n, nz, device, {fp[0], fp[1]}, std::vector<Int>(AI.colptr(), AI.colptr() + n + 1), ctx, true, ++R.tick,
+                                            AI.rowidx(), AI.values(), std::this_thread::get_id()});
         else owned_ = true;
     }
     ~HipModel() {
@@ -94,6 +98,19 @@ public:
             }
         }
         for (ipxk_context* c : drop) ipxk_destroy(c);
+    }
+    // The context a live solver object of THIS thread holds for the model whose AI() arrays these are (nullptr: none).  For
+    // an LU kernel inside the reference's Basis (LuKernelHip): a Basis::Factorize / Basis::Load that runs while KKTSolverBasisHip
+    // is at work goes through the solver's own context, where ipxk_lu_factorize finds the factors of the basis Maxvolume has
+    // just factorized and hands them out instead of computing them again.  The pointers only SELECT the context; that the
+    // matrix handed to ipxk_lu_factorize is the resident one is established there, entry by entry.
+    static ipxk_context* InUse(const Int* rowidx, const double* values) {
+        Registry& R = registry();
+        std::lock_guard<std::mutex> lock(R.mutex);
+        for (const Entry& e : R.entries)
+            if (e.in_use && e.rowidx == rowidx && e.values == values && e.owner == std::this_thread::get_id())
+                return e.ctx;
+        return nullptr;
     }
     HipModel(const HipModel&) = delete;
     HipModel& operator=(const HipModel&) = delete;
@@ -167,6 +184,9 @@ private:
         ipxk_context* ctx;
         bool in_use;
         long last_use;
+        const Int* rowidx;          // Model::AI() arrays of the object that holds the context (valid while in_use)
+        const double* values;
+        std::thread::id owner;
     };
     struct Registry {
         std::mutex mutex;

@@ -93,7 +93,9 @@ bool KKTSolverBasisHip::MaxvolumeOnDevice(Info* info) {
     ipxk_context* ctx = device_.get();
     std::vector<Int> status(n+m), basic(m);
     std::vector<double> colscale(n+m);
-    bool same_basis = device_lu_valid_ && (Int)device_member_.size() == n+m;
+    // (the LU kernel of the reference's Basis may go through this context too -- LuKernelHip::SharedWithSolver: a refactorization
+    // by DropPrimal / DropDual's ExchangeIfStable replaces the resident factors, and the generation counter tells)
+    bool same_basis = device_lu_valid_ && (Int)device_member_.size() == n+m && ipxk_lu_generation(ctx) == device_lu_generation_;
     for (Int j = 0; j < n+m; j++) {
         colscale[j] = reference_.colscale_[j];
         status[j] = basis_.StatusOf(j);
@@ -157,6 +159,7 @@ bool KKTSolverBasisHip::MaxvolumeOnDevice(Info* info) {
     for (Int p = 0; p < m; p++)
         device_member_[basis_out[p]] = 1;
     device_lu_valid_ = true;
+    device_lu_generation_ = ipxk_lu_generation(ctx);
     prepared_once_ = false;                   // (the factors of an earlier GetLuFactors hand-off are gone)
     Timer timer_load;
     struct AddOnExit { Timer& t; ~AddOnExit() { g_phase_seconds[3] += t.Elapsed(); } } add_on_exit{timer_load};

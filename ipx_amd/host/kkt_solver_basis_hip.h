@@ -64,6 +64,7 @@ private:
     Int factorizations_at_handoff_{-1};   // Basis::factorizations() when those factors were handed over
     std::vector<signed char> device_member_;   // per variable: 1 if in the basis whose factors the device LU holds
     bool device_lu_valid_{false};
+    Int device_lu_generation_{-1};              // ipxk_lu_generation() when those factors were computed: any other factorization through the context since then invalidates them
     Int maxiter_{-1};
     Int iter_{0};
     Int device_maxvolume_calls_{0}, cpu_maxvolume_calls_{0};

@@ -13,6 +13,7 @@
 
 #include <memory>
 
+#include "hip_device.h"
 #include "ipx_kkt_hip.h"
 #include "lu_factorization.h"
 
@@ -26,6 +27,16 @@ public:
     //            Factorize() throw std::runtime_error.
     explicit LuKernelHip(ipxk_context* ctx, std::unique_ptr<LuFactorization> fallback = nullptr)
         : ctx_(ctx), fallback_(std::move(fallback)) {}
+    // As above, but every Factorize() first asks HipModel for the context a live KKT solver object of this thread holds for the
+    // model whose AI() arrays it is handed (hip_device.h) and uses @ctx only when there is none: the factorization that
+    // Basis::Load / Basis::Factorize request right after Maxvolume on the device is then not computed a second time
+    // (ipxk_lu_info.reused; src/basis.cc:81-114, src/kkt_solver_basis.cc:57-61).
+    struct SharedWithSolver {};
+    LuKernelHip(SharedWithSolver, ipxk_context* ctx, std::unique_ptr<LuFactorization> fallback = nullptr)
+        : ctx_(ctx), fallback_(std::move(fallback)), share_(true) {}
+
+    // # factorizations served from the resident factors of the same basis so far
+    Int reused() const { return reused_; }
 
     // # factorizations handed to the fallback kernel so far
     Int fallbacks() const { return fallbacks_; }
@@ -41,7 +52,8 @@ private:
 
     ipxk_context* ctx_;
     std::unique_ptr<LuFactorization> fallback_;
-    Int fallbacks_{0};
+    bool share_{false};
+    Int fallbacks_{0}, reused_{0};
     ipxk_lu_info info_{};
 };
 

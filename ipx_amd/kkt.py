@@ -33,7 +33,7 @@ EXPORTS = [
     "ipxk_kkt_basis_solve", "ipxk_newton_solve", "ipxk_iterate_set", "ipxk_iterate_get", "ipxk_iterate_update",
     "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_ipm_step", "ipxk_iterate_objectives", "ipxk_ipm_driver", "ipxk_iterate_factorize_diag", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns", "ipxk_comm_info", "ipxk_maxvolume_sequential",
     "ipxk_time_normal_apply", "ipxk_equilibrate", "ipxk_transpose", "ipxk_lu_factorize", "ipxk_lu_factorize_basis",
-    "ipxk_lu_get_factors", "ipxk_split_prepare_lu", "ipxk_maxvolume", "ipxk_ipm_driver_basis",
+    "ipxk_lu_get_factors", "ipxk_lu_generation", "ipxk_split_prepare_lu", "ipxk_maxvolume", "ipxk_ipm_driver_basis",
     "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_layout_info", "ipxk_layout_array", "ipxk_split_inverse_stats", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
     "ipxk_dev_download",
 ]
@@ -55,7 +55,7 @@ class LuInfo(C.Structure):
     _fields_ = [("lnz", c_i64), ("unz", c_i64), ("num_dependent", c_i64), ("col_singletons", c_i64),
                 ("row_singletons", c_i64), ("bump", c_i64), ("rounds", c_i64), ("seconds_singletons", c_f64),
                 ("seconds_bump", c_f64), ("seconds_assemble", c_f64), ("spikes", c_i64), ("sparse_pivots", c_i64),
-                ("sparse_rounds", c_i64)]
+                ("sparse_rounds", c_i64), ("reused", c_i64)]
 
 
 class MaxvolumeParams(C.Structure):
@@ -106,6 +106,7 @@ def load_library():
         L = C.CDLL(LIB_PATH)
         L.ipxk_last_error.restype = C.c_char_p
         L.ipxk_num_dense_cols.restype = c_i64
+        L.ipxk_lu_generation.restype = c_i64
         L.ipxk_normal_apply_bytes.restype = c_i64
         _lib = L
     return _lib
@@ -567,6 +568,10 @@ class KktContext:
         self._check(self.lib.ipxk_lu_factorize_basis(self.h, _ip(basis), c_f64(pivottol), C.c_int(1 if strict else 0),
                                                      C.byref(info)))
         return self._lu_result(self.m, info, download)
+
+    def lu_generation(self):
+        """number of LU factorizations this context has computed (a reused one does not count)"""
+        return int(self.lib.ipxk_lu_generation(self.h))
 
     def split_prepare_lu(self, status, colscale):
         status, colscale = _I(status), _F(colscale)

@@ -42,6 +42,7 @@ ipxk_context* LuContext() {
 }
 
 long g_factorizations = 0;
+long g_reused = 0;
 long g_max_bump = 0;
 double g_seconds = 0.0;
 
@@ -49,6 +50,7 @@ double g_seconds = 0.0;
 
 // counters for the test programs (tests/dropin/lp_main.cc)
 extern "C" long dropin_lu_factorizations() { return g_factorizations; }
+extern "C" long dropin_lu_reused() { return g_reused; }
 extern "C" long dropin_lu_max_bump() { return g_max_bump; }
 extern "C" double dropin_lu_seconds() { return g_seconds; }
 
@@ -58,9 +60,13 @@ void BasicLuKernel::_Factorize(Int dim, const Int* Bbegin, const Int* Bend, cons
                                double pivottol, bool strict_abs_pivottol, SparseMatrix* L, SparseMatrix* U,
                                std::vector<Int>* rowperm, std::vector<Int>* colperm,
                                std::vector<Int>* dependent_cols) {
-    LuKernelHip lu(LuContext());        // no fallback: a basis the device LU declines ends the run loudly
+    // no fallback: a basis the device LU declines ends the run loudly.  A factorization requested while a KKT solver object is at
+    // work goes through that object's context (LuKernelHip::SharedWithSolver), where the resident factors of the same basis are
+    // handed out again.
+    LuKernelHip lu(LuKernelHip::SharedWithSolver{}, LuContext());
     lu.Factorize(dim, Bbegin, Bend, Bi, Bx, pivottol, strict_abs_pivottol, L, U, rowperm, colperm, dependent_cols);
     g_factorizations++;
+    g_reused += lu.reused();
     if (lu.info().bump > g_max_bump) g_max_bump = lu.info().bump;
     g_seconds += lu.info().seconds_singletons + lu.info().seconds_bump + lu.info().seconds_assemble;
 }

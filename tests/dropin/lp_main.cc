@@ -24,6 +24,7 @@
 #include "lp_solver.h"
 
 extern "C" long dropin_lu_factorizations();
+extern "C" long dropin_lu_reused();
 extern "C" long dropin_lu_max_bump();
 extern "C" double dropin_lu_seconds();
 #ifdef IPX_LP_HIP
@@ -114,6 +115,7 @@ int main(int argc, char** argv) {
     PUT(mean_fill); PUT(max_fill); PUT(volume_increase);
 #undef PUT
     f << "lu_factorizations " << dropin_lu_factorizations() << '\n';
+    f << "lu_reused " << dropin_lu_reused() << '\n';
     f << "lu_max_bump " << dropin_lu_max_bump() << '\n';
     f << "lu_device_seconds " << dropin_lu_seconds() << '\n';
 #ifdef IPX_LP_HIP

@@ -628,3 +628,46 @@ def test_lu_dense_block_beyond_16384_rows(kkt, monkeypatch):
         r = (B if tr == "N" else B.T) @ x - rhs
         assert np.abs(r).max() <= 1e-9 * (1 + np.abs(x).max()), tr
     ctx.close()
+
+
+def test_lu_factorize_hands_out_the_resident_factors_of_the_same_basis(kkt):
+    """Basis::Load after Maxvolume on the device (src/basis.cc:81-114) asks for the factorization of the basis whose factors the
+    context already holds, columns in ascending order of the variable: ipxk_lu_factorize recognises it -- entry by entry, on the
+    device -- computes nothing (info.reused, ipxk_lu_generation) and returns the same L, U, rowperm with the column permutation in
+    the caller's numbering; the contract holds for the caller's matrix.  One changed value, another tolerance, another set of
+    columns: a real factorization."""
+    m, n = 3000, 7000
+    P = synth.lp_like_basis(m, n, seed=5, bump=300, offdiag=3)
+    A = P["A"]
+    AI = A.with_identity()
+    ctx = kkt.KktContext(A)
+    F1 = ctx.lu_factorize_basis(P["basis"], 0.1)
+    gen = ctx.lu_generation()
+    order = np.sort(P["basis"])                                  # Basis::Load numbers the basic variables in ascending order
+    begin, end = AI.p[order].copy(), AI.p[order + 1].copy()
+    F2 = ctx.lu_factorize(m, begin, end, AI.i, AI.x, 0.1)
+    assert F2["reused"] == 1 and ctx.lu_generation() == gen
+    for key in ("L", "U"):
+        assert np.array_equal(F1[key].p, F2[key].p) and np.array_equal(F1[key].i, F2[key].i) and np.array_equal(F1[key].x, F2[key].x)
+    assert np.array_equal(F1["rowperm"], F2["rowperm"])
+    assert np.array_equal(P["basis"][F1["colperm"]], order[F2["colperm"]])       # the same variables in the same pivot order
+    Bp = np.concatenate([[0], np.cumsum(end - begin)])
+    Bi = np.concatenate([AI.i[b:e] for b, e in zip(begin, end)])
+    Bx = np.concatenate([AI.x[b:e] for b, e in zip(begin, end)])
+    assert check_contract(dict(dim=m, Bp=Bp, Bi=Bi, Bx=Bx), F2) < 1e-10
+    # the operator is still built from the resident factors
+    ctx.split_prepare_lu(P["status"], synth.synthetic_basis_state(P["status"], 1.0, 5))
+    # not the same matrix / not the same tolerance: computed
+    x2 = AI.x.copy()
+    x2[begin[m // 2]] *= 1.0000001
+    assert ctx.lu_factorize(m, begin, end, AI.i, x2, 0.1, download=False)["reused"] == 0 and ctx.lu_generation() == gen + 1
+    ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+    assert ctx.lu_factorize(m, begin, end, AI.i, AI.x, 0.3, download=False)["reused"] == 0
+    ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+    other = order.copy()
+    nonbasic = np.setdiff1d(np.arange(n + m), order)
+    other[5] = nonbasic[0]
+    other.sort()
+    r = ctx.lu_factorize(m, AI.p[other].copy(), AI.p[other + 1].copy(), AI.i, AI.x, 0.1, download=False)
+    assert r["reused"] == 0
+    ctx.close()
