@@ -712,6 +712,185 @@ __global__ __launch_bounds__(kPanelThreads) void lu_panel_multi_kernel(Dense A, 
     if (tid == 0) { A.bstep[0] = step; A.bstep[1] = np; A.bstep[3] = base; }
 }
 
+// COOPERATIVE OUTER PANEL (round 5).  The two-level scheme above spends a one-workgroup launch (24 us) per sub-panel of 2 ... 16 columns
+// plus a launch (15 us) that carries the sub-panel's update to the rest of the outer panel: 316 us per 32 columns at 8000 rows, 620 us
+// beyond 8192 rows -- 70 of the 80 ms of a 7350-row block, and the largest item of a whole LP solve
+// (profiles/r05_lp_dropin_24000_kernel_summary_before_eta_rework.txt).  Here the WHOLE outer panel of kPanel columns is factorized by ONE launch
+// of G <= 64 workgroups of 256 threads that share the rows (R = 1 / 2 rows of the panel per thread in registers: up to 8192 / 32 768 rows).  Per column ONE exchange: every workgroup publishes its best candidate (|entry|, row) TOGETHER with that row's 32
+// panel entries (write-through stores, drained, then one agent-scope add to a counter); everyone polls the counter, reads the G
+// messages past L1, takes the same winner (largest |entry|, ties: smaller row -- a total order, so the choice does not depend on G)
+// and has the pivot row with it.  No second exchange, no sub-panels, no side buffer.  Every entry still receives its updates one pivot at
+// a time in pivot order, products rounded before they are subtracted: the factors equal the other kernels' bit for bit.
+// All G workgroups must be resident at once: G <= 64 (two per compute unit fit) on 256 compute units, nothing else on the stream (the
+// look-ahead's late update runs under a CU mask that leaves 32 units free); a poll that does not see its target within kCoopSpinLimit polls raises an abort flag
+// that ends every workgroup, and the factorization fails loudly instead of hanging.
+constexpr int kCoopThreads = 256;
+constexpr int kCoopMaxG = 64;
+constexpr int kCoopSlot = kPanel + 2;                 // a message: |entry|, row, the row's kPanel entries
+constexpr int kCoopSpinLimit = 1 << 22;
+struct CoopShared {
+    double red_v[kCoopThreads / 64];
+    int red_r[kCoopThreads / 64];
+    double row[kPanel];
+    double slots[kCoopMaxG * kCoopSlot];
+    int abort;
+};
+struct Coop {
+    double* slots;          // [2][G][kCoopSlot]
+    unsigned* bar;          // arrivals so far (monotonic over the launches of a factorization)
+    unsigned base;          // arrivals before this launch
+    int* abort_flag;
+};
+template <int R, int T>
+__device__ __forceinline__ void coop_steps(const Dense& A, CoopShared& sh, const Coop& C, double (&v)[R][kPanel], int c0, int c1, unsigned& active,
+                                           int& np, int& step, unsigned& arrived, bool& dead) {
+    if constexpr (T < kPanel) {
+        if (c0 + T >= c1 || dead) return;              // uniform over the grid
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = gridDim.x;
+        const int row0 = blockIdx.x * R * kCoopThreads;
+        double best = 0.0;
+        int br = INT_MAX;
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const double a = ((active >> q) & 1u) ? fabs(v[q][T]) : 0.0;
+            if (a > best) { best = a; br = row0 + q * kCoopThreads + tid; }       // rows ascend with q: the first maximum stays
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double ov = __shfl_xor(best, d, 64);
+            const int orr = __shfl_xor(br, d, 64);
+            if (ov > best || (ov == best && orr < br)) { best = ov; br = orr; }
+        }
+        if (lane == 0) { sh.red_v[wave] = best; sh.red_r[wave] = br; }
+        __syncthreads();
+        double bv = 0.0;
+        int rr = INT_MAX;
+#pragma unroll
+        for (int w = 0; w < kCoopThreads / 64; w++) {
+            const double ov = sh.red_v[w];
+            const int orr = sh.red_r[w];
+            if (ov > bv || (ov == bv && orr < rr)) { bv = ov; rr = orr; }
+        }
+        if (!(bv > 0.0)) { bv = 0.0; rr = INT_MAX; }       // (no candidate, or not a number: never a pivot)
+        if (rr != INT_MAX && (rr - row0) % kCoopThreads == tid) {
+            const int qo = (rr - row0) / kCoopThreads;
+#pragma unroll
+            for (int q = 0; q < R; q++)
+                if (q == qo) {
+#pragma unroll
+                    for (int t2 = 0; t2 < kPanel; t2++) sh.row[t2] = v[q][t2];
+                }
+        }
+        __syncthreads();
+        // ---- the exchange
+        constexpr int par = T & 1;
+        double* mine = C.slots + ((size_t)par * G + blockIdx.x) * kCoopSlot;
+        if (wave == 0) {
+            if (lane < kCoopSlot) {
+                const double x = lane == 0 ? bv : lane == 1 ? __longlong_as_double((long long)rr) : sh.row[lane - 2];
+                __hip_atomic_store(mine + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // write-through
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                arrived += (unsigned)G;
+                const unsigned target = C.base + arrived;
+                __hip_atomic_fetch_add(C.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int spins = 0, gone = 0;
+                while ((int)(__hip_atomic_load(C.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kCoopSpinLimit || ((spins & 1023) == 0 && __hip_atomic_load(C.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        __hip_atomic_store(C.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gone = 1;
+                        break;
+                    }
+                }
+                sh.abort = gone;
+            }
+        }
+        __syncthreads();
+        if (sh.abort) { dead = true; return; }
+        const double* all = C.slots + (size_t)par * G * kCoopSlot;
+        for (int e = tid; e < G * kCoopSlot; e += kCoopThreads) sh.slots[e] = __hip_atomic_load(all + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        // ---- the same winner everywhere
+        double wv = lane < G ? sh.slots[lane * kCoopSlot] : 0.0;
+        int wr = lane < G ? (int)__double_as_longlong(sh.slots[lane * kCoopSlot + 1]) : INT_MAX;
+        int wg = lane;
+        if (!(wv > 0.0)) { wv = 0.0; wr = INT_MAX; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double ov = __shfl_xor(wv, d, 64);
+            const int orr = __shfl_xor(wr, d, 64);
+            const int og = __shfl_xor(wg, d, 64);
+            if (ov > wv || (ov == wv && orr < wr)) { wv = ov; wr = orr; wg = og; }
+        }
+        static_assert(kCoopMaxG <= 64, "the winner is combined over the 64 lanes of a wavefront");
+        wv = __shfl(wv, 0, 64); wr = __shfl(wr, 0, 64); wg = __shfl(wg, 0, 64);
+        const bool dependent = wr == INT_MAX || !(wv >= A.abstol) || wv == 0.0;
+        const int pr = dependent ? -1 : wr;
+        if (blockIdx.x == 0 && tid == 0) {
+            if (dependent) A.bcstep[c0 + T] = -1;
+            else {
+                A.brstep[pr] = step;
+                A.bcstep[c0 + T] = step;
+                A.prow[np] = pr;
+                A.pcol[np] = c0 + T;
+            }
+        }
+        if (pr >= 0) {
+            const double* su = sh.slots + wg * kCoopSlot + 2;
+            if (pr >= row0 && pr < row0 + R * kCoopThreads && (pr - row0) % kCoopThreads == tid) active &= ~(1u << ((pr - row0) / kCoopThreads));
+            np++; step++;
+            const double piv = su[T];
+#pragma unroll
+            for (int q = 0; q < R; q++)
+                if ((active >> q) & 1u) {
+                    const double l = v[q][T] / piv;
+                    v[q][T] = l;
+#pragma unroll
+                    for (int t2 = T + 1; t2 < kPanel; t2++) {
+                        const double u = su[t2];
+                        if (c0 + t2 < c1 && u != 0.0) v[q][t2] -= l * u;
+                    }
+                }
+        }
+        // (sh.slots / sh.row / red_* are rewritten only after the next step's first barrier, which every thread reaches after this read)
+        coop_steps<R, T + 1>(A, sh, C, v, c0, c1, active, np, step, arrived, dead);
+    }
+}
+template <int R>
+__global__ __launch_bounds__(kCoopThreads) __attribute__((amdgpu_waves_per_eu(1, 2))) void lu_panel_coop_kernel(Dense A, Coop C, int c0, int c1, const int* __restrict__ step_src) {
+    __shared__ CoopShared sh;
+    const int kb = A.kb, tid = threadIdx.x;
+    const int row0 = blockIdx.x * R * kCoopThreads;
+    unsigned active = 0, have = 0;
+    double v[R][kPanel];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+        const int r = row0 + q * kCoopThreads + tid;
+        if (r < kb) { have |= 1u << q; if (A.brstep[r] < 0) active |= 1u << q; }
+#pragma unroll
+        for (int t = 0; t < kPanel; t++) v[q][t] = (r < kb && c0 + t < c1) ? A.D[(size_t)(c0 + t) * kb + r] : 0.0;
+    }
+    if (tid == 0) sh.abort = 0;
+    __syncthreads();
+    int np = 0;
+    int step = step_src ? step_src[0] : A.bstep[0];       // (look-ahead: the count so far is in the other set)
+    unsigned arrived = 0;
+    bool dead = false;
+    coop_steps<R, 0>(A, sh, C, v, c0, c1, active, np, step, arrived, dead);
+    if (dead) return;                                      // nothing was written: the host finds the abort flag
+#pragma unroll
+    for (int q = 0; q < R; q++)
+        if ((have >> q) & 1u) {
+            const int r = row0 + q * kCoopThreads + tid;
+#pragma unroll
+            for (int t = 0; t < kPanel; t++)
+                if (c0 + t < c1) A.D[(size_t)(c0 + t) * kb + r] = v[q][t];
+        }
+    if (blockIdx.x == 0 && tid == 0) { A.bstep[0] = step; A.bstep[1] = np; A.bstep[3] = 0; }
+}
+
 // The panel's rows of U in the trailing columns: row prow[t] of column c2 receives the updates of the panel's
 // earlier pivots, in pivot order.  One thread per trailing column.
 // mode 0: the pivots of the last panel call, prow[0 .. bstep[1]) (one-level panels); 1: those of the last SUB-panel,
@@ -1350,6 +1529,8 @@ struct LuWork {
     DevBuf<int> rloc, cloc, brow, bcol, brstep, bcstep, bstep, prow, pcol;
     DevBuf<double> ubuf;               // [kPanel][kb] the outer panel's rows of U, contiguous (MFMA trailing update)
     DevBuf<double> usub;               // [sub-panel pivot][kPanel] a sub-panel's rows of U in the rest of the outer panel
+    DevBuf<double> coop_slots;         // cooperative outer panel: the workgroups' messages, [2][kCoopMaxG][kCoopSlot]
+    DevBuf<unsigned> coop_bar;         // [0] arrivals, [1] abort flag
     DevBuf<u64> cand_bits, claim_abs, skey, skey2, lkey, lkey2, ukey, ukey2;
     DevBuf<double> pivot, D, lval, lval2, uval, uval2;
     DevBuf<unsigned char> ckind;
@@ -2029,15 +2210,37 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
                 for (hipEvent_t* e : {&W_.ev_rows[0], &W_.ev_rows[1], &W_.ev_trail[0], &W_.ev_trail[1]})
                     IPXK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
             }
+            // the outer panel by ONE launch of <= 32 cooperating workgroups (IPXK_LU_COOP=0: the sub-panel launches below)
+            const bool coop = !(getenv("IPXK_LU_COOP") && getenv("IPXK_LU_COOP")[0] == '0') && !getenv("IPXK_LU_PANEL_W");
+            // 1 row per thread up to 8192 rows (G <= 32), 2 beyond (G <= 64).  Measured at 8000 rows: 1 and 2 rows per thread 68.9 ms
+            // both (the exchange, not the width of the barrier, is what a column costs: ~5 us); 4 rows per thread spill to scratch
+            // (146 ms) and are not used
+            int coopR = kb <= 8 * kPanelThreads ? 1 : 2;
+            if (const char* e = getenv("IPXK_LU_COOP_R")) {                   // (measurement)
+                const int r = atoi(e);
+                if ((r == 1 || r == 2) && r >= coopR) coopR = r;
+            }
+            const int coopG = (kb + coopR * kCoopThreads - 1) / (coopR * kCoopThreads);
+            unsigned coop_base = 0;
+            if (coop) {
+                W_.coop_slots.ensure((size_t)2 * kCoopMaxG * kCoopSlot); W_.coop_bar.ensure(2);
+                IPXK_HIP(hipMemsetAsync(W_.coop_bar.get(), 0, 2 * sizeof(unsigned), s));
+            }
             int k = 0, last_late = -1;                  // outer panel index; the last outer panel with a late update in flight
             for (int c0 = 0; c0 < kb; c0 += kPanel, k++) {
                 const int c1o = std::min(kb, c0 + kPanel);
                 const Dense& P = lookahead ? Ap[k & 1] : A;
                 const int* step_src = (lookahead && k > 0) ? Ap[(k - 1) & 1].bstep : nullptr;
+                if (coop) {
+                    const Coop C{W_.coop_slots.get(), W_.coop_bar.get(), coop_base, reinterpret_cast<int*>(W_.coop_bar.get() + 1)};
+                    if (coopR == 1) hipLaunchKernelGGL((lu_panel_coop_kernel<1>), dim3(coopG), dim3(kCoopThreads), 0, s, P, C, c0, c1o, step_src);
+                    else hipLaunchKernelGGL((lu_panel_coop_kernel<2>), dim3(coopG), dim3(kCoopThreads), 0, s, P, C, c0, c1o, step_src);
+                    coop_base += (unsigned)((c1o - c0) * coopG);
+                }
                 // (measured and dropped: the whole outer panel in ONE launch, the sub-panels' updates of the rest of the outer
                 // panel by that one workgroup too -- bit-identical, but one CU moves those kb x 28 columns at 50-100 GB/s:
                 // 228 ms at 8000 rows against 130 with the three launches per sub-panel below)
-                for (int ci = c0; ci < c1o; ci += W) {
+                for (int ci = c0; ci < c1o && !coop; ci += W) {
                     const int ce = std::min(c1o, ci + W), first = ci == c0 ? 1 : 0;
                     const double* us = fused_sub ? W_.usub.get() : nullptr;
                     if (W == kNarrowWide) hipLaunchKernelGGL((lu_panel_multi_kernel<2, kNarrowWide>), dim3(1), dim3(kPanelThreads), 0, s, P, ci, ce, first, us, c1o, step_src);
@@ -2084,7 +2287,10 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
                 IPXK_HIP(hipMemcpyAsync(bstep.get(), bstep.get() + 4, 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
         }
         IPXK_HIP(hipMemcpyAsync(h, bstep.get(), 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        h[2] = 0;
+        if (S->work.coop_bar.size() >= 2) IPXK_HIP(hipMemcpyAsync(h + 2, S->work.coop_bar.get() + 1, sizeof(int), hipMemcpyDeviceToHost, s));
         IPXK_HIP(hipStreamSynchronize(s));
+        if (h[2]) throw Error(IPXK_E_HIP, "LU: the cooperative panel kernel gave up waiting for its workgroups (IPXK_LU_COOP=0 selects the one-workgroup panels)");
         bpiv = h[0];
     }
     const int ndep = kb - bpiv;

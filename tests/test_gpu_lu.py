@@ -455,21 +455,28 @@ def test_dense_block_inverse_is_refined_before_it_is_rejected(kkt, monkeypatch):
 
 
 def test_dense_lu_launch_variants_give_identical_factors(kkt, monkeypatch):
-    """the dense LU's launch structure does not change a bit of the factors: the sub-panel's rows of U and its update of the
-    rest of the outer panel in one launch (default) or two (IPXK_LU_FUSED_SUB=0), and the look-ahead (the late trailing update
-    on a second, CU-masked stream; default from 6144 rows on, forced here for the smaller bumps too) against the in-order form
-    -- bumps of 1500 / 2600 / 6500 rows, i.e. 2 / 4 / 8 rows per thread in the panel kernels (and 16, forced, on the two smaller
+    """the dense LU's launch structure does not change a bit of the factors: the outer panel by ONE launch of cooperating workgroups
+    (default since round 5; 1 / 2 rows per thread) against the one-workgroup sub-panel launches (IPXK_LU_COOP=0) with the sub-panel's rows
+    of U and its update of the rest of the outer panel in one launch or two (IPXK_LU_FUSED_SUB), each with and without the look-ahead
+    (the late trailing update on a second, CU-masked stream; default from 6144 rows on, forced here for the smaller bumps too) -- bumps
+    of 1500 / 2600 / 6500 / 9000 rows, i.e. 2 / 4 / 8 / 16 rows per thread in the sub-panel kernels (and 16, forced, on the two smaller
     ones), trailing update on the matrix cores"""
     c = kkt.KktContext(synth.synthetic_lp(8, 12, 2, 1))
-    for dim, bump, dens in ((4000, 1500, 0.05), (6000, 2600, 0.02), (12000, 6500, 0.01)):
+    monkeypatch.setenv("IPXK_LU_BUMP_MAX", "20000")          # (the 9000-row bump dense as it stands)
+    for dim, bump, dens in ((4000, 1500, 0.05), (6000, 2600, 0.02), (12000, 6500, 0.01), (12000, 9000, 0.004)):
         G = synth.lp_like_basis_matrix(dim=dim, bump=bump, bump_density=dens, seed=7)
         ref = None
-        for fused, look in ((("1", "1"), ("0", "0"), ("1", "0"), ("0", "1"), ("w2", "1")) if bump < 5000 else (("1", "1"), ("0", "0"))):
-            if fused == "w2":                 # sub-panels of 2 columns, 16 rows per thread: the panels of bumps beyond 8192 rows
+        variants = (("c", "1"), ("c", "0"), ("1", "1"), ("0", "0"), ("1", "0"), ("0", "1"), ("w2", "1")) if bump < 5000 else (("c", "1"), ("c", "0"), ("1", "1"), ("0", "0"))
+        for fused, look in variants:
+            monkeypatch.delenv("IPXK_LU_PANEL_W", raising=False)
+            monkeypatch.delenv("IPXK_LU_COOP", raising=False)
+            if fused == "c":                  # the cooperative outer panel
+                fused = "1"
+            elif fused == "w2":               # sub-panels of 2 columns, 16 rows per thread: the panels of bumps beyond 8192 rows
                 monkeypatch.setenv("IPXK_LU_PANEL_W", "2")
                 fused = "1"
             else:
-                monkeypatch.delenv("IPXK_LU_PANEL_W", raising=False)
+                monkeypatch.setenv("IPXK_LU_COOP", "0")
             monkeypatch.setenv("IPXK_LU_FUSED_SUB", fused)
             monkeypatch.setenv("IPXK_LU_LOOKAHEAD", look)
             F = c.lu_factorize(dim, G["Bp"][:-1], G["Bp"][1:], G["Bi"], G["Bx"], 0.1)
