@@ -318,7 +318,10 @@ typedef struct {
   double volume_tol;        /* ipx_parameters.volume_tol, default 2.0 */
   ipxint maxskip_updates;   /* default 10 */
   ipxint rows_per_slice;    /* default 10000 */
-  ipxint max_etas;          /* exchanges between refactorizations, default 100 */
+  ipxint max_etas;          /* exchanges between refactorizations, default (0) 100; < 0: as many as pay -- a
+                               refactorization when the etas since the last one have cost as much as it
+                               costs (a fixed cost model, not the clock: the run stays reproducible),
+                               at least 100, at most 1024 or what 2 GiB of dense etas hold */
 } ipxk_maxvolume_params;
 typedef struct {
   ipxint updates, skipped, slices;   /* Maxvolume::updates() / skipped() / slices() */

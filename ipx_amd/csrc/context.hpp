@@ -22,6 +22,22 @@ enum PartialSlot {
     kNumPartialSlots
 };
 
+// A second copy of the model with rows and columns renumbered for locality (layout_device.hip, reorder_model): the loop of the
+// preconditioned CR method of the diag path runs on it, in permuted numbering; everything else keeps the original numbering.
+struct Reordered {
+    bool active = false;                 // the copy exists and is the faster one
+    int levels = 0;                      // depth of the breadth-first level structure the numbering comes from
+    int components = 0;
+    double ms = 0.0;                     // time of the analysis + the second copy inside ipxk_create
+    float us_original = 0.f, us_reordered = 0.f;      // the two products of NormalMatrix::Apply, timed on both copies
+    DevBuf<int> rowperm, rowinv, colperm, colinv;     // new -> old, old -> new
+    DevBuf<int> Ap, Ai, Tp, Ti;          // the renumbered matrix: CSC and the row-wise copy
+    DevBuf<double> Ax, Tx;
+    GatherMatrix Acols, Arows;
+    DevBuf<double> W, diagonal, resscale, rhs, y, tcols;       // the solver's vectors in the new numbering
+    bool in_use = false;                 // set around the CR loop of kkt_diag_solve_dev: operator and preconditioner take the copy
+};
+
 struct SplitOperator;   // trisolve.hip
 struct PrepareHost;     // trisolve.hip
 struct LuState;         // lu.hip
@@ -60,6 +76,7 @@ struct Context {
     double create_ms[4] = {0, 0, 0, 0};   // ipxk_create: upload + transpose, Acols layouts, Arows layouts, the rest
     GatherMatrix Acols;                 // rows = columns of A  (computes A'y)
     GatherMatrix Arows;                 // rows = rows of A     (computes A t)
+    Reordered reord;                    // the same matrix renumbered for locality, if that pays (layout_device.hip)
     int64_t num_dense = 0, nz_dense = 0;
     std::vector<ipxint> dense_cols;
 
@@ -164,6 +181,13 @@ bool device_build_sorted(LayoutScratch& S, SortedMatrix& out, const SlicedMatrix
 int acc_rows_per_block(int nrows, int ns);
 bool device_build_acc(LayoutScratch& S, AccMatrix& out, const SlicedMatrix& sliced, int nrows, int ncols, int64_t nnz, const int* dptr,
                       const int* didx, const double* dval, hipStream_t s);
+
+// layout_device.hip: the locality-recovering renumbering (SURVEY section 7 / 8d "row/column reordering ... a pure permutation")
+void reorder_model(Context* c);
+float time_normal_pair(Context* c, GatherMatrix& Ac, GatherMatrix& Ar);     // spmv.hip: microseconds of the two products
+void reorder_permute_rows(Context* c, const double* in_old, double* out_new);      // out_new[i'] = in_old[rowperm[i']]
+void reorder_unpermute_rows(Context* c, const double* in_new, double* out_old);    // out_old[rowperm[i']] = in_new[i']
+void reorder_permute_weights(Context* c, const double* W_old, double* W_new);      // n structural by colperm, m slack by rowperm
 
 // dense_inverse.hip
 void dense_lu_inverse(Context* c, int kb, const double* D, const double* invL, const double* invU, double* X, double* Xt, int refine = 0);

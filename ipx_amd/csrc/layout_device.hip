@@ -15,6 +15,9 @@
 // (long rows, gathered vectors that fit an XCD's L2, gathers with locality: phased / fused / sorted-fused layouts).
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <chrono>
+#include <memory>
+
 #include "context.hpp"
 
 namespace ipxk {
@@ -766,6 +769,242 @@ bool device_build_acc_fused(LayoutScratch& S, AccMatrix& out, int nrows, int nco
     out.nbatches = nb_total; out.deferred = (int64_t)ndef;
     out.built = true;
     return true;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// A renumbering of rows and columns that recovers locality (round 5).
+// The SpMV of a matrix whose gathers have locality runs at 0.53 of the HBM roof, that of a uniformly random one at 0.31 (the x gathers
+// miss the XCD's L2).  LPs that HAVE structure often arrive with it hidden -- rows and columns in the order a modelling tool emitted
+// them.  A pure permutation brings it back: breadth-first levels of the bipartite graph rows <-> columns from a pseudo-peripheral row
+// (Cuthill-McKee without the degree sort: two passes, the second from the smallest row of the first one's last level; further components
+// after the first, up to kMaxComponents), rows and columns numbered by (level, old index) with one radix sort each.  The levels of a
+// breadth-first search do not depend on which thread wins a race, so the numbering is deterministic.  A second copy of the model in
+// the new numbering gets its own gather layouts (the same builders), both copies' products are timed, and the copy is used -- by the
+// CR loop of the diag path, kkt_diag.hip -- only if it is at least 10 % faster.  A matrix without structure is recognised early (half
+// of the rows reached within 8 levels: an expander) and costs a millisecond.  IPXK_REORDER=0: never; =1: keep the copy whatever the
+// timing says (tests).
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kMaxComponents = 64;
+__global__ void bfs_expand_kernel(int nf, const int* __restrict__ frontier, const int* __restrict__ ptr, const int* __restrict__ idx,
+                                  int* level_of, int level, int* __restrict__ next, int* next_count) {
+    IPXK_GS(t, nf) {
+        const int v = frontier[t];
+        for (int p = ptr[v]; p < ptr[v + 1]; p++) {
+            const int w = idx[p];
+            if (level_of[w] < 0 && atomicCAS(&level_of[w], -1, level) == -1) next[atomicAdd(next_count, 1)] = w;
+        }
+    }
+}
+__global__ void first_unvisited_kernel(int n, const int* __restrict__ level_of, const int* __restrict__ ptr, int* out) {
+    IPXK_GS(i, n) if (level_of[i] < 0 && ptr[i + 1] > ptr[i]) atomicMin(out, (int)i);
+}
+__global__ void min_of_list_kernel(int nf, const int* __restrict__ list, int* out) {
+    IPXK_GS(t, nf) atomicMin(out, list[t]);
+}
+__global__ void level_keys_kernel(int n, const int* __restrict__ level_of, u64* __restrict__ keys, unsigned* __restrict__ vals) {
+    IPXK_GS(i, n) {
+        const unsigned lv = level_of[i] < 0 ? 0x7fffffffu : (unsigned)level_of[i];       // never reached (empty rows / columns): last
+        keys[i] = ((u64)lv << 32) | (u64)i;
+        vals[i] = (unsigned)i;
+    }
+}
+__global__ void invert_perm_kernel(int n, const unsigned* __restrict__ perm, int* __restrict__ perm_out, int* __restrict__ inv) {
+    IPXK_GS(i, n) { perm_out[i] = (int)perm[i]; inv[perm[i]] = (int)i; }
+}
+__global__ void permuted_keys_kernel(int64_t nz, const int* __restrict__ colof, const int* __restrict__ Ai, const int* __restrict__ colinv,
+                                     const int* __restrict__ rowinv, u64* __restrict__ keys, unsigned* __restrict__ pos) {
+    IPXK_GS(e, nz) {
+        keys[e] = ((u64)(unsigned)colinv[colof[e]] << 32) | (u64)(unsigned)rowinv[Ai[e]];
+        pos[e] = (unsigned)e;
+    }
+}
+__global__ void permuted_fill_kernel(int64_t nz, const u64* __restrict__ keys, const unsigned* __restrict__ pos, const double* __restrict__ Ax,
+                                     int* __restrict__ Ai_new, double* __restrict__ Ax_new, unsigned* __restrict__ col_new) {
+    IPXK_GS(e, nz) {
+        Ai_new[e] = (int)(keys[e] & 0xffffffffu);
+        col_new[e] = (unsigned)(keys[e] >> 32);
+        Ax_new[e] = Ax[pos[e]];
+    }
+}
+__global__ void gather_rows_kernel(int n, const int* __restrict__ perm, const double* __restrict__ in, double* __restrict__ out) {
+    IPXK_GS(i, n) out[i] = in[perm[i]];
+}
+__global__ void scatter_rows_kernel(int n, const int* __restrict__ perm, const double* __restrict__ in, double* __restrict__ out) {
+    IPXK_GS(i, n) out[perm[i]] = in[i];
+}
+template <class K>
+void sort_pairs_u64(Tmp& T, const K* kin, K* kout, const unsigned* vin, unsigned* vout, size_t n, int bits, hipStream_t s) {
+    sort_pairs<K>(T, kin, kout, vin, vout, n, bits, s);
+}
+
+// breadth-first levels of the bipartite graph from row `start`; rows and columns not yet reached only.  Returns the number of row
+// levels added (level numbers continue from level0), the rows reached, and the smallest row of the last row frontier.
+struct BfsOut { int levels = 0; int64_t rows = 0; int last_min = -1; int64_t rows_by_8 = 0; };
+BfsOut bfs_levels(Context* c, int start, int level0, int* row_level, int* col_level, int* fr, int* fc, int* counters, int* h) {
+    hipStream_t s = c->stream;
+    const int m = (int)c->m, n = (int)c->n;
+    (void)m; (void)n;
+    BfsOut out;
+    IPXK_HIP(hipMemcpyAsync(row_level + start, &level0, sizeof(int), hipMemcpyHostToDevice, s));
+    IPXK_HIP(hipMemcpyAsync(fr, &start, sizeof(int), hipMemcpyHostToDevice, s));
+    int nf = 1, level = level0;
+    out.rows = 1;
+    out.last_min = start;
+    while (nf > 0) {
+        IPXK_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(int), s));
+        // the columns of the frontier's rows get this level; the rows of those columns the next one
+        hipLaunchKernelGGL(bfs_expand_kernel, dim3(gridn(nf)), dim3(kBlock), 0, s, nf, fr, c->pl_Tp.get(), c->pl_Ti.get(), col_level, level, fc, counters);
+        IPXK_HIP(hipMemcpyAsync(h, counters, sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        const int nc = h[0];
+        if (nc == 0) break;
+        hipLaunchKernelGGL(bfs_expand_kernel, dim3(gridn(nc)), dim3(kBlock), 0, s, nc, fc, c->pl_Ap.get(), c->pl_Ai.get(), row_level, level + 1, fr, counters + 1);
+        IPXK_HIP(hipMemcpyAsync(h, counters + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        nf = h[0];
+        if (nf == 0) break;
+        level++;
+        out.rows += nf;
+        if (level - level0 <= 8) out.rows_by_8 = out.rows;
+        // smallest row of this frontier (the start of the second pass if it turns out to be the last one)
+        const int big = 0x7fffffff;
+        IPXK_HIP(hipMemcpyAsync(counters + 2, &big, sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(min_of_list_kernel, dim3(gridn(nf)), dim3(kBlock), 0, s, nf, fr, counters + 2);
+        IPXK_HIP(hipMemcpyAsync(h + 1, counters + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        out.last_min = h[1];
+    }
+    out.levels = level - level0 + 1;
+    return out;
+}
+
+}  // namespace
+
+void reorder_model(Context* c) {
+    Reordered& R = c->reord;
+    R = Reordered();
+    const char* env = getenv("IPXK_REORDER");
+    if (env && env[0] == '0') return;
+    const bool force = env && env[0] == '1';
+    const int64_t m = c->m, n = c->n, nz = c->nnz;
+    if (!c->have_plain || m < 2 || n < 1 || nz < 1 || c->nranks > 1) return;
+    if (!force && nz < (int64_t(1) << 20)) return;          // small models: every gathered vector is cache resident anyway
+    hipStream_t s = c->stream;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since0 = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    DevBuf<int> row_level((size_t)m), col_level((size_t)n), fr((size_t)m), fc((size_t)n), counters(4);
+    int* h = nullptr;
+    IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&h), 4 * sizeof(int)));
+    struct Free { int* p; ~Free() { (void)hipHostFree(p); } } free_h{h};
+    auto clear_levels = [&]() {
+        IPXK_HIP(hipMemsetAsync(row_level.get(), 0xff, (size_t)m * sizeof(int), s));
+        IPXK_HIP(hipMemsetAsync(col_level.get(), 0xff, (size_t)n * sizeof(int), s));
+    };
+    auto first_unvisited = [&]() {
+        const int big = 0x7fffffff;
+        IPXK_HIP(hipMemcpyAsync(counters.get() + 3, &big, sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(first_unvisited_kernel, dim3(gridn(m)), dim3(kBlock), 0, s, (int)m, row_level.get(), c->pl_Tp.get(), counters.get() + 3);
+        IPXK_HIP(hipMemcpyAsync(h + 2, counters.get() + 3, sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        return h[2] == big ? -1 : h[2];
+    };
+    // pass 1: from the first nonempty row, to find a row at the far end
+    clear_levels();
+    int start = first_unvisited();
+    if (start < 0) return;
+    BfsOut b1 = bfs_levels(c, start, 0, row_level.get(), col_level.get(), fr.get(), fc.get(), counters.get(), h);
+    if (!force && b1.rows_by_8 * 2 >= m) {                  // an expander: no numbering helps
+        R.levels = b1.levels;
+        R.ms = ms_since0();
+        if (getenv("IPXK_VERBOSE")) fprintf(stderr, "ipxk: reordering: %lld of %lld rows within 8 levels of row %d -- no locality to recover (%.1f ms)\n",
+                                            (long long)b1.rows_by_8, (long long)m, start, R.ms);
+        return;
+    }
+    // pass 2: the levels that count, from the far end; then the other components
+    clear_levels();
+    int level0 = 0, comps = 0;
+    int64_t reached = 0;
+    start = b1.last_min;
+    while (start >= 0 && comps < kMaxComponents) {
+        const BfsOut b = bfs_levels(c, start, level0, row_level.get(), col_level.get(), fr.get(), fc.get(), counters.get(), h);
+        level0 += b.levels;
+        reached += b.rows;
+        comps++;
+        if (reached >= m) break;
+        start = first_unvisited();
+    }
+    R.levels = level0;
+    R.components = comps;
+    // numbering: (level, old index)
+    Tmp T;
+    const size_t big = (size_t)std::max(m, n);
+    DevBuf<u64> k1(big), k2(big);
+    DevBuf<unsigned> v1(big), v2(big);
+    R.rowperm.ensure((size_t)m); R.rowinv.ensure((size_t)m); R.colperm.ensure((size_t)n); R.colinv.ensure((size_t)n);
+    hipLaunchKernelGGL(level_keys_kernel, dim3(gridn(m)), dim3(kBlock), 0, s, (int)m, row_level.get(), k1.get(), v1.get());
+    sort_pairs<u64>(T, k1.get(), k2.get(), v1.get(), v2.get(), (size_t)m, 64, s);
+    hipLaunchKernelGGL(invert_perm_kernel, dim3(gridn(m)), dim3(kBlock), 0, s, (int)m, v2.get(), R.rowperm.get(), R.rowinv.get());
+    hipLaunchKernelGGL(level_keys_kernel, dim3(gridn(n)), dim3(kBlock), 0, s, (int)n, col_level.get(), k1.get(), v1.get());
+    sort_pairs<u64>(T, k1.get(), k2.get(), v1.get(), v2.get(), (size_t)n, 64, s);
+    hipLaunchKernelGGL(invert_perm_kernel, dim3(gridn(n)), dim3(kBlock), 0, s, (int)n, v2.get(), R.colperm.get(), R.colinv.get());
+    // the matrix in the new numbering: entries keyed (new column, new row), sorted; then its row-wise copy as upload_plain_model builds it
+    const size_t nz1 = (size_t)nz;
+    R.Ap.ensure((size_t)n + 1); R.Ai.ensure(nz1); R.Ax.ensure(nz1); R.Tp.ensure((size_t)m + 1); R.Ti.ensure(nz1); R.Tx.ensure(nz1);
+    {
+        DevBuf<int> colof(nz1);
+        DevBuf<u64> q1(nz1), q2(nz1);
+        DevBuf<unsigned> p1(nz1), p2(nz1), cols_new(nz1);
+        hipLaunchKernelGGL(rowof_kernel, dim3(gridn(n)), dim3(kBlock), 0, s, (int)n, c->pl_Ap.get(), colof.get(), (unsigned*)nullptr);
+        hipLaunchKernelGGL(permuted_keys_kernel, dim3(gridn(nz)), dim3(kBlock), 0, s, nz, colof.get(), c->pl_Ai.get(), R.colinv.get(), R.rowinv.get(),
+                           q1.get(), p1.get());
+        sort_pairs<u64>(T, q1.get(), q2.get(), p1.get(), p2.get(), nz1, 32 + bits_for((u64)std::max<int64_t>(n, 2) - 1), s);
+        hipLaunchKernelGGL(permuted_fill_kernel, dim3(gridn(nz)), dim3(kBlock), 0, s, nz, q2.get(), p2.get(), c->pl_Ax.get(), R.Ai.get(), R.Ax.get(),
+                           cols_new.get());
+        hipLaunchKernelGGL(row_pointers_kernel, dim3(gridn(n + 1)), dim3(kBlock), 0, s, n, nz, cols_new.get(), R.Ap.get());
+        // Transpose (as in upload_plain_model)
+        DevBuf<unsigned> pos(nz1), rows2(nz1), perm(nz1);
+        hipLaunchKernelGGL(rowof_kernel, dim3(gridn(n)), dim3(kBlock), 0, s, (int)n, R.Ap.get(), colof.get(), pos.get());
+        sort_pairs<unsigned>(T, reinterpret_cast<const unsigned*>(R.Ai.get()), rows2.get(), pos.get(), perm.get(), nz1, bits_for((u64)std::max<int64_t>(m, 2) - 1), s);
+        hipLaunchKernelGGL(gather_transposed_kernel, dim3(gridn(nz)), dim3(kBlock), 0, s, nz, perm.get(), colof.get(), R.Ax.get(), R.Ti.get(), R.Tx.get());
+        hipLaunchKernelGGL(row_pointers_kernel, dim3(gridn(m + 1)), dim3(kBlock), 0, s, m, nz, rows2.get(), R.Tp.get());
+        IPXK_HIP(hipStreamSynchronize(s));
+    }
+    // its gather layouts, by the builders of the original
+    {
+        std::unique_ptr<LayoutScratch, void (*)(LayoutScratch*)> S(new_layout_scratch(), free_layout_scratch);
+        R.Acols.csr_ptr = R.Ap.get(); R.Acols.csr_idx = R.Ai.get(); R.Acols.csr_val = R.Ax.get();
+        R.Arows.csr_ptr = R.Tp.get(); R.Arows.csr_idx = R.Ti.get(); R.Arows.csr_val = R.Tx.get();
+        const bool ok = R.Acols.build_device(*S, n, m, nz, R.Ap.get(), R.Ai.get(), R.Ax.get(), s) &&
+                        R.Arows.build_device(*S, m, n, nz, R.Tp.get(), R.Ti.get(), R.Tx.get(), s);
+        if (!ok) { R = Reordered(); return; }
+    }
+    R.us_original = time_normal_pair(c, c->Acols, c->Arows);
+    R.us_reordered = time_normal_pair(c, R.Acols, R.Arows);
+    R.active = force || R.us_reordered < 0.9f * R.us_original;
+    R.ms = ms_since0();
+    if (getenv("IPXK_VERBOSE"))
+        fprintf(stderr, "ipxk: reordering: %d levels in %d component(s); the two products %.1f us on the model as given, %.1f us renumbered -> %s (%.1f ms)\n",
+                R.levels, R.components, R.us_original, R.us_reordered, R.active ? "renumbered copy in use" : "not used", R.ms);
+    if (!R.active) {                                        // keep the numbering (ipxk_reorder_info), drop the copy
+        R.Acols = GatherMatrix(); R.Arows = GatherMatrix();
+        R.Ap = DevBuf<int>(); R.Ai = DevBuf<int>(); R.Tp = DevBuf<int>(); R.Ti = DevBuf<int>(); R.Ax = DevBuf<double>(); R.Tx = DevBuf<double>();
+        return;
+    }
+    R.W.ensure((size_t)(n + m)); R.diagonal.ensure((size_t)m); R.resscale.ensure((size_t)m); R.rhs.ensure((size_t)m); R.y.ensure((size_t)m);
+    R.tcols.ensure((size_t)n);
+}
+
+void reorder_permute_rows(Context* c, const double* in_old, double* out_new) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(gridn(c->m)), dim3(kBlock), 0, c->stream, (int)c->m, c->reord.rowperm.get(), in_old, out_new);
+}
+void reorder_unpermute_rows(Context* c, const double* in_new, double* out_old) {
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(gridn(c->m)), dim3(kBlock), 0, c->stream, (int)c->m, c->reord.rowperm.get(), in_new, out_old);
+}
+void reorder_permute_weights(Context* c, const double* W_old, double* W_new) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(gridn(c->n)), dim3(kBlock), 0, c->stream, (int)c->n, c->reord.colperm.get(), W_old, W_new);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(gridn(c->m)), dim3(kBlock), 0, c->stream, (int)c->m, c->reord.rowperm.get(), W_old + c->n, W_new + c->n);
 }
 
 }  // namespace ipxk

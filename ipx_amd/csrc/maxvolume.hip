@@ -149,6 +149,122 @@ __global__ __launch_bounds__(kEtaThreads) void mv_eta_btran_kernel(int K, const 
         __syncthreads();
     }
 }
+// ---- the etas as DENSE vectors (round 5) -------------------------------------------------------------------------------------
+// The two kernels above walk the etas one after the other -- 6.5 us per eta of 8000 entries, 0.65 ms per application with 100 of
+// them, three applications per exchange: a third of Maxvolume's kernel time on the IPM's bases of a 24 000-row LP, whose tableau
+// columns fill a third of the vector.  Stored as rows of a dense K x m matrix E (row s = eta s, 0 at its own pivot position), the
+// same product form splits into a K x K triangular system for the multipliers and ONE pass over E:
+//   forward:  alpha_t piv_t = base_t - sum_{prev(t) < s < t} E[s][pos_t] alpha_s,  base_t = alpha_prev(t) if position pos_t was
+//             replaced before (prev(t) = the last such exchange), else v[pos_t];  then
+//             v[i] = (alpha_last(i) or v[i]) - sum_{s > last(i)} E[s][i] alpha_s          (last(i): the last exchange at position i)
+//   backward: d_t = E[t] . v;  w_t piv_t = cur_t - d_t - sum_{s > t, prev(s) <= t} E[t][pos_s] (w_s - v[pos_s]),  cur_t = w_next(t)
+//             if the position is replaced again later, else v[pos_t];  then v[pos_t] = w_t for the first exchange of each position.
+// The sums of the forward direction run in the order of the sequential kernel (s ascending, every product rounded before it is
+// subtracted, zeros skipped): the same result bit for bit.  The triangular systems are solved by one workgroup, a barrier per
+// eta (K <= 1024); T[t][s] = E[s][pos_t] (s < t) is kept both ways round so that either direction reads it contiguously.
+constexpr int kEtaDenseMax = 1024;
+__global__ void mv_eta_dense_append_kernel(int m, int K, int cap, const Scalars* S, const double* __restrict__ lhs, double* __restrict__ E,
+                                           int* pos, double* piv, int* prev, int* next, int* last, double* __restrict__ T, double* __restrict__ Tt) {
+    const int pmax = S->pmax;
+    IPXK_GRID_STRIDE(p, m) E[(size_t)K * m + p] = (int)p == pmax ? 0.0 : lhs[p];
+    IPXK_GRID_STRIDE(t, K) {                         // the older etas at the new pivot position
+        const double e = E[(size_t)t * m + pmax];
+        T[(size_t)K * cap + t] = e;
+        Tt[(size_t)t * cap + K] = e;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        pos[K] = pmax;
+        piv[K] = lhs[pmax];
+        const int pr = last[pmax];
+        prev[K] = pr;
+        next[K] = -1;
+        if (pr >= 0) next[pr] = K;
+        last[pmax] = K;
+    }
+}
+__global__ __launch_bounds__(kEtaDenseMax) void mv_eta_dense_ftran_solve_kernel(int K, int cap, const double* __restrict__ v, const int* __restrict__ pos,
+                                                                               const double* __restrict__ piv, const int* __restrict__ prev,
+                                                                               const double* __restrict__ Tt, double* __restrict__ alpha) {
+    __shared__ double s_alpha;
+    const int t = threadIdx.x;
+    const int pr = t < K ? prev[t] : -1;
+    double r = (t < K && pr < 0) ? v[pos[t]] : 0.0;
+    const double pv = t < K ? piv[t] : 1.0;
+    for (int s = 0; s < K; s++) {
+        if (t == s) { const double a = r / pv; s_alpha = a; alpha[s] = a; }
+        __syncthreads();
+        const double a = s_alpha;
+        if (t > s && t < K) {
+            if (s == pr) r = a;
+            else if (s > pr) {
+                const double e = Tt[(size_t)s * cap + t];
+                if (e != 0.0) r -= e * a;
+            }
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(kBlock) void mv_eta_dense_ftran_apply_kernel(int m, int K, const double* __restrict__ E, const double* __restrict__ alpha,
+                                                                         const int* __restrict__ last, double* __restrict__ v) {
+    __shared__ double sa[kEtaDenseMax];
+    for (int t = threadIdx.x; t < K; t += kBlock) sa[t] = alpha[t];
+    __syncthreads();
+    IPXK_GRID_STRIDE(i, m) {
+        const int l = last[i];
+        double x = l >= 0 ? sa[l] : v[i];
+        for (int s = l + 1; s < K; s++) {
+            const double e = E[(size_t)s * m + i];
+            if (e != 0.0) x -= e * sa[s];
+        }
+        v[i] = x;
+    }
+}
+// d_t = E[t] . v (one workgroup per eta, fixed tree)
+__global__ __launch_bounds__(kBlock) void mv_eta_dense_dots_kernel(int m, const double* __restrict__ E, const double* __restrict__ v, double* __restrict__ d) {
+    __shared__ double red[kBlock / 64];
+    const double* e = E + (size_t)blockIdx.x * m;
+    double sum = 0.0;
+    for (int i = threadIdx.x; i < m; i += kBlock) sum += e[i] * v[i];
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) sum += __shfl_xor(sum, k, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int k = 0; k < kBlock / 64; k++) tot += red[k];
+        d[blockIdx.x] = tot;
+    }
+}
+__global__ __launch_bounds__(kEtaDenseMax) void mv_eta_dense_btran_solve_kernel(int K, int cap, double* v, const int* __restrict__ pos,
+                                                                               const double* __restrict__ piv, const int* __restrict__ prev,
+                                                                               const int* __restrict__ next, const double* __restrict__ T,
+                                                                               const double* __restrict__ d) {
+    __shared__ double s_diff;
+    __shared__ double s_w[kEtaDenseMax];
+    const int t = threadIdx.x;
+    const double cv = t < K ? v[pos[t]] : 0.0;          // the vector as it came in, at this eta's position
+    const double dt = t < K ? d[t] : 0.0, pv = t < K ? piv[t] : 1.0;
+    const int nx = t < K ? next[t] : -1;
+    double acc = 0.0;
+    __syncthreads();
+    for (int s = K - 1; s >= 0; s--) {
+        if (t == s) {
+            const double cur = nx >= 0 ? s_w[nx] : cv;
+            const double w = (cur - dt - acc) / pv;
+            s_w[s] = w;
+            s_diff = w - cv;
+        }
+        __syncthreads();
+        if (t < s) {
+            // (prev[s] <= t: position pos_s is not replaced again between t and s, so eta t meets the value w_s there)
+            const double e = T[(size_t)s * cap + t];
+            if (e != 0.0 && prev[s] <= t) acc += e * s_diff;
+        }
+        __syncthreads();
+    }
+    if (t < K && prev[t] < 0) v[pos[t]] = s_w[t];
+}
+
 // ---- ScaleFtran (src/maxvolume.cc:322-337) + the recomputed weight (:269-275) + # nonzeros of the column ----
 __global__ __launch_bounds__(kBlock) void mv_scale_ftran_kernel(int m, const Scalars* S, const double* __restrict__ lhs,
                                                                 const double* __restrict__ colscale, const double* __restrict__ invscale,
@@ -383,6 +499,9 @@ struct MaxvolState {
     DevBuf<double> colscale, invscale, colweights, row, mask, rhs, lhs, unit, btran, work;
     DevBuf<int> map2basis, slice_of, flag, rank, eta_ptr, eta_pos, eta_idx;
     DevBuf<double> eta_piv, eta_val;
+    // the etas as dense vectors (mv_eta_dense_*): E [cap][m], T / Tt [cap][cap], multipliers, dots, links between the exchanges of a position
+    DevBuf<double> etaE, etaT, etaTt, eta_alpha, eta_d;
+    DevBuf<int> eta_prev, eta_next, eta_last;
     DevBuf<ipxint> basis, status;
     DevBuf<Part> part;
     DevBuf<Scalars> scalars;
@@ -391,6 +510,103 @@ struct MaxvolState {
     ~MaxvolState() { if (h) (void)hipHostFree(h); }
 };
 void destroy_maxvol(MaxvolState* M) { delete M; }
+
+// The etas of the exchanges since the last refactorization (both Maxvolume variants): dense rows (mv_eta_dense_*) where the
+// K x m matrix fits, else the compact lists walked one after the other.  When to refactorize: after max_etas exchanges (the
+// reference's update limit, src/maxvolume.cc:318-319) -- or, with max_etas < 0 (what KKTSolverBasisHip passes), when the time
+// the etas have cost since the last refactorization reaches the time a refactorization costs, both taken from a MODEL so that a
+// run does not depend on the clock: a refactorization 25 ms + 3.5e-13 s x (rows of the dense block)^3 (LU + the block's inverse:
+// 0.16 s at 7350 rows, 1.2 s at 15 000), an application of K etas K x (0.6 us + 8 m bytes at 2 TB/s), three applications per
+// exchange; at least 100, at most 1024 etas.  (Measured on the 24 000 x 60 000 LP: 40 refactorizations of 0.15 s inside
+// Maxvolume with the fixed limit of 100.)
+struct EtaFile {
+    Context* c;
+    MaxvolState& M;
+    int m;
+    hipStream_t s;
+    bool dense = false, adaptive = false;
+    int cap = 100;                 // most etas the buffers hold
+    int limit = 100;               // fixed mode: refactorize after so many
+    int64_t sparse_cap = 0, sparse_used = 0;
+    int K = 0;
+    double overhead_s = 0.0, refactor_s = 0.0;
+
+    EtaFile(Context* ctx, MaxvolState& state, int rows, ipxint max_etas_in) : c(ctx), M(state), m(rows), s(ctx->stream) {
+        adaptive = max_etas_in < 0;
+        limit = (int)std::max<ipxint>(1, max_etas_in > 0 ? max_etas_in : 100);
+        static const bool dense_off = getenv("IPXK_MAXVOL_DENSE_ETAS") && getenv("IPXK_MAXVOL_DENSE_ETAS")[0] == '0';
+        const int64_t fit = (int64_t(1) << 28) / std::max(m, 1);                   // 2 GiB of etas
+        cap = adaptive ? (int)std::min<int64_t>(kEtaDenseMax, std::max<int64_t>(limit, fit)) : limit;
+        dense = !dense_off && cap <= kEtaDenseMax && (int64_t)cap <= std::max<int64_t>(fit, 1) && cap <= kEtaDenseMax;
+        if (!dense) { cap = limit; adaptive = false; }
+        if (dense) {
+            M.etaE.ensure((size_t)cap * m); M.etaT.ensure((size_t)cap * cap); M.etaTt.ensure((size_t)cap * cap);
+            M.eta_alpha.ensure((size_t)cap); M.eta_d.ensure((size_t)cap);
+            M.eta_pos.ensure((size_t)cap); M.eta_piv.ensure((size_t)cap); M.eta_prev.ensure((size_t)cap); M.eta_next.ensure((size_t)cap);
+            M.eta_last.ensure((size_t)m);
+        } else {
+            sparse_cap = std::max<int64_t>(4 * (int64_t)m, int64_t(1) << 20);
+            M.flag.ensure((size_t)m); M.rank.ensure((size_t)m);
+            M.eta_ptr.ensure((size_t)cap + 1); M.eta_pos.ensure((size_t)cap); M.eta_piv.ensure((size_t)cap);
+            M.eta_idx.ensure((size_t)sparse_cap + m); M.eta_val.ensure((size_t)sparse_cap + m);
+        }
+        reset(0);
+    }
+    // after a (re)factorization whose dense block has `block_rows` rows
+    void reset(int block_rows) {
+        K = 0;
+        sparse_used = 0;
+        overhead_s = 0.0;
+        refactor_s = 0.025 + 3.5e-13 * (double)block_rows * (double)block_rows * (double)block_rows;
+        if (dense) IPXK_HIP(hipMemsetAsync(M.eta_last.get(), 0xff, (size_t)m * sizeof(int), s));
+        else IPXK_HIP(hipMemsetAsync(M.eta_ptr.get(), 0, sizeof(int), s));
+    }
+    // the eta of the exchange described by *S (pmax) from the tableau column lhs; eta_nnz: its number of nonzeros
+    void append(const Scalars* S, const double* lhs, int eta_nnz) {
+        const int gm = grid_for(m);
+        if (dense) {
+            hipLaunchKernelGGL(mv_eta_dense_append_kernel, dim3(gm), dim3(kBlock), 0, s, m, K, cap, S, lhs, M.etaE.get(), M.eta_pos.get(), M.eta_piv.get(),
+                               M.eta_prev.get(), M.eta_next.get(), M.eta_last.get(), M.etaT.get(), M.etaTt.get());
+        } else {
+            hipLaunchKernelGGL(mv_eta_flag_kernel, dim3(gm), dim3(kBlock), 0, s, m, S, lhs, M.flag.get());
+            size_t bytes = 0;
+            IPXK_HIP(rocprim::exclusive_scan(nullptr, bytes, M.flag.get(), M.rank.get(), 0, (size_t)m, rocprim::plus<int>(), s));
+            if (M.tmp.size() < bytes) M.tmp.resize(bytes);
+            IPXK_HIP(rocprim::exclusive_scan(M.tmp.get(), bytes, M.flag.get(), M.rank.get(), 0, (size_t)m, rocprim::plus<int>(), s));
+            hipLaunchKernelGGL(mv_eta_store_kernel, dim3(gm), dim3(kBlock), 0, s, m, K, S, lhs, M.flag.get(), M.rank.get(), M.eta_ptr.get(), M.eta_pos.get(),
+                               M.eta_piv.get(), M.eta_idx.get(), M.eta_val.get(), M.scalars.get());
+            sparse_used += eta_nnz;
+        }
+        K++;
+        overhead_s += 3.0 * (double)K * (0.6e-6 + 8.0 * (double)m / 2e12);
+    }
+    bool full() const {                                                             // NeedFreshFactorization (src/maxvolume.cc:318-319)
+        if (K >= cap) return true;
+        if (!dense && sparse_used + m > sparse_cap) return true;
+        if (adaptive) return K >= 100 && overhead_s >= refactor_s;
+        return K >= limit;
+    }
+    void apply(bool transposed, double* v) {
+        if (K == 0) return;
+        if (dense && transposed) {
+            hipLaunchKernelGGL(mv_eta_dense_dots_kernel, dim3(K), dim3(kBlock), 0, s, m, M.etaE.get(), v, M.eta_d.get());
+            hipLaunchKernelGGL(mv_eta_dense_btran_solve_kernel, dim3(1), dim3(kEtaDenseMax), 0, s, K, cap, v, M.eta_pos.get(), M.eta_piv.get(),
+                               M.eta_prev.get(), M.eta_next.get(), M.etaT.get(), M.eta_d.get());
+        } else if (dense) {
+            hipLaunchKernelGGL(mv_eta_dense_ftran_solve_kernel, dim3(1), dim3(kEtaDenseMax), 0, s, K, cap, v, M.eta_pos.get(), M.eta_piv.get(),
+                               M.eta_prev.get(), M.etaTt.get(), M.eta_alpha.get());
+            hipLaunchKernelGGL(mv_eta_dense_ftran_apply_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, K, M.etaE.get(), M.eta_alpha.get(),
+                               M.eta_last.get(), v);
+        } else if (transposed) {
+            hipLaunchKernelGGL(mv_eta_btran_kernel, dim3(1), dim3(kEtaThreads), 0, s, K, M.eta_ptr.get(), M.eta_pos.get(), M.eta_piv.get(), M.eta_idx.get(),
+                               M.eta_val.get(), v);
+        } else {
+            hipLaunchKernelGGL(mv_eta_ftran_kernel, dim3(1), dim3(kEtaThreads), 0, s, K, M.eta_ptr.get(), M.eta_pos.get(), M.eta_piv.get(), M.eta_idx.get(),
+                               M.eta_val.get(), v);
+        }
+    }
+};
+
 
 void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_in, const ipxk_maxvolume_params* prm_in,
                    ipxint* basis_out, ipxint* status_out, ipxk_maxvolume_info* info, ipxint* log, ipxint log_cap) {
@@ -407,15 +623,13 @@ void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_i
     MaxvolState& M = *c->maxvol;
     const double t_start = now_s();
     const double volumetol = std::max(prm->volume_tol, 1.0);
-    const int max_etas = (int)std::max<ipxint>(1, prm->max_etas > 0 ? prm->max_etas : 100);
-    const int64_t eta_cap = std::max<int64_t>(4 * (int64_t)m, int64_t(1) << 20);
-
     for (DevBuf<double>* b : {&M.colscale, &M.colweights, &M.row, &M.mask}) b->ensure((size_t)N);
     for (DevBuf<double>* b : {&M.invscale, &M.rhs, &M.lhs, &M.unit, &M.btran, &M.work}) b->ensure((size_t)m);
-    M.map2basis.ensure((size_t)N); M.slice_of.ensure((size_t)m); M.flag.ensure((size_t)m); M.rank.ensure((size_t)m);
-    M.eta_ptr.ensure((size_t)max_etas + 1); M.eta_pos.ensure((size_t)max_etas); M.eta_piv.ensure((size_t)max_etas);
-    M.eta_idx.ensure((size_t)eta_cap + m); M.eta_val.ensure((size_t)eta_cap + m);
+    M.map2basis.ensure((size_t)N); M.slice_of.ensure((size_t)m);
     M.part.ensure(kRedGrid); M.scalars.ensure(1);
+    EtaFile etas(c, M, m, prm->max_etas);
+    etas.reset(V.bump_size);
+    int& K = etas.K;
     if (!M.h) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&M.h), sizeof(Scalars)));
 
     // host mirrors of basis and status (refactorizations, results)
@@ -444,29 +658,19 @@ void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_i
         for (int i = 0; i < m; i++) slice_of[vi[i].second] = i % num_slices;
         M.slice_of.upload(slice_of, s);
     }
-    const int zero = 0;
-    IPXK_HIP(hipMemcpyAsync(M.eta_ptr.get(), &zero, sizeof(int), hipMemcpyHostToDevice, s));
     IPXK_HIP(hipStreamSynchronize(s));
 
     const int *Ap = nullptr, *Ai = nullptr;
     const double* Ax = nullptr;
     lu_plain_matrix(c, &Ap, &Ai, &Ax);
 
-    int K = 0;                                   // etas since the last factorization
-    int64_t eta_used = 0;
     ipxk_maxvolume_info I{};
     I.slices = num_slices;
     auto read_scalars = [&]() {
         IPXK_HIP(hipMemcpyAsync(M.h, M.scalars.get(), sizeof(Scalars), hipMemcpyDeviceToHost, s));
         IPXK_HIP(hipStreamSynchronize(s));
     };
-    auto apply_etas = [&](bool transposed, double* v) {
-        if (K == 0) return;
-        if (transposed) hipLaunchKernelGGL(mv_eta_btran_kernel, dim3(1), dim3(kEtaThreads), 0, s, K, M.eta_ptr.get(), M.eta_pos.get(),
-                                           M.eta_piv.get(), M.eta_idx.get(), M.eta_val.get(), v);
-        else hipLaunchKernelGGL(mv_eta_ftran_kernel, dim3(1), dim3(kEtaThreads), 0, s, K, M.eta_ptr.get(), M.eta_pos.get(),
-                                M.eta_piv.get(), M.eta_idx.get(), M.eta_val.get(), v);
-    };
+    auto apply_etas = [&](bool transposed, double* v) { etas.apply(transposed, v); };
     // the reference's ladder for the LU pivot tolerance (Basis::TightenLuPivotTol, src/basis.cc:490-503); the value is the context's
     double& pivottol = c->maxvol_pivottol;
     auto tighten_pivottol = [&]() {
@@ -485,9 +689,7 @@ void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_i
         }
         split_prepare_lu(c, status_h.data(), colscale_in);
         lu_plain_matrix(c, &Ap, &Ai, &Ax);
-        K = 0;
-        eta_used = 0;
-        IPXK_HIP(hipMemcpyAsync(M.eta_ptr.get(), &zero, sizeof(int), hipMemcpyHostToDevice, s));
+        etas.reset((int)li.bump);
         I.factorizations++;
         return true;
     };
@@ -552,29 +754,19 @@ void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_i
                 continue;                                                           // "try again" (:290-291)
             }
             // the eta of this exchange
-            hipLaunchKernelGGL(mv_eta_flag_kernel, dim3(gm), dim3(kBlock), 0, s, m, M.scalars.get(), M.lhs.get(), M.flag.get());
-            {
-                size_t bytes = 0;
-                IPXK_HIP(rocprim::exclusive_scan(nullptr, bytes, M.flag.get(), M.rank.get(), 0, (size_t)m, rocprim::plus<int>(), s));
-                if (M.tmp.size() < bytes) M.tmp.resize(bytes);
-                IPXK_HIP(rocprim::exclusive_scan(M.tmp.get(), bytes, M.flag.get(), M.rank.get(), 0, (size_t)m, rocprim::plus<int>(), s));
-            }
-            hipLaunchKernelGGL(mv_eta_store_kernel, dim3(gm), dim3(kBlock), 0, s, m, K, M.scalars.get(), M.lhs.get(), M.flag.get(), M.rank.get(),
-                               M.eta_ptr.get(), M.eta_pos.get(), M.eta_piv.get(), M.eta_idx.get(), M.eta_val.get(), M.scalars.get());
+            etas.append(M.scalars.get(), M.lhs.get(), a.eta_nnz);
             const double alpha = ((double)a.used_pmax - a.weight_recomp) / (a.colscale_jn * pivot);      // :307
             hipLaunchKernelGGL(mv_weights_kernel, dim3(gN), dim3(kBlock), 0, s, N, M.scalars.get(), alpha, M.row.get(), M.colscale.get(),
                                M.colweights.get());
             hipLaunchKernelGGL(mv_exchange_kernel, dim3(1), dim3(1), 0, s, M.scalars.get(), M.basis.get(), M.map2basis.get(), M.colscale.get(),
                                M.invscale.get(), M.mask.get());
-            K++;
-            eta_used += a.eta_nnz;
             if (log && I.updates < log_cap) { log[2 * I.updates] = a.jb; log[2 * I.updates + 1] = a.jn; }
             I.updates++;
             I.volinc += std::log2(a.vmax);                                          // :294
             basis_h[(size_t)a.pmax] = a.jn;
             status_h[(size_t)a.jn] = IPXK_BASIC;
             status_h[(size_t)a.jb] = IPXK_NONBASIC;
-            if (K >= max_etas || eta_used + m > eta_cap)                            // NeedFreshFactorization (:318-319)
+            if (etas.full())                                                        // NeedFreshFactorization (:318-319)
                 if (!refactorize()) break;
         }
         I.skipped += skipped;
@@ -612,13 +804,12 @@ void maxvolume_sequential_dev(Context* c, const ipxint* status_in, const double*
     MaxvolState& M = *c->maxvol;
     const double t_start = now_s();
     const double volumetol = std::max(volume_tol, 1.0);
-    const int max_etas = (int)std::max<ipxint>(1, max_etas_in > 0 ? max_etas_in : 100);
-    const int64_t eta_cap = std::max<int64_t>(4 * (int64_t)m, int64_t(1) << 20);
     for (DevBuf<double>* b : {&M.invscale, &M.rhs, &M.lhs, &M.unit, &M.btran}) b->ensure((size_t)m);
-    M.map2basis.ensure((size_t)N); M.flag.ensure((size_t)m); M.rank.ensure((size_t)m);
-    M.eta_ptr.ensure((size_t)max_etas + 1); M.eta_pos.ensure((size_t)max_etas); M.eta_piv.ensure((size_t)max_etas);
-    M.eta_idx.ensure((size_t)eta_cap + m); M.eta_val.ensure((size_t)eta_cap + m);
+    M.map2basis.ensure((size_t)N);
     M.part.ensure(kRedGrid); M.scalars.ensure(1);
+    EtaFile etas(c, M, m, max_etas_in);
+    etas.reset(V.bump_size);
+    int& K = etas.K;
     M.colscale.ensure((size_t)N); M.mask.ensure((size_t)N);
     if (!M.h) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&M.h), sizeof(Scalars)));
     std::vector<ipxint> basis_h((size_t)m), status_h(status_in, status_in + N);
@@ -632,15 +823,11 @@ void maxvolume_sequential_dev(Context* c, const ipxint* status_in, const double*
                        M.colscale.get(), M.mask.get(), M.map2basis.get());
     hipLaunchKernelGGL(mv_init_basis_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, M.basis.get(), M.status.get(), colscale_dev.get(),
                        M.invscale.get(), M.map2basis.get());
-    const int zero = 0;
-    IPXK_HIP(hipMemcpyAsync(M.eta_ptr.get(), &zero, sizeof(int), hipMemcpyHostToDevice, s));
     IPXK_HIP(hipStreamSynchronize(s));
     for (int p = 0; p < m; p++) IPXK_REQUIRE(basis_h[p] >= 0 && basis_h[p] < N && status_h[basis_h[p]] >= 0, "status of a basic variable is not BASIC / BASIC_FREE");
     const int *Ap = nullptr, *Ai = nullptr;
     const double* Ax = nullptr;
     lu_plain_matrix(c, &Ap, &Ai, &Ax);
-    int K = 0;
-    int64_t eta_used = 0;
     ipxk_maxvolume_info I{};
     double& pivottol = c->maxvol_pivottol;
     auto tighten_pivottol = [&]() {                   // Basis::TightenLuPivotTol, src/basis.cc:490-503
@@ -650,22 +837,14 @@ void maxvolume_sequential_dev(Context* c, const ipxint* status_in, const double*
         else return false;
         return true;
     };
-    auto apply_etas = [&](bool transposed, double* v) {
-        if (K == 0) return;
-        if (transposed) hipLaunchKernelGGL(mv_eta_btran_kernel, dim3(1), dim3(kEtaThreads), 0, s, K, M.eta_ptr.get(), M.eta_pos.get(),
-                                           M.eta_piv.get(), M.eta_idx.get(), M.eta_val.get(), v);
-        else hipLaunchKernelGGL(mv_eta_ftran_kernel, dim3(1), dim3(kEtaThreads), 0, s, K, M.eta_ptr.get(), M.eta_pos.get(),
-                                M.eta_piv.get(), M.eta_idx.get(), M.eta_val.get(), v);
-    };
+    auto apply_etas = [&](bool transposed, double* v) { etas.apply(transposed, v); };
     auto refactorize = [&]() {
         ipxk_lu_info li{};
         lu_factorize_basis(c, basis_h.data(), pivottol, false, &li);
         if (li.num_dependent > 0) { I.errflag = 301; return false; }
         split_prepare_lu(c, status_h.data(), colscale_in);
         lu_plain_matrix(c, &Ap, &Ai, &Ax);
-        K = 0;
-        eta_used = 0;
-        IPXK_HIP(hipMemcpyAsync(M.eta_ptr.get(), &zero, sizeof(int), hipMemcpyHostToDevice, s));
+        etas.reset((int)li.bump);
         I.factorizations++;
         return true;
     };
@@ -713,18 +892,8 @@ void maxvolume_sequential_dev(Context* c, const ipxint* status_in, const double*
                 if (!refactorize()) break;
                 continue;                                                           // "try again" (:86-87)
             }
-            hipLaunchKernelGGL(mv_eta_flag_kernel, dim3(gm), dim3(kBlock), 0, s, m, M.scalars.get(), M.lhs.get(), M.flag.get());
-            {
-                size_t bytes = 0;
-                IPXK_HIP(rocprim::exclusive_scan(nullptr, bytes, M.flag.get(), M.rank.get(), 0, (size_t)m, rocprim::plus<int>(), s));
-                if (M.tmp.size() < bytes) M.tmp.resize(bytes);
-                IPXK_HIP(rocprim::exclusive_scan(M.tmp.get(), bytes, M.flag.get(), M.rank.get(), 0, (size_t)m, rocprim::plus<int>(), s));
-            }
-            hipLaunchKernelGGL(mv_eta_store_kernel, dim3(gm), dim3(kBlock), 0, s, m, K, M.scalars.get(), M.lhs.get(), M.flag.get(), M.rank.get(),
-                               M.eta_ptr.get(), M.eta_pos.get(), M.eta_piv.get(), M.eta_idx.get(), M.eta_val.get(), M.scalars.get());
+            etas.append(M.scalars.get(), M.lhs.get(), a.eta_nnz);
             hipLaunchKernelGGL(mvs_exchange_kernel, dim3(1), dim3(1), 0, s, M.scalars.get(), M.basis.get(), M.map2basis.get(), M.invscale.get());
-            K++;
-            eta_used += a.eta_nnz;
             if (log && I.updates + updates_last < log_cap) { log[2 * (I.updates + updates_last)] = a.jb; log[2 * (I.updates + updates_last) + 1] = j; }
             updates_last++;
             I.volinc += std::log2(a.vmax);                                          // :90
@@ -732,7 +901,7 @@ void maxvolume_sequential_dev(Context* c, const ipxint* status_in, const double*
             status_h[(size_t)j] = IPXK_BASIC;
             status_h[(size_t)a.jb] = IPXK_NONBASIC;
             cand.pop_back();
-            if (K >= max_etas || eta_used + m > eta_cap)
+            if (etas.full())
                 if (!refactorize()) break;
         }
         I.updates += updates_last;

@@ -1165,6 +1165,31 @@ static double ms_since(std::chrono::steady_clock::time_point& t0) {
 // indices, Transpose and the layouts of both gather matrices happen there (layout_device.hip).  Matrices the device
 // builders do not cover take the host builders on host copies of the entries -- of the caller's arrays for the CSC, a
 // download of the device's row-wise copy for the other gather matrix.
+// the time of the two products of NormalMatrix::Apply on a pair of gather matrices (microseconds)
+float time_normal_pair(Context* c, GatherMatrix& Ac, GatherMatrix& Ar) {
+    hipStream_t s = c->stream;
+    const size_t m = (size_t)std::max<int64_t>(c->m, 1), n = (size_t)std::max<int64_t>(c->n, 1);
+    DevBuf<double> y(m), t(n), out(m);
+    IPXK_HIP(hipMemsetAsync(y.get(), 0, m * sizeof(double), s));
+    hipEvent_t e0, e1;
+    IPXK_HIP(hipEventCreate(&e0));
+    IPXK_HIP(hipEventCreate(&e1));
+    EpiScale ep1{{}, nullptr, t.get()}, ep2{{}, nullptr, out.get()};
+    const int reps = 5;
+    for (int r = 0; r < 2 + reps; r++) {
+        if (r == 2) IPXK_HIP(hipEventRecord(e0, s));
+        launch_spmv(Ac, y.get(), ep1, nullptr, nullptr, s);
+        launch_spmv(Ar, t.get(), ep2, nullptr, nullptr, s);
+    }
+    IPXK_HIP(hipEventRecord(e1, s));
+    IPXK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    IPXK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return ms * 1e3f / reps;
+}
+
 void build_model(Context* c, const ipxint* Ap, const ipxint* Ai, const double* Ax) {
     const int64_t m = c->m, n = c->n;
     auto t0 = std::chrono::steady_clock::now();
@@ -1187,6 +1212,7 @@ void build_model(Context* c, const ipxint* Ap, const ipxint* Ai, const double* A
     find_dense_columns(c);
     c->tcols.resize(n > 0 ? n : 1);
     prepare_dense_columns(c);
+    if (c->num_dense == 0) reorder_model(c);       // (the Sherman-Morrison-Woodbury preconditioner keeps the numbering as given)
     c->create_ms[3] = ms_since(t0);
     if (getenv("IPXK_VERBOSE"))
         fprintf(stderr, "ipxk: model %lld x %lld nnz %lld on the device: upload + transpose %.1f ms, A' layouts %.1f ms, A layouts %.1f ms, rest %.1f ms\n",

@@ -45,8 +45,57 @@ KKTSolverBasisHip::KKTSolverBasisHip(const Control& control, Basis& basis)
 }
 
 KKTSolverBasisHip::~KKTSolverBasisHip() {
+    // whoever comes next (crossover, LpSolver's basic solution) reads the reference's Basis: it learns the final basis now at the
+    // latest.  The device factorized exactly this basis without dependent columns, and Load's factorization is those factors handed
+    // out again (LuKernelHip::SharedWithSolver), so there is no error to report from here; an exception must not leave a destructor.
+    if (basis_pending_) {
+        try {
+            Timer timer;
+            (void)SyncBasis();
+            g_phase_seconds[3] += timer.Elapsed();
+        } catch (...) {
+        }
+    }
     // the context outlives this object (HipModel registry): it must not keep a pointer to this solver's Control
     ipxk_set_interrupt(device_.get(), nullptr, nullptr);
+}
+
+const Basis* KKTSolverBasisHip::_basis() const {
+    // IPM::PrintOutput asks for the Basis every iteration but reads it only at debug level 4 (src/ipm.cc:685-691)
+    if (basis_pending_ && control_.Debug(4))
+        (void)const_cast<KKTSolverBasisHip*>(this)->SyncBasis();
+    return &basis_;
+}
+
+Int KKTSolverBasisHip::SyncBasis() {
+    if (!basis_pending_)
+        return 0;
+    basis_pending_ = false;
+    std::vector<int> basic_status(device_status_.begin(), device_status_.end());
+    return basis_.Load(basic_status.data());      // loads and factorizes (src/basis.cc:81-114)
+}
+
+// Would the reference's DropPrimal / DropDual find a candidate?  Their screening conditions (src/kkt_solver_basis.cc:208-216:
+// a BASIC variable whose nearer bound is closer than ipm_drop_primal and 100 times closer than its dual; :306-314: a NONBASIC
+// variable whose larger dual is below ipm_drop_dual and 100 times below its primal distance) evaluated on the basis the device
+// holds.  Only used to decide whether the reference's Basis must be brought up to date before its own procedures run.
+bool KKTSolverBasisHip::DegenerateCandidateExists(const Iterate& iterate) const {
+    const Vector &xl = iterate.xl(), &xu = iterate.xu(), &zl = iterate.zl(), &zu = iterate.zu();
+    const double near_bound = control_.ipm_drop_primal(), near_zero = control_.ipm_drop_dual();
+    for (std::size_t j = 0; j < device_status_.size(); j++) {
+        if (device_status_[j] == Basis::BASIC) {
+            const bool at_lower = xl[j] <= xu[j];
+            const double dist = at_lower ? xl[j] : xu[j], dual = at_lower ? zl[j] : zu[j];
+            if (dist <= near_bound && dist < 0.01 * dual)
+                return true;
+        } else if (device_status_[j] == Basis::NONBASIC) {
+            const bool lower_active = zl[j] >= zu[j];
+            const double dual = lower_active ? zl[j] : zu[j], dist = lower_active ? xl[j] : xu[j];
+            if (dual <= near_zero && dual < 0.01 * dist)
+                return true;
+        }
+    }
+    return false;
 }
 
 Int KKTSolverBasisHip::_basis_changes() const { return reference_.basis_changes_; }
@@ -59,6 +108,17 @@ Int KKTSolverBasisHip::_basis_changes() const { return reference_.basis_changes_
 void KKTSolverBasisHip::DropDegenerateVariables(Iterate* iterate, Info* info) {
     if (iterate->pobjective() < iterate->dobjective())
         return;                      // possibly infeasible / unbounded: the reference removes nothing then (:30-35)
+    if (basis_pending_) {
+        // the reference's Basis still holds the basis of an earlier iteration: without a candidate its two procedures would do
+        // nothing on the CURRENT basis, so they are not called on the old one; with one, the Basis is brought up to date first
+        if (!DegenerateCandidateExists(*iterate))
+            return;
+        Timer timer;
+        info->errflag = SyncBasis();
+        g_phase_seconds[3] += timer.Elapsed();
+        if (info->errflag)
+            return;
+    }
     reference_.DropPrimal(iterate, info);
     if (!info->errflag)
         reference_.DropDual(iterate, info);
@@ -81,7 +141,10 @@ void KKTSolverBasisHip::_Factorize(Iterate* iterate, Info* info) {
         return;
     if (!(on_device && MaxvolumeOnDevice(info))) {
         timer.Reset();
-        MaxvolumeOnBasis(info);
+        if (!info->errflag)
+            info->errflag = SyncBasis();          // the reference's own path works on its Basis
+        if (!info->errflag)
+            MaxvolumeOnBasis(info);
         g_phase_seconds[4] += timer.Elapsed();
     }
     factorized_ = info->errflag == 0;
@@ -98,13 +161,13 @@ bool KKTSolverBasisHip::MaxvolumeOnDevice(Info* info) {
     bool same_basis = device_lu_valid_ && (Int)device_member_.size() == n+m && ipxk_lu_generation(ctx) == device_lu_generation_;
     for (Int j = 0; j < n+m; j++) {
         colscale[j] = reference_.colscale_[j];
-        status[j] = basis_.StatusOf(j);
+        status[j] = basis_pending_ ? device_status_[j] : static_cast<Int>(basis_.StatusOf(j));
         const bool member = status[j] == Basis::BASIC || status[j] == Basis::BASIC_FREE;
         if (same_basis && member != (device_member_[j] != 0))
             same_basis = false;
     }
     for (Int p = 0; p < m; p++)
-        basic[p] = basis_[p];
+        basic[p] = basis_pending_ ? device_basis_[p] : basis_[p];
     Timer timer;
     // the factors of the current basis on the device: those of the previous call's final refactorization when the
     // basis is still the same set of columns (then only the scaling is handed over), else a fresh device LU
@@ -127,14 +190,14 @@ bool KKTSolverBasisHip::MaxvolumeOnDevice(Info* info) {
     ipxk_maxvolume_info mv;
     int rc;
     if (control_.update_heuristic() == 0) {
-        rc = ipxk_maxvolume_sequential(ctx, status.data(), colscale.data(), control_.volume_tol(), control_.maxpasses(), 100,
+        rc = ipxk_maxvolume_sequential(ctx, status.data(), colscale.data(), control_.volume_tol(), control_.maxpasses(), -1,
                                        basis_out.data(), status_out.data(), &mv, nullptr, 0);
     } else {
         ipxk_maxvolume_params prm;
         prm.volume_tol = control_.volume_tol();
         prm.maxskip_updates = control_.maxskip_updates();
         prm.rows_per_slice = control_.rows_per_slice();
-        prm.max_etas = 100;
+        prm.max_etas = -1;          // refactorize when the etas have cost as much as a refactorization (ipx_kkt_hip.h)
         rc = ipxk_maxvolume(ctx, status.data(), colscale.data(), &prm, basis_out.data(), status_out.data(), &mv, nullptr, 0);
     }
     if (rc == IPXK_E_UNSUPPORTED) {            // a refactorization on the way hit the dense limit: nothing was handed back yet
@@ -161,16 +224,22 @@ bool KKTSolverBasisHip::MaxvolumeOnDevice(Info* info) {
     device_lu_valid_ = true;
     device_lu_generation_ = ipxk_lu_generation(ctx);
     prepared_once_ = false;                   // (the factors of an earlier GetLuFactors hand-off are gone)
-    Timer timer_load;
-    struct AddOnExit { Timer& t; ~AddOnExit() { g_phase_seconds[3] += t.Elapsed(); } } add_on_exit{timer_load};
     if (mv.updates > 0) {
-        // the reference's Basis learns the final basis: loads and factorizes (src/basis.cc:81-114), as :57-61 would
-        std::vector<int> basic_status(n+m);
-        for (Int j = 0; j < n+m; j++)
-            basic_status[j] = static_cast<int>(status_out[j]);
-        info->errflag = basis_.Load(basic_status.data());
-    } else if (!basis_.FactorizationIsFresh()) {
+        // the reference's Basis learns the final basis when somebody needs it there (see basis_pending_): Basis::Load -- loads
+        // and factorizes (src/basis.cc:81-114), as :57-61 would -- with the resident factors handed out again
+        device_status_ = status_out;
+        device_basis_ = basis_out;
+        basis_pending_ = true;
+        static const bool eager = std::getenv("IPXK_EAGER_BASIS_LOAD") != nullptr;     // (measurement: Load at once, as until round 5)
+        if (eager) {
+            Timer timer_load;
+            info->errflag = SyncBasis();
+            g_phase_seconds[3] += timer_load.Elapsed();
+        }
+    } else if (!basis_pending_ && !basis_.FactorizationIsFresh()) {
+        Timer timer_load;
         info->errflag = basis_.Factorize();     // updates by DropPrimal / DropDual (:57-61)
+        g_phase_seconds[3] += timer_load.Elapsed();
     }
     return true;
 }

@@ -34,6 +34,10 @@ public:
     Int maxiter() const { return maxiter_; }
     void maxiter(Int new_maxiter) { maxiter_ = new_maxiter; }
 
+    // The reference's Basis learns the basis of the last Factorize() only when it is needed there (see basis_pending_ below);
+    // code that reads the Basis itself while this solver object is alive calls this first.  Returns Basis::Load's error code.
+    Int FlushBasis() { return SyncBasis(); }
+
     // # Factorize calls whose Maxvolume ran on the device / on the reference's Basis (CPU) so far
     Int device_maxvolume_calls() const { return device_maxvolume_calls_; }
     Int cpu_maxvolume_calls() const { return cpu_maxvolume_calls_; }
@@ -44,10 +48,15 @@ private:
                 Vector& x, Vector& y, Info* info) override;
     Int _iter() const override { return iter_; }
     Int _basis_changes() const override;
-    const Basis* _basis() const override { return &basis_; }
+    const Basis* _basis() const override;
 
     // the reference's DropPrimal / DropDual (src/kkt_solver_basis.cc:196-387) on reference_'s colscale_ / basis_changes_
     void DropDegenerateVariables(Iterate* iterate, Info* info);
+    // true if DropPrimal / DropDual would find a candidate in the basis the device holds (the screening conditions of
+    // src/kkt_solver_basis.cc:208-216, 306-314 on the iterate; nothing is pivoted here)
+    bool DegenerateCandidateExists(const Iterate& iterate) const;
+    // hands the basis the device holds to the reference's Basis (Basis::Load); returns its error code
+    Int SyncBasis();
     // Maxvolume + fresh factorization + operator on the device; false: declined (nothing changed, take the CPU path)
     bool MaxvolumeOnDevice(Info* info);
     void MaxvolumeOnBasis(Info* info);
@@ -63,6 +72,13 @@ private:
     bool prepared_once_{false};  // the device holds the factors of an earlier hand-off from Basis::GetLuFactors
     Int factorizations_at_handoff_{-1};   // Basis::factorizations() when those factors were handed over
     std::vector<signed char> device_member_;   // per variable: 1 if in the basis whose factors the device LU holds
+    // The basis after Maxvolume on the device, as the device holds it.  basis_pending_: the reference's Basis has not been told yet --
+    // Basis::Load costs a pass of the reference's own host code over the factors (download, stability estimate: 0.4 s at 24 000 rows
+    // with 54 M entries), and between two Factorize calls nobody asks the Basis anything unless DropPrimal / DropDual have a
+    // candidate.  So the Load happens when one exists, when IPM prints Basis statistics (Debug(4)), on the CPU path, and at the latest
+    // in the destructor (crossover and LpSolver read the Basis afterwards).
+    std::vector<Int> device_status_, device_basis_;
+    bool basis_pending_{false};
     bool device_lu_valid_{false};
     Int device_lu_generation_{-1};              // ipxk_lu_generation() when those factors were computed: any other factorization through the context since then invalidates them
     Int maxiter_{-1};

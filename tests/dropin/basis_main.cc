@@ -91,6 +91,7 @@ int main(int argc, char** argv) {
     for (;; rounds++) {
         ipx::Info i1, i2;
         hip.Factorize(&iterate, &i1);
+        if (!i1.errflag) i1.errflag = hip.FlushBasis();     // (the reference's solver reads the shared Basis next)
         ref.Factorize(&iterate, &i2);
         if (i1.errflag || i2.errflag) { std::printf("Factorize errflag %ld %ld\n", (long)i1.errflag, (long)i2.errflag); return 2; }
         if (ref.basis_changes() == 0) break;
