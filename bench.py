@@ -349,6 +349,7 @@ def main():
         out["roofline"]["frac_of_measured_triad"] = achieved / triad
     if rank == 0 and world == 1 and not args.no_banded:
         out["roofline"]["banded_matrix_probe"] = bench_banded(kkt, synth, m, n)
+        out["roofline"]["shuffled_banded_probe"] = bench_banded_shuffled(kkt, synth, m, n)
     if rank == 0 and world == 1 and not args.no_basis:
         out["config"]["basis_path"] = bench_basis(kkt, synth, m, n, args)
     if rank == 0 and world == 1 and not args.no_lu:
@@ -417,6 +418,9 @@ def main():
                 summ[k + "_ms_per_solve"] = oc[k].get("ms_per_solve")
         if "roofline" in out and "banded_matrix_probe" in out["roofline"]:
             summ["banded_probe_frac"] = out["roofline"]["banded_matrix_probe"].get("frac")
+        if "roofline" in out and "shuffled_banded_probe" in out["roofline"]:
+            summ["shuffled_banded_probe_frac"] = out["roofline"]["shuffled_banded_probe"].get("frac_cr_iteration_apply")
+            summ["shuffled_banded_probe_frac_as_given"] = out["roofline"]["shuffled_banded_probe"].get("frac_as_given")
         if out.get("cpu_baseline"):
             summ["gpu_over_cpu"] = cfg.get("gpu_over_cpu")
         out["summary"] = summ
@@ -615,6 +619,51 @@ def bench_banded(kkt, synth, m, n):
     return {"us_per_apply": ms * 1e3, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9,
             "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "matrix": "8 rows per column within a 4096-row band",
             "layouts": list(layouts)}
+
+
+def bench_banded_shuffled(kkt, synth, m, n):
+    """The banded matrix of bench_banded with its rows and columns in random order -- structure a modelling tool has hidden.  ipxk_create
+    looks for a renumbering (breadth-first levels, layout_device.hip), keeps a renumbered copy if its two products are faster, and the CR
+    loop of the KKT solve runs on it.  Reported: the two products on the model as given (NormalMatrix::Apply through the ABI), on the
+    renumbered copy (the library's own timing at creation), and what a CR iteration of the KKT solve costs with and without the copy."""
+    import os, time
+    A, _, _ = synth.shuffled(synth.banded_lp(m, n, 8, 4096, 12345), 7)
+    st = synth.synthetic_ipm_state(m, n, 1.0, 12345)
+    tol = 0.3 * np.sqrt(st["mu"])
+    out = {"matrix": "8 rows per column within a 4096-row band, rows and columns randomly permuted"}
+    res = {}
+    for mode in ("0", None):
+        if mode is None: os.environ.pop("IPXK_REORDER", None)
+        else: os.environ["IPXK_REORDER"] = mode
+        t0 = time.time()
+        ctx = kkt.KktContext(A)
+        create_s = time.time() - t0
+        info = ctx.reorder_info()
+        assert ctx.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"]) == 0
+        ctx.set_pointer_mode(True)
+        a, b, x, y = ctx.vector(n + m, st["a"]), ctx.vector(m, st["b"]), ctx.vector(n + m), ctx.vector(m)
+        it, err, _ = ctx.kkt_diag_solve_resident(a, b, x, y, tol, 500)
+        ctx.synchronize()
+        t0 = time.time()
+        reps = 5
+        for _ in range(reps): it, err, tm = ctx.kkt_diag_solve_resident(a, b, x, y, tol, 500)
+        ctx.synchronize()
+        ms_solve = (time.time() - t0) / reps * 1e3
+        nbytes = ctx.normal_apply_bytes
+        res[mode] = dict(create_s=create_s, info=info, iters=it, errflag=err, ms_per_solve=ms_solve, us_per_cr_iteration=ms_solve * 1e3 / max(it + 1, 1), nbytes=nbytes)
+        ctx.close()
+    os.environ.pop("IPXK_REORDER", None)
+    i1 = res[None]["info"]
+    nb = res[None]["nbytes"]
+    out.update(renumbering_active=bool(i1["active"]), levels=int(i1["levels"]), reorder_ms=i1["ms"],
+               us_two_products_as_given=i1["us_original"], us_two_products_renumbered=i1["us_reordered"],
+               frac_as_given=(nb / (i1["us_original"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if i1["us_original"] else None,
+               frac_cr_iteration_apply=(nb / (i1["us_reordered"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if i1["us_reordered"] else None,
+               kkt_solve_as_given={k: res["0"][k] for k in ("iters", "errflag", "ms_per_solve", "us_per_cr_iteration")},
+               kkt_solve_renumbered={k: res[None][k] for k in ("iters", "errflag", "ms_per_solve", "us_per_cr_iteration")},
+               create_s_as_given=res["0"]["create_s"], create_s_with_renumbering=res[None]["create_s"],
+               note="frac_* = algorithmic bytes of one NormalMatrix::Apply over the time of its two products (epilogue without weights), timed by the library at creation on both copies")
+    return out
 
 
 # Sources whose kernels move the bytes the PMC summaries under profiles/ report.  A summary names the git blob hash

@@ -134,6 +134,23 @@ int ipxk_set_interrupt(ipxk_context* ctx, ipxint (*interrupt)(void* user), void*
  * (Control::lu_pivottol(), src/basis.cc:30; <= 0: 0.1).  The model and its layouts stay; workspaces stay allocated. */
 int ipxk_reset_solver_state(ipxk_context* ctx, double lu_pivottol);
 ipxint ipxk_num_dense_cols(const ipxk_context* ctx);
+/* The locality-recovering renumbering of the model ("row/column reordering ... must stay a pure permutation").
+ * ipxk_create looks for one -- breadth-first levels of the bipartite graph rows <-> columns from a pseudo-peripheral row, rows
+ * and columns numbered by (level, index) -- builds a second copy of the matrix in that numbering with gather layouts of its own,
+ * times NormalMatrix::Apply's two products on both copies and keeps the copy if it is at least 10 % faster.  Then the CR loop of
+ * ipxk_kkt_diag_solve (src/kkt_solver_diag.cc:98-99) runs on the copy: right-hand side, weights, preconditioner and residual
+ * scaling are permuted going in, y coming out; nothing else of the ABI sees the numbering.  Models with dense columns (the
+ * Sherman-Morrison-Woodbury preconditioner), partitioned contexts and models of fewer than 2^20 entries keep the numbering as given;
+ * a matrix without structure (half of its rows within 8 levels of any row) is recognised at once.  IPXK_REORDER=0: never, =1: always. */
+typedef struct {
+  ipxint active;             /* 1: the renumbered copy is in use */
+  ipxint levels, components; /* of the breadth-first structure */
+  double ms;                 /* cost inside ipxk_create */
+  double us_original, us_reordered;   /* the two products of one Apply on either copy (0: not timed) */
+} ipxk_reorder_info;
+int ipxk_get_reorder_info(const ipxk_context* ctx, ipxk_reorder_info* info);
+/* rowperm[m], colperm[n]: new index -> index as given (either may be NULL); fails if no renumbering was computed */
+int ipxk_get_reordering(ipxk_context* ctx, ipxint* rowperm, ipxint* colperm);
 /* Copies out the device-side row-wise matrix (for bit-exact index parity
  * tests against Transpose): ATp[m+1], ATi[nnz], ATx[nnz]; NULL skips. */
 int ipxk_get_rowwise(const ipxk_context* ctx, ipxint* ATp, ipxint* ATi,

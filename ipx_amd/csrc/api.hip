@@ -286,6 +286,33 @@ int ipxk_reset_solver_state(ipxk_context* c, double lu_pivottol) {
     });
 }
 
+int ipxk_get_reorder_info(const ipxk_context* c, ipxk_reorder_info* info) {
+    return guarded([&] {
+        IPXK_REQUIRE(c && info, "NULL argument");
+        const Reordered& R = c->reord;
+        info->active = R.active ? 1 : 0;
+        info->levels = R.levels;
+        info->components = R.components;
+        info->ms = R.ms;
+        info->us_original = R.us_original;
+        info->us_reordered = R.us_reordered;
+    });
+}
+
+int ipxk_get_reordering(ipxk_context* c, ipxint* rowperm, ipxint* colperm) {
+    return guarded([&] {
+        IPXK_REQUIRE(c, "NULL argument");
+        IPXK_REQUIRE(c->reord.rowperm.size() >= (size_t)c->m && c->reord.colperm.size() >= (size_t)c->n, "no renumbering of this model was computed");
+        bind_device(c);
+        std::vector<int> r((size_t)c->m), q((size_t)c->n);
+        c->reord.rowperm.download(r.data(), r.size(), c->stream);
+        c->reord.colperm.download(q.data(), q.size(), c->stream);
+        IPXK_HIP(hipStreamSynchronize(c->stream));
+        if (rowperm) for (size_t i = 0; i < r.size(); i++) rowperm[i] = r[i];
+        if (colperm) for (size_t j = 0; j < q.size(); j++) colperm[j] = q[j];
+    });
+}
+
 int ipxk_synchronize(ipxk_context* c) {
     return guarded([&] {
         IPXK_REQUIRE(c != nullptr, "ctx is NULL");

@@ -347,7 +347,7 @@ static CrResult run_cr(Context* c, const CrOps& ops, const double* rhs, double t
     CrVecs v;
     v.m = m; v.lhs = lhs; v.residual = c->v_residual.get(); v.sresidual = c->v_sresidual.get();
     v.step = c->v_step.get(); v.Cstep = c->v_Cstep.get(); v.Cres = c->v_Cres.get();
-    v.pCstep = c->v_pCstep.get(); v.resscale = resscale; v.diag = c->diagonal.get();
+    v.pCstep = c->v_pCstep.get(); v.resscale = resscale; v.diag = c->reord.in_use ? c->reord.diagonal.get() : c->diagonal.get();
 
     IPXK_HIP(hipEventRecord(c->ev_a, s));
 

@@ -116,6 +116,12 @@ void kkt_diag_factorize_dev(Context* c, const double* xl, const double* xu, cons
     c->normal_prepared = true;
     diag_factorize_dev(c, c->W, precond_dense_cols, errflag);
     if (*errflag) return;
+    if (c->reord.active && c->kdense == 0) {
+        // the CR loop will run in the renumbered model: weights, preconditioner and residual scaling in its numbering
+        reorder_permute_weights(c, c->W, c->reord.W.get());
+        reorder_permute_rows(c, c->diagonal.get(), c->reord.diagonal.get());
+        reorder_permute_rows(c, c->resscale.get(), c->reord.resscale.get());
+    }
     c->kkt_diag_factorized = true;
 }
 
@@ -143,9 +149,20 @@ CrResult kkt_diag_solve_dev(Context* c, const double* a, const double* b, double
     }
 
     // :95-105
-    IPXK_HIP(hipMemsetAsync(y, 0, sizeof(double) * m, s));
-    CrResult res = pcr_solve_dev(c, c->v_rhs.get(), tol, c->resscale.get(), maxiter, y, true, interrupt,
-                                 user, nullptr, 0, times);
+    CrResult res;
+    if (c->reord.active && c->kdense == 0 && !comm_active(c)) {
+        // rows renumbered for locality: the right-hand side goes over, the loop runs on the renumbered copy, y comes back --
+        // pure permutations on either side of the same arithmetic (row sums in the renumbered order of a row's entries)
+        Reordered& R = c->reord;
+        reorder_permute_rows(c, c->v_rhs.get(), R.rhs.get());
+        IPXK_HIP(hipMemsetAsync(R.y.get(), 0, sizeof(double) * m, s));
+        struct InUse { Reordered& R; explicit InUse(Reordered& r) : R(r) { R.in_use = true; } ~InUse() { R.in_use = false; } } in_use(R);
+        res = pcr_solve_dev(c, R.rhs.get(), tol, R.resscale.get(), maxiter, R.y.get(), true, interrupt, user, nullptr, 0, times);
+        reorder_unpermute_rows(c, R.y.get(), y);
+    } else {
+        IPXK_HIP(hipMemsetAsync(y, 0, sizeof(double) * m, s));
+        res = pcr_solve_dev(c, c->v_rhs.get(), tol, c->resscale.get(), maxiter, y, true, interrupt, user, nullptr, 0, times);
+    }
 
     // :108-117
     if (comm_rows(c)) {

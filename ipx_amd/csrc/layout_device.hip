@@ -841,42 +841,72 @@ void sort_pairs_u64(Tmp& T, const K* kin, K* kout, const unsigned* vin, unsigned
 
 // breadth-first levels of the bipartite graph from row `start`; rows and columns not yet reached only.  Returns the number of row
 // levels added (level numbers continue from level0), the rows reached, and the smallest row of the last row frontier.
+// No host round trip per level: the kernels take the size of their frontier from a ring of three device counters (a level's kernel
+// zeroes the counters two levels ahead), the sizes go into a history array, and the host looks at the history every kBfsBatch levels --
+// launches past the last level find an empty frontier and do nothing.
+constexpr int kBfsBatch = 16;
+constexpr int kBfsMaxLevels = 1 << 20;
+__global__ void bfs_level_kernel(const int* __restrict__ frontier, const int* __restrict__ ptr, const int* __restrict__ idx, int* level_of, int level,
+                                 int* __restrict__ next, const int* count_in, int* count_out, int* zero_a, int* zero_b, int* hist_slot) {
+    const int nf = *count_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (zero_a) *zero_a = 0;
+        if (zero_b) *zero_b = 0;
+        if (hist_slot) *hist_slot = nf;
+    }
+    IPXK_GS(t, nf) {
+        const int v = frontier[t];
+        for (int p = ptr[v]; p < ptr[v + 1]; p++) {
+            const int w = idx[p];
+            if (level_of[w] < 0 && atomicCAS(&level_of[w], -1, level) == -1) next[atomicAdd(count_out, 1)] = w;
+        }
+    }
+}
 struct BfsOut { int levels = 0; int64_t rows = 0; int last_min = -1; int64_t rows_by_8 = 0; };
-BfsOut bfs_levels(Context* c, int start, int level0, int* row_level, int* col_level, int* fr, int* fc, int* counters, int* h) {
+BfsOut bfs_levels(Context* c, int start, int level0, int* row_level, int* col_level, int* fr, int* fc, int* ring, int* hist, std::vector<int>& hh) {
     hipStream_t s = c->stream;
-    const int m = (int)c->m, n = (int)c->n;
-    (void)m; (void)n;
     BfsOut out;
+    // ring: cntR[3] at ring[0..2], cntC[3] at ring[3..5]
+    const int init[6] = {1, 0, 0, 0, 0, 0};
+    IPXK_HIP(hipMemcpyAsync(ring, init, sizeof(init), hipMemcpyHostToDevice, s));
     IPXK_HIP(hipMemcpyAsync(row_level + start, &level0, sizeof(int), hipMemcpyHostToDevice, s));
     IPXK_HIP(hipMemcpyAsync(fr, &start, sizeof(int), hipMemcpyHostToDevice, s));
-    int nf = 1, level = level0;
-    out.rows = 1;
-    out.last_min = start;
-    while (nf > 0) {
-        IPXK_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(int), s));
-        // the columns of the frontier's rows get this level; the rows of those columns the next one
-        hipLaunchKernelGGL(bfs_expand_kernel, dim3(gridn(nf)), dim3(kBlock), 0, s, nf, fr, c->pl_Tp.get(), c->pl_Ti.get(), col_level, level, fc, counters);
-        IPXK_HIP(hipMemcpyAsync(h, counters, sizeof(int), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipStreamSynchronize(s));                    // (init, start, level0 are stack variables)
+    const int grid = 2048;
+    int L = 0, found = -1;
+    hh.clear();
+    while (found < 0 && L < kBfsMaxLevels) {
+        for (int b = 0; b < kBfsBatch; b++, L++) {
+            int* cntR = ring + L % 3;
+            int* cntC = ring + 3 + L % 3;
+            // rows of level L -> their columns (level L); zeroes cntR[L+2] and cntC[L+1]; history of the row frontier sizes
+            hipLaunchKernelGGL(bfs_level_kernel, dim3(grid), dim3(kBlock), 0, s, fr, c->pl_Tp.get(), c->pl_Ti.get(), col_level, level0 + L, fc, cntR, cntC,
+                               ring + (L + 2) % 3, ring + 3 + (L + 1) % 3, hist + L);
+            // those columns -> rows of level L + 1
+            hipLaunchKernelGGL(bfs_level_kernel, dim3(grid), dim3(kBlock), 0, s, fc, c->pl_Ap.get(), c->pl_Ai.get(), row_level, level0 + L + 1, fr, cntC,
+                               ring + (L + 1) % 3, (int*)nullptr, (int*)nullptr, (int*)nullptr);
+        }
+        hh.resize((size_t)L);
+        IPXK_HIP(hipMemcpyAsync(hh.data() + (L - kBfsBatch), hist + (L - kBfsBatch), kBfsBatch * sizeof(int), hipMemcpyDeviceToHost, s));
         IPXK_HIP(hipStreamSynchronize(s));
-        const int nc = h[0];
-        if (nc == 0) break;
-        hipLaunchKernelGGL(bfs_expand_kernel, dim3(gridn(nc)), dim3(kBlock), 0, s, nc, fc, c->pl_Ap.get(), c->pl_Ai.get(), row_level, level + 1, fr, counters + 1);
-        IPXK_HIP(hipMemcpyAsync(h, counters + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-        IPXK_HIP(hipStreamSynchronize(s));
-        nf = h[0];
-        if (nf == 0) break;
-        level++;
-        out.rows += nf;
-        if (level - level0 <= 8) out.rows_by_8 = out.rows;
-        // smallest row of this frontier (the start of the second pass if it turns out to be the last one)
-        const int big = 0x7fffffff;
-        IPXK_HIP(hipMemcpyAsync(counters + 2, &big, sizeof(int), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(min_of_list_kernel, dim3(gridn(nf)), dim3(kBlock), 0, s, nf, fr, counters + 2);
-        IPXK_HIP(hipMemcpyAsync(h + 1, counters + 2, sizeof(int), hipMemcpyDeviceToHost, s));
-        IPXK_HIP(hipStreamSynchronize(s));
-        out.last_min = h[1];
+        for (int l = L - kBfsBatch; l < L; l++) if (hh[(size_t)l] == 0) { found = l; break; }
     }
-    out.levels = level - level0 + 1;
+    if (found < 0) found = L;
+    out.levels = found;                                   // row levels level0 .. level0 + found - 1
+    for (int l = 0; l < found; l++) { out.rows += hh[(size_t)l]; if (l <= 8) out.rows_by_8 = out.rows; }
+    // the last non-empty row frontier is still in fr (later launches wrote nothing)
+    const int last_nf = found > 0 ? hh[(size_t)found - 1] : 0;
+    if (last_nf > 0) {
+        const int big = 0x7fffffff;
+        int got = big;
+        IPXK_HIP(hipMemcpyAsync(ring, &big, sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(min_of_list_kernel, dim3(gridn(last_nf)), dim3(kBlock), 0, s, last_nf, fr, ring);
+        IPXK_HIP(hipMemcpyAsync(&got, ring, sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipStreamSynchronize(s));
+        out.last_min = got == big ? start : got;
+    } else {
+        out.last_min = start;
+    }
     return out;
 }
 
@@ -894,7 +924,8 @@ void reorder_model(Context* c) {
     hipStream_t s = c->stream;
     const auto t0 = std::chrono::steady_clock::now();
     auto ms_since0 = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-    DevBuf<int> row_level((size_t)m), col_level((size_t)n), fr((size_t)m), fc((size_t)n), counters(4);
+    DevBuf<int> row_level((size_t)m), col_level((size_t)n), fr((size_t)m), fc((size_t)n), counters(8), hist((size_t)kBfsMaxLevels);
+    std::vector<int> hh;
     int* h = nullptr;
     IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&h), 4 * sizeof(int)));
     struct Free { int* p; ~Free() { (void)hipHostFree(p); } } free_h{h};
@@ -904,9 +935,9 @@ void reorder_model(Context* c) {
     };
     auto first_unvisited = [&]() {
         const int big = 0x7fffffff;
-        IPXK_HIP(hipMemcpyAsync(counters.get() + 3, &big, sizeof(int), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(first_unvisited_kernel, dim3(gridn(m)), dim3(kBlock), 0, s, (int)m, row_level.get(), c->pl_Tp.get(), counters.get() + 3);
-        IPXK_HIP(hipMemcpyAsync(h + 2, counters.get() + 3, sizeof(int), hipMemcpyDeviceToHost, s));
+        IPXK_HIP(hipMemcpyAsync(counters.get() + 7, &big, sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(first_unvisited_kernel, dim3(gridn(m)), dim3(kBlock), 0, s, (int)m, row_level.get(), c->pl_Tp.get(), counters.get() + 7);
+        IPXK_HIP(hipMemcpyAsync(h + 2, counters.get() + 7, sizeof(int), hipMemcpyDeviceToHost, s));
         IPXK_HIP(hipStreamSynchronize(s));
         return h[2] == big ? -1 : h[2];
     };
@@ -914,7 +945,7 @@ void reorder_model(Context* c) {
     clear_levels();
     int start = first_unvisited();
     if (start < 0) return;
-    BfsOut b1 = bfs_levels(c, start, 0, row_level.get(), col_level.get(), fr.get(), fc.get(), counters.get(), h);
+    BfsOut b1 = bfs_levels(c, start, 0, row_level.get(), col_level.get(), fr.get(), fc.get(), counters.get(), hist.get(), hh);
     if (!force && b1.rows_by_8 * 2 >= m) {                  // an expander: no numbering helps
         R.levels = b1.levels;
         R.ms = ms_since0();
@@ -928,7 +959,7 @@ void reorder_model(Context* c) {
     int64_t reached = 0;
     start = b1.last_min;
     while (start >= 0 && comps < kMaxComponents) {
-        const BfsOut b = bfs_levels(c, start, level0, row_level.get(), col_level.get(), fr.get(), fc.get(), counters.get(), h);
+        const BfsOut b = bfs_levels(c, start, level0, row_level.get(), col_level.get(), fr.get(), fc.get(), counters.get(), hist.get(), hh);
         level0 += b.levels;
         reached += b.rows;
         comps++;

@@ -523,7 +523,7 @@ int diag_apply_dev(Context* c, const double* rhs, double* lhs, int slot, const i
     if (c->kdense == 0) {
         const int g = vec_grid(m);
         hipLaunchKernelGGL(diag_apply_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs,
-                           c->diagonal.get(), lhs, c->part(slot), done);
+                           c->reord.in_use ? c->reord.diagonal.get() : c->diagonal.get(), lhs, c->part(slot), done);
         return g;
     }
     const int k = (int)c->kdense;

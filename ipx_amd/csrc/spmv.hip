@@ -1261,6 +1261,16 @@ void normal_apply_dev(Context* c, const double* W, const double* rhs, double* lh
         if (ndot) *ndot = g;
         return;
     }
+    if (c->reord.in_use) {
+        // the CR loop of the diag path in the renumbered model (layout_device.hip): rhs, lhs and the weights in the new numbering
+        Reordered& R = c->reord;
+        EpiScale e1{{}, R.W.get(), R.tcols.get()};
+        launch_spmv(R.Acols, rhs, e1, nullptr, done, c->stream);
+        EpiNormalRows e2{{}, R.W.get() + n, rhs, lhs};
+        const int np = launch_spmv(R.Arows, R.tcols.get(), e2, ndot ? c->part(kPartCdot) : nullptr, done, c->stream);
+        if (ndot) *ndot = np;
+        return;
+    }
     double* stage = comm_rows(c) ? comm_stage(c, (size_t)n) : nullptr;
     EpiScale e1{{}, W, stage ? stage : c->tcols.get()};
     launch_spmv(c->Acols, rhs, e1, nullptr, done, c->stream);

@@ -25,7 +25,7 @@ NONBASIC_FIXED, NONBASIC, BASIC, BASIC_FREE = -2, -1, 0, 1
 
 EXPORTS = [
     "ipxk_last_error", "ipxk_device_count", "ipxk_create", "ipxk_destroy", "ipxk_set_pointer_mode",
-    "ipxk_set_stream", "ipxk_synchronize", "ipxk_set_profiling", "ipxk_set_interrupt", "ipxk_reset_solver_state", "ipxk_num_dense_cols", "ipxk_get_rowwise",
+    "ipxk_set_stream", "ipxk_synchronize", "ipxk_set_profiling", "ipxk_set_interrupt", "ipxk_reset_solver_state", "ipxk_get_reorder_info", "ipxk_get_reordering", "ipxk_num_dense_cols", "ipxk_get_rowwise",
     "ipxk_normal_prepare", "ipxk_normal_apply", "ipxk_diag_factorize", "ipxk_diag_apply",
     "ipxk_diag_get", "ipxk_pcr_solve", "ipxk_cr_diagnostics", "ipxk_kkt_diag_factorize", "ipxk_kkt_diag_solve",
     "ipxk_kkt_diag_get", "ipxk_split_prepare", "ipxk_split_rescale", "ipxk_split_apply", "ipxk_forward_solve",
@@ -56,6 +56,10 @@ class LuInfo(C.Structure):
                 ("row_singletons", c_i64), ("bump", c_i64), ("rounds", c_i64), ("seconds_singletons", c_f64),
                 ("seconds_bump", c_f64), ("seconds_assemble", c_f64), ("spikes", c_i64), ("sparse_pivots", c_i64),
                 ("sparse_rounds", c_i64), ("reused", c_i64)]
+
+
+class ReorderInfo(C.Structure):
+    _fields_ = [("active", c_i64), ("levels", c_i64), ("components", c_i64), ("ms", c_f64), ("us_original", c_f64), ("us_reordered", c_f64)]
 
 
 class MaxvolumeParams(C.Structure):
@@ -233,6 +237,18 @@ class KktContext:
 
     def synchronize(self):
         self._check(self.lib.ipxk_synchronize(self.h))
+
+    def reorder_info(self):
+        """the locality-recovering renumbering ipxk_create found (or not): dict(active, levels, components, ms, us_original, us_reordered)"""
+        info = ReorderInfo()
+        self._check(self.lib.ipxk_get_reorder_info(self.h, C.byref(info)))
+        return {name: getattr(info, name) for name, _ in ReorderInfo._fields_}
+
+    def reordering(self):
+        """(rowperm, colperm): new index -> index as given"""
+        r, q = np.zeros(self.m, i64), np.zeros(self.n, i64)
+        self._check(self.lib.ipxk_get_reordering(self.h, _ip(r), _ip(q)))
+        return r, q
 
     def reset_solver_state(self, lu_pivottol=0.0):
         """the context as a new solver object finds it (HipModel hands a cached context out through this): nothing prepared /

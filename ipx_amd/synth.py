@@ -88,6 +88,17 @@ def banded_lp(m, n, k=8, bandwidth=4096, seed=12345):
     return CscMatrix(m, n, np.arange(n + 1, dtype=i64) * k, rows.reshape(-1), vals.reshape(-1))
 
 
+def shuffled(A, seed=12345):
+    """A with rows and columns in random order: (P A Q, rowperm, colperm) with row i of the result = row rowperm[i] of A.
+    What banded_lp looks like after a modelling tool has emitted its rows and columns in no particular order."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    rp, cp = rng.permutation(A.nrow).astype(i64), rng.permutation(A.ncol).astype(i64)
+    M = sp.csc_matrix((A.x, A.i, A.p), shape=(A.nrow, A.ncol))[rp][:, cp].tocsc()
+    M.sort_indices()
+    return CscMatrix(A.nrow, A.ncol, M.indptr.astype(i64), M.indices.astype(i64), M.data.astype(f64)), rp, cp
+
+
 def synthetic_ipm_state(m, n, spread=1.0, seed=12345):
     """xl, zl = 10^(spread*U[-1,1]) independently, xu=inf, zu=0 (W_j = xl_j/zl_j spans
     4*spread decades); a, b ~ U[-0.5,0.5).  Returns dict with xl,xu,zl,zu,mu,a,b."""
