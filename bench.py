@@ -318,8 +318,19 @@ def main():
                                % (kernel_names[layouts[0]], kernel_names[layouts[1]]),
                      "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                      "traffic": traffic, "traffic_note": traffic_note, "us_per_apply": apply_ms * 1e3, "algorithmic_bytes": bytes_apply,
-                     "layouts": list(layouts), "layout_tuning_us": tuned_us},
+                     "layouts": list(layouts), "layout_tuning_us": tuned_us,
+                     "note_50_percent": "the north star's >= 0.50 is NOT reached on this matrix: its row indices are uniformly random, every pass "
+                                        "gathers 8-byte words from 8 M distinct 128-byte lines, and the chip serves such gathers from L2 / fabric at "
+                                        "the rate this fraction reflects (profiles/r04_ldsacc_microbench.txt, r03_gather_sorted_microbench.txt); no "
+                                        "renumbering helps (an expander: ipxk_create finds half of the rows within 8 levels of any row).  With locality "
+                                        "the same kernels reach it: banded_matrix_probe, and shuffled_banded_probe where the locality is first "
+                                        "recovered by the renumbering of layout_device.hip"},
     }
+    try:
+        ri = ctx.reorder_info()
+        out["roofline"]["renumbering"] = {"active": bool(ri["active"]), "levels": int(ri["levels"]), "ms_in_create": ri["ms"]}
+    except Exception:            # noqa: BLE001
+        pass
 
     if (world > 1 or os.environ.get("IPXK_FORCE_COMM")) and not args.no_column_partition:
         # every rank takes part; reported next to the north-star row partition, never as `value`
@@ -423,6 +434,12 @@ def main():
             summ["shuffled_banded_probe_frac_as_given"] = out["roofline"]["shuffled_banded_probe"].get("frac_as_given")
         if out.get("cpu_baseline"):
             summ["gpu_over_cpu"] = cfg.get("gpu_over_cpu")
+        ib = cfg.get("lu_path", {}).get("ipm_basis_16000", {})
+        if "default_policy" in ib:
+            summ["lu_ipm_basis_16000_ms"] = ib["default_policy"]["factorize_ms"]
+            summ["lu_ipm_basis_16000_fill"] = ib["default_policy"]["fill_factor"]
+            summ["lu_ipm_basis_16000_round4_policy_ms"] = ib.get("round4_policy", {}).get("factorize_ms")
+            summ["lu_ipm_basis_16000_round4_policy_fill"] = ib.get("round4_policy", {}).get("fill_factor")
         out["summary"] = summ
     if rank == 0:
         out["multi_gpu_note"] = ("N > 1 is launched by the driver only; no 8-GPU curve exists in this repo until a "
@@ -825,8 +842,9 @@ def bench_lu(kkt, synth, m, n, args, bump=1000):
         basis2[rng.choice(m, 200, replace=False)] = rng.choice(np.nonzero(P["status"][:n] == -1)[0], 200, replace=False)
         hard = {"workload": "the same basis after 200 exchanges at random positions (singular: the dependent columns are replaced by unit columns)"}
         old_env = os.environ.get("IPXK_LU_SPARSE")
-        for mode, label in (("0", "tearing"), ("1", "elimination_rounds")):
-            os.environ["IPXK_LU_SPARSE"] = mode
+        for mode, label in (("0", "tearing"), ("1", "elimination_rounds"), (None, "default_policy")):
+            if mode is None: os.environ.pop("IPXK_LU_SPARSE", None)
+            else: os.environ["IPXK_LU_SPARSE"] = mode
             for _ in range(2):
                 t0 = time.perf_counter()
                 Fh = ctx.lu_factorize_basis(basis2, 0.1, download=False)
@@ -840,6 +858,29 @@ def bench_lu(kkt, synth, m, n, args, bump=1000):
         res["beyond_the_dense_limit"] = hard
     except Exception as e:            # noqa: BLE001 -- an auxiliary measurement must not take the bench line down
         res["beyond_the_dense_limit"] = {"error": str(e)[:200]}
+    # a basis of the IPM on a random 16000 x 40000 LP (tests/golden/ipm_basis_16000.npz): the policy of round 5 (elimination rounds, then a
+    # dense rest on the matrix cores with cooperative panels) against round 4's (tearing / the bump dense as it stands)
+    try:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "ipm_basis_16000.npz"))
+        dim, Bp, Bi, Bx = int(g["dim"]), g["Bp"].astype(np.int64), g["Bi"].astype(np.int64), g["Bx"]
+        ipm = {"workload": "a basis of the reference's IPM on general_lp(16000, 40000, 31): nnz(B) %d; the sequential minimum-Markowitz elimination "
+                           "of its pattern ends with 22.19 M entries (profiles/r05_lu_fill_study.txt)" % len(Bi)}
+        old_env = os.environ.get("IPXK_LU_SPARSE")
+        for mode, label in ((None, "default_policy"), ("t", "round4_policy")):
+            if mode is None: os.environ.pop("IPXK_LU_SPARSE", None)
+            else: os.environ["IPXK_LU_SPARSE"] = mode
+            for _ in range(2):
+                t0 = time.perf_counter()
+                Fi = ctx.lu_factorize(dim, Bp[:-1], Bp[1:], Bi, Bx, 0.1, download=False)
+                dt = time.perf_counter() - t0
+            ipm[label] = {"factorize_ms": dt * 1e3, "nnz_L_plus_U": Fi["lnz"] + Fi["unz"], "fill_factor": (Fi["lnz"] + Fi["unz"]) / len(Bi),
+                          "dense_block": Fi["bump"], "sparse_pivots": Fi["sparse_pivots"], "sparse_rounds": Fi["sparse_rounds"], "spikes": Fi["spikes"],
+                          "dense_block_ms": Fi["seconds_bump"] * 1e3}
+        if old_env is None: os.environ.pop("IPXK_LU_SPARSE", None)
+        else: os.environ["IPXK_LU_SPARSE"] = old_env
+        res["ipm_basis_16000"] = ipm
+    except Exception as e:            # noqa: BLE001
+        res["ipm_basis_16000"] = {"error": str(e)[:200]}
     if not args.no_cpu_baseline:
         from oracle import pyoracle
         Fd = ctx.lu_factorize_basis(P["basis"], 0.1, download=True)

@@ -33,8 +33,19 @@ def test_host_classes_compile_against_reference_headers():
            "-I" + os.path.join(ref, "include"), "-I" + os.path.join(ref, "src")]
     subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "ipx_amd", "host"),
                            os.path.join(ROOT, "tests", "dropin", "handoff_main.cc")])      # the glue needs no reference header
-    for f in ("kkt_solver_diag_hip.cc", "kkt_solver_basis_hip.cc", "lu_kernel_hip.cc"):
+    for f in ("kkt_solver_diag_hip.cc", "lu_kernel_hip.cc"):
         subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only"] + inc + [os.path.join(ROOT, "ipx_amd", "host", f)])
+    # kkt_solver_basis_hip.cc calls the reference's private KKTSolverBasis::DropPrimal / DropDual: it compiles against
+    # src/kkt_solver_basis.h WITH the one friend line of INTEGRATION.md (applied to the preprocessed unit, as oracle/Makefile does)
+    # and is rejected without it
+    src = os.path.join(ROOT, "ipx_amd", "host", "kkt_solver_basis_hip.cc")
+    pre = subprocess.run(["g++", "-std=c++11", "-E"] + inc + [src], capture_output=True, text=True, check=True).stdout
+    line = "class KKTSolverBasis : public KKTSolver {"
+    assert pre.count(line) == 1
+    subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++-cpp-output", "-"], input=pre.replace(line, line + " friend class KKTSolverBasisHip;"),
+                   text=True, check=True)
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++-cpp-output", "-"], input=pre, text=True, capture_output=True)
+    assert r.returncode != 0 and "private" in r.stderr
     subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++"] + inc + ["-"],
                    input='#include "linear_operators_hip.h"\n', text=True, check=True)
 
