@@ -842,19 +842,21 @@ def bench_lu(kkt, synth, m, n, args, bump=1000):
         basis2[rng.choice(m, 200, replace=False)] = rng.choice(np.nonzero(P["status"][:n] == -1)[0], 200, replace=False)
         hard = {"workload": "the same basis after 200 exchanges at random positions (singular: the dependent columns are replaced by unit columns)"}
         old_env = os.environ.get("IPXK_LU_SPARSE")
-        for mode, label in (("0", "tearing"), ("1", "elimination_rounds"), (None, "default_policy")):
-            if mode is None: os.environ.pop("IPXK_LU_SPARSE", None)
-            else: os.environ["IPXK_LU_SPARSE"] = mode
-            for _ in range(2):
-                t0 = time.perf_counter()
-                Fh = ctx.lu_factorize_basis(basis2, 0.1, download=False)
-                dt = time.perf_counter() - t0
-            hard[label] = {"factorize_ms": dt * 1e3, "fill_factor": (Fh["lnz"] + Fh["unz"]) / nb, "spikes": Fh["spikes"], "sparse_pivots": Fh["sparse_pivots"],
-                           "sparse_rounds": Fh["sparse_rounds"], "dense_block": Fh["bump"], "rounds": Fh["rounds"], "dependent": Fh["num_dependent"]}
-        if old_env is None:
-            os.environ.pop("IPXK_LU_SPARSE", None)
-        else:
-            os.environ["IPXK_LU_SPARSE"] = old_env
+        try:
+          for mode, label in (("0", "tearing"), ("1", "elimination_rounds"), (None, "default_policy")):
+              if mode is None: os.environ.pop("IPXK_LU_SPARSE", None)
+              else: os.environ["IPXK_LU_SPARSE"] = mode
+              for _ in range(2):
+                  t0 = time.perf_counter()
+                  Fh = ctx.lu_factorize_basis(basis2, 0.1, download=False)
+                  dt = time.perf_counter() - t0
+              hard[label] = {"factorize_ms": dt * 1e3, "fill_factor": (Fh["lnz"] + Fh["unz"]) / nb, "spikes": Fh["spikes"], "sparse_pivots": Fh["sparse_pivots"],
+                             "sparse_rounds": Fh["sparse_rounds"], "dense_block": Fh["bump"], "rounds": Fh["rounds"], "dependent": Fh["num_dependent"]}
+        finally:
+          if old_env is None:
+              os.environ.pop("IPXK_LU_SPARSE", None)
+          else:
+              os.environ["IPXK_LU_SPARSE"] = old_env
         res["beyond_the_dense_limit"] = hard
     except Exception as e:            # noqa: BLE001 -- an auxiliary measurement must not take the bench line down
         res["beyond_the_dense_limit"] = {"error": str(e)[:200]}
@@ -866,18 +868,20 @@ def bench_lu(kkt, synth, m, n, args, bump=1000):
         ipm = {"workload": "a basis of the reference's IPM on general_lp(16000, 40000, 31): nnz(B) %d; the sequential minimum-Markowitz elimination "
                            "of its pattern ends with 22.19 M entries (profiles/r05_lu_fill_study.txt)" % len(Bi)}
         old_env = os.environ.get("IPXK_LU_SPARSE")
-        for mode, label in ((None, "default_policy"), ("t", "round4_policy")):
-            if mode is None: os.environ.pop("IPXK_LU_SPARSE", None)
-            else: os.environ["IPXK_LU_SPARSE"] = mode
-            for _ in range(2):
-                t0 = time.perf_counter()
-                Fi = ctx.lu_factorize(dim, Bp[:-1], Bp[1:], Bi, Bx, 0.1, download=False)
-                dt = time.perf_counter() - t0
-            ipm[label] = {"factorize_ms": dt * 1e3, "nnz_L_plus_U": Fi["lnz"] + Fi["unz"], "fill_factor": (Fi["lnz"] + Fi["unz"]) / len(Bi),
-                          "dense_block": Fi["bump"], "sparse_pivots": Fi["sparse_pivots"], "sparse_rounds": Fi["sparse_rounds"], "spikes": Fi["spikes"],
-                          "dense_block_ms": Fi["seconds_bump"] * 1e3}
-        if old_env is None: os.environ.pop("IPXK_LU_SPARSE", None)
-        else: os.environ["IPXK_LU_SPARSE"] = old_env
+        try:
+            for mode, label in ((None, "default_policy"), ("t", "round4_policy")):
+                if mode is None: os.environ.pop("IPXK_LU_SPARSE", None)
+                else: os.environ["IPXK_LU_SPARSE"] = mode
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    Fi = ctx.lu_factorize(dim, Bp[:-1], Bp[1:], Bi, Bx, 0.1, download=False)
+                    dt = time.perf_counter() - t0
+                ipm[label] = {"factorize_ms": dt * 1e3, "nnz_L_plus_U": Fi["lnz"] + Fi["unz"], "fill_factor": (Fi["lnz"] + Fi["unz"]) / len(Bi),
+                              "dense_block": Fi["bump"], "sparse_pivots": Fi["sparse_pivots"], "sparse_rounds": Fi["sparse_rounds"], "spikes": Fi["spikes"],
+                              "dense_block_ms": Fi["seconds_bump"] * 1e3}
+        finally:
+            if old_env is None: os.environ.pop("IPXK_LU_SPARSE", None)
+            else: os.environ["IPXK_LU_SPARSE"] = old_env
         res["ipm_basis_16000"] = ipm
     except Exception as e:            # noqa: BLE001
         res["ipm_basis_16000"] = {"error": str(e)[:200]}

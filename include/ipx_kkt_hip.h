@@ -584,12 +584,20 @@ int ipxk_spmv_layout(const ipxk_context* ctx, int layout[2], double us[6]);
  * is not, and IPX's late bases are ill conditioned by construction (that is what
  * the stability loop of src/basis.cc:130-152 and the residual test of
  * src/lu_factorization.cc:87-127 are for).  Every inverse is therefore probed at
- * Prepare with two fixed vectors, || T (M z) - z ||_inf <= 1e-10 (IPXK_INVERSE_TOL),
- * and a block that fails keeps its level-scheduled / blocked solve.  Returns the
- * number of probes, of rejected inverses and the worst residual seen since
- * ipxk_create. */
+ * Prepare with two fixed vectors, || T (M z) - z ||_inf: the inverted levels of a
+ * sweep must meet 1e-10, the inverse of a dense block of the factors 1e-8
+ * (IPXK_INVERSE_TOL sets both).  A dense block's inverse from the matrix cores that
+ * misses 1e-8 gets up to two refinement steps X += X (I - D X) first
+ * (IPXK_DENSE_INVERSE_REFINE); one that still misses it but stays below 1e-5 is held
+ * against the blocked solve it would replace, probed with the same two vectors, and
+ * kept if it is within four times that solve's own residual (an ill-conditioned
+ * block leaves neither at 1e-8).  A block that fails keeps its level-scheduled /
+ * blocked solve.  Returns the number of probes, of rejected inverses and the worst
+ * accepted residual seen since ipxk_create; ipxk_split_inverse_refined the number
+ * of refinement steps taken. */
 int ipxk_split_inverse_stats(const ipxk_context* ctx, ipxint* probes,
                              ipxint* rejected, double* worst_residual);
+ipxint ipxk_split_inverse_refined(const ipxk_context* ctx);
 /* Inspection of the device layouts (tests: the layouts built on the device by
  * radix sorts, layout_device.hip, against the host builders, array by array;
  * IPXK_LAYOUT_BUILD=host forces the host builders).  The reference's

@@ -1002,6 +1002,8 @@ int ipxk_split_inverse_stats(const ipxk_context* c, ipxint* probes, ipxint* reje
     });
 }
 
+ipxint ipxk_split_inverse_refined(const ipxk_context* c) { return c ? (ipxint)c->split_stats.inverse_refined : 0; }
+
 // Layout inspection (tests/test_gpu_layout.py: the device builders against the host builders, array by array).
 int ipxk_layout_info(const ipxk_context* c, int which, ipxint info[40], double create_ms[4]) {
     return guarded([&] {

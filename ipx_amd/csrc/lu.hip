@@ -1216,6 +1216,7 @@ __global__ __launch_bounds__(kBlock) void sp_win_kernel(Sparse S, int* __restric
         if (win) {
             const long long n64 = (long long)S.rc[i] * S.cc[j];
             if (n64 > (1LL << 28)) *bad = 1; else n = (int)n64;
+            atomicAdd(reinterpret_cast<unsigned long long*>(S.stats + 42), (unsigned long long)n);       // the round's total in 64 bits (the int scan below wraps beyond 2^31)
             atomicAdd(S.stats + 3, 1);
             atomicAdd(S.stats + 4, S.rc[i] + S.cc[j] - 1);       // the entries of the pivot row and column leave the matrix
         }
@@ -1718,8 +1719,15 @@ SparseOut sparse_rounds(hipStream_t s, LuWork& W, int dim, int64_t nb, const int
         IPXK_HIP(hipMemcpyAsync(h + kSpStats, P.uoff.get() + dimL, sizeof(int), hipMemcpyDeviceToHost, s));
         IPXK_HIP(hipStreamSynchronize(s));
         const int nwin = h[3];
-        const int64_t nupd = h[kSpStats];
-        if (h[40]) throw Error(IPXK_E_UNSUPPORTED, "LU: a pivot of an elimination round would send out more than 2^28 updates");
+        int64_t nupd = h[kSpStats];
+        const int64_t nupd64 = (int64_t)(((unsigned long long)(unsigned)h[43] << 32) | (unsigned long long)(unsigned)h[42]);
+        if (h[40] || nupd64 + nnz >= (int64_t(1) << 31)) {
+            // more updates than 32-bit positions hold (a round of a matrix that has become dense): the dense code takes what is left if
+            // it can (round 5's policy), else the rounds are given up
+            if (fill_to_dense && dimL <= kb_max) break;
+            throw Error(IPXK_E_UNSUPPORTED, "LU: an elimination round would send out more updates than 32-bit positions hold");
+        }
+        nupd = nupd64;
         if (verbose)
             fprintf(stderr, "ipxk: elimination round %d: active %d nnz %lld cheapest %d limit %d candidates %d winners %d updates %lld\n", out.rounds + 1, dimL,
                     (long long)nnz, h[0], h[2], h[1], nwin, (long long)nupd);

@@ -34,7 +34,7 @@ EXPORTS = [
     "ipxk_iterate_residuals", "ipxk_iterate_complementarity", "ipxk_step_to_boundary", "ipxk_ipm_step", "ipxk_iterate_objectives", "ipxk_ipm_driver", "ipxk_iterate_factorize_diag", "ipxk_comm_unique_id", "ipxk_comm_init", "ipxk_comm_init_columns", "ipxk_comm_info", "ipxk_maxvolume_sequential",
     "ipxk_time_normal_apply", "ipxk_equilibrate", "ipxk_transpose", "ipxk_lu_factorize", "ipxk_lu_factorize_basis",
     "ipxk_lu_get_factors", "ipxk_lu_generation", "ipxk_split_prepare_lu", "ipxk_maxvolume", "ipxk_ipm_driver_basis",
-    "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_layout_info", "ipxk_layout_array", "ipxk_split_inverse_stats", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
+    "ipxk_normal_apply_bytes", "ipxk_spmv_layout", "ipxk_layout_info", "ipxk_layout_array", "ipxk_split_inverse_stats", "ipxk_split_inverse_refined", "ipxk_dev_alloc", "ipxk_dev_free", "ipxk_dev_upload",
     "ipxk_dev_download",
 ]
 
@@ -111,6 +111,7 @@ def load_library():
         L.ipxk_last_error.restype = C.c_char_p
         L.ipxk_num_dense_cols.restype = c_i64
         L.ipxk_lu_generation.restype = c_i64
+        L.ipxk_split_inverse_refined.restype = c_i64
         L.ipxk_normal_apply_bytes.restype = c_i64
         _lib = L
     return _lib
@@ -285,6 +286,10 @@ class KktContext:
         a, b, w = C.c_int64(0), C.c_int64(0), C.c_double(0.0)
         self._check(self.lib.ipxk_split_inverse_stats(self.h, C.byref(a), C.byref(b), C.byref(w)))
         return a.value, b.value, w.value
+
+    def split_inverse_refined(self):
+        """# refinement steps of dense-block inverses since the context was created"""
+        return int(self.lib.ipxk_split_inverse_refined(self.h))
 
     def layout_info(self, which):
         """Scalars of the device layouts of gather matrix `which` (0: A'y, 1: A t) and the create timings (ms)."""
