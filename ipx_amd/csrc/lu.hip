@@ -722,7 +722,7 @@ __global__ __launch_bounds__(kPanelThreads) void lu_panel_multi_kernel(Dense A, 
 // and has the pivot row with it.  No second exchange, no sub-panels, no side buffer.  Every entry still receives its updates one pivot at
 // a time in pivot order, products rounded before they are subtracted: the factors equal the other kernels' bit for bit.
 // All G workgroups must be resident at once: G <= 64 (two per compute unit fit) on 256 compute units, nothing else on the stream (the
-// look-ahead's late update runs under a CU mask that leaves 32 units free); a poll that does not see its target within kCoopSpinLimit polls raises an abort flag
+// look-ahead's late update runs under a CU mask that leaves 32 units free); a poll that does not see its word within kCoopSpinLimit polls raises an abort flag
 // that ends every workgroup, and the factorization fails loudly instead of hanging.
 constexpr int kCoopThreads = 256;
 constexpr int kCoopMaxG = 64;
@@ -736,18 +736,19 @@ struct CoopShared {
     int abort;
 };
 struct Coop {
-    double* slots;          // [2][G][kCoopSlot]
-    unsigned* bar;          // arrivals so far (monotonic over the launches of a factorization)
-    unsigned base;          // arrivals before this launch
+    double* slots;          // [5][G][kCoopSlot], every word the sentinel or a message
+    int set0;               // the set of this launch's first step (the steps of a factorization take the five sets in turn)
     int* abort_flag;
 };
+constexpr long long kCoopSentinel = 0x7ff8dead5eed0001LL;       // a quiet NaN with a payload of its own
 template <int R, int T>
 __device__ __forceinline__ void coop_steps(const Dense& A, CoopShared& sh, const Coop& C, double (&v)[R][kPanel], int c0, int c1, unsigned& active,
-                                           int& np, int& step, unsigned& arrived, bool& dead) {
+                                           int& np, int& step, bool& dead) {
     if constexpr (T < kPanel) {
         if (c0 + T >= c1 || dead) return;              // uniform over the grid
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = gridDim.x;
         const int row0 = blockIdx.x * R * kCoopThreads;
+        if (wave == 1 + (T & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the slot this wave reset two steps ago (see the exchange)
         double best = 0.0;
         int br = INT_MAX;
 #pragma unroll
@@ -782,36 +783,62 @@ __device__ __forceinline__ void coop_steps(const Dense& A, CoopShared& sh, const
                 }
         }
         __syncthreads();
-        // ---- the exchange
-        constexpr int par = T & 1;
-        double* mine = C.slots + ((size_t)par * G + blockIdx.x) * kCoopSlot;
-        if (wave == 0) {
-            if (lane < kCoopSlot) {
-                const double x = lane == 0 ? bv : lane == 1 ? __longlong_as_double((long long)rr) : sh.row[lane - 2];
-                __hip_atomic_store(mine + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // write-through
+        // ---- the exchange: a message IS its own flag.  FIVE sets of message slots are used in turn; a slot holds a sentinel (a NaN
+        // pattern no candidate, row index or matrix entry is) until its workgroup writes the step's message there, word by word with
+        // write-through stores and nothing else -- no drain, no counter: the readers poll every word past L1 until it is not the
+        // sentinel.  A slot is reset three steps before its next use (it held the messages of step t - 2, and by the time a workgroup
+        // has read all messages of step t everyone has published t - 1, i.e. finished reading t - 2); waves 1 and 2 take turns, and the
+        // wave that reset a slot at step t waits for that store at the START of step t + 2 -- two steps later, so the wait is free --
+        // in front of the barriers that precede the publication of step t + 2.  So whoever has seen a workgroup's message of step u
+        // finds that workgroup's slot of step u + 1 reset or already written, never stale.
+        const int set = (C.set0 + T) % 5;
+        double* mine = C.slots + ((size_t)set * G + blockIdx.x) * kCoopSlot;
+        if (wave == 0 && lane < kCoopSlot) {
+            const double x = lane == 0 ? bv : lane == 1 ? __longlong_as_double((long long)rr) : sh.row[lane - 2];
+            __hip_atomic_store(mine + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // write-through
+        }
+        const double* all = C.slots + (size_t)set * G * kCoopSlot;
+        int gone = 0;
+        {
+            // all of a thread's words are requested at once (independent loads: one round trip); only those still holding the
+            // sentinel are asked for again
+            constexpr int kPer = (kCoopMaxG * kCoopSlot + kCoopThreads - 1) / kCoopThreads;
+            const int nw = G * kCoopSlot;
+            double x[kPer];
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                const int e = tid + k * kCoopThreads;
+                x[k] = e < nw ? __hip_atomic_load(all + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) {
-                arrived += (unsigned)G;
-                const unsigned target = C.base + arrived;
-                __hip_atomic_fetch_add(C.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int spins = 0, gone = 0;
-                while ((int)(__hip_atomic_load(C.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > kCoopSpinLimit || ((spins & 1023) == 0 && __hip_atomic_load(C.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                        __hip_atomic_store(C.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        gone = 1;
-                        break;
-                    }
+            int spins = 0;
+            for (;;) {
+                bool pending = false;
+#pragma unroll
+                for (int k = 0; k < kPer; k++) pending |= __double_as_longlong(x[k]) == kCoopSentinel;
+                if (!pending) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kCoopSpinLimit || ((spins & 1023) == 0 && __hip_atomic_load(C.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_store(C.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gone = 1;
+                    break;
                 }
-                sh.abort = gone;
+#pragma unroll
+                for (int k = 0; k < kPer; k++)
+                    if (__double_as_longlong(x[k]) == kCoopSentinel) x[k] = __hip_atomic_load(all + tid + k * kCoopThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                const int e = tid + k * kCoopThreads;
+                if (e < nw) sh.slots[e] = x[k];
             }
         }
+        if (gone) sh.abort = 1;
         __syncthreads();
         if (sh.abort) { dead = true; return; }
-        const double* all = C.slots + (size_t)par * G * kCoopSlot;
-        for (int e = tid; e < G * kCoopSlot; e += kCoopThreads) sh.slots[e] = __hip_atomic_load(all + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
+        if (wave == 1 + (T & 1) && lane < kCoopSlot) {
+            double* ahead = C.slots + ((size_t)((set + 3) % 5) * G + blockIdx.x) * kCoopSlot;
+            __hip_atomic_store(ahead + lane, __longlong_as_double(kCoopSentinel), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // ---- the same winner everywhere
         double wv = lane < G ? sh.slots[lane * kCoopSlot] : 0.0;
         int wr = lane < G ? (int)__double_as_longlong(sh.slots[lane * kCoopSlot + 1]) : INT_MAX;
@@ -855,7 +882,7 @@ __device__ __forceinline__ void coop_steps(const Dense& A, CoopShared& sh, const
                 }
         }
         // (sh.slots / sh.row / red_* are rewritten only after the next step's first barrier, which every thread reaches after this read)
-        coop_steps<R, T + 1>(A, sh, C, v, c0, c1, active, np, step, arrived, dead);
+        coop_steps<R, T + 1>(A, sh, C, v, c0, c1, active, np, step, dead);
     }
 }
 template <int R>
@@ -876,9 +903,8 @@ __global__ __launch_bounds__(kCoopThreads) __attribute__((amdgpu_waves_per_eu(1,
     __syncthreads();
     int np = 0;
     int step = step_src ? step_src[0] : A.bstep[0];       // (look-ahead: the count so far is in the other set)
-    unsigned arrived = 0;
     bool dead = false;
-    coop_steps<R, 0>(A, sh, C, v, c0, c1, active, np, step, arrived, dead);
+    coop_steps<R, 0>(A, sh, C, v, c0, c1, active, np, step, dead);
     if (dead) return;                                      // nothing was written: the host finds the abort flag
 #pragma unroll
     for (int q = 0; q < R; q++)
@@ -1530,8 +1556,8 @@ struct LuWork {
     DevBuf<int> rloc, cloc, brow, bcol, brstep, bcstep, bstep, prow, pcol;
     DevBuf<double> ubuf;               // [kPanel][kb] the outer panel's rows of U, contiguous (MFMA trailing update)
     DevBuf<double> usub;               // [sub-panel pivot][kPanel] a sub-panel's rows of U in the rest of the outer panel
-    DevBuf<double> coop_slots;         // cooperative outer panel: the workgroups' messages, [2][kCoopMaxG][kCoopSlot]
-    DevBuf<unsigned> coop_bar;         // [0] arrivals, [1] abort flag
+    DevBuf<double> coop_slots;         // cooperative outer panel: the workgroups' messages, [5][kCoopMaxG][kCoopSlot]
+    DevBuf<unsigned> coop_bar;         // [1] abort flag
     DevBuf<u64> cand_bits, claim_abs, skey, skey2, lkey, lkey2, ukey, ukey2;
     DevBuf<double> pivot, D, lval, lval2, uval, uval2;
     DevBuf<unsigned char> ckind;
@@ -2229,10 +2255,12 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
                 if ((r == 1 || r == 2) && r >= coopR) coopR = r;
             }
             const int coopG = (kb + coopR * kCoopThreads - 1) / (coopR * kCoopThreads);
-            unsigned coop_base = 0;
+            int coop_steps_done = 0;
             if (coop) {
-                W_.coop_slots.ensure((size_t)2 * kCoopMaxG * kCoopSlot); W_.coop_bar.ensure(2);
+                W_.coop_slots.ensure((size_t)5 * kCoopMaxG * kCoopSlot); W_.coop_bar.ensure(2);
                 IPXK_HIP(hipMemsetAsync(W_.coop_bar.get(), 0, 2 * sizeof(unsigned), s));
+                hipLaunchKernelGGL(lu_fill_u64_kernel, dim3(8), dim3(kBlock), 0, s, (int64_t)5 * kCoopMaxG * kCoopSlot, (u64)kCoopSentinel,
+                                   reinterpret_cast<u64*>(W_.coop_slots.get()));
             }
             int k = 0, last_late = -1;                  // outer panel index; the last outer panel with a late update in flight
             for (int c0 = 0; c0 < kb; c0 += kPanel, k++) {
@@ -2240,10 +2268,10 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
                 const Dense& P = lookahead ? Ap[k & 1] : A;
                 const int* step_src = (lookahead && k > 0) ? Ap[(k - 1) & 1].bstep : nullptr;
                 if (coop) {
-                    const Coop C{W_.coop_slots.get(), W_.coop_bar.get(), coop_base, reinterpret_cast<int*>(W_.coop_bar.get() + 1)};
+                    const Coop C{W_.coop_slots.get(), coop_steps_done % 5, reinterpret_cast<int*>(W_.coop_bar.get() + 1)};
                     if (coopR == 1) hipLaunchKernelGGL((lu_panel_coop_kernel<1>), dim3(coopG), dim3(kCoopThreads), 0, s, P, C, c0, c1o, step_src);
                     else hipLaunchKernelGGL((lu_panel_coop_kernel<2>), dim3(coopG), dim3(kCoopThreads), 0, s, P, C, c0, c1o, step_src);
-                    coop_base += (unsigned)((c1o - c0) * coopG);
+                    coop_steps_done += c1o - c0;
                 }
                 // (measured and dropped: the whole outer panel in ONE launch, the sub-panels' updates of the rest of the outer
                 // panel by that one workgroup too -- bit-identical, but one CU moves those kb x 28 columns at 50-100 GB/s:

@@ -512,7 +512,8 @@ struct MaxvolState {
 void destroy_maxvol(MaxvolState* M) { delete M; }
 
 // The etas of the exchanges since the last refactorization (both Maxvolume variants): dense rows (mv_eta_dense_*) where the
-// K x m matrix fits, else the compact lists walked one after the other.  When to refactorize: after max_etas exchanges (the
+// K x m matrix fits and pays (EtaFile::reset: long vectors with short etas -- the slack bases of a 1M-row model -- keep the lists), else the
+// compact lists walked one after the other.  When to refactorize: after max_etas exchanges (the
 // reference's update limit, src/maxvolume.cc:318-319) -- or, with max_etas < 0 (what KKTSolverBasisHip passes), when the time
 // the etas have cost since the last refactorization reaches the time a refactorization costs, both taken from a MODEL so that a
 // run does not depend on the clock: a refactorization 25 ms + 3.5e-13 s x (rows of the dense block)^3 (LU + the block's inverse:
@@ -524,12 +525,19 @@ struct EtaFile {
     MaxvolState& M;
     int m;
     hipStream_t s;
-    bool dense = false, adaptive = false;
+    bool dense = false, dense_possible = false, adaptive = false;
     int cap = 100;                 // most etas the buffers hold
     int limit = 100;               // fixed mode: refactorize after so many
     int64_t sparse_cap = 0, sparse_used = 0;
     int K = 0;
     double overhead_s = 0.0, refactor_s = 0.0;
+    int64_t seg_nnz = 0;           // entries of the etas of the current segment (decides the next segment's form)
+    bool have_history = false;
+
+    // cost of one eta in one application (seconds): the list kernels spend two workgroup barriers and a dependent load per eta plus
+    // its entries through one workgroup; the dense form a barrier of the triangular solve plus the eta's row of E in the one pass
+    double cost_list(double nnz) const { return 2.5e-6 + 0.5e-9 * nnz; }
+    double cost_dense() const { return 0.6e-6 + 8.0 * (double)m / 2e12; }
 
     EtaFile(Context* ctx, MaxvolState& state, int rows, ipxint max_etas_in) : c(ctx), M(state), m(rows), s(ctx->stream) {
         adaptive = max_etas_in < 0;
@@ -537,29 +545,41 @@ struct EtaFile {
         static const bool dense_off = getenv("IPXK_MAXVOL_DENSE_ETAS") && getenv("IPXK_MAXVOL_DENSE_ETAS")[0] == '0';
         const int64_t fit = (int64_t(1) << 28) / std::max(m, 1);                   // 2 GiB of etas
         cap = adaptive ? (int)std::min<int64_t>(kEtaDenseMax, std::max<int64_t>(limit, fit)) : limit;
-        dense = !dense_off && cap <= kEtaDenseMax && (int64_t)cap <= std::max<int64_t>(fit, 1) && cap <= kEtaDenseMax;
-        if (!dense) { cap = limit; adaptive = false; }
+        dense_possible = !dense_off && cap <= kEtaDenseMax && (int64_t)cap <= std::max<int64_t>(fit, 1);
+        if (!dense_possible) { cap = limit; adaptive = false; }
+        sparse_cap = std::max<int64_t>(4 * (int64_t)m, int64_t(1) << 20);
+        M.eta_pos.ensure((size_t)cap); M.eta_piv.ensure((size_t)cap);
+        reset(0);
+    }
+    // after a (re)factorization whose dense block has `block_rows` rows: the next segment's etas as dense rows or as lists, whichever
+    // the previous segment's etas would have cost less in (no segment yet: from m alone -- the lists only pay beyond ~ 475 000 rows)
+    void reset(int block_rows) {
+        if (dense_possible) {
+            const double avg = have_history && K > 0 ? (double)seg_nnz / K : 0.0;
+            dense = cost_dense() < cost_list(avg);
+            static const bool force = getenv("IPXK_MAXVOL_DENSE_ETAS") && getenv("IPXK_MAXVOL_DENSE_ETAS")[0] == '1';
+            if (force) dense = true;
+        } else {
+            dense = false;
+        }
+        if (K > 0) have_history = true;
+        K = 0;
+        sparse_used = 0;
+        seg_nnz = 0;
+        overhead_s = 0.0;
+        refactor_s = 0.025 + 3.5e-13 * (double)block_rows * (double)block_rows * (double)block_rows;
         if (dense) {
             M.etaE.ensure((size_t)cap * m); M.etaT.ensure((size_t)cap * cap); M.etaTt.ensure((size_t)cap * cap);
             M.eta_alpha.ensure((size_t)cap); M.eta_d.ensure((size_t)cap);
-            M.eta_pos.ensure((size_t)cap); M.eta_piv.ensure((size_t)cap); M.eta_prev.ensure((size_t)cap); M.eta_next.ensure((size_t)cap);
+            M.eta_prev.ensure((size_t)cap); M.eta_next.ensure((size_t)cap);
             M.eta_last.ensure((size_t)m);
+            IPXK_HIP(hipMemsetAsync(M.eta_last.get(), 0xff, (size_t)m * sizeof(int), s));
         } else {
-            sparse_cap = std::max<int64_t>(4 * (int64_t)m, int64_t(1) << 20);
             M.flag.ensure((size_t)m); M.rank.ensure((size_t)m);
-            M.eta_ptr.ensure((size_t)cap + 1); M.eta_pos.ensure((size_t)cap); M.eta_piv.ensure((size_t)cap);
+            M.eta_ptr.ensure((size_t)cap + 1);
             M.eta_idx.ensure((size_t)sparse_cap + m); M.eta_val.ensure((size_t)sparse_cap + m);
+            IPXK_HIP(hipMemsetAsync(M.eta_ptr.get(), 0, sizeof(int), s));
         }
-        reset(0);
-    }
-    // after a (re)factorization whose dense block has `block_rows` rows
-    void reset(int block_rows) {
-        K = 0;
-        sparse_used = 0;
-        overhead_s = 0.0;
-        refactor_s = 0.025 + 3.5e-13 * (double)block_rows * (double)block_rows * (double)block_rows;
-        if (dense) IPXK_HIP(hipMemsetAsync(M.eta_last.get(), 0xff, (size_t)m * sizeof(int), s));
-        else IPXK_HIP(hipMemsetAsync(M.eta_ptr.get(), 0, sizeof(int), s));
     }
     // the eta of the exchange described by *S (pmax) from the tableau column lhs; eta_nnz: its number of nonzeros
     void append(const Scalars* S, const double* lhs, int eta_nnz) {
@@ -578,7 +598,8 @@ struct EtaFile {
             sparse_used += eta_nnz;
         }
         K++;
-        overhead_s += 3.0 * (double)K * (0.6e-6 + 8.0 * (double)m / 2e12);
+        seg_nnz += eta_nnz;
+        overhead_s += 3.0 * (dense ? (double)K * cost_dense() : (double)K * 2.5e-6 + 0.5e-9 * (double)seg_nnz);
     }
     bool full() const {                                                             // NeedFreshFactorization (src/maxvolume.cc:318-319)
         if (K >= cap) return true;
@@ -606,7 +627,6 @@ struct EtaFile {
         }
     }
 };
-
 
 void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_in, const ipxk_maxvolume_params* prm_in,
                    ipxint* basis_out, ipxint* status_out, ipxk_maxvolume_info* info, ipxint* log, ipxint log_cap) {
