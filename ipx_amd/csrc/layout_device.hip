@@ -953,6 +953,7 @@ void reorder_model(Context* c) {
                                             (long long)b1.rows_by_8, (long long)m, start, R.ms);
         return;
     }
+    const double t_pass1 = ms_since0();
     // pass 2: the levels that count, from the far end; then the other components
     clear_levels();
     int level0 = 0, comps = 0;
@@ -968,6 +969,7 @@ void reorder_model(Context* c) {
     }
     R.levels = level0;
     R.components = comps;
+    const double t_pass2 = ms_since0();
     // numbering: (level, old index)
     Tmp T;
     const size_t big = (size_t)std::max(m, n);
@@ -980,6 +982,8 @@ void reorder_model(Context* c) {
     hipLaunchKernelGGL(level_keys_kernel, dim3(gridn(n)), dim3(kBlock), 0, s, (int)n, col_level.get(), k1.get(), v1.get());
     sort_pairs<u64>(T, k1.get(), k2.get(), v1.get(), v2.get(), (size_t)n, 64, s);
     hipLaunchKernelGGL(invert_perm_kernel, dim3(gridn(n)), dim3(kBlock), 0, s, (int)n, v2.get(), R.colperm.get(), R.colinv.get());
+    IPXK_HIP(hipStreamSynchronize(s));
+    const double t_perm = ms_since0();
     // the matrix in the new numbering: entries keyed (new column, new row), sorted; then its row-wise copy as upload_plain_model builds it
     const size_t nz1 = (size_t)nz;
     R.Ap.ensure((size_t)n + 1); R.Ai.ensure(nz1); R.Ax.ensure(nz1); R.Tp.ensure((size_t)m + 1); R.Ti.ensure(nz1); R.Tx.ensure(nz1);
@@ -1002,6 +1006,7 @@ void reorder_model(Context* c) {
         hipLaunchKernelGGL(row_pointers_kernel, dim3(gridn(m + 1)), dim3(kBlock), 0, s, m, nz, rows2.get(), R.Tp.get());
         IPXK_HIP(hipStreamSynchronize(s));
     }
+    const double t_matrix = ms_since0();
     // its gather layouts, by the builders of the original
     {
         std::unique_ptr<LayoutScratch, void (*)(LayoutScratch*)> S(new_layout_scratch(), free_layout_scratch);
@@ -1011,6 +1016,7 @@ void reorder_model(Context* c) {
                         R.Arows.build_device(*S, m, n, nz, R.Tp.get(), R.Ti.get(), R.Tx.get(), s);
         if (!ok) { R = Reordered(); return; }
     }
+    const double t_layouts = ms_since0();
     R.us_original = time_normal_pair(c, c->Acols, c->Arows);
     R.us_reordered = time_normal_pair(c, R.Acols, R.Arows);
     R.active = force || R.us_reordered < 0.9f * R.us_original;
@@ -1018,6 +1024,9 @@ void reorder_model(Context* c) {
     if (getenv("IPXK_VERBOSE"))
         fprintf(stderr, "ipxk: reordering: %d levels in %d component(s); the two products %.1f us on the model as given, %.1f us renumbered -> %s (%.1f ms)\n",
                 R.levels, R.components, R.us_original, R.us_reordered, R.active ? "renumbered copy in use" : "not used", R.ms);
+    if (getenv("IPXK_VERBOSE"))
+        fprintf(stderr, "ipxk:   first pass %.1f ms, second pass + components %.1f, numbering %.1f, renumbered matrix %.1f, its layouts %.1f, timing both %.1f\n",
+                t_pass1, t_pass2 - t_pass1, t_perm - t_pass2, t_matrix - t_perm, t_layouts - t_matrix, R.ms - t_layouts);
     if (!R.active) {                                        // keep the numbering (ipxk_reorder_info), drop the copy
         R.Acols = GatherMatrix(); R.Arows = GatherMatrix();
         R.Ap = DevBuf<int>(); R.Ai = DevBuf<int>(); R.Tp = DevBuf<int>(); R.Ti = DevBuf<int>(); R.Ax = DevBuf<double>(); R.Tx = DevBuf<double>();
