@@ -872,7 +872,7 @@ BfsOut bfs_levels(Context* c, int start, int level0, int* row_level, int* col_le
     IPXK_HIP(hipMemcpyAsync(row_level + start, &level0, sizeof(int), hipMemcpyHostToDevice, s));
     IPXK_HIP(hipMemcpyAsync(fr, &start, sizeof(int), hipMemcpyHostToDevice, s));
     IPXK_HIP(hipStreamSynchronize(s));                    // (init, start, level0 are stack variables)
-    const int grid = 2048;
+    const int grid = 256;                                 // (a frontier of a matrix with structure holds a few thousand rows; larger ones stride)
     int L = 0, found = -1;
     hh.clear();
     while (found < 0 && L < kBfsMaxLevels) {
