@@ -734,11 +734,16 @@ struct CoopShared {
     double row[kPanel];
     double slots[kCoopMaxG * kCoopSlot];
     int abort;
+    int part, G;            // this workgroup among the participants, their number
+    int plain;              // all participants share one XCD (checked): messages and resets by plain stores that stay in its L2
 };
 struct Coop {
     double* slots;          // [5][G][kCoopSlot], every word the sentinel or a message
     int set0;               // the set of this launch's first step (the steps of a factorization take the five sets in turn)
     int* abort_flag;
+    int xcd_mode;           // 1: only the workgroups with blockIdx % 8 == 0 take part (one XCD under the round-robin dispatch of gfx950)
+    unsigned epoch;         // of the placement check
+    unsigned long long* xcc_slots;
 };
 constexpr long long kCoopSentinel = 0x7ff8dead5eed0001LL;       // a quiet NaN with a payload of its own
 template <int R, int T>
@@ -746,8 +751,9 @@ __device__ __forceinline__ void coop_steps(const Dense& A, CoopShared& sh, const
                                            int& np, int& step, bool& dead) {
     if constexpr (T < kPanel) {
         if (c0 + T >= c1 || dead) return;              // uniform over the grid
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = gridDim.x;
-        const int row0 = blockIdx.x * R * kCoopThreads;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = sh.G, part = sh.part;
+        const bool plain = sh.plain != 0;
+        const int row0 = part * R * kCoopThreads;
         if (wave == 1 + (T & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the slot this wave reset two steps ago (see the exchange)
         double best = 0.0;
         int br = INT_MAX;
@@ -792,10 +798,11 @@ __device__ __forceinline__ void coop_steps(const Dense& A, CoopShared& sh, const
         // in front of the barriers that precede the publication of step t + 2.  So whoever has seen a workgroup's message of step u
         // finds that workgroup's slot of step u + 1 reset or already written, never stale.
         const int set = (C.set0 + T) % 5;
-        double* mine = C.slots + ((size_t)set * G + blockIdx.x) * kCoopSlot;
+        double* mine = C.slots + ((size_t)set * G + part) * kCoopSlot;
         if (wave == 0 && lane < kCoopSlot) {
             const double x = lane == 0 ? bv : lane == 1 ? __longlong_as_double((long long)rr) : sh.row[lane - 2];
-            __hip_atomic_store(mine + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // write-through
+            if (plain) __hip_atomic_store(mine + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // stays in the XCD's L2
+            else __hip_atomic_store(mine + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               // write-through
         }
         const double* all = C.slots + (size_t)set * G * kCoopSlot;
         int gone = 0;
@@ -836,8 +843,9 @@ __device__ __forceinline__ void coop_steps(const Dense& A, CoopShared& sh, const
         __syncthreads();
         if (sh.abort) { dead = true; return; }
         if (wave == 1 + (T & 1) && lane < kCoopSlot) {
-            double* ahead = C.slots + ((size_t)((set + 3) % 5) * G + blockIdx.x) * kCoopSlot;
-            __hip_atomic_store(ahead + lane, __longlong_as_double(kCoopSentinel), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double* ahead = C.slots + ((size_t)((set + 3) % 5) * G + part) * kCoopSlot;
+            if (plain) __hip_atomic_store(ahead + lane, __longlong_as_double(kCoopSentinel), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(ahead + lane, __longlong_as_double(kCoopSentinel), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // ---- the same winner everywhere
         double wv = lane < G ? sh.slots[lane * kCoopSlot] : 0.0;
@@ -855,7 +863,7 @@ __device__ __forceinline__ void coop_steps(const Dense& A, CoopShared& sh, const
         wv = __shfl(wv, 0, 64); wr = __shfl(wr, 0, 64); wg = __shfl(wg, 0, 64);
         const bool dependent = wr == INT_MAX || !(wv >= A.abstol) || wv == 0.0;
         const int pr = dependent ? -1 : wr;
-        if (blockIdx.x == 0 && tid == 0) {
+        if (part == 0 && tid == 0) {
             if (dependent) A.bcstep[c0 + T] = -1;
             else {
                 A.brstep[pr] = step;
@@ -888,8 +896,31 @@ __device__ __forceinline__ void coop_steps(const Dense& A, CoopShared& sh, const
 template <int R>
 __global__ __launch_bounds__(kCoopThreads) __attribute__((amdgpu_waves_per_eu(1, 2))) void lu_panel_coop_kernel(Dense A, Coop C, int c0, int c1, const int* __restrict__ step_src) {
     __shared__ CoopShared sh;
+    if (C.xcd_mode && (blockIdx.x & 7)) return;
     const int kb = A.kb, tid = threadIdx.x;
-    const int row0 = blockIdx.x * R * kCoopThreads;
+    const int part = C.xcd_mode ? blockIdx.x >> 3 : blockIdx.x, G = C.xcd_mode ? (gridDim.x + 7) >> 3 : gridDim.x;
+    const int row0 = part * R * kCoopThreads;
+    if (tid == 0) { sh.abort = 0; sh.part = part; sh.G = G; sh.plain = 0; }
+    if (C.xcd_mode && tid < 64) {
+        // the placement is an observation, not a contract (as for the one-XCD runs of the sweeps, trisolve.hip): every participant
+        // publishes the XCD it runs on and reads everybody else's; plain stores only if all agree -- all see the same ids and decide alike
+        unsigned xcc = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xff;
+        if (tid == 0) __hip_atomic_store(C.xcc_slots + part, ((unsigned long long)C.epoch << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool same = true;
+        for (int i = tid; i < G; i += 64) {
+            unsigned long long w;
+            int spins = 0;
+            while (((w = __hip_atomic_load(C.xcc_slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != C.epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kCoopSpinLimit) { __hip_atomic_store(C.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            same &= (unsigned)(w & 0xff) == xcc && (w >> 32) == C.epoch;
+        }
+        same = __all(same);
+        if (tid == 0) sh.plain = same ? 1 : 0;
+    }
     unsigned active = 0, have = 0;
     double v[R][kPanel];
 #pragma unroll
@@ -899,7 +930,6 @@ __global__ __launch_bounds__(kCoopThreads) __attribute__((amdgpu_waves_per_eu(1,
 #pragma unroll
         for (int t = 0; t < kPanel; t++) v[q][t] = (r < kb && c0 + t < c1) ? A.D[(size_t)(c0 + t) * kb + r] : 0.0;
     }
-    if (tid == 0) sh.abort = 0;
     __syncthreads();
     int np = 0;
     int step = step_src ? step_src[0] : A.bstep[0];       // (look-ahead: the count so far is in the other set)
@@ -914,7 +944,7 @@ __global__ __launch_bounds__(kCoopThreads) __attribute__((amdgpu_waves_per_eu(1,
             for (int t = 0; t < kPanel; t++)
                 if (c0 + t < c1) A.D[(size_t)(c0 + t) * kb + r] = v[q][t];
         }
-    if (blockIdx.x == 0 && tid == 0) { A.bstep[0] = step; A.bstep[1] = np; A.bstep[3] = 0; }
+    if (part == 0 && tid == 0) { A.bstep[0] = step; A.bstep[1] = np; A.bstep[3] = 0; }
 }
 
 // The panel's rows of U in the trailing columns: row prow[t] of column c2 receives the updates of the panel's
@@ -1558,6 +1588,8 @@ struct LuWork {
     DevBuf<double> usub;               // [sub-panel pivot][kPanel] a sub-panel's rows of U in the rest of the outer panel
     DevBuf<double> coop_slots;         // cooperative outer panel: the workgroups' messages, [5][kCoopMaxG][kCoopSlot]
     DevBuf<unsigned> coop_bar;         // [1] abort flag
+    DevBuf<unsigned long long> coop_xcc;   // placement check of the one-XCD form
+    unsigned coop_epoch = 0;
     DevBuf<u64> cand_bits, claim_abs, skey, skey2, lkey, lkey2, ukey, ukey2;
     DevBuf<double> pivot, D, lval, lval2, uval, uval2;
     DevBuf<unsigned char> ckind;
@@ -2256,8 +2288,16 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
             }
             const int coopG = (kb + coopR * kCoopThreads - 1) / (coopR * kCoopThreads);
             int coop_steps_done = 0;
+            // the participants on ONE XCD (its L2 is coherent: messages by plain stores) where one workgroup per compute unit of that
+            // XCD holds them all and nothing else competes for the XCD: at most 24 workgroups, no look-ahead (blocks of up to 6144
+            // rows).  Measured: 2600 / 5000 rows 16.0 / 37.4 -> 14.4 / 33.0 ms; with the look-ahead's late update on the other stream
+            // the participants wait for compute units of their XCD, 8000 rows 62.8 -> 76.3 ms, 12 000 rows 149 -> 193 ms, so those
+            // blocks keep all XCDs and write-through messages.  (IPXK_LU_COOP_XCD=0: never, =1: wherever at most 32 workgroups take part)
+            const char* xcd_env = getenv("IPXK_LU_COOP_XCD");
+            const bool coop_xcd = coop && !(xcd_env && xcd_env[0] == '0') && ((xcd_env && xcd_env[0] == '1') ? coopG <= 32 : (!lookahead && coopG <= 24));
             if (coop) {
                 W_.coop_slots.ensure((size_t)5 * kCoopMaxG * kCoopSlot); W_.coop_bar.ensure(2);
+                if (W_.coop_xcc.size() < (size_t)kCoopMaxG) { W_.coop_xcc.ensure((size_t)kCoopMaxG); IPXK_HIP(hipMemsetAsync(W_.coop_xcc.get(), 0, kCoopMaxG * sizeof(unsigned long long), s)); }
                 IPXK_HIP(hipMemsetAsync(W_.coop_bar.get(), 0, 2 * sizeof(unsigned), s));
                 hipLaunchKernelGGL(lu_fill_u64_kernel, dim3(8), dim3(kBlock), 0, s, (int64_t)5 * kCoopMaxG * kCoopSlot, (u64)kCoopSentinel,
                                    reinterpret_cast<u64*>(W_.coop_slots.get()));
@@ -2268,9 +2308,12 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
                 const Dense& P = lookahead ? Ap[k & 1] : A;
                 const int* step_src = (lookahead && k > 0) ? Ap[(k - 1) & 1].bstep : nullptr;
                 if (coop) {
-                    const Coop C{W_.coop_slots.get(), coop_steps_done % 5, reinterpret_cast<int*>(W_.coop_bar.get() + 1)};
-                    if (coopR == 1) hipLaunchKernelGGL((lu_panel_coop_kernel<1>), dim3(coopG), dim3(kCoopThreads), 0, s, P, C, c0, c1o, step_src);
-                    else hipLaunchKernelGGL((lu_panel_coop_kernel<2>), dim3(coopG), dim3(kCoopThreads), 0, s, P, C, c0, c1o, step_src);
+                    if (++W_.coop_epoch == 0) ++W_.coop_epoch;
+                    const Coop C{W_.coop_slots.get(), coop_steps_done % 5, reinterpret_cast<int*>(W_.coop_bar.get() + 1), coop_xcd ? 1 : 0, W_.coop_epoch,
+                                 W_.coop_xcc.get()};
+                    const int grid = coop_xcd ? coopG * 8 : coopG;
+                    if (coopR == 1) hipLaunchKernelGGL((lu_panel_coop_kernel<1>), dim3(grid), dim3(kCoopThreads), 0, s, P, C, c0, c1o, step_src);
+                    else hipLaunchKernelGGL((lu_panel_coop_kernel<2>), dim3(grid), dim3(kCoopThreads), 0, s, P, C, c0, c1o, step_src);
                     coop_steps_done += c1o - c0;
                 }
                 // (measured and dropped: the whole outer panel in ONE launch, the sub-panels' updates of the rest of the outer
