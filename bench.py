@@ -721,7 +721,7 @@ def pmc_traffic(fname, key, workload, layouts):
     now = source_hashes()
     changed = sorted(p for p in have if now.get(p) != have[p])
     if changed:
-        return None, "kernel sources changed since the PMC run (%s): re-run scripts/prof_r04.sh" % ", ".join(changed)
+        return None, "kernel sources changed since the PMC run (%s): re-run scripts/prof_r05.sh" % ", ".join(changed)
     return pm[key], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s; sources unchanged since (%d files hashed)" % (
         pm.get("source", "profiles/"), len(have))
 

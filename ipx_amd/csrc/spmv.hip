@@ -1212,7 +1212,14 @@ void build_model(Context* c, const ipxint* Ap, const ipxint* Ai, const double* A
     find_dense_columns(c);
     c->tcols.resize(n > 0 ? n : 1);
     prepare_dense_columns(c);
-    if (c->num_dense == 0) reorder_model(c);       // (the Sherman-Morrison-Woodbury preconditioner keeps the numbering as given)
+    if (c->num_dense == 0) {                       // (the Sherman-Morrison-Woodbury preconditioner keeps the numbering as given)
+        try {
+            reorder_model(c);
+        } catch (const Error& e) {                 // an optional acceleration: a model is created without it rather than not at all
+            if (getenv("IPXK_VERBOSE")) fprintf(stderr, "ipxk: reordering given up: %s\n", e.what());
+            c->reord = Reordered();
+        }
+    }
     c->create_ms[3] = ms_since(t0);
     if (getenv("IPXK_VERBOSE"))
         fprintf(stderr, "ipxk: model %lld x %lld nnz %lld on the device: upload + transpose %.1f ms, A' layouts %.1f ms, A layouts %.1f ms, rest %.1f ms\n",
