@@ -292,3 +292,28 @@ def test_basis_classes_object_against_object(m, n, seed):
     print(r.stdout, r.stderr[-2000:])
     assert r.returncode == 0 and "DONE" in r.stdout, r.stdout + r.stderr[-2000:]
     assert r.stdout.count("PASS") == 3
+
+
+@pytest.mark.gpu
+def test_deferred_basis_load_changes_nothing_but_the_number_of_loads(tmp_path):
+    """KKTSolverBasisHip tells the reference's Basis about the basis Maxvolume left on the device only when the Basis is needed
+    (a drop candidate, Debug(4) statistics, the CPU path, the destructor); IPXK_EAGER_BASIS_LOAD=1 restores the Load after every
+    Factorize.  Same LP both ways: identical statuses, iteration counts, basis updates and objectives (the IPM never sees the
+    difference), crossover reaches the same vertex objective, and the deferred run asks the LU kernel far less often."""
+    _need_bins()
+    din = str(tmp_path / "in")
+    write_model(din, *general_lp(3000, 7500, 41), crossover=1)
+    runs = {}
+    for tag, env in (("deferred", {}), ("eager", {"IPXK_EAGER_BASIS_LOAD": "1"})):
+        dout = str(tmp_path / tag)
+        os.makedirs(dout, exist_ok=True)
+        r = subprocess.run([HIP_BIN, din, dout], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        runs[tag] = {ln.split()[0]: float(ln.split()[1]) for ln in open(os.path.join(dout, "info.txt"))}
+    d, e = runs["deferred"], runs["eager"]
+    for k in ("status", "status_ipm", "status_crossover", "iter", "kktiter1", "kktiter2", "updates_ipm", "primal_dropped", "dual_dropped"):
+        assert d[k] == e[k], (k, d[k], e[k])
+    assert d["status_ipm"] == IPX_STATUS_optimal and d["status_crossover"] == IPX_STATUS_optimal
+    assert d["pobjval"] == e["pobjval"] and d["dobjval"] == e["dobjval"] and close(d["objval"], e["objval"], 1e-12)
+    print("LU requests of the Basis: deferred %d (reused %d), eager %d (reused %d)" % (d["lu_factorizations"], d["lu_reused"], e["lu_factorizations"], e["lu_reused"]))
+    assert d["lu_factorizations"] < e["lu_factorizations"] and e["lu_reused"] > d["lu_reused"] >= 1
