@@ -1204,11 +1204,11 @@ __device__ __forceinline__ void bump_solve_lds(int kb, const double* __restrict_
 template <bool TRANS>
 __global__ __launch_bounds__(kBumpThreads) void bump_solve_kernel(int kb, const double* __restrict__ D, const double* __restrict__ invL,
                                                                   const double* __restrict__ invU, const int* __restrict__ pos,
-                                                                  double* y, const int* done) {
+                                                                  double* y, const int* done, double* gx = nullptr) {
     if (done && *done) return;
-    extern __shared__ double xs[];       // kb + 64
-    double* x = xs;
-    double* xb = xs + kb;
+    extern __shared__ double xs[];       // kb + 64; a block too large for LDS (more than kBumpLdsRows rows) keeps x in the global scratch gx
+    double* x = gx ? gx : xs;
+    double* xb = gx ? xs : xs + kb;
     const int tid = threadIdx.x;
     for (int t = tid; t < kb; t += kBumpThreads) x[t] = y[pos[t]];
     __syncthreads();
@@ -1218,11 +1218,11 @@ __global__ __launch_bounds__(kBumpThreads) void bump_solve_kernel(int kb, const 
 // The blocked solve applied to the guard's two vectors: w[q kb + t] = (inverse(D22) z_q)[t] as the one-workgroup solve computes it
 // (workgroup q).  Its residual is what an explicit inverse of the same block can be held to.
 __global__ __launch_bounds__(kBumpThreads) void bump_probe_solve_kernel(int kb, const double* __restrict__ D, const double* __restrict__ invL,
-                                                                        const double* __restrict__ invU, double* __restrict__ w) {
-    extern __shared__ double xs[];       // kb + 64
-    double* x = xs;
-    double* xb = xs + kb;
+                                                                        const double* __restrict__ invU, double* __restrict__ w, double* gx = nullptr) {
+    extern __shared__ double xs[];       // kb + 64 (or 64 with x in the global scratch: one stretch of kb per workgroup)
     const int q = blockIdx.x;
+    double* x = gx ? gx + (size_t)q * kb : xs;
+    double* xb = gx ? xs : xs + kb;
     for (int t = threadIdx.x; t < kb; t += kBumpThreads) x[t] = probe_z(q, t);
     __syncthreads();
     bump_solve_lds<false>(kb, D, invL, invU, x, xb);
@@ -1272,7 +1272,10 @@ __global__ void bump_positions_kernel(int s0, int kb, const int* __restrict__ po
     }
 }
 // between the two sweeps of a pair: `y` is the result of the first one
-// the blocked solve keeps the kb unknowns of the block in LDS: beyond 64 KB of dynamic LDS the kernels have to be allowed
+// the blocked solve keeps the kb unknowns of the block in LDS: beyond 64 KB of dynamic LDS the kernels have to be allowed; beyond the
+// 160 KB of a compute unit (blocks of more than kBumpLdsRows rows -- what the LU leaves of an 80 000-row IPM basis) the unknowns live
+// in a global scratch vector instead (one workgroup: its own stores are visible to it after a barrier)
+constexpr int kBumpLdsRows = 160 * 1024 / 8 - 64;
 static void allow_bump_lds(size_t bytes) {
     static size_t allowed = 64 * 1024;
     if (bytes <= allowed) return;
@@ -1294,12 +1297,15 @@ static void bump_between(Context* c, bool trans, double* y, const int* done) {
                            trans ? S->bump_invT.get() : S->bump_inv.get(), S->bump_x.get(), pos, y, done);
         return;
     }
-    const size_t lds = (size_t)(kb + 64) * sizeof(double);
-    allow_bump_lds(lds);
+    const bool in_lds = kb <= kBumpLdsRows;
+    const size_t lds = (size_t)((in_lds ? kb : 0) + 64) * sizeof(double);
+    double* gx = nullptr;
+    if (in_lds) allow_bump_lds(lds);
+    else { S->bump_gx.ensure((size_t)2 * kb); gx = S->bump_gx.get(); }
     if (trans) hipLaunchKernelGGL(bump_solve_kernel<true>, dim3(1), dim3(kBumpThreads), lds, c->stream, kb, S->bumpD.get(), S->bump_invL.get(),
-                                  S->bump_invU.get(), S->bump_pos_bwd.get(), y, done);
+                                  S->bump_invU.get(), S->bump_pos_bwd.get(), y, done, gx);
     else hipLaunchKernelGGL(bump_solve_kernel<false>, dim3(1), dim3(kBumpThreads), lds, c->stream, kb, S->bumpD.get(), S->bump_invL.get(),
-                            S->bump_invU.get(), S->bump_pos_fwd.get(), y, done);
+                            S->bump_invU.get(), S->bump_pos_fwd.get(), y, done, gx);
 }
 
 // Cuts the trailing block [s0, s0 + kb) = [s0, m) out of the factors: D22 = (L22 + I) U22 goes to S->bumpD (dense, with
@@ -1348,7 +1354,9 @@ static DeviceFactors cut_dense_block(Context* c, SplitOperator* S, const DeviceF
         const char* di_env = getenv("IPXK_DENSE_INVERSE_MIN");          // (read per Prepare: the tests switch it)
         const int di_min = di_env ? atoi(di_env) : 1;
         const bool by_blas = di_min > 0 && kb >= di_min;
-        allow_bump_lds((size_t)(kb + 64) * sizeof(double));
+        const bool in_lds = kb <= kBumpLdsRows;
+        if (in_lds) allow_bump_lds((size_t)(kb + 64) * sizeof(double));
+        IPXK_REQUIRE(by_blas || in_lds, "a dense block of this size is inverted on the matrix cores only (IPXK_DENSE_INVERSE_MIN)");
         if (!by_blas) hipLaunchKernelGGL(bump_inverse_kernel, dim3(kb), dim3(kBumpThreads), (size_t)(kb + 64) * sizeof(double), s, kb, S->bumpD.get(),
                            S->bump_invL.get(), S->bump_invU.get(), S->bump_inv.get(), S->bump_invT.get());
         // the guard (whoever computed the inverse): D22 (inverse z) against z; a block that fails keeps the blocked solve.  The
@@ -1389,8 +1397,10 @@ static DeviceFactors cut_dense_block(Context* c, SplitOperator* S, const DeviceF
         double resid_solve = -1.0;
         if (!(resid <= inverse_tol(true)) && resid < 1e-5 && inverse_tol(true) > 0.0) {       // (tolerance 0: "reject everything", tests)
             IPXK_HIP(hipMemsetAsync(pw + 4 * (size_t)kb, 0, 2 * sizeof(double), s));
-            hipLaunchKernelGGL(bump_probe_solve_kernel, dim3(2), dim3(kBumpThreads), (size_t)(kb + 64) * sizeof(double), s, kb, S->bumpD.get(),
-                               S->bump_invL.get(), S->bump_invU.get(), pw);
+            double* gx = nullptr;
+            if (!in_lds) { S->bump_gx.ensure((size_t)2 * kb); gx = S->bump_gx.get(); }
+            hipLaunchKernelGGL(bump_probe_solve_kernel, dim3(2), dim3(kBumpThreads), (size_t)((in_lds ? kb : 0) + 64) * sizeof(double), s, kb, S->bumpD.get(),
+                               S->bump_invL.get(), S->bump_invU.get(), pw, gx);
             const dim3 pgrid((kb + 63) / 64, nchunks);
             hipLaunchKernelGGL(bump_probe_partial_kernel, pgrid, dim3(kBlock), 0, s, kb, S->bumpD.get(), pw, 1, part);
             hipLaunchKernelGGL(bump_probe_finish_kernel, dim3(vec_grid(kb)), dim3(kBlock), 0, s, kb, nchunks, part, (const double*)nullptr, pw + 2 * (size_t)kb,

@@ -147,6 +147,7 @@ struct SplitOperator {
     // large blocks: inverse(D22) itself, row major, and its transpose (bump_size^2 each; empty for small blocks) --
     // the solve between the sweeps of a pair is then ONE matrix-vector product spread over the chip
     DevBuf<double> bump_inv, bump_invT, bump_x;
+    DevBuf<double> bump_gx;                // blocks too large for LDS: the unknowns of the one-workgroup blocked solve (2 x bump_size)
     bool bump_explicit = false;
     DevBuf<double> bump_probe;             // workspace of the guard of the explicit inverse
     DevBuf<int> bump_pos_fwd, bump_pos_bwd;   // position of bump unknown t in the result of the L sweep / of the U' sweep

@@ -616,65 +616,31 @@ def test_lu_bump_of_20000_rows_returns_factors(kkt, monkeypatch):
 
 
 def test_lu_dense_block_beyond_16384_rows(kkt, monkeypatch):
-    """a dense block of 16 385 ... 32 768 rows (32 rows per thread, sub-panels of one column): a sparse planted bump of 16 600 rows
-    sent to the dense code as it stands (round 4's policy with the limit raised); Prepare inverts the block on the matrix cores and
-    B x = r, B' x = r are solved to 1e-9"""
-    monkeypatch.setenv("IPXK_LU_BUMP_MAX", "20000")
-    m, n, bump = 18000, 40000, 16600
-    P = synth.lp_like_basis(m, n, seed=4, bump=bump, offdiag=3, bump_density=0.002)
+    """a dense block of 16 385 ... 32 768 rows (cooperative panel with 2 rows per thread, or 32 rows per thread in the one-workgroup
+    sub-panels): a sparse planted bump of 21 000 rows sent to the dense code as it stands (round 4's policy with the limit raised) --
+    also more rows than the LDS of a compute unit holds as doubles (20 416), so the one-workgroup blocked solve that stands in for a
+    rejected inverse keeps its unknowns in a global scratch vector.  Prepare inverts the block on the matrix cores and B x = r,
+    B' x = r are solved to 1e-9; with the inverse rejected (IPXK_INVERSE_TOL=0) the blocked solve gives the same to 1e-9."""
+    monkeypatch.setenv("IPXK_LU_BUMP_MAX", "30000")
+    m, n, bump = 22500, 50000, 21000
+    P = synth.lp_like_basis(m, n, seed=4, bump=bump, offdiag=3, bump_density=0.0015)
     colscale = synth.synthetic_basis_state(P["status"], 1.0, 4)
     ctx = kkt.KktContext(P["A"])
     F = ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
-    assert 16384 < F["bump"] <= bump and F["sparse_rounds"] == 0 and F["spikes"] == 0 and F["num_dependent"] == 0
-    ctx.split_prepare_lu(P["status"], colscale)
+    assert 20416 < F["bump"] <= bump and F["sparse_rounds"] == 0 and F["spikes"] == 0 and F["num_dependent"] == 0
     G = P["G"]
     B = sp.csc_matrix((G["Bx"].copy(), G["Bi"].copy(), G["Bp"].copy()), shape=(m, m))
     rhs = np.random.default_rng(1).standard_normal(m)
-    for tr in ("N", "T"):
-        x = ctx.solve_dense(rhs, tr)
-        r = (B if tr == "N" else B.T) @ x - rhs
-        assert np.abs(r).max() <= 1e-9 * (1 + np.abs(x).max()), tr
-    ctx.close()
-
-
-def test_lu_factorize_hands_out_the_resident_factors_of_the_same_basis(kkt):
-    """Basis::Load after Maxvolume on the device (src/basis.cc:81-114) asks for the factorization of the basis whose factors the
-    context already holds, columns in ascending order of the variable: ipxk_lu_factorize recognises it -- entry by entry, on the
-    device -- computes nothing (info.reused, ipxk_lu_generation) and returns the same L, U, rowperm with the column permutation in
-    the caller's numbering; the contract holds for the caller's matrix.  One changed value, another tolerance, another set of
-    columns: a real factorization."""
-    m, n = 3000, 7000
-    P = synth.lp_like_basis(m, n, seed=5, bump=300, offdiag=3)
-    A = P["A"]
-    AI = A.with_identity()
-    ctx = kkt.KktContext(A)
-    F1 = ctx.lu_factorize_basis(P["basis"], 0.1)
-    gen = ctx.lu_generation()
-    order = np.sort(P["basis"])                                  # Basis::Load numbers the basic variables in ascending order
-    begin, end = AI.p[order].copy(), AI.p[order + 1].copy()
-    F2 = ctx.lu_factorize(m, begin, end, AI.i, AI.x, 0.1)
-    assert F2["reused"] == 1 and ctx.lu_generation() == gen
-    for key in ("L", "U"):
-        assert np.array_equal(F1[key].p, F2[key].p) and np.array_equal(F1[key].i, F2[key].i) and np.array_equal(F1[key].x, F2[key].x)
-    assert np.array_equal(F1["rowperm"], F2["rowperm"])
-    assert np.array_equal(P["basis"][F1["colperm"]], order[F2["colperm"]])       # the same variables in the same pivot order
-    Bp = np.concatenate([[0], np.cumsum(end - begin)])
-    Bi = np.concatenate([AI.i[b:e] for b, e in zip(begin, end)])
-    Bx = np.concatenate([AI.x[b:e] for b, e in zip(begin, end)])
-    assert check_contract(dict(dim=m, Bp=Bp, Bi=Bi, Bx=Bx), F2) < 1e-10
-    # the operator is still built from the resident factors
-    ctx.split_prepare_lu(P["status"], synth.synthetic_basis_state(P["status"], 1.0, 5))
-    # not the same matrix / not the same tolerance: computed
-    x2 = AI.x.copy()
-    x2[begin[m // 2]] *= 1.0000001
-    assert ctx.lu_factorize(m, begin, end, AI.i, x2, 0.1, download=False)["reused"] == 0 and ctx.lu_generation() == gen + 1
-    ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
-    assert ctx.lu_factorize(m, begin, end, AI.i, AI.x, 0.3, download=False)["reused"] == 0
-    ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
-    other = order.copy()
-    nonbasic = np.setdiff1d(np.arange(n + m), order)
-    other[5] = nonbasic[0]
-    other.sort()
-    r = ctx.lu_factorize(m, AI.p[other].copy(), AI.p[other + 1].copy(), AI.i, AI.x, 0.1, download=False)
-    assert r["reused"] == 0
+    for tol in (None, "0"):
+        if tol is None:
+            monkeypatch.delenv("IPXK_INVERSE_TOL", raising=False)
+        else:
+            monkeypatch.setenv("IPXK_INVERSE_TOL", tol)
+        ctx.split_prepare_lu(P["status"], colscale)
+        for tr in ("N", "T"):
+            x = ctx.solve_dense(rhs, tr)
+            r = (B if tr == "N" else B.T) @ x - rhs
+            assert np.abs(r).max() <= 1e-9 * (1 + np.abs(x).max()), (tol, tr)
+    probes, rejected, worst = ctx.split_inverse_stats()
+    assert rejected >= 1          # (the second Prepare's inverse, by the tolerance of zero)
     ctx.close()
