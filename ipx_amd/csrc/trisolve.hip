@@ -554,9 +554,13 @@ __global__ __launch_bounds__(kBlock) void block_gather_kernel(SweepView S, int K
     }
 }
 // y[pos[t]] = (row t of M) z  [/ the column scale of unknown t: scaled U sweep]; M is lower triangular: a workgroup
-// takes the rows b and K-1-b, K+1 entries together, every thread a few independent loads, fixed reduction tree.
+// takes kGemvPairs pairs of rows (t, K-1-t) -- every pair K+1 entries together --, thread q the columns q, q + 256, ...
+// of all its rows: z[l] is fetched (INLINE_Z: formed, two gathers and a division) once per workgroup and column, the
+// 2 kGemvPairs loads of a column are independent, fixed reduction tree.
 // INLINE_Z (a head: rows without outside entries): z[l] = xin[zsrc[l]] [/ pre_scale] is formed on the fly, no gather
 // launch in front.  Second copy of the result as SweepView::dst2 asks.
+// (Until round 5 one pair per workgroup: a head of 1800 unknowns formed its z 900 times over, 15.6 us for 12.5 MB.)
+constexpr int kGemvPairs = 2;
 template <bool INLINE_Z>
 __global__ __launch_bounds__(kBlock) void block_gemv_kernel(int K, const double* __restrict__ M, const double* __restrict__ z,
                                                             const int* __restrict__ zsrc, const double* __restrict__ xin,
@@ -565,33 +569,63 @@ __global__ __launch_bounds__(kBlock) void block_gemv_kernel(int K, const double*
                                                             const double* __restrict__ post_scale, double* __restrict__ y,
                                                             const int* __restrict__ dst2, double* __restrict__ out2, const int* done) {
     if (done && *done) return;
-    __shared__ double red[2][kBlock / 64];
-    const int ta = blockIdx.x, tb = K - 1 - blockIdx.x;            // ta <= tb; equal for the middle row of an odd K
-    const int na = ta + 1, total = na + (tb > ta ? tb + 1 : 0);
-    double sa = 0.0, sb = 0.0;
-    for (int q = threadIdx.x; q < total; q += kBlock) {
-        const bool first = q < na;
-        const int l = first ? q : q - na;
-        double zl;
-        if (INLINE_Z) { zl = xin[zsrc[l]]; if (pre_scale) zl /= pre_scale[unk[l]]; }
-        else zl = z[l];
-        const double p = M[(size_t)(first ? ta : tb) * K + l] * zl;
-        if (first) sa += p; else sb += p;
+    constexpr int R = 2 * kGemvPairs;
+    __shared__ double red[R][kBlock / 64];
+    // rows of the workgroup: pair r = (t0 + r, K - 1 - t0 - r); a pair past the middle is left out (row = -1)
+    const int t0 = blockIdx.x * kGemvPairs;
+    int row[R];
+#pragma unroll
+    for (int r = 0; r < kGemvPairs; r++) {
+        const int ta = t0 + r, tb = K - 1 - ta;
+        row[r] = ta <= tb ? ta : -1;
+        row[kGemvPairs + r] = ta < tb ? tb : -1;
     }
+    const int ncol = K - t0;                                       // the longest row of the workgroup: K - 1 - t0
+    double acc[R];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { sa += __shfl_xor(sa, d, 64); sb += __shfl_xor(sb, d, 64); }
+    for (int r = 0; r < R; r++) acc[r] = 0.0;
+    // four columns per round: their z and all the loads of M issued before the first product
+    constexpr int UN = 4;
+    for (int l0 = threadIdx.x; l0 < ncol; l0 += UN * kBlock) {
+        double zl[UN], mv[UN][R];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int l = l0 + u * kBlock;
+            zl[u] = 0.0;
+            if (l < ncol) {
+                if (INLINE_Z) { zl[u] = xin[zsrc[l]]; if (pre_scale) zl[u] /= pre_scale[unk[l]]; }
+                else zl[u] = z[l];
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) mv[u][r] = l <= row[r] ? M[(size_t)row[r] * K + l] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (l0 + u * kBlock <= row[r]) acc[r] += mv[u][r] * zl[u];      // (a column beyond the row contributes nothing, whatever its z)
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { red[0][wave] = sa; red[1][wave] = sb; }
-    __syncthreads();
-    if (threadIdx.x < 2 && (threadIdx.x == 0 || tb > ta)) {
-        const int t = threadIdx.x == 0 ? ta : tb;
-        double s2 = 0.0;
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; w++) s2 += red[threadIdx.x][w];
-        const double v = post_scale ? s2 / post_scale[unk[t]] : s2;
-        const int pos = tpos[t];
-        y[pos] = v;
-        if (dst2 && dst2[pos] >= 0) out2[dst2[pos]] = v;
+    for (int r = 0; r < R; r++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc[r] += __shfl_xor(acc[r], d, 64);
+        if (lane == 0) red[r][wave] = acc[r];
+    }
+    __syncthreads();
+    if (threadIdx.x < R) {
+        int t = -1;
+#pragma unroll
+        for (int r = 0; r < R; r++) if (threadIdx.x == r) t = row[r];
+        if (t >= 0) {
+            double s2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; w++) s2 += red[threadIdx.x][w];
+            const double v = post_scale ? s2 / post_scale[unk[t]] : s2;
+            const int pos = tpos[t];
+            y[pos] = v;
+            if (dst2 && dst2[pos] >= 0) out2[dst2[pos]] = v;
+        }
     }
 }
 
@@ -838,6 +872,14 @@ void plan_sweep(Sweep& S, bool level_launches) {
         int b = l + 1;
         while (b < nlev && kind[b] == kind[l]) b++;
         push(l, b, kind[l]);
+        if (getenv("IPXK_SWEEP_STATS")) {
+            int64_t unknowns = 0;
+            for (int t = l; t < b; t++) unknowns += S.level_width[t];
+            fprintf(stderr, "ipxk: sweep plan: levels %d..%d %s, %d chunks, %lld unknowns; widths", l, b - 1, kind[l] == Sweep::kOneXcd ? "one XCD" : "all XCDs",
+                    S.level_chunk[b] - S.level_chunk[l], (long long)unknowns);
+            for (int t = l; t < b; t++) fprintf(stderr, " %d", S.level_width[t]);
+            fprintf(stderr, "\n");
+        }
         l = b;
     }
 }
@@ -877,7 +919,7 @@ static void run_sweep(Context* c, const Sweep& S, bool scaled, const double* xin
     auto run_block = [&](const Sweep::Block& T) {
         const double* us = scaled ? sp->uscale.get() : nullptr;
         const double *pre = S.scale_mode == 1 ? us : nullptr, *post = S.scale_mode == 2 ? us : nullptr;
-        const int wgs = (T.K + 1) / 2;
+        const int wgs = ((T.K + 1) / 2 + kGemvPairs - 1) / kGemvPairs;
         if (T.nh == 0) {
             hipLaunchKernelGGL(block_gemv_kernel<true>, dim3(wgs), dim3(kBlock), 0, c->stream, T.K, T.M.get(), T.z.get(), T.zsrc.get(), xin, pre,
                                T.pos.get(), T.unk.get(), post, xout, dst2, out2, done);
