@@ -169,6 +169,9 @@ void upload_plain_model(Context* c, const ipxint* Ap, const ipxint* Ai, const do
 void ensure_host_model(Context* c, bool rowwise);
 void fetch_columns(Context* c, const std::vector<ipxint>& cols, std::vector<ipxint>& Cp, std::vector<ipxint>& Ci, std::vector<double>& Cx);
 int device_max_row_length(LayoutScratch& S, int nrows, const int* dptr, hipStream_t s);
+// rows of more than kMaxRowLen entries out of a row-wise matrix: fills G's long-row arrays, returns the matrix without them
+bool device_strip_long_rows(LayoutScratch& S, GatherMatrix& G, int nrows, const int* dptr, const int* didx, const double* dval,
+                            DevBuf<int>& sptr, DevBuf<int>& sidx, DevBuf<double>& sval, int64_t* nnz_short, hipStream_t s);
 bool device_build_sliced(LayoutScratch& S, SlicedMatrix& out, int nrows, int ncols, int64_t nnz, const int* dptr, const int* didx,
                          const double* dval, hipStream_t s, int ns_request = 0);
 bool device_build_sorted_fused(LayoutScratch& S, SortedMatrix& out, int nrows, int ncols, int64_t nnz, const int* dptr, const int* didx,

@@ -14,6 +14,7 @@
 // (spmv.hip) stays as that test's reference and as the path of matrices the device path does not cover
 // (long rows, gathered vectors that fit an XCD's L2, gathers with locality: phased / fused / sorted-fused layouts).
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <chrono>
 #include <memory>
@@ -73,6 +74,9 @@ __global__ void max_len_kernel(int nrows, const int* __restrict__ ptr, int* out)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) best = max(best, __shfl_xor(best, d, 64));
     if ((threadIdx.x & 63) == 0 && best > 0) atomicMax(out, best);
+}
+__global__ void row_extent_kernel(int n, const int* __restrict__ rows, const int* __restrict__ ptr, int* __restrict__ ext) {
+    IPXK_GS(l, n) { ext[2 * l] = ptr[rows[l]]; ext[2 * l + 1] = ptr[rows[l] + 1]; }
 }
 // key of the sliced layout: (tile, row in tile), tile = row block * ns + slice of the gathered index
 __global__ void sliced_keys_kernel(int nrows, const int* __restrict__ ptr, const int* __restrict__ idx, int R, int ns, int slice,
@@ -489,6 +493,107 @@ int device_max_row_length(LayoutScratch& S, int nrows, const int* dptr, hipStrea
     IPXK_HIP(hipMemcpyAsync(&h, S.stats.get(), sizeof(int), hipMemcpyDeviceToHost, s));
     IPXK_HIP(hipStreamSynchronize(s));
     return h;
+}
+
+// ---------------------------------------------------------------------------
+// Long rows (more than kMaxRowLen entries: dense columns of A in the row-wise copy, dense rows in the column-wise one) taken out of a
+// row-wise matrix on the device: the flags, the segment arrays of the long-row kernels -- equal to GatherMatrix::build()'s -- and the
+// matrix with those rows left empty, from which the tile layouts are then built as for a matrix without long rows.
+// (Until round 5 a single long row sent the whole model to the host builders: 1.1 s per gather matrix at 15 M entries.)
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int kMaxLongRowsDevice = 1 << 16;
+__global__ void long_flag_kernel(int nrows, const int* __restrict__ ptr, unsigned char* __restrict__ flag, int* __restrict__ slen, int* counters,
+                                 int* __restrict__ list, int cap) {
+    IPXK_GS(r, (int64_t)nrows + 1) {
+        if (r == nrows) { slen[r] = 0; continue; }
+        const int len = ptr[r + 1] - ptr[r];
+        const bool lg = len > kMaxRowLen;
+        flag[r] = lg ? 1 : 0;
+        slen[r] = lg ? 0 : len;
+        if (lg) {
+            const int k = atomicAdd(counters, 1);
+            if (k < cap) list[k] = (int)r;
+        }
+    }
+}
+__global__ void strip_copy_kernel(int nrows, const int* __restrict__ ptr, const int* __restrict__ sptr, const unsigned char* __restrict__ flag,
+                                  const int* __restrict__ idx, const double* __restrict__ val, int* __restrict__ oidx, double* __restrict__ oval) {
+    // 8 lanes per row: a wavefront copies 8 rows, consecutive entries by consecutive lanes
+    const int g = threadIdx.x & 7;
+    for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; r < nrows; r += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+        if (flag[r]) continue;
+        const int p0 = ptr[r], len = ptr[r + 1] - p0, q0 = sptr[r];
+        for (int t = g; t < len; t += 8) { oidx[q0 + t] = idx[p0 + t]; oval[q0 + t] = val[p0 + t]; }
+    }
+}
+__global__ void long_copy_kernel(const int* __restrict__ lrow, const int* __restrict__ loff, const int* __restrict__ ptr, const int* __restrict__ idx,
+                                 const double* __restrict__ val, int* __restrict__ lidx, double* __restrict__ lval) {
+    const int l = blockIdx.x, r = lrow[l], p0 = ptr[r], len = ptr[r + 1] - p0, q0 = loff[l];
+    for (int t = threadIdx.x; t < len; t += blockDim.x) { lidx[q0 + t] = idx[p0 + t]; lval[q0 + t] = val[p0 + t]; }
+}
+}  // namespace
+
+bool device_strip_long_rows(LayoutScratch& S, GatherMatrix& G, int nrows, const int* dptr, const int* didx, const double* dval,
+                            DevBuf<int>& sptr, DevBuf<int>& sidx, DevBuf<double>& sval, int64_t* nnz_short, hipStream_t s) {
+    S.stats.ensure(8);
+    IPXK_HIP(hipMemsetAsync(S.stats.get(), 0, 8 * sizeof(int), s));
+    DevBuf<int> slen((size_t)nrows + 1), list((size_t)kMaxLongRowsDevice);
+    G.row_long.ensure((size_t)nrows);
+    hipLaunchKernelGGL(long_flag_kernel, dim3(gridn((int64_t)nrows + 1)), dim3(kBlock), 0, s, nrows, dptr, G.row_long.get(), slen.get(), S.stats.get(),
+                       list.get(), kMaxLongRowsDevice);
+    sptr.ensure((size_t)nrows + 1);
+    {
+        size_t bytes = 0;
+        IPXK_HIP(rocprim::exclusive_scan(nullptr, bytes, slen.get(), sptr.get(), 0, (size_t)nrows + 1, rocprim::plus<int>(), s));
+        IPXK_HIP(rocprim::exclusive_scan(S.T.need(bytes), bytes, slen.get(), sptr.get(), 0, (size_t)nrows + 1, rocprim::plus<int>(), s));
+    }
+    int nl = 0, ns_total = 0;
+    IPXK_HIP(hipMemcpyAsync(&nl, S.stats.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipMemcpyAsync(&ns_total, sptr.get() + nrows, sizeof(int), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    if (nl <= 0 || nl > kMaxLongRowsDevice) return false;
+    std::vector<int> lrow((size_t)nl);
+    IPXK_HIP(hipMemcpyAsync(lrow.data(), list.get(), (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, s));
+    IPXK_HIP(hipStreamSynchronize(s));
+    std::sort(lrow.begin(), lrow.end());                       // (the atomic appended them in no particular order)
+    // their extents: two words per long row
+    DevBuf<int> dl((size_t)nl), ext((size_t)2 * nl);
+    dl.upload(lrow, s);
+    hipLaunchKernelGGL(row_extent_kernel, dim3(gridn(nl)), dim3(kBlock), 0, s, nl, dl.get(), dptr, ext.get());
+    std::vector<int> he((size_t)2 * nl);
+    ext.download(he.data(), he.size(), s);
+    IPXK_HIP(hipStreamSynchronize(s));
+    std::vector<int> sp0, sp1, lslot, loff((size_t)nl);
+    int64_t nlong_entries = 0;
+    for (int l = 0; l < nl; l++) {
+        const int len = he[2 * l + 1] - he[2 * l];
+        loff[l] = (int)nlong_entries;
+        lslot.push_back((int)sp0.size());
+        for (int q0 = 0; q0 < len; q0 += kLongSeg) {
+            sp0.push_back((int)(nlong_entries + q0));
+            sp1.push_back((int)(nlong_entries + std::min(q0 + kLongSeg, len)));
+        }
+        nlong_entries += len;
+    }
+    lslot.push_back((int)sp0.size());
+    G.nlong = nl;
+    G.nseg = (int)sp0.size();
+    G.seg_p0.upload(sp0, s); G.seg_p1.upload(sp1, s); G.long_row.upload(lrow, s); G.long_slot.upload(lslot, s);
+    G.lidx.ensure((size_t)nlong_entries); G.lval.ensure((size_t)nlong_entries);
+    DevBuf<int> doff((size_t)nl);
+    doff.upload(loff, s);
+    hipLaunchKernelGGL(long_copy_kernel, dim3(nl), dim3(kBlock), 0, s, dl.get(), doff.get(), dptr, didx, dval, G.lidx.get(), G.lval.get());
+    G.long_partials.resize((size_t)std::max(G.nseg, 1));
+    G.h_row_long.assign((size_t)nrows, 0);
+    for (int r : lrow) G.h_row_long[(size_t)r] = 1;
+    sidx.ensure((size_t)std::max(ns_total, 1)); sval.ensure((size_t)std::max(ns_total, 1));
+    hipLaunchKernelGGL(strip_copy_kernel, dim3(gridn((int64_t)nrows * 8)), dim3(kBlock), 0, s, nrows, dptr, sptr.get(), G.row_long.get(), didx, dval,
+                       sidx.get(), sval.get());
+    IPXK_HIP(hipStreamSynchronize(s));                          // the host vectors and temporaries go out of scope
+    IPXK_HIP(hipGetLastError());
+    *nnz_short = ns_total;
+    return true;
 }
 
 // ---------------------------------------------------------------------------

@@ -329,10 +329,7 @@ bool GatherMatrix::build_device_local(LayoutScratch& S, int64_t nrows_, int64_t 
     if (!device_build_sliced(S, fu, (int)nrows_, (int)ncols_, nnz_, dptr, didx, dval, s, 1)) return false;
     nrows = (int)nrows_; ncols = (int)ncols_; nnz = nnz_;
     set_geometry(nrows_, ncols_);
-    nlong = 0; nseg = 0;
-    h_row_long.clear();
-    long_partials.resize(1);
-    sliced = std::move(fu);
+    sliced = std::move(fu);                       // (nlong, nseg, ... : set by build_device)
     sliced.dominant_fraction = share;
     use_sliced = true;
     use_sorted = false; use_sorted_fused = false; use_acc = false; use_acc_fused = false; use_plain = false;
@@ -366,7 +363,7 @@ bool GatherMatrix::build_device_local(LayoutScratch& S, int64_t nrows_, int64_t 
         else { use_sorted_fused = false; if (!keep_all) sorted = SortedMatrix(); }
     }
     AccMatrix af;
-    if (!(getenv("IPXK_SPMV_ACC") && getenv("IPXK_SPMV_ACC")[0] == '0') && device_build_acc_fused(S, af, nrows, ncols, nnz_, dptr, didx, dval, s)) {
+    if (nlong == 0 && !(getenv("IPXK_SPMV_ACC") && getenv("IPXK_SPMV_ACC")[0] == '0') && device_build_acc_fused(S, af, nrows, ncols, nnz_, dptr, didx, dval, s)) {
         accf = std::move(af);
         use_acc_fused = true;
         tuned_us_acc_fused = time_current();
@@ -401,16 +398,28 @@ bool GatherMatrix::build_device(LayoutScratch& S, int64_t nrows_, int64_t ncols_
     if (const char* e = getenv("IPXK_SPMV_SORTED")) if (e[0] == '0') return false;
     if (tune_level < 2 || keep_plain || nnz_ < (1 << 16) || getenv("IPXK_STAMPS")) return false;
     if (nrows_ >= (int64_t(1) << 31) - 1 || ncols_ >= (int64_t(1) << 31) - 1 || nnz_ >= (int64_t(1) << 31) - kLongSeg) return false;
-    if (device_max_row_length(S, (int)nrows_, dptr, s) > kMaxRowLen) return false;      // long rows: host path
-    SlicedMatrix sl;
-    const bool slices = device_build_sliced(S, sl, (int)nrows_, (int)ncols_, nnz_, dptr, didx, dval, s);
-    if (!slices || !(sl.dominant_fraction <= 1.5 / sl.nslices))
-        return build_device_local(S, nrows_, ncols_, nnz_, dptr, didx, dval, slices ? sl.dominant_fraction : 1.0, s);
-    nrows = (int)nrows_; ncols = (int)ncols_; nnz = nnz_;
-    set_geometry(nrows_, ncols_);
     nlong = 0; nseg = 0;
     h_row_long.clear();
     long_partials.resize(1);
+    // long rows go to the long-row kernels' arrays; the tile layouts are built from the matrix without them
+    DevBuf<int> sptr, sidx;
+    DevBuf<double> sval;
+    const int64_t nnz_all = nnz_;
+    if (device_max_row_length(S, (int)nrows_, dptr, s) > kMaxRowLen) {
+        if (getenv("IPXK_LONG_ROWS_HOST")) return false;                                // (tests: the host builders as the reference)
+        if (!device_strip_long_rows(S, *this, (int)nrows_, dptr, didx, dval, sptr, sidx, sval, &nnz_, s)) return false;
+        dptr = sptr.get(); didx = sidx.get(); dval = sval.get();
+        if (nnz_ < (1 << 16)) { nlong = 0; nseg = 0; h_row_long.clear(); return false; }
+    }
+    SlicedMatrix sl;
+    const bool slices = device_build_sliced(S, sl, (int)nrows_, (int)ncols_, nnz_, dptr, didx, dval, s);
+    if (!slices || !(sl.dominant_fraction <= 1.5 / sl.nslices)) {
+        const bool ok = build_device_local(S, nrows_, ncols_, nnz_, dptr, didx, dval, slices ? sl.dominant_fraction : 1.0, s);
+        nnz = nnz_all;
+        return ok;
+    }
+    nrows = (int)nrows_; ncols = (int)ncols_; nnz = nnz_;
+    set_geometry(nrows_, ncols_);
     sliced = std::move(sl);
     use_sliced = true;
     use_sorted = false; use_sorted_fused = false;
@@ -460,6 +469,7 @@ bool GatherMatrix::build_device(LayoutScratch& S, int64_t nrows_, int64_t ncols_
                 nrows, ncols, (long long)nnz, tuned_us_sliced, tuned_us_sorted, tuned_us_acc, (long long)acc.nbatches,
                 acc.built ? 100.0 * (double)acc.deferred / (double)nnz : 0.0, sliced.dominant_fraction,
                 use_acc ? "accumulated" : use_sorted ? "sorted" : "sliced");
+    nnz = nnz_all;
     return true;
 }
 

@@ -165,3 +165,69 @@ def test_device_layouts_of_matrices_with_locality_equal_host_layouts():
                     host.close()
         finally:
             dev.close()
+
+
+def _lp_with_long_rows_and_columns(m, n, seed):
+    """synthetic LP plus a ladder of longer and longer columns and rows (12 ... 6000 entries, each at most 1.5 x the one before, so
+    that the reference's FindDenseColumns, src/model.cc, flags none of them): rows of more than 255 entries in both gather matrices,
+    some of them longer than one segment of the long-row kernels (2048)"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    lens = [12]
+    while lens[-1] < 6000:
+        lens.append(int(lens[-1] * 1.5))
+    rows, cols, vals = [], [], []
+    for k, L in enumerate(lens):
+        for rep in range(3):
+            j = int(rng.integers(0, n))
+            r = rng.choice(m, L, replace=False)
+            rows += list(r); cols += [j] * L; vals += list(rng.uniform(0.5, 2.0, L) * rng.choice([-1.0, 1.0], L))
+            i = int(rng.integers(0, m))
+            c = rng.choice(n, L, replace=False)
+            rows += [i] * L; cols += list(c); vals += list(rng.uniform(0.5, 2.0, L) * rng.choice([-1.0, 1.0], L))
+    E = sp.coo_matrix((vals, (rows, cols)), shape=(m, n)).tocsc()
+    T = (synth.synthetic_lp(m, n, 8, seed).to_scipy() + E).tocsc()
+    T.sum_duplicates(); T.sort_indices()
+    return synth.CscMatrix(m, n, T.indptr.astype(np.int64), T.indices.astype(np.int64), T.data.copy())
+
+
+def test_long_rows_are_taken_out_on_the_device():
+    """a model with rows of more than 255 entries in A and in A' (none of them a dense column by the reference's rule): the device builders
+    take them out (layout_device.hip, device_strip_long_rows) instead of handing the model to the host builders; products and a KKT solve
+    against the host-built context and scipy"""
+    A = _lp_with_long_rows_and_columns(300000, 700000, 11)
+    rng = np.random.default_rng(2)
+    W = rng.uniform(0.1, 10.0, A.nrow + A.ncol)
+    y = rng.standard_normal(A.nrow)
+    S0 = A.to_scipy()
+    ref = W[A.ncol:] * y + S0 @ (W[:A.ncol] * (S0.T @ y))
+    st = synth.synthetic_ipm_state(A.nrow, A.ncol, 1.0, 3)
+    out = {}
+    for mode in ("device", "host"):
+        env = {"IPXK_LONG_ROWS_HOST": "1"} if mode == "host" else {}
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            c = kkt.KktContext(A, device=0)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        try:
+            assert c.num_dense_cols == 0
+            info = [c.layout_info(w) for w in (0, 1)]
+            assert info[0][0]["nlong"] > 0 and info[1][0]["nlong"] > 0, info
+            c.normal_prepare(W)
+            l, d = c.normal_apply(y)
+            assert np.abs(l - ref).max() <= 1e-12 * np.abs(ref).max(), mode
+            c.kkt_diag_factorize(st["xl"], st["xu"], st["zl"], st["zu"], st["mu"])
+            x, yy, it, e, _ = c.kkt_diag_solve(st["a"], st["b"], 0.3 * np.sqrt(st["mu"]), 500)
+            out[mode] = (l, it, e, yy, [i[0]["nlong"] for i in info], sum(info[0][1]), c.spmv_layout()[0])
+        finally:
+            c.close()
+    d, h = out["device"], out["host"]
+    assert d[4] == h[4], (d[4], h[4])
+    assert np.abs(d[0] - h[0]).max() <= 1e-13 * np.abs(h[0]).max()
+    assert d[2] == h[2] == 0 and abs(d[1] - h[1]) <= 1
+    assert np.abs(d[3] - h[3]).max() <= 1e-6 * np.abs(h[3]).max()
+    print("create with long rows: device builders %.1f ms (%s), host builders %.1f ms (%s)" % (d[5], d[6], h[5], h[6]))
+    assert d[5] < 0.5 * h[5], (d[5], h[5])
