@@ -2264,8 +2264,14 @@ static void lu_factorize_device(Context* c, LuState* S, int dim, int64_t nb_in, 
                 uint32_t mask[8];
                 for (int w = 0; w < 8; w++) mask[w] = 0xffffffffu;
                 const bool spread = getenv("IPXK_LU_LOOKAHEAD_SPREAD") != nullptr;       // (measurement: the free units taken from all eight words of the mask)
-                for (int b = 0; b < free_cus; b++) {
-                    const int bit = spread ? (b % 8) * 32 + b / 8 : b;
+                // (bit b of the mask = unit b / 8 of XCC b % 8, scripts/bench_cumask.hip; an XCC whose bits are all clear keeps all its units: the
+                // default frees 4 units of every XCD.  Measured and not used: 16 / 24 units of XCC 0 alone for a one-XCD panel of 16 / 24
+                // workgroups with two rows per thread -- workgroups go to the XCCs in turn whatever the mask says, so the late update's share
+                // on XCC 0 crawls on what is left of it: 8000 rows 62.7 -> 82 / 106 ms, 12 000 rows 149 -> 205 / 324 ms)
+                int xcc0 = 0;
+                if (const char* e = getenv("IPXK_LU_LOOKAHEAD_XCC0")) xcc0 = std::max(0, std::min(31, atoi(e)));    // (measurement: that many units of XCC 0 only)
+                for (int b = 0; b < (xcc0 ? xcc0 : free_cus); b++) {
+                    const int bit = xcc0 ? 8 * b : spread ? (b % 8) * 32 + b / 8 : b;
                     mask[bit / 32] &= ~(1u << (bit % 32));
                 }
                 if (free_cus > 0 && hipExtStreamCreateWithCUMask(&W_.s2, 8, mask) != hipSuccess) {
