@@ -231,3 +231,44 @@ def test_long_rows_are_taken_out_on_the_device():
     assert np.abs(d[3] - h[3]).max() <= 1e-6 * np.abs(h[3]).max()
     print("create with long rows: device builders %.1f ms (%s), host builders %.1f ms (%s)" % (d[5], d[6], h[5], h[6]))
     assert d[5] < 0.5 * h[5], (d[5], h[5])
+
+
+def test_basis_operator_on_a_model_with_long_rows_built_on_the_device():
+    """the basis-split operator C = I + inv(B) N N' inv(B') (N N' on the model matrix with masked values: the model has long rows, so N is
+    not built as a matrix of its own) on the device-built layouts against the host-built ones and against scipy"""
+    import scipy.sparse as sp
+    m, n = 200000, 450000
+    A0 = _lp_with_long_rows_and_columns(m, n, 12)
+    B = synth.planted_lu_basis(A0, offdiag=3, seed=21)
+    colscale = synth.synthetic_basis_state(B["status"], 1.0, 21)
+    u = np.random.default_rng(4).standard_normal(m)
+    out = {}
+    for mode in ("device", "host"):
+        env = {"IPXK_LONG_ROWS_HOST": "1"} if mode == "host" else {}
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            c = kkt.KktContext(B["A"], device=0)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        try:
+            assert c.layout_info(0)[0]["nlong"] > 0 or c.layout_info(1)[0]["nlong"] > 0
+            c.split_prepare(B["L"], B["U"], B["rowperm"], B["colperm"], B["basis"], B["status"], colscale)
+            out[mode] = c.split_apply(u)[0]
+        finally:
+            c.close()
+    assert np.abs(out["device"] - out["host"]).max() <= 1e-12 * np.abs(out["host"]).max()
+    # scipy: C u = u + inv(Bs) N N' inv(Bs') u in pivot order; Bs = (L+I) U diag(s) with s the scaling of the basic columns in pivot order,
+    # N = the nonbasic columns, scaled, rows in pivot order
+    from scipy.sparse.linalg import spsolve_triangular
+    AI = sp.hstack([B["A"].to_scipy(), sp.identity(m, format="csc")]).tocsc()
+    s_piv = colscale[B["basis"][B["colperm"]]]
+    nb = np.flatnonzero(B["status"] == -1)
+    N = (AI[:, nb] @ sp.diags(colscale[nb])).tocsr()[B["rowperm"], :].tocsc()
+    L1 = (B["L"].to_scipy() + sp.identity(m)).tocsr()
+    U = B["U"].to_scipy().tocsr()
+    w = spsolve_triangular(L1.T.tocsr(), spsolve_triangular(U.T.tocsr(), u / s_piv, lower=True), lower=False)
+    t = N @ (N.T @ w)
+    ref = u + spsolve_triangular(U, spsolve_triangular(L1, t, lower=True), lower=False) / s_piv
+    assert np.abs(out["device"] - ref).max() <= 1e-9 * np.abs(ref).max()
