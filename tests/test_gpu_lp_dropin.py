@@ -317,3 +317,48 @@ def test_deferred_basis_load_changes_nothing_but_the_number_of_loads(tmp_path):
     assert d["pobjval"] == e["pobjval"] and d["dobjval"] == e["dobjval"] and close(d["objval"], e["objval"], 1e-12)
     print("LU requests of the Basis: deferred %d (reused %d), eager %d (reused %d)" % (d["lu_factorizations"], d["lu_reused"], e["lu_factorizations"], e["lu_reused"]))
     assert d["lu_factorizations"] < e["lu_factorizations"] and e["lu_reused"] > d["lu_reused"] >= 1
+
+
+def lp_with_dense_rows_and_columns(m, n, seed, k=6):
+    """general_lp plus three dense constraint rows (400 / 1500 / 3000 entries: rows of more than 255 entries in the gather matrix of A, taken
+    out by the device layout builders) and two columns of 600 entries (dense columns by the reference's rule, src/model.cc:34-56: the
+    diagonal preconditioner of the initial phase takes its Sherman-Morrison-Woodbury branch); feasible and bounded by construction"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    obj, lb, ub, Ap, Ai, Ax, rhs, ct = general_lp(m, n, seed, k=k)
+    S = sp.csc_matrix((np.asarray(Ax), np.asarray(Ai), np.asarray(Ap)), shape=(m, n)).tolil()
+    for L in (400, 1500, 3000):
+        i = int(rng.integers(0, m))
+        c = rng.choice(n, L, replace=False)
+        S[i, c] = rng.uniform(0.5, 2.0, L) * rng.choice([-1.0, 1.0], L)
+    for rep in range(2):
+        j = int(rng.integers(0, n))
+        r = rng.choice(m, 600, replace=False)
+        S[r, j] = rng.uniform(0.5, 2.0, 600) * rng.choice([-1.0, 1.0], 600)
+    S = S.tocsc(); S.sort_indices()
+    # the same interior point as general_lp's: recompute the right-hand side and the objective for the new matrix
+    x0 = rng.uniform(0.5, 2.0, n)
+    lb2, ub2 = np.asarray(lb, float), np.asarray(ub, float)
+    boxed = np.isfinite(lb2) & np.isfinite(ub2)
+    x0[boxed] = 0.5 * (lb2[boxed] + ub2[boxed])
+    ctv = np.asarray(ct)
+    s0 = np.where(ctv == "=", 0.0, rng.uniform(0.5, 2.0, m))
+    rhs = S @ x0 + s0
+    y0 = np.where(ctv == "=", rng.uniform(-1.0, 1.0, m), -rng.uniform(0.5, 1.5, m))
+    zl = np.where(np.isfinite(lb2), rng.uniform(0.5, 2.0, n), 0.0)
+    zu = np.where(np.isfinite(ub2), rng.uniform(0.5, 2.0, n), 0.0)
+    obj = S.T @ y0 + zl - zu
+    return (obj, lb2, ub2, S.indptr.astype(np.int64), S.indices.astype(np.int64), S.data, rhs, list(ct))
+
+
+@pytest.mark.gpu
+def test_lp_with_dense_rows_and_dense_columns_through_both_solvers(tmp_path):
+    """a model of more than 65 536 entries (the device layout builders' range) with long rows and dense columns through the reference's
+    whole LpSolver on the Hip classes and on its own: same statuses and objectives (compare_runs)"""
+    _need_bins()
+    model = lp_with_dense_rows_and_columns(5000, 13000, 51)
+    ref, hip = both(tmp_path, "lpdense", *model, crossover=0)
+    compare_runs(ref, hip)
+    assert hip[0]["status_ipm"] == IPX_STATUS_optimal, hip[2]
+    assert hip[0]["kktiter1"] > 0 and hip[0]["kktiter2"] > 0
+    print("time_ipm1 ref %.3f hip %.3f, time_ipm2 ref %.3f hip %.3f" % (ref[0]["time_ipm1"], hip[0]["time_ipm1"], ref[0]["time_ipm2"], hip[0]["time_ipm2"]))
