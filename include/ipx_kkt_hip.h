@@ -328,7 +328,9 @@ int ipxk_split_prepare_lu(ipxk_context* ctx, const ipxint* status,
  * exchange fails the stability test (the pivot from the tableau row against the
  * one from the tableau column, relative 1e-8).  On return basis_out[m] /
  * status_out[n+m] hold the new basis (either may be NULL), the context the
- * operator for it, exchange_log (may be NULL) the accepted exchanges as pairs
+ * operator for it (by a fresh factorization, src/kkt_solver_basis.cc:56-61, or -- when that would cost more than
+ * carrying the last exchanges through the solves that follow, a fixed cost model -- by the earlier factors with the
+ * exchanges as a product form behind them: info.kept_etas; IPXK_MAXVOL_KEEP_ETAS=0 in the environment: always fresh), exchange_log (may be NULL) the accepted exchanges as pairs
  * (leaving variable, entering variable), at most log_cap of them.
  * info.errflag: 0, or IPX_ERROR_basis_too_ill_conditioned (306). */
 typedef struct {
@@ -347,6 +349,10 @@ typedef struct {
   ipxint errflag;
   double volinc;                     /* Maxvolume::volinc(): log2 of the volume gained */
   double seconds;
+  ipxint kept_etas;                  /* > 0: no final refactorization -- the context holds the factors of an earlier basis and
+                                        this many etas (product form) behind them, which every solve and operator application
+                                        of the context applies, and the next ipxk_maxvolume goes on with; any factorization
+                                        in the context (ipxk_lu_factorize*, ipxk_split_prepare*) ends that state */
 } ipxk_maxvolume_info;
 int ipxk_maxvolume(ipxk_context* ctx, const ipxint* status, const double* colscale,
                    const ipxk_maxvolume_params* params, ipxint* basis_out,

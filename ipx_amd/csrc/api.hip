@@ -278,6 +278,7 @@ int ipxk_reset_solver_state(ipxk_context* c, double lu_pivottol) {
         lu_invalidate(c);
         nmatrix_invalidate(c);
         c->maxvol_pivottol = lu_pivottol > 0.0 ? lu_pivottol : 0.1;
+        maxvol_drop_etas(c);
         c->interrupt = nullptr;
         c->interrupt_user = nullptr;
         c->profile_ops = false;

@@ -138,6 +138,7 @@ struct Context {
     LuState* lu = nullptr;                 // factors of the last ipxk_lu_factorize* (lu.hip)
     DevBuf<double> dense_work;             // workspace of the dense block inverse (dense_inverse.hip), grow-only
     MaxvolState* maxvol = nullptr;         // workspaces of ipxk_maxvolume (maxvolume.hip)
+    bool etas_live = false;                // the operator `split` stands for a LATER basis than its factors: Maxvolume's last exchanges are applied as etas behind them (maxvolume.hip)
     NMatrix* nmat = nullptr;               // N of the split operator as a matrix of its own (nmatrix.hip)
 
     // ---- multi-GPU ----
@@ -273,6 +274,8 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
 // lhs = C rhs (device vectors), dot partials -> part(kPartCdot); returns # partials
 int split_apply_dev(Context* c, const double* rhs, double* lhs, const int* done);
 void split_rescale_host(Context* c, const ipxint* status, const double* colscale);
+// the operator follows Maxvolume's exchanges without new factors (Context::etas_live): the basis by position (device), its statuses and scaling
+void split_follow_basis(Context* c, const ipxint* basis_dev, const ipxint* status, const double* colscale);
 // out = inverse(B) in / inverse(B') in on the (scaled) factors; in may be out
 void forward_solve_dev(Context* c, const double* in, double* out, bool scaled, const int* done);
 void backward_solve_dev(Context* c, const double* in, double* out, bool scaled, const int* done);
@@ -302,6 +305,9 @@ void maxvolume_sequential_dev(Context* c, const ipxint* status, const double* co
                               ipxint max_etas, ipxint* basis_out, ipxint* status_out, ipxk_maxvolume_info* info, ipxint* log,
                               ipxint log_cap);
 void destroy_maxvol(MaxvolState*);
+void maxvol_apply_etas(Context* c, bool transposed, double* v);     // v (by basis position) <- inverse(E_K ... E_1) v  /  its transpose
+const ipxint* maxvol_current_basis(Context* c);                     // device, by basis position: the basis factors + etas stand for
+void maxvol_drop_etas(Context* c);                                  // a new factorization / operator: the eta file is history
 void destroy_nmatrix(NMatrix*);
 void nmatrix_invalidate(Context* c);
 // N = the NONBASIC columns of A with nonzero weight as a pair of gather matrices built on the device (nmatrix.hip):

@@ -24,6 +24,7 @@
 // restatement the tests compare with keeps the same etas.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_scan.hpp>
+#include <exception>
 
 #include <algorithm>
 #include <chrono>
@@ -265,6 +266,87 @@ __global__ __launch_bounds__(kEtaDenseMax) void mv_eta_dense_btran_solve_kernel(
     if (t < K && prev[t] < 0) v[pos[t]] = s_w[t];
 }
 
+// ---- the two triangular systems as MATRICES (for the eta file that stays behind the factors after Maxvolume, see maxvol_apply_etas) ----
+// The multipliers are linear in what the solve kernels read: forward  alpha = F vp  (vp = the vector at the positions of the etas that
+// are the FIRST at their position, Kd of them), backward  w = G [d; vp].  One workgroup per unit input runs the solve kernel's own
+// recurrence (same chains of repeated positions), all unit inputs in parallel; an application inside the CR loop of the KKT solve is
+// then two small matrix-vector products instead of K dependent steps with two barriers each (0.55 us per eta: 0.25 ms at K = 450).
+// Other rounding than the sequential form (sums in another order), which Maxvolume itself keeps for its decisions.
+__global__ __launch_bounds__(kEtaDenseMax) void mv_eta_forward_matrix_kernel(int K, int Kd, int cap, const int* __restrict__ first, const double* __restrict__ piv,
+                                                                            const int* __restrict__ prev, const double* __restrict__ Tt,
+                                                                            double* __restrict__ F) {
+    __shared__ double s_alpha;
+    const int t = threadIdx.x, j = blockIdx.x;
+    const int pr = t < K ? prev[t] : -1;
+    double r = (t < K && t == first[j]) ? 1.0 : 0.0;                // unit input: 1 at the position whose first eta is first[j]
+    const double pv = t < K ? piv[t] : 1.0;
+    for (int s = 0; s < K; s++) {
+        if (t == s) { const double a = r / pv; s_alpha = a; F[(size_t)s * Kd + j] = a; }
+        __syncthreads();
+        const double a = s_alpha;
+        if (t > s && t < K) {
+            if (s == pr) r = a;
+            else if (s > pr) r -= Tt[(size_t)s * cap + t] * a;
+        }
+        __syncthreads();
+    }
+}
+// unit input u < K: d = e_u, vp = 0;  u >= K: d = 0, vp = e_(u-K)
+__global__ __launch_bounds__(kEtaDenseMax) void mv_eta_backward_matrix_kernel(int K, int Kd, int cap, const int* __restrict__ jof, const double* __restrict__ piv,
+                                                                             const int* __restrict__ prev, const int* __restrict__ next,
+                                                                             const double* __restrict__ T, double* __restrict__ G) {
+    __shared__ double s_diff;
+    __shared__ double s_w[kEtaDenseMax];
+    const int t = threadIdx.x, u = blockIdx.x, W = K + Kd;
+    const double cv = (t < K && u >= K && jof[t] == u - K) ? 1.0 : 0.0;
+    const double dt = (t < K && u == t) ? 1.0 : 0.0, pv = t < K ? piv[t] : 1.0;
+    const int nx = t < K ? next[t] : -1;
+    double acc = 0.0;
+    __syncthreads();
+    for (int s = K - 1; s >= 0; s--) {
+        if (t == s) {
+            const double cur = nx >= 0 ? s_w[nx] : cv;
+            const double w = (cur - dt - acc) / pv;
+            s_w[s] = w;
+            s_diff = w - cv;
+            G[(size_t)s * W + u] = w;
+        }
+        __syncthreads();
+        if (t < s && prev[s] <= t) acc += T[(size_t)s * cap + t] * s_diff;
+        __syncthreads();
+    }
+}
+// alpha[t] = F[t] . vp,  vp[j] = v[pos[first[j]]]   (one wavefront per row)
+__global__ __launch_bounds__(kBlock) void mv_eta_forward_gemv_kernel(int K, int Kd, const double* __restrict__ F, const int* __restrict__ first,
+                                                                    const int* __restrict__ pos, const double* __restrict__ v, double* __restrict__ alpha) {
+    const int lane = threadIdx.x & 63;
+    for (int t = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); t < K; t += gridDim.x * (kBlock / 64)) {
+        double sum = 0.0;
+        for (int j = lane; j < Kd; j += 64) sum += F[(size_t)t * Kd + j] * v[pos[first[j]]];
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) sum += __shfl_xor(sum, k, 64);
+        if (lane == 0) alpha[t] = sum;
+    }
+}
+// w[t] = G[t] . [d; vp]
+__global__ __launch_bounds__(kBlock) void mv_eta_backward_gemv_kernel(int K, int Kd, const double* __restrict__ G, const int* __restrict__ first,
+                                                                     const int* __restrict__ pos, const double* __restrict__ d, const double* __restrict__ v,
+                                                                     double* __restrict__ w) {
+    const int lane = threadIdx.x & 63, W = K + Kd;
+    for (int t = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); t < K; t += gridDim.x * (kBlock / 64)) {
+        double sum = 0.0;
+        for (int u = lane; u < W; u += 64) sum += G[(size_t)t * W + u] * (u < K ? d[u] : v[pos[first[u - K]]]);
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) sum += __shfl_xor(sum, k, 64);
+        if (lane == 0) w[t] = sum;
+    }
+}
+// v[pos[first[j]]] = w[first[j]]
+__global__ void mv_eta_backward_scatter_kernel(int Kd, const int* __restrict__ first, const int* __restrict__ pos, const double* __restrict__ w,
+                                               double* __restrict__ v) {
+    IPXK_GRID_STRIDE(j, Kd) v[pos[first[j]]] = w[first[j]];
+}
+
 // ---- ScaleFtran (src/maxvolume.cc:322-337) + the recomputed weight (:269-275) + # nonzeros of the column ----
 __global__ __launch_bounds__(kBlock) void mv_scale_ftran_kernel(int m, const Scalars* S, const double* __restrict__ lhs,
                                                                 const double* __restrict__ colscale, const double* __restrict__ invscale,
@@ -502,11 +584,24 @@ struct MaxvolState {
     // the etas as dense vectors (mv_eta_dense_*): E [cap][m], T / Tt [cap][cap], multipliers, dots, links between the exchanges of a position
     DevBuf<double> etaE, etaT, etaTt, eta_alpha, eta_d;
     DevBuf<int> eta_prev, eta_next, eta_last;
+    DevBuf<double> etaF, etaG, eta_w;      // the triangular systems of a kept eta file as matrices (mv_eta_*_matrix_kernel)
+    DevBuf<int> eta_first, eta_jof;
     DevBuf<ipxint> basis, status;
     DevBuf<Part> part;
     DevBuf<Scalars> scalars;
     DevBuf<unsigned char> tmp;
     Scalars* h = nullptr;      // pinned
+    // the eta file kept BEHIND the resident factors between two calls (Context::etas_live): what EtaFile needs to go on, and the basis
+    // the factors + etas represent (by basis position; the device copy is `basis`)
+    struct Saved {
+        bool live = false, dense = false, have_history = false;
+        int K = 0, cap = 0, m = 0;
+        int64_t sparse_used = 0, seg_nnz = 0;
+        double overhead_s = 0.0, refactor_s = 0.0;
+        long lu_generation = -1;       // of the factors the etas stand behind (a later factorization in the context: no resuming)
+        int Kd = 0;                    // > 0: etaF / etaG hold the matrices of the two triangular systems (Kd etas are the first at their position)
+    } saved;
+    std::vector<ipxint> basis_h;
     ~MaxvolState() { if (h) (void)hipHostFree(h); }
 };
 void destroy_maxvol(MaxvolState* M) { delete M; }
@@ -539,7 +634,7 @@ struct EtaFile {
     double cost_list(double nnz) const { return 2.5e-6 + 0.5e-9 * nnz; }
     double cost_dense() const { return 0.6e-6 + 8.0 * (double)m / 2e12; }
 
-    EtaFile(Context* ctx, MaxvolState& state, int rows, ipxint max_etas_in) : c(ctx), M(state), m(rows), s(ctx->stream) {
+    EtaFile(Context* ctx, MaxvolState& state, int rows, ipxint max_etas_in, bool resume = false) : c(ctx), M(state), m(rows), s(ctx->stream) {
         adaptive = max_etas_in < 0;
         limit = (int)std::max<ipxint>(1, max_etas_in > 0 ? max_etas_in : 100);
         static const bool dense_off = getenv("IPXK_MAXVOL_DENSE_ETAS") && getenv("IPXK_MAXVOL_DENSE_ETAS")[0] == '0';
@@ -549,7 +644,53 @@ struct EtaFile {
         if (!dense_possible) { cap = limit; adaptive = false; }
         sparse_cap = std::max<int64_t>(4 * (int64_t)m, int64_t(1) << 20);
         M.eta_pos.ensure((size_t)cap); M.eta_piv.ensure((size_t)cap);
-        reset(0);
+        const MaxvolState::Saved& sv = M.saved;
+        if (resume && sv.live && sv.cap == cap && sv.m == m && (sv.dense ? dense_possible : true)) {
+            // the etas of the previous call are still behind the factors: go on where it stopped
+            dense = sv.dense; have_history = sv.have_history; K = sv.K; sparse_used = sv.sparse_used; seg_nnz = sv.seg_nnz;
+            overhead_s = sv.overhead_s; refactor_s = sv.refactor_s;
+            resumed = true;
+        } else {
+            reset(0);
+        }
+    }
+    bool resumed = false;
+    void save() {
+        MaxvolState::Saved& sv = M.saved;
+        sv.live = true; sv.dense = dense; sv.have_history = have_history; sv.K = K; sv.cap = cap; sv.m = m; sv.sparse_used = sparse_used;
+        sv.seg_nnz = seg_nnz; sv.overhead_s = overhead_s; sv.refactor_s = refactor_s;
+        sv.lu_generation = lu_generation(c);
+        sv.Kd = 0;
+        static const bool matrices_off = getenv("IPXK_MAXVOL_ETA_MATRICES") && getenv("IPXK_MAXVOL_ETA_MATRICES")[0] == '0';
+        if (dense && K > 0 && !matrices_off) {
+            // the two triangular systems as matrices, for the applications inside the KKT solve (mv_eta_*_matrix_kernel)
+            std::vector<int> prev_h((size_t)K), pos_h((size_t)K), first, jof((size_t)K, -1);
+            M.eta_prev.download(prev_h.data(), (size_t)K, s);
+            M.eta_pos.download(pos_h.data(), (size_t)K, s);
+            IPXK_HIP(hipStreamSynchronize(s));
+            for (int t = 0; t < K; t++) {
+                if (prev_h[t] < 0) { jof[t] = (int)first.size(); first.push_back(t); }
+                else jof[t] = jof[prev_h[t]];
+            }
+            const int Kd = (int)first.size();
+            M.eta_first.upload(first, s); M.eta_jof.upload(jof, s);
+            M.etaF.ensure((size_t)K * Kd); M.etaG.ensure((size_t)K * (K + Kd)); M.eta_w.ensure((size_t)K);
+            hipLaunchKernelGGL(mv_eta_forward_matrix_kernel, dim3(Kd), dim3(kEtaDenseMax), 0, s, K, Kd, cap, M.eta_first.get(), M.eta_piv.get(),
+                               M.eta_prev.get(), M.etaTt.get(), M.etaF.get());
+            hipLaunchKernelGGL(mv_eta_backward_matrix_kernel, dim3(K + Kd), dim3(kEtaDenseMax), 0, s, K, Kd, cap, M.eta_jof.get(), M.eta_piv.get(),
+                               M.eta_prev.get(), M.eta_next.get(), M.etaT.get(), M.etaG.get());
+            IPXK_HIP(hipStreamSynchronize(s));               // (the host vectors go out of scope)
+            IPXK_HIP(hipGetLastError());
+            sv.Kd = Kd;
+        }
+    }
+    // what the K etas cost in the solves of one KKT solve (~ 100 CR iterations, one application per direction and iteration, a few dense
+    // solves around them) against what a refactorization costs: whether the etas stay behind the factors when Maxvolume is over
+    bool worth_keeping() const {
+        if (K == 0 || full()) return false;
+        // (dense form: the triangular systems go through their matrices inside the KKT solve -- what is left per eta is its row of E)
+        const double per_eta = dense ? 8.0 * (double)m / 2e12 + 0.05e-6 : cost_list(K > 0 ? (double)seg_nnz / K : 0.0);
+        return 220.0 * ((double)K * per_eta + 40e-6) < refactor_s;          // (40 us: the seven extra launches of an application)
     }
     // after a (re)factorization whose dense block has `block_rows` rows: the next segment's etas as dense rows or as lists, whichever
     // the previous segment's etas would have cost less in (no segment yet: from m alone -- the lists only pay beyond ~ 475 000 rows)
@@ -607,8 +748,26 @@ struct EtaFile {
         if (adaptive) return K >= 100 && overhead_s >= refactor_s;
         return K >= limit;
     }
-    void apply(bool transposed, double* v) {
+    void apply(bool transposed, double* v) { apply_etas(M, m, K, cap, dense, transposed, v, s); }
+    // Kd > 0: the triangular systems through their matrices (a kept file inside the KKT solve); 0: the sequential, bit-reproducible form
+    static void apply_etas(MaxvolState& M, int m, int K, int cap, bool dense, bool transposed, double* v, hipStream_t s, int Kd = 0) {
         if (K == 0) return;
+        if (dense && Kd > 0) {
+            const int gk = (K + kBlock / 64 - 1) / (kBlock / 64);
+            if (transposed) {
+                hipLaunchKernelGGL(mv_eta_dense_dots_kernel, dim3(K), dim3(kBlock), 0, s, m, M.etaE.get(), v, M.eta_d.get());
+                hipLaunchKernelGGL(mv_eta_backward_gemv_kernel, dim3(gk), dim3(kBlock), 0, s, K, Kd, M.etaG.get(), M.eta_first.get(), M.eta_pos.get(),
+                                   M.eta_d.get(), v, M.eta_w.get());
+                hipLaunchKernelGGL(mv_eta_backward_scatter_kernel, dim3(grid_for(Kd)), dim3(kBlock), 0, s, Kd, M.eta_first.get(), M.eta_pos.get(),
+                                   M.eta_w.get(), v);
+            } else {
+                hipLaunchKernelGGL(mv_eta_forward_gemv_kernel, dim3(gk), dim3(kBlock), 0, s, K, Kd, M.etaF.get(), M.eta_first.get(), M.eta_pos.get(), v,
+                                   M.eta_alpha.get());
+                hipLaunchKernelGGL(mv_eta_dense_ftran_apply_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, K, M.etaE.get(), M.eta_alpha.get(),
+                                   M.eta_last.get(), v);
+            }
+            return;
+        }
         if (dense && transposed) {
             hipLaunchKernelGGL(mv_eta_dense_dots_kernel, dim3(K), dim3(kBlock), 0, s, m, M.etaE.get(), v, M.eta_d.get());
             hipLaunchKernelGGL(mv_eta_dense_btran_solve_kernel, dim3(1), dim3(kEtaDenseMax), 0, s, K, cap, v, M.eta_pos.get(), M.eta_piv.get(),
@@ -627,6 +786,28 @@ struct EtaFile {
         }
     }
 };
+
+// ---- the etas behind the resident factors (Context::etas_live) -------------------------------------------------------------
+// When Maxvolume is over and its last exchanges are few, the fresh factorization of the final basis that the reference asks for
+// (src/kkt_solver_basis.cc:56-61, Basis::GetLuFactors) costs more than carrying the etas through the solves of the KKT solve that
+// follows: B_new = B_old E_1 ... E_K, so  inverse(B_new) v = inverse(E_K) ... inverse(E_1) inverse(B_old) v  -- the resident factors and
+// the eta file as they stand (the form Basis::SolveDense has after Forrest-Tomlin updates, src/forrest_tomlin.cc:67-78).  The operator
+// of trisolve.hip and solve_dense_dev apply the etas through the two functions below; the next call of Maxvolume goes on with the same
+// file.  A new operator (ipxk_split_prepare*) ends this state; a new factorization in the context (the LU kernel of the reference's
+// Basis may share it) leaves operator and etas as they are -- they do not read the LU state -- but the next Maxvolume starts from fresh factors.
+void maxvol_apply_etas(Context* c, bool transposed, double* v) {
+    IPXK_REQUIRE(c->maxvol && c->maxvol->saved.live, "no eta file behind the factors");
+    MaxvolState& M = *c->maxvol;
+    EtaFile::apply_etas(M, M.saved.m, M.saved.K, M.saved.cap, M.saved.dense, transposed, v, c->stream, M.saved.Kd);
+}
+const ipxint* maxvol_current_basis(Context* c) {
+    IPXK_REQUIRE(c->maxvol && c->maxvol->saved.live, "no eta file behind the factors");
+    return c->maxvol->basis.get();
+}
+void maxvol_drop_etas(Context* c) {
+    c->etas_live = false;
+    if (c->maxvol) c->maxvol->saved.live = false;
+}
 
 void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_in, const ipxk_maxvolume_params* prm_in,
                    ipxint* basis_out, ipxint* status_out, ipxk_maxvolume_info* info, ipxint* log, ipxint log_cap) {
@@ -647,19 +828,43 @@ void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_i
     for (DevBuf<double>* b : {&M.invscale, &M.rhs, &M.lhs, &M.unit, &M.btran, &M.work}) b->ensure((size_t)m);
     M.map2basis.ensure((size_t)N); M.slice_of.ensure((size_t)m);
     M.part.ensure(kRedGrid); M.scalars.ensure(1);
-    EtaFile etas(c, M, m, prm->max_etas);
-    etas.reset(V.bump_size);
+    // the etas of the previous call may still stand behind the factors (see maxvol_apply_etas): this call goes on with them, and while it
+    // runs it applies them itself -- the solves of trisolve.hip must not
+    const bool resume = c->etas_live && M.saved.live && (int64_t)M.basis_h.size() == (int64_t)m && M.saved.lu_generation == lu_generation(c);
+    EtaFile etas(c, M, m, prm->max_etas, resume);
+    const bool resumed = etas.resumed;
+    std::vector<ipxint> basis_h((size_t)m), status_h(status_in, status_in + N);
+    if (resumed) basis_h = M.basis_h;
+    if (c->etas_live && !resumed) {
+        // an eta file this call cannot take over (other parameters): a fresh factorization of the basis it stands for first
+        IPXK_REQUIRE((int64_t)M.basis_h.size() == (int64_t)m, "eta file without its basis");
+        basis_h = M.basis_h;
+        maxvol_drop_etas(c);
+        ipxk_lu_info li{};
+        lu_factorize_basis(c, basis_h.data(), c->maxvol_pivottol, false, &li);
+        IPXK_REQUIRE(li.num_dependent == 0, "the basis behind the eta file is singular");
+        split_prepare_lu(c, status_h.data(), colscale_in);
+        IPXK_REQUIRE(lu_view(c, &V), "no factorization");
+    }
+    c->etas_live = false;
+    M.saved.live = false;
+    // (a call that went on with an eta file and ends by an exception leaves an operator without the etas it needs: it goes, so that what
+    // follows fails loudly -- "SplittedNormalMatrix not prepared" -- instead of solving with the wrong basis)
+    struct ResumeGuard {
+        Context* c; bool armed;
+        ~ResumeGuard() { if (armed && std::uncaught_exceptions() > 0 && c->split) { destroy_split(c->split); c->split = nullptr; } }
+    } resume_guard{c, resumed};
+    if (!resumed) etas.reset(V.bump_size);
     int& K = etas.K;
     if (!M.h) IPXK_HIP(hipHostMalloc(reinterpret_cast<void**>(&M.h), sizeof(Scalars)));
 
     // host mirrors of basis and status (refactorizations, results)
-    std::vector<ipxint> basis_h((size_t)m), status_h(status_in, status_in + N);
-    IPXK_HIP(hipMemcpyAsync(basis_h.data(), V.basis, (size_t)m * sizeof(ipxint), hipMemcpyDeviceToHost, s));
+    if (!resumed) IPXK_HIP(hipMemcpyAsync(basis_h.data(), V.basis, (size_t)m * sizeof(ipxint), hipMemcpyDeviceToHost, s));
     DevBuf<double> colscale_dev;
     colscale_dev.upload(colscale_in, (size_t)N, s);
     M.status.upload(status_in, (size_t)N, s);
     M.basis.ensure((size_t)m);
-    IPXK_HIP(hipMemcpyAsync(M.basis.get(), V.basis, (size_t)m * sizeof(ipxint), hipMemcpyDeviceToDevice, s));
+    if (!resumed) IPXK_HIP(hipMemcpyAsync(M.basis.get(), V.basis, (size_t)m * sizeof(ipxint), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(mv_init_columns_kernel, dim3(grid_for(N)), dim3(kBlock), 0, s, N, M.status.get(), colscale_dev.get(),
                        M.colscale.get(), M.mask.get(), M.map2basis.get());
     hipLaunchKernelGGL(mv_init_basis_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, M.basis.get(), M.status.get(), colscale_dev.get(),
@@ -797,7 +1002,22 @@ void maxvolume_dev(Context* c, const ipxint* status_in, const double* colscale_i
     // the tail of KKTSolverBasis::_Factorize (src/kkt_solver_basis.cc:56-61): a fresh factorization of the final
     // basis and the operator built from it
     // (IPXK_MAXVOL_SKIP_FINAL=1, measurements only: leaves the context with the factors of the last refactorized basis)
-    if (K > 0 && !I.errflag && !getenv("IPXK_MAXVOL_SKIP_FINAL")) (void)refactorize();
+    // ... unless carrying the etas through the solves that follow is cheaper (EtaFile::worth_keeping; IPXK_MAXVOL_KEEP_ETAS=0: never,
+    // =1: whenever the file is not full): the operator then only learns the new basis and its scaling
+    // (a run that ends with an error flag keeps them too: factors + etas stay a consistent operator of the basis reported)
+    if (K > 0 && !getenv("IPXK_MAXVOL_SKIP_FINAL")) {
+        const char* keep_env = getenv("IPXK_MAXVOL_KEEP_ETAS");
+        const bool keep = I.errflag != 0 || (keep_env ? (keep_env[0] == '1' && !etas.full()) : etas.worth_keeping());
+        if (keep) {
+            etas.save();
+            M.basis_h = basis_h;
+            c->etas_live = true;
+            split_follow_basis(c, M.basis.get(), status_h.data(), colscale_in);
+            I.kept_etas = K;
+        } else {
+            (void)refactorize();
+        }
+    }
     IPXK_HIP(hipStreamSynchronize(s));
     I.seconds = now_s() - t_start;
     if (basis_out) std::copy(basis_h.begin(), basis_h.end(), basis_out);
@@ -814,6 +1034,15 @@ void maxvolume_sequential_dev(Context* c, const ipxint* status_in, const double*
                               ipxint max_etas_in, ipxint* basis_out, ipxint* status_out, ipxk_maxvolume_info* info, ipxint* log,
                               ipxint log_cap) {
     LuView V;
+    if (c->etas_live && c->maxvol && (int64_t)c->maxvol->basis_h.size() == c->m) {
+        // (the sequential variant starts from fresh factors: the basis behind an eta file of the other variant is factorized first)
+        std::vector<ipxint> bh = c->maxvol->basis_h;
+        maxvol_drop_etas(c);
+        ipxk_lu_info li{};
+        lu_factorize_basis(c, bh.data(), c->maxvol_pivottol, false, &li);
+        IPXK_REQUIRE(li.num_dependent == 0, "the basis behind the eta file is singular");
+        split_prepare_lu(c, status_in, colscale_in);
+    }
     IPXK_REQUIRE(lu_view(c, &V) && V.from_basis && V.ndep == 0, "maxvolume needs the factorization of the current basis (ipxk_lu_factorize_basis)");
     IPXK_REQUIRE(c->split, "maxvolume needs the operator of the current basis (ipxk_split_prepare_lu)");
     const int m = (int)c->m, n = (int)c->n;

@@ -1494,6 +1494,7 @@ void split_prepare_host(Context* c, const ipxint* Lp, const ipxint* Li, const do
                         const ipxint* Up, const ipxint* Ui, const double* Ux, const ipxint* rowperm,
                         const ipxint* colperm, const ipxint* basis, const ipxint* status,
                         const double* colscale) {
+    maxvol_drop_etas(c);
     const int m = (int)c->m, n = (int)c->n;
     hipStream_t s = c->stream;
     IPXK_REQUIRE(c->nranks == 1, "the basis path does not shard: run it as independent replicas");
@@ -1595,6 +1596,7 @@ __global__ void perms_from_lu_kernel(int m, const ipxint* __restrict__ rowperm, 
 // SplittedNormalMatrix::Prepare (splitted_normal_matrix.cc:18-66) with L, U and the permutations never leaving the
 // device.
 void split_prepare_lu(Context* c, const ipxint* status, const double* colscale) {
+    maxvol_drop_etas(c);
     LuView V;
     IPXK_REQUIRE(lu_view(c, &V) && V.from_basis, "no LU factorization of a basis of this context's matrix (ipxk_lu_factorize_basis)");
     IPXK_REQUIRE(V.ndep == 0, "the factorization replaced dependent columns: repair the basis and factorize again "
@@ -1640,6 +1642,46 @@ void split_rescale_host(Context* c, const ipxint* status, const double* colscale
     IPXK_HIP(hipStreamSynchronize(c->stream));
 }
 
+// ---- the operator behind an eta file (Context::etas_live, maxvolume.hip) ----
+// B_new = B_old E (E the product of Maxvolume's last exchanges, acting on vectors by basis position), hence with the column scaling S of
+// the NEW basis   inverse(B~) = inverse(S) inverse(E) inverse(U) inverse(L),   inverse(B~') = inverse(L') inverse(U') inverse(E') inverse(S):
+// the UNSCALED sweeps of the resident factors, the eta file between them and the scaling, and the scaling as a vector operation.
+// t[colperm[k]] = rhs[k] / scale[k]          (pivot order -> basis position)
+__global__ void eta_scatter_scale_kernel(int m, const double* __restrict__ rhs, const int* __restrict__ colperm, const double* __restrict__ scale,
+                                         double* __restrict__ t, const int* done) {
+    if (done && *done) return;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x) t[colperm[k]] = rhs[k] / scale[k];
+}
+// lhs = free ? 0 : t[colperm[k]] / scale[k] + rhs;  partial dot rhs'lhs       (splitted_normal_matrix.cc:112-116)
+__global__ __launch_bounds__(kBlock) void split_finish_etas_kernel(int m, const double* __restrict__ rhs, const unsigned char* __restrict__ free_mask,
+                                                                   const double* __restrict__ t, const int* __restrict__ colperm,
+                                                                   const double* __restrict__ scale, double* __restrict__ lhs, double* partial,
+                                                                   const int* done) {
+    if (done && *done) return;
+    __shared__ double red[kBlock / 64 + 1];
+    double acc = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock) {
+        const double r = rhs[i];
+        const double l = free_mask[i] ? 0.0 : t[colperm[i]] / scale[i] + r;
+        lhs[i] = l;
+        acc += r * l;
+    }
+    acc = block_reduce<SumOp>(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+__global__ void narrow_basis_kernel(int m, const ipxint* __restrict__ in, int* __restrict__ out) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < m; p += gridDim.x * blockDim.x) out[p] = (int)in[p];
+}
+void split_follow_basis(Context* c, const ipxint* basis_dev, const ipxint* status, const double* colscale) {
+    SplitOperator* S = c->split;
+    IPXK_REQUIRE(S != nullptr, "SplittedNormalMatrix not prepared");
+    const int m = S->m;
+    if (m > 0) hipLaunchKernelGGL(narrow_basis_kernel, dim3(vec_grid(m)), dim3(kBlock), 0, c->stream, m, basis_dev, S->basis.get());
+    S->eta_t.ensure((size_t)std::max(m, 1)); S->eta_in.ensure((size_t)std::max(m, 1));
+    upload_scaling(c, S, status, colscale);       // scaling of the new basis in pivot order, free positions, weights / matrix of the new N
+    IPXK_HIP(hipStreamSynchronize(c->stream));
+}
+
 // ---------------------------------------------------------------------------
 // _Apply                                    (splitted_normal_matrix.cc:90-117)
 // ---------------------------------------------------------------------------
@@ -1650,13 +1692,21 @@ int split_apply_dev(Context* c, const double* rhs, double* lhs, const int* done)
     const int g = vec_grid(m);
     double* work = S->w0.get();
     double* u = S->w1.get();
+    const bool etas = c->etas_live;
     fill_results(c, {&S->Ut, &S->Lt, &S->Lf, &S->Uf}, done);
     // inverse(B') * rhs
     time_mark(c, kTimeBt, true);
-    run_sweep(c, S->Ut, true, rhs, done);
+    const double* bt_in = rhs;
+    if (etas) {
+        hipLaunchKernelGGL(eta_scatter_scale_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs, S->colperm.get(), S->uscale.get(), S->eta_t.get(), done);
+        maxvol_apply_etas(c, true, S->eta_t.get());
+        hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, S->eta_t.get(), S->colperm.get(), S->eta_in.get(), done);
+        bt_in = S->eta_in.get();
+    }
+    run_sweep(c, S->Ut, !etas, bt_in, done);
     bump_between(c, true, S->Ut.y.get(), done);
     // (the L' sweep also leaves its result in u in the row order of A, for the N N' product)
-    run_sweep(c, S->Lt, true, S->Ut.y.get(), done, S->row_after_backward.get(), u);
+    run_sweep(c, S->Lt, !etas, S->Ut.y.get(), done, S->row_after_backward.get(), u);
     time_mark(c, kTimeBt, false);
     time_mark(c, kTimeOp, true);
     // N N' of it: A (M D^2) A'
@@ -1675,13 +1725,21 @@ int split_apply_dev(Context* c, const double* rhs, double* lhs, const int* done)
     time_mark(c, kTimeOp, false);
     // inverse(B) * that (the L sweep reads `work` through rowperm)
     time_mark(c, kTimeB, true);
-    run_sweep(c, S->Lf, true, work, done);
+    run_sweep(c, S->Lf, !etas, work, done);
     bump_between(c, false, S->Lf.y.get(), done);
-    run_sweep(c, S->Uf, true, S->Lf.y.get(), done);
+    run_sweep(c, S->Uf, !etas, S->Lf.y.get(), done);
+    if (etas) {
+        unpack_result(c, S->Uf, S->colperm.get(), S->eta_t.get());          // by basis position
+        maxvol_apply_etas(c, false, S->eta_t.get());
+    }
     time_mark(c, kTimeB, false);
     // lhs = result + rhs; zero free positions; dot
-    hipLaunchKernelGGL(split_finish_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs, S->free_mask.get(), S->Uf.y.get(),
-                       S->Uf.posof.get(), lhs, c->part(kPartCdot), done);
+    if (etas)
+        hipLaunchKernelGGL(split_finish_etas_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs, S->free_mask.get(), S->eta_t.get(), S->colperm.get(),
+                           S->uscale.get(), lhs, c->part(kPartCdot), done);
+    else
+        hipLaunchKernelGGL(split_finish_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs, S->free_mask.get(), S->Uf.y.get(),
+                           S->Uf.posof.get(), lhs, c->part(kPartCdot), done);
     return g;
 }
 
@@ -1693,6 +1751,12 @@ void solve_dense_dev(Context* c, const double* rhs, double* lhs, char trans) {
     const int g = vec_grid(m);
     if (trans == 't' || trans == 'T') {
         double* work = S->w3.get();
+        if (c->etas_live) {
+            // inverse(B_new') = inverse(B_old') inverse(E'): the eta file first, on a copy (rhs may be lhs, and is not to be changed otherwise)
+            IPXK_HIP(hipMemcpyAsync(S->eta_t.get(), rhs, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, s));
+            maxvol_apply_etas(c, true, S->eta_t.get());
+            rhs = S->eta_t.get();
+        }
         hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(kBlock), 0, s, m, rhs, S->colperm.get(), work,
                            (const int*)nullptr);
         fill_results(c, {&S->Ut, &S->Lt}, nullptr);
@@ -1706,6 +1770,7 @@ void solve_dense_dev(Context* c, const double* rhs, double* lhs, char trans) {
         bump_between(c, false, S->Lf.y.get(), nullptr);
         run_sweep(c, S->Uf, false, S->Lf.y.get(), nullptr);
         unpack_result(c, S->Uf, S->colperm.get(), lhs);            // lhs[colperm[k]] = solution[k]
+        if (c->etas_live) maxvol_apply_etas(c, false, lhs);        // inverse(B_new) = inverse(E) inverse(B_old)
     }
 }
 

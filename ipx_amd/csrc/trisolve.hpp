@@ -134,6 +134,7 @@ struct SplitOperator {
     int sweep_grid_all = 0;                // workgroups of an all-XCD run: all resident on this operator's device (0: not asked yet)
     DevBuf<int> abort_flag;
     DevBuf<double> tI;                     // m
+    DevBuf<double> eta_t, eta_in;          // m each: vectors by basis position / pivot order around the eta file (Context::etas_live)
     bool level_launches = false;           // IPXK_TRISOLVE=levels: one launch per level (debugging aid)
     bool masked_values = false;            // N N' uses the gather matrices' masked value arrays (spmv.hip)
     bool real_N = false;                   // N N' uses N built as a matrix of its own (nmatrix.hip)

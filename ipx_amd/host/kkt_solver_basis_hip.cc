@@ -20,6 +20,11 @@ extern "C" long ipx_hip_cpu_prepare_calls() { return g_cpu_prepare_calls; }
 static long g_device_maxvolume_calls = 0, g_cpu_maxvolume_calls = 0;
 extern "C" long ipx_hip_device_maxvolume_calls() { return g_device_maxvolume_calls; }
 extern "C" long ipx_hip_cpu_maxvolume_calls() { return g_cpu_maxvolume_calls; }
+// # of those calls on the device that ended WITHOUT the final refactorization: the last exchanges stay behind the factors as etas
+// (ipxk_maxvolume_info.kept_etas), and the etas kept over all of them
+static long g_kept_eta_calls = 0, g_kept_etas = 0;
+extern "C" long ipx_hip_kept_eta_calls() { return g_kept_eta_calls; }
+extern "C" long ipx_hip_kept_etas() { return g_kept_etas; }
 // where KKTSolverBasisHip::Factorize spends its time, over all solver objects of the process (seconds): the reference's
 // DropPrimal / DropDual, the device LU + Prepare of the current basis, Maxvolume on the device, Basis::Load / Factorize of
 // the reference's Basis afterwards, the CPU path (Maxvolume on Basis + hand-off)
@@ -208,6 +213,10 @@ bool KKTSolverBasisHip::MaxvolumeOnDevice(Info* info) {
     g_phase_seconds[2] += timer_maxvol.Elapsed();
     device_maxvolume_calls_++;
     g_device_maxvolume_calls++;
+    if (control_.update_heuristic() != 0 && mv.kept_etas > 0) {
+        g_kept_eta_calls++;
+        g_kept_etas += mv.kept_etas;
+    }
     info->updates_ipm += mv.updates;
     info->time_maxvol += timer.Elapsed();
     reference_.basis_changes_ += mv.updates;

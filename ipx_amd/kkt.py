@@ -68,7 +68,7 @@ class MaxvolumeParams(C.Structure):
 
 class MaxvolumeInfo(C.Structure):
     _fields_ = [("updates", c_i64), ("skipped", c_i64), ("slices", c_i64), ("refused", c_i64), ("factorizations", c_i64),
-                ("errflag", c_i64), ("volinc", c_f64), ("seconds", c_f64)]
+                ("errflag", c_i64), ("volinc", c_f64), ("seconds", c_f64), ("kept_etas", c_i64)]
 
 
 class IpmParams(C.Structure):

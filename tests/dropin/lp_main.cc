@@ -33,6 +33,8 @@ extern "C" double ipx_hip_cpu_prepare_seconds();
 extern "C" long ipx_hip_cpu_prepare_calls();
 extern "C" long ipx_hip_device_maxvolume_calls();
 extern "C" long ipx_hip_cpu_maxvolume_calls();
+extern "C" long ipx_hip_kept_eta_calls();
+extern "C" long ipx_hip_kept_etas();
 extern "C" double ipx_hip_factorize_phase_seconds(int phase);
 #endif
 
@@ -124,6 +126,8 @@ int main(int argc, char** argv) {
     // one device model per Model: the three solver objects of LpSolver::Solve share one context (hip_device.h)
     f << "device_maxvolume_calls " << ipx_hip_device_maxvolume_calls() << '\n';
     f << "cpu_maxvolume_calls " << ipx_hip_cpu_maxvolume_calls() << '\n';
+    f << "kept_eta_calls " << ipx_hip_kept_eta_calls() << '\n';
+    f << "kept_etas " << ipx_hip_kept_etas() << '\n';
     {
         const char* names[5] = {"factorize_drop_seconds", "factorize_device_lu_prepare_seconds", "factorize_device_maxvolume_seconds",
                                 "factorize_basis_load_seconds", "factorize_cpu_path_seconds"};

@@ -268,7 +268,9 @@ def test_synthetic_lp_through_both_solvers(tmp_path, m, n, seed, params):
     # no second factorization: the Basis::Load that follows Maxvolume on the device (deferred until the Basis is needed, at the latest
     # when the solver object goes) is served from the resident factors, and the reference's Basis factorizes fewer times than the
     # run with the reference's classes
-    assert hi["lu_reused"] >= 1 and hi["lu_factorizations"] <= ref[0]["lu_factorizations"], (hi["lu_reused"], hi["lu_factorizations"], ref[0]["lu_factorizations"])
+    # (or, since the end of round 5, there is nothing to hand out: Maxvolume kept its last exchanges as etas behind the earlier factors
+    # instead of factorizing the final basis -- then the Load factorizes, once)
+    assert (hi["lu_reused"] >= 1 or hi["kept_eta_calls"] >= 1) and hi["lu_factorizations"] <= ref[0]["lu_factorizations"], (hi["lu_reused"], hi["kept_eta_calls"], hi["lu_factorizations"], ref[0]["lu_factorizations"])
     print("ref:", ref[2], "hip:", hip[2])
     print("time_ipm2 ref %.3f hip %.3f; cr2 ref %.3f hip %.3f; factorize ref %.3f hip %.3f; LU on device %.3f s in %d calls, largest bump %d"
           % (ref[0]["time_ipm2"], hi["time_ipm2"], ref[0]["time_cr2"], hi["time_cr2"], ref[0]["time_kkt_factorize"],
@@ -304,7 +306,9 @@ def test_deferred_basis_load_changes_nothing_but_the_number_of_loads(tmp_path):
     din = str(tmp_path / "in")
     write_model(din, *general_lp(3000, 7500, 41), crossover=1)
     runs = {}
-    for tag, env in (("deferred", {}), ("eager", {"IPXK_EAGER_BASIS_LOAD": "1"})):
+    # (both with the final refactorization of every Maxvolume, IPXK_MAXVOL_KEEP_ETAS=0: an eager Load factorizes in the shared context,
+    # after which Maxvolume cannot go on with etas kept behind the earlier factors -- the two runs would differ in rounding)
+    for tag, env in (("deferred", {"IPXK_MAXVOL_KEEP_ETAS": "0"}), ("eager", {"IPXK_EAGER_BASIS_LOAD": "1", "IPXK_MAXVOL_KEEP_ETAS": "0"})):
         dout = str(tmp_path / tag)
         os.makedirs(dout, exist_ok=True)
         r = subprocess.run([HIP_BIN, din, dout], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
