@@ -213,7 +213,18 @@ __global__ __launch_bounds__(kBlock) void mv_eta_dense_ftran_apply_kernel(int m,
     IPXK_GRID_STRIDE(i, m) {
         const int l = last[i];
         double x = l >= 0 ? sa[l] : v[i];
-        for (int s = l + 1; s < K; s++) {
+        // eight entries of the column in flight at a time; the products are still subtracted one after the other in the order of the etas
+        // (a thread walked its column one dependent load at a time before: 82 us per application with 400 etas of 24 000 entries)
+        int s = l + 1;
+        for (; s + 8 <= K; s += 8) {
+            double e[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) e[q] = E[(size_t)(s + q) * m + i];
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (e[q] != 0.0) x -= e[q] * sa[s + q];
+        }
+        for (; s < K; s++) {
             const double e = E[(size_t)s * m + i];
             if (e != 0.0) x -= e * sa[s];
         }
@@ -675,9 +686,9 @@ struct EtaFile {
             const int Kd = (int)first.size();
             M.eta_first.upload(first, s); M.eta_jof.upload(jof, s);
             M.etaF.ensure((size_t)K * Kd); M.etaG.ensure((size_t)K * (K + Kd)); M.eta_w.ensure((size_t)K);
-            hipLaunchKernelGGL(mv_eta_forward_matrix_kernel, dim3(Kd), dim3(kEtaDenseMax), 0, s, K, Kd, cap, M.eta_first.get(), M.eta_piv.get(),
+            hipLaunchKernelGGL(mv_eta_forward_matrix_kernel, dim3(Kd), dim3(std::min(kEtaDenseMax, (K + 63) / 64 * 64)), 0, s, K, Kd, cap, M.eta_first.get(), M.eta_piv.get(),
                                M.eta_prev.get(), M.etaTt.get(), M.etaF.get());
-            hipLaunchKernelGGL(mv_eta_backward_matrix_kernel, dim3(K + Kd), dim3(kEtaDenseMax), 0, s, K, Kd, cap, M.eta_jof.get(), M.eta_piv.get(),
+            hipLaunchKernelGGL(mv_eta_backward_matrix_kernel, dim3(K + Kd), dim3(std::min(kEtaDenseMax, (K + 63) / 64 * 64)), 0, s, K, Kd, cap, M.eta_jof.get(), M.eta_piv.get(),
                                M.eta_prev.get(), M.eta_next.get(), M.etaT.get(), M.etaG.get());
             IPXK_HIP(hipStreamSynchronize(s));               // (the host vectors go out of scope)
             IPXK_HIP(hipGetLastError());
@@ -768,12 +779,14 @@ struct EtaFile {
             }
             return;
         }
+        // (the one-workgroup solves: only as many wavefronts as there are etas -- their two barriers per eta cost by the wavefront)
+        const int solve_threads = std::min(kEtaDenseMax, (K + 63) / 64 * 64);
         if (dense && transposed) {
             hipLaunchKernelGGL(mv_eta_dense_dots_kernel, dim3(K), dim3(kBlock), 0, s, m, M.etaE.get(), v, M.eta_d.get());
-            hipLaunchKernelGGL(mv_eta_dense_btran_solve_kernel, dim3(1), dim3(kEtaDenseMax), 0, s, K, cap, v, M.eta_pos.get(), M.eta_piv.get(),
+            hipLaunchKernelGGL(mv_eta_dense_btran_solve_kernel, dim3(1), dim3(solve_threads), 0, s, K, cap, v, M.eta_pos.get(), M.eta_piv.get(),
                                M.eta_prev.get(), M.eta_next.get(), M.etaT.get(), M.eta_d.get());
         } else if (dense) {
-            hipLaunchKernelGGL(mv_eta_dense_ftran_solve_kernel, dim3(1), dim3(kEtaDenseMax), 0, s, K, cap, v, M.eta_pos.get(), M.eta_piv.get(),
+            hipLaunchKernelGGL(mv_eta_dense_ftran_solve_kernel, dim3(1), dim3(solve_threads), 0, s, K, cap, v, M.eta_pos.get(), M.eta_piv.get(),
                                M.eta_prev.get(), M.etaTt.get(), M.eta_alpha.get());
             hipLaunchKernelGGL(mv_eta_dense_ftran_apply_kernel, dim3(grid_for(m)), dim3(kBlock), 0, s, m, K, M.etaE.get(), M.eta_alpha.get(),
                                M.eta_last.get(), v);
