@@ -183,26 +183,61 @@ __global__ void mv_eta_dense_append_kernel(int m, int K, int cap, const Scalars*
         last[pmax] = K;
     }
 }
+// (Blocked since the end of round 5: the 64 etas of a block are solved by ONE wavefront -- the multiplier of a step goes to the later lanes
+// by a lane read, no barrier -- and the threads of the later blocks then subtract the block's 64 products in the same order from LDS: one
+// workgroup barrier per 64 etas instead of two per eta.  Every r_t still receives its products in the order of the etas: the same bits.)
 __global__ __launch_bounds__(kEtaDenseMax) void mv_eta_dense_ftran_solve_kernel(int K, int cap, const double* __restrict__ v, const int* __restrict__ pos,
                                                                                const double* __restrict__ piv, const int* __restrict__ prev,
                                                                                const double* __restrict__ Tt, double* __restrict__ alpha) {
-    __shared__ double s_alpha;
-    const int t = threadIdx.x;
+    __shared__ double s_a[2][64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int pr = t < K ? prev[t] : -1;
     double r = (t < K && pr < 0) ? v[pos[t]] : 0.0;
     const double pv = t < K ? piv[t] : 1.0;
-    for (int s = 0; s < K; s++) {
-        if (t == s) { const double a = r / pv; s_alpha = a; alpha[s] = a; }
-        __syncthreads();
-        const double a = s_alpha;
-        if (t > s && t < K) {
-            if (s == pr) r = a;
-            else if (s > pr) {
-                const double e = Tt[(size_t)s * cap + t];
-                if (e != 0.0) r -= e * a;
+    for (int b0 = 0, blk = 0; b0 < K; b0 += 64, blk++) {
+        const int b1 = min(b0 + 64, K);
+        double* sa = s_a[blk & 1];
+        // (the entries of T a thread needs for 16 steps are fetched together, ahead of the steps: a dependent load per step was most of a step)
+        constexpr int CH = 16;
+        if (wave == blk) {
+            for (int s0 = b0; s0 < b1; s0 += CH) {
+                double e[CH];
+#pragma unroll
+                for (int q = 0; q < CH; q++) e[q] = (s0 + q < b1 && t > s0 + q && t < K) ? Tt[(size_t)(s0 + q) * cap + t] : 0.0;
+#pragma unroll
+                for (int q = 0; q < CH; q++) {
+                    const int s = s0 + q;
+                    if (s < b1) {                                       // wave-uniform
+                        const double mine = r / pv;                     // (only lane s - b0's value is used)
+                        const int hi = __builtin_amdgcn_readlane(__double2hiint(mine), s - b0), lo = __builtin_amdgcn_readlane(__double2loint(mine), s - b0);
+                        const double a = __hiloint2double(hi, lo);
+                        if (t == s) { alpha[s] = a; sa[s - b0] = a; }
+                        if (t > s && t < K) {
+                            if (s == pr) r = a;
+                            else if (s > pr && e[q] != 0.0) r -= e[q] * a;
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
+        if (wave > blk && t < K) {
+            for (int s0 = b0; s0 < b1; s0 += CH) {
+                double e[CH];
+#pragma unroll
+                for (int q = 0; q < CH; q++) e[q] = s0 + q < b1 ? Tt[(size_t)(s0 + q) * cap + t] : 0.0;
+#pragma unroll
+                for (int q = 0; q < CH; q++) {
+                    const int s = s0 + q;
+                    if (s < b1) {
+                        const double a = sa[s - b0];
+                        if (s == pr) r = a;
+                        else if (s > pr && e[q] != 0.0) r -= e[q] * a;
+                    }
+                }
+            }
+        }
+        // (the other buffer is written next, after everybody has passed this block's barrier: nobody still reads it)
     }
 }
 __global__ __launch_bounds__(kBlock) void mv_eta_dense_ftran_apply_kernel(int m, int K, const double* __restrict__ E, const double* __restrict__ alpha,
@@ -247,34 +282,71 @@ __global__ __launch_bounds__(kBlock) void mv_eta_dense_dots_kernel(int m, const 
         d[blockIdx.x] = tot;
     }
 }
+// (blocked like the forward solve: the 64 etas of a block by one wavefront, from the last eta down; the earlier threads then add the block's
+// products in the same descending order)
 __global__ __launch_bounds__(kEtaDenseMax) void mv_eta_dense_btran_solve_kernel(int K, int cap, double* v, const int* __restrict__ pos,
                                                                                const double* __restrict__ piv, const int* __restrict__ prev,
                                                                                const int* __restrict__ next, const double* __restrict__ T,
                                                                                const double* __restrict__ d) {
-    __shared__ double s_diff;
     __shared__ double s_w[kEtaDenseMax];
-    const int t = threadIdx.x;
+    __shared__ double s_diff[2][64];
+    __shared__ int s_prev[2][64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const double cv = t < K ? v[pos[t]] : 0.0;          // the vector as it came in, at this eta's position
     const double dt = t < K ? d[t] : 0.0, pv = t < K ? piv[t] : 1.0;
-    const int nx = t < K ? next[t] : -1;
+    const int nx = t < K ? next[t] : -1, myprev = t < K ? prev[t] : -1;
     double acc = 0.0;
     __syncthreads();
-    for (int s = K - 1; s >= 0; s--) {
-        if (t == s) {
-            const double cur = nx >= 0 ? s_w[nx] : cv;
-            const double w = (cur - dt - acc) / pv;
-            s_w[s] = w;
-            s_diff = w - cv;
+    const int nblk = (K + 63) / 64;
+    for (int blk = nblk - 1, it = 0; blk >= 0; blk--, it++) {
+        const int b0 = blk * 64, b1 = min(b0 + 64, K);
+        double* sd = s_diff[it & 1];
+        int* sp = s_prev[it & 1];
+        constexpr int CH = 16;
+        if (wave == blk) {
+            for (int s1 = b1 - 1; s1 >= b0; s1 -= CH) {
+                double e[CH];
+#pragma unroll
+                for (int q = 0; q < CH; q++) e[q] = (s1 - q >= b0 && t < s1 - q) ? T[(size_t)(s1 - q) * cap + t] : 0.0;
+#pragma unroll
+                for (int q = 0; q < CH; q++) {
+                    const int s = s1 - q;
+                    if (s >= b0) {                                      // wave-uniform
+                        double diff_mine = 0.0;
+                        if (t == s) {
+                            // (s_w[nx], nx > s: written by this wavefront in an earlier step of this loop, or by a later block before its barrier)
+                            const double cur = nx >= 0 ? s_w[nx] : cv;
+                            const double w = (cur - dt - acc) / pv;
+                            s_w[s] = w;
+                            diff_mine = w - cv;
+                            sd[s - b0] = diff_mine;
+                            sp[s - b0] = myprev;
+                        }
+                        const int hi = __builtin_amdgcn_readlane(__double2hiint(diff_mine), s - b0), lo = __builtin_amdgcn_readlane(__double2loint(diff_mine), s - b0);
+                        const double diff = __hiloint2double(hi, lo);
+                        const int prs = __builtin_amdgcn_readlane(myprev, s - b0);
+                        if (t < s && t >= b0 && e[q] != 0.0 && prs <= t) acc += e[q] * diff;
+                    }
+                }
+            }
         }
         __syncthreads();
-        if (t < s) {
-            // (prev[s] <= t: position pos_s is not replaced again between t and s, so eta t meets the value w_s there)
-            const double e = T[(size_t)s * cap + t];
-            if (e != 0.0 && prev[s] <= t) acc += e * s_diff;
+        if (wave < blk) {
+            for (int s1 = b1 - 1; s1 >= b0; s1 -= CH) {
+                double e[CH];
+#pragma unroll
+                for (int q = 0; q < CH; q++) e[q] = s1 - q >= b0 ? T[(size_t)(s1 - q) * cap + t] : 0.0;
+#pragma unroll
+                for (int q = 0; q < CH; q++) {
+                    const int s = s1 - q;
+                    // (prev[s] <= t: position pos_s is not replaced again between t and s, so eta t meets the value w_s there)
+                    if (s >= b0 && e[q] != 0.0 && sp[s - b0] <= t) acc += e[q] * sd[s - b0];
+                }
+            }
         }
-        __syncthreads();
     }
-    if (t < K && prev[t] < 0) v[pos[t]] = s_w[t];
+    __syncthreads();
+    if (t < K && myprev < 0) v[pos[t]] = s_w[t];
 }
 
 // ---- the two triangular systems as MATRICES (for the eta file that stays behind the factors after Maxvolume, see maxvol_apply_etas) ----

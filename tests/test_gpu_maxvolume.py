@@ -162,3 +162,26 @@ def test_maxvolume_against_the_reference_itself(args):
     print(r.stdout)
     assert r.returncode == 0 and "DONE" in r.stdout and "PASS" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
     assert "IDENTICAL decisions" in r.stdout, r.stdout
+
+
+def test_dense_etas_equal_the_lists_with_hundreds_of_etas(kkt, po, monkeypatch):
+    """the dense form of the eta file (blocked triangular solves: one wavefront per 64 etas) against the lists walked one eta after the
+    other, with up to 1024 etas between refactorizations: the same exchanges in the same order, the same counters"""
+    m, n, bump, seed = 6000, 14000, 300, 9
+    P, status, colscale, Ao = setup(po, m, n, bump, seed, spread=2.0)
+    runs = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("IPXK_MAXVOL_DENSE_ETAS", form)
+        monkeypatch.setenv("IPXK_MAXVOL_KEEP_ETAS", "0")
+        ctx = kkt.KktContext(P["A"])
+        ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+        ctx.split_prepare_lu(status, colscale)
+        got = ctx.maxvolume(status, colscale, volume_tol=2.0, maxskip_updates=10, rows_per_slice=1000, max_etas=1024)
+        assert got["errflag"] == 0
+        runs[form] = got
+        ctx.close()
+    d, l = runs["1"], runs["0"]
+    print("updates %d, factorizations dense %d / lists %d" % (d["updates"], d["factorizations"], l["factorizations"]))
+    assert d["updates"] > 1500, d["updates"]                   # (more than one refactorization apart: files of several hundred etas)
+    assert np.array_equal(d["exchanges"], l["exchanges"]) and np.array_equal(d["basis"], l["basis"])
+    assert (d["updates"], d["skipped"], d["refused"]) == (l["updates"], l["skipped"], l["refused"]) and d["volinc"] == l["volinc"]
