@@ -12,6 +12,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/ipx_kkt_hip.h"
@@ -77,6 +78,11 @@ public:
         if (n == n_) return;
         release();
         if (n > 0) IPXK_HIP(hipMalloc(reinterpret_cast<void**>(&p_), n * sizeof(T)));
+        // IPXK_POISON=1 (debugging aid): fresh buffers of doubles hold NaNs, so that a read of something never written shows
+        if (n > 0 && std::is_same<T, double>::value) {
+            static const bool poison = getenv("IPXK_POISON") != nullptr;
+            if (poison) { IPXK_HIP(hipMemset(p_, 0xff, n * sizeof(T))); IPXK_HIP(hipDeviceSynchronize()); }   // (before anybody's stream writes it)
+        }
         n_ = n;
     }
     // grow-only variant of resize: keeps the allocation when it is already large enough
