@@ -319,8 +319,9 @@ int ipxk_split_prepare_lu(ipxk_context* ctx, const ipxint* status,
  * ScaleFtran :322-337, FindLargest :179-200) over the part of ipx::Basis it
  * drives (SolveDense, SolveForUpdate, TableauRow, ExchangeIfStable,
  * src/basis.cc:162-330), followed by the tail of KKTSolverBasis::_Factorize
- * (src/kkt_solver_basis.cc:46-61): a fresh factorization of the final basis and
- * the split operator built from it.  Precondition: ipxk_lu_factorize_basis +
+ * (src/kkt_solver_basis.cc:46-61): the split operator of the final basis -- from
+ * a fresh factorization, or from the earlier factors with the last exchanges
+ * behind them (kept_etas below).  Precondition: ipxk_lu_factorize_basis +
  * ipxk_split_prepare_lu for the current basis.  status / colscale: n+m entries
  * as for ipxk_split_prepare (BASIC_FREE variables never leave, NONBASIC_FIXED
  * ones never enter).  The factorization is kept current by product-form etas on
@@ -345,7 +346,7 @@ typedef struct {
 typedef struct {
   ipxint updates, skipped, slices;   /* Maxvolume::updates() / skipped() / slices() */
   ipxint refused;                    /* exchanges refused as unstable (then refactorized) */
-  ipxint factorizations;             /* refactorizations, the final one included */
+  ipxint factorizations;             /* refactorizations, the final one (if any: kept_etas) included */
   ipxint errflag;
   double volinc;                     /* Maxvolume::volinc(): log2 of the volume gained */
   double seconds;

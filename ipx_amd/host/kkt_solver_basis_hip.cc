@@ -174,8 +174,9 @@ bool KKTSolverBasisHip::MaxvolumeOnDevice(Info* info) {
     for (Int p = 0; p < m; p++)
         basic[p] = basis_pending_ ? device_basis_[p] : basis_[p];
     Timer timer;
-    // the factors of the current basis on the device: those of the previous call's final refactorization when the
-    // basis is still the same set of columns (then only the scaling is handed over), else a fresh device LU
+    // the factors of the current basis on the device: what the previous call left (its final refactorization, or earlier factors
+    // with its last exchanges behind them as etas) when the basis is still the same set of columns -- then only the scaling is
+    // handed over --, else a fresh device LU
     if (same_basis) {
         HipCheck(ipxk_split_rescale(ctx, status.data(), colscale.data()));
     } else {
@@ -226,7 +227,7 @@ bool KKTSolverBasisHip::MaxvolumeOnDevice(Info* info) {
     control_.Debug()
         << " Maxvolume on the device: " << mv.updates << " updates, " << mv.skipped << " skipped, "
         << mv.factorizations << " factorizations, volume increase 2^" << sci2(mv.volinc) << '\n';
-    // the device holds the fresh factorization and the operator of the final basis
+    // the device holds the operator of the final basis (fresh factors, or the earlier ones + etas: mv.kept_etas)
     device_member_.assign(n+m, 0);
     for (Int p = 0; p < m; p++)
         device_member_[basis_out[p]] = 1;

@@ -6,7 +6,8 @@
 // (the test harness applies it with sed on the way into the compiler, oracle/Makefile) -- nothing
 // of those functions is restated here.  Then Maxvolume ON THE DEVICE (ipxk_maxvolume / ipxk_maxvolume_sequential: the identical decisions as
 // ipx::Maxvolume, pinned against it up to 1M rows) from a device factorization of the current basis, which ends with
-// the fresh factorization and the split operator of the final basis; the final basis goes back into the reference's
+// the split operator of the final basis (a fresh factorization, or the earlier factors with the last exchanges behind them
+// as etas when that is cheaper: ipxk_maxvolume_info.kept_etas); the final basis goes back into the reference's
 // Basis with Basis::Load (src/basis.h:86-94: loads and factorizes -- the factorization the reference performs at
 // this point anyway, :57-61).  The reference's CPU Maxvolume and its CPU SplittedNormalMatrix::Prepare leave the
 // main phase.  A basis the device LU declines (IPXK_E_UNSUPPORTED, dependent columns) takes the reference's
@@ -57,7 +58,7 @@ private:
     bool DegenerateCandidateExists(const Iterate& iterate) const;
     // hands the basis the device holds to the reference's Basis (Basis::Load); returns its error code
     Int SyncBasis();
-    // Maxvolume + fresh factorization + operator on the device; false: declined (nothing changed, take the CPU path)
+    // Maxvolume + the operator of the final basis on the device; false: declined (nothing changed, take the CPU path)
     bool MaxvolumeOnDevice(Info* info);
     void MaxvolumeOnBasis(Info* info);
 
