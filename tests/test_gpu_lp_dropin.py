@@ -365,4 +365,7 @@ def test_lp_with_dense_rows_and_dense_columns_through_both_solvers(tmp_path):
     compare_runs(ref, hip)
     assert hip[0]["status_ipm"] == IPX_STATUS_optimal, hip[2]
     assert hip[0]["kktiter1"] > 0 and hip[0]["kktiter2"] > 0
+    # (at this size every Maxvolume of the run ends without its final refactorization: the KKT solves run through factors + etas)
+    assert hip[0]["kept_eta_calls"] >= 1 and hip[0]["kept_etas"] >= hip[0]["kept_eta_calls"], (hip[0]["kept_eta_calls"], hip[0]["kept_etas"])
+    print("Maxvolume calls that kept their etas: %d of %d (%d etas)" % (hip[0]["kept_eta_calls"], hip[0]["device_maxvolume_calls"], hip[0]["kept_etas"]))
     print("time_ipm1 ref %.3f hip %.3f, time_ipm2 ref %.3f hip %.3f" % (ref[0]["time_ipm1"], hip[0]["time_ipm1"], ref[0]["time_ipm2"], hip[0]["time_ipm2"]))

@@ -185,3 +185,48 @@ def test_dense_etas_equal_the_lists_with_hundreds_of_etas(kkt, po, monkeypatch):
     assert d["updates"] > 1500, d["updates"]                   # (more than one refactorization apart: files of several hundred etas)
     assert np.array_equal(d["exchanges"], l["exchanges"]) and np.array_equal(d["basis"], l["basis"])
     assert (d["updates"], d["skipped"], d["refused"]) == (l["updates"], l["skipped"], l["refused"]) and d["volinc"] == l["volinc"]
+
+
+def test_maxvolume_goes_on_with_the_etas_it_kept(kkt, oracle, po, monkeypatch):
+    """two Maxvolume calls in a row with different scaling factors, the first one leaving its exchanges behind the factors as etas
+    (IPXK_MAXVOL_KEEP_ETAS=1): the second call goes on with the same eta file, as the restatement's basis object does with its updates --
+    the same exchanges in the same order in both calls, the same final basis; and the operator of the final basis solves the KKT system
+    like the one built from a fresh factorization"""
+    m, n, bump, seed = 1000, 2300, 50, 11
+    P, status, colscale, Ao = setup(po, m, n, bump, seed)
+    monkeypatch.setenv("IPXK_MAXVOL_KEEP_ETAS", "1")
+    B = oracle.basis(Ao, P["basis"], status, max_etas=400)
+    ctx = kkt.KktContext(P["A"])
+    ctx.lu_factorize_basis(P["basis"], 0.1, download=False)
+    ctx.split_prepare_lu(status, colscale)
+    want1 = B.maxvolume(colscale, volume_tol=2.0, maxskip_updates=10, rows_per_slice=300)
+    got1 = ctx.maxvolume(status, colscale, volume_tol=2.0, maxskip_updates=10, rows_per_slice=300, max_etas=400)
+    assert got1["errflag"] == 0 and got1["kept_etas"] > 0 and got1["updates"] > 5
+    assert np.array_equal(got1["exchanges"], want1["exchanges"])
+    # new scaling factors for the basis that came out (as the next interior-point iterate would bring them)
+    basis_o, status_o, _ = B.get()
+    assert np.array_equal(got1["basis"], basis_o) and np.array_equal(got1["status"], status_o)
+    colscale2 = synth.synthetic_maxvolume_state(got1["status"], 1.0, seed + 100)
+    ctx.split_rescale(got1["status"], colscale2)
+    want2 = B.maxvolume(colscale2, volume_tol=2.0, maxskip_updates=10, rows_per_slice=300)
+    got2 = ctx.maxvolume(got1["status"], colscale2, volume_tol=2.0, maxskip_updates=10, rows_per_slice=300, max_etas=400)
+    assert got2["errflag"] == 0 and want2["updates"] > 5
+    assert np.array_equal(got2["exchanges"], want2["exchanges"])
+    assert (got2["updates"], got2["skipped"], got2["refused"]) == (want2["updates"], want2["skipped"], want2["refused"])
+    basis_o, status_o, counts = B.get()
+    assert np.array_equal(got2["basis"], basis_o) and np.array_equal(got2["status"], status_o)
+    assert got2["kept_etas"] == counts["etas"] > got1["kept_etas"]          # one file over both calls, never refactorized in between
+    # the operator of the final basis: SolveDense and the KKT solve against a fresh factorization
+    Bm = basis_matrix(Ao, got2["basis"])
+    rhs = np.random.default_rng(3).standard_normal(m)
+    for tr, Mx in (("n", Bm), ("t", Bm.T)):
+        x = ctx.solve_dense(rhs, tr)
+        assert np.abs(Mx @ x - rhs).max() <= 1e-8 * (1 + np.abs(x).max())
+    st = synth.synthetic_ipm_state(m, n, 1.0, seed)
+    x1, y1, it1, e1, _ = ctx.kkt_basis_solve(st["a"], st["b"], 1e-9, 2000)
+    ctx.lu_factorize_basis(got2["basis"], 0.1, download=False)
+    ctx.split_prepare_lu(got2["status"], colscale2)
+    x2, y2, it2, e2, _ = ctx.kkt_basis_solve(st["a"], st["b"], 1e-9, 2000)
+    assert e1 == e2 == 0 and abs(it1 - it2) <= max(3, it2 // 10)
+    assert np.abs(x1 - x2).max() <= 1e-6 * np.abs(x2).max() and np.abs(y1 - y2).max() <= 1e-6 * np.abs(y2).max()
+    ctx.close()
